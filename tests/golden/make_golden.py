@@ -1,0 +1,176 @@
+"""Generate golden vectors by running the UNMODIFIED reference (build container only).
+
+    python tests/golden/make_golden.py
+
+Imports ``/root/reference/model/las_model.py`` and ``solver/solver.py`` (stubbing the three
+unused third-party imports they pull in at module top: pydub, python_speech_features,
+editdistance), loads the deterministic weights of ``las_pytorch_amd.synth`` with
+``load_state_dict(strict=True)`` (which also pins key names and shapes), runs the cases below
+on CPU and stores inputs-by-recipe + expected outputs in ``tests/golden/*.npz``.
+
+Only data is stored (seeds, shapes, expected outputs); no reference source travels.
+The GPU box never runs this script (``/root/reference`` does not exist there).
+"""
+import os
+import sys
+import types
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, ROOT)
+REF = "/root/reference"
+
+
+def import_reference():
+    def lev(a, b):
+        a, b = list(a), list(b)
+        prev = list(range(len(b) + 1))
+        for i, ca in enumerate(a, 1):
+            cur = [i]
+            for j, cb in enumerate(b, 1):
+                cur.append(min(prev[j] + 1, cur[j - 1] + 1, prev[j - 1] + (ca != cb)))
+            prev = cur
+        return prev[-1]
+
+    for name in ("pydub", "python_speech_features", "editdistance"):
+        m = types.ModuleType(name)
+        m.AudioSegment = object
+        m.logfbank = None
+        m.eval = lev
+        sys.modules[name] = m
+    sys.path.insert(0, REF)
+    from model.las_model import LAS, Listener, Speller          # noqa: E402
+    from solver.solver import batch_iterator, label_smoothing_loss  # noqa: E402
+    return LAS, Listener, Speller, batch_iterator, label_smoothing_loss
+
+
+from las_pytorch_amd import synth  # noqa: E402
+
+
+def build_ref(LAS, Listener, Speller, c, sd_np, *, max_label_len, decode_mode=1, multi_head=1, use_mlp=True,
+              activate="relu"):
+    listener = Listener(input_feature_dim=c["F"], hidden_size=c["H"], num_layers=c["L"], rnn_unit="LSTM",
+                        use_gpu=False)
+    speller = Speller(vocab_size=c["V"], hidden_size=c["Hs"], rnn_unit="LSTM", num_layers=c["Ls"],
+                      max_label_len=max_label_len, use_mlp_in_attention=use_mlp, mlp_dim_in_attention=c["M"],
+                      mlp_activate_in_attention=activate, listener_hidden_size=c["H"], multi_head=multi_head,
+                      decode_mode=decode_mode, use_gpu=False)
+    las = LAS(listener, speller)
+    las.load_state_dict({k: torch.from_numpy(v.copy()) for k, v in sd_np.items()}, strict=True)
+    return las
+
+
+def stack(lst):
+    return torch.stack(lst, 0).detach().numpy()
+
+
+def run_case(refmods, name, cfg_name, B, T, U, *, scale=None, seed=17, multi_head=1, use_mlp=True,
+             activate="relu", free_len=None, full=True, with_grads=True, ragged=False, sub_t=1, sub_d=1):
+    LAS, Listener, Speller, batch_iterator, ls_loss = refmods
+    c = synth.CONFIGS[cfg_name]
+    shapes = synth.config_shapes(cfg_name, multi_head=multi_head, use_mlp=use_mlp)
+    sd_np = synth.make_state_dict(shapes, seed=seed, scale=scale)
+    x = torch.from_numpy(synth.make_inputs(B, T, c["F"], seed=seed))
+    idx, lens = synth.make_labels(B, U, c["V"], seed=seed, ragged=ragged)
+    labels = torch.from_numpy(synth.onehot_labels(idx, lens, c["V"]))
+    free_len = free_len or U
+    out = dict(meta=np.array([B, T, U, seed, multi_head, int(use_mlp), free_len, int(ragged), sub_t, sub_d], dtype=np.int64),
+               scale=np.array([-1.0 if scale is None else scale], dtype=np.float64),
+               cfg=np.array(cfg_name), activate=np.array(activate))
+
+    las = build_ref(LAS, Listener, Speller, c, sd_np, max_label_len=free_len, decode_mode=1,
+                    multi_head=multi_head, use_mlp=use_mlp, activate=activate)
+    # G1: listener output per layer
+    feats, h = [], x
+    for l in range(c["L"]):
+        h, _ = getattr(las.listener, f"pLSTM_layer{l}")(h)
+        feats.append(h)
+    for l, f in enumerate(feats):
+        out[f"listener_l{l}"] = f.detach().numpy()[:, ::sub_t, ::sub_d].copy()
+        out[f"listener_l{l}_sum"] = np.array([f.double().sum().item(), f.double().abs().sum().item()])
+
+    # G2: teacher forced (tf_rate=1 → coin always true)
+    preds, atts = las(batch_data=x, batch_label=labels, teacher_force_rate=1.0, is_training=True)
+    out["tf_logp"] = stack(preds)                                   # (U,B,V)
+    att = np.stack([stack(h_) for h_ in zip(*atts)], 0)             # (heads,U,B,T')
+    out["tf_att"] = att[:, :, :, ::sub_t] if not full else att
+    out["tf_att_sum"] = np.array([float(att.astype(np.float64).sum())])
+    out["tf_argmax"] = out["tf_logp"].argmax(-1)
+    top2 = np.sort(out["tf_logp"], axis=-1)[..., -2:]
+    out["tf_margin"] = np.array([float((top2[..., 1] - top2[..., 0]).min())])
+
+    # G3: greedy (is_training=False → free run for max_label_len steps, decode_mode 1)
+    preds, _ = las(batch_data=x, batch_label=labels, teacher_force_rate=0.0, is_training=False)
+    out["greedy_logp"] = stack(preds)
+    out["greedy_argmax"] = out["greedy_logp"].argmax(-1)
+    top2 = np.sort(out["greedy_logp"], axis=-1)[..., -2:]
+    out["greedy_margin"] = np.array([float((top2[..., 1] - top2[..., 0]).min())])
+
+    # G4: decode_mode 0 free-run (feeds log-probs back)
+    las.speller.decode_mode = 0
+    preds, _ = las(batch_data=x, batch_label=labels, teacher_force_rate=0.0, is_training=False)
+    out["mode0_logp"] = stack(preds)
+    las.speller.decode_mode = 1
+
+    # G5: losses, grads, clip, Adam step
+    if with_grads:
+        for kind, ls in (("ls", 0.1), ("nll", 0.0)):
+            las.zero_grad()
+            preds, _ = las(batch_data=x, batch_label=labels, teacher_force_rate=1.0, is_training=True)
+            pred_y = torch.cat([p.unsqueeze(1) for p in preds], 1)
+            if ls > 0:
+                loss = ls_loss(pred_y, labels.float(), label_smoothing=ls)
+            else:
+                loss = torch.nn.NLLLoss(ignore_index=0)(pred_y.permute(0, 2, 1), labels.argmax(2))
+            loss.backward()
+            out[f"loss_{kind}"] = np.array([loss.item()])
+            gn = {k: p.grad.detach().numpy() for k, p in las.named_parameters()}
+            out[f"gradnorm_{kind}"] = np.array([np.linalg.norm(g.astype(np.float64)) for g in gn.values()])
+            out[f"gradtotal_{kind}"] = np.array([np.sqrt(sum((g.astype(np.float64) ** 2).sum() for g in gn.values()))])
+            if kind == "ls":
+                for k, g in gn.items():
+                    out["grad/" + k] = g.copy() if full else g.reshape(-1)[:: max(1, g.size // 64)][:64].copy()
+        # one full solver step through the reference's own batch_iterator (loss → bwd → clip 1.0 → Adam 2e-4)
+        las2 = build_ref(LAS, Listener, Speller, c, sd_np, max_label_len=free_len, multi_head=multi_head,
+                         use_mlp=use_mlp, activate=activate)
+        opt = torch.optim.Adam(las2.parameters(), lr=2e-4)           # train.py:82, yaml lr
+        np.random.seed(0)
+        loss_np, ler = batch_iterator(x, labels, las2, opt, tf_rate=1.0, is_training=True, max_label_len=U,
+                                      label_smoothing=0.1, use_gpu=False)
+        out["step_loss"] = np.array([float(loss_np)])
+        out["step_ler"] = np.array(ler, dtype=np.float64)
+        out["step_param_sum"] = np.array([p.detach().double().sum().item() for p in las2.parameters()])
+        out["step_param_delta"] = np.array([
+            (p.detach().double() - torch.from_numpy(sd_np[k]).double()).abs().sum().item()
+            for k, p in las2.named_parameters()])
+    np.savez_compressed(os.path.join(HERE, name + ".npz"), **out)
+    size = os.path.getsize(os.path.join(HERE, name + ".npz"))
+    print(f"{name}: {size/1024:.1f} KB  tf_margin={out['tf_margin'][0]:.2e} greedy_margin={out['greedy_margin'][0]:.2e} "
+          f"greedy={out['greedy_argmax'][:, 0].tolist()[:12]}")
+
+
+def main():
+    torch.manual_seed(0)
+    torch.set_num_threads(8)
+    refmods = import_reference()
+    # tiny config, stored in full (two weight scales; the 0.5 set saturates gates and activates the clip)
+    run_case(refmods, "tiny_default", "tiny", B=2, T=16, U=5, free_len=7)
+    run_case(refmods, "tiny_sat", "tiny", B=3, T=32, U=6, scale=0.5, free_len=9, ragged=True)
+    run_case(refmods, "tiny_mh4", "tiny", B=2, T=16, U=5, multi_head=4, scale=0.3)
+    run_case(refmods, "tiny_nomlp", "tiny", B=2, T=16, U=5, use_mlp=False, scale=0.3)
+    run_case(refmods, "tiny_noact", "tiny", B=2, T=16, U=5, activate="None", scale=0.3)
+    # S / P short utterances: full outputs, gradient slices
+    run_case(refmods, "S_short", "S", B=4, T=64, U=8, full=False)
+    run_case(refmods, "S_short_sat", "S", B=4, T=64, U=8, scale=0.2, full=False, ragged=True)
+    run_case(refmods, "P_short", "P", B=4, T=64, U=8, full=False)
+    run_case(refmods, "P_short_sat", "P", B=3, T=64, U=8, scale=0.15, full=False, ragged=True)
+    # S / P LibriSpeech-shaped T=800: subsampled listener output, full log-probs
+    run_case(refmods, "S_T800", "S", B=2, T=800, U=12, full=False, with_grads=False, sub_t=10, sub_d=8)
+    run_case(refmods, "P_T800", "P", B=2, T=800, U=12, full=False, with_grads=False, sub_t=5, sub_d=16)
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,35 @@
+"""Rebuild the inputs of a golden case from its stored recipe (seeds/shapes only)."""
+import os
+
+import numpy as np
+
+from las_pytorch_amd import synth
+
+GOLDEN_DIR = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+ALL_CASES = ["tiny_default", "tiny_sat", "tiny_mh4", "tiny_nomlp", "tiny_noact",
+             "S_short", "S_short_sat", "P_short", "P_short_sat", "S_T800", "P_T800"]
+
+
+def load_case(name):
+    g = dict(np.load(os.path.join(GOLDEN_DIR, name + ".npz")))
+    B, T, U, seed, multi_head, use_mlp, free_len, ragged, sub_t, sub_d = [int(v) for v in g["meta"]]
+    scale = float(g["scale"][0])
+    scale = None if scale < 0 else scale
+    cfg_name = str(g["cfg"])
+    c = synth.CONFIGS[cfg_name]
+    shapes = synth.config_shapes(cfg_name, multi_head=multi_head, use_mlp=bool(use_mlp))
+    sd = synth.make_state_dict(shapes, seed=seed, scale=scale)
+    x = synth.make_inputs(B, T, c["F"], seed=seed)
+    idx, lens = synth.make_labels(B, U, c["V"], seed=seed, ragged=bool(ragged))
+    onehot = synth.onehot_labels(idx, lens, c["V"])
+    info = dict(B=B, T=T, U=U, seed=seed, multi_head=multi_head, use_mlp=bool(use_mlp), free_len=free_len,
+                ragged=bool(ragged), sub_t=sub_t, sub_d=sub_d, scale=scale, cfg_name=cfg_name, cfg=c,
+                activate=str(g["activate"]), with_grads="loss_ls" in g, full=cfg_name == "tiny")
+    return g, info, sd, x, idx, lens, onehot
+
+
+def oracle_cfg(info, max_label_len=None, decode_mode=1):
+    c = info["cfg"]
+    return dict(listener_layers=c["L"], speller_layers=c["Ls"], max_label_len=max_label_len or info["free_len"],
+                decode_mode=decode_mode, use_mlp=info["use_mlp"], activate=info["activate"],
+                multi_head=info["multi_head"])

@@ -1,0 +1,74 @@
+"""The CPU oracle (oracle/las_oracle.py) against the golden vectors captured from the reference
+(tests/golden/make_golden.py).  Tolerance: <=1e-6 abs on log-probs / activations in fp32
+(SURVEY.md section 8c); argmax sequences identical."""
+import numpy as np
+import pytest
+import torch
+
+from golden_util import ALL_CASES, load_case, oracle_cfg
+from oracle import las_oracle as O
+
+ATOL = 2e-6
+
+
+@pytest.mark.parametrize("name", ALL_CASES)
+def test_forward_matches_reference(name):
+    g, info, sd_np, x, idx, lens, onehot = load_case(name)
+    sd = O.to_torch_sd(sd_np)
+    xt = torch.from_numpy(x)
+    lab = torch.from_numpy(onehot)
+    c = info["cfg"]
+    with torch.no_grad():
+        feats = O.listener_forward(xt, sd, c["L"], return_all=True)
+        for l, f in enumerate(feats):
+            np.testing.assert_allclose(f.numpy()[:, ::info["sub_t"], ::info["sub_d"]], g[f"listener_l{l}"], atol=ATOL, rtol=0)
+            assert abs(f.double().sum().item() - g[f"listener_l{l}_sum"][0]) < 1e-3 * max(1.0, g[f"listener_l{l}_sum"][1] * 1e-3)
+        preds, atts = O.las_forward(xt, lab, sd, oracle_cfg(info), teacher_force=True)
+        logp = torch.stack(preds).numpy()
+        np.testing.assert_allclose(logp, g["tf_logp"], atol=ATOL, rtol=0)
+        assert (logp.argmax(-1) == g["tf_argmax"]).all()
+        att = np.stack([torch.stack(h).numpy() for h in zip(*atts)], 0)
+        if info["full"]:
+            np.testing.assert_allclose(att, g["tf_att"], atol=ATOL, rtol=0)
+        else:
+            np.testing.assert_allclose(att[:, :, :, ::info["sub_t"]], g["tf_att"], atol=ATOL, rtol=0)
+        preds, _ = O.las_forward(xt, lab, sd, oracle_cfg(info), teacher_force=False, is_training=False)
+        logp = torch.stack(preds).numpy()
+        assert logp.shape == g["greedy_logp"].shape
+        assert (logp.argmax(-1) == g["greedy_argmax"]).all()
+        np.testing.assert_allclose(logp, g["greedy_logp"], atol=ATOL, rtol=0)
+        preds, _ = O.las_forward(xt, lab, sd, oracle_cfg(info, decode_mode=0), teacher_force=False, is_training=False)
+        np.testing.assert_allclose(torch.stack(preds).numpy(), g["mode0_logp"], atol=5e-6, rtol=0)
+
+
+@pytest.mark.parametrize("name", [n for n in ALL_CASES if "T800" not in n])
+def test_loss_and_grads_match_reference(name):
+    g, info, sd_np, x, idx, lens, onehot = load_case(name)
+    xt = torch.from_numpy(x)
+    lab = torch.from_numpy(onehot)
+    for kind, ls in (("ls", 0.1), ("nll", 0.0)):
+        sd = O.to_torch_sd(sd_np, requires_grad=True)
+        preds, _ = O.las_forward(xt, lab, sd, oracle_cfg(info), teacher_force=True)
+        loss, _ = O.solver_step_loss(preds, lab, info["U"], ls)
+        loss.backward()
+        assert abs(loss.item() - g[f"loss_{kind}"][0]) < 2e-6 * max(1, abs(g[f"loss_{kind}"][0]))
+        norms = np.array([sd[k].grad.double().norm().item() for k in sd_np])
+        np.testing.assert_allclose(norms, g[f"gradnorm_{kind}"], rtol=2e-4, atol=1e-8)
+        if kind == "ls":
+            for k in sd_np:
+                got = sd[k].grad.numpy()
+                want = g["grad/" + k]
+                if not info["full"]:
+                    got = got.reshape(-1)[:: max(1, got.size // 64)][:64]
+                np.testing.assert_allclose(got, want, rtol=1e-3, atol=2e-7)
+
+
+def test_ler_handmade():
+    # solver/solver.py:11-24 semantics: zeros skipped, prediction stops at first 1, truth strips 0 and 1
+    pred = [[5, 0, 6, 7, 1, 9, 9], [2, 2, 2, 2, 2, 2, 2], [1, 5, 6, 7, 0, 0, 0], [3, 4, 5, 6, 1, 0, 0]]
+    true = [[5, 6, 7, 1, 0, 0, 0], [2, 3, 1, 0, 0, 0, 0], [5, 6, 7, 1, 0, 0, 0], [3, 9, 5, 1, 0, 0, 0]]
+    got = O.letter_error_rate(np.array(pred), np.array(true))
+    assert got == [0.0, 6 / 2, 3 / 3, 2 / 3]
+    assert O.edit_distance("kitten", "sitting") == 3
+    with pytest.raises(ZeroDivisionError):
+        O.letter_error_rate(np.array([[1, 0]]), np.array([[1, 0]]))
