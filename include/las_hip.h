@@ -1,0 +1,139 @@
+/* liblas_hip.so — C ABI of the MI355X-native LAS hot path (gfx950 only).
+ *
+ * The reference (jiwidi/las-pytorch) has NO native boundary for this path: its Listener/Speller call
+ * torch.nn.LSTM / nn.Linear / torch.bmm directly (reference model/las_model.py).  These entry points
+ * are what a ctypes binding inside the reference's model/las_model.py would call instead; each one
+ * names the reference lines it replaces.  INTEGRATION.md shows that binding.
+ *
+ * Conventions
+ *   - extern "C", plain pointers and sizes; no torch types.  Every pointer is a DEVICE pointer into
+ *     caller-owned memory (PyTorch-ROCm tensors: tensor.data_ptr()); fp32 contiguous unless stated.
+ *   - All work is enqueued asynchronously on `stream` (a hipStream_t passed as void*); no hidden
+ *     device synchronisation.  The library allocates nothing persistent.
+ *   - Return value: 0 = ok; nonzero = error (1 argument/shape precondition, 2 HIP runtime error,
+ *     3 unsupported configuration, 4 device-side failure).  las_last_error() returns a thread-local
+ *     message.  Never throws, never exits.
+ *   - `err_word` is a caller-owned, zero-initialised device uint32: kernels that hand data between
+ *     workgroups write a nonzero code there if a bounded spin expires (results are then invalid).
+ *   - Re-entrant per device; no global mutable state.
+ */
+#ifndef LAS_HIP_H
+#define LAS_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define LAS_ABI_VERSION 1
+#define LAS_MAX_SPELLER_LAYERS 4
+
+/* flags */
+#define LAS_FLAG_STASH          1   /* keep what the backward pass needs (training) */
+#define LAS_FLAG_FORCE_GENERIC  2   /* use the generic (L2-streaming) recurrence kernels: A/B tests */
+
+int las_abi_version(void);
+const char* las_last_error(void);
+
+/* ------------------------------------------------------------------------------------------------
+ * Listener: one pyramidal BiLSTM layer.
+ * Replaces pBLSTMLayer.forward, reference model/las_model.py:81-91 (time-pair concat + nn.LSTM
+ * bidirectional, batch_first) and its autograd (solver/solver.py:95).
+ *   x (B, T_in, D_in) -> out (B, T_in/2, 2H);  T = T_in/2, D = 2*D_in.
+ *   weights in PyTorch layout: w_ih (4H, D), w_hh (4H, H), b_ih (4H), b_hh (4H); *_r = reverse direction.
+ * reserve: las_pblstm_reserve_floats() floats, 16-byte aligned; written by fwd, read by bwd.
+ * ---------------------------------------------------------------------------------------------- */
+size_t las_pblstm_reserve_floats(int B, int T_in, int H, int flags);
+int las_pblstm_fwd(const float* x, int B, int T_in, int D_in, int H,
+                   const float* w_ih_f, const float* w_hh_f, const float* b_ih_f, const float* b_hh_f,
+                   const float* w_ih_r, const float* w_hh_r, const float* b_ih_r, const float* b_hh_r,
+                   float* out, float* reserve, uint32_t* err_word, int flags, void* stream);
+
+size_t las_pblstm_bwd_workspace_floats(int B, int T_in, int H);
+/* dout (B,T,2H).  Gradient outputs are OVERWRITTEN.  dx (B,T_in,D_in) may be NULL (first layer). */
+int las_pblstm_bwd(const float* x, const float* dout, int B, int T_in, int D_in, int H,
+                   const float* w_ih_f, const float* w_hh_f, const float* w_ih_r, const float* w_hh_r,
+                   const float* reserve, float* workspace,
+                   float* dx,
+                   float* dw_ih_f, float* dw_hh_f, float* db_ih_f, float* db_hh_f,
+                   float* dw_ih_r, float* dw_hh_r, float* db_ih_r, float* db_hh_r,
+                   uint32_t* err_word, int flags, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Speller: attention keys (loop-invariant), decode loop, backward.
+ * Replaces Speller.forward / forward_step and Attention.forward, reference model/las_model.py:178-238,
+ * 275-297 (single-head dot attention with optional phi/psi MLP + relu), CreateOnehotVariable /
+ * TimeDistributed (utils/functions.py:54-63,72-77).
+ * ---------------------------------------------------------------------------------------------- */
+typedef struct las_speller_desc {
+    int B;            /* utterances */
+    int Tp;           /* encoder frames T' */
+    int D;            /* listener feature dim 2H (== Hs, reference las_model.py:198) */
+    int Hs;           /* speller hidden size */
+    int V;            /* vocabulary (label_dim) */
+    int M;            /* attention MLP dim (ignored when !use_mlp) */
+    int L;            /* speller LSTM layers (1..LAS_MAX_SPELLER_LAYERS) */
+    int use_mlp;      /* use_mlp_in_attention */
+    int relu;         /* 1: relu after phi/psi, 0: no activation */
+    int multi_head;   /* must be 1 */
+    /* parameters, PyTorch layouts: w_ih[0] (4Hs, V+Hs), w_ih[l>0] (4Hs, Hs), w_hh (4Hs, Hs), biases (4Hs) */
+    const float* w_ih[LAS_MAX_SPELLER_LAYERS];
+    const float* w_hh[LAS_MAX_SPELLER_LAYERS];
+    const float* b_ih[LAS_MAX_SPELLER_LAYERS];
+    const float* b_hh[LAS_MAX_SPELLER_LAYERS];
+    const float* w_phi; const float* b_phi;   /* (M, Hs), (M) */
+    const float* w_psi; const float* b_psi;   /* (M, D), (M) */
+    const float* w_c;   const float* b_c;     /* (V, 2Hs), (V) */
+} las_speller_desc;
+
+typedef struct las_speller_grads {           /* all OVERWRITTEN by las_speller_bwd */
+    float* dw_ih[LAS_MAX_SPELLER_LAYERS];
+    float* dw_hh[LAS_MAX_SPELLER_LAYERS];
+    float* db_ih[LAS_MAX_SPELLER_LAYERS];
+    float* db_hh[LAS_MAX_SPELLER_LAYERS];
+    float* dw_phi; float* db_phi;
+    float* dw_psi; float* db_psi;
+    float* dw_c;   float* db_c;
+    float* dfeat;                             /* (B, Tp, D) */
+} las_speller_grads;
+
+/* keys (B,Tp,M) = act(psi(feat)): the reference recomputes this every decode step (las_model.py:279). */
+int las_attn_keys_fwd(const las_speller_desc* d, const float* feat, float* keys, void* stream);
+
+size_t las_speller_reserve_floats(const las_speller_desc* d, int U);
+/* Decode U steps.
+ *   labels_onehot : int64 (B, U_lab, V) one-hot ground truth as utils/data.py:141-143 delivers it, or NULL
+ *   teacher_forced: 1 -> step s+1 is fed labels[:, s] (las_model.py:216-217); 0 -> free running with
+ *   decode_mode 0 (feed log-probs, :220-221) or 1 (feed one-hot argmax, :223-227).  Mode 2 (sampling) is
+ *   not implemented.
+ *   logp (U,B,V), att (U,B,Tp), argmax (U,B) int32 or NULL.  keys may be NULL when !use_mlp. */
+int las_speller_fwd(const las_speller_desc* d, const float* feat, const float* keys,
+                    const int64_t* labels_onehot, int U_lab, int U, int teacher_forced, int decode_mode,
+                    float* logp, float* att, int32_t* argmax, float* reserve, int flags, void* stream);
+
+size_t las_speller_bwd_workspace_floats(const las_speller_desc* d, int U);
+/* dlogp (U,B,V): gradient of the loss wrt the returned log-probs.  feedback_mode0: the forward ran
+ * free-running with decode_mode 0 (gradient flows through the fed-back log-probs). */
+int las_speller_bwd(const las_speller_desc* d, const float* feat, const float* keys,
+                    const float* logp, const float* att, const float* dlogp, int U, int feedback_mode0,
+                    const float* reserve, float* workspace, const las_speller_grads* g, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Building blocks exported for tests / micro-benchmarks.
+ * ---------------------------------------------------------------------------------------------- */
+/* C[M,N] (+)= act(A(M,K) B(K,N) + bias0 + bias1); a_kc: A(m,k)=A[m*lda+k] else A[k*lda+m];
+ * b_kc: B(k,n)=B[n*ldb+k] else B[k*ldb+n]. */
+int las_gemm_f32(const float* A, const float* B, float* C, const float* bias0, const float* bias1,
+                 int M, int N, int K, int64_t lda, int64_t ldb, int64_t ldc, int a_kc, int b_kc,
+                 int batch, int64_t sA, int64_t sB, int64_t sC, int splitk, int accumulate, int relu, void* stream);
+/* recurrence only: gates (2,B,T,4H) pre-activations in, see las_pblstm_fwd for the rest */
+size_t las_rec_xbuf_bytes(int B, int H);
+int las_pblstm_rec_fwd(float* gates, const float* w_hh_f, const float* w_hh_r, float* out, float* cbuf, float* hprev,
+                       int B, int T, int H, void* xbuf, uint32_t* err_word, int flags, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* LAS_HIP_H */

@@ -1,0 +1,116 @@
+"""ctypes binding of liblas_hip.so (include/las_hip.h).  No fallback: if the library is missing the
+import of the product path fails loudly — there is no CPU or eager-PyTorch substitute."""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "liblas_hip.so")
+MAX_L = 4
+
+FLAG_STASH = 1
+FLAG_FORCE_GENERIC = 2
+
+_f = C.c_void_p   # every device pointer is passed as an integer address
+
+
+class SpellerDesc(C.Structure):
+    _fields_ = [("B", C.c_int), ("Tp", C.c_int), ("D", C.c_int), ("Hs", C.c_int), ("V", C.c_int), ("M", C.c_int),
+                ("L", C.c_int), ("use_mlp", C.c_int), ("relu", C.c_int), ("multi_head", C.c_int),
+                ("w_ih", _f * MAX_L), ("w_hh", _f * MAX_L), ("b_ih", _f * MAX_L), ("b_hh", _f * MAX_L),
+                ("w_phi", _f), ("b_phi", _f), ("w_psi", _f), ("b_psi", _f), ("w_c", _f), ("b_c", _f)]
+
+
+class SpellerGrads(C.Structure):
+    _fields_ = [("dw_ih", _f * MAX_L), ("dw_hh", _f * MAX_L), ("db_ih", _f * MAX_L), ("db_hh", _f * MAX_L),
+                ("dw_phi", _f), ("db_phi", _f), ("dw_psi", _f), ("db_psi", _f), ("dw_c", _f), ("db_c", _f),
+                ("dfeat", _f)]
+
+
+# name -> (restype, argtypes); every symbol include/las_hip.h declares
+PROTOTYPES = {
+    "las_abi_version": (C.c_int, []),
+    "las_last_error": (C.c_char_p, []),
+    "las_pblstm_reserve_floats": (C.c_size_t, [C.c_int] * 4),
+    "las_pblstm_fwd": (C.c_int, [_f, C.c_int, C.c_int, C.c_int, C.c_int] + [_f] * 8 + [_f, _f, _f, C.c_int, _f]),
+    "las_pblstm_bwd_workspace_floats": (C.c_size_t, [C.c_int] * 3),
+    "las_pblstm_bwd": (C.c_int, [_f, _f, C.c_int, C.c_int, C.c_int, C.c_int] + [_f] * 4 + [_f, _f, _f] + [_f] * 8
+                       + [_f, C.c_int, _f]),
+    "las_attn_keys_fwd": (C.c_int, [C.POINTER(SpellerDesc), _f, _f, _f]),
+    "las_speller_reserve_floats": (C.c_size_t, [C.POINTER(SpellerDesc), C.c_int]),
+    "las_speller_fwd": (C.c_int, [C.POINTER(SpellerDesc), _f, _f, _f, C.c_int, C.c_int, C.c_int, C.c_int, _f, _f, _f, _f,
+                                  C.c_int, _f]),
+    "las_speller_bwd_workspace_floats": (C.c_size_t, [C.POINTER(SpellerDesc), C.c_int]),
+    "las_speller_bwd": (C.c_int, [C.POINTER(SpellerDesc), _f, _f, _f, _f, _f, C.c_int, C.c_int, _f, _f,
+                                  C.POINTER(SpellerGrads), _f]),
+    "las_gemm_f32": (C.c_int, [_f] * 5 + [C.c_int] * 3 + [C.c_int64] * 3 + [C.c_int, C.c_int, C.c_int]
+                     + [C.c_int64] * 3 + [C.c_int, C.c_int, C.c_int, _f]),
+    "las_rec_xbuf_bytes": (C.c_size_t, [C.c_int, C.c_int]),
+    "las_pblstm_rec_fwd": (C.c_int, [_f] * 6 + [C.c_int] * 3 + [_f, _f, C.c_int, _f]),
+}
+
+_lib = None
+
+
+def lib():
+    """Load liblas_hip.so (built in-tree by ``__graft_entry__.build()`` / ``make -C las_pytorch_amd/csrc``)."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError(
+                f"{LIB_PATH} is missing: the LAS hot path has no CPU/eager fallback. "
+                "Build it with `python -c 'import __graft_entry__ as g; g.build()'` (hipcc --offload-arch=gfx950).")
+        l = C.CDLL(LIB_PATH)
+        for name, (res, args) in PROTOTYPES.items():
+            fn = getattr(l, name)      # AttributeError here = header / library mismatch
+            fn.restype = res
+            fn.argtypes = args
+        _lib = l
+    return _lib
+
+
+def check(rc):
+    if rc != 0:
+        msg = lib().las_last_error().decode(errors="replace")
+        raise RuntimeError(f"liblas_hip error {rc}: {msg}")
+
+
+def ptr(t):
+    """Device address of a contiguous fp32/int tensor (None -> NULL)."""
+    if t is None:
+        return None
+    if not t.is_cuda:
+        raise RuntimeError("the LAS HIP path needs CUDA(ROCm) tensors; there is no CPU fallback")
+    if not t.is_contiguous():
+        raise RuntimeError("the LAS HIP path needs contiguous tensors")
+    return t.data_ptr()
+
+
+def stream_ptr():
+    return torch.cuda.current_stream().cuda_stream
+
+
+_err_words = {}
+
+
+def err_word(device):
+    """Per-device uint32 the kernels write a nonzero code into when a bounded hand-off spin expires."""
+    key = torch.device(device).index if torch.device(device).index is not None else torch.cuda.current_device()
+    w = _err_words.get(key)
+    if w is None:
+        w = torch.zeros(4, dtype=torch.int32, device=f"cuda:{key}")
+        _err_words[key] = w
+    return w
+
+
+def check_device_errors():
+    """Synchronising check of the device error words (tests, smoke and bench call this after timing)."""
+    for key, w in _err_words.items():
+        v = int(w[0].item())
+        if v != 0:
+            w.zero_()
+            raise RuntimeError(f"liblas_hip device-side failure 0x{v & 0xffffffff:08x} on cuda:{key} "
+                               "(inter-workgroup hand-off timed out; results are invalid)")

@@ -1,0 +1,227 @@
+// fp32 MFMA GEMM for gfx950:  C[M,N] (+)= act( A(M,K) * B(K,N) + bias0[N] + bias1[N] )
+//
+// Replaces the dense contractions the reference delegates to ATen/cuDNN:
+//   * LSTM input projection  X * W_ih^T + b_ih + b_hh   (nn.LSTM, reference model/las_model.py:90)
+//   * psi(listener_feature)  relu(feat * W_psi^T + b)    (model/las_model.py:279, utils/functions.py:72-77)
+//   * every dX / dW contraction of the backward pass (autograd of the above, solver/solver.py:95)
+//
+// Design (CDNA4): 128x128 block tile, BK=16, 256 threads = 4 wave64 in a 2x2 grid, each wave owns a
+// 64x64 sub-tile = 2x2 v_mfma_f32_32x32x2_f32 accumulators (64 acc VGPRs).  f32-in MFMA is exact fp32
+// (bitwise an fmaf chain) at the fp32 vector rate (157 TF peak) — there is no TF32 on gfx950.
+// Operands go global -> registers -> LDS (K-major tiles so a fragment read is 32 consecutive dwords per
+// half-wave: conflict-free ds_read_b32), double-buffered with one barrier per k-tile.
+// Either operand may be K-contiguous or M/N-contiguous (all four transposition cases of the backward pass).
+#include "las_common.h"
+#include "las_kernels.h"
+
+namespace las {
+
+constexpr int BM = 128, BN = 128, BK = 16, PAD = 4, GEMM_THREADS = 256;
+
+struct GemmParams {
+    const float* A; const float* B; float* C; const float* bias0; const float* bias1;
+    int M, N, K;
+    long lda, ldb, ldc;
+    long sA, sB, sC;
+    int splitk, kper;
+    int accumulate, relu, atomic;
+    int a_vec, b_vec;   // 16-byte vector loads legal for this operand
+};
+
+// Load one BK x BM(BN) operand tile into registers (2 float4 per thread).
+// KC = true : element(r, k) at P[r*ld + k]   (row index r is the M or N index)
+// KC = false: element(r, k) at P[k*ld + r]
+template <bool KC>
+__device__ __forceinline__ void load_tile(const float* __restrict__ P, long ld, int R, int K, int r0, int k0, int kend,
+                                          bool vec_ok, f32x4 (&reg)[2]) {
+    const int t = threadIdx.x;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int idx = t + i * GEMM_THREADS;
+        f32x4 v = {0.f, 0.f, 0.f, 0.f};
+        if (KC) {
+            const int row = idx >> 2, kq = (idx & 3) * 4;
+            const int r = r0 + row, k = k0 + kq;
+            if (r < R) {
+                const float* p = P + (long)r * ld + k;
+                if (vec_ok && k + 3 < kend) {
+                    v = *reinterpret_cast<const f32x4*>(p);
+                } else {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) if (k + j < kend) v[j] = p[j];
+                }
+            }
+        } else {
+            const int krow = idx >> 5, rq = (idx & 31) * 4;
+            const int k = k0 + krow, r = r0 + rq;
+            if (k < kend) {
+                const float* p = P + (long)k * ld + r;
+                if (vec_ok && r + 3 < R) {
+                    v = *reinterpret_cast<const f32x4*>(p);
+                } else {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) if (r + j < R) v[j] = p[j];
+                }
+            }
+        }
+        reg[i] = v;
+    }
+}
+
+template <bool KC>
+__device__ __forceinline__ void store_tile(float (*S)[BM + PAD], const f32x4 (&reg)[2]) {
+    const int t = threadIdx.x;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int idx = t + i * GEMM_THREADS;
+        if (KC) {
+            const int row = idx >> 2, kq = (idx & 3) * 4;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) S[kq + j][row] = reg[i][j];
+        } else {
+            const int krow = idx >> 5, rq = (idx & 31) * 4;
+            *reinterpret_cast<f32x4*>(&S[krow][rq]) = reg[i];
+        }
+    }
+}
+
+template <bool A_KC, bool B_KC>
+__global__ __launch_bounds__(GEMM_THREADS) void gemm_f32_kernel(GemmParams p) {
+    __shared__ __attribute__((aligned(16))) float As[2][BK][BM + PAD];
+    __shared__ __attribute__((aligned(16))) float Bs[2][BK][BN + PAD];
+
+    const int bz = blockIdx.z / p.splitk, kz = blockIdx.z % p.splitk;
+    const float* A = p.A + (long)bz * p.sA;
+    const float* B = p.B + (long)bz * p.sB;
+    float* C = p.C + (long)bz * p.sC;
+    const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
+    const int kbeg = kz * p.kper;
+    const int kend = min(p.K, kbeg + p.kper);
+    const int ntiles = (kend - kbeg + BK - 1) / BK;
+
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int wm = (wave >> 1) * 64, wn = (wave & 1) * 64;
+    const int lr = lane & 31, lk = lane >> 5;
+
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    f32x4 ra[2], rb[2];
+    if (ntiles > 0) {
+        load_tile<A_KC>(A, p.lda, p.M, p.K, m0, kbeg, kend, p.a_vec, ra);
+        load_tile<B_KC>(B, p.ldb, p.N, p.K, n0, kbeg, kend, p.b_vec, rb);
+        store_tile<A_KC>(As[0], ra);
+        store_tile<B_KC>(Bs[0], rb);
+    }
+    __syncthreads();
+
+    for (int kt = 0; kt < ntiles; ++kt) {
+        const int cur = kt & 1;
+        const bool more = kt + 1 < ntiles;
+        if (more) {
+            load_tile<A_KC>(A, p.lda, p.M, p.K, m0, kbeg + (kt + 1) * BK, kend, p.a_vec, ra);
+            load_tile<B_KC>(B, p.ldb, p.N, p.K, n0, kbeg + (kt + 1) * BK, kend, p.b_vec, rb);
+        }
+#pragma unroll
+        for (int kk = 0; kk < BK / 2; ++kk) {
+            float a[2], b[2];
+#pragma unroll
+            for (int i = 0; i < 2; ++i) a[i] = As[cur][kk * 2 + lk][wm + i * 32 + lr];
+#pragma unroll
+            for (int j = 0; j < 2; ++j) b[j] = Bs[cur][kk * 2 + lk][wn + j * 32 + lr];
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], b[j], acc[i][j], 0, 0, 0);
+        }
+        if (more) {
+            store_tile<A_KC>(As[cur ^ 1], ra);
+            store_tile<B_KC>(Bs[cur ^ 1], rb);
+        }
+        __syncthreads();
+    }
+
+    // Epilogue.  C/D map of 32x32 MFMA: col(n) = lane&31, row(m) = (r&3) + 8*(r>>2) + 4*(lane>>5).
+    const bool add_bias = (kz == 0);
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int n = n0 + wn + j * 32 + lr;
+        if (n >= p.N) continue;
+        float bsum = 0.f;
+        if (add_bias) {
+            if (p.bias0) bsum += p.bias0[n];
+            if (p.bias1) bsum += p.bias1[n];
+        }
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int m = m0 + wm + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lk;
+                if (m >= p.M) continue;
+                float v = acc[i][j][r] + bsum;
+                float* c = C + (long)m * p.ldc + n;
+                if (p.atomic) {
+                    atomicAdd(c, v);
+                } else {
+                    if (p.accumulate) v += *c;
+                    if (p.relu) v = fmaxf(v, 0.f);
+                    *c = v;
+                }
+            }
+        }
+    }
+}
+
+int gemm_f32(const GemmDesc& d, hipStream_t stream) {
+    LAS_REQUIRE(d.M > 0 && d.N > 0 && d.K >= 0, "gemm dims");
+    LAS_REQUIRE(d.A && d.B && d.C, "gemm pointers");
+    GemmParams p;
+    p.A = d.A; p.B = d.B; p.C = d.C; p.bias0 = d.bias0; p.bias1 = d.bias1;
+    p.M = d.M; p.N = d.N; p.K = d.K; p.lda = d.lda; p.ldb = d.ldb; p.ldc = d.ldc;
+    p.sA = d.sA; p.sB = d.sB; p.sC = d.sC;
+    const int batch = d.batch > 0 ? d.batch : 1;
+    int splitk = d.splitk > 0 ? d.splitk : 1;
+    const int gx = cdiv(d.N, BN), gy = cdiv(d.M, BM);
+    if (d.splitk == 0) {
+        // auto: few output tiles and a long K -> split K so the launch covers the chip (256 CUs)
+        const long tiles = (long)gx * gy * batch;
+        if (!d.relu && tiles < 128 && d.K >= 1024) {
+            splitk = (int)min((long)cdiv(d.K, 256), max(1L, 256 / tiles));
+        }
+    }
+    int kper = cdiv(cdiv(d.K, splitk), BK) * BK;
+    if (kper == 0) kper = BK;
+    splitk = max(1, cdiv(d.K, kper));
+    LAS_REQUIRE(!(splitk > 1 && d.relu), "relu epilogue needs splitk==1");
+    p.splitk = splitk; p.kper = kper;
+    p.accumulate = d.accumulate; p.relu = d.relu; p.atomic = splitk > 1;
+    auto aligned = [](const float* ptr, long ld, long bs) {
+        return ((uintptr_t)ptr % 16 == 0) && (ld % 4 == 0) && (bs % 4 == 0);
+    };
+    p.a_vec = aligned(d.A, d.lda, d.sA);
+    p.b_vec = aligned(d.B, d.ldb, d.sB);
+    if (p.atomic && !d.accumulate) {
+        // split-K partials are summed with atomics: C must start from zero
+        if (d.ldc == d.N) {
+            LAS_HIP_CHECK(hipMemsetAsync(d.C, 0, sizeof(float) * ((size_t)(batch - 1) * d.sC + (size_t)d.M * d.N), stream));
+        } else {
+            LAS_HIP_CHECK(hipMemset2DAsync(d.C, sizeof(float) * d.ldc, 0, sizeof(float) * d.N, (size_t)d.M, stream));
+            LAS_REQUIRE(batch == 1, "split-K with strided C and batch>1");
+        }
+    }
+    dim3 grid(gx, gy, batch * splitk), block(GEMM_THREADS);
+    if (d.a_kc && d.b_kc) hipLaunchKernelGGL((gemm_f32_kernel<true, true>), grid, block, 0, stream, p);
+    else if (d.a_kc && !d.b_kc) hipLaunchKernelGGL((gemm_f32_kernel<true, false>), grid, block, 0, stream, p);
+    else if (!d.a_kc && d.b_kc) hipLaunchKernelGGL((gemm_f32_kernel<false, true>), grid, block, 0, stream, p);
+    else hipLaunchKernelGGL((gemm_f32_kernel<false, false>), grid, block, 0, stream, p);
+    LAS_LAUNCH_CHECK();
+    return LAS_OK;
+}
+
+}  // namespace las

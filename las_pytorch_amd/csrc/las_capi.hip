@@ -1,0 +1,431 @@
+// C-ABI layer of liblas_hip.so: argument checking, workspace carving and kernel orchestration.
+// Declarations and the reference lines each entry point replaces: include/las_hip.h.
+#include "../../include/las_hip.h"
+#include "las_common.h"
+#include "las_kernels.h"
+
+using namespace las;
+
+namespace {
+
+inline size_t r4(size_t n) { return (n + 3) & ~(size_t)3; }   // keep every carved section 16-byte aligned
+
+struct PblstmLayout {
+    size_t gates, cbuf, hprev, xbuf, total;
+    PblstmLayout(int B, int T, int H, bool stash) {
+        size_t o = 0;
+        gates = o; o += r4((size_t)2 * B * T * 4 * H);
+        cbuf = o; if (stash) o += r4((size_t)2 * B * T * H);
+        hprev = o; if (stash) o += r4((size_t)2 * B * T * H);
+        xbuf = o; o += r4(rec_xbuf_bytes(B, H) / sizeof(float));
+        total = o;
+    }
+};
+
+struct PblstmBwdLayout {
+    size_t dgates, wt, xbuf, total;
+    PblstmBwdLayout(int B, int T, int H) {
+        size_t o = 0;
+        dgates = o; o += r4((size_t)2 * B * T * 4 * H);
+        wt = o; o += r4((size_t)2 * H * 4 * H);
+        xbuf = o; o += r4(rec_xbuf_bytes(B, H) / sizeof(float));
+        total = o;
+    }
+};
+
+struct SpellerLayout {
+    size_t y_all, ctx_all, h_all, c_all, gates_all, q_all, total;
+    SpellerLayout(const las_speller_desc* d, int U) {
+        size_t o = 0;
+        const size_t B = d->B;
+        y_all = o; o += r4((size_t)(U + 1) * B * d->V);
+        ctx_all = o; o += r4((size_t)(U + 1) * B * d->D);
+        h_all = o; o += r4((size_t)d->L * U * B * d->Hs);
+        c_all = o; o += r4((size_t)d->L * U * B * d->Hs);
+        gates_all = o; o += r4((size_t)d->L * U * B * 4 * d->Hs);
+        q_all = o; if (d->use_mlp) o += r4((size_t)U * B * d->M);
+        total = o;
+    }
+};
+
+struct SpellerBwdLayout {
+    size_t dG_all, dz_all, dctx_all, de_all, dqpre_all, dh_top, dh_below, dh_carry, dc_carry, dx0, dK, total;
+    SpellerBwdLayout(const las_speller_desc* d, int U) {
+        size_t o = 0;
+        const size_t B = d->B;
+        const size_t Mq = d->use_mlp ? d->M : d->Hs;
+        dG_all = o; o += r4((size_t)d->L * U * B * 4 * d->Hs);
+        dz_all = o; o += r4((size_t)U * B * d->V);
+        dctx_all = o; o += r4((size_t)U * B * d->D);
+        de_all = o; o += r4((size_t)U * B * d->Tp);
+        dqpre_all = o; o += r4((size_t)U * B * d->M);
+        dh_top = o; o += r4(B * d->Hs);
+        dh_below = o; o += r4(B * d->Hs);
+        dh_carry = o; o += r4((size_t)d->L * B * d->Hs);
+        dc_carry = o; o += r4((size_t)d->L * B * d->Hs);
+        dx0 = o; o += r4(B * (d->V + d->D));
+        dK = o; o += r4(B * d->Tp * Mq);
+        total = o;
+    }
+};
+
+int check_desc(const las_speller_desc* d) {
+    LAS_REQUIRE(d != nullptr, "descriptor");
+    LAS_REQUIRE(d->B > 0 && d->Tp > 0 && d->D > 0 && d->Hs > 0 && d->V > 0, "speller dims");
+    LAS_REQUIRE(d->L >= 1 && d->L <= LAS_MAX_SPELLER_LAYERS, "speller layers");
+    LAS_REQUIRE(d->D == d->Hs, "Speller hidden_size must equal 2*listener_hidden_size (reference las_model.py:198)");
+    if (d->multi_head != 1) return fail(LAS_ERR_UNSUPPORTED, "multi-head attention is not implemented by the HIP path%s", "");
+    LAS_REQUIRE(!d->use_mlp || d->M > 0, "attention mlp dim");
+    for (int l = 0; l < d->L; ++l) LAS_REQUIRE(d->w_ih[l] && d->w_hh[l] && d->b_ih[l] && d->b_hh[l], "speller LSTM weights");
+    LAS_REQUIRE(d->w_c && d->b_c, "character distribution weights");
+    LAS_REQUIRE(!d->use_mlp || (d->w_phi && d->b_phi && d->w_psi && d->b_psi), "attention MLP weights");
+    return LAS_OK;
+}
+
+#define LAS_TRY(expr) do { int _rc = (expr); if (_rc != LAS_OK) return _rc; } while (0)
+
+}  // namespace
+
+extern "C" {
+
+int las_abi_version(void) { return LAS_ABI_VERSION; }
+const char* las_last_error(void) { return g_err; }
+
+// ---------------------------------------------------------------------------------------------- pBLSTM
+size_t las_pblstm_reserve_floats(int B, int T_in, int H, int flags) {
+    return PblstmLayout(B, T_in / 2, H, flags & LAS_FLAG_STASH).total;
+}
+
+int las_pblstm_fwd(const float* x, int B, int T_in, int D_in, int H, const float* w_ih_f, const float* w_hh_f,
+                   const float* b_ih_f, const float* b_hh_f, const float* w_ih_r, const float* w_hh_r, const float* b_ih_r,
+                   const float* b_hh_r, float* out, float* reserve, uint32_t* err_word, int flags, void* stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    LAS_REQUIRE(B > 0 && T_in > 0 && D_in > 0 && H > 0, "pblstm dims");
+    LAS_REQUIRE(T_in % 2 == 0, "pBLSTM needs an even number of frames (reference las_model.py:86-87)");
+    LAS_REQUIRE(x && out && reserve && err_word, "pblstm pointers");
+    LAS_REQUIRE(w_ih_f && w_hh_f && b_ih_f && b_hh_f && w_ih_r && w_hh_r && b_ih_r && b_hh_r, "pblstm weights");
+    LAS_REQUIRE((uintptr_t)reserve % 16 == 0, "reserve alignment");
+    const int T = T_in / 2, D = 2 * D_in;
+    const bool stash = flags & LAS_FLAG_STASH;
+    PblstmLayout lay(B, T, H, stash);
+    float* gates = reserve + lay.gates;
+    // K2: input projection for both directions (MFMA GEMM, biases fused)
+    for (int dir = 0; dir < 2; ++dir) {
+        GemmDesc g;
+        g.A = x; g.lda = D; g.a_kc = true;
+        g.B = dir ? w_ih_r : w_ih_f; g.ldb = D; g.b_kc = true;
+        g.C = gates + (size_t)dir * B * T * 4 * H; g.ldc = 4 * H;
+        g.bias0 = dir ? b_ih_r : b_ih_f; g.bias1 = dir ? b_hh_r : b_hh_f;
+        g.M = B * T; g.N = 4 * H; g.K = D; g.splitk = 1;
+        LAS_TRY(gemm_f32(g, stream));
+    }
+    // K3: time recurrence
+    return pblstm_rec_fwd(gates, w_hh_f, w_hh_r, out, stash ? reserve + lay.cbuf : nullptr, stash ? reserve + lay.hprev : nullptr,
+                          B, T, H, stash, (unsigned long long*)(reserve + lay.xbuf), err_word,
+                          flags & LAS_FLAG_FORCE_GENERIC, stream);
+}
+
+size_t las_pblstm_bwd_workspace_floats(int B, int T_in, int H) { return PblstmBwdLayout(B, T_in / 2, H).total; }
+
+int las_pblstm_bwd(const float* x, const float* dout, int B, int T_in, int D_in, int H, const float* w_ih_f,
+                   const float* w_hh_f, const float* w_ih_r, const float* w_hh_r, const float* reserve, float* workspace,
+                   float* dx, float* dw_ih_f, float* dw_hh_f, float* db_ih_f, float* db_hh_f, float* dw_ih_r, float* dw_hh_r,
+                   float* db_ih_r, float* db_hh_r, uint32_t* err_word, int flags, void* stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    LAS_REQUIRE(B > 0 && T_in > 0 && D_in > 0 && H > 0 && T_in % 2 == 0, "pblstm dims");
+    LAS_REQUIRE(x && dout && reserve && workspace && err_word, "pblstm bwd pointers");
+    LAS_REQUIRE(dw_ih_f && dw_hh_f && db_ih_f && db_hh_f && dw_ih_r && dw_hh_r && db_ih_r && db_hh_r, "pblstm grad outputs");
+    const int T = T_in / 2, D = 2 * D_in;
+    PblstmLayout lay(B, T, H, true);
+    PblstmBwdLayout wl(B, T, H);
+    const float* gates = reserve + lay.gates;
+    const float* cbuf = reserve + lay.cbuf;
+    const float* hprev = reserve + lay.hprev;
+    float* dgates = workspace + wl.dgates;
+    float* wt = workspace + wl.wt;
+    LAS_TRY(transpose2d(w_hh_f, wt, 4 * H, H, stream));
+    LAS_TRY(transpose2d(w_hh_r, wt + (size_t)H * 4 * H, 4 * H, H, stream));
+    LAS_TRY(pblstm_rec_bwd(dout, gates, cbuf, wt, dgates, B, T, H, (unsigned long long*)(workspace + wl.xbuf), err_word,
+                           flags & LAS_FLAG_FORCE_GENERIC, stream));
+    const int BT = B * T;
+    for (int dir = 0; dir < 2; ++dir) {
+        const float* dG = dgates + (size_t)dir * BT * 4 * H;
+        const float* hp = hprev + (size_t)dir * BT * H;
+        float* dw_ih = dir ? dw_ih_r : dw_ih_f;
+        float* dw_hh = dir ? dw_hh_r : dw_hh_f;
+        float* db_ih = dir ? db_ih_r : db_ih_f;
+        float* db_hh = dir ? db_hh_r : db_hh_f;
+        {   // dW_ih = dG^T X
+            GemmDesc g;
+            g.A = dG; g.lda = 4 * H; g.a_kc = false;
+            g.B = x; g.ldb = D; g.b_kc = false;
+            g.C = dw_ih; g.ldc = D; g.M = 4 * H; g.N = D; g.K = BT;
+            LAS_TRY(gemm_f32(g, stream));
+        }
+        {   // dW_hh = dG^T H_prev
+            GemmDesc g;
+            g.A = dG; g.lda = 4 * H; g.a_kc = false;
+            g.B = hp; g.ldb = H; g.b_kc = false;
+            g.C = dw_hh; g.ldc = H; g.M = 4 * H; g.N = H; g.K = BT;
+            LAS_TRY(gemm_f32(g, stream));
+        }
+        LAS_TRY(colsum(dG, 4 * H, BT, 4 * H, db_ih, 0, stream));
+        LAS_HIP_CHECK(hipMemcpyAsync(db_hh, db_ih, sizeof(float) * 4 * H, hipMemcpyDeviceToDevice, stream));
+        if (dx) {   // dX (+)= dG W_ih
+            GemmDesc g;
+            g.A = dG; g.lda = 4 * H; g.a_kc = true;
+            g.B = dir ? w_ih_r : w_ih_f; g.ldb = D; g.b_kc = false;
+            g.C = dx; g.ldc = D; g.M = BT; g.N = D; g.K = 4 * H; g.splitk = 1;
+            g.accumulate = dir == 1;
+            LAS_TRY(gemm_f32(g, stream));
+        }
+    }
+    return LAS_OK;
+}
+
+// ---------------------------------------------------------------------------------------------- Speller
+int las_attn_keys_fwd(const las_speller_desc* d, const float* feat, float* keys, void* stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    LAS_TRY(check_desc(d));
+    LAS_REQUIRE(d->use_mlp, "keys are the listener features themselves when the attention MLP is off");
+    LAS_REQUIRE(feat && keys, "keys pointers");
+    GemmDesc g;
+    g.A = feat; g.lda = d->D; g.a_kc = true;
+    g.B = d->w_psi; g.ldb = d->D; g.b_kc = true;
+    g.C = keys; g.ldc = d->M; g.bias0 = d->b_psi;
+    g.M = d->B * d->Tp; g.N = d->M; g.K = d->D; g.splitk = 1; g.relu = d->relu;
+    return gemm_f32(g, stream);
+}
+
+size_t las_speller_reserve_floats(const las_speller_desc* d, int U) { return SpellerLayout(d, U).total; }
+
+int las_speller_fwd(const las_speller_desc* d, const float* feat, const float* keys, const int64_t* labels_onehot, int U_lab,
+                    int U, int teacher_forced, int decode_mode, float* logp, float* att, int32_t* argmax, float* reserve,
+                    int flags, void* stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    LAS_TRY(check_desc(d));
+    LAS_REQUIRE(U > 0, "decode steps");
+    LAS_REQUIRE(feat && logp && att && reserve, "speller pointers");
+    LAS_REQUIRE(!d->use_mlp || keys, "attention keys");
+    LAS_REQUIRE(!teacher_forced || (labels_onehot && U_lab >= U), "teacher forcing needs labels for every step");
+    if (!teacher_forced && decode_mode != 0 && decode_mode != 1)
+        return fail(LAS_ERR_UNSUPPORTED, "decode_mode %s%ld is not implemented by the HIP path", "", (long)decode_mode);
+    LAS_REQUIRE((uintptr_t)reserve % 16 == 0, "reserve alignment");
+    (void)flags;
+    const int B = d->B, Hs = d->Hs, V = d->V, D = d->D, Tp = d->Tp, L = d->L;
+    SpellerLayout lay(d, U);
+    float* y_all = reserve + lay.y_all;
+    float* ctx_all = reserve + lay.ctx_all;
+    float* h_all = reserve + lay.h_all;
+    float* c_all = reserve + lay.c_all;
+    float* gates_all = reserve + lay.gates_all;
+    float* q_all = d->use_mlp ? reserve + lay.q_all : nullptr;
+    const size_t sH = (size_t)B * Hs;       // one (B,Hs) slab
+
+    LAS_TRY(labels_to_y(teacher_forced ? (const long long*)labels_onehot : nullptr, y_all, B, U, V, U_lab, stream));
+    LAS_TRY(copy2d(feat, (long)Tp * D, ctx_all, D, B, D, 0, stream));     // ctx_{-1} = feat[:,0,:] (las_model.py:198)
+
+    for (int s = 0; s < U; ++s) {
+        for (int l = 0; l < L; ++l) {
+            CellSeg segs[3];
+            int n = 0;
+            if (l == 0) {
+                segs[n].x = y_all + (size_t)s * B * V; segs[n].ldx = V; segs[n].w = d->w_ih[0]; segs[n].ldw = V + Hs; segs[n].K = V; ++n;
+                segs[n].x = ctx_all + (size_t)s * B * D; segs[n].ldx = D; segs[n].w = d->w_ih[0] + V; segs[n].ldw = V + Hs; segs[n].K = D; ++n;
+            } else {
+                segs[n].x = h_all + ((size_t)(l - 1) * U + s) * sH; segs[n].ldx = Hs; segs[n].w = d->w_ih[l]; segs[n].ldw = Hs; segs[n].K = Hs; ++n;
+            }
+            if (s > 0) {
+                segs[n].x = h_all + ((size_t)l * U + s - 1) * sH; segs[n].ldx = Hs; segs[n].w = d->w_hh[l]; segs[n].ldw = Hs; segs[n].K = Hs; ++n;
+            }
+            LAS_TRY(lstm_cell_fwd(segs, n, d->b_ih[l], d->b_hh[l], s > 0 ? c_all + ((size_t)l * U + s - 1) * sH : nullptr,
+                                  h_all + ((size_t)l * U + s) * sH, c_all + ((size_t)l * U + s) * sH,
+                                  gates_all + ((size_t)l * U + s) * 4 * sH, B, Hs, stream));
+        }
+        AttnFwdArgs a;
+        a.h_top = h_all + ((size_t)(L - 1) * U + s) * sH;
+        a.feat = feat; a.keys = d->use_mlp ? keys : feat;
+        a.w_phi = d->w_phi; a.b_phi = d->b_phi; a.w_c = d->w_c; a.b_c = d->b_c;
+        a.q_out = q_all ? q_all + (size_t)s * B * d->M : nullptr;
+        a.att_out = att + (size_t)s * B * Tp;
+        a.ctx_out = ctx_all + (size_t)(s + 1) * B * D;
+        a.logp_out = logp + (size_t)s * B * V;
+        a.argmax_out = argmax ? argmax + (size_t)s * B : nullptr;
+        a.y_next = teacher_forced ? nullptr : y_all + (size_t)(s + 1) * B * V;
+        a.y_mode = decode_mode;
+        a.B = B; a.Tp = Tp; a.D = D; a.M = d->M; a.V = V; a.Hs = Hs; a.use_mlp = d->use_mlp; a.relu = d->relu;
+        LAS_TRY(attn_step_fwd(a, stream));
+    }
+    return LAS_OK;
+}
+
+size_t las_speller_bwd_workspace_floats(const las_speller_desc* d, int U) { return SpellerBwdLayout(d, U).total; }
+
+int las_speller_bwd(const las_speller_desc* d, const float* feat, const float* keys, const float* logp, const float* att,
+                    const float* dlogp, int U, int feedback_mode0, const float* reserve, float* workspace,
+                    const las_speller_grads* g, void* stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    LAS_TRY(check_desc(d));
+    LAS_REQUIRE(U > 0 && feat && logp && att && dlogp && reserve && workspace && g, "speller bwd pointers");
+    LAS_REQUIRE(!d->use_mlp || keys, "attention keys");
+    LAS_REQUIRE(g->dfeat && g->dw_c && g->db_c, "speller grad outputs");
+    LAS_REQUIRE(!d->use_mlp || (g->dw_phi && g->db_phi && g->dw_psi && g->db_psi), "attention grad outputs");
+    const int B = d->B, Hs = d->Hs, V = d->V, D = d->D, Tp = d->Tp, L = d->L, M = d->M;
+    for (int l = 0; l < L; ++l) LAS_REQUIRE(g->dw_ih[l] && g->dw_hh[l] && g->db_ih[l] && g->db_hh[l], "LSTM grad outputs");
+    SpellerLayout lay(d, U);
+    SpellerBwdLayout wl(d, U);
+    const float* y_all = reserve + lay.y_all;
+    const float* ctx_all = reserve + lay.ctx_all;
+    const float* h_all = reserve + lay.h_all;
+    const float* c_all = reserve + lay.c_all;
+    const float* gates_all = reserve + lay.gates_all;
+    const float* q_all = d->use_mlp ? reserve + lay.q_all : nullptr;
+    float* dG_all = workspace + wl.dG_all;
+    float* dz_all = workspace + wl.dz_all;
+    float* dctx_all = workspace + wl.dctx_all;
+    float* de_all = workspace + wl.de_all;
+    float* dqpre_all = workspace + wl.dqpre_all;
+    float* dh_top = workspace + wl.dh_top;
+    float* dh_below = workspace + wl.dh_below;
+    float* dh_carry = workspace + wl.dh_carry;
+    float* dc_carry = workspace + wl.dc_carry;
+    float* dx0 = workspace + wl.dx0;
+    float* dK = workspace + wl.dK;
+    const size_t sH = (size_t)B * Hs;
+    const float* keys_eff = d->use_mlp ? keys : feat;
+    const float* h_top_all = h_all + (size_t)(L - 1) * U * sH;
+
+    for (int s = U - 1; s >= 0; --s) {
+        const bool last = (s == U - 1);
+        AttnBwdArgs a;
+        a.dlogp = dlogp + (size_t)s * B * V; a.logp = logp + (size_t)s * B * V;
+        a.h_top = h_top_all + (size_t)s * sH; a.ctx = ctx_all + (size_t)(s + 1) * B * D;
+        a.att = att + (size_t)s * B * Tp; a.q = q_all ? q_all + (size_t)s * B * M : nullptr;
+        a.feat = feat; a.keys = keys_eff; a.w_phi = d->w_phi; a.w_c = d->w_c;
+        a.dctx_carry = last ? nullptr : dx0 + V; a.ldc = V + D;
+        a.dy_carry = (feedback_mode0 && !last) ? dx0 : nullptr; a.ldy = V + D;
+        a.dz_out = dz_all + (size_t)s * B * V; a.dctx_out = dctx_all + (size_t)s * B * D;
+        a.de_out = de_all + (size_t)s * B * Tp; a.dqpre_out = dqpre_all + (size_t)s * B * M; a.dh_top_out = dh_top;
+        a.B = B; a.Tp = Tp; a.D = D; a.M = M; a.V = V; a.Hs = Hs; a.use_mlp = d->use_mlp; a.relu = d->relu;
+        LAS_TRY(attn_step_bwd(a, stream));
+        const float* dh_above = dh_top;
+        for (int l = L - 1; l >= 0; --l) {
+            float* dGl = dG_all + ((size_t)l * U + s) * 4 * sH;
+            LAS_TRY(lstm_cell_bwd_pointwise(dh_above, last ? nullptr : dh_carry + (size_t)l * sH,
+                                            last ? nullptr : dc_carry + (size_t)l * sH,
+                                            gates_all + ((size_t)l * U + s) * 4 * sH, c_all + ((size_t)l * U + s) * sH,
+                                            s > 0 ? c_all + ((size_t)l * U + s - 1) * sH : nullptr, dGl,
+                                            dc_carry + (size_t)l * sH, B, Hs, stream));
+            if (l > 0) {
+                LAS_TRY(smallm_gemm_nn2(dGl, 4 * Hs, B, 4 * Hs, d->w_ih[l], Hs, dh_below, Hs, Hs, d->w_hh[l], Hs,
+                                        dh_carry + (size_t)l * sH, Hs, Hs, stream));
+                dh_above = dh_below;
+            } else {
+                LAS_TRY(smallm_gemm_nn2(dGl, 4 * Hs, B, 4 * Hs, d->w_ih[0], V + Hs, dx0, V + D, V + D, d->w_hh[0], Hs,
+                                        dh_carry, Hs, Hs, stream));
+            }
+        }
+    }
+
+    // ---- deferred (loop-invariant-shaped) contractions, all MFMA GEMMs -------------------------
+    const int UB = U * B;
+    {   // dfeat[b] = att[:,b,:]^T dctx_all[:,b,:]   (context path, las_model.py:293-297)
+        GemmDesc q;
+        q.A = att; q.lda = (long)B * Tp; q.a_kc = false; q.sA = Tp;
+        q.B = dctx_all; q.ldb = (long)B * D; q.b_kc = false; q.sB = D;
+        q.C = g->dfeat; q.ldc = D; q.sC = (long)Tp * D; q.batch = B;
+        q.M = Tp; q.N = D; q.K = U; q.splitk = 1;
+        LAS_TRY(gemm_f32(q, stream));
+    }
+    // first decoder input used feat[:,0,:] as context (las_model.py:198)
+    LAS_TRY(copy2d(dx0 + V, V + D, g->dfeat, (long)Tp * D, B, D, 1, stream));
+    const int Mq = d->use_mlp ? M : Hs;
+    {   // dK[b] = de[:,b,:]^T q[:,b,:]   (energy path)
+        GemmDesc q;
+        q.A = de_all; q.lda = (long)B * Tp; q.a_kc = false; q.sA = Tp;
+        q.B = d->use_mlp ? q_all : h_top_all; q.ldb = (long)B * Mq; q.b_kc = false; q.sB = Mq;
+        q.C = d->use_mlp ? dK : g->dfeat; q.ldc = Mq; q.sC = (long)Tp * Mq; q.batch = B;
+        q.M = Tp; q.N = Mq; q.K = U; q.splitk = 1; q.accumulate = !d->use_mlp;
+        LAS_TRY(gemm_f32(q, stream));
+    }
+    if (d->use_mlp) {
+        const int BT = B * Tp;
+        if (d->relu) LAS_TRY(relu_mask_inplace(dK, keys, (long)BT * M, stream));
+        {   // dW_psi = dKpre^T feat
+            GemmDesc q;
+            q.A = dK; q.lda = M; q.a_kc = false; q.B = feat; q.ldb = D; q.b_kc = false;
+            q.C = g->dw_psi; q.ldc = D; q.M = M; q.N = D; q.K = BT;
+            LAS_TRY(gemm_f32(q, stream));
+        }
+        LAS_TRY(colsum(dK, M, BT, M, g->db_psi, 0, stream));
+        {   // dfeat += dKpre W_psi
+            GemmDesc q;
+            q.A = dK; q.lda = M; q.a_kc = true; q.B = d->w_psi; q.ldb = D; q.b_kc = false;
+            q.C = g->dfeat; q.ldc = D; q.M = BT; q.N = D; q.K = M; q.splitk = 1; q.accumulate = true;
+            LAS_TRY(gemm_f32(q, stream));
+        }
+        {   // dW_phi = dqpre^T h_top
+            GemmDesc q;
+            q.A = dqpre_all; q.lda = M; q.a_kc = false; q.B = h_top_all; q.ldb = Hs; q.b_kc = false;
+            q.C = g->dw_phi; q.ldc = Hs; q.M = M; q.N = Hs; q.K = UB;
+            LAS_TRY(gemm_f32(q, stream));
+        }
+        LAS_TRY(colsum(dqpre_all, M, UB, M, g->db_phi, 0, stream));
+    }
+    {   // dW_c = dz^T [h_top | ctx]
+        GemmDesc q;
+        q.A = dz_all; q.lda = V; q.a_kc = false; q.B = h_top_all; q.ldb = Hs; q.b_kc = false;
+        q.C = g->dw_c; q.ldc = Hs + D; q.M = V; q.N = Hs; q.K = UB;
+        LAS_TRY(gemm_f32(q, stream));
+        q.B = ctx_all + (size_t)B * D; q.ldb = D; q.C = g->dw_c + Hs; q.N = D;
+        LAS_TRY(gemm_f32(q, stream));
+        LAS_TRY(colsum(dz_all, V, UB, V, g->db_c, 0, stream));
+    }
+    for (int l = 0; l < L; ++l) {
+        const float* dGl = dG_all + (size_t)l * U * 4 * sH;
+        GemmDesc q;
+        q.A = dGl; q.lda = 4 * Hs; q.a_kc = false; q.b_kc = false; q.M = 4 * Hs; q.K = UB;
+        if (l == 0) {
+            q.B = y_all; q.ldb = V; q.C = g->dw_ih[0]; q.ldc = V + Hs; q.N = V;
+            LAS_TRY(gemm_f32(q, stream));
+            q.B = ctx_all; q.ldb = D; q.C = g->dw_ih[0] + V; q.N = D;
+            LAS_TRY(gemm_f32(q, stream));
+        } else {
+            q.B = h_all + (size_t)(l - 1) * U * sH; q.ldb = Hs; q.C = g->dw_ih[l]; q.ldc = Hs; q.N = Hs;
+            LAS_TRY(gemm_f32(q, stream));
+        }
+        if (U > 1) {   // dW_hh = sum_{s>=1} dG_s^T h_{s-1}
+            GemmDesc r;
+            r.A = dGl + 4 * sH; r.lda = 4 * Hs; r.a_kc = false;
+            r.B = h_all + (size_t)l * U * sH; r.ldb = Hs; r.b_kc = false;
+            r.C = g->dw_hh[l]; r.ldc = Hs; r.M = 4 * Hs; r.N = Hs; r.K = (U - 1) * B;
+            LAS_TRY(gemm_f32(r, stream));
+        } else {
+            LAS_HIP_CHECK(hipMemsetAsync(g->dw_hh[l], 0, sizeof(float) * 4 * Hs * Hs, stream));
+        }
+        LAS_TRY(colsum(dGl, 4 * Hs, UB, 4 * Hs, g->db_ih[l], 0, stream));
+        LAS_HIP_CHECK(hipMemcpyAsync(g->db_hh[l], g->db_ih[l], sizeof(float) * 4 * Hs, hipMemcpyDeviceToDevice, stream));
+    }
+    return LAS_OK;
+}
+
+// ---------------------------------------------------------------------------------------------- building blocks
+int las_gemm_f32(const float* A, const float* B, float* C, const float* bias0, const float* bias1, int M, int N, int K,
+                 int64_t lda, int64_t ldb, int64_t ldc, int a_kc, int b_kc, int batch, int64_t sA, int64_t sB, int64_t sC,
+                 int splitk, int accumulate, int relu, void* stream) {
+    GemmDesc g;
+    g.A = A; g.B = B; g.C = C; g.bias0 = bias0; g.bias1 = bias1; g.M = M; g.N = N; g.K = K;
+    g.lda = lda; g.ldb = ldb; g.ldc = ldc; g.a_kc = a_kc; g.b_kc = b_kc; g.batch = batch; g.sA = sA; g.sB = sB; g.sC = sC;
+    g.splitk = splitk; g.accumulate = accumulate; g.relu = relu;
+    return gemm_f32(g, (hipStream_t)stream);
+}
+
+size_t las_rec_xbuf_bytes(int B, int H) { return rec_xbuf_bytes(B, H); }
+
+int las_pblstm_rec_fwd(float* gates, const float* w_hh_f, const float* w_hh_r, float* out, float* cbuf, float* hprev, int B,
+                       int T, int H, void* xbuf, uint32_t* err_word, int flags, void* stream) {
+    return pblstm_rec_fwd(gates, w_hh_f, w_hh_r, out, cbuf, hprev, B, T, H, flags & LAS_FLAG_STASH,
+                          (unsigned long long*)xbuf, err_word, flags & LAS_FLAG_FORCE_GENERIC, (hipStream_t)stream);
+}
+
+}  // extern "C"

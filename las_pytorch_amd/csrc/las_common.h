@@ -1,0 +1,57 @@
+// Shared device/host helpers for the LAS hot-path kernels (gfx950 / CDNA4 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <string.h>
+
+namespace las {
+
+// ---- status / error string (thread-local; C ABI returns int) --------------------------
+enum : int {
+    LAS_OK = 0,
+    LAS_ERR_ARG = 1,        // shape / pointer / alignment precondition violated
+    LAS_ERR_HIP = 2,        // a HIP runtime call failed
+    LAS_ERR_UNSUPPORTED = 3,// configuration not implemented by the kernels
+    LAS_ERR_DEVICE = 4,     // a kernel reported a device-side failure (e.g. hand-off timeout)
+};
+
+extern thread_local char g_err[512];
+
+inline int fail(int code, const char* fmt, const char* a = "", long x = 0, long y = 0) {
+    snprintf(g_err, sizeof(g_err), fmt, a, x, y);
+    return code;
+}
+
+#define LAS_HIP_CHECK(expr)                                                              \
+    do {                                                                                 \
+        hipError_t _e = (expr);                                                          \
+        if (_e != hipSuccess) {                                                          \
+            snprintf(::las::g_err, sizeof(::las::g_err), "%s failed: %s (%s:%d)", #expr, \
+                     hipGetErrorString(_e), __FILE__, __LINE__);                         \
+            return ::las::LAS_ERR_HIP;                                                   \
+        }                                                                                \
+    } while (0)
+
+#define LAS_REQUIRE(cond, msg)                                                           \
+    do {                                                                                 \
+        if (!(cond)) {                                                                   \
+            snprintf(::las::g_err, sizeof(::las::g_err), "precondition failed: %s [%s] (%s:%d)", msg, #cond, \
+                     __FILE__, __LINE__);                                                \
+            return ::las::LAS_ERR_ARG;                                                   \
+        }                                                                                \
+    } while (0)
+
+#define LAS_LAUNCH_CHECK() LAS_HIP_CHECK(hipGetLastError())
+
+// ---- accurate transcendental helpers (no fast-math: parity bar is 1e-3 rel through ~400
+//      recurrent steps and identical argmax; SURVEY.md section 7 "Transcendentals parity") ----
+__device__ __forceinline__ float sigmoidf_acc(float x) { return 1.0f / (1.0f + expf(-x)); }
+__device__ __forceinline__ float tanhf_acc(float x) { return tanhf(x); }
+
+using f32x4 = __attribute__((ext_vector_type(4))) float;
+using f32x16 = __attribute__((ext_vector_type(16))) float;
+
+static inline int cdiv(long a, long b) { return (int)((a + b - 1) / b); }
+
+}  // namespace las

@@ -1,0 +1,109 @@
+// Internal C++ interface between the kernel translation units and the C-ABI layer (las_capi.hip).
+#pragma once
+#include <hip/hip_runtime.h>
+
+namespace las {
+
+// ---- gemm_f32.hip ----------------------------------------------------------------------
+struct GemmDesc {
+    const float* A = nullptr;      // A(m,k) = a_kc ? A[m*lda + k] : A[k*lda + m]
+    const float* B = nullptr;      // B(k,n) = b_kc ? B[n*ldb + k] : B[k*ldb + n]
+    float* C = nullptr;            // C[m*ldc + n]
+    const float* bias0 = nullptr;  // optional per-N bias (added once)
+    const float* bias1 = nullptr;
+    int M = 0, N = 0, K = 0;
+    long lda = 0, ldb = 0, ldc = 0;
+    bool a_kc = true, b_kc = true;
+    int batch = 1;
+    long sA = 0, sB = 0, sC = 0;   // batch strides (elements)
+    int splitk = 0;                // 0 = auto, 1 = none, >1 = forced (atomic accumulation)
+    bool accumulate = false;       // C += ...
+    bool relu = false;
+};
+int gemm_f32(const GemmDesc& d, hipStream_t stream);
+
+// ---- pblstm_rec.hip --------------------------------------------------------------------
+// Forward time recurrence of one bidirectional LSTM layer, both directions in one launch.
+//   gates : (2, B, T, 4H)  in: x_t W_ih^T + b_ih + b_hh (PyTorch row order i,f,g,o) ; out (if stash): post-activation gates
+//   out   : (B, T, 2H)     h_fwd(t) | h_bwd(t)
+//   cbuf  : (2, B, T, H)   cell state c_t             (stash, may be null when !stash)
+//   hprev : (2, B, T, H)   h used as recurrent input at time t (stash)
+//   xbuf  : hand-off granules for the multi-CU variants, >= rec_xbuf_bytes(); err: device error word
+int pblstm_rec_fwd(float* gates, const float* w_hh_f, const float* w_hh_r, float* out, float* cbuf, float* hprev,
+                   int B, int T, int H, int stash, unsigned long long* xbuf, unsigned* err, int force_generic,
+                   hipStream_t stream);
+// Backward (BPTT) of the same recurrence.
+//   dout  : (B, T, 2H) upstream gradient ; gates/cbuf/hprev: the forward stash
+//   dgates: (2, B, T, 4H) out: dG_t (pre-activation gradients, PyTorch row order)
+//   w_hh_t: (2, H, 4H) transposed recurrent weights (see transpose_w_hh)
+int pblstm_rec_bwd(const float* dout, const float* gates, const float* cbuf, const float* w_hh_t, float* dgates,
+                   int B, int T, int H, unsigned long long* xbuf, unsigned* err, int force_generic,
+                   hipStream_t stream);
+size_t rec_xbuf_bytes(int B, int H);
+int transpose2d(const float* src, float* dst, int rows, int cols, hipStream_t stream);  // dst[c][r] = src[r][c]
+
+// ---- speller.hip -----------------------------------------------------------------------
+struct CellSeg {            // one dense input segment of an LSTM cell step:  gates += x(B,K) * W(4Hs,K)^T
+    const float* x = nullptr; long ldx = 0;
+    const float* w = nullptr; long ldw = 0;
+    int K = 0;
+};
+// One LSTM cell step for all B utterances (speller layer): gates = sum_seg x_seg W_seg^T + b_ih + b_hh, then the cell.
+// gates_out (B,4Hs) post-activation stash (may be null); c_prev may be null (zero state).
+int lstm_cell_fwd(const CellSeg* segs, int nseg, const float* b_ih, const float* b_hh, const float* c_prev, float* h_out,
+                  float* c_out, float* gates_out, int B, int Hs, hipStream_t stream);
+// Pointwise part of the cell backward: dh = dh_a + dh_b, dc_in, stash -> dG (B,4Hs), dc_prev (B,Hs)
+int lstm_cell_bwd_pointwise(const float* dh_a, const float* dh_b, const float* dc_in, const float* gates,
+                            const float* c, const float* c_prev, float* dG, float* dc_prev, int B, int Hs,
+                            hipStream_t stream);
+// Small-M dense products of the cell backward: out_i(B,N_i) = a(B,K) * W_i(K,N_i), i = 0,1 (W row-major, ld = ldw_i)
+int smallm_gemm_nn2(const float* a, long lda, int B, int K, const float* w0, long ldw0, float* out0, long ldo0, int N0,
+                    const float* w1, long ldw1, float* out1, long ldo1, int N1, hipStream_t stream);
+
+struct AttnFwdArgs {
+    const float* h_top;    // (B,Hs) decoder state
+    const float* feat;     // (B,Tp,D)   D = 2H = Hs
+    const float* keys;     // (B,Tp,M)   relu(psi(feat)) (or feat itself when !use_mlp)
+    const float* w_phi; const float* b_phi;     // (M,Hs),(M)
+    const float* w_c; const float* b_c;         // (V,2Hs),(V)
+    float* q_out;          // (B,M)   post-activation query (stash)
+    float* att_out;        // (B,Tp)  attention weights
+    float* ctx_out;        // (B,D)
+    float* logp_out;       // (B,V)
+    int* argmax_out;       // (B) or null
+    float* y_next;         // (B,V) or null: next-step input written on device (free-running decode)
+    int y_mode;            // 0: feed log-probs back, 1: feed one-hot argmax
+    int B, Tp, D, M, V, Hs;
+    int use_mlp, relu;
+};
+int attn_step_fwd(const AttnFwdArgs& a, hipStream_t stream);
+
+struct AttnBwdArgs {
+    const float* dlogp;    // (B,V) upstream gradient of this step's log-probs (may include mode-0 feedback grad)
+    const float* logp;     // (B,V)
+    const float* h_top;    // (B,Hs)
+    const float* ctx;      // (B,D)
+    const float* att;      // (B,Tp)
+    const float* q;        // (B,M)
+    const float* feat; const float* keys;
+    const float* w_phi; const float* w_c;
+    const float* dctx_carry; long ldc;   // (B,D) gradient flowing into this step's context from step s+1's input (may be null)
+    const float* dy_carry; long ldy;     // (B,V) gradient flowing into this step's log-probs from step s+1's input (decode_mode 0)
+    float* dz_out;         // (B,V)   stash for dW_c / db_c
+    float* dctx_out;       // (B,D)   total context gradient (stash for dfeat GEMM)
+    float* de_out;         // (B,Tp)  energy gradient (stash for dK GEMM)
+    float* dqpre_out;      // (B,M)   pre-activation query gradient (stash for dW_phi)
+    float* dh_top_out;     // (B,Hs)  gradient wrt decoder state from this step's attention + char distribution
+    int B, Tp, D, M, V, Hs;
+    int use_mlp, relu;
+};
+int attn_step_bwd(const AttnBwdArgs& a, hipStream_t stream);
+
+// ---- misc.hip --------------------------------------------------------------------------
+int colsum(const float* src, long ld, int rows, int cols, float* dst, int accumulate, hipStream_t stream);  // dst[c] (+)= sum_r src[r][c]
+int relu_mask_inplace(float* grad, const float* act, long n, hipStream_t stream);                           // grad = act>0 ? grad : 0
+int add_inplace(float* dst, const float* src, long n, hipStream_t stream);
+int copy2d(const float* src, long lds, float* dst, long ldd, int rows, int cols, int accumulate, hipStream_t stream);
+int labels_to_y(const long long* labels, float* y_all, int B, int U, int V, int u_lab, hipStream_t stream);
+
+}  // namespace las

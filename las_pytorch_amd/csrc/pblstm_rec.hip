@@ -1,0 +1,427 @@
+// Persistent-RNN time recurrence of one bidirectional LSTM layer (forward and BPTT) for gfx950.
+//
+// Replaces the recurrent half of nn.LSTM(bidirectional=True) that the reference's pBLSTMLayer calls
+// (reference model/las_model.py:72-79,90; cell equations are torch's: gates i,f,g,o, zero initial state,
+// reverse direction runs t = T-1..0).  The input half (x_t W_ih^T + biases) is the MFMA GEMM in gemm_f32.hip.
+//
+// Design (CDNA4):
+//   * One *group* of G workgroups (1024 threads = 16 wave64 each, one per CU) owns ONE (utterance, direction)
+//     for all T steps.  W_hh (4H x H fp32: 256 KB at H=128, 1 MB at H=256) never leaves the register file:
+//     each thread keeps 64 weights (4 gates x 16 k) in VGPRs, so a CU holds 256 KB and G = H^2/16384 CUs hold
+//     the whole matrix (G=1 at H=128, G=4 at H=256, G=16 at H=512).  Per step only h_{t-1} (H floats) moves.
+//   * Inside a CU h_{t-1} lives in LDS (double buffered, one barrier per step); each unit's 4 gate rows are
+//     split over LPU = H/16 lanes, reduced with cross-lane shuffles, and the owning lane applies the cell.
+//   * Between the G CUs of a group the new h slice travels as 8-byte {epoch tag, value} granules written with
+//     ONE agent-scope (sc1, write-through) store each and polled with relaxed agent-scope loads: the data is
+//     the flag, no fence, placement-independent (MI355X per-XCD L2s are not coherent).  Two parity slots
+//     make the protocol race-free; every spin is bounded and reports through a device error word.
+//   * Group members are placed on the same XCD when the dispatcher's observed round-robin holds (speed only).
+// A generic fallback (any H, weights streamed from L2) keeps every shape correct.
+#include "las_common.h"
+#include "las_kernels.h"
+
+namespace las {
+
+constexpr int REC_THREADS = 1024;
+constexpr unsigned SPIN_LIMIT = 1u << 22;
+using u64 = unsigned long long;
+
+__device__ __forceinline__ float poll_granule(u64* g, unsigned epoch, unsigned* err) {
+    unsigned spins = 0;
+    for (;;) {
+        const u64 x = __hip_atomic_load(g, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if ((unsigned)(x >> 32) == epoch) return __uint_as_float((unsigned)x);
+        ++spins;
+        if ((spins & 255u) == 0) {
+            if (spins > SPIN_LIMIT) { atomicExch(err, 0xDEAD0001u); return 0.f; }
+            if (__hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) return 0.f;
+        }
+        __builtin_amdgcn_s_sleep(1);
+    }
+}
+
+__device__ __forceinline__ void publish_granule(u64* g, unsigned epoch, float v) {
+    __hip_atomic_store(g, ((u64)epoch << 32) | (u64)__float_as_uint(v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+// group / member decode shared by forward and backward
+template <int G>
+__device__ __forceinline__ void decode_block(int ngroups, int& group, int& member) {
+    const int bid = blockIdx.x;
+    if (G > 1 && (ngroups & 7) == 0) {      // XCD-local groups under round-robin dispatch (block b -> XCD b%8)
+        const int xcd = bid & 7, q = bid >> 3;
+        member = q % G;
+        group = (q / G) * 8 + xcd;
+    } else {
+        member = bid % G;
+        group = bid / G;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Forward, register-resident W_hh
+// ------------------------------------------------------------------------------------------------
+template <int H, bool STASH>
+__global__ __launch_bounds__(REC_THREADS) void rec_fwd_fast(float* __restrict__ gates, const float* __restrict__ w_hh_f,
+                                                            const float* __restrict__ w_hh_r, float* __restrict__ out,
+                                                            float* __restrict__ cbuf, float* __restrict__ hprev, int B,
+                                                            int T, u64* xbuf, unsigned* err) {
+    constexpr int LPU = H / 16;             // lanes cooperating on one hidden unit
+    constexpr int UW = REC_THREADS / LPU;   // hidden units owned by this workgroup
+    constexpr int G = H / UW;               // workgroups per (utterance, direction)
+    __shared__ __attribute__((aligned(16))) float hs[2][H];
+
+    int group, member;
+    decode_block<G>(2 * B, group, member);
+    const int dir = group & 1, b = group >> 1;
+    const float* __restrict__ w_hh = dir ? w_hh_r : w_hh_f;
+    const int tid = threadIdx.x;
+    const int kc = tid % LPU, ul = tid / LPU;
+    const int j = member * UW + ul;
+    const bool owner = (kc == 0);
+
+    f32x4 w[4][4];
+#pragma unroll
+    for (int g = 0; g < 4; ++g)
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+            w[g][i] = *reinterpret_cast<const f32x4*>(w_hh + (long)(g * H + j) * H + i * 4 * LPU + kc * 4);
+
+    float* gbase = gates + ((long)(dir * B + b) * T) * 4 * H + j;
+    float* cb = STASH ? cbuf + ((long)(dir * B + b) * T) * H + j : nullptr;
+    float* hp = STASH ? hprev + ((long)(dir * B + b) * T) * H + j : nullptr;
+    float* ob = out + ((long)b * T) * 2 * H + dir * H + j;
+    u64* xg = xbuf + (long)group * 2 * H;
+
+    for (int i = tid; i < H; i += REC_THREADS) hs[0][i] = 0.f;
+    __syncthreads();
+
+    float c = 0.f;
+    float pre[4] = {0.f, 0.f, 0.f, 0.f};
+    if (owner) {
+        const int t0 = dir ? T - 1 : 0;
+#pragma unroll
+        for (int g = 0; g < 4; ++g) pre[g] = gbase[(long)t0 * 4 * H + g * H];
+    }
+    int cur = 0;
+    for (int step = 0; step < T; ++step) {
+        const int t = dir ? T - 1 - step : step;
+        float nxt[4] = {0.f, 0.f, 0.f, 0.f};
+        if (owner && step + 1 < T) {
+            const int tn = dir ? t - 1 : t + 1;
+#pragma unroll
+            for (int g = 0; g < 4; ++g) nxt[g] = gbase[(long)tn * 4 * H + g * H];
+        }
+        f32x4 hv[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) hv[i] = *reinterpret_cast<const f32x4*>(&hs[cur][i * 4 * LPU + kc * 4]);
+        float acc[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+#pragma unroll
+                for (int g = 0; g < 4; ++g) acc[g] = fmaf(w[g][i][e], hv[i][e], acc[g]);
+#pragma unroll
+        for (int m = 1; m < LPU; m <<= 1)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) acc[g] += __shfl_xor(acc[g], m);
+
+        if (owner) {
+            const float ig = sigmoidf_acc(acc[0] + pre[0]);
+            const float fg = sigmoidf_acc(acc[1] + pre[1]);
+            const float gg = tanhf_acc(acc[2] + pre[2]);
+            const float og = sigmoidf_acc(acc[3] + pre[3]);
+            c = fg * c + ig * gg;
+            const float h = og * tanhf_acc(c);
+            if (G > 1) publish_granule(xg + (step & 1) * H + j, (unsigned)step + 1u, h);
+            hs[cur ^ 1][j] = h;
+            ob[(long)t * 2 * H] = h;
+            if (STASH) {
+                hp[(long)t * H] = hs[cur][j];
+                cb[(long)t * H] = c;
+                float* gp = gbase + (long)t * 4 * H;
+                gp[0] = ig; gp[H] = fg; gp[2 * H] = gg; gp[3 * H] = og;
+            }
+#pragma unroll
+            for (int g = 0; g < 4; ++g) pre[g] = nxt[g];
+        }
+        if (G > 1) {
+            if (tid < H && tid / UW != member)
+                hs[cur ^ 1][tid] = poll_granule(xg + (step & 1) * H + tid, (unsigned)step + 1u, err);
+        }
+        __syncthreads();
+        cur ^= 1;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Forward, generic fallback: one workgroup per (utterance, direction), W_hh streamed from L2
+// ------------------------------------------------------------------------------------------------
+template <bool STASH>
+__global__ __launch_bounds__(256) void rec_fwd_generic(float* __restrict__ gates, const float* __restrict__ w_hh_f,
+                                                       const float* __restrict__ w_hh_r, float* __restrict__ out,
+                                                       float* __restrict__ cbuf, float* __restrict__ hprev, int B, int T,
+                                                       int H) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* hs0 = smem; float* hs1 = smem + H; float* cs = smem + 2 * H;
+    const int dir = blockIdx.x & 1, b = blockIdx.x >> 1;
+    const float* __restrict__ w_hh = dir ? w_hh_r : w_hh_f;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nw = blockDim.x >> 6;
+    for (int i = tid; i < H; i += blockDim.x) { hs0[i] = 0.f; cs[i] = 0.f; }
+    __syncthreads();
+    float* gb = gates + ((long)(dir * B + b) * T) * 4 * H;
+    for (int step = 0; step < T; ++step) {
+        const int t = dir ? T - 1 - step : step;
+        float* hc = (step & 1) ? hs1 : hs0;
+        float* hn = (step & 1) ? hs0 : hs1;
+        float* gp = gb + (long)t * 4 * H;
+        for (int j = wave; j < H; j += nw) {
+            float acc[4] = {0.f, 0.f, 0.f, 0.f};
+            for (int k = lane; k < H; k += 64) {
+                const float hv = hc[k];
+#pragma unroll
+                for (int g = 0; g < 4; ++g) acc[g] = fmaf(w_hh[(long)(g * H + j) * H + k], hv, acc[g]);
+            }
+#pragma unroll
+            for (int m = 32; m >= 1; m >>= 1)
+#pragma unroll
+                for (int g = 0; g < 4; ++g) acc[g] += __shfl_xor(acc[g], m);
+            if (lane == 0) {
+                const float ig = sigmoidf_acc(acc[0] + gp[j]);
+                const float fg = sigmoidf_acc(acc[1] + gp[H + j]);
+                const float gg = tanhf_acc(acc[2] + gp[2 * H + j]);
+                const float og = sigmoidf_acc(acc[3] + gp[3 * H + j]);
+                const float c = fg * cs[j] + ig * gg;
+                const float h = og * tanhf_acc(c);
+                cs[j] = c;
+                hn[j] = h;
+                out[((long)b * T + t) * 2 * H + dir * H + j] = h;
+                if (STASH) {
+                    const long o = ((long)(dir * B + b) * T + t) * H + j;
+                    hprev[o] = hc[j];
+                    cbuf[o] = c;
+                    gp[j] = ig; gp[H + j] = fg; gp[2 * H + j] = gg; gp[3 * H + j] = og;
+                }
+            }
+        }
+        __syncthreads();
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Backward (BPTT), register-resident W_hh^T.  Every workgroup of a group recomputes the full dG_t (cheap,
+// H threads) so that only dh (H floats) is exchanged per step, exactly like the forward pass.
+// ------------------------------------------------------------------------------------------------
+template <int H>
+__global__ __launch_bounds__(REC_THREADS) void rec_bwd_fast(const float* __restrict__ dout, const float* __restrict__ gates,
+                                                            const float* __restrict__ cbuf, const float* __restrict__ w_hh_t,
+                                                            float* __restrict__ dgates, int B, int T, u64* xbuf,
+                                                            unsigned* err) {
+    constexpr int LPU = H / 16;
+    constexpr int UW = REC_THREADS / LPU;
+    constexpr int G = H / UW;
+    __shared__ __attribute__((aligned(16))) float dhs[2][H];
+    __shared__ __attribute__((aligned(16))) float dgs[4 * H];
+
+    int group, member;
+    decode_block<G>(2 * B, group, member);
+    const int dir = group & 1, b = group >> 1;
+    const int tid = threadIdx.x;
+    const int rc = tid % LPU, kl = tid / LPU;
+    const int k = member * UW + kl;                      // the dh_{t-1} component this thread group produces
+    const float* __restrict__ wt = w_hh_t + ((long)dir * H + k) * 4 * H;
+
+    f32x4 w[16];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) w[i] = *reinterpret_cast<const f32x4*>(wt + i * 4 * LPU + rc * 4);
+
+    const long seq = (long)(dir * B + b) * T;
+    const float* gb = gates + seq * 4 * H;
+    const float* cb = cbuf + seq * H;
+    float* dgb = dgates + seq * 4 * H;
+    const float* dob = dout + ((long)b * T) * 2 * H + dir * H;
+    u64* xg = xbuf + (long)group * 2 * H;
+
+    for (int i = tid; i < H; i += REC_THREADS) dhs[0][i] = 0.f;
+    __syncthreads();
+
+    const bool pw = tid < H;                             // pointwise role: unit j = tid
+    const int j = tid;
+    const bool mine = pw && (j / UW == member);
+    float dc = 0.f;
+    // prefetch registers for the first processed step
+    float p_i = 0, p_f = 0, p_g = 0, p_o = 0, p_c = 0, p_cp = 0, p_do = 0;
+    auto load_step = [&](int t) {
+        const float* gp = gb + (long)t * 4 * H + j;
+        p_i = gp[0]; p_f = gp[H]; p_g = gp[2 * H]; p_o = gp[3 * H];
+        p_c = cb[(long)t * H + j];
+        const int tp = dir ? t + 1 : t - 1;              // previously processed time in the FORWARD pass
+        p_cp = (tp >= 0 && tp < T) ? cb[(long)tp * H + j] : 0.f;
+        p_do = dob[(long)t * 2 * H + j];
+    };
+    if (pw) load_step(dir ? 0 : T - 1);
+
+    int cur = 0;
+    for (int step = 0; step < T; ++step) {
+        const int t = dir ? step : T - 1 - step;         // reverse of the forward processing order
+        if (pw) {
+            const float ig = p_i, fg = p_f, gg = p_g, og = p_o, c_t = p_c, c_prev = p_cp;
+            const float dh = p_do + dhs[cur][j];
+            if (step + 1 < T) load_step(dir ? t + 1 : t - 1);
+            const float tc = tanhf_acc(c_t);
+            const float dct = dc + dh * og * (1.f - tc * tc);
+            const float dGi = dct * gg * ig * (1.f - ig);
+            const float dGf = dct * c_prev * fg * (1.f - fg);
+            const float dGg = dct * ig * (1.f - gg * gg);
+            const float dGo = dh * tc * og * (1.f - og);
+            dc = dct * fg;
+            dgs[j] = dGi; dgs[H + j] = dGf; dgs[2 * H + j] = dGg; dgs[3 * H + j] = dGo;
+            if (mine) {
+                float* dp = dgb + (long)t * 4 * H + j;
+                dp[0] = dGi; dp[H] = dGf; dp[2 * H] = dGg; dp[3 * H] = dGo;
+            }
+        }
+        __syncthreads();
+        float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            const f32x4 d = *reinterpret_cast<const f32x4*>(&dgs[i * 4 * LPU + rc * 4]);
+            a0 = fmaf(w[i][0], d[0], a0); a1 = fmaf(w[i][1], d[1], a1);
+            a2 = fmaf(w[i][2], d[2], a2); a3 = fmaf(w[i][3], d[3], a3);
+        }
+        float acc = (a0 + a1) + (a2 + a3);
+#pragma unroll
+        for (int m = 1; m < LPU; m <<= 1) acc += __shfl_xor(acc, m);
+        if (rc == 0) {
+            if (G > 1) publish_granule(xg + (step & 1) * H + k, (unsigned)step + 1u, acc);
+            dhs[cur ^ 1][k] = acc;
+        }
+        if (G > 1) {
+            if (tid < H && tid / UW != member)
+                dhs[cur ^ 1][tid] = poll_granule(xg + (step & 1) * H + tid, (unsigned)step + 1u, err);
+        }
+        __syncthreads();
+        cur ^= 1;
+    }
+}
+
+__global__ __launch_bounds__(256) void rec_bwd_generic(const float* __restrict__ dout, const float* __restrict__ gates,
+                                                       const float* __restrict__ cbuf, const float* __restrict__ w_hh_t,
+                                                       float* __restrict__ dgates, int B, int T, int H) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* dh0 = smem; float* dh1 = smem + H; float* dcs = smem + 2 * H; float* dgs = smem + 3 * H;
+    const int dir = blockIdx.x & 1, b = blockIdx.x >> 1;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nw = blockDim.x >> 6;
+    for (int i = tid; i < H; i += blockDim.x) { dh0[i] = 0.f; dcs[i] = 0.f; }
+    __syncthreads();
+    const long seq = (long)(dir * B + b) * T;
+    const float* wt = w_hh_t + (long)dir * H * 4 * H;
+    for (int step = 0; step < T; ++step) {
+        const int t = dir ? step : T - 1 - step;
+        float* dhc = (step & 1) ? dh1 : dh0;
+        float* dhn = (step & 1) ? dh0 : dh1;
+        for (int j = tid; j < H; j += blockDim.x) {
+            const float* gp = gates + (seq + t) * 4 * H + j;
+            const float ig = gp[0], fg = gp[H], gg = gp[2 * H], og = gp[3 * H];
+            const float c_t = cbuf[(seq + t) * H + j];
+            const int tp = dir ? t + 1 : t - 1;
+            const float c_prev = (tp >= 0 && tp < T) ? cbuf[(seq + tp) * H + j] : 0.f;
+            const float dh = dout[((long)b * T + t) * 2 * H + dir * H + j] + dhc[j];
+            const float tc = tanhf_acc(c_t);
+            const float dct = dcs[j] + dh * og * (1.f - tc * tc);
+            const float dGi = dct * gg * ig * (1.f - ig);
+            const float dGf = dct * c_prev * fg * (1.f - fg);
+            const float dGg = dct * ig * (1.f - gg * gg);
+            const float dGo = dh * tc * og * (1.f - og);
+            dcs[j] = dct * fg;
+            dgs[j] = dGi; dgs[H + j] = dGf; dgs[2 * H + j] = dGg; dgs[3 * H + j] = dGo;
+            float* dp = dgates + (seq + t) * 4 * H + j;
+            dp[0] = dGi; dp[H] = dGf; dp[2 * H] = dGg; dp[3 * H] = dGo;
+        }
+        __syncthreads();
+        for (int k = wave; k < H; k += nw) {
+            float acc = 0.f;
+            for (int r = lane; r < 4 * H; r += 64) acc = fmaf(wt[(long)k * 4 * H + r], dgs[r], acc);
+#pragma unroll
+            for (int m = 32; m >= 1; m >>= 1) acc += __shfl_xor(acc, m);
+            if (lane == 0) dhn[k] = acc;
+        }
+        __syncthreads();
+    }
+}
+
+__global__ void transpose2d_kernel(const float* __restrict__ src, float* __restrict__ dst, int rows, int cols) {
+    __shared__ float tile[32][33];
+    const int c0 = blockIdx.x * 32, r0 = blockIdx.y * 32;
+    for (int i = threadIdx.y; i < 32; i += blockDim.y) {
+        const int r = r0 + i, c = c0 + threadIdx.x;
+        tile[i][threadIdx.x] = (r < rows && c < cols) ? src[(long)r * cols + c] : 0.f;
+    }
+    __syncthreads();
+    for (int i = threadIdx.y; i < 32; i += blockDim.y) {
+        const int c = c0 + i, r = r0 + threadIdx.x;
+        if (r < rows && c < cols) dst[(long)c * rows + r] = tile[threadIdx.x][i];
+    }
+}
+
+int transpose2d(const float* src, float* dst, int rows, int cols, hipStream_t stream) {
+    dim3 grid(cdiv(cols, 32), cdiv(rows, 32)), block(32, 8);
+    hipLaunchKernelGGL(transpose2d_kernel, grid, block, 0, stream, src, dst, rows, cols);
+    LAS_LAUNCH_CHECK();
+    return LAS_OK;
+}
+
+size_t rec_xbuf_bytes(int B, int H) { return (size_t)2 * B * 2 * H * sizeof(u64); }
+
+static bool fast_h(int H) { return H == 128 || H == 256 || H == 512; }
+
+int pblstm_rec_fwd(float* gates, const float* w_hh_f, const float* w_hh_r, float* out, float* cbuf, float* hprev, int B,
+                   int T, int H, int stash, u64* xbuf, unsigned* err, int force_generic, hipStream_t stream) {
+    LAS_REQUIRE(B > 0 && T > 0 && H > 0, "rec dims");
+    LAS_REQUIRE(!stash || (cbuf && hprev), "stash buffers");
+    const int ngroups = 2 * B;
+    if (fast_h(H) && !force_generic) {
+        LAS_REQUIRE(xbuf && err, "hand-off buffers");
+        const int G = H * H / 16384;
+        if (G > 1) LAS_HIP_CHECK(hipMemsetAsync(xbuf, 0, rec_xbuf_bytes(B, H), stream));
+        dim3 grid(ngroups * G), block(REC_THREADS);
+#define LAUNCH_FWD(HH)                                                                                              \
+    if (stash) hipLaunchKernelGGL((rec_fwd_fast<HH, true>), grid, block, 0, stream, gates, w_hh_f, w_hh_r, out, cbuf, \
+                                  hprev, B, T, xbuf, err);                                                            \
+    else hipLaunchKernelGGL((rec_fwd_fast<HH, false>), grid, block, 0, stream, gates, w_hh_f, w_hh_r, out, cbuf,     \
+                            hprev, B, T, xbuf, err);
+        if (H == 128) { LAUNCH_FWD(128) } else if (H == 256) { LAUNCH_FWD(256) } else { LAUNCH_FWD(512) }
+#undef LAUNCH_FWD
+    } else {
+        const size_t smem = sizeof(float) * 3 * H;
+        if (stash) hipLaunchKernelGGL((rec_fwd_generic<true>), dim3(ngroups), dim3(256), smem, stream, gates, w_hh_f, w_hh_r,
+                                      out, cbuf, hprev, B, T, H);
+        else hipLaunchKernelGGL((rec_fwd_generic<false>), dim3(ngroups), dim3(256), smem, stream, gates, w_hh_f, w_hh_r, out,
+                                cbuf, hprev, B, T, H);
+    }
+    LAS_LAUNCH_CHECK();
+    return LAS_OK;
+}
+
+int pblstm_rec_bwd(const float* dout, const float* gates, const float* cbuf, const float* w_hh_t, float* dgates, int B,
+                   int T, int H, u64* xbuf, unsigned* err, int force_generic, hipStream_t stream) {
+    LAS_REQUIRE(B > 0 && T > 0 && H > 0, "rec dims");
+    const int ngroups = 2 * B;
+    if (fast_h(H) && !force_generic) {
+        LAS_REQUIRE(xbuf && err, "hand-off buffers");
+        const int G = H * H / 16384;
+        if (G > 1) LAS_HIP_CHECK(hipMemsetAsync(xbuf, 0, rec_xbuf_bytes(B, H), stream));
+        dim3 grid(ngroups * G), block(REC_THREADS);
+        if (H == 128) hipLaunchKernelGGL((rec_bwd_fast<128>), grid, block, 0, stream, dout, gates, cbuf, w_hh_t, dgates, B, T, xbuf, err);
+        else if (H == 256) hipLaunchKernelGGL((rec_bwd_fast<256>), grid, block, 0, stream, dout, gates, cbuf, w_hh_t, dgates, B, T, xbuf, err);
+        else hipLaunchKernelGGL((rec_bwd_fast<512>), grid, block, 0, stream, dout, gates, cbuf, w_hh_t, dgates, B, T, xbuf, err);
+    } else {
+        const size_t smem = sizeof(float) * 7 * H;
+        hipLaunchKernelGGL(rec_bwd_generic, dim3(ngroups), dim3(256), smem, stream, dout, gates, cbuf, w_hh_t, dgates, B, T, H);
+    }
+    LAS_LAUNCH_CHECK();
+    return LAS_OK;
+}
+
+}  // namespace las

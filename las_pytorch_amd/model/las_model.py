@@ -1,0 +1,375 @@
+"""Drop-in ``Listener`` / ``Speller`` / ``LAS`` modules backed by liblas_hip.so.
+
+Mirrors the public surface of the reference's ``model/las_model.py`` (constructor signatures, attribute
+names, ``state_dict`` keys, return types — SURVEY.md section 8b) so ``train.py`` / ``solver.batch_iterator``
+style callers work unchanged, while every FLOP of forward and backward runs in the HIP kernels:
+
+  reference                                   | here
+  --------------------------------------------+---------------------------------------------------------
+  pBLSTMLayer.forward  (las_model.py:81-91)   | las_pblstm_fwd / las_pblstm_bwd   (MFMA GEMM + persistent RNN)
+  Listener.forward     (las_model.py:129-134) | stack of the above
+  Speller.forward      (las_model.py:186-238) | las_attn_keys_fwd + las_speller_fwd / las_speller_bwd
+  Attention.forward    (las_model.py:275-297) | fused into the speller step kernels (psi hoisted out of the loop)
+  LAS.forward/serialize(las_model.py:24-63)   | same logic
+
+There is no CPU or eager fallback: CPU tensors raise.
+"""
+from __future__ import annotations
+
+import math
+
+import numpy as np
+import torch
+import torch.nn as nn
+
+from .. import _cabi
+from .._cabi import FLAG_FORCE_GENERIC, FLAG_STASH, SpellerDesc, SpellerGrads, check, lib, ptr, stream_ptr
+
+# set by tests to A/B the generic recurrence kernels against the register-resident ones
+FORCE_GENERIC_RECURRENCE = False
+
+
+def _flags(stash):
+    return (FLAG_STASH if stash else 0) | (FLAG_FORCE_GENERIC if FORCE_GENERIC_RECURRENCE else 0)
+
+
+def _f32c(t):
+    if t.dtype != torch.float32:
+        raise RuntimeError("the LAS HIP path computes in fp32; got " + str(t.dtype))
+    return t.contiguous()
+
+
+class _LSTMParams(nn.Module):
+    """Parameter container with torch.nn.LSTM's names, shapes, registration order and init
+    (U(-1/sqrt(H), 1/sqrt(H)) in registration order), so checkpoints and seeded initialisation match the
+    reference's ``nn.LSTM`` (las_model.py:72-79,164-166).  It owns no forward: the kernels do."""
+
+    def __init__(self, input_size, hidden_size, num_layers=1, bidirectional=False):
+        super().__init__()
+        self.input_size, self.hidden_size, self.num_layers, self.bidirectional = input_size, hidden_size, num_layers, bidirectional
+        dirs = 2 if bidirectional else 1
+        for layer in range(num_layers):
+            for d in range(dirs):
+                in_size = input_size if layer == 0 else hidden_size * dirs
+                sfx = "_reverse" if d == 1 else ""
+                self.register_parameter(f"weight_ih_l{layer}{sfx}", nn.Parameter(torch.empty(4 * hidden_size, in_size)))
+                self.register_parameter(f"weight_hh_l{layer}{sfx}", nn.Parameter(torch.empty(4 * hidden_size, hidden_size)))
+                self.register_parameter(f"bias_ih_l{layer}{sfx}", nn.Parameter(torch.empty(4 * hidden_size)))
+                self.register_parameter(f"bias_hh_l{layer}{sfx}", nn.Parameter(torch.empty(4 * hidden_size)))
+        stdv = 1.0 / math.sqrt(hidden_size)
+        for w in self.parameters():
+            nn.init.uniform_(w, -stdv, stdv)
+
+    def extra_repr(self):
+        return f"{self.input_size}, {self.hidden_size}, num_layers={self.num_layers}, bidirectional={self.bidirectional}"
+
+
+def _require_lstm(rnn_unit):
+    if str(rnn_unit).upper() != "LSTM":
+        raise NotImplementedError(f"rnn_unit={rnn_unit!r}: only LSTM is implemented by the HIP path "
+                                  "(the reference's configs use LSTM only, config/librispeech-config.yaml:20,26)")
+
+
+# --------------------------------------------------------------------------------------------------
+# pBLSTM layer
+# --------------------------------------------------------------------------------------------------
+class _PBLSTMFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, w_ih_f, w_hh_f, b_ih_f, b_hh_f, w_ih_r, w_hh_r, b_ih_r, b_hh_r):
+        x = _f32c(x)
+        B, T_in, D_in = x.shape
+        H = w_hh_f.shape[1]
+        if T_in % 2 != 0:
+            raise RuntimeError(f"pBLSTM needs an even number of frames, got {T_in} (reference las_model.py:86-87)")
+        ws = [_f32c(w) for w in (w_ih_f, w_hh_f, b_ih_f, b_hh_f, w_ih_r, w_hh_r, b_ih_r, b_hh_r)]
+        stash = any(ctx.needs_input_grad)      # grad mode is off inside Function.forward; this is the reliable signal
+        flags = _flags(stash)
+        L = lib()
+        out = torch.empty(B, T_in // 2, 2 * H, device=x.device, dtype=torch.float32)
+        reserve = torch.empty(L.las_pblstm_reserve_floats(B, T_in, H, flags), device=x.device, dtype=torch.float32)
+        check(L.las_pblstm_fwd(ptr(x), B, T_in, D_in, H, *[ptr(w) for w in ws], ptr(out), ptr(reserve),
+                               ptr(_cabi.err_word(x.device)), flags, stream_ptr()))
+        if stash:
+            ctx.save_for_backward(x, ws[0], ws[1], ws[4], ws[5], reserve)
+            ctx.dims = (B, T_in, D_in, H)
+            ctx.need_dx = ctx.needs_input_grad[0]
+            ctx.flags = flags
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        x, w_ih_f, w_hh_f, w_ih_r, w_hh_r, reserve = ctx.saved_tensors
+        B, T_in, D_in, H = ctx.dims
+        dout = _f32c(dout)
+        L = lib()
+        dev = x.device
+        work = torch.empty(L.las_pblstm_bwd_workspace_floats(B, T_in, H), device=dev, dtype=torch.float32)
+        dx = torch.empty_like(x) if ctx.need_dx else None
+        g = [torch.empty_like(w_ih_f), torch.empty_like(w_hh_f), torch.empty(4 * H, device=dev), torch.empty(4 * H, device=dev),
+             torch.empty_like(w_ih_r), torch.empty_like(w_hh_r), torch.empty(4 * H, device=dev), torch.empty(4 * H, device=dev)]
+        check(L.las_pblstm_bwd(ptr(x), ptr(dout), B, T_in, D_in, H, ptr(w_ih_f), ptr(w_hh_f), ptr(w_ih_r), ptr(w_hh_r),
+                               ptr(reserve), ptr(work), ptr(dx), *[ptr(t) for t in g], ptr(_cabi.err_word(dev)),
+                               ctx.flags, stream_ptr()))
+        return (dx, *g)
+
+
+class pBLSTMLayer(nn.Module):
+    """Reference model/las_model.py:66-91: halve the time resolution by concatenating frame pairs, then a
+    bidirectional LSTM.  ``forward`` returns ``(output, hidden)`` like the reference; ``hidden`` (the final
+    (h_n, c_n), discarded by every reference caller, las_model.py:130,132) is returned as ``None``."""
+
+    def __init__(self, input_feature_dim, hidden_dim, rnn_unit="LSTM", dropout_rate=0.0):
+        super().__init__()
+        _require_lstm(rnn_unit)
+        self.rnn_unit = nn.LSTM          # attribute kept for parity with the reference (class object, :69)
+        self.BLSTM = _LSTMParams(input_feature_dim * 2, hidden_dim, 1, bidirectional=True)
+        self.dropout_rate = dropout_rate  # dropout on a 1-layer LSTM is a no-op in torch as well
+
+    def forward(self, input_x):
+        p = self.BLSTM
+        out = _PBLSTMFn.apply(input_x, p.weight_ih_l0, p.weight_hh_l0, p.bias_ih_l0, p.bias_hh_l0,
+                              p.weight_ih_l0_reverse, p.weight_hh_l0_reverse, p.bias_ih_l0_reverse, p.bias_hh_l0_reverse)
+        return out, None
+
+
+class Listener(nn.Module):
+    """Reference model/las_model.py:96-134.  Same constructor; ``use_gpu`` accepted and ignored (as there)."""
+
+    def __init__(self, input_feature_dim, hidden_size, num_layers, rnn_unit, use_gpu, dropout_rate=0.0, **kwargs):
+        super().__init__()
+        self.input_feature_dim = input_feature_dim
+        self.hidden_size = hidden_size
+        self.num_layers = num_layers
+        self.rnn_unit = rnn_unit
+        self.dropout_rate = dropout_rate
+        assert self.num_layers >= 1, "Listener should have at least 1 layer"
+        self.pLSTM_layer0 = pBLSTMLayer(input_feature_dim, hidden_size, rnn_unit=rnn_unit, dropout_rate=dropout_rate)
+        for i in range(1, self.num_layers):
+            setattr(self, "pLSTM_layer" + str(i),
+                    pBLSTMLayer(hidden_size * 2, hidden_size, rnn_unit=rnn_unit, dropout_rate=dropout_rate))
+
+    def forward(self, input_x):
+        output, _ = self.pLSTM_layer0(input_x)
+        for i in range(1, self.num_layers):
+            output, _ = getattr(self, "pLSTM_layer" + str(i))(output)
+        return output
+
+
+# --------------------------------------------------------------------------------------------------
+# Speller
+# --------------------------------------------------------------------------------------------------
+class Attention(nn.Module):
+    """Parameter container + configuration of the reference's Attention (las_model.py:249-273).  Its
+    arithmetic (las_model.py:275-297) is fused into the speller step kernels."""
+
+    def __init__(self, mlp_preprocess_input, preprocess_mlp_dim, activate, mode="dot", input_feature_dim=512, multi_head=1):
+        super().__init__()
+        self.mode = mode.lower()
+        self.mlp_preprocess_input = mlp_preprocess_input
+        self.multi_head = multi_head
+        self.input_feature_dim = input_feature_dim
+        if self.mode != "dot":
+            raise NotImplementedError("only dot attention exists in the reference (las_model.py:315-317)")
+        if multi_head != 1:
+            raise NotImplementedError("multi-head attention (reference las_model.py:298-314) is not implemented by the HIP path yet")
+        self.activate = None
+        if mlp_preprocess_input:
+            self.preprocess_mlp_dim = preprocess_mlp_dim
+            self.phi = nn.Linear(input_feature_dim, preprocess_mlp_dim * multi_head)
+            self.psi = nn.Linear(input_feature_dim, preprocess_mlp_dim)
+            if activate != "None":
+                if activate != "relu":
+                    raise NotImplementedError(f"mlp_activate_in_attention={activate!r}: the HIP path implements 'relu' and 'None'")
+                self.activate = activate
+
+    def forward(self, decoder_state, listener_feature):
+        raise RuntimeError("Attention is fused into the Speller step kernels; call Speller.forward / forward_step")
+
+
+class _SpellerFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, cfg, feat, labels, *params):
+        (U, teacher_forced, decode_mode, L, use_mlp, relu, M, V) = cfg
+        feat = _f32c(feat)
+        B, Tp, D = feat.shape
+        params = [_f32c(p) for p in params]
+        lstm = params[:4 * L]
+        rest = params[4 * L:]
+        Hs = lstm[1].shape[1]
+        dev = feat.device
+        Lh = lib()
+        d = SpellerDesc()
+        d.B, d.Tp, d.D, d.Hs, d.V, d.M, d.L = B, Tp, D, Hs, V, M, L
+        d.use_mlp, d.relu, d.multi_head = int(use_mlp), int(relu), 1
+        for l in range(L):
+            d.w_ih[l], d.w_hh[l], d.b_ih[l], d.b_hh[l] = (ptr(lstm[4 * l + i]) for i in range(4))
+        if use_mlp:
+            w_phi, b_phi, w_psi, b_psi, w_c, b_c = rest
+            d.w_phi, d.b_phi, d.w_psi, d.b_psi = ptr(w_phi), ptr(b_phi), ptr(w_psi), ptr(b_psi)
+        else:
+            w_c, b_c = rest
+        d.w_c, d.b_c = ptr(w_c), ptr(b_c)
+        if D != Hs:
+            raise RuntimeError(f"Speller hidden_size ({Hs}) must equal 2*listener_hidden_size ({D}) (reference las_model.py:198)")
+        stream = stream_ptr()
+        keys = None
+        if use_mlp:
+            keys = torch.empty(B, Tp, M, device=dev, dtype=torch.float32)
+            check(Lh.las_attn_keys_fwd(d, ptr(feat), ptr(keys), stream))
+        u_lab = 0
+        if labels is not None:
+            if labels.dtype != torch.int64:
+                labels = labels.to(torch.int64)
+            labels = labels.contiguous()
+            u_lab = labels.shape[1]
+        logp = torch.empty(U, B, V, device=dev, dtype=torch.float32)
+        att = torch.empty(U, B, Tp, device=dev, dtype=torch.float32)
+        reserve = torch.empty(Lh.las_speller_reserve_floats(d, U), device=dev, dtype=torch.float32)
+        check(Lh.las_speller_fwd(d, ptr(feat), ptr(keys), ptr(labels) if teacher_forced else None, u_lab, U,
+                                 int(teacher_forced), decode_mode, ptr(logp), ptr(att), None, ptr(reserve), FLAG_STASH, stream))
+        ctx.mark_non_differentiable(att)
+        if any(ctx.needs_input_grad):
+            ctx.save_for_backward(feat, keys, logp, att, reserve, *params)
+            ctx.cfg = cfg
+            ctx.dims = (B, Tp, D, Hs)
+        return logp, att
+
+    @staticmethod
+    def backward(ctx, dlogp, _datt):
+        feat, keys, logp, att, reserve, *params = ctx.saved_tensors
+        (U, teacher_forced, decode_mode, L, use_mlp, relu, M, V) = ctx.cfg
+        B, Tp, D, Hs = ctx.dims
+        dev = feat.device
+        dlogp = _f32c(dlogp)
+        lstm = params[:4 * L]
+        rest = params[4 * L:]
+        Lh = lib()
+        d = SpellerDesc()
+        d.B, d.Tp, d.D, d.Hs, d.V, d.M, d.L = B, Tp, D, Hs, V, M, L
+        d.use_mlp, d.relu, d.multi_head = int(use_mlp), int(relu), 1
+        for l in range(L):
+            d.w_ih[l], d.w_hh[l], d.b_ih[l], d.b_hh[l] = (ptr(lstm[4 * l + i]) for i in range(4))
+        if use_mlp:
+            w_phi, b_phi, w_psi, b_psi, w_c, b_c = rest
+            d.w_phi, d.b_phi, d.w_psi, d.b_psi = ptr(w_phi), ptr(b_phi), ptr(w_psi), ptr(b_psi)
+        else:
+            w_c, b_c = rest
+        d.w_c, d.b_c = ptr(w_c), ptr(b_c)
+        grads = [torch.empty_like(p) for p in params]
+        dfeat = torch.empty_like(feat)
+        g = SpellerGrads()
+        for l in range(L):
+            g.dw_ih[l], g.dw_hh[l], g.db_ih[l], g.db_hh[l] = (ptr(grads[4 * l + i]) for i in range(4))
+        rg = grads[4 * L:]
+        if use_mlp:
+            g.dw_phi, g.db_phi, g.dw_psi, g.db_psi, g.dw_c, g.db_c = (ptr(t) for t in rg)
+        else:
+            g.dw_c, g.db_c = (ptr(t) for t in rg)
+        g.dfeat = ptr(dfeat)
+        work = torch.empty(Lh.las_speller_bwd_workspace_floats(d, U), device=dev, dtype=torch.float32)
+        mode0 = int((not teacher_forced) and decode_mode == 0)
+        check(Lh.las_speller_bwd(d, ptr(feat), ptr(keys), ptr(logp), ptr(att), ptr(dlogp), U, mode0, ptr(reserve),
+                                 ptr(work), g, stream_ptr()))
+        return (None, dfeat, None, *grads)
+
+
+class Speller(nn.Module):
+    """Reference model/las_model.py:138-238.  Same constructor, attributes and return types."""
+
+    def __init__(self, vocab_size, hidden_size, rnn_unit, num_layers, max_label_len, use_mlp_in_attention,
+                 mlp_dim_in_attention, mlp_activate_in_attention, listener_hidden_size, multi_head, decode_mode,
+                 use_gpu=True, **kwargs):
+        super().__init__()
+        _require_lstm(rnn_unit)
+        self.rnn_unit = nn.LSTM           # the reference stores the class (las_model.py:156)
+        self.hidden_size = hidden_size
+        self.num_layers = num_layers
+        self.max_label_len = max_label_len
+        self.decode_mode = decode_mode
+        self.use_gpu = use_gpu
+        self.float_type = torch.cuda.FloatTensor if use_gpu else torch.FloatTensor
+        self.label_dim = vocab_size
+        if num_layers > _cabi.MAX_L:
+            raise NotImplementedError(f"at most {_cabi.MAX_L} speller layers")
+        self.rnn_layer = _LSTMParams(vocab_size + hidden_size, hidden_size, num_layers=num_layers)
+        self.attention = Attention(mlp_preprocess_input=use_mlp_in_attention, preprocess_mlp_dim=mlp_dim_in_attention,
+                                   activate=mlp_activate_in_attention, input_feature_dim=2 * listener_hidden_size,
+                                   multi_head=multi_head)
+        self.character_distribution = nn.Linear(hidden_size * 2, vocab_size)
+        self.softmax = nn.LogSoftmax(dim=-1)   # attribute parity only; the log-softmax is fused in the step kernel
+
+    def _params(self):
+        ps = []
+        for l in range(self.num_layers):
+            ps += [getattr(self.rnn_layer, f"weight_ih_l{l}"), getattr(self.rnn_layer, f"weight_hh_l{l}"),
+                   getattr(self.rnn_layer, f"bias_ih_l{l}"), getattr(self.rnn_layer, f"bias_hh_l{l}")]
+        a = self.attention
+        if a.mlp_preprocess_input:
+            ps += [a.phi.weight, a.phi.bias, a.psi.weight, a.psi.bias]
+        ps += [self.character_distribution.weight, self.character_distribution.bias]
+        return ps
+
+    def _run(self, listener_feature, ground_truth, teacher_force, steps):
+        a = self.attention
+        use_mlp = bool(a.mlp_preprocess_input)
+        cfg = (int(steps), bool(teacher_force), int(self.decode_mode), int(self.num_layers), use_mlp,
+               a.activate == "relu", int(a.preprocess_mlp_dim) if use_mlp else 0, int(self.label_dim))
+        if not teacher_force and self.decode_mode not in (0, 1):
+            raise NotImplementedError("decode_mode 2 (Categorical sampling, reference las_model.py:229-234) is not implemented")
+        return _SpellerFn.apply(cfg, listener_feature, ground_truth if teacher_force else None, *self._params())
+
+    def forward(self, listener_feature, ground_truth=None, teacher_force_rate=0.9):
+        if ground_truth is None:
+            teacher_force_rate = 0
+        # exactly one draw from the global NumPy RNG per call, like the reference (las_model.py:189)
+        teacher_force = True if np.random.random_sample() < teacher_force_rate else False
+        if (ground_truth is None) or (not teacher_force):
+            max_step = self.max_label_len
+        else:
+            max_step = ground_truth.size()[1]
+        logp, att = self._run(listener_feature, ground_truth, teacher_force, max_step)
+        raw_pred_seq = list(logp.unbind(0))                 # list[U] of (B,V)   (callers cat them, solver.py:68)
+        attention_record = [[a] for a in att.unbind(0)]     # list[U] of [ (B,T') ]
+        return raw_pred_seq, attention_record
+
+    def forward_step(self, input_word, last_hidden_state, listener_feature):
+        raise NotImplementedError("forward_step with caller-managed state is not exported by the HIP path yet; "
+                                  "use Speller.forward (the only caller in the reference, las_model.py:210)")
+
+
+class LAS(nn.Module):
+    """Reference model/las_model.py:24-63."""
+
+    def __init__(self, listener, speller):
+        super().__init__()
+        self.listener = listener
+        self.speller = speller
+
+    def forward(self, batch_data, batch_label, teacher_force_rate, is_training=True):
+        listener_feature = self.listener(batch_data)
+        if is_training:
+            raw_pred_seq, attention_record = self.speller(listener_feature, ground_truth=batch_label,
+                                                          teacher_force_rate=teacher_force_rate)
+        else:
+            raw_pred_seq, attention_record = self.speller(listener_feature, ground_truth=None, teacher_force_rate=0)
+        return raw_pred_seq, attention_record
+
+    def serialize(self, optimizer, epoch, tr_loss, val_loss):
+        package = {
+            "einput": self.listener.input_feature_dim,
+            "ehidden": self.listener.hidden_size,
+            "elayer": self.listener.num_layers,
+            "edropout": self.listener.dropout_rate,
+            "etype": self.listener.rnn_unit,
+            "dvocab_size": self.speller.label_dim,
+            "dhidden": self.speller.hidden_size,
+            "dlayer": self.speller.num_layers,
+            "etype": self.speller.rnn_unit,     # duplicate key kept: the reference's second assignment wins (:54)
+            "state_dict": self.state_dict(),
+            "optim_dict": optimizer.state_dict(),
+            "epoch": epoch,
+        }
+        if tr_loss is not None:
+            package["tr_loss"] = tr_loss
+            package["val_loss"] = val_loss
+        return package

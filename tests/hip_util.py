@@ -1,0 +1,31 @@
+"""Helpers shared by the GPU parity tests."""
+import numpy as np
+import torch
+
+from las_pytorch_amd import LAS, Listener, Speller
+
+
+def build_las(c, sd_np, *, max_label_len, decode_mode=1, multi_head=1, use_mlp=True, activate="relu", device="cuda"):
+    listener = Listener(input_feature_dim=c["F"], hidden_size=c["H"], num_layers=c["L"], rnn_unit="LSTM", use_gpu=True)
+    speller = Speller(vocab_size=c["V"], hidden_size=c["Hs"], rnn_unit="LSTM", num_layers=c["Ls"],
+                      max_label_len=max_label_len, use_mlp_in_attention=use_mlp, mlp_dim_in_attention=c["M"],
+                      mlp_activate_in_attention=activate, listener_hidden_size=c["H"], multi_head=multi_head,
+                      decode_mode=decode_mode, use_gpu=True)
+    las = LAS(listener, speller)
+    las.load_state_dict({k: torch.from_numpy(np.asarray(v).copy()) for k, v in sd_np.items()}, strict=True)
+    return las.to(device)
+
+
+def assert_close(got, want, name, rtol=1e-3, atol=1e-5):
+    """North-star tolerance: |a-b| <= 1e-3*|b| + 1e-5."""
+    got = np.asarray(got, dtype=np.float64)
+    want = np.asarray(want, dtype=np.float64)
+    assert got.shape == want.shape, f"{name}: shape {got.shape} vs {want.shape}"
+    err = np.abs(got - want)
+    tol = rtol * np.abs(want) + atol
+    bad = err > tol
+    if bad.any() or not np.isfinite(got).all():
+        i = np.unravel_index(np.argmax(err - tol), err.shape)
+        raise AssertionError(f"{name}: {bad.sum()}/{bad.size} elements out of tolerance; worst at {i}: got {got[i]:.8g} "
+                             f"want {want[i]:.8g} (abs err {err[i]:.3g}); max abs err {err.max():.3g}; finite={np.isfinite(got).all()}")
+    return float(err.max())
