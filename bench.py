@@ -1,0 +1,221 @@
+#!/usr/bin/env python3
+"""Headline benchmark of the LAS hot path on MI355X (BASELINE.json: utterances/sec, B=32, T=800, 80-mel, fwd+bwd).
+
+    python bench.py --gpus N --steps K --warmup W [--workload P_train|S_train|P_fwd|S_fwd|P_long] [--batch 32]
+
+A "step" is one pass of the hot path over one synthetic batch per GPU: Listener (pyramidal BiLSTM) + Speller
+(teacher-forced decode, U=128) forward, the reference's label-smoothing loss (solver/solver.py:33-45), backward
+through every HIP kernel, ONE flat gradient all-reduce (N>1), global-norm clip at 1.0 (solver.py:96) and an
+Adam step (lr 2e-4, train.py:82) — i.e. everything solver.batch_iterator does per batch except the host-side
+LER bookkeeping.  Inputs are resident in HBM before the timed region.  One process per GPU; for N>1 launch with
+``python -m torch.distributed.run --nproc-per-node N bench.py --gpus N ...`` (RCCL over xGMI).
+
+Rank 0 prints ONE JSON line with ``roofline`` (dominant kernel: the layer-0 pBLSTM forward recurrence, timed with
+HIP events on the launch stream) and ``cpu_baseline`` (oracle/cpu_baseline.py — the nn.LSTM-module port of the
+reference's CPU path — timed on this box's host cores on a bounded sample).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+import torch.distributed as dist  # noqa: E402
+
+WORKLOADS = {
+    # name: (config, T, U, train)
+    "P_train": ("P", 800, 128, True),     # BASELINE configs[2]/[3]: paper-size, fwd+bwd  (the metric's "fwd+bwd")
+    "S_train": ("S", 800, 128, True),
+    "P_fwd": ("P", 800, 128, False),
+    "S_fwd": ("S", 800, 128, False),       # BASELINE configs[1]
+    "P_long": ("P", 3000, 128, True),      # BASELINE configs[4] (use --batch 8)
+}
+HBM_PEAK_GBS = 8000.0    # MI355X HBM3E spec peak (guides/MI355X_MICROARCH.md)
+
+
+def build_model(cfg_name, U, device):
+    from las_pytorch_amd import LAS, Listener, Speller, synth
+    c = synth.CONFIGS[cfg_name]
+    sd_np = synth.make_state_dict(synth.config_shapes(cfg_name), seed=17)
+    listener = Listener(input_feature_dim=c["F"], hidden_size=c["H"], num_layers=c["L"], rnn_unit="LSTM", use_gpu=True)
+    speller = Speller(vocab_size=c["V"], hidden_size=c["Hs"], rnn_unit="LSTM", num_layers=c["Ls"], max_label_len=U,
+                      use_mlp_in_attention=True, mlp_dim_in_attention=c["M"], mlp_activate_in_attention="relu",
+                      listener_hidden_size=c["H"], multi_head=1, decode_mode=1, use_gpu=True)
+    las = LAS(listener, speller)
+    las.load_state_dict({k: torch.from_numpy(v.copy()) for k, v in sd_np.items()}, strict=True)
+    return las.to(device), c, sd_np
+
+
+def roofline_rec_fwd(c, B, T, iters=20):
+    """Times the dominant kernel (layer-0 forward recurrence, rec_fwd_fast<H>) alone with HIP events on the stream it
+    is launched on, on real pre-activations, and prices it against the HBM roofline with the ALGORITHMIC bytes of the
+    pBLSTM layer it belongs to: B*4*T_l*(D_l+2H) + weights."""
+    from las_pytorch_amd import _cabi, synth
+    L = _cabi.lib()
+    H, F = c["H"], c["F"]
+    T_l, D_l = T // 2, 2 * F
+    g = torch.Generator(device="cpu").manual_seed(1)
+    x = torch.from_numpy(synth.make_inputs(B, T, F, seed=17)).cuda()
+    bound = 1.0 / np.sqrt(H)
+    ws = []
+    for _ in range(2):
+        ws += [(torch.rand(4 * H, D_l, generator=g) * 2 - 1) * bound, (torch.rand(4 * H, H, generator=g) * 2 - 1) * bound,
+               (torch.rand(4 * H, generator=g) * 2 - 1) * bound, (torch.rand(4 * H, generator=g) * 2 - 1) * bound]
+    ws = [w.cuda() for w in ws]
+    flags = _cabi.FLAG_STASH
+    out = torch.empty(B, T_l, 2 * H, device="cuda")
+    err = _cabi.err_word("cuda")
+    n_g = 2 * B * T_l * 4 * H
+    gates = torch.empty(n_g, device="cuda")
+    pre = torch.empty(n_g, device="cuda")
+    # pre-activations: X W_ih^T + b_ih + b_hh per direction via the exported GEMM
+    xv = x.view(B * T_l, D_l)
+    for d in range(2):
+        _cabi.check(L.las_gemm_f32(_cabi.ptr(xv), _cabi.ptr(ws[4 * d]), pre.data_ptr() + d * (n_g // 2) * 4, _cabi.ptr(ws[4 * d + 2]),
+                                   _cabi.ptr(ws[4 * d + 3]), B * T_l, 4 * H, D_l, D_l, D_l, 4 * H, 1, 1, 1, 0, 0, 0, 1, 0, 0,
+                                   _cabi.stream_ptr()))
+    cbuf = torch.empty(2 * B * T_l * H, device="cuda")
+    hprev = torch.empty(2 * B * T_l * H, device="cuda")
+    xbuf = torch.empty(L.las_rec_xbuf_bytes(B, H) // 4 + 4, device="cuda")
+    evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(iters)]
+    for it in range(iters + 3):
+        gates.copy_(pre)
+        if it >= 3:
+            evs[it - 3][0].record()
+        _cabi.check(L.las_pblstm_rec_fwd(_cabi.ptr(gates), _cabi.ptr(ws[1]), _cabi.ptr(ws[5]), _cabi.ptr(out), _cabi.ptr(cbuf),
+                                         _cabi.ptr(hprev), B, T_l, H, _cabi.ptr(xbuf), _cabi.ptr(err), flags, _cabi.stream_ptr()))
+        if it >= 3:
+            evs[it - 3][1].record()
+    torch.cuda.synchronize()
+    _cabi.check_device_errors()
+    ms = float(np.mean([a.elapsed_time(b) for a, b in evs]))
+    w_bytes = 4 * 2 * (4 * H * D_l + 4 * H * H + 8 * H)
+    alg_bytes = B * 4 * T_l * (D_l + 2 * H) + w_bytes
+    achieved = alg_bytes / (ms * 1e-3) / 1e9
+    return dict(bound="hbm", kernel=f"rec_fwd_fast<{H}> layer0 (B={B},T_l={T_l})", achieved=round(achieved, 2), peak=HBM_PEAK_GBS,
+                unit="GB/s", frac=round(achieved / HBM_PEAK_GBS, 5), traffic=None, kernel_ms=round(ms, 4),
+                us_per_step=round(ms * 1e3 / T_l, 3), algorithmic_bytes=alg_bytes)
+
+
+def cpu_baseline(cfg_name, B, T, U, train):
+    from las_pytorch_amd import synth
+    from oracle import cpu_baseline as CB
+    c = synth.CONFIGS[cfg_name]
+    sd_np = synth.make_state_dict(synth.config_shapes(cfg_name), seed=17)
+    x = synth.make_inputs(B, T, c["F"], seed=17)
+    idx, lens = synth.make_labels(B, U, c["V"], seed=17)
+    onehot = synth.onehot_labels(idx, lens, c["V"])
+    r = CB.time_cpu(c, sd_np, x, onehot, train=train, iters=3, warmup=1)
+    return dict(value=round(r["utt_per_s"], 3), unit="utt/s", cores=r["threads"], kind="port",
+                sample=f"{r['iters']} steps after 1 warm-up of the same workload (B={B},T={T},U={U}, {'fwd+loss+bwd+clip+Adam' if train else 'fwd'}) "
+                       f"on the host CPU, torch {torch.__version__} oneDNN LSTM path, {r['ms_per_step']:.0f} ms/step",
+                ms_per_step=round(r["ms_per_step"], 1))
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--workload", default="P_train", choices=sorted(WORKLOADS))
+    ap.add_argument("--batch", type=int, default=32, help="utterances per GPU (weak scaling: fixed per-GPU batch)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-roofline", action="store_true")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("launch with: python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 "
+                             "bench.py --gpus N ...")
+    torch.cuda.set_device(local_rank)
+    device = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        dist.init_process_group("nccl", device_id=device)
+
+    import las_pytorch_amd
+    from las_pytorch_amd import dp, synth
+    from las_pytorch_amd.solver.solver import label_smoothing_loss
+
+    cfg_name, T, U, train = WORKLOADS[args.workload]
+    B = args.batch
+    las, c, _ = build_model(cfg_name, U, device)
+    x = torch.from_numpy(synth.make_inputs(B, T, c["F"], seed=17, rank=rank)).to(device)
+    idx, lens = synth.make_labels(B, U, c["V"], seed=17, rank=rank)
+    lab = torch.from_numpy(synth.onehot_labels(idx, lens, c["V"])).to(device)
+    labf = lab.float()
+
+    if train:
+        reducer = dp.FlatGradAllReducer(las)
+        opt = torch.optim.Adam(las.parameters(), lr=2e-4, fused=True)
+
+        def step():
+            reducer.zero()
+            preds, _ = las(batch_data=x, batch_label=lab, teacher_force_rate=1.0, is_training=True)
+            loss = label_smoothing_loss(torch.stack(preds, 1), labf, 0.1)
+            loss.backward()
+            reducer.allreduce_mean()
+            reducer.clip_(1.0)
+            opt.step()
+            return loss
+    else:
+        def step():
+            with torch.no_grad():
+                preds, _ = las(batch_data=x, batch_label=lab, teacher_force_rate=1.0, is_training=True)
+            return preds[-1]
+
+    for _ in range(args.warmup):
+        step()
+    if train:
+        reducer.check_views()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    last = None
+    for _ in range(args.steps):
+        last = step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], device=device, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    las_pytorch_amd.check_device_errors()
+    final = float(last.float().mean().item())
+    assert np.isfinite(final), "non-finite result in the timed region"
+
+    if rank == 0:
+        ms = dt / args.steps * 1e3
+        res = {
+            "metric": "utterances/sec", "value": round(world * B * args.steps / dt, 2), "unit": "utt/s", "n_gpus": world,
+            "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms, 3), "higher_is_better": True,
+            "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"{args.workload}: Listener {c['H']}x{c['L']} / Speller {c['Hs']}x{c['Ls']}, "
+                                   f"(B={B},T={T},F={c['F']}) log-mel per GPU, teacher-forced U={U}, "
+                                   + ("fwd + label-smoothing loss + bwd + grad all-reduce + clip(1.0) + Adam" if train else "fwd only"),
+                       "per_gpu_batch": B, "global_batch": B * world, "frames": T, "decode_steps": U,
+                       "parallelism": f"dp{world}", "final_loss_or_logp": round(final, 6)},
+        }
+        if not args.no_roofline:
+            res["roofline"] = roofline_rec_fwd(c, B, T)
+        if world == 1 and not args.no_cpu_baseline:
+            res["cpu_baseline"] = cpu_baseline(cfg_name, B, T, U, train)
+        print(json.dumps(res), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -72,3 +72,17 @@ def test_ler_handmade():
     assert O.edit_distance("kitten", "sitting") == 3
     with pytest.raises(ZeroDivisionError):
         O.letter_error_rate(np.array([[1, 0]]), np.array([[1, 0]]))
+
+
+@pytest.mark.parametrize("name", ["S_short", "P_short_sat", "tiny_default"])
+def test_cpu_baseline_matches_reference(name):
+    """oracle/cpu_baseline.py (the nn.LSTM-module port that bench.py times on the host) == the reference."""
+    from oracle import cpu_baseline as CB
+    g, info, sd_np, x, idx, lens, onehot = load_case(name)
+    m = CB.build(info["cfg"], sd_np)
+    with torch.no_grad():
+        preds = m(torch.from_numpy(x), torch.from_numpy(onehot), info["U"])
+    np.testing.assert_allclose(torch.stack(preds).numpy(), g["tf_logp"], atol=ATOL, rtol=0)
+    preds = m(torch.from_numpy(x), torch.from_numpy(onehot), info["U"])
+    loss = CB.label_smoothing_loss(torch.stack(preds, 1), torch.from_numpy(onehot).float(), 0.1)
+    assert abs(loss.item() - g["loss_ls"][0]) < 2e-6 * max(1, abs(g["loss_ls"][0]))
