@@ -41,6 +41,11 @@ struct CellParams {
     int B, Hs;
 };
 
+// K loop of the small-M MFMA kernels: every wave owns runs of UNR consecutive k-blocks and issues all of a run's
+// loads before its MFMAs, so one L2 round trip covers UNR*(1+MT) vector loads instead of one (the step kernels
+// are latency-bound: ~10 iterations of load->wait->MFMA cost 10 L2 latencies when done one block at a time).
+constexpr int CELL_UNR = 4;
+
 template <int VEC, int MT>
 __global__ __launch_bounds__(CELL_THREADS) void lstm_cell_fwd_kernel(CellParams p) {
     __shared__ float red[CELL_NW][MT][16][17];
@@ -58,26 +63,26 @@ __global__ __launch_bounds__(CELL_THREADS) void lstm_cell_fwd_kernel(CellParams 
         const CellSeg sg = p.seg[s];
         const float* __restrict__ wp = sg.w + wrow * sg.ldw;
         const int nkb = (sg.K + KB - 1) / KB;
-#pragma unroll 2
-        for (int kb = wave; kb < nkb; kb += CELL_NW) {
-            const int k = kb * KB + kq * VEC;
-            float bw[VEC];
-            load_vec<VEC>(wp + k, sg.K - k, bw);
-            float ax[MT][VEC];
+        for (int kb0 = wave * CELL_UNR; kb0 < nkb; kb0 += CELL_NW * CELL_UNR) {
+            float bw[CELL_UNR][VEC];
+            float ax[CELL_UNR][MT][VEC];
 #pragma unroll
-            for (int mt = 0; mt < MT; ++mt) {
-                const int b = b0 + mt * 16 + r;
-                if (b < p.B) load_vec<VEC>(sg.x + (long)b * sg.ldx + k, sg.K - k, ax[mt]);
-                else {
+            for (int u = 0; u < CELL_UNR; ++u) {
+                const int k = (kb0 + u) * KB + kq * VEC;
+                load_vec<VEC>(wp + k, sg.K - k, bw[u]);
 #pragma unroll
-                    for (int e = 0; e < VEC; ++e) ax[mt][e] = 0.f;
+                for (int mt = 0; mt < MT; ++mt) {
+                    const int b = b0 + mt * 16 + r;
+                    load_vec<VEC>(sg.x + (long)min(b, p.B - 1) * sg.ldx + k, b < p.B ? sg.K - k : 0, ax[u][mt]);
                 }
             }
 #pragma unroll
-            for (int e = 0; e < VEC; ++e)
+            for (int u = 0; u < CELL_UNR; ++u)
 #pragma unroll
-                for (int mt = 0; mt < MT; ++mt)
-                    acc[mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(ax[mt][e], bw[e], acc[mt], 0, 0, 0);
+                for (int e = 0; e < VEC; ++e)
+#pragma unroll
+                    for (int mt = 0; mt < MT; ++mt)
+                        acc[mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(ax[u][mt][e], bw[u][e], acc[mt], 0, 0, 0);
         }
     }
 #pragma unroll
@@ -132,7 +137,8 @@ int lstm_cell_fwd(const CellSeg* segs, int nseg, const float* b_ih, const float*
     for (int i = 0; i < nseg; ++i) { p.seg[i] = segs[i]; vec = min(vec, seg_vec(segs[i])); }
     p.nseg = nseg; p.b_ih = b_ih; p.b_hh = b_hh; p.c_prev = c_prev; p.h_out = h_out; p.c_out = c_out; p.gates_out = gates_out;
     p.B = B; p.Hs = Hs;
-    const int mt = B <= 16 ? 1 : (B <= 32 ? 2 : 4);
+    // one 16-utterance M-tile per workgroup while that keeps the grid within one wave of the 256 CUs
+    const int mt = (long)(Hs / 4) * cdiv(B, 16) <= 512 ? 1 : (B <= 32 ? 2 : 4);
     dim3 grid(Hs / 4, cdiv(B, 16 * mt)), block(CELL_THREADS);
 #define CELL_LAUNCH(V, M) hipLaunchKernelGGL((lstm_cell_fwd_kernel<V, M>), grid, block, 0, stream, p)
 #define CELL_DISPATCH(V) { if (mt == 1) CELL_LAUNCH(V, 1); else if (mt == 2) CELL_LAUNCH(V, 2); else CELL_LAUNCH(V, 4); }
@@ -196,31 +202,33 @@ __global__ __launch_bounds__(CELL_THREADS) void smallm_gemm_nn_kernel(SmallMPara
     const int N = p.N[set];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int r = lane & 15, kq = lane >> 4;
-    const int n = n0 + r;
-    const bool nok = n < N;
+    const int n = min(n0 + r, N - 1);                // clamped column: out-of-range columns are never stored
 
     f32x4 acc[MT];
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt) acc[mt] = f32x4{0.f, 0.f, 0.f, 0.f};
     const int nkb = (p.K + 15) / 16;
-#pragma unroll 2
-    for (int kb = wave; kb < nkb; kb += CELL_NW) {
-        const int k = kb * 16 + kq * 4;
-        float bw[4];
+    for (int kb0 = wave * CELL_UNR; kb0 < nkb; kb0 += CELL_NW * CELL_UNR) {
+        float bw[CELL_UNR][4];
+        float ax[CELL_UNR][MT][4];
 #pragma unroll
-        for (int e = 0; e < 4; ++e) bw[e] = (nok && k + e < p.K) ? W[(long)(k + e) * ldw + n] : 0.f;
-        float ax[MT][4];
+        for (int u = 0; u < CELL_UNR; ++u) {
+            const int k = (kb0 + u) * 16 + kq * 4;
 #pragma unroll
-        for (int mt = 0; mt < MT; ++mt) {
-            const int b = b0 + mt * 16 + r;
-            if (b < p.B) load_vec<4>(p.a + (long)b * p.lda + k, p.K - k, ax[mt]);
-            else { ax[mt][0] = ax[mt][1] = ax[mt][2] = ax[mt][3] = 0.f; }
+            for (int e = 0; e < 4; ++e) bw[u][e] = (k + e < p.K) ? W[(long)(k + e) * ldw + n] : 0.f;
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) {
+                const int b = b0 + mt * 16 + r;
+                load_vec<4>(p.a + (long)min(b, p.B - 1) * p.lda + k, b < p.B ? p.K - k : 0, ax[u][mt]);
+            }
         }
 #pragma unroll
-        for (int e = 0; e < 4; ++e)
+        for (int u = 0; u < CELL_UNR; ++u)
 #pragma unroll
-            for (int mt = 0; mt < MT; ++mt)
-                acc[mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(ax[mt][e], bw[e], acc[mt], 0, 0, 0);
+            for (int e = 0; e < 4; ++e)
+#pragma unroll
+                for (int mt = 0; mt < MT; ++mt)
+                    acc[mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(ax[u][mt][e], bw[u][e], acc[mt], 0, 0, 0);
     }
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt)
@@ -248,7 +256,7 @@ int smallm_gemm_nn2(const float* a, long lda, int B, int K, const float* w0, lon
     p.w[1] = w1; p.ldw[1] = ldw1; p.out[1] = out1; p.ldo[1] = ldo1; p.N[1] = w1 ? N1 : 0;
     p.tiles0 = cdiv(N0, 16);
     const int tiles = p.tiles0 + (w1 ? cdiv(N1, 16) : 0);
-    const int mt = B <= 16 ? 1 : (B <= 32 ? 2 : 4);
+    const int mt = (long)tiles * cdiv(B, 16) <= 512 ? 1 : (B <= 32 ? 2 : 4);
     dim3 grid(tiles, cdiv(B, 16 * mt)), block(CELL_THREADS);
     if (mt == 1) hipLaunchKernelGGL((smallm_gemm_nn_kernel<1>), grid, block, 0, stream, p);
     else if (mt == 2) hipLaunchKernelGGL((smallm_gemm_nn_kernel<2>), grid, block, 0, stream, p);
@@ -258,9 +266,11 @@ int smallm_gemm_nn2(const float* a, long lda, int B, int K, const float* w0, lon
 }
 
 // ------------------------------------------------------------------------------------------------
-// attention + character distribution, forward.  One workgroup per utterance.
+// attention + character distribution.  One workgroup of 1024 threads (16 wave64) per utterance.
+// Every phase is shaped so that ALL of its global loads are independent and issued together (one L2 round trip
+// per phase): the decode step is a chain of ~6 dependent phases and each costs a memory latency, not bandwidth.
 // ------------------------------------------------------------------------------------------------
-constexpr int ATT_THREADS = 256, ATT_NW = 4, ATT_MAX_TP = 4096, ATT_MAX_V = 128;
+constexpr int ATT_THREADS = 1024, ATT_NW = 16, ATT_MAX_TP = 4096, ATT_MAX_V = 128;
 
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
@@ -272,116 +282,120 @@ __device__ __forceinline__ float wave_max(float v) {
     for (int m = 32; m >= 1; m >>= 1) v = fmaxf(v, __shfl_xor(v, m));
     return v;
 }
-__device__ __forceinline__ float block_sum(float v, float* scratch) {   // scratch: ATT_NW floats
-    v = wave_sum(v);
-    __syncthreads();
-    if ((threadIdx.x & 63) == 0) scratch[threadIdx.x >> 6] = v;
-    __syncthreads();
-    float s = 0.f;
+template <int W>
+__device__ __forceinline__ float group_sum(float v) {       // sum over aligned groups of W lanes
 #pragma unroll
-    for (int w = 0; w < ATT_NW; ++w) s += scratch[w];
-    return s;
+    for (int m = W / 2; m >= 1; m >>= 1) v += __shfl_xor(v, m);
+    return v;
 }
-__device__ __forceinline__ float block_max(float v, float* scratch) {
-    v = wave_max(v);
-    __syncthreads();
-    if ((threadIdx.x & 63) == 0) scratch[threadIdx.x >> 6] = v;
-    __syncthreads();
-    float s = scratch[0];
-#pragma unroll
-    for (int w = 1; w < ATT_NW; ++w) s = fmaxf(s, scratch[w]);
-    return s;
+__device__ __forceinline__ float dot4(const f32x4 a, const f32x4 b, float acc) {
+    acc = fmaf(a[0], b[0], acc); acc = fmaf(a[1], b[1], acc); acc = fmaf(a[2], b[2], acc); acc = fmaf(a[3], b[3], acc);
+    return acc;
 }
+__device__ __forceinline__ f32x4 ld4(const float* p) { return *reinterpret_cast<const f32x4*>(p); }
 
-// dot of a global row (len n) with an LDS vector, lanes of one wave striding by 64 (coalesced), full-wave reduce
-__device__ __forceinline__ float wave_dot(const float* __restrict__ row, const float* vec, int n, int lane) {
-    float acc = 0.f;
-    for (int k = lane; k < n; k += 64) acc = fmaf(row[k], vec[k], acc);
-    return wave_sum(acc);
-}
+// rows x K (row-major, ld) times a vector: out[row] for rows [0,R), G lanes per row, vector read through `vec(k)`.
+// All loads of a pass are independent.  K % 4 == 0.
 
 __global__ __launch_bounds__(ATT_THREADS) void attn_step_fwd_kernel(AttnFwdArgs a) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    // layout: cat[Hs + D] | q[Mq] | e[Tp] | logit[V] | scratch[8]
     const int Mq = a.use_mlp ? a.M : a.Hs;
-    float* cat = smem;                       // [h_top | ctx]
-    float* qs = cat + a.Hs + a.D;
+    const int C4 = a.D / 4;                               // float4 column groups of a feature row
+    const int NTQ = min(ATT_THREADS / C4, 64);            // time slices of the context reduction
+    // layout: q[Mq] | e[Tp] | ctx[D] | logit[V(+pad)] | part[NTQ*D]
+    float* qs = smem;
     float* es = qs + Mq;
-    float* lg = es + a.Tp;
-    float* scratch = lg + a.V;
-    const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    float* ctxs = es + ((a.Tp + 3) & ~3);
+    float* lg = ctxs + a.D;
+    float* part = lg + ((a.V + 3) & ~3);
+    const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63;
+    const float* __restrict__ hb = a.h_top + (long)b * a.Hs;
 
-    for (int k = tid; k < a.Hs; k += ATT_THREADS) cat[k] = a.h_top[(long)b * a.Hs + k];
-    __syncthreads();
-    // 1. query
+    // 1. query q = act(W_phi h + b_phi): 16 lanes per output row
     if (a.use_mlp) {
-        for (int m = wave; m < a.M; m += ATT_NW) {
-            float v = wave_dot(a.w_phi + (long)m * a.Hs, cat, a.Hs, lane);
-            if (lane == 0) {
-                v += a.b_phi[m];
-                if (a.relu) v = fmaxf(v, 0.f);
-                qs[m] = v;
-                if (a.q_out) a.q_out[(long)b * a.M + m] = v;
+        const int ks = tid & 15;
+        for (int m = tid >> 4; m < a.M; m += ATT_THREADS / 16) {
+            const float* wr = a.w_phi + (long)m * a.Hs;
+            float acc = 0.f;
+#pragma unroll 8
+            for (int k = ks * 4; k < a.Hs; k += 64) acc = dot4(ld4(wr + k), ld4(hb + k), acc);
+            acc = group_sum<16>(acc);
+            if (ks == 0) {
+                acc += a.b_phi[m];
+                if (a.relu) acc = fmaxf(acc, 0.f);
+                qs[m] = acc;
+                if (a.q_out) a.q_out[(long)b * a.M + m] = acc;
             }
         }
     } else {
-        for (int k = tid; k < a.Hs; k += ATT_THREADS) qs[k] = cat[k];
+        for (int k = tid; k < a.Hs; k += ATT_THREADS) qs[k] = hb[k];
     }
     __syncthreads();
-    // 2. energies: 16 lanes per frame
+    // 2. energies e[t] = q . keys[t]: 16 lanes per frame
     {
         const float* kb = a.keys + (long)b * a.Tp * Mq;
-        const int sub = lane >> 4, sl = lane & 15;
-        for (int t = wave * 4 + sub; t < a.Tp; t += ATT_NW * 4) {
+        const int ms = tid & 15;
+        for (int t = tid >> 4; t < a.Tp; t += ATT_THREADS / 16) {
             const float* kr = kb + (long)t * Mq;
             float acc = 0.f;
-            for (int m = sl; m < Mq; m += 16) acc = fmaf(qs[m], kr[m], acc);
-#pragma unroll
-            for (int mm = 8; mm >= 1; mm >>= 1) acc += __shfl_xor(acc, mm);
-            if (sl == 0) es[t] = acc;
+#pragma unroll 4
+            for (int m = ms * 4; m < Mq; m += 64) acc = dot4(ld4(kr + m), ld4(qs + m), acc);
+            acc = group_sum<16>(acc);
+            if (ms == 0) es[t] = acc;
         }
     }
     __syncthreads();
-    // 3. softmax over all Tp frames (no mask, reference las_model.py:292)
-    float lmax = -INFINITY;
-    for (int t = tid; t < a.Tp; t += ATT_THREADS) lmax = fmaxf(lmax, es[t]);
-    const float mx = block_max(lmax, scratch);
-    float lsum = 0.f;
-    for (int t = tid; t < a.Tp; t += ATT_THREADS) { const float ex = expf(es[t] - mx); es[t] = ex; lsum += ex; }
-    const float inv = 1.0f / block_sum(lsum, scratch);
-    for (int t = tid; t < a.Tp; t += ATT_THREADS) {
-        const float w = es[t] * inv;
-        es[t] = w;
-        a.att_out[(long)b * a.Tp + t] = w;
-    }
-    __syncthreads();
-    // 4. context
+    // 3. softmax statistics over ALL frames (no mask, reference las_model.py:292), redundantly per wave (no barrier)
+    float mx = -INFINITY;
+    for (int t = lane; t < a.Tp; t += 64) mx = fmaxf(mx, es[t]);
+    mx = wave_max(mx);
+    float sm = 0.f;
+    for (int t = lane; t < a.Tp; t += 64) sm += expf(es[t] - mx);
+    const float inv = 1.0f / wave_sum(sm);
+    for (int t = tid; t < a.Tp; t += ATT_THREADS) a.att_out[(long)b * a.Tp + t] = expf(es[t] - mx) * inv;
+    // 4. context = sum_t a_t feat_t : (column group, time slice) per thread, then LDS reduce over slices
     {
         const float* fb = a.feat + (long)b * a.Tp * a.D;
-        for (int d = tid; d < a.D; d += ATT_THREADS) {
-            float acc0 = 0.f, acc1 = 0.f, acc2 = 0.f, acc3 = 0.f;
-            int t = 0;
-            for (; t + 3 < a.Tp; t += 4) {
-                acc0 = fmaf(es[t], fb[(long)t * a.D + d], acc0);
-                acc1 = fmaf(es[t + 1], fb[(long)(t + 1) * a.D + d], acc1);
-                acc2 = fmaf(es[t + 2], fb[(long)(t + 2) * a.D + d], acc2);
-                acc3 = fmaf(es[t + 3], fb[(long)(t + 3) * a.D + d], acc3);
+        const int c4 = tid % C4, tq = tid / C4;
+        if (tq < NTQ) {
+            f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll 8
+            for (int t = tq; t < a.Tp; t += NTQ) {
+                const float w = expf(es[t] - mx) * inv;
+                const f32x4 f = ld4(fb + (long)t * a.D + c4 * 4);
+                acc[0] = fmaf(w, f[0], acc[0]); acc[1] = fmaf(w, f[1], acc[1]);
+                acc[2] = fmaf(w, f[2], acc[2]); acc[3] = fmaf(w, f[3], acc[3]);
             }
-            for (; t < a.Tp; ++t) acc0 = fmaf(es[t], fb[(long)t * a.D + d], acc0);
-            const float c = (acc0 + acc1) + (acc2 + acc3);
-            cat[a.Hs + d] = c;
-            a.ctx_out[(long)b * a.D + d] = c;
+            *reinterpret_cast<f32x4*>(part + (long)tq * a.D + c4 * 4) = acc;
         }
     }
     __syncthreads();
-    // 5. character distribution
-    for (int v = wave; v < a.V; v += ATT_NW) {
-        const float s = wave_dot(a.w_c + (long)v * (a.Hs + a.D), cat, a.Hs + a.D, lane);
-        if (lane == 0) lg[v] = s + a.b_c[v];
+    for (int d = tid; d < a.D; d += ATT_THREADS) {
+        float acc = 0.f;
+        for (int q = 0; q < NTQ; ++q) acc += part[(long)q * a.D + d];
+        ctxs[d] = acc;
+        a.ctx_out[(long)b * a.D + d] = acc;
+    }
+    __syncthreads();
+    // 5. character distribution logits = W_c [h | ctx] + b_c : 32 lanes per output row
+    {
+        const int ks = tid & 31;
+        const int K2 = a.Hs + a.D;
+        for (int v = tid >> 5; v < a.V; v += ATT_THREADS / 32) {
+            const float* wr = a.w_c + (long)v * K2;
+            float acc = 0.f;
+#pragma unroll 8
+            for (int k = ks * 4; k < K2; k += 128) {
+                const f32x4 x = (k < a.Hs) ? ld4(hb + k) : ld4(ctxs + (k - a.Hs));
+                acc = dot4(ld4(wr + k), x, acc);
+            }
+            acc = group_sum<32>(acc);
+            if (ks == 0) lg[v] = acc + a.b_c[v];
+        }
     }
     __syncthreads();
     // 6. log-softmax + argmax (first maximal index, as torch.topk/argmax)
-    if (wave == 0) {
+    if (tid < 64) {
         float m = -INFINITY;
         for (int v = lane; v < a.V; v += 64) m = fmaxf(m, lg[v]);
         m = wave_max(m);
@@ -405,97 +419,123 @@ __global__ __launch_bounds__(ATT_THREADS) void attn_step_fwd_kernel(AttnFwdArgs 
     }
 }
 
+static int attn_dims_ok(int Hs, int D, int Mq) {
+    return Hs % 4 == 0 && D % 4 == 0 && Mq % 4 == 0 && D / 4 <= ATT_THREADS && Mq / 4 <= ATT_THREADS;
+}
+
 int attn_step_fwd(const AttnFwdArgs& a, hipStream_t stream) {
     LAS_REQUIRE(a.Tp <= ATT_MAX_TP, "attention length above kernel limit (4096 encoder frames)");
     LAS_REQUIRE(a.V <= ATT_MAX_V, "vocab above kernel limit");
     const int Mq = a.use_mlp ? a.M : a.Hs;
     LAS_REQUIRE(a.use_mlp || a.D == a.Hs, "attention without MLP needs decoder dim == feature dim");
-    const size_t smem = sizeof(float) * (size_t)(a.Hs + a.D + Mq + a.Tp + a.V + 8);
+    LAS_REQUIRE(attn_dims_ok(a.Hs, a.D, Mq), "attention dims must be multiples of 4 (and <= 4096)");
+    const int NTQ = min(ATT_THREADS / (a.D / 4), 64);
+    const size_t smem = sizeof(float) * (size_t)(Mq + a.Tp + 4 + a.D + a.V + 4 + (size_t)NTQ * a.D);
     hipLaunchKernelGGL(attn_step_fwd_kernel, dim3(a.B), dim3(ATT_THREADS), smem, stream, a);
     LAS_LAUNCH_CHECK();
     return LAS_OK;
 }
 
 // ------------------------------------------------------------------------------------------------
-// attention + character distribution, backward (one decode step, one workgroup per utterance)
+// backward of one decode step's attention + character distribution (one workgroup per utterance)
 // ------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(ATT_THREADS) void attn_step_bwd_kernel(AttnBwdArgs a) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int Mq = a.use_mlp ? a.M : a.Hs;
-    // layout: dz[V] | dcat[Hs + D] | da[Tp] | dq[Mq] | part[4*Mq] | scratch[8]
+    const int Q4 = Mq / 4;
+    const int NTQ = min(ATT_THREADS / Q4, 64);
+    // layout: dz[V(+pad)] | dctx[D] | de[Tp(+pad)] | dq[Mq] | part[NTQ*Mq]
     float* dz = smem;
-    float* dcat = dz + a.V;
-    float* da = dcat + a.Hs + a.D;
-    float* dq = da + a.Tp;
+    float* dctx = dz + ((a.V + 3) & ~3);
+    float* de = dctx + a.D;
+    float* dq = de + ((a.Tp + 3) & ~3);
     float* part = dq + Mq;
-    float* scratch = part + 4 * Mq;
-    const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63;
 
-    // 1. log-softmax backward: dz = dlogp - exp(logp) * sum(dlogp)
-    float part_sum = 0.f;
-    for (int v = tid; v < a.V; v += ATT_THREADS) {
-        float g = a.dlogp[(long)b * a.V + v];
-        if (a.dy_carry) g += a.dy_carry[(long)b * a.ldy + v];
-        dz[v] = g;                      // stage the total upstream gradient
-        part_sum += g;
-    }
-    const float gsum = block_sum(part_sum, scratch);
-    for (int v = tid; v < a.V; v += ATT_THREADS) {
-        const float z = dz[v] - expf(a.logp[(long)b * a.V + v]) * gsum;
-        dz[v] = z;
-        a.dz_out[(long)b * a.V + v] = z;
+    // 1. log-softmax backward: dz = g - exp(logp) * sum(g), g = dlogp (+ fed-back gradient in decode_mode 0)
+    {
+        float ps = 0.f;
+        for (int v = lane; v < a.V; v += 64) {
+            float g = a.dlogp[(long)b * a.V + v];
+            if (a.dy_carry) g += a.dy_carry[(long)b * a.ldy + v];
+            ps += g;
+        }
+        const float gsum = wave_sum(ps);                  // every wave computes it redundantly (V is tiny)
+        if (tid < 64) {
+            for (int v = lane; v < a.V; v += 64) {
+                float g = a.dlogp[(long)b * a.V + v];
+                if (a.dy_carry) g += a.dy_carry[(long)b * a.ldy + v];
+                const float z = g - expf(a.logp[(long)b * a.V + v]) * gsum;
+                dz[v] = z;
+                a.dz_out[(long)b * a.V + v] = z;
+            }
+        }
     }
     __syncthreads();
-    // 2. [dh_top | dctx] = dz * W_c ; dctx += carry
+    // 2. [dh_top | dctx] = dz W_c ; dctx += carry.  One column per thread, V independent coalesced loads.
     const int K2 = a.Hs + a.D;
-    for (int k = tid; k < K2; k += ATT_THREADS) {
+    float dh_keep[2] = {0.f, 0.f};                        // this thread's dh_top columns (k = tid, tid + 1024)
+    for (int k = tid, it = 0; k < K2; k += ATT_THREADS, ++it) {
         float acc = 0.f;
+#pragma unroll 6
         for (int v = 0; v < a.V; ++v) acc = fmaf(dz[v], a.w_c[(long)v * K2 + k], acc);
         if (k >= a.Hs) {
             if (a.dctx_carry) acc += a.dctx_carry[(long)b * a.ldc + (k - a.Hs)];
             a.dctx_out[(long)b * a.D + (k - a.Hs)] = acc;
+            dctx[k - a.Hs] = acc;
+        } else {
+            if (it < 2) dh_keep[it] = acc;
         }
-        dcat[k] = acc;
     }
     __syncthreads();
     // 3. da[t] = dctx . feat_t   (16 lanes per frame)
     {
         const float* fb = a.feat + (long)b * a.Tp * a.D;
-        const float* dctx = dcat + a.Hs;
-        const int sub = lane >> 4, sl = lane & 15;
-        for (int t = wave * 4 + sub; t < a.Tp; t += ATT_NW * 4) {
+        const int ds = tid & 15;
+        for (int t = tid >> 4; t < a.Tp; t += ATT_THREADS / 16) {
             const float* fr = fb + (long)t * a.D;
             float acc = 0.f;
-            for (int d = sl; d < a.D; d += 16) acc = fmaf(dctx[d], fr[d], acc);
-#pragma unroll
-            for (int mm = 8; mm >= 1; mm >>= 1) acc += __shfl_xor(acc, mm);
-            if (sl == 0) da[t] = acc;
+#pragma unroll 8
+            for (int d = ds * 4; d < a.D; d += 64) acc = dot4(ld4(fr + d), ld4(dctx + d), acc);
+            acc = group_sum<16>(acc);
+            if (ds == 0) de[t] = acc;
         }
     }
     __syncthreads();
-    // 4. softmax backward: de = a * (da - sum_t a_t da_t)
-    float ls = 0.f;
-    for (int t = tid; t < a.Tp; t += ATT_THREADS) ls = fmaf(a.att[(long)b * a.Tp + t], da[t], ls);
-    const float sdot = block_sum(ls, scratch);
-    for (int t = tid; t < a.Tp; t += ATT_THREADS) {
-        const float de = a.att[(long)b * a.Tp + t] * (da[t] - sdot);
-        da[t] = de;
-        a.de_out[(long)b * a.Tp + t] = de;
+    // 4. softmax backward: de = a * (da - sum_t a_t da_t)   (statistic redundantly per wave)
+    {
+        const float* ab = a.att + (long)b * a.Tp;
+        float ls = 0.f;
+        for (int t = lane; t < a.Tp; t += 64) ls = fmaf(ab[t], de[t], ls);
+        const float sdot = wave_sum(ls);
+        __syncthreads();                                  // everyone has read da before it is overwritten
+        for (int t = tid; t < a.Tp; t += ATT_THREADS) {
+            const float v = ab[t] * (de[t] - sdot);
+            de[t] = v;
+            a.de_out[(long)b * a.Tp + t] = v;
+        }
     }
     __syncthreads();
-    // 5. dq[m] = sum_t de[t] * keys[t][m]   (4 time-quarters per m, then LDS reduce)
+    // 5. dq[m] = sum_t de[t] keys[t][m] : (column group, time slice) per thread, LDS reduce over slices
     {
         const float* kb = a.keys + (long)b * a.Tp * Mq;
-        for (int idx = tid; idx < 4 * Mq; idx += ATT_THREADS) {
-            const int m = idx % Mq, tq = idx / Mq;
-            float acc = 0.f;
-            for (int t = tq; t < a.Tp; t += 4) acc = fmaf(da[t], kb[(long)t * Mq + m], acc);
-            part[idx] = acc;
+        const int m4 = tid % Q4, tq = tid / Q4;
+        if (tq < NTQ) {
+            f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll 8
+            for (int t = tq; t < a.Tp; t += NTQ) {
+                const float w = de[t];
+                const f32x4 f = ld4(kb + (long)t * Mq + m4 * 4);
+                acc[0] = fmaf(w, f[0], acc[0]); acc[1] = fmaf(w, f[1], acc[1]);
+                acc[2] = fmaf(w, f[2], acc[2]); acc[3] = fmaf(w, f[3], acc[3]);
+            }
+            *reinterpret_cast<f32x4*>(part + (long)tq * Mq + m4 * 4) = acc;
         }
     }
     __syncthreads();
     for (int m = tid; m < Mq; m += ATT_THREADS) {
-        float v = (part[m] + part[Mq + m]) + (part[2 * Mq + m] + part[3 * Mq + m]);
+        float v = 0.f;
+        for (int q = 0; q < NTQ; ++q) v += part[(long)q * Mq + m];
         if (a.use_mlp) {
             if (a.relu && !(a.q[(long)b * a.M + m] > 0.f)) v = 0.f;
             a.dqpre_out[(long)b * a.M + m] = v;
@@ -503,10 +543,15 @@ __global__ __launch_bounds__(ATT_THREADS) void attn_step_bwd_kernel(AttnBwdArgs 
         dq[m] = v;
     }
     __syncthreads();
-    // 6. dh_top += dqpre * W_phi  (or += dq when there is no MLP)
-    for (int k = tid; k < a.Hs; k += ATT_THREADS) {
-        float acc = dcat[k];
+    // 6. dh_top += dqpre W_phi  (or += dq when there is no MLP)
+    for (int k = tid, it = 0; k < a.Hs; k += ATT_THREADS, ++it) {
+        float acc = 0.f;
+        if (it < 2) acc = dh_keep[it];
+        else {  // columns beyond 2048: recompute the W_c part (never at the reference's sizes)
+            for (int v = 0; v < a.V; ++v) acc = fmaf(dz[v], a.w_c[(long)v * K2 + k], acc);
+        }
         if (a.use_mlp) {
+#pragma unroll 8
             for (int m = 0; m < a.M; ++m) acc = fmaf(dq[m], a.w_phi[(long)m * a.Hs + k], acc);
         } else {
             acc += dq[k];
@@ -518,7 +563,9 @@ __global__ __launch_bounds__(ATT_THREADS) void attn_step_bwd_kernel(AttnBwdArgs 
 int attn_step_bwd(const AttnBwdArgs& a, hipStream_t stream) {
     LAS_REQUIRE(a.Tp <= ATT_MAX_TP && a.V <= ATT_MAX_V, "attention backward limits");
     const int Mq = a.use_mlp ? a.M : a.Hs;
-    const size_t smem = sizeof(float) * (size_t)(a.V + a.Hs + a.D + a.Tp + 5 * Mq + 8);
+    LAS_REQUIRE(attn_dims_ok(a.Hs, a.D, Mq), "attention dims must be multiples of 4 (and <= 4096)");
+    const int NTQ = min(ATT_THREADS / (Mq / 4), 64);
+    const size_t smem = sizeof(float) * (size_t)(a.V + 4 + a.D + a.Tp + 4 + Mq + (size_t)NTQ * Mq);
     hipLaunchKernelGGL(attn_step_bwd_kernel, dim3(a.B), dim3(ATT_THREADS), smem, stream, a);
     LAS_LAUNCH_CHECK();
     return LAS_OK;
