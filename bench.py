@@ -126,6 +126,7 @@ def main():
     ap.add_argument("--batch", type=int, default=32, help="utterances per GPU (weak scaling: fixed per-GPU batch)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--graph", type=int, default=0, help="1: replay fwd+loss+bwd as one captured HIP graph per step")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -171,6 +172,29 @@ def main():
             with torch.no_grad():
                 preds, _ = las(batch_data=x, batch_label=lab, teacher_force_rate=1.0, is_training=True)
             return preds[-1]
+
+    if args.graph and train:
+        # capture fwd + loss + bwd (+ gradient zeroing) once; all-reduce / clip / Adam stay eager after the replay
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            for _ in range(3):
+                step()
+        torch.cuda.current_stream().wait_stream(side)
+        torch.cuda.synchronize()
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph):
+            reducer.zero()
+            preds, _ = las(batch_data=x, batch_label=lab, teacher_force_rate=1.0, is_training=True)
+            static_loss = label_smoothing_loss(torch.stack(preds, 1), labf, 0.1)
+            static_loss.backward()
+
+        def step():  # noqa: F811
+            graph.replay()
+            reducer.allreduce_mean()
+            reducer.clip_(1.0)
+            opt.step()
+            return static_loss
 
     for _ in range(args.warmup):
         step()

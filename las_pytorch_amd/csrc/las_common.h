@@ -46,8 +46,24 @@ inline int fail(int code, const char* fmt, const char* a = "", long x = 0, long 
 
 // ---- accurate transcendental helpers (no fast-math: parity bar is 1e-3 rel through ~400
 //      recurrent steps and identical argmax; SURVEY.md section 7 "Transcendentals parity") ----
+// Two flavours.  LAS_ACCURATE_ACT=1 uses libm-grade expf/tanhf and IEEE division (~0.75 us per recurrent step of
+// dependent latency in the persistent LSTM kernels).  The default uses the hardware transcendental units
+// (v_exp_f32 / v_rcp_f32, ~1 ulp each; absolute error of sigma/tanh <= ~3e-7), which keeps the 1e-3 / identical-argmax
+// parity bar with three orders of magnitude of margin (tests/test_hip_parity.py records the observed error).
+#ifndef LAS_ACCURATE_ACT
+#define LAS_ACCURATE_ACT 0
+#endif
+#if LAS_ACCURATE_ACT
 __device__ __forceinline__ float sigmoidf_acc(float x) { return 1.0f / (1.0f + expf(-x)); }
 __device__ __forceinline__ float tanhf_acc(float x) { return tanhf(x); }
+#else
+__device__ __forceinline__ float sigmoidf_acc(float x) {
+    return __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-1.4426950408889634f * x));
+}
+__device__ __forceinline__ float tanhf_acc(float x) {      // 1 - 2/(e^{2x}+1): saturates correctly at +-inf
+    return 1.0f - 2.0f * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(2.8853900817779268f * x));
+}
+#endif
 
 using f32x4 = __attribute__((ext_vector_type(4))) float;
 using f32x16 = __attribute__((ext_vector_type(16))) float;

@@ -19,6 +19,7 @@
 // A generic fallback (any H, weights streamed from L2) keeps every shape correct.
 #include "las_common.h"
 #include "las_kernels.h"
+#include <stdlib.h>
 
 namespace las {
 
@@ -43,6 +44,51 @@ __device__ __forceinline__ float poll_granule(u64* g, unsigned epoch, unsigned* 
 __device__ __forceinline__ void publish_granule(u64* g, unsigned epoch, float v) {
     __hip_atomic_store(g, ((u64)epoch << 32) | (u64)__float_as_uint(v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
+// Same-XCD publish: a plain 8-byte store stays in the XCD's (shared, coherent) L2, where the group's other CUs read
+// it with an L1-bypassing load at L2 latency; the agent-scope (sc1) form above writes through to memory and drops
+// the line, so every reader pays a fabric round trip.  ONLY valid when every member of the group has verified at
+// run time that the whole group sits on one XCD (same_xcd_group below); otherwise the agent-scope form is used.
+__device__ __forceinline__ void publish_granule_l2(u64* g, unsigned epoch, float v) {
+    *reinterpret_cast<volatile u64*>(g) = ((u64)epoch << 32) | (u64)__float_as_uint(v);
+}
+
+constexpr int XID_SLOTS = 32;        // id granules per group (G <= 32)
+
+// Run-time placement check, placement-independent itself: every member publishes its XCC id with the agent-scope
+// protocol and reads all the others'.  Returns true iff all G members of this group run on the same XCD.
+template <int G>
+__device__ __forceinline__ bool same_xcd_group(u64* idbuf, int member, unsigned* err, int* lds_flag) {
+    if (G == 1) return true;
+    unsigned xcc;
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID, 0, 4)" : "=s"(xcc));
+    const int tid = threadIdx.x;
+    if (tid == 0) {
+        *lds_flag = 1;
+        __hip_atomic_store(idbuf + member, ((u64)0xC0DE0001u << 32) | (u64)xcc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    __syncthreads();
+    if (tid < G) {
+        unsigned spins = 0;
+        u64 x;
+        for (;;) {
+            x = __hip_atomic_load(idbuf + tid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if ((unsigned)(x >> 32) == 0xC0DE0001u) break;
+            if (++spins > SPIN_LIMIT) { atomicExch(err, 0xDEAD0002u); break; }
+            __builtin_amdgcn_s_sleep(2);
+        }
+        if ((unsigned)x != xcc || (unsigned)(x >> 32) != 0xC0DE0001u) *lds_flag = 0;
+    }
+    __syncthreads();
+    return *lds_flag != 0;
+}
+
+// Workgroup barrier that orders LDS traffic only.  __syncthreads() also drains the vector-memory counter, i.e. it
+// waits for this step's global stores (h, stash) to be acknowledged — ~0.3 us per recurrent step for nothing.
+__device__ __forceinline__ void lds_barrier() {
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+}
 
 // group / member decode shared by forward and backward
 template <int G>
@@ -58,59 +104,84 @@ __device__ __forceinline__ void decode_block(int ngroups, int& group, int& membe
     }
 }
 
+// sum over aligned groups of W (<= 16) lanes with DPP row operations: 1 VALU instruction per level, no LDS traffic
+template <int W>
+__device__ __forceinline__ float row_sum(float v) {
+    if (W >= 2) v += __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, v), 0xB1, 0xF, 0xF, true));   // quad_perm [1,0,3,2]
+    if (W >= 4) v += __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, v), 0x4E, 0xF, 0xF, true));   // quad_perm [2,3,0,1]
+    if (W >= 8) v += __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, v), 0x141, 0xF, 0xF, true));  // row_half_mirror
+    if (W >= 16) v += __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, v), 0x140, 0xF, 0xF, true)); // row_mirror
+    return v;
+}
+
 // ------------------------------------------------------------------------------------------------
-// Forward, register-resident W_hh
+// Forward, register-resident W_hh.
+// Per step: (1) every wave does its share of the mat-vec (4 LDS reads, 64 FMAs, DPP reduction) and drops the gate
+// sums of its units into LDS; (2) ONE wave per 64 units applies the cell with all lanes active (coalesced
+// pre-activation loads and h / stash stores) and publishes h, while the other waves already poll the other CUs'
+// granules.  The per-step instruction stream — the real bound of this latency-critical loop — stays ~100
+// instructions per wave instead of every wave running the cell code with 4 of 64 lanes active.
 // ------------------------------------------------------------------------------------------------
-template <int H, bool STASH>
-__global__ __launch_bounds__(REC_THREADS) void rec_fwd_fast(float* __restrict__ gates, const float* __restrict__ w_hh_f,
-                                                            const float* __restrict__ w_hh_r, float* __restrict__ out,
-                                                            float* __restrict__ cbuf, float* __restrict__ hprev, int B,
-                                                            int T, u64* xbuf, unsigned* err) {
-    constexpr int LPU = H / 16;             // lanes cooperating on one hidden unit
-    constexpr int UW = REC_THREADS / LPU;   // hidden units owned by this workgroup
+template <int H, int UW, bool STASH>
+__global__ __launch_bounds__(UW * (H / 16)) void rec_fwd_fast(float* __restrict__ gates, const float* __restrict__ w_hh_f,
+                                                              const float* __restrict__ w_hh_r, float* __restrict__ out,
+                                                              float* __restrict__ cbuf, float* __restrict__ hprev, int B,
+                                                              int T, u64* xbuf, unsigned* err, int dbg) {
+    constexpr int LPU = H / 16;             // lanes cooperating on one hidden unit (16 k-values each)
+    constexpr int NT = UW * LPU;            // threads: UW hidden units owned by this workgroup
     constexpr int G = H / UW;               // workgroups per (utterance, direction)
+    constexpr int PS = (UW + 63) / 64 * 64;   // pollers start on a wave boundary: a wave that both publishes and polls
+                                              // could run its poll branch first and deadlock the group
+    static_assert(G == 1 || NT > PS, "no polling threads");
     __shared__ __attribute__((aligned(16))) float hs[2][H];
+    __shared__ __attribute__((aligned(16))) float gsum[UW][4];
+    __shared__ int xcd_flag;
 
     int group, member;
     decode_block<G>(2 * B, group, member);
+    const bool l2x = !(dbg & 64) && same_xcd_group<G>(xbuf + (long)2 * B * 2 * H + (long)group * XID_SLOTS, member, err, &xcd_flag);
     const int dir = group & 1, b = group >> 1;
     const float* __restrict__ w_hh = dir ? w_hh_r : w_hh_f;
     const int tid = threadIdx.x;
     const int kc = tid % LPU, ul = tid / LPU;
-    const int j = member * UW + ul;
-    const bool owner = (kc == 0);
 
     f32x4 w[4][4];
+    {
+        const int j = member * UW + ul;
 #pragma unroll
-    for (int g = 0; g < 4; ++g)
+        for (int g = 0; g < 4; ++g)
 #pragma unroll
-        for (int i = 0; i < 4; ++i)
-            w[g][i] = *reinterpret_cast<const f32x4*>(w_hh + (long)(g * H + j) * H + i * 4 * LPU + kc * 4);
-
-    float* gbase = gates + ((long)(dir * B + b) * T) * 4 * H + j;
-    float* cb = STASH ? cbuf + ((long)(dir * B + b) * T) * H + j : nullptr;
-    float* hp = STASH ? hprev + ((long)(dir * B + b) * T) * H + j : nullptr;
-    float* ob = out + ((long)b * T) * 2 * H + dir * H + j;
-    u64* xg = xbuf + (long)group * 2 * H;
-
-    for (int i = tid; i < H; i += REC_THREADS) hs[0][i] = 0.f;
+            for (int i = 0; i < 4; ++i)
+                w[g][i] = *reinterpret_cast<const f32x4*>(w_hh + (long)(g * H + j) * H + i * 4 * LPU + kc * 4);
+    }
+    for (int i = tid; i < 2 * H; i += NT) (&hs[0][0])[i] = 0.f;
     __syncthreads();
 
+    // cell role: thread tid < UW owns hidden unit jc
+    const bool cell = tid < UW;
+    const int jc = member * UW + (cell ? tid : 0);
+    const long seq = (long)(dir * B + b) * T;
+    float* gb = gates + seq * 4 * H + jc;
     float c = 0.f;
     float pre[4] = {0.f, 0.f, 0.f, 0.f};
-    if (owner) {
+    if (cell) {
         const int t0 = dir ? T - 1 : 0;
 #pragma unroll
-        for (int g = 0; g < 4; ++g) pre[g] = gbase[(long)t0 * 4 * H + g * H];
+        for (int g = 0; g < 4; ++g) pre[g] = gb[(long)t0 * 4 * H + g * H];
     }
+    // polling role: threads of the waves after the cell waves fetch the H - UW foreign units
+    const bool poller = G > 1 && tid >= PS;
+    u64* xg = xbuf + (long)group * 2 * H;
+
     int cur = 0;
     for (int step = 0; step < T; ++step) {
         const int t = dir ? T - 1 - step : step;
+        const unsigned epoch = (unsigned)step + 1u;
         float nxt[4] = {0.f, 0.f, 0.f, 0.f};
-        if (owner && step + 1 < T) {
+        if (cell && step + 1 < T) {
             const int tn = dir ? t - 1 : t + 1;
 #pragma unroll
-            for (int g = 0; g < 4; ++g) nxt[g] = gbase[(long)tn * 4 * H + g * H];
+            for (int g = 0; g < 4; ++g) nxt[g] = gb[(long)tn * 4 * H + g * H];
         }
         f32x4 hv[4];
 #pragma unroll
@@ -123,34 +194,43 @@ __global__ __launch_bounds__(REC_THREADS) void rec_fwd_fast(float* __restrict__ 
 #pragma unroll
                 for (int g = 0; g < 4; ++g) acc[g] = fmaf(w[g][i][e], hv[i][e], acc[g]);
 #pragma unroll
-        for (int m = 1; m < LPU; m <<= 1)
-#pragma unroll
-            for (int g = 0; g < 4; ++g) acc[g] += __shfl_xor(acc[g], m);
+        for (int g = 0; g < 4; ++g) {
+            acc[g] = row_sum<(LPU < 16 ? LPU : 16)>(acc[g]);
+            if (LPU > 16) acc[g] += __shfl_xor(acc[g], 16);
+        }
+        if (kc == 0) *reinterpret_cast<f32x4*>(&gsum[ul][0]) = f32x4{acc[0], acc[1], acc[2], acc[3]};
+        lds_barrier();
 
-        if (owner) {
-            const float ig = sigmoidf_acc(acc[0] + pre[0]);
-            const float fg = sigmoidf_acc(acc[1] + pre[1]);
-            const float gg = tanhf_acc(acc[2] + pre[2]);
-            const float og = sigmoidf_acc(acc[3] + pre[3]);
+        if (cell) {
+            const f32x4 s4 = *reinterpret_cast<const f32x4*>(&gsum[tid][0]);
+            const float ig = sigmoidf_acc(s4[0] + pre[0]);
+            const float fg = sigmoidf_acc(s4[1] + pre[1]);
+            const float gg = tanhf_acc(s4[2] + pre[2]);
+            const float og = sigmoidf_acc(s4[3] + pre[3]);
             c = fg * c + ig * gg;
             const float h = og * tanhf_acc(c);
-            if (G > 1) publish_granule(xg + (step & 1) * H + j, (unsigned)step + 1u, h);
-            hs[cur ^ 1][j] = h;
-            ob[(long)t * 2 * H] = h;
+            if (G > 1 && !(dbg & 1)) {
+                u64* gp64 = xg + (step & 1) * H + jc;
+                if (l2x) publish_granule_l2(gp64, epoch, h); else publish_granule(gp64, epoch, h);
+            }
+            const float hp = hs[cur][jc];
+            hs[cur ^ 1][jc] = h;
+            out[((long)b * T + t) * 2 * H + dir * H + jc] = h;
             if (STASH) {
-                hp[(long)t * H] = hs[cur][j];
-                cb[(long)t * H] = c;
-                float* gp = gbase + (long)t * 4 * H;
+                hprev[(seq + t) * H + jc] = hp;
+                cbuf[(seq + t) * H + jc] = c;
+                float* gp = gb + (long)t * 4 * H;
                 gp[0] = ig; gp[H] = fg; gp[2 * H] = gg; gp[3 * H] = og;
             }
 #pragma unroll
             for (int g = 0; g < 4; ++g) pre[g] = nxt[g];
+        } else if (poller && !(dbg & 1)) {
+            for (int fidx = tid - PS; fidx < H - UW; fidx += NT - PS) {
+                const int fu = fidx < member * UW ? fidx : fidx + UW;       // foreign hidden unit index
+                hs[cur ^ 1][fu] = poll_granule(xg + (step & 1) * H + fu, epoch, err);
+            }
         }
-        if (G > 1) {
-            if (tid < H && tid / UW != member)
-                hs[cur ^ 1][tid] = poll_granule(xg + (step & 1) * H + tid, (unsigned)step + 1u, err);
-        }
-        __syncthreads();
+        lds_barrier();
         cur ^= 1;
     }
 }
@@ -223,9 +303,11 @@ __global__ __launch_bounds__(REC_THREADS) void rec_bwd_fast(const float* __restr
     constexpr int G = H / UW;
     __shared__ __attribute__((aligned(16))) float dhs[2][H];
     __shared__ __attribute__((aligned(16))) float dgs[4 * H];
+    __shared__ int xcd_flag;
 
     int group, member;
     decode_block<G>(2 * B, group, member);
+    const bool l2x = same_xcd_group<G>(xbuf + (long)2 * B * 2 * H + (long)group * XID_SLOTS, member, err, &xcd_flag);
     const int dir = group & 1, b = group >> 1;
     const int tid = threadIdx.x;
     const int rc = tid % LPU, kl = tid / LPU;
@@ -282,7 +364,7 @@ __global__ __launch_bounds__(REC_THREADS) void rec_bwd_fast(const float* __restr
                 dp[0] = dGi; dp[H] = dGf; dp[2 * H] = dGg; dp[3 * H] = dGo;
             }
         }
-        __syncthreads();
+        lds_barrier();
         float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
 #pragma unroll
         for (int i = 0; i < 16; ++i) {
@@ -291,17 +373,20 @@ __global__ __launch_bounds__(REC_THREADS) void rec_bwd_fast(const float* __restr
             a2 = fmaf(w[i][2], d[2], a2); a3 = fmaf(w[i][3], d[3], a3);
         }
         float acc = (a0 + a1) + (a2 + a3);
-#pragma unroll
-        for (int m = 1; m < LPU; m <<= 1) acc += __shfl_xor(acc, m);
+        acc = row_sum<(LPU < 16 ? LPU : 16)>(acc);
+        if (LPU > 16) acc += __shfl_xor(acc, 16);
         if (rc == 0) {
-            if (G > 1) publish_granule(xg + (step & 1) * H + k, (unsigned)step + 1u, acc);
+            if (G > 1) {
+                u64* gp64 = xg + (step & 1) * H + k;
+                if (l2x) publish_granule_l2(gp64, (unsigned)step + 1u, acc); else publish_granule(gp64, (unsigned)step + 1u, acc);
+            }
             dhs[cur ^ 1][k] = acc;
         }
         if (G > 1) {
             if (tid < H && tid / UW != member)
                 dhs[cur ^ 1][tid] = poll_granule(xg + (step & 1) * H + tid, (unsigned)step + 1u, err);
         }
-        __syncthreads();
+        lds_barrier();
         cur ^= 1;
     }
 }
@@ -372,7 +457,7 @@ int transpose2d(const float* src, float* dst, int rows, int cols, hipStream_t st
     return LAS_OK;
 }
 
-size_t rec_xbuf_bytes(int B, int H) { return (size_t)2 * B * 2 * H * sizeof(u64); }
+size_t rec_xbuf_bytes(int B, int H) { return ((size_t)2 * B * 2 * H + (size_t)2 * B * XID_SLOTS) * sizeof(u64); }
 
 static bool fast_h(int H) { return H == 128 || H == 256 || H == 512; }
 
@@ -383,16 +468,30 @@ int pblstm_rec_fwd(float* gates, const float* w_hh_f, const float* w_hh_r, float
     const int ngroups = 2 * B;
     if (fast_h(H) && !force_generic) {
         LAS_REQUIRE(xbuf && err, "hand-off buffers");
-        const int G = H * H / 16384;
-        if (G > 1) LAS_HIP_CHECK(hipMemsetAsync(xbuf, 0, rec_xbuf_bytes(B, H), stream));
-        dim3 grid(ngroups * G), block(REC_THREADS);
-#define LAUNCH_FWD(HH)                                                                                              \
-    if (stash) hipLaunchKernelGGL((rec_fwd_fast<HH, true>), grid, block, 0, stream, gates, w_hh_f, w_hh_r, out, cbuf, \
-                                  hprev, B, T, xbuf, err);                                                            \
-    else hipLaunchKernelGGL((rec_fwd_fast<HH, false>), grid, block, 0, stream, gates, w_hh_f, w_hh_r, out, cbuf,     \
-                            hprev, B, T, xbuf, err);
-        if (H == 128) { LAUNCH_FWD(128) } else if (H == 256) { LAUNCH_FWD(256) } else { LAUNCH_FWD(512) }
-#undef LAUNCH_FWD
+        static int dbg = getenv("LAS_REC_DBG") ? atoi(getenv("LAS_REC_DBG")) : 0;
+        static int nb_env = getenv("LAS_REC_NB") ? atoi(getenv("LAS_REC_NB")) : 0;
+        static int uw_env = getenv("LAS_REC_UW") ? atoi(getenv("LAS_REC_UW")) : 0;
+        // UW: hidden units per workgroup.  Smaller UW = more CUs per sequence; two half-size workgroups per CU
+        // (UW=32 at H=256) let the hardware overlap one group's hand-off wait with the other's compute.
+        int uw = uw_env > 0 ? uw_env : (H == 128 ? 128 : (H == 256 ? 64 : 32));   // measured best on MI355X at B=32
+        (void)nb_env;
+        LAS_HIP_CHECK(hipMemsetAsync(xbuf, 0, rec_xbuf_bytes(B, H), stream));
+        const int G = H / uw;
+        dim3 grid(2 * B * G), block(uw * (H / 16));
+        bool launched = false;
+#define TRY_FWD(HH, UWV)                                                                                                  \
+    if (!launched && H == HH && uw == UWV) {                                                                             \
+        launched = true;                                                                                                  \
+        if (stash) hipLaunchKernelGGL((rec_fwd_fast<HH, UWV, true>), grid, block, 0, stream, gates, w_hh_f, w_hh_r, out,  \
+                                      cbuf, hprev, B, T, xbuf, err, dbg);                                                 \
+        else hipLaunchKernelGGL((rec_fwd_fast<HH, UWV, false>), grid, block, 0, stream, gates, w_hh_f, w_hh_r, out, cbuf, \
+                                hprev, B, T, xbuf, err, dbg);                                                             \
+    }
+        TRY_FWD(128, 128) TRY_FWD(128, 64) TRY_FWD(128, 32) TRY_FWD(128, 16)
+        TRY_FWD(256, 64) TRY_FWD(256, 32) TRY_FWD(256, 16)
+        TRY_FWD(512, 32) TRY_FWD(512, 16)
+#undef TRY_FWD
+        if (!launched) return fail(LAS_ERR_UNSUPPORTED, "no recurrence kernel for %s H=%ld uw=%ld", "", (long)H, (long)uw);
     } else {
         const size_t smem = sizeof(float) * 3 * H;
         if (stash) hipLaunchKernelGGL((rec_fwd_generic<true>), dim3(ngroups), dim3(256), smem, stream, gates, w_hh_f, w_hh_r,
