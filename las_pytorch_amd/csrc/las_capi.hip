@@ -34,16 +34,19 @@ struct PblstmBwdLayout {
 };
 
 struct SpellerLayout {
-    size_t y_all, ctx_all, h_all, c_all, gates_all, q_all, total;
+    size_t y_all, ctx_all, h_all, c_all, gates_all, q_all, w0p, total;
+    int Vp;                    // label width padded to a multiple of 16: every cell operand is aligned and tail-free
     SpellerLayout(const las_speller_desc* d, int U) {
         size_t o = 0;
         const size_t B = d->B;
-        y_all = o; o += r4((size_t)(U + 1) * B * d->V);
+        Vp = (d->V + 15) & ~15;
+        y_all = o; o += r4((size_t)(U + 1) * B * Vp);
         ctx_all = o; o += r4((size_t)(U + 1) * B * d->D);
         h_all = o; o += r4((size_t)d->L * U * B * d->Hs);
         c_all = o; o += r4((size_t)d->L * U * B * d->Hs);
         gates_all = o; o += r4((size_t)d->L * U * B * 4 * d->Hs);
         q_all = o; if (d->use_mlp) o += r4((size_t)U * B * d->M);
+        w0p = o; o += r4((size_t)4 * d->Hs * (Vp + d->Hs));      // W_ih0 re-laid as [W_y | 0 | W_ctx], ld = Vp + Hs
         total = o;
     }
 };
@@ -222,25 +225,34 @@ int las_speller_fwd(const las_speller_desc* d, const float* feat, const float* k
     float* q_all = d->use_mlp ? reserve + lay.q_all : nullptr;
     const size_t sH = (size_t)B * Hs;       // one (B,Hs) slab
 
-    LAS_TRY(labels_to_y(teacher_forced ? (const long long*)labels_onehot : nullptr, y_all, B, U, V, U_lab, stream));
+    const int Vp = lay.Vp;
+    float* w0p = reserve + lay.w0p;
+    LAS_REQUIRE(Hs % 16 == 0, "speller hidden size must be a multiple of 16");
+    LAS_TRY(labels_to_y(teacher_forced ? (const long long*)labels_onehot : nullptr, y_all, B, U, V, Vp, U_lab, stream));
     LAS_TRY(copy2d(feat, (long)Tp * D, ctx_all, D, B, D, 0, stream));     // ctx_{-1} = feat[:,0,:] (las_model.py:198)
+    // 16-byte aligned, tail-free shadow of W_ih0: columns [0,V) = label part, [V,Vp) = 0, [Vp,Vp+Hs) = context part
+    LAS_HIP_CHECK(hipMemsetAsync(w0p, 0, sizeof(float) * (size_t)4 * Hs * (Vp + Hs), stream));
+    LAS_TRY(copy2d(d->w_ih[0], V + Hs, w0p, Vp + Hs, 4 * Hs, V, 0, stream));
+    LAS_TRY(copy2d(d->w_ih[0] + V, V + Hs, w0p + Vp, Vp + Hs, 4 * Hs, Hs, 0, stream));
 
     for (int s = 0; s < U; ++s) {
         for (int l = 0; l < L; ++l) {
             CellSeg segs[3];
             int n = 0;
             if (l == 0) {
-                segs[n].x = y_all + (size_t)s * B * V; segs[n].ldx = V; segs[n].w = d->w_ih[0]; segs[n].ldw = V + Hs; segs[n].K = V; ++n;
-                segs[n].x = ctx_all + (size_t)s * B * D; segs[n].ldx = D; segs[n].w = d->w_ih[0] + V; segs[n].ldw = V + Hs; segs[n].K = D; ++n;
+                segs[n].x = ctx_all + (size_t)s * B * D; segs[n].ldx = D; segs[n].w = w0p + Vp; segs[n].ldw = Vp + Hs; segs[n].K = D; ++n;
             } else {
                 segs[n].x = h_all + ((size_t)(l - 1) * U + s) * sH; segs[n].ldx = Hs; segs[n].w = d->w_ih[l]; segs[n].ldw = Hs; segs[n].K = Hs; ++n;
             }
             if (s > 0) {
                 segs[n].x = h_all + ((size_t)l * U + s - 1) * sH; segs[n].ldx = Hs; segs[n].w = d->w_hh[l]; segs[n].ldw = Hs; segs[n].K = Hs; ++n;
             }
-            LAS_TRY(lstm_cell_fwd(segs, n, d->b_ih[l], d->b_hh[l], s > 0 ? c_all + ((size_t)l * U + s - 1) * sH : nullptr,
-                                  h_all + ((size_t)l * U + s) * sH, c_all + ((size_t)l * U + s) * sH,
-                                  gates_all + ((size_t)l * U + s) * 4 * sH, B, Hs, stream));
+            if (l == 0) {
+                segs[n].x = y_all + (size_t)s * B * Vp; segs[n].ldx = Vp; segs[n].w = w0p; segs[n].ldw = Vp + Hs; segs[n].K = Vp; ++n;
+            }
+            const size_t o = ((size_t)l * U + s) * sH;
+            LAS_TRY(lstm_cell_fwd(segs, n, d->b_ih[l], d->b_hh[l], s > 0 ? c_all + o - sH : nullptr, h_all + o, c_all + o,
+                                  gates_all + 4 * o, B, Hs, stream));
         }
         AttnFwdArgs a;
         a.h_top = h_all + ((size_t)(L - 1) * U + s) * sH;
@@ -251,7 +263,7 @@ int las_speller_fwd(const las_speller_desc* d, const float* feat, const float* k
         a.ctx_out = ctx_all + (size_t)(s + 1) * B * D;
         a.logp_out = logp + (size_t)s * B * V;
         a.argmax_out = argmax ? argmax + (size_t)s * B : nullptr;
-        a.y_next = teacher_forced ? nullptr : y_all + (size_t)(s + 1) * B * V;
+        a.y_next = teacher_forced ? nullptr : y_all + (size_t)(s + 1) * B * Vp; a.ldy = Vp;
         a.y_mode = decode_mode;
         a.B = B; a.Tp = Tp; a.D = D; a.M = d->M; a.V = V; a.Hs = Hs; a.use_mlp = d->use_mlp; a.relu = d->relu;
         LAS_TRY(attn_step_fwd(a, stream));
@@ -386,7 +398,7 @@ int las_speller_bwd(const las_speller_desc* d, const float* feat, const float* k
         GemmDesc q;
         q.A = dGl; q.lda = 4 * Hs; q.a_kc = false; q.b_kc = false; q.M = 4 * Hs; q.K = UB;
         if (l == 0) {
-            q.B = y_all; q.ldb = V; q.C = g->dw_ih[0]; q.ldc = V + Hs; q.N = V;
+            q.B = y_all; q.ldb = lay.Vp; q.C = g->dw_ih[0]; q.ldc = V + Hs; q.N = V;
             LAS_TRY(gemm_f32(q, stream));
             q.B = ctx_all; q.ldb = D; q.C = g->dw_ih[0] + V; q.N = D;
             LAS_TRY(gemm_f32(q, stream));

@@ -71,7 +71,7 @@ struct AttnFwdArgs {
     float* ctx_out;        // (B,D)
     float* logp_out;       // (B,V)
     int* argmax_out;       // (B) or null
-    float* y_next;         // (B,V) or null: next-step input written on device (free-running decode)
+    float* y_next; long ldy; // (B,ldy) or null: next-step input written on device (free-running decode)
     int y_mode;            // 0: feed log-probs back, 1: feed one-hot argmax
     int B, Tp, D, M, V, Hs;
     int use_mlp, relu;
@@ -104,6 +104,6 @@ int colsum(const float* src, long ld, int rows, int cols, float* dst, int accumu
 int relu_mask_inplace(float* grad, const float* act, long n, hipStream_t stream);                           // grad = act>0 ? grad : 0
 int add_inplace(float* dst, const float* src, long n, hipStream_t stream);
 int copy2d(const float* src, long lds, float* dst, long ldd, int rows, int cols, int accumulate, hipStream_t stream);
-int labels_to_y(const long long* labels, float* y_all, int B, int U, int V, int u_lab, hipStream_t stream);
+int labels_to_y(const long long* labels, float* y_all, int B, int U, int V, int Vp, int u_lab, hipStream_t stream);
 
 }  // namespace las

@@ -66,22 +66,23 @@ int copy2d(const float* src, long lds, float* dst, long ldd, int rows, int cols,
 // Teacher-forcing inputs: y_all[0] = onehot(<sos>=0) (reference las_model.py:193-195),
 // y_all[1+s][b][:] = float(ground_truth[b][s][:]) (las_model.py:216-217; any label rows, incl. all-zero padding)
 __global__ void labels_to_y_kernel(const long long* __restrict__ labels, float* __restrict__ y_all, int B, int U, int V,
-                                   int u_lab) {
+                                   int Vp, int u_lab) {
     const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
-    const long n = (long)(U + 1) * B * V;
+    const long n = (long)(U + 1) * B * Vp;
     if (i >= n) return;
-    const int v = i % V;
-    const int b = (i / V) % B;
-    const int s = i / ((long)V * B);
-    float val;
-    if (s == 0) val = (v == 0) ? 1.f : 0.f;
-    else if (labels && s - 1 < u_lab) val = (float)labels[((long)b * u_lab + (s - 1)) * V + v];
-    else val = 0.f;
+    const int v = i % Vp;                       // rows are padded to Vp (multiple of 4) with zeros
+    const int b = (i / Vp) % B;
+    const int s = i / ((long)Vp * B);
+    float val = 0.f;
+    if (v < V) {
+        if (s == 0) val = (v == 0) ? 1.f : 0.f;
+        else if (labels && s - 1 < u_lab) val = (float)labels[((long)b * u_lab + (s - 1)) * V + v];
+    }
     y_all[i] = val;
 }
-int labels_to_y(const long long* labels, float* y_all, int B, int U, int V, int u_lab, hipStream_t stream) {
-    const long n = (long)(U + 1) * B * V;
-    hipLaunchKernelGGL(labels_to_y_kernel, dim3(cdiv(n, 256)), dim3(256), 0, stream, labels, y_all, B, U, V, u_lab);
+int labels_to_y(const long long* labels, float* y_all, int B, int U, int V, int Vp, int u_lab, hipStream_t stream) {
+    const long n = (long)(U + 1) * B * Vp;
+    hipLaunchKernelGGL(labels_to_y_kernel, dim3(cdiv(n, 256)), dim3(256), 0, stream, labels, y_all, B, U, V, Vp, u_lab);
     LAS_LAUNCH_CHECK();
     return LAS_OK;
 }

@@ -19,7 +19,7 @@
 
 namespace las {
 
-constexpr int CELL_THREADS = 512, CELL_NW = 8;
+constexpr int CELL_THREADS = 512, CELL_NW = 8, CELL_UNR = 4;
 
 template <int VEC>
 __device__ __forceinline__ void load_vec(const float* __restrict__ p, int remain, float (&v)[VEC]) {
@@ -33,6 +33,26 @@ __device__ __forceinline__ void load_vec(const float* __restrict__ p, int remain
     }
 }
 
+__device__ __forceinline__ f32x4 ld4(const float* p) { return *reinterpret_cast<const f32x4*>(p); }
+// Branch-free guarded loads: the load itself is unconditional (from element 0 when !ok) and the result is selected
+// afterwards.  A per-load branch makes hipcc wait for outstanding loads at every join, which serialises a prefetch
+// batch into one memory round trip per load.
+__device__ __forceinline__ f32x4 ld4c(const float* base, long off, bool ok) {
+    const f32x4 v = ld4(base + (ok ? off : 0));
+    const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+    return ok ? v : z;
+}
+__device__ __forceinline__ float ld1c(const float* base, long off, bool ok) {
+    const float v = base[ok ? off : 0];
+    return ok ? v : 0.f;
+}
+__device__ __forceinline__ float dot4(const f32x4 a, const f32x4 b, float acc) {
+    acc = fmaf(a[0], b[0], acc); acc = fmaf(a[1], b[1], acc); acc = fmaf(a[2], b[2], acc); acc = fmaf(a[3], b[3], acc);
+    return acc;
+}
+
+constexpr int CELL_MAXB = 9;     // k-blocks (16 k each) whose loads one wave keeps in flight at once
+
 struct CellParams {
     CellSeg seg[3];
     int nseg;
@@ -41,12 +61,11 @@ struct CellParams {
     int B, Hs;
 };
 
-// K loop of the small-M MFMA kernels: every wave owns runs of UNR consecutive k-blocks and issues all of a run's
-// loads before its MFMAs, so one L2 round trip covers UNR*(1+MT) vector loads instead of one (the step kernels
-// are latency-bound: ~10 iterations of load->wait->MFMA cost 10 L2 latencies when done one block at a time).
-constexpr int CELL_UNR = 4;
-
-template <int VEC, int MT>
+// One LSTM cell step.  The decode step is a chain of dependent kernels and each kernel pays ~2-3 us for every
+// dependent round trip to data another kernel just produced, so ALL global loads of a wave (its share of the
+// concatenated K axis of every input segment, plus the cell's bias / c_prev operands) are issued before the
+// first MFMA: one memory round trip per kernel.
+template <int MT>
 __global__ __launch_bounds__(CELL_THREADS) void lstm_cell_fwd_kernel(CellParams p) {
     __shared__ float red[CELL_NW][MT][16][17];
     const int j0 = blockIdx.x * 4, b0 = blockIdx.y * (16 * MT);
@@ -54,36 +73,59 @@ __global__ __launch_bounds__(CELL_THREADS) void lstm_cell_fwd_kernel(CellParams 
     const int r = lane & 15, kq = lane >> 4;
     const long wrow = (long)(r >> 2) * p.Hs + j0 + (r & 3);      // tile column n = gate*4 + unit
 
+    // operands of the cell non-linearity (threads that will apply it)
+    const int pbl = tid >> 2, pu = tid & 3;
+    const int pb = b0 + pbl, pj = j0 + pu;
+    const bool pw = tid < MT * 64 && pb < p.B;
+    // raw loads only (no arithmetic on them here: a use would force a wait before the main load batch is issued)
+    float cp = 0.f, bi[4], bh[4];
+    {
+        const long po = (long)min(pb, p.B - 1) * p.Hs + pj;
+        cp = p.c_prev ? p.c_prev[po] : 0.f;
+#pragma unroll
+        for (int g = 0; g < 4; ++g) { bi[g] = p.b_ih[g * p.Hs + pj]; bh[g] = p.b_hh[g * p.Hs + pj]; }
+    }
+
+    const int nb0 = (p.seg[0].K + 15) >> 4;
+    const int nb1 = p.nseg > 1 ? (p.seg[1].K + 15) >> 4 : 0;
+    const int nb2 = p.nseg > 2 ? (p.seg[2].K + 15) >> 4 : 0;
+    const int tot = nb0 + nb1 + nb2;
+    const int per = (tot + CELL_NW - 1) / CELL_NW;
+    const int beg = wave * per, end = min(tot, beg + per);
+
     f32x4 acc[MT];
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt) acc[mt] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-    constexpr int KB = 4 * VEC;
-    for (int s = 0; s < p.nseg; ++s) {
-        const CellSeg sg = p.seg[s];
-        const float* __restrict__ wp = sg.w + wrow * sg.ldw;
-        const int nkb = (sg.K + KB - 1) / KB;
-        for (int kb0 = wave * CELL_UNR; kb0 < nkb; kb0 += CELL_NW * CELL_UNR) {
-            float bw[CELL_UNR][VEC];
-            float ax[CELL_UNR][MT][VEC];
+    for (int base = beg; base < end; base += CELL_MAXB) {
+        float bw[CELL_MAXB][4];
+        float ax[CELL_MAXB][MT][4];
 #pragma unroll
-            for (int u = 0; u < CELL_UNR; ++u) {
-                const int k = (kb0 + u) * KB + kq * VEC;
-                load_vec<VEC>(wp + k, sg.K - k, bw[u]);
+        for (int u = 0; u < CELL_MAXB; ++u) {
+            const int blk = base + u;
+            int kb = blk, si = 0;
+            if (kb >= nb0) { kb -= nb0; si = 1; if (kb >= nb1) { kb -= nb1; si = 2; } }
+            const float* __restrict__ sx = p.seg[si].x; const float* __restrict__ sw = p.seg[si].w;
+            const long ldx = p.seg[si].ldx, ldw = p.seg[si].ldw;
+            const bool live = blk < end;                          // wave-uniform
+            const int k = (live ? kb : 0) * 16 + kq * 4;           // every segment K is a multiple of 16 (host-checked)
+            const f32x4 wv = ld4c(sw, wrow * ldw + k, live);
+            bw[u][0] = wv[0]; bw[u][1] = wv[1]; bw[u][2] = wv[2]; bw[u][3] = wv[3];
 #pragma unroll
-                for (int mt = 0; mt < MT; ++mt) {
-                    const int b = b0 + mt * 16 + r;
-                    load_vec<VEC>(sg.x + (long)min(b, p.B - 1) * sg.ldx + k, b < p.B ? sg.K - k : 0, ax[u][mt]);
-                }
+            for (int mt = 0; mt < MT; ++mt) {
+                const int b = b0 + mt * 16 + r;
+                const f32x4 xv = ld4c(sx, (long)b * ldx + k, live && b < p.B);
+                ax[u][mt][0] = xv[0]; ax[u][mt][1] = xv[1]; ax[u][mt][2] = xv[2]; ax[u][mt][3] = xv[3];
             }
-#pragma unroll
-            for (int u = 0; u < CELL_UNR; ++u)
-#pragma unroll
-                for (int e = 0; e < VEC; ++e)
-#pragma unroll
-                    for (int mt = 0; mt < MT; ++mt)
-                        acc[mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(ax[u][mt][e], bw[u][e], acc[mt], 0, 0, 0);
         }
+        __builtin_amdgcn_sched_barrier(0);       // every load of the batch is issued before the first MFMA
+#pragma unroll
+        for (int u = 0; u < CELL_MAXB; ++u)
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+#pragma unroll
+                for (int mt = 0; mt < MT; ++mt)
+                    acc[mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(ax[u][mt][e], bw[u][e], acc[mt], 0, 0, 0);
     }
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt)
@@ -91,60 +133,47 @@ __global__ __launch_bounds__(CELL_THREADS) void lstm_cell_fwd_kernel(CellParams 
         for (int rr = 0; rr < 4; ++rr) red[wave][mt][kq * 4 + rr][r] = acc[mt][rr];
     __syncthreads();
 
-    if (tid < MT * 64) {
-        const int bl = tid >> 2, u = tid & 3;
-        const int b = b0 + bl, j = j0 + u;
-        if (b < p.B) {
-            float g4[4];
+    if (pw) {
+        float g4[4];
 #pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                float s = 0.f;
+        for (int g = 0; g < 4; ++g) {
+            float s = 0.f;
 #pragma unroll
-                for (int w = 0; w < CELL_NW; ++w) s += red[w][bl >> 4][bl & 15][g * 4 + u];
-                const int row = g * p.Hs + j;
-                g4[g] = s + p.b_ih[row] + p.b_hh[row];
-            }
-            const float ig = sigmoidf_acc(g4[0]), fg = sigmoidf_acc(g4[1]), gg = tanhf_acc(g4[2]), og = sigmoidf_acc(g4[3]);
-            const float cp = p.c_prev ? p.c_prev[(long)b * p.Hs + j] : 0.f;
-            const float c = fg * cp + ig * gg;
-            const float h = og * tanhf_acc(c);
-            p.h_out[(long)b * p.Hs + j] = h;
-            p.c_out[(long)b * p.Hs + j] = c;
-            if (p.gates_out) {
-                float* go = p.gates_out + (long)b * 4 * p.Hs + j;
-                go[0] = ig; go[p.Hs] = fg; go[2 * p.Hs] = gg; go[3 * p.Hs] = og;
-            }
+            for (int w = 0; w < CELL_NW; ++w) s += red[w][pbl >> 4][pbl & 15][g * 4 + pu];
+            g4[g] = s + (bi[g] + bh[g]);
+        }
+        const float ig = sigmoidf_acc(g4[0]), fg = sigmoidf_acc(g4[1]), gg = tanhf_acc(g4[2]), og = sigmoidf_acc(g4[3]);
+        const float c = fg * cp + ig * gg;
+        const float h = og * tanhf_acc(c);
+        p.h_out[(long)pb * p.Hs + pj] = h;
+        p.c_out[(long)pb * p.Hs + pj] = c;
+        if (p.gates_out) {
+            float* go = p.gates_out + (long)pb * 4 * p.Hs + pj;
+            go[0] = ig; go[p.Hs] = fg; go[2 * p.Hs] = gg; go[3 * p.Hs] = og;
         }
     }
 }
 
-static int seg_vec(const CellSeg& s) {
-    auto al = [&](int bytes) {
-        return ((uintptr_t)s.x % bytes == 0) && ((uintptr_t)s.w % bytes == 0) && ((s.ldx * 4) % bytes == 0) &&
-               ((s.ldw * 4) % bytes == 0);
-    };
-    if (al(16)) return 4;
-    if (al(8)) return 2;
-    return 1;
-}
+static bool al16(const void* p, long ld) { return ((uintptr_t)p % 16 == 0) && (ld % 4 == 0); }
 
 int lstm_cell_fwd(const CellSeg* segs, int nseg, const float* b_ih, const float* b_hh, const float* c_prev, float* h_out,
                   float* c_out, float* gates_out, int B, int Hs, hipStream_t stream) {
     LAS_REQUIRE(nseg >= 1 && nseg <= 3, "cell segments");
     LAS_REQUIRE(Hs % 4 == 0, "speller hidden size must be a multiple of 4");
     CellParams p;
-    int vec = 4;
-    for (int i = 0; i < nseg; ++i) { p.seg[i] = segs[i]; vec = min(vec, seg_vec(segs[i])); }
+    for (int i = 0; i < nseg; ++i) {
+        p.seg[i] = segs[i];
+        LAS_REQUIRE(al16(segs[i].x, segs[i].ldx) && al16(segs[i].w, segs[i].ldw), "cell operands must be 16-byte aligned");
+        LAS_REQUIRE(segs[i].K % 16 == 0, "cell segment widths must be multiples of 16 (pad the label segment)");
+    }
+    for (int i = nseg; i < 3; ++i) p.seg[i] = segs[0];
     p.nseg = nseg; p.b_ih = b_ih; p.b_hh = b_hh; p.c_prev = c_prev; p.h_out = h_out; p.c_out = c_out; p.gates_out = gates_out;
     p.B = B; p.Hs = Hs;
-    // one 16-utterance M-tile per workgroup while that keeps the grid within one wave of the 256 CUs
-    const int mt = (long)(Hs / 4) * cdiv(B, 16) <= 512 ? 1 : (B <= 32 ? 2 : 4);
+    // one 16-utterance M-tile per workgroup while that keeps the grid within ~two waves of the 256 CUs
+    const int mt = (long)(Hs / 4) * cdiv(B, 16) <= 1024 ? 1 : 2;
     dim3 grid(Hs / 4, cdiv(B, 16 * mt)), block(CELL_THREADS);
-#define CELL_LAUNCH(V, M) hipLaunchKernelGGL((lstm_cell_fwd_kernel<V, M>), grid, block, 0, stream, p)
-#define CELL_DISPATCH(V) { if (mt == 1) CELL_LAUNCH(V, 1); else if (mt == 2) CELL_LAUNCH(V, 2); else CELL_LAUNCH(V, 4); }
-    if (vec == 4) CELL_DISPATCH(4) else if (vec == 2) CELL_DISPATCH(2) else CELL_DISPATCH(1)
-#undef CELL_DISPATCH
-#undef CELL_LAUNCH
+    if (mt == 1) hipLaunchKernelGGL((lstm_cell_fwd_kernel<1>), grid, block, 0, stream, p);
+    else hipLaunchKernelGGL((lstm_cell_fwd_kernel<2>), grid, block, 0, stream, p);
     LAS_LAUNCH_CHECK();
     return LAS_OK;
 }
@@ -288,11 +317,6 @@ __device__ __forceinline__ float group_sum(float v) {       // sum over aligned 
     for (int m = W / 2; m >= 1; m >>= 1) v += __shfl_xor(v, m);
     return v;
 }
-__device__ __forceinline__ float dot4(const f32x4 a, const f32x4 b, float acc) {
-    acc = fmaf(a[0], b[0], acc); acc = fmaf(a[1], b[1], acc); acc = fmaf(a[2], b[2], acc); acc = fmaf(a[3], b[3], acc);
-    return acc;
-}
-__device__ __forceinline__ f32x4 ld4(const float* p) { return *reinterpret_cast<const f32x4*>(p); }
 
 // rows x K (row-major, ld) times a vector: out[row] for rows [0,R), G lanes per row, vector read through `vec(k)`.
 // All loads of a pass are independent.  K % 4 == 0.
@@ -414,7 +438,7 @@ __global__ __launch_bounds__(ATT_THREADS) void attn_step_fwd_kernel(AttnFwdArgs 
         if (a.y_next) {
             // next-step input: log-probs (decode_mode 0, las_model.py:220-221) or one-hot argmax (mode 1, :223-227)
             for (int v = lane; v < a.V; v += 64)
-                a.y_next[(long)b * a.V + v] = (a.y_mode == 0) ? (lg[v] - lse) : (v == best ? 1.0f : 0.f);
+                a.y_next[(long)b * a.ldy + v] = (a.y_mode == 0) ? (lg[v] - lse) : (v == best ? 1.0f : 0.f);
         }
     }
 }
