@@ -172,5 +172,32 @@ def main():
     run_case(refmods, "P_T800", "P", B=2, T=800, U=12, full=False, with_grads=False, sub_t=5, sub_d=16)
 
 
-if __name__ == "__main__":
+
+
+def make_init_golden():
+    """Seeded initialisation of the reference modules (torch.manual_seed(17), train.py:41): per-parameter checksums.
+    The drop-in modules must consume the RNG identically (same registration order and init calls)."""
+    LAS, Listener, Speller, _, _ = import_reference()
+    out = {}
+    for cfg_name in ("S", "P"):
+        c = synth.CONFIGS[cfg_name]
+        torch.manual_seed(17)
+        listener = Listener(input_feature_dim=c["F"], hidden_size=c["H"], num_layers=c["L"], rnn_unit="LSTM", use_gpu=False)
+        speller = Speller(vocab_size=c["V"], hidden_size=c["Hs"], rnn_unit="LSTM", num_layers=c["Ls"], max_label_len=8,
+                          use_mlp_in_attention=True, mlp_dim_in_attention=c["M"], mlp_activate_in_attention="relu",
+                          listener_hidden_size=c["H"], multi_head=1, decode_mode=1, use_gpu=False)
+        las = LAS(listener, speller)
+        out[f"{cfg_name}_sum"] = np.array([p.detach().double().sum().item() for p in las.parameters()])
+        out[f"{cfg_name}_abs"] = np.array([p.detach().double().abs().sum().item() for p in las.parameters()])
+        out[f"{cfg_name}_first"] = np.array([p.detach().reshape(-1)[0].item() for p in las.parameters()])
+    np.savez_compressed(os.path.join(HERE, "init_seed17.npz"), **out)
+    print("init_seed17 written")
+
+
+if __name__ == "__main__" and len(sys.argv) > 1 and sys.argv[1] == "init":
+    make_init_golden()
+
+
+if __name__ == "__main__" and len(sys.argv) == 1:
     main()
+    make_init_golden()

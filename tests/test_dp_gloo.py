@@ -1,0 +1,91 @@
+"""Data-parallel path on CPU: two gloo processes, equal utterance shards, ONE all-reduce of the flat gradient;
+the averaged gradient must equal the single-process gradient of the whole batch (the loss is a batch mean,
+reference solver/solver.py:43).  The model here is the CPU oracle wrapped in nn.Parameters (the HIP modules need
+a GPU); the code under test is las_pytorch_amd.dp."""
+import os
+import socket
+
+import numpy as np
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from las_pytorch_amd import dp, synth
+from oracle import las_oracle as O
+
+
+class OracleLAS(torch.nn.Module):
+    def __init__(self, sd_np):
+        super().__init__()
+        self.keys = list(sd_np.keys())
+        self.params = torch.nn.ParameterList([torch.nn.Parameter(torch.from_numpy(v.copy())) for v in sd_np.values()])
+
+    def forward(self, x, onehot, U):
+        sd = dict(zip(self.keys, self.params))
+        preds, _ = O.las_forward(x, onehot, sd, dict(listener_layers=2, speller_layers=2, max_label_len=U, decode_mode=1),
+                                 teacher_force=True)
+        loss, _ = O.solver_step_loss(preds, onehot, U, 0.1)
+        return loss
+
+
+def _data(B=4, T=16, U=5):
+    c = synth.CONFIGS["tiny"]
+    sd_np = synth.make_state_dict(synth.config_shapes("tiny"), seed=23, scale=0.3)
+    x = torch.from_numpy(synth.make_inputs(B, T, c["F"], seed=23))
+    idx, lens = synth.make_labels(B, U, c["V"], seed=23)
+    onehot = torch.from_numpy(synth.onehot_labels(idx, lens, c["V"]))
+    return sd_np, x, onehot, U
+
+
+def _worker(rank, world, port, out_dir):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    torch.set_num_threads(1)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        sd_np, x, onehot, U = _data()
+        model = OracleLAS(sd_np)
+        red = dp.FlatGradAllReducer(model)
+        sl = dp.shard_batch(x.shape[0], rank, world)
+        for it in range(2):                      # second iteration checks that zero() keeps the views alive
+            red.zero()
+            model(x[sl], onehot[sl], U).backward()
+            red.check_views()
+            red.allreduce_mean()
+        total = red.clip_(1.0)
+        dp.sync_coin()
+        coin = np.random.random_sample()
+        np.savez(os.path.join(out_dir, f"r{rank}.npz"), flat=red.flat.numpy(), total=float(total), coin=coin)
+    finally:
+        dist.destroy_process_group()
+
+
+def test_two_rank_allreduce_equals_full_batch_gradient(tmp_path):
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    mp.start_processes(_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True, start_method="spawn")
+    r0, r1 = np.load(tmp_path / "r0.npz"), np.load(tmp_path / "r1.npz")
+    np.testing.assert_array_equal(r0["flat"], r1["flat"])          # replicas stay identical
+    assert r0["coin"] == r1["coin"]                                  # one shared teacher-forcing coin per step
+    # single process, whole batch
+    sd_np, x, onehot, U = _data()
+    model = OracleLAS(sd_np)
+    red = dp.FlatGradAllReducer(model)
+    model(x, onehot, U).backward()
+    want_total = float(red.clip_(1.0))
+    np.testing.assert_allclose(r0["flat"], red.flat.numpy(), rtol=2e-4, atol=2e-7)
+    assert abs(r0["total"] - want_total) < 1e-5 * want_total
+    # clip semantics == torch.nn.utils.clip_grad_norm_(params, 1) (solver/solver.py:96)
+    model2 = OracleLAS(sd_np)
+    model2(x, onehot, U).backward()
+    t = torch.nn.utils.clip_grad_norm_(model2.parameters(), 1)
+    flat2 = torch.cat([p.grad.reshape(-1) for p in model2.parameters()]).numpy()
+    np.testing.assert_allclose(red.flat.numpy(), flat2, rtol=1e-5, atol=1e-8)
+    assert abs(float(t) - want_total) < 1e-5 * want_total
+
+
+def test_shard_batch():
+    assert dp.shard_batch(32, 3, 8) == slice(12, 16)
+    try:
+        dp.shard_batch(10, 0, 4)
+        raise SystemExit("expected an assertion")
+    except AssertionError:
+        pass
