@@ -99,6 +99,20 @@ def build(c, sd_np):
     return m
 
 
+def best_threads(c, sd_np, x, onehot, *, train, candidates=(8, 16, 32)):
+    """The decode loop is dispatch-bound (small ops): more threads than ~16-32 make it SLOWER (128 threads on the
+    bench host: 16 s/step vs ~2 s).  One probe step per candidate; the fastest is the honest baseline."""
+    best, best_t = None, None
+    ncpu = torch.get_num_threads()
+    for t in candidates:
+        if t > max(ncpu, 1):
+            continue
+        r = time_cpu(c, sd_np, x, onehot, train=train, iters=1, warmup=0, threads=t)
+        if best is None or r["ms_per_step"] < best:
+            best, best_t = r["ms_per_step"], t
+    return best_t or ncpu
+
+
 def time_cpu(c, sd_np, x, onehot, *, train, iters=3, warmup=1, threads=None):
     """Times fwd (or fwd + label-smoothing loss + bwd + clip 1.0 + Adam 2e-4, solver.py:81-97) on the host.
     Returns dict(utt_per_s, ms_per_step, threads, iters)."""
