@@ -307,6 +307,15 @@ int las_speller_bwd(const las_speller_desc* d, const float* feat, const float* k
     const float* keys_eff = d->use_mlp ? keys : feat;
     const float* h_top_all = h_all + (size_t)(L - 1) * U * sH;
 
+    auto cell_pw = [&](int l, int s, bool last) {
+        CellPw pw;
+        const size_t o = ((size_t)l * U + s) * sH;
+        pw.gates = gates_all + 4 * o; pw.c = c_all + o; pw.c_prev = s > 0 ? c_all + o - sH : nullptr;
+        pw.dh_carry = last ? nullptr : dh_carry + (size_t)l * sH;
+        pw.dc_in = last ? nullptr : dc_carry + (size_t)l * sH;
+        pw.dG = dG_all + 4 * o; pw.dc_out = dc_carry + (size_t)l * sH;
+        return pw;
+    };
     for (int s = U - 1; s >= 0; --s) {
         const bool last = (s == U - 1);
         AttnBwdArgs a;
@@ -317,24 +326,19 @@ int las_speller_bwd(const las_speller_desc* d, const float* feat, const float* k
         a.dctx_carry = last ? nullptr : dx0 + V; a.ldc = V + D;
         a.dy_carry = (feedback_mode0 && !last) ? dx0 : nullptr; a.ldy = V + D;
         a.dz_out = dz_all + (size_t)s * B * V; a.dctx_out = dctx_all + (size_t)s * B * D;
-        a.de_out = de_all + (size_t)s * B * Tp; a.dqpre_out = dqpre_all + (size_t)s * B * M; a.dh_top_out = dh_top;
+        a.de_out = de_all + (size_t)s * B * Tp; a.dqpre_out = dqpre_all + (size_t)s * B * M;
+        a.dh_top_out = nullptr;
+        a.pw = cell_pw(L - 1, s, last);                    // top layer's pointwise backward fused into this kernel
         a.B = B; a.Tp = Tp; a.D = D; a.M = M; a.V = V; a.Hs = Hs; a.use_mlp = d->use_mlp; a.relu = d->relu;
         LAS_TRY(attn_step_bwd(a, stream));
-        const float* dh_above = dh_top;
         for (int l = L - 1; l >= 0; --l) {
-            float* dGl = dG_all + ((size_t)l * U + s) * 4 * sH;
-            LAS_TRY(lstm_cell_bwd_pointwise(dh_above, last ? nullptr : dh_carry + (size_t)l * sH,
-                                            last ? nullptr : dc_carry + (size_t)l * sH,
-                                            gates_all + ((size_t)l * U + s) * 4 * sH, c_all + ((size_t)l * U + s) * sH,
-                                            s > 0 ? c_all + ((size_t)l * U + s - 1) * sH : nullptr, dGl,
-                                            dc_carry + (size_t)l * sH, B, Hs, stream));
-            if (l > 0) {
-                LAS_TRY(smallm_gemm_nn2(dGl, 4 * Hs, B, 4 * Hs, d->w_ih[l], Hs, dh_below, Hs, Hs, d->w_hh[l], Hs,
-                                        dh_carry + (size_t)l * sH, Hs, Hs, stream));
-                dh_above = dh_below;
+            const float* dGl = dG_all + ((size_t)l * U + s) * 4 * sH;
+            if (l > 0) {   // dh of layer l-1 feeds that layer's pointwise step in the epilogue; dh_carry[l] for step s-1
+                LAS_TRY(smallm_gemm_nn2(dGl, 4 * Hs, B, 4 * Hs, d->w_ih[l], Hs, nullptr, Hs, Hs, d->w_hh[l], Hs,
+                                        dh_carry + (size_t)l * sH, Hs, Hs, cell_pw(l - 1, s, last), Hs, stream));
             } else {
-                LAS_TRY(smallm_gemm_nn2(dGl, 4 * Hs, B, 4 * Hs, d->w_ih[0], V + Hs, dx0, V + D, V + D, d->w_hh[0], Hs,
-                                        dh_carry, Hs, Hs, stream));
+                LAS_TRY(smallm_gemm_nn2(dGl, 4 * Hs, B, 4 * Hs, d->w_ih[0], V + Hs, dx0, V + D, V + D, d->w_hh[0], Hs, dh_carry,
+                                        Hs, Hs, CellPw(), Hs, stream));
             }
         }
     }

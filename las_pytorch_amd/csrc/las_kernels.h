@@ -56,9 +56,19 @@ int lstm_cell_fwd(const CellSeg* segs, int nseg, const float* b_ih, const float*
 int lstm_cell_bwd_pointwise(const float* dh_a, const float* dh_b, const float* dc_in, const float* gates,
                             const float* c, const float* c_prev, float* dG, float* dc_prev, int B, int Hs,
                             hipStream_t stream);
-// Small-M dense products of the cell backward: out_i(B,N_i) = a(B,K) * W_i(K,N_i), i = 0,1 (W row-major, ld = ldw_i)
+// Operands of one cell's backward pointwise step, fused into the kernel that produces that cell's dh:
+// dh = (produced value) + dh_carry ; stash -> dG (B,4Hs), dc_out (B,Hs).  dc_out may alias dc_in.
+struct CellPw {
+    const float* gates = nullptr;    // (B,4Hs) forward stash of this cell; null = fusion disabled
+    const float* c = nullptr; const float* c_prev = nullptr;     // (B,Hs); c_prev null at step 0
+    const float* dh_carry = nullptr; const float* dc_in = nullptr;  // (B,Hs), null at the last step
+    float* dG = nullptr; float* dc_out = nullptr;
+};
+// Small-M dense products of the cell backward: out_i(B,N_i) = a(B,K) * W_i(K,N_i), i = 0,1 (W row-major, ld = ldw_i).
+// If pw.gates is set, N0 must equal Hs and the epilogue of output 0 applies the NEXT LOWER cell's backward pointwise
+// step to the dh it just produced (out0 may then be null).
 int smallm_gemm_nn2(const float* a, long lda, int B, int K, const float* w0, long ldw0, float* out0, long ldo0, int N0,
-                    const float* w1, long ldw1, float* out1, long ldo1, int N1, hipStream_t stream);
+                    const float* w1, long ldw1, float* out1, long ldo1, int N1, const CellPw& pw, int Hs, hipStream_t stream);
 
 struct AttnFwdArgs {
     const float* h_top;    // (B,Hs) decoder state
@@ -93,7 +103,8 @@ struct AttnBwdArgs {
     float* dctx_out;       // (B,D)   total context gradient (stash for dfeat GEMM)
     float* de_out;         // (B,Tp)  energy gradient (stash for dK GEMM)
     float* dqpre_out;      // (B,M)   pre-activation query gradient (stash for dW_phi)
-    float* dh_top_out;     // (B,Hs)  gradient wrt decoder state from this step's attention + char distribution
+    float* dh_top_out;     // (B,Hs)  gradient wrt decoder state from this step's attention + char distribution (may be null)
+    CellPw pw;             // top LSTM layer's backward pointwise step, fused (pw.gates == null: disabled)
     int B, Tp, D, M, V, Hs;
     int use_mlp, relu;
 };

@@ -178,6 +178,23 @@ int lstm_cell_fwd(const CellSeg* segs, int nseg, const float* b_ih, const float*
     return LAS_OK;
 }
 
+// one (utterance, unit) of the cell backward pointwise step (single step)
+__device__ __forceinline__ void cell_bwd_point(const CellPw& pw, long b, int j, int Hs, float dh) {
+    const long idx = b * Hs + j;
+    if (pw.dh_carry) dh += pw.dh_carry[idx];
+    const float* gp = pw.gates + b * 4 * Hs + j;
+    const float ig = gp[0], fg = gp[Hs], gg = gp[2 * Hs], og = gp[3 * Hs];
+    const float tc = tanhf_acc(pw.c[idx]);
+    const float cp = pw.c_prev ? pw.c_prev[idx] : 0.f;
+    const float dct = (pw.dc_in ? pw.dc_in[idx] : 0.f) + dh * og * (1.f - tc * tc);
+    float* dp = pw.dG + b * 4 * Hs + j;
+    dp[0] = dct * gg * ig * (1.f - ig);
+    dp[Hs] = dct * cp * fg * (1.f - fg);
+    dp[2 * Hs] = dct * ig * (1.f - gg * gg);
+    dp[3 * Hs] = dh * tc * og * (1.f - og);
+    pw.dc_out[idx] = dct * fg;
+}
+
 // ------------------------------------------------------------------------------------------------
 // cell backward: pointwise part
 // ------------------------------------------------------------------------------------------------
@@ -218,6 +235,7 @@ int lstm_cell_bwd_pointwise(const float* dh_a, const float* dh_b, const float* d
 struct SmallMParams {
     const float* a; long lda; int B, K;
     const float* w[2]; long ldw[2]; float* out[2]; long ldo[2]; int N[2]; int tiles0;
+    CellPw pw; int Hs;
 };
 
 template <int MT>
@@ -271,15 +289,19 @@ __global__ __launch_bounds__(CELL_THREADS) void smallm_gemm_nn_kernel(SmallMPara
             float s = 0.f;
 #pragma unroll
             for (int w = 0; w < CELL_NW; ++w) s += red[w][bl >> 4][bl & 15][c];
-            p.out[set][(long)b * p.ldo[set] + n0 + c] = s;
+            if (p.out[set]) p.out[set][(long)b * p.ldo[set] + n0 + c] = s;
+            if (set == 0 && p.pw.gates) cell_bwd_point(p.pw, b, n0 + c, p.Hs, s);   // next lower cell's pointwise step
         }
     }
 }
 
 int smallm_gemm_nn2(const float* a, long lda, int B, int K, const float* w0, long ldw0, float* out0, long ldo0, int N0,
-                    const float* w1, long ldw1, float* out1, long ldo1, int N1, hipStream_t stream) {
+                    const float* w1, long ldw1, float* out1, long ldo1, int N1, const CellPw& pw, int Hs, hipStream_t stream) {
     LAS_REQUIRE(((uintptr_t)a % 16 == 0) && (lda % 4 == 0), "smallm A alignment");
+    LAS_REQUIRE(!pw.gates || N0 == Hs, "fused pointwise needs N0 == Hs");
+    LAS_REQUIRE(out0 || pw.gates, "smallm output 0");
     SmallMParams p;
+    p.pw = pw; p.Hs = Hs;
     p.a = a; p.lda = lda; p.B = B; p.K = K;
     p.w[0] = w0; p.ldw[0] = ldw0; p.out[0] = out0; p.ldo[0] = ldo0; p.N[0] = N0;
     p.w[1] = w1; p.ldw[1] = ldw1; p.out[1] = out1; p.ldo[1] = ldo1; p.N[1] = w1 ? N1 : 0;
@@ -580,7 +602,8 @@ __global__ __launch_bounds__(ATT_THREADS) void attn_step_bwd_kernel(AttnBwdArgs 
         } else {
             acc += dq[k];
         }
-        a.dh_top_out[(long)b * a.Hs + k] = acc;
+        if (a.dh_top_out) a.dh_top_out[(long)b * a.Hs + k] = acc;
+        if (a.pw.gates) cell_bwd_point(a.pw, b, k, a.Hs, acc);      // top LSTM layer's pointwise step, fused
     }
 }
 
