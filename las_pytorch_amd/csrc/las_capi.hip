@@ -52,7 +52,7 @@ struct SpellerLayout {
 };
 
 struct SpellerBwdLayout {
-    size_t dG_all, dz_all, dctx_all, de_all, dqpre_all, dh_top, dh_below, dh_carry, dc_carry, dx0, dK, total;
+    size_t dG_all, dz_all, dctx_all, de_all, dqpre_all, dh_top, dh_below, dh_carry, dc_carry, dx0, dK, dcat_all, total;
     SpellerBwdLayout(const las_speller_desc* d, int U) {
         size_t o = 0;
         const size_t B = d->B;
@@ -68,6 +68,7 @@ struct SpellerBwdLayout {
         dc_carry = o; o += r4((size_t)d->L * B * d->Hs);
         dx0 = o; o += r4(B * (d->V + d->D));
         dK = o; o += r4(B * d->Tp * Mq);
+        dcat_all = o; o += r4((size_t)U * B * (d->Hs + d->D));    // dz W_c for every step (teacher forcing / mode 1)
         total = o;
     }
 };
@@ -261,12 +262,24 @@ int las_speller_fwd(const las_speller_desc* d, const float* feat, const float* k
         a.q_out = q_all ? q_all + (size_t)s * B * d->M : nullptr;
         a.att_out = att + (size_t)s * B * Tp;
         a.ctx_out = ctx_all + (size_t)(s + 1) * B * D;
-        a.logp_out = logp + (size_t)s * B * V;
+        a.logp_out = teacher_forced ? nullptr : logp + (size_t)s * B * V;   // teacher forcing: deferred to one GEMM below
         a.argmax_out = argmax ? argmax + (size_t)s * B : nullptr;
         a.y_next = teacher_forced ? nullptr : y_all + (size_t)(s + 1) * B * Vp; a.ldy = Vp;
         a.y_mode = decode_mode;
         a.B = B; a.Tp = Tp; a.D = D; a.M = d->M; a.V = V; a.Hs = Hs; a.use_mlp = d->use_mlp; a.relu = d->relu;
         LAS_TRY(attn_step_fwd(a, stream));
+    }
+    if (teacher_forced) {
+        // character distribution of all U steps at once (reference las_model.py:181-182, per step there):
+        // logits = [h_top | ctx] W_c^T + b_c as two MFMA GEMMs over U*B rows, then a row-wise log-softmax
+        GemmDesc q;
+        q.A = h_all + (size_t)(L - 1) * U * sH; q.lda = Hs; q.a_kc = true;
+        q.B = d->w_c; q.ldb = Hs + D; q.b_kc = true; q.bias0 = d->b_c;
+        q.C = logp; q.ldc = V; q.M = U * B; q.N = V; q.K = Hs; q.splitk = 1;
+        LAS_TRY(gemm_f32(q, stream));
+        q.A = ctx_all + (size_t)B * D; q.lda = D; q.B = d->w_c + Hs; q.bias0 = nullptr; q.K = D; q.accumulate = true;
+        LAS_TRY(gemm_f32(q, stream));
+        LAS_TRY(log_softmax_rows(logp, (long)U * B, V, stream));
     }
     return LAS_OK;
 }
@@ -307,6 +320,15 @@ int las_speller_bwd(const las_speller_desc* d, const float* feat, const float* k
     const float* keys_eff = d->use_mlp ? keys : feat;
     const float* h_top_all = h_all + (size_t)(L - 1) * U * sH;
 
+    float* dcat_all = workspace + wl.dcat_all;
+    const bool hoist = !feedback_mode0;
+    if (hoist) {
+        LAS_TRY(log_softmax_bwd_rows(dlogp, logp, dz_all, (long)U * B, V, stream));
+        GemmDesc q;      // [dh_top | dctx] contributions of the character distribution for every step
+        q.A = dz_all; q.lda = V; q.a_kc = true; q.B = d->w_c; q.ldb = Hs + D; q.b_kc = false;
+        q.C = dcat_all; q.ldc = Hs + D; q.M = U * B; q.N = Hs + D; q.K = V; q.splitk = 1;
+        LAS_TRY(gemm_f32(q, stream));
+    }
     auto cell_pw = [&](int l, int s, bool last) {
         CellPw pw;
         const size_t o = ((size_t)l * U + s) * sH;
@@ -320,6 +342,7 @@ int las_speller_bwd(const las_speller_desc* d, const float* feat, const float* k
         const bool last = (s == U - 1);
         AttnBwdArgs a;
         a.dlogp = dlogp + (size_t)s * B * V; a.logp = logp + (size_t)s * B * V;
+        a.dcat_pre = hoist ? dcat_all + (size_t)s * B * (Hs + D) : nullptr;
         a.h_top = h_top_all + (size_t)s * sH; a.ctx = ctx_all + (size_t)(s + 1) * B * D;
         a.att = att + (size_t)s * B * Tp; a.q = q_all ? q_all + (size_t)s * B * M : nullptr;
         a.feat = feat; a.keys = keys_eff; a.w_phi = d->w_phi; a.w_c = d->w_c;

@@ -79,7 +79,7 @@ struct AttnFwdArgs {
     float* q_out;          // (B,M)   post-activation query (stash)
     float* att_out;        // (B,Tp)  attention weights
     float* ctx_out;        // (B,D)
-    float* logp_out;       // (B,V)
+    float* logp_out;       // (B,V); null = character distribution deferred to one GEMM after the loop (teacher forcing)
     int* argmax_out;       // (B) or null
     float* y_next; long ldy; // (B,ldy) or null: next-step input written on device (free-running decode)
     int y_mode;            // 0: feed log-probs back, 1: feed one-hot argmax
@@ -90,6 +90,7 @@ int attn_step_fwd(const AttnFwdArgs& a, hipStream_t stream);
 
 struct AttnBwdArgs {
     const float* dlogp;    // (B,V) upstream gradient of this step's log-probs (may include mode-0 feedback grad)
+    const float* dcat_pre; // (B,Hs+D) or null: dz W_c precomputed for all steps by one GEMM (no gradient through y)
     const float* logp;     // (B,V)
     const float* h_top;    // (B,Hs)
     const float* ctx;      // (B,D)
@@ -115,6 +116,8 @@ int colsum(const float* src, long ld, int rows, int cols, float* dst, int accumu
 int relu_mask_inplace(float* grad, const float* act, long n, hipStream_t stream);                           // grad = act>0 ? grad : 0
 int add_inplace(float* dst, const float* src, long n, hipStream_t stream);
 int copy2d(const float* src, long lds, float* dst, long ldd, int rows, int cols, int accumulate, hipStream_t stream);
+int log_softmax_rows(float* x, long rows, int V, hipStream_t stream);
+int log_softmax_bwd_rows(const float* dlogp, const float* logp, float* dz, long rows, int V, hipStream_t stream);
 int labels_to_y(const long long* labels, float* y_all, int B, int U, int V, int Vp, int u_lab, hipStream_t stream);
 
 }  // namespace las

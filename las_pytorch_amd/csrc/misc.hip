@@ -87,4 +87,37 @@ int labels_to_y(const long long* labels, float* y_all, int B, int U, int V, int 
     return LAS_OK;
 }
 
+// In-place log-softmax over rows of width V (teacher-forced decode: the character distribution of ALL steps is one
+// GEMM after the loop instead of a per-step phase; reference las_model.py:182)
+__global__ void log_softmax_rows_kernel(float* __restrict__ x, long rows, int V) {
+    const long r = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= rows) return;
+    float* p = x + r * V;
+    float m = -INFINITY;
+    for (int v = 0; v < V; ++v) m = fmaxf(m, p[v]);
+    float s = 0.f;
+    for (int v = 0; v < V; ++v) s += expf(p[v] - m);
+    const float lse = m + logf(s);
+    for (int v = 0; v < V; ++v) p[v] -= lse;
+}
+int log_softmax_rows(float* x, long rows, int V, hipStream_t stream) {
+    hipLaunchKernelGGL(log_softmax_rows_kernel, dim3(cdiv(rows, 128)), dim3(128), 0, stream, x, rows, V);
+    LAS_LAUNCH_CHECK();
+    return LAS_OK;
+}
+// dz = dlogp - exp(logp) * sum(dlogp) per row
+__global__ void log_softmax_bwd_rows_kernel(const float* __restrict__ dlogp, const float* __restrict__ logp,
+                                            float* __restrict__ dz, long rows, int V) {
+    const long r = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= rows) return;
+    float s = 0.f;
+    for (int v = 0; v < V; ++v) s += dlogp[r * V + v];
+    for (int v = 0; v < V; ++v) dz[r * V + v] = dlogp[r * V + v] - expf(logp[r * V + v]) * s;
+}
+int log_softmax_bwd_rows(const float* dlogp, const float* logp, float* dz, long rows, int V, hipStream_t stream) {
+    hipLaunchKernelGGL(log_softmax_bwd_rows_kernel, dim3(cdiv(rows, 128)), dim3(128), 0, stream, dlogp, logp, dz, rows, V);
+    LAS_LAUNCH_CHECK();
+    return LAS_OK;
+}
+
 }  // namespace las

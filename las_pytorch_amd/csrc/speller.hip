@@ -423,6 +423,7 @@ __global__ __launch_bounds__(ATT_THREADS) void attn_step_fwd_kernel(AttnFwdArgs 
         a.ctx_out[(long)b * a.D + d] = acc;
     }
     __syncthreads();
+    if (a.logp_out == nullptr) return;       // deferred: one GEMM + log-softmax over all steps after the loop
     // 5. character distribution logits = W_c [h | ctx] + b_c : 32 lanes per output row
     {
         const int ks = tid & 31;
@@ -498,6 +499,21 @@ __global__ __launch_bounds__(ATT_THREADS) void attn_step_bwd_kernel(AttnBwdArgs 
     float* part = dq + Mq;
     const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63;
 
+    const int K2 = a.Hs + a.D;
+    float dh_keep[2] = {0.f, 0.f};                        // this thread's dh_top columns (k = tid, tid + 1024)
+    if (a.dcat_pre) {
+        // [dh_top | dctx] = dz W_c was computed for every step by one GEMM before the loop
+        for (int k = tid, it = 0; k < K2; k += ATT_THREADS, ++it) {
+            float acc = a.dcat_pre[(long)b * K2 + k];
+            if (k >= a.Hs) {
+                if (a.dctx_carry) acc += a.dctx_carry[(long)b * a.ldc + (k - a.Hs)];
+                a.dctx_out[(long)b * a.D + (k - a.Hs)] = acc;
+                dctx[k - a.Hs] = acc;
+            } else if (it < 2) {
+                dh_keep[it] = acc;
+            }
+        }
+    } else {
     // 1. log-softmax backward: dz = g - exp(logp) * sum(g), g = dlogp (+ fed-back gradient in decode_mode 0)
     {
         float ps = 0.f;
@@ -519,8 +535,6 @@ __global__ __launch_bounds__(ATT_THREADS) void attn_step_bwd_kernel(AttnBwdArgs 
     }
     __syncthreads();
     // 2. [dh_top | dctx] = dz W_c ; dctx += carry.  One column per thread, V independent coalesced loads.
-    const int K2 = a.Hs + a.D;
-    float dh_keep[2] = {0.f, 0.f};                        // this thread's dh_top columns (k = tid, tid + 1024)
     for (int k = tid, it = 0; k < K2; k += ATT_THREADS, ++it) {
         float acc = 0.f;
 #pragma unroll 6
@@ -529,9 +543,10 @@ __global__ __launch_bounds__(ATT_THREADS) void attn_step_bwd_kernel(AttnBwdArgs 
             if (a.dctx_carry) acc += a.dctx_carry[(long)b * a.ldc + (k - a.Hs)];
             a.dctx_out[(long)b * a.D + (k - a.Hs)] = acc;
             dctx[k - a.Hs] = acc;
-        } else {
-            if (it < 2) dh_keep[it] = acc;
+        } else if (it < 2) {
+            dh_keep[it] = acc;
         }
+    }
     }
     __syncthreads();
     // 3. da[t] = dctx . feat_t   (16 lanes per frame)
