@@ -16,7 +16,12 @@
 
 namespace las {
 
-constexpr int BM = 128, BN = 128, BK = 16, PAD = 4, GEMM_THREADS = 256;
+#ifndef LAS_GEMM_BK
+#define LAS_GEMM_BK 16
+#endif
+constexpr int BM = 128, BN = 128, BK = LAS_GEMM_BK, PAD = 4, GEMM_THREADS = 256;
+constexpr int NLD = BM * BK / 4 / GEMM_THREADS;     // float4 loads per thread per operand tile
+constexpr int KQ = BK / 4;                           // float4 per K-contiguous row segment
 
 struct GemmParams {
     const float* A; const float* B; float* C; const float* bias0; const float* bias1;
@@ -26,21 +31,39 @@ struct GemmParams {
     int splitk, kper;
     int accumulate, relu, atomic;
     int a_vec, b_vec;   // 16-byte vector loads legal for this operand
+    int gx, swz;
 };
 
-// Load one BK x BM(BN) operand tile into registers (2 float4 per thread).
+// Load one BK x BM(BN) operand tile into registers (NLD float4 per thread).
 // KC = true : element(r, k) at P[r*ld + k]   (row index r is the M or N index)
 // KC = false: element(r, k) at P[k*ld + r]
 template <bool KC>
 __device__ __forceinline__ void load_tile(const float* __restrict__ P, long ld, int R, int K, int r0, int k0, int kend,
-                                          bool vec_ok, f32x4 (&reg)[2]) {
+                                          bool vec_ok, f32x4 (&reg)[NLD]) {
     const int t = threadIdx.x;
+    // Interior tiles (the common case) take a branch-free path: per-element guards compile to a branch + wait per
+    // load, which serialises the tile fetch into one exposed memory latency per load.
+    const bool interior = vec_ok && (r0 + BM <= R) && (k0 + BK <= kend);      // workgroup-uniform
+    if (interior) {
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
+        for (int i = 0; i < NLD; ++i) {
+            const int idx = t + i * GEMM_THREADS;
+            if (KC) {
+                const int row = idx / KQ, kq = (idx % KQ) * 4;
+                reg[i] = *reinterpret_cast<const f32x4*>(P + (long)(r0 + row) * ld + k0 + kq);
+            } else {
+                const int krow = idx >> 5, rq = (idx & 31) * 4;
+                reg[i] = *reinterpret_cast<const f32x4*>(P + (long)(k0 + krow) * ld + r0 + rq);
+            }
+        }
+        return;
+    }
+#pragma unroll
+    for (int i = 0; i < NLD; ++i) {
         const int idx = t + i * GEMM_THREADS;
         f32x4 v = {0.f, 0.f, 0.f, 0.f};
         if (KC) {
-            const int row = idx >> 2, kq = (idx & 3) * 4;
+            const int row = idx / KQ, kq = (idx % KQ) * 4;
             const int r = r0 + row, k = k0 + kq;
             if (r < R) {
                 const float* p = P + (long)r * ld + k;
@@ -69,13 +92,13 @@ __device__ __forceinline__ void load_tile(const float* __restrict__ P, long ld, 
 }
 
 template <bool KC>
-__device__ __forceinline__ void store_tile(float (*S)[BM + PAD], const f32x4 (&reg)[2]) {
+__device__ __forceinline__ void store_tile(float (*S)[BM + PAD], const f32x4 (&reg)[NLD]) {
     const int t = threadIdx.x;
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
+    for (int i = 0; i < NLD; ++i) {
         const int idx = t + i * GEMM_THREADS;
         if (KC) {
-            const int row = idx >> 2, kq = (idx & 3) * 4;
+            const int row = idx / KQ, kq = (idx % KQ) * 4;
 #pragma unroll
             for (int j = 0; j < 4; ++j) S[kq + j][row] = reg[i][j];
         } else {
@@ -94,7 +117,11 @@ __global__ __launch_bounds__(GEMM_THREADS) void gemm_f32_kernel(GemmParams p) {
     const float* A = p.A + (long)bz * p.sA;
     const float* B = p.B + (long)bz * p.sB;
     float* C = p.C + (long)bz * p.sC;
-    const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
+    // XCD-aware tile order: workgroups are dispatched round-robin over the 8 XCDs (private L2 each); remap so that
+    // each XCD works on a contiguous run of tiles (the N-tiles of one M-tile share the A panel in that XCD's L2).
+    int tile = blockIdx.x;
+    if (p.swz) tile = (tile & 7) * (gridDim.x >> 3) + (tile >> 3);
+    const int m0 = (tile / p.gx) * BM, n0 = (tile % p.gx) * BN;
     const int kbeg = kz * p.kper;
     const int kend = min(p.K, kbeg + p.kper);
     const int ntiles = (kend - kbeg + BK - 1) / BK;
@@ -111,7 +138,7 @@ __global__ __launch_bounds__(GEMM_THREADS) void gemm_f32_kernel(GemmParams p) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-    f32x4 ra[2], rb[2];
+    f32x4 ra[NLD], rb[NLD];
     if (ntiles > 0) {
         load_tile<A_KC>(A, p.lda, p.M, p.K, m0, kbeg, kend, p.a_vec, ra);
         load_tile<B_KC>(B, p.ldb, p.N, p.K, n0, kbeg, kend, p.b_vec, rb);
@@ -127,18 +154,28 @@ __global__ __launch_bounds__(GEMM_THREADS) void gemm_f32_kernel(GemmParams p) {
             load_tile<A_KC>(A, p.lda, p.M, p.K, m0, kbeg + (kt + 1) * BK, kend, p.a_vec, ra);
             load_tile<B_KC>(B, p.ldb, p.N, p.K, n0, kbeg + (kt + 1) * BK, kend, p.b_vec, rb);
         }
+        // fragments of k-step kk+1 are read from LDS before the MFMAs of k-step kk are issued (software pipeline):
+        // a single wave per SIMD then keeps the matrix pipe busy instead of idling for an LDS latency per k-step
+        float a[2], b[2];
+#pragma unroll
+        for (int i = 0; i < 2; ++i) a[i] = As[cur][lk][wm + i * 32 + lr];
+#pragma unroll
+        for (int j = 0; j < 2; ++j) b[j] = Bs[cur][lk][wn + j * 32 + lr];
 #pragma unroll
         for (int kk = 0; kk < BK / 2; ++kk) {
-            float a[2], b[2];
+            float an[2] = {0.f, 0.f}, bn[2] = {0.f, 0.f};
+            if (kk + 1 < BK / 2) {
 #pragma unroll
-            for (int i = 0; i < 2; ++i) a[i] = As[cur][kk * 2 + lk][wm + i * 32 + lr];
+                for (int i = 0; i < 2; ++i) an[i] = As[cur][(kk + 1) * 2 + lk][wm + i * 32 + lr];
 #pragma unroll
-            for (int j = 0; j < 2; ++j) b[j] = Bs[cur][kk * 2 + lk][wn + j * 32 + lr];
+                for (int j = 0; j < 2; ++j) bn[j] = Bs[cur][(kk + 1) * 2 + lk][wn + j * 32 + lr];
+            }
 #pragma unroll
             for (int i = 0; i < 2; ++i)
 #pragma unroll
                 for (int j = 0; j < 2; ++j)
                     acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], b[j], acc[i][j], 0, 0, 0);
+            a[0] = an[0]; a[1] = an[1]; b[0] = bn[0]; b[1] = bn[1];
         }
         if (more) {
             store_tile<A_KC>(As[cur ^ 1], ra);
@@ -215,7 +252,8 @@ int gemm_f32(const GemmDesc& d, hipStream_t stream) {
             LAS_REQUIRE(batch == 1, "split-K with strided C and batch>1");
         }
     }
-    dim3 grid(gx, gy, batch * splitk), block(GEMM_THREADS);
+    p.gx = gx; p.swz = ((gx * gy) % 8 == 0) && (gx * gy >= 64);
+    dim3 grid(gx * gy, 1, batch * splitk), block(GEMM_THREADS);
     if (d.a_kc && d.b_kc) hipLaunchKernelGGL((gemm_f32_kernel<true, true>), grid, block, 0, stream, p);
     else if (d.a_kc && !d.b_kc) hipLaunchKernelGGL((gemm_f32_kernel<true, false>), grid, block, 0, stream, p);
     else if (!d.a_kc && d.b_kc) hipLaunchKernelGGL((gemm_f32_kernel<false, true>), grid, block, 0, stream, p);
