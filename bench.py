@@ -142,9 +142,12 @@ def main():
                              "bench.py --gpus N ...")
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
-    if world > 1:
+    use_dist = world > 1 or os.environ.get("LAS_FORCE_DIST") == "1"      # the latter: exercise the RCCL path on one GPU
+    if use_dist:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        dist.init_process_group("nccl", device_id=device)
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29511")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
 
     import las_pytorch_amd
     from las_pytorch_amd import dp, synth
@@ -159,7 +162,7 @@ def main():
     labf = lab.float()
 
     if train:
-        reducer = dp.FlatGradAllReducer(las)
+        reducer = dp.FlatGradAllReducer(las, force=os.environ.get("LAS_FORCE_DIST") == "1")
         opt = torch.optim.Adam(las.parameters(), lr=2e-4, fused=True)
 
         def step():
@@ -204,7 +207,7 @@ def main():
         step()
     if train:
         reducer.check_views()
-    if world > 1:
+    if use_dist:
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
@@ -212,10 +215,10 @@ def main():
     for _ in range(args.steps):
         last = step()
     torch.cuda.synchronize()
-    if world > 1:
+    if use_dist:
         dist.barrier()
     dt = time.perf_counter() - t0
-    if world > 1:
+    if use_dist:
         t = torch.tensor([dt], device=device, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
@@ -240,7 +243,7 @@ def main():
         if world == 1 and not args.no_cpu_baseline:
             res["cpu_baseline"] = cpu_baseline(cfg_name, B, T, U, train)
         print(json.dumps(res), flush=True)
-    if world > 1:
+    if use_dist:
         dist.barrier()
         dist.destroy_process_group()
 

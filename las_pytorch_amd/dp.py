@@ -19,7 +19,8 @@ class FlatGradAllReducer:
     """Makes every ``p.grad`` a view into one contiguous fp32 buffer so the whole gradient crosses the fabric as a
     single collective (message: S 7.96 MB, P 39.9 MB)."""
 
-    def __init__(self, module: torch.nn.Module):
+    def __init__(self, module: torch.nn.Module, force: bool = False):
+        self.force = force          # all-reduce even in a 1-rank group (exercises the collective path)
         self.params = [p for p in module.parameters() if p.requires_grad]
         n = sum(p.numel() for p in self.params)
         dev = self.params[0].device
@@ -40,9 +41,10 @@ class FlatGradAllReducer:
             assert p.grad is not None and p.grad.untyped_storage().data_ptr() == base, "a .grad left the flat buffer"
 
     def allreduce_mean(self):
-        if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
-            dist.all_reduce(self.flat, op=dist.ReduceOp.SUM)
-            self.flat.div_(dist.get_world_size())
+        if dist.is_available() and dist.is_initialized():
+            if dist.get_world_size() > 1 or self.force:
+                dist.all_reduce(self.flat, op=dist.ReduceOp.SUM)
+                self.flat.div_(dist.get_world_size())
 
     def clip_(self, max_norm=1.0):
         """clip_grad_norm_(params, max_norm) on the flat buffer (solver/solver.py:96), same formula as torch's."""
