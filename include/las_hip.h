@@ -113,6 +113,14 @@ int las_speller_fwd(const las_speller_desc* d, const float* feat, const float* k
                     const int64_t* labels_onehot, int U_lab, int U, int teacher_forced, int decode_mode,
                     float* logp, float* att, int32_t* argmax, float* reserve, int flags, void* stream);
 
+/* One decode step with caller-managed state: Speller.forward_step, reference model/las_model.py:178-184.
+ *   input_word (B, V+Hs) = [y | context] as the reference concatenates it (:198,:236); h_in/c_in (L,B,Hs) or both NULL
+ *   (zero state).  Outputs: logp (B,V), h_out/c_out (L,B,Hs), ctx (B,D), att (B,Tp).  Inference only (no stash). */
+size_t las_speller_step_workspace_floats(const las_speller_desc* d);
+int las_speller_step_fwd(const las_speller_desc* d, const float* feat, const float* keys, const float* input_word,
+                         const float* h_in, const float* c_in, float* logp, float* h_out, float* c_out, float* ctx,
+                         float* att, float* workspace, void* stream);
+
 size_t las_speller_bwd_workspace_floats(const las_speller_desc* d, int U);
 /* dlogp (U,B,V): gradient of the loss wrt the returned log-probs.  feedback_mode0: the forward ran
  * free-running with decode_mode 0 (gradient flows through the fed-back log-probs). */

@@ -284,6 +284,57 @@ int las_speller_fwd(const las_speller_desc* d, const float* feat, const float* k
     return LAS_OK;
 }
 
+// One decode step with caller-managed state (reference Speller.forward_step, las_model.py:178-184). Inference only.
+size_t las_speller_step_workspace_floats(const las_speller_desc* d) {
+    const size_t Vp = (d->V + 15) & ~15;
+    return r4((size_t)d->B * Vp) + r4((size_t)d->B * d->D) + r4((size_t)4 * d->Hs * (Vp + d->Hs));
+}
+
+int las_speller_step_fwd(const las_speller_desc* d, const float* feat, const float* keys, const float* input_word,
+                         const float* h_in, const float* c_in, float* logp, float* h_out, float* c_out, float* ctx, float* att,
+                         float* workspace, void* stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    LAS_TRY(check_desc(d));
+    LAS_REQUIRE(feat && input_word && logp && h_out && c_out && ctx && att && workspace, "step pointers");
+    LAS_REQUIRE(!d->use_mlp || keys, "attention keys");
+    LAS_REQUIRE((h_in == nullptr) == (c_in == nullptr), "h/c state must both be given or both be NULL");
+    const int B = d->B, Hs = d->Hs, V = d->V, D = d->D, Tp = d->Tp, L = d->L;
+    LAS_REQUIRE(Hs % 16 == 0, "speller hidden size must be a multiple of 16");
+    const int Vp = (V + 15) & ~15;
+    float* y = workspace;
+    float* cin = y + r4((size_t)B * Vp);
+    float* w0p = cin + r4((size_t)B * D);
+    const size_t sH = (size_t)B * Hs;
+    // split the reference's concatenated input [y | ctx] (las_model.py:198,236) into aligned, padded operands
+    LAS_HIP_CHECK(hipMemsetAsync(y, 0, sizeof(float) * (size_t)B * Vp, stream));
+    LAS_TRY(copy2d(input_word, V + Hs, y, Vp, B, V, 0, stream));
+    LAS_TRY(copy2d(input_word + V, V + Hs, cin, D, B, D, 0, stream));
+    LAS_HIP_CHECK(hipMemsetAsync(w0p, 0, sizeof(float) * (size_t)4 * Hs * (Vp + Hs), stream));
+    LAS_TRY(copy2d(d->w_ih[0], V + Hs, w0p, Vp + Hs, 4 * Hs, V, 0, stream));
+    LAS_TRY(copy2d(d->w_ih[0] + V, V + Hs, w0p + Vp, Vp + Hs, 4 * Hs, Hs, 0, stream));
+    for (int l = 0; l < L; ++l) {
+        CellSeg segs[3];
+        int n = 0;
+        if (l == 0) {
+            segs[n].x = cin; segs[n].ldx = D; segs[n].w = w0p + Vp; segs[n].ldw = Vp + Hs; segs[n].K = D; ++n;
+            segs[n].x = y; segs[n].ldx = Vp; segs[n].w = w0p; segs[n].ldw = Vp + Hs; segs[n].K = Vp; ++n;
+        } else {
+            segs[n].x = h_out + (size_t)(l - 1) * sH; segs[n].ldx = Hs; segs[n].w = d->w_ih[l]; segs[n].ldw = Hs; segs[n].K = Hs; ++n;
+        }
+        if (h_in) { segs[n].x = h_in + (size_t)l * sH; segs[n].ldx = Hs; segs[n].w = d->w_hh[l]; segs[n].ldw = Hs; segs[n].K = Hs; ++n; }
+        LAS_TRY(lstm_cell_fwd(segs, n, d->b_ih[l], d->b_hh[l], c_in ? c_in + (size_t)l * sH : nullptr, h_out + (size_t)l * sH,
+                              c_out + (size_t)l * sH, nullptr, B, Hs, stream));
+    }
+    AttnFwdArgs a;
+    a.h_top = h_out + (size_t)(L - 1) * sH;
+    a.feat = feat; a.keys = d->use_mlp ? keys : feat;
+    a.w_phi = d->w_phi; a.b_phi = d->b_phi; a.w_c = d->w_c; a.b_c = d->b_c;
+    a.q_out = nullptr; a.att_out = att; a.ctx_out = ctx; a.logp_out = logp; a.argmax_out = nullptr; a.y_next = nullptr; a.ldy = 0;
+    a.y_mode = 1;
+    a.B = B; a.Tp = Tp; a.D = D; a.M = d->M; a.V = V; a.Hs = Hs; a.use_mlp = d->use_mlp; a.relu = d->relu;
+    return attn_step_fwd(a, stream);
+}
+
 size_t las_speller_bwd_workspace_floats(const las_speller_desc* d, int U) { return SpellerBwdLayout(d, U).total; }
 
 int las_speller_bwd(const las_speller_desc* d, const float* feat, const float* keys, const float* logp, const float* att,

@@ -186,6 +186,23 @@ class Attention(nn.Module):
         raise RuntimeError("Attention is fused into the Speller step kernels; call Speller.forward / forward_step")
 
 
+def _speller_desc(B, Tp, D, Hs, V, M, L, use_mlp, relu, lstm, rest):
+    """Fill the C descriptor from (already contiguous fp32) parameter tensors; returns it (pointers only — the
+    caller keeps the tensors alive)."""
+    d = SpellerDesc()
+    d.B, d.Tp, d.D, d.Hs, d.V, d.M, d.L = B, Tp, D, Hs, V, M, L
+    d.use_mlp, d.relu, d.multi_head = int(use_mlp), int(relu), 1
+    for l in range(L):
+        d.w_ih[l], d.w_hh[l], d.b_ih[l], d.b_hh[l] = (ptr(lstm[4 * l + i]) for i in range(4))
+    if use_mlp:
+        w_phi, b_phi, w_psi, b_psi, w_c, b_c = rest
+        d.w_phi, d.b_phi, d.w_psi, d.b_psi = ptr(w_phi), ptr(b_phi), ptr(w_psi), ptr(b_psi)
+    else:
+        w_c, b_c = rest
+    d.w_c, d.b_c = ptr(w_c), ptr(b_c)
+    return d
+
+
 class _SpellerFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, cfg, feat, labels, *params):
@@ -333,8 +350,38 @@ class Speller(nn.Module):
         return raw_pred_seq, attention_record
 
     def forward_step(self, input_word, last_hidden_state, listener_feature):
-        raise NotImplementedError("forward_step with caller-managed state is not exported by the HIP path yet; "
-                                  "use Speller.forward (the only caller in the reference, las_model.py:210)")
+        """One decode step with caller-managed state (reference las_model.py:178-184): ``input_word`` (B,1,V+Hs),
+        ``last_hidden_state`` = (h, c) each (L,B,Hs) or None, returns (raw_pred (B,V), (h, c), context (B,2H),
+        [attention_score (B,T')]).  Inference only: the step API keeps no stash, so its outputs carry no autograd
+        history (``Speller.forward`` is the differentiable path; it is the reference's only caller, :210)."""
+        a = self.attention
+        use_mlp = bool(a.mlp_preprocess_input)
+        feat = _f32c(listener_feature.detach())
+        B, Tp, D = feat.shape
+        Hs, L, V = self.hidden_size, self.num_layers, self.label_dim
+        M = int(a.preprocess_mlp_dim) if use_mlp else 0
+        params = [_f32c(p.detach()) for p in self._params()]
+        d = _speller_desc(B, Tp, D, Hs, V, M, L, use_mlp, a.activate == "relu", params[:4 * L], params[4 * L:])
+        if D != Hs:
+            raise RuntimeError(f"Speller hidden_size ({Hs}) must equal 2*listener_hidden_size ({D}) (reference las_model.py:198)")
+        x = _f32c(input_word.detach().reshape(B, -1))
+        if x.shape[1] != V + Hs:
+            raise RuntimeError(f"input_word must be (B,1,{V + Hs}), got {tuple(input_word.shape)}")
+        dev = feat.device
+        Lh, stream = lib(), stream_ptr()
+        keys = None
+        if use_mlp:
+            keys = torch.empty(B, Tp, M, device=dev, dtype=torch.float32)
+            check(Lh.las_attn_keys_fwd(d, ptr(feat), ptr(keys), stream))
+        h_in = c_in = None
+        if last_hidden_state is not None:
+            h_in, c_in = (_f32c(t.detach()) for t in last_hidden_state)
+        logp = torch.empty(B, V, device=dev); ctx = torch.empty(B, D, device=dev); att = torch.empty(B, Tp, device=dev)
+        h_out = torch.empty(L, B, Hs, device=dev); c_out = torch.empty(L, B, Hs, device=dev)
+        work = torch.empty(Lh.las_speller_step_workspace_floats(d), device=dev, dtype=torch.float32)
+        check(Lh.las_speller_step_fwd(d, ptr(feat), ptr(keys), ptr(x), ptr(h_in), ptr(c_in), ptr(logp), ptr(h_out), ptr(c_out),
+                                      ptr(ctx), ptr(att), ptr(work), stream))
+        return logp, (h_out, c_out), ctx, [att]
 
 
 class LAS(nn.Module):

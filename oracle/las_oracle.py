@@ -191,6 +191,23 @@ def speller_forward(feat, sd, *, num_layers, max_label_len, decode_mode, ground_
     return preds, atts
 
 
+def speller_step(input_word, hidden, feat, sd, *, num_layers, use_mlp=True, activate="relu", multi_head=1, prefix="speller."):
+    """model/las_model.py:178-184 (Speller.forward_step): input_word (B,V+Hs), hidden = (h,c) each (L,B,Hs) or None."""
+    B = feat.shape[0]
+    Hs = sd[prefix + "rnn_layer.weight_hh_l0"].shape[1]
+    h = [feat.new_zeros(B, Hs) if hidden is None else hidden[0][l] for l in range(num_layers)]
+    c = [feat.new_zeros(B, Hs) if hidden is None else hidden[1][l] for l in range(num_layers)]
+    x = input_word
+    for l in range(num_layers):
+        h[l], c[l] = lstm_cell(x, h[l], c[l], sd[f"{prefix}rnn_layer.weight_ih_l{l}"], sd[f"{prefix}rnn_layer.weight_hh_l{l}"],
+                               sd[f"{prefix}rnn_layer.bias_ih_l{l}"], sd[f"{prefix}rnn_layer.bias_hh_l{l}"])
+        x = h[l]
+    scores, ctx = attention_forward(x, feat, sd, prefix + "attention.", use_mlp, activate, multi_head)
+    logits = torch.cat([x, ctx], dim=-1) @ sd[prefix + "character_distribution.weight"].t() \
+        + sd[prefix + "character_distribution.bias"]
+    return torch.log_softmax(logits, dim=-1), (torch.stack(h), torch.stack(c)), ctx, scores
+
+
 def las_forward(x, labels, sd, cfg, *, teacher_force, is_training=True):
     """model/las_model.py:30-40.  ``cfg`` keys: listener_layers, speller_layers,
     max_label_len, decode_mode, use_mlp, activate, multi_head."""

@@ -76,8 +76,8 @@ def test_surface_attributes_and_errors():
         lis(torch.zeros(2, 16, 80))
     with pytest.raises(NotImplementedError):
         Listener(80, 128, 2, "GRU", False)
-    with pytest.raises(NotImplementedError):
-        _build("S", mlp_dummy=None).speller.forward_step(None, None, None)
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        las.speller.forward_step(torch.zeros(2, 1, 30 + 256), None, torch.zeros(2, 4, 256))
     with pytest.raises(AssertionError):
         Listener(80, 128, 0, "LSTM", False)
 

@@ -172,3 +172,37 @@ def test_host_rng_and_surface():
     with pytest.raises(RuntimeError):
         las.listener(torch.zeros(2, 6, c["F"], device="cuda")[:, :5])   # odd frame count after layer 0 (T=5)
     _check_err()
+
+
+def test_forward_step_matches_oracle_and_loop():
+    """Speller.forward_step (reference las_model.py:178-184) with caller-managed state: three chained steps equal the
+    oracle's step function and the first steps of Speller.forward."""
+    from las_pytorch_amd import synth
+    from oracle import las_oracle as O
+    c = synth.CONFIGS["S"]
+    sd_np = synth.make_state_dict(synth.config_shapes("S"), seed=11, scale=0.15)
+    las = build_las(c, sd_np, max_label_len=3)
+    sd = O.to_torch_sd(sd_np)
+    x = synth.make_inputs(3, 32, c["F"], seed=11)
+    with torch.no_grad():
+        feat_o = O.listener_forward(torch.from_numpy(x), sd, c["L"])
+        feat = las.listener(torch.from_numpy(x).cuda())
+        B, V = 3, c["V"]
+        y = torch.zeros(B, V); y[:, 0] = 1.0
+        inp_o = torch.cat([y, feat_o[:, 0, :]], -1)
+        inp = torch.cat([y.cuda(), feat[:, 0, :]], -1).unsqueeze(1)
+        hid_o, hid = None, None
+        for step in range(3):
+            lp_o, hid_o, ctx_o, sc_o = O.speller_step(inp_o, hid_o, feat_o, sd, num_layers=c["Ls"])
+            lp, hid, ctx, sc = las.speller.forward_step(inp, hid, feat)
+            assert_close(lp.cpu().numpy(), lp_o.numpy(), f"step{step}/logp")
+            assert_close(ctx.cpu().numpy(), ctx_o.numpy(), f"step{step}/ctx")
+            assert_close(sc[0].cpu().numpy(), sc_o[0].numpy(), f"step{step}/att", atol=1e-6)
+            assert_close(hid[0].cpu().numpy(), hid_o[0].numpy(), f"step{step}/h")
+            yo = torch.zeros(B, V); yo[torch.arange(B), lp_o.argmax(-1)] = 1.0
+            inp_o = torch.cat([yo, ctx_o], -1)
+            inp = torch.cat([yo.cuda(), ctx], -1).unsqueeze(1)
+        # the loop API (greedy) walks through the same states
+        preds, _ = las.speller(feat, ground_truth=None, teacher_force_rate=0)
+        assert_close(preds[2].cpu().numpy(), lp.cpu().numpy(), "loop vs step", rtol=1e-5, atol=1e-6)
+    _check_err()
