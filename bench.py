@@ -97,9 +97,17 @@ def roofline_rec_fwd(c, B, T, iters=20):
     w_bytes = 4 * 2 * (4 * H * D_l + 4 * H * H + 8 * H)
     alg_bytes = B * 4 * T_l * (D_l + 2 * H) + w_bytes
     achieved = alg_bytes / (ms * 1e-3) / 1e9
+    # HBM bytes per launch from the PMC counters (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes): measured
+    # offline on this kernel and shape and committed under profiles/ (a counter run cannot nest inside this process)
+    traffic, traffic_src = None, None
+    pmc = os.path.join(ROOT, "profiles", "r01_pmc_rec_fwd.json")
+    if os.path.exists(pmc):
+        j = json.load(open(pmc))
+        if j["shape"] == dict(B=B, T_l=T_l, H=H):
+            traffic, traffic_src = int(j["traffic_bytes"]), "profiles/r01_pmc_rec_fwd.json"
     return dict(bound="hbm", kernel=f"rec_fwd_fast<{H}> layer0 (B={B},T_l={T_l})", achieved=round(achieved, 2), peak=HBM_PEAK_GBS,
-                unit="GB/s", frac=round(achieved / HBM_PEAK_GBS, 5), traffic=None, kernel_ms=round(ms, 4),
-                us_per_step=round(ms * 1e3 / T_l, 3), algorithmic_bytes=alg_bytes)
+                unit="GB/s", frac=round(achieved / HBM_PEAK_GBS, 5), traffic=traffic, traffic_source=traffic_src,
+                kernel_ms=round(ms, 4), us_per_step=round(ms * 1e3 / T_l, 3), algorithmic_bytes=alg_bytes)
 
 
 def cpu_baseline(cfg_name, B, T, U, train):
