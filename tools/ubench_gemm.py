@@ -36,3 +36,8 @@ tot += run("spl dfeat += dK Wpsi", 3200, 512, 64, True, False, splitk=1)
 tot += run("spl dfeat (batched)", 100, 512, 128, False, False, batch=32, splitk=1)
 tot += run("spl dK (batched)", 100, 64, 128, False, False, batch=32, splitk=1)
 print(f"sum over one training step: {tot/1e3:.3f} ms")
+if os.environ.get("BIG"):
+    run("4096^3 NT", 4096, 4096, 4096, True, True, splitk=1, reps=5)
+    run("4096^3 NN", 4096, 4096, 4096, True, False, splitk=1, reps=5)
+    run("4096^3 TN", 4096, 4096, 4096, False, False, splitk=1, reps=5)
+    run("8192x1024x1024 NT", 8192, 1024, 1024, True, True, splitk=1, reps=10)
