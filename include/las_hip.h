@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define LAS_ABI_VERSION 1
+#define LAS_ABI_VERSION 2
 #define LAS_MAX_SPELLER_LAYERS 4
 
 /* flags */
@@ -77,15 +77,16 @@ typedef struct las_speller_desc {
     int L;            /* speller LSTM layers (1..LAS_MAX_SPELLER_LAYERS) */
     int use_mlp;      /* use_mlp_in_attention */
     int relu;         /* 1: relu after phi/psi, 0: no activation */
-    int multi_head;   /* must be 1 */
+    int multi_head;   /* attention heads (reference las_model.py:298-314); > 1 needs use_mlp and w_dr/b_dr */
     /* parameters, PyTorch layouts: w_ih[0] (4Hs, V+Hs), w_ih[l>0] (4Hs, Hs), w_hh (4Hs, Hs), biases (4Hs) */
     const float* w_ih[LAS_MAX_SPELLER_LAYERS];
     const float* w_hh[LAS_MAX_SPELLER_LAYERS];
     const float* b_ih[LAS_MAX_SPELLER_LAYERS];
     const float* b_hh[LAS_MAX_SPELLER_LAYERS];
-    const float* w_phi; const float* b_phi;   /* (M, Hs), (M) */
+    const float* w_phi; const float* b_phi;   /* (M*heads, Hs), (M*heads) */
     const float* w_psi; const float* b_psi;   /* (M, D), (M) */
     const float* w_c;   const float* b_c;     /* (V, 2Hs), (V) */
+    const float* w_dr;  const float* b_dr;    /* dim_reduce (D, heads*D), (D): multi_head > 1 only, else NULL */
 } las_speller_desc;
 
 typedef struct las_speller_grads {           /* all OVERWRITTEN by las_speller_bwd */
@@ -96,6 +97,7 @@ typedef struct las_speller_grads {           /* all OVERWRITTEN by las_speller_b
     float* dw_phi; float* db_phi;
     float* dw_psi; float* db_psi;
     float* dw_c;   float* db_c;
+    float* dw_dr;  float* db_dr;              /* multi_head > 1 only */
     float* dfeat;                             /* (B, Tp, D) */
 } las_speller_grads;
 
@@ -108,7 +110,7 @@ size_t las_speller_reserve_floats(const las_speller_desc* d, int U);
  *   teacher_forced: 1 -> step s+1 is fed labels[:, s] (las_model.py:216-217); 0 -> free running with
  *   decode_mode 0 (feed log-probs, :220-221) or 1 (feed one-hot argmax, :223-227).  Mode 2 (sampling) is
  *   not implemented.
- *   logp (U,B,V), att (U,B,Tp), argmax (U,B) int32 or NULL.  keys may be NULL when !use_mlp. */
+ *   logp (U,B,V), att (U,heads,B,Tp), argmax (U,B) int32 or NULL.  keys may be NULL when !use_mlp. */
 int las_speller_fwd(const las_speller_desc* d, const float* feat, const float* keys,
                     const int64_t* labels_onehot, int U_lab, int U, int teacher_forced, int decode_mode,
                     float* logp, float* att, int32_t* argmax, float* reserve, int flags, void* stream);

@@ -21,13 +21,14 @@ class SpellerDesc(C.Structure):
     _fields_ = [("B", C.c_int), ("Tp", C.c_int), ("D", C.c_int), ("Hs", C.c_int), ("V", C.c_int), ("M", C.c_int),
                 ("L", C.c_int), ("use_mlp", C.c_int), ("relu", C.c_int), ("multi_head", C.c_int),
                 ("w_ih", _f * MAX_L), ("w_hh", _f * MAX_L), ("b_ih", _f * MAX_L), ("b_hh", _f * MAX_L),
-                ("w_phi", _f), ("b_phi", _f), ("w_psi", _f), ("b_psi", _f), ("w_c", _f), ("b_c", _f)]
+                ("w_phi", _f), ("b_phi", _f), ("w_psi", _f), ("b_psi", _f), ("w_c", _f), ("b_c", _f),
+                ("w_dr", _f), ("b_dr", _f)]
 
 
 class SpellerGrads(C.Structure):
     _fields_ = [("dw_ih", _f * MAX_L), ("dw_hh", _f * MAX_L), ("db_ih", _f * MAX_L), ("db_hh", _f * MAX_L),
                 ("dw_phi", _f), ("db_phi", _f), ("dw_psi", _f), ("db_psi", _f), ("dw_c", _f), ("db_c", _f),
-                ("dfeat", _f)]
+                ("dw_dr", _f), ("db_dr", _f), ("dfeat", _f)]
 
 
 # name -> (restype, argtypes); every symbol include/las_hip.h declares

@@ -34,7 +34,7 @@ struct PblstmBwdLayout {
 };
 
 struct SpellerLayout {
-    size_t y_all, ctx_all, h_all, c_all, gates_all, q_all, w0p, total;
+    size_t y_all, ctx_all, h_all, c_all, gates_all, q_all, w0p, ctxcat_all, total;
     int Vp;                    // label width padded to a multiple of 16: every cell operand is aligned and tail-free
     SpellerLayout(const las_speller_desc* d, int U) {
         size_t o = 0;
@@ -45,14 +45,15 @@ struct SpellerLayout {
         h_all = o; o += r4((size_t)d->L * U * B * d->Hs);
         c_all = o; o += r4((size_t)d->L * U * B * d->Hs);
         gates_all = o; o += r4((size_t)d->L * U * B * 4 * d->Hs);
-        q_all = o; if (d->use_mlp) o += r4((size_t)U * B * d->M);
+        q_all = o; if (d->use_mlp) o += r4((size_t)U * B * d->M * d->multi_head);
+        ctxcat_all = o; if (d->multi_head > 1) o += r4((size_t)U * B * d->multi_head * d->D);   // per-head contexts (dim_reduce input)
         w0p = o; o += r4((size_t)4 * d->Hs * (Vp + d->Hs));      // W_ih0 re-laid as [W_y | 0 | W_ctx], ld = Vp + Hs
         total = o;
     }
 };
 
 struct SpellerBwdLayout {
-    size_t dG_all, dz_all, dctx_all, de_all, dqpre_all, dh_top, dh_below, dh_carry, dc_carry, dx0, dK, dcat_all, total;
+    size_t dG_all, dz_all, dctx_all, de_all, dqpre_all, dh_top, dh_below, dh_carry, dc_carry, dx0, dK, dcat_all, dctxcat_all, total;
     SpellerBwdLayout(const las_speller_desc* d, int U) {
         size_t o = 0;
         const size_t B = d->B;
@@ -60,15 +61,16 @@ struct SpellerBwdLayout {
         dG_all = o; o += r4((size_t)d->L * U * B * 4 * d->Hs);
         dz_all = o; o += r4((size_t)U * B * d->V);
         dctx_all = o; o += r4((size_t)U * B * d->D);
-        de_all = o; o += r4((size_t)U * B * d->Tp);
-        dqpre_all = o; o += r4((size_t)U * B * d->M);
-        dh_top = o; o += r4(B * d->Hs);
+        de_all = o; o += r4((size_t)U * B * d->Tp * d->multi_head);
+        dqpre_all = o; o += r4((size_t)U * B * d->M * d->multi_head);
+        dh_top = o; o += r4((size_t)(d->multi_head + 1) * B * d->Hs);     // decoder-state gradient parts (one per head + W_c part)
         dh_below = o; o += r4(B * d->Hs);
         dh_carry = o; o += r4((size_t)d->L * B * d->Hs);
         dc_carry = o; o += r4((size_t)d->L * B * d->Hs);
         dx0 = o; o += r4(B * (d->V + d->D));
         dK = o; o += r4(B * d->Tp * Mq);
         dcat_all = o; o += r4((size_t)U * B * (d->Hs + d->D));    // dz W_c for every step (teacher forcing / mode 1)
+        dctxcat_all = o; if (d->multi_head > 1) o += r4((size_t)U * B * d->multi_head * d->D);
         total = o;
     }
 };
@@ -78,7 +80,9 @@ int check_desc(const las_speller_desc* d) {
     LAS_REQUIRE(d->B > 0 && d->Tp > 0 && d->D > 0 && d->Hs > 0 && d->V > 0, "speller dims");
     LAS_REQUIRE(d->L >= 1 && d->L <= LAS_MAX_SPELLER_LAYERS, "speller layers");
     LAS_REQUIRE(d->D == d->Hs, "Speller hidden_size must equal 2*listener_hidden_size (reference las_model.py:198)");
-    if (d->multi_head != 1) return fail(LAS_ERR_UNSUPPORTED, "multi-head attention is not implemented by the HIP path%s", "");
+    LAS_REQUIRE(d->multi_head >= 1 && d->multi_head <= 16, "attention heads");
+    LAS_REQUIRE(d->multi_head == 1 || (d->use_mlp && d->w_dr && d->b_dr),
+                "multi-head attention needs the phi/psi MLP and dim_reduce (reference las_model.py:266-269)");
     LAS_REQUIRE(!d->use_mlp || d->M > 0, "attention mlp dim");
     for (int l = 0; l < d->L; ++l) LAS_REQUIRE(d->w_ih[l] && d->w_hh[l] && d->b_ih[l] && d->b_hh[l], "speller LSTM weights");
     LAS_REQUIRE(d->w_c && d->b_c, "character distribution weights");
@@ -255,19 +259,35 @@ int las_speller_fwd(const las_speller_desc* d, const float* feat, const float* k
             LAS_TRY(lstm_cell_fwd(segs, n, d->b_ih[l], d->b_hh[l], s > 0 ? c_all + o - sH : nullptr, h_all + o, c_all + o,
                                   gates_all + 4 * o, B, Hs, stream));
         }
+        const int NH = d->multi_head;
         AttnFwdArgs a;
         a.h_top = h_all + ((size_t)(L - 1) * U + s) * sH;
         a.feat = feat; a.keys = d->use_mlp ? keys : feat;
         a.w_phi = d->w_phi; a.b_phi = d->b_phi; a.w_c = d->w_c; a.b_c = d->b_c;
-        a.q_out = q_all ? q_all + (size_t)s * B * d->M : nullptr;
-        a.att_out = att + (size_t)s * B * Tp;
-        a.ctx_out = ctx_all + (size_t)(s + 1) * B * D;
+        a.q_out = q_all ? q_all + (size_t)s * B * d->M * NH : nullptr; a.ldq = (long)d->M * NH;
+        a.att_out = att + (size_t)s * NH * B * Tp; a.att_hs = (long)B * Tp;
         a.logp_out = teacher_forced ? nullptr : logp + (size_t)s * B * V;   // teacher forcing: deferred to one GEMM below
         a.argmax_out = argmax ? argmax + (size_t)s * B : nullptr;
         a.y_next = teacher_forced ? nullptr : y_all + (size_t)(s + 1) * B * Vp; a.ldy = Vp;
         a.y_mode = decode_mode;
         a.B = B; a.Tp = Tp; a.D = D; a.M = d->M; a.V = V; a.Hs = Hs; a.use_mlp = d->use_mlp; a.relu = d->relu;
-        LAS_TRY(attn_step_fwd(a, stream));
+        a.heads = NH;
+        float* ctx_next = ctx_all + (size_t)(s + 1) * B * D;
+        if (NH == 1) {
+            a.ctx_out = ctx_next; a.ldctx = D;
+            LAS_TRY(attn_step_fwd(a, stream));
+        } else {
+            // per-head attention -> concatenated contexts -> dim_reduce (las_model.py:298-314) -> character distribution
+            float* ctxcat = reserve + lay.ctxcat_all + (size_t)s * B * NH * D;
+            a.ctx_out = ctxcat; a.ldctx = (long)NH * D; a.phases = 1;
+            LAS_TRY(attn_step_fwd(a, stream));
+            CellSeg sg; sg.x = ctxcat; sg.ldx = (long)NH * D; sg.w = d->w_dr; sg.ldw = (long)NH * D; sg.K = NH * D;
+            LAS_TRY(smallm_linear_nt(&sg, 1, d->b_dr, ctx_next, D, B, D, stream));
+            if (!teacher_forced) {
+                a.phases = 2; a.ctx_in = ctx_next;
+                LAS_TRY(attn_step_fwd(a, stream));
+            }
+        }
     }
     if (teacher_forced) {
         // character distribution of all U steps at once (reference las_model.py:181-182, per step there):
@@ -287,7 +307,8 @@ int las_speller_fwd(const las_speller_desc* d, const float* feat, const float* k
 // One decode step with caller-managed state (reference Speller.forward_step, las_model.py:178-184). Inference only.
 size_t las_speller_step_workspace_floats(const las_speller_desc* d) {
     const size_t Vp = (d->V + 15) & ~15;
-    return r4((size_t)d->B * Vp) + r4((size_t)d->B * d->D) + r4((size_t)4 * d->Hs * (Vp + d->Hs));
+    return r4((size_t)d->B * Vp) + r4((size_t)d->B * d->D) + r4((size_t)4 * d->Hs * (Vp + d->Hs)) +
+           r4((size_t)d->B * d->multi_head * d->D);
 }
 
 int las_speller_step_fwd(const las_speller_desc* d, const float* feat, const float* keys, const float* input_word,
@@ -325,13 +346,25 @@ int las_speller_step_fwd(const las_speller_desc* d, const float* feat, const flo
         LAS_TRY(lstm_cell_fwd(segs, n, d->b_ih[l], d->b_hh[l], c_in ? c_in + (size_t)l * sH : nullptr, h_out + (size_t)l * sH,
                               c_out + (size_t)l * sH, nullptr, B, Hs, stream));
     }
+    const int NH = d->multi_head;
+    float* ctxcat = w0p + r4((size_t)4 * Hs * (Vp + Hs));
     AttnFwdArgs a;
     a.h_top = h_out + (size_t)(L - 1) * sH;
     a.feat = feat; a.keys = d->use_mlp ? keys : feat;
     a.w_phi = d->w_phi; a.b_phi = d->b_phi; a.w_c = d->w_c; a.b_c = d->b_c;
-    a.q_out = nullptr; a.att_out = att; a.ctx_out = ctx; a.logp_out = logp; a.argmax_out = nullptr; a.y_next = nullptr; a.ldy = 0;
+    a.q_out = nullptr; a.att_out = att; a.att_hs = (long)B * Tp; a.logp_out = logp; a.argmax_out = nullptr; a.y_next = nullptr; a.ldy = 0;
     a.y_mode = 1;
     a.B = B; a.Tp = Tp; a.D = D; a.M = d->M; a.V = V; a.Hs = Hs; a.use_mlp = d->use_mlp; a.relu = d->relu;
+    a.heads = NH;
+    if (NH == 1) {
+        a.ctx_out = ctx; a.ldctx = D;
+        return attn_step_fwd(a, stream);
+    }
+    a.ctx_out = ctxcat; a.ldctx = (long)NH * D; a.phases = 1;
+    LAS_TRY(attn_step_fwd(a, stream));
+    CellSeg sg; sg.x = ctxcat; sg.ldx = (long)NH * D; sg.w = d->w_dr; sg.ldw = (long)NH * D; sg.K = NH * D;
+    LAS_TRY(smallm_linear_nt(&sg, 1, d->b_dr, ctx, D, B, D, stream));
+    a.phases = 2; a.ctx_in = ctx;
     return attn_step_fwd(a, stream);
 }
 
@@ -346,6 +379,7 @@ int las_speller_bwd(const las_speller_desc* d, const float* feat, const float* k
     LAS_REQUIRE(!d->use_mlp || keys, "attention keys");
     LAS_REQUIRE(g->dfeat && g->dw_c && g->db_c, "speller grad outputs");
     LAS_REQUIRE(!d->use_mlp || (g->dw_phi && g->db_phi && g->dw_psi && g->db_psi), "attention grad outputs");
+    LAS_REQUIRE(d->multi_head == 1 || (g->dw_dr && g->db_dr), "dim_reduce grad outputs");
     const int B = d->B, Hs = d->Hs, V = d->V, D = d->D, Tp = d->Tp, L = d->L, M = d->M;
     for (int l = 0; l < L; ++l) LAS_REQUIRE(g->dw_ih[l] && g->dw_hh[l] && g->db_ih[l] && g->db_hh[l], "LSTM grad outputs");
     SpellerLayout lay(d, U);
@@ -389,22 +423,44 @@ int las_speller_bwd(const las_speller_desc* d, const float* feat, const float* k
         pw.dG = dG_all + 4 * o; pw.dc_out = dc_carry + (size_t)l * sH;
         return pw;
     };
+    const int NH = d->multi_head;
+    float* dctxcat_all = NH > 1 ? workspace + wl.dctxcat_all : nullptr;
+    const float* ctxcat_all = NH > 1 ? reserve + lay.ctxcat_all : nullptr;
     for (int s = U - 1; s >= 0; --s) {
         const bool last = (s == U - 1);
         AttnBwdArgs a;
         a.dlogp = dlogp + (size_t)s * B * V; a.logp = logp + (size_t)s * B * V;
         a.dcat_pre = hoist ? dcat_all + (size_t)s * B * (Hs + D) : nullptr;
         a.h_top = h_top_all + (size_t)s * sH; a.ctx = ctx_all + (size_t)(s + 1) * B * D;
-        a.att = att + (size_t)s * B * Tp; a.q = q_all ? q_all + (size_t)s * B * M : nullptr;
+        a.att = att + (size_t)s * NH * B * Tp; a.att_hs = (long)B * Tp;
+        a.q = q_all ? q_all + (size_t)s * B * M * NH : nullptr; a.ldq = (long)M * NH;
         a.feat = feat; a.keys = keys_eff; a.w_phi = d->w_phi; a.w_c = d->w_c;
         a.dctx_carry = last ? nullptr : dx0 + V; a.ldc = V + D;
         a.dy_carry = (feedback_mode0 && !last) ? dx0 : nullptr; a.ldy = V + D;
         a.dz_out = dz_all + (size_t)s * B * V; a.dctx_out = dctx_all + (size_t)s * B * D;
-        a.de_out = de_all + (size_t)s * B * Tp; a.dqpre_out = dqpre_all + (size_t)s * B * M;
-        a.dh_top_out = nullptr;
-        a.pw = cell_pw(L - 1, s, last);                    // top layer's pointwise backward fused into this kernel
+        a.de_out = de_all + (size_t)s * NH * B * Tp; a.dqpre_out = dqpre_all + (size_t)s * B * M * NH;
         a.B = B; a.Tp = Tp; a.D = D; a.M = M; a.V = V; a.Hs = Hs; a.use_mlp = d->use_mlp; a.relu = d->relu;
-        LAS_TRY(attn_step_bwd(a, stream));
+        a.heads = NH;
+        if (NH == 1) {
+            a.dh_top_out = nullptr;
+            a.pw = cell_pw(L - 1, s, last);                // top layer's pointwise backward fused into this kernel
+            LAS_TRY(attn_step_bwd(a, stream));
+        } else {
+            // (1) character-distribution part -> total context gradient + decoder-state part 0
+            a.phases = 1; a.dh_top_out = dh_top; a.dh_hs = 0;
+            LAS_TRY(attn_step_bwd(a, stream));
+            // (2) dim_reduce backward: gradient of the concatenated per-head contexts
+            float* dcc = dctxcat_all + (size_t)s * B * NH * D;
+            LAS_TRY(smallm_gemm_nn2(dctx_all + (size_t)s * B * D, D, B, D, d->w_dr, (long)NH * D, dcc, (long)NH * D, NH * D, nullptr, 0,
+                                    nullptr, 0, 0, CellPw(), Hs, stream));
+            // (3) per-head attention backward -> decoder-state parts 1..NH
+            a.phases = 2; a.dctx_in = dcc; a.ld_dctx_in = (long)NH * D; a.dh_top_out = dh_top + sH; a.dh_hs = (long)sH;
+            LAS_TRY(attn_step_bwd(a, stream));
+            // (4) sum the parts and apply the top cell's pointwise backward
+            const CellPw pw = cell_pw(L - 1, s, last);
+            LAS_TRY(lstm_cell_bwd_pointwise(dh_top, NH + 1, (long)sH, pw.dh_carry, pw.dc_in, pw.gates, pw.c, pw.c_prev, pw.dG,
+                                            pw.dc_out, B, Hs, stream));
+        }
         for (int l = L - 1; l >= 0; --l) {
             const float* dGl = dG_all + ((size_t)l * U + s) * 4 * sH;
             if (l > 0) {   // dh of layer l-1 feeds that layer's pointwise step in the epilogue; dh_carry[l] for step s-1
@@ -419,24 +475,33 @@ int las_speller_bwd(const las_speller_desc* d, const float* feat, const float* k
 
     // ---- deferred (loop-invariant-shaped) contractions, all MFMA GEMMs -------------------------
     const int UB = U * B;
-    {   // dfeat[b] = att[:,b,:]^T dctx_all[:,b,:]   (context path, las_model.py:293-297)
+    for (int hd = 0; hd < NH; ++hd) {   // dfeat[b] (+)= att_h[:,b,:]^T dctx_h[:,b,:]   (context path, las_model.py:293-297,307-313)
         GemmDesc q;
-        q.A = att; q.lda = (long)B * Tp; q.a_kc = false; q.sA = Tp;
-        q.B = dctx_all; q.ldb = (long)B * D; q.b_kc = false; q.sB = D;
+        q.A = att + (size_t)hd * B * Tp; q.lda = (long)NH * B * Tp; q.a_kc = false; q.sA = Tp;
+        if (NH == 1) { q.B = dctx_all; q.ldb = (long)B * D; q.sB = D; }
+        else { q.B = dctxcat_all + (size_t)hd * D; q.ldb = (long)B * NH * D; q.sB = (long)NH * D; }
+        q.b_kc = false;
         q.C = g->dfeat; q.ldc = D; q.sC = (long)Tp * D; q.batch = B;
-        q.M = Tp; q.N = D; q.K = U; q.splitk = 1;
+        q.M = Tp; q.N = D; q.K = U; q.splitk = 1; q.accumulate = hd > 0;
         LAS_TRY(gemm_f32(q, stream));
     }
     // first decoder input used feat[:,0,:] as context (las_model.py:198)
     LAS_TRY(copy2d(dx0 + V, V + D, g->dfeat, (long)Tp * D, B, D, 1, stream));
     const int Mq = d->use_mlp ? M : Hs;
-    {   // dK[b] = de[:,b,:]^T q[:,b,:]   (energy path)
+    for (int hd = 0; hd < NH; ++hd) {   // dK[b] (+)= de_h[:,b,:]^T q_h[:,b,:]   (energy path)
         GemmDesc q;
-        q.A = de_all; q.lda = (long)B * Tp; q.a_kc = false; q.sA = Tp;
-        q.B = d->use_mlp ? q_all : h_top_all; q.ldb = (long)B * Mq; q.b_kc = false; q.sB = Mq;
+        q.A = de_all + (size_t)hd * B * Tp; q.lda = (long)NH * B * Tp; q.a_kc = false; q.sA = Tp;
+        q.B = d->use_mlp ? q_all + (size_t)hd * M : h_top_all; q.ldb = (long)B * Mq * NH; q.b_kc = false; q.sB = (long)Mq * NH;
         q.C = d->use_mlp ? dK : g->dfeat; q.ldc = Mq; q.sC = (long)Tp * Mq; q.batch = B;
-        q.M = Tp; q.N = Mq; q.K = U; q.splitk = 1; q.accumulate = !d->use_mlp;
+        q.M = Tp; q.N = Mq; q.K = U; q.splitk = 1; q.accumulate = !d->use_mlp || hd > 0;
         LAS_TRY(gemm_f32(q, stream));
+    }
+    if (NH > 1) {   // dim_reduce gradients: dW_dr = dctx^T ctxcat, db_dr = sum dctx
+        GemmDesc q;
+        q.A = dctx_all; q.lda = D; q.a_kc = false; q.B = ctxcat_all; q.ldb = (long)NH * D; q.b_kc = false;
+        q.C = g->dw_dr; q.ldc = (long)NH * D; q.M = D; q.N = NH * D; q.K = U * B;
+        LAS_TRY(gemm_f32(q, stream));
+        LAS_TRY(colsum(dctx_all, D, U * B, D, g->db_dr, 0, stream));
     }
     if (d->use_mlp) {
         const int BT = B * Tp;
@@ -456,11 +521,11 @@ int las_speller_bwd(const las_speller_desc* d, const float* feat, const float* k
         }
         {   // dW_phi = dqpre^T h_top
             GemmDesc q;
-            q.A = dqpre_all; q.lda = M; q.a_kc = false; q.B = h_top_all; q.ldb = Hs; q.b_kc = false;
-            q.C = g->dw_phi; q.ldc = Hs; q.M = M; q.N = Hs; q.K = UB;
+            q.A = dqpre_all; q.lda = (long)M * NH; q.a_kc = false; q.B = h_top_all; q.ldb = Hs; q.b_kc = false;
+            q.C = g->dw_phi; q.ldc = Hs; q.M = M * NH; q.N = Hs; q.K = UB;
             LAS_TRY(gemm_f32(q, stream));
         }
-        LAS_TRY(colsum(dqpre_all, M, UB, M, g->db_phi, 0, stream));
+        LAS_TRY(colsum(dqpre_all, (long)M * NH, UB, M * NH, g->db_phi, 0, stream));
     }
     {   // dW_c = dz^T [h_top | ctx]
         GemmDesc q;

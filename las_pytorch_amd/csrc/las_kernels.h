@@ -52,9 +52,11 @@ struct CellSeg {            // one dense input segment of an LSTM cell step:  ga
 // gates_out (B,4Hs) post-activation stash (may be null); c_prev may be null (zero state).
 int lstm_cell_fwd(const CellSeg* segs, int nseg, const float* b_ih, const float* b_hh, const float* c_prev, float* h_out,
                   float* c_out, float* gates_out, int B, int Hs, hipStream_t stream);
+// Same small-M MFMA machinery as a plain linear layer: out(B,N) = sum_seg x_seg W_seg^T + bias  (W rows = outputs, N % 16 == 0)
+int smallm_linear_nt(const CellSeg* segs, int nseg, const float* bias, float* out, long ldo, int B, int N, hipStream_t stream);
 // Pointwise part of the cell backward: dh = dh_a + dh_b, dc_in, stash -> dG (B,4Hs), dc_prev (B,Hs)
-int lstm_cell_bwd_pointwise(const float* dh_a, const float* dh_b, const float* dc_in, const float* gates,
-                            const float* c, const float* c_prev, float* dG, float* dc_prev, int B, int Hs,
+int lstm_cell_bwd_pointwise(const float* dh_a, int nparts, long part_stride, const float* dh_b, const float* dc_in,
+                            const float* gates, const float* c, const float* c_prev, float* dG, float* dc_prev, int B, int Hs,
                             hipStream_t stream);
 // Operands of one cell's backward pointwise step, fused into the kernel that produces that cell's dh:
 // dh = (produced value) + dh_carry ; stash -> dG (B,4Hs), dc_out (B,Hs).  dc_out may alias dc_in.
@@ -85,6 +87,12 @@ struct AttnFwdArgs {
     int y_mode;            // 0: feed log-probs back, 1: feed one-hot argmax
     int B, Tp, D, M, V, Hs;
     int use_mlp, relu;
+    // multi-head (reference las_model.py:298-314): grid (B, heads); head h uses rows [h*M,(h+1)*M) of phi and writes its
+    // context to ctx_out[b*ldctx + h*D ...] (the concatenation fed to dim_reduce).  phases: bit0 attention, bit1
+    // character distribution (with ctx_in: read the context from memory instead of computing it).
+    int heads = 1; long ldq = 0, ldctx = 0, att_hs = 0;
+    const float* ctx_in = nullptr;
+    int phases = 3;
 };
 int attn_step_fwd(const AttnFwdArgs& a, hipStream_t stream);
 
@@ -106,6 +114,10 @@ struct AttnBwdArgs {
     float* dqpre_out;      // (B,M)   pre-activation query gradient (stash for dW_phi)
     float* dh_top_out;     // (B,Hs)  gradient wrt decoder state from this step's attention + char distribution (may be null)
     CellPw pw;             // top LSTM layer's backward pointwise step, fused (pw.gates == null: disabled)
+    // multi-head: phases bit0 = character-distribution part (dz, dh_top part 0, total dctx), bit1 = per-head attention part
+    // (grid (B, heads); dctx_in = this head's slice of the dim_reduce input gradient; dh_top_out + h*dh_hs receives its part)
+    int heads = 1; int phases = 3; long ldq = 0, att_hs = 0, dh_hs = 0;
+    const float* dctx_in = nullptr; long ld_dctx_in = 0;
     int B, Tp, D, M, V, Hs;
     int use_mlp, relu;
 };

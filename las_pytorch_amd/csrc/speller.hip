@@ -59,6 +59,7 @@ struct CellParams {
     const float* b_ih; const float* b_hh; const float* c_prev;
     float* h_out; float* c_out; float* gates_out;
     int B, Hs;
+    float* linear_out; long ldo; const float* linear_bias;   // plain linear layer instead of the LSTM cell
 };
 
 // One LSTM cell step.  The decode step is a chain of dependent kernels and each kernel pays ~2-3 us for every
@@ -71,15 +72,16 @@ __global__ __launch_bounds__(CELL_THREADS) void lstm_cell_fwd_kernel(CellParams 
     const int j0 = blockIdx.x * 4, b0 = blockIdx.y * (16 * MT);
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int r = lane & 15, kq = lane >> 4;
-    const long wrow = (long)(r >> 2) * p.Hs + j0 + (r & 3);      // tile column n = gate*4 + unit
+    const bool lin = p.linear_out != nullptr;
+    const long wrow = lin ? (long)blockIdx.x * 16 + r : (long)(r >> 2) * p.Hs + j0 + (r & 3);   // tile column n = gate*4 + unit
 
     // operands of the cell non-linearity (threads that will apply it)
     const int pbl = tid >> 2, pu = tid & 3;
     const int pb = b0 + pbl, pj = j0 + pu;
     const bool pw = tid < MT * 64 && pb < p.B;
     // raw loads only (no arithmetic on them here: a use would force a wait before the main load batch is issued)
-    float cp = 0.f, bi[4], bh[4];
-    {
+    float cp = 0.f, bi[4] = {0.f, 0.f, 0.f, 0.f}, bh[4] = {0.f, 0.f, 0.f, 0.f};
+    if (!lin) {
         const long po = (long)min(pb, p.B - 1) * p.Hs + pj;
         cp = p.c_prev ? p.c_prev[po] : 0.f;
 #pragma unroll
@@ -133,6 +135,20 @@ __global__ __launch_bounds__(CELL_THREADS) void lstm_cell_fwd_kernel(CellParams 
         for (int rr = 0; rr < 4; ++rr) red[wave][mt][kq * 4 + rr][r] = acc[mt][rr];
     __syncthreads();
 
+    if (lin) {
+        const int n0 = blockIdx.x * 16;
+        for (int idx = tid; idx < MT * 256; idx += CELL_THREADS) {
+            const int bl = idx >> 4, c = idx & 15;
+            const int b = b0 + bl;
+            if (b < p.B) {
+                float s = p.linear_bias ? p.linear_bias[n0 + c] : 0.f;
+#pragma unroll
+                for (int w = 0; w < CELL_NW; ++w) s += red[w][bl >> 4][bl & 15][c];
+                p.linear_out[(long)b * p.ldo + n0 + c] = s;
+            }
+        }
+        return;
+    }
     if (pw) {
         float g4[4];
 #pragma unroll
@@ -168,12 +184,29 @@ int lstm_cell_fwd(const CellSeg* segs, int nseg, const float* b_ih, const float*
     }
     for (int i = nseg; i < 3; ++i) p.seg[i] = segs[0];
     p.nseg = nseg; p.b_ih = b_ih; p.b_hh = b_hh; p.c_prev = c_prev; p.h_out = h_out; p.c_out = c_out; p.gates_out = gates_out;
-    p.B = B; p.Hs = Hs;
+    p.B = B; p.Hs = Hs; p.linear_out = nullptr; p.ldo = 0; p.linear_bias = nullptr;
     // one 16-utterance M-tile per workgroup while that keeps the grid within ~two waves of the 256 CUs
-    const int mt = (long)(Hs / 4) * cdiv(B, 16) <= 1024 ? 1 : 2;
+    static int mt_env = getenv("LAS_CELL_MT") ? atoi(getenv("LAS_CELL_MT")) : 0;
+    const int mt = mt_env ? mt_env : ((long)(Hs / 4) * cdiv(B, 16) <= 1024 ? 1 : 2);
     dim3 grid(Hs / 4, cdiv(B, 16 * mt)), block(CELL_THREADS);
     if (mt == 1) hipLaunchKernelGGL((lstm_cell_fwd_kernel<1>), grid, block, 0, stream, p);
     else hipLaunchKernelGGL((lstm_cell_fwd_kernel<2>), grid, block, 0, stream, p);
+    LAS_LAUNCH_CHECK();
+    return LAS_OK;
+}
+
+int smallm_linear_nt(const CellSeg* segs, int nseg, const float* bias, float* out, long ldo, int B, int N, hipStream_t stream) {
+    LAS_REQUIRE(nseg >= 1 && nseg <= 3 && N % 16 == 0, "linear segments / width");
+    CellParams p;
+    for (int i = 0; i < nseg; ++i) {
+        p.seg[i] = segs[i];
+        LAS_REQUIRE(al16(segs[i].x, segs[i].ldx) && al16(segs[i].w, segs[i].ldw) && segs[i].K % 16 == 0, "linear operands");
+    }
+    for (int i = nseg; i < 3; ++i) p.seg[i] = segs[0];
+    p.nseg = nseg; p.b_ih = nullptr; p.b_hh = nullptr; p.c_prev = nullptr; p.h_out = nullptr; p.c_out = nullptr; p.gates_out = nullptr;
+    p.B = B; p.Hs = 0; p.linear_out = out; p.ldo = ldo; p.linear_bias = bias;
+    dim3 grid(N / 16, cdiv(B, 16)), block(CELL_THREADS);
+    hipLaunchKernelGGL((lstm_cell_fwd_kernel<1>), grid, block, 0, stream, p);
     LAS_LAUNCH_CHECK();
     return LAS_OK;
 }
@@ -198,14 +231,16 @@ __device__ __forceinline__ void cell_bwd_point(const CellPw& pw, long b, int j, 
 // ------------------------------------------------------------------------------------------------
 // cell backward: pointwise part
 // ------------------------------------------------------------------------------------------------
-__global__ void lstm_cell_bwd_pointwise_kernel(const float* __restrict__ dh_a, const float* __restrict__ dh_b,
-                                               const float* __restrict__ dc_in, const float* __restrict__ gates,
+__global__ void lstm_cell_bwd_pointwise_kernel(const float* __restrict__ dh_a, int nparts, long part_stride,
+                                               const float* __restrict__ dh_b,
+                                               const float* dc_in, const float* __restrict__ gates,
                                                const float* __restrict__ c, const float* __restrict__ c_prev,
-                                               float* __restrict__ dG, float* __restrict__ dc_prev, int B, int Hs) {
+                                               float* __restrict__ dG, float* dc_prev, int B, int Hs) {
     const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= (long)B * Hs) return;
     const int b = idx / Hs, j = idx % Hs;
-    float dh = dh_a ? dh_a[idx] : 0.f;
+    float dh = 0.f;
+    for (int q = 0; q < nparts; ++q) dh += dh_a[idx + q * part_stride];
     if (dh_b) dh += dh_b[idx];
     const float* gp = gates + (long)b * 4 * Hs + j;
     const float ig = gp[0], fg = gp[Hs], gg = gp[2 * Hs], og = gp[3 * Hs];
@@ -220,10 +255,11 @@ __global__ void lstm_cell_bwd_pointwise_kernel(const float* __restrict__ dh_a, c
     dc_prev[idx] = dct * fg;
 }
 
-int lstm_cell_bwd_pointwise(const float* dh_a, const float* dh_b, const float* dc_in, const float* gates, const float* c,
-                            const float* c_prev, float* dG, float* dc_prev, int B, int Hs, hipStream_t stream) {
+int lstm_cell_bwd_pointwise(const float* dh_a, int nparts, long part_stride, const float* dh_b, const float* dc_in,
+                            const float* gates, const float* c, const float* c_prev, float* dG, float* dc_prev, int B, int Hs,
+                            hipStream_t stream) {
     const long n = (long)B * Hs;
-    hipLaunchKernelGGL(lstm_cell_bwd_pointwise_kernel, dim3(cdiv(n, 256)), dim3(256), 0, stream, dh_a, dh_b, dc_in, gates, c,
+    hipLaunchKernelGGL(lstm_cell_bwd_pointwise_kernel, dim3(cdiv(n, 256)), dim3(256), 0, stream, dh_a, nparts, part_stride, dh_b, dc_in, gates, c,
                        c_prev, dG, dc_prev, B, Hs);
     LAS_LAUNCH_CHECK();
     return LAS_OK;
@@ -354,23 +390,32 @@ __global__ __launch_bounds__(ATT_THREADS) void attn_step_fwd_kernel(AttnFwdArgs 
     float* ctxs = es + ((a.Tp + 3) & ~3);
     float* lg = ctxs + a.D;
     float* part = lg + ((a.V + 3) & ~3);
-    const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63;
+    const int b = blockIdx.x, hd = blockIdx.y, tid = threadIdx.x, lane = tid & 63;
     const float* __restrict__ hb = a.h_top + (long)b * a.Hs;
+    const long ldq = a.ldq ? a.ldq : a.M, ldctx = a.ldctx ? a.ldctx : a.D;
+    const float* __restrict__ w_phi = a.w_phi + (long)hd * a.M * a.Hs;      // this head's rows of phi
+    const float* __restrict__ b_phi = a.b_phi + (long)hd * a.M;
+    float mx = 0.f, inv = 0.f;
 
+    if (!(a.phases & 1)) {
+        // character-distribution-only pass (multi-head, free running): the context was produced by dim_reduce
+        for (int d = tid; d < a.D; d += ATT_THREADS) ctxs[d] = a.ctx_in[(long)b * a.D + d];
+        __syncthreads();
+    } else {
     // 1. query q = act(W_phi h + b_phi): 16 lanes per output row
     if (a.use_mlp) {
         const int ks = tid & 15;
         for (int m = tid >> 4; m < a.M; m += ATT_THREADS / 16) {
-            const float* wr = a.w_phi + (long)m * a.Hs;
+            const float* wr = w_phi + (long)m * a.Hs;
             float acc = 0.f;
 #pragma unroll 8
             for (int k = ks * 4; k < a.Hs; k += 64) acc = dot4(ld4(wr + k), ld4(hb + k), acc);
             acc = group_sum<16>(acc);
             if (ks == 0) {
-                acc += a.b_phi[m];
+                acc += b_phi[m];
                 if (a.relu) acc = fmaxf(acc, 0.f);
                 qs[m] = acc;
-                if (a.q_out) a.q_out[(long)b * a.M + m] = acc;
+                if (a.q_out) a.q_out[(long)b * ldq + (long)hd * a.M + m] = acc;
             }
         }
     } else {
@@ -392,13 +437,13 @@ __global__ __launch_bounds__(ATT_THREADS) void attn_step_fwd_kernel(AttnFwdArgs 
     }
     __syncthreads();
     // 3. softmax statistics over ALL frames (no mask, reference las_model.py:292), redundantly per wave (no barrier)
-    float mx = -INFINITY;
+    mx = -INFINITY;
     for (int t = lane; t < a.Tp; t += 64) mx = fmaxf(mx, es[t]);
     mx = wave_max(mx);
     float sm = 0.f;
     for (int t = lane; t < a.Tp; t += 64) sm += expf(es[t] - mx);
-    const float inv = 1.0f / wave_sum(sm);
-    for (int t = tid; t < a.Tp; t += ATT_THREADS) a.att_out[(long)b * a.Tp + t] = expf(es[t] - mx) * inv;
+    inv = 1.0f / wave_sum(sm);
+    for (int t = tid; t < a.Tp; t += ATT_THREADS) a.att_out[(long)hd * a.att_hs + (long)b * a.Tp + t] = expf(es[t] - mx) * inv;
     // 4. context = sum_t a_t feat_t : (column group, time slice) per thread, then LDS reduce over slices
     {
         const float* fb = a.feat + (long)b * a.Tp * a.D;
@@ -420,10 +465,11 @@ __global__ __launch_bounds__(ATT_THREADS) void attn_step_fwd_kernel(AttnFwdArgs 
         float acc = 0.f;
         for (int q = 0; q < NTQ; ++q) acc += part[(long)q * a.D + d];
         ctxs[d] = acc;
-        a.ctx_out[(long)b * a.D + d] = acc;
+        a.ctx_out[(long)b * ldctx + (long)hd * a.D + d] = acc;
     }
     __syncthreads();
-    if (a.logp_out == nullptr) return;       // deferred: one GEMM + log-softmax over all steps after the loop
+    }   // phases & 1
+    if (a.logp_out == nullptr || !(a.phases & 2)) return;   // deferred: one GEMM + log-softmax over all steps after the loop
     // 5. character distribution logits = W_c [h | ctx] + b_c : 32 lanes per output row
     {
         const int ks = tid & 31;
@@ -478,7 +524,8 @@ int attn_step_fwd(const AttnFwdArgs& a, hipStream_t stream) {
     LAS_REQUIRE(attn_dims_ok(a.Hs, a.D, Mq), "attention dims must be multiples of 4 (and <= 4096)");
     const int NTQ = min(ATT_THREADS / (a.D / 4), 64);
     const size_t smem = sizeof(float) * (size_t)(Mq + a.Tp + 4 + a.D + a.V + 4 + (size_t)NTQ * a.D);
-    hipLaunchKernelGGL(attn_step_fwd_kernel, dim3(a.B), dim3(ATT_THREADS), smem, stream, a);
+    LAS_REQUIRE(a.heads >= 1 && ((a.phases & 1) || a.ctx_in), "attention phases");
+    hipLaunchKernelGGL(attn_step_fwd_kernel, dim3(a.B, (a.phases & 1) ? a.heads : 1), dim3(ATT_THREADS), smem, stream, a);
     LAS_LAUNCH_CHECK();
     return LAS_OK;
 }
@@ -497,11 +544,16 @@ __global__ __launch_bounds__(ATT_THREADS) void attn_step_bwd_kernel(AttnBwdArgs 
     float* de = dctx + a.D;
     float* dq = de + ((a.Tp + 3) & ~3);
     float* part = dq + Mq;
-    const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63;
+    const int b = blockIdx.x, hd = blockIdx.y, tid = threadIdx.x, lane = tid & 63;
+    const long ldq = a.ldq ? a.ldq : a.M;
+    const float* __restrict__ w_phi = a.w_phi + (long)hd * a.M * a.Hs;     // this head's rows of phi
 
     const int K2 = a.Hs + a.D;
     float dh_keep[2] = {0.f, 0.f};                        // this thread's dh_top columns (k = tid, tid + 1024)
-    if (a.dcat_pre) {
+    if (!(a.phases & 1)) {
+        // per-head attention part only: this head's slice of the dim_reduce input gradient is the context gradient
+        for (int d = tid; d < a.D; d += ATT_THREADS) dctx[d] = a.dctx_in[(long)b * a.ld_dctx_in + (long)hd * a.D + d];
+    } else if (a.dcat_pre) {
         // [dh_top | dctx] = dz W_c was computed for every step by one GEMM before the loop
         for (int k = tid, it = 0; k < K2; k += ATT_THREADS, ++it) {
             float acc = a.dcat_pre[(long)b * K2 + k];
@@ -548,6 +600,11 @@ __global__ __launch_bounds__(ATT_THREADS) void attn_step_bwd_kernel(AttnBwdArgs 
         }
     }
     }
+    if (!(a.phases & 2)) {
+        // character-distribution part only (multi-head): hand the decoder-state gradient part to the summing kernel
+        for (int k = tid, it = 0; k < a.Hs && it < 2; k += ATT_THREADS, ++it) a.dh_top_out[(long)b * a.Hs + k] = dh_keep[it];
+        return;
+    }
     __syncthreads();
     // 3. da[t] = dctx . feat_t   (16 lanes per frame)
     {
@@ -565,7 +622,7 @@ __global__ __launch_bounds__(ATT_THREADS) void attn_step_bwd_kernel(AttnBwdArgs 
     __syncthreads();
     // 4. softmax backward: de = a * (da - sum_t a_t da_t)   (statistic redundantly per wave)
     {
-        const float* ab = a.att + (long)b * a.Tp;
+        const float* ab = a.att + (long)hd * a.att_hs + (long)b * a.Tp;
         float ls = 0.f;
         for (int t = lane; t < a.Tp; t += 64) ls = fmaf(ab[t], de[t], ls);
         const float sdot = wave_sum(ls);
@@ -573,7 +630,7 @@ __global__ __launch_bounds__(ATT_THREADS) void attn_step_bwd_kernel(AttnBwdArgs 
         for (int t = tid; t < a.Tp; t += ATT_THREADS) {
             const float v = ab[t] * (de[t] - sdot);
             de[t] = v;
-            a.de_out[(long)b * a.Tp + t] = v;
+            a.de_out[(long)hd * a.att_hs + (long)b * a.Tp + t] = v;
         }
     }
     __syncthreads();
@@ -598,8 +655,8 @@ __global__ __launch_bounds__(ATT_THREADS) void attn_step_bwd_kernel(AttnBwdArgs 
         float v = 0.f;
         for (int q = 0; q < NTQ; ++q) v += part[(long)q * Mq + m];
         if (a.use_mlp) {
-            if (a.relu && !(a.q[(long)b * a.M + m] > 0.f)) v = 0.f;
-            a.dqpre_out[(long)b * a.M + m] = v;
+            if (a.relu && !(a.q[(long)b * ldq + (long)hd * a.M + m] > 0.f)) v = 0.f;
+            a.dqpre_out[(long)b * ldq + (long)hd * a.M + m] = v;
         }
         dq[m] = v;
     }
@@ -613,11 +670,11 @@ __global__ __launch_bounds__(ATT_THREADS) void attn_step_bwd_kernel(AttnBwdArgs 
         }
         if (a.use_mlp) {
 #pragma unroll 8
-            for (int m = 0; m < a.M; ++m) acc = fmaf(dq[m], a.w_phi[(long)m * a.Hs + k], acc);
+            for (int m = 0; m < a.M; ++m) acc = fmaf(dq[m], w_phi[(long)m * a.Hs + k], acc);
         } else {
             acc += dq[k];
         }
-        if (a.dh_top_out) a.dh_top_out[(long)b * a.Hs + k] = acc;
+        if (a.dh_top_out) a.dh_top_out[(long)hd * a.dh_hs + (long)b * a.Hs + k] = acc;
         if (a.pw.gates) cell_bwd_point(a.pw, b, k, a.Hs, acc);      // top LSTM layer's pointwise step, fused
     }
 }
@@ -628,7 +685,9 @@ int attn_step_bwd(const AttnBwdArgs& a, hipStream_t stream) {
     LAS_REQUIRE(attn_dims_ok(a.Hs, a.D, Mq), "attention dims must be multiples of 4 (and <= 4096)");
     const int NTQ = min(ATT_THREADS / (Mq / 4), 64);
     const size_t smem = sizeof(float) * (size_t)(a.V + 4 + a.D + a.Tp + 4 + Mq + (size_t)NTQ * Mq);
-    hipLaunchKernelGGL(attn_step_bwd_kernel, dim3(a.B), dim3(ATT_THREADS), smem, stream, a);
+    LAS_REQUIRE(a.heads >= 1 && ((a.phases & 1) || a.dctx_in), "attention backward phases");
+    LAS_REQUIRE(a.Hs <= 2 * ATT_THREADS || (a.phases == 3), "split phases need Hs <= 2048");
+    hipLaunchKernelGGL(attn_step_bwd_kernel, dim3(a.B, (a.phases & 1) ? 1 : a.heads), dim3(ATT_THREADS), smem, stream, a);
     LAS_LAUNCH_CHECK();
     return LAS_OK;
 }

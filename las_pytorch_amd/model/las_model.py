@@ -170,13 +170,16 @@ class Attention(nn.Module):
         self.input_feature_dim = input_feature_dim
         if self.mode != "dot":
             raise NotImplementedError("only dot attention exists in the reference (las_model.py:315-317)")
-        if multi_head != 1:
-            raise NotImplementedError("multi-head attention (reference las_model.py:298-314) is not implemented by the HIP path yet")
+        if multi_head > 1 and not mlp_preprocess_input:
+            raise NotImplementedError("multi-head attention needs use_mlp_in_attention (phi/dim_reduce only exist with the MLP, "
+                                      "reference las_model.py:264-269)")
         self.activate = None
         if mlp_preprocess_input:
             self.preprocess_mlp_dim = preprocess_mlp_dim
             self.phi = nn.Linear(input_feature_dim, preprocess_mlp_dim * multi_head)
             self.psi = nn.Linear(input_feature_dim, preprocess_mlp_dim)
+            if self.multi_head > 1:
+                self.dim_reduce = nn.Linear(input_feature_dim * multi_head, input_feature_dim)
             if activate != "None":
                 if activate != "relu":
                     raise NotImplementedError(f"mlp_activate_in_attention={activate!r}: the HIP path implements 'relu' and 'None'")
@@ -186,48 +189,39 @@ class Attention(nn.Module):
         raise RuntimeError("Attention is fused into the Speller step kernels; call Speller.forward / forward_step")
 
 
-def _speller_desc(B, Tp, D, Hs, V, M, L, use_mlp, relu, lstm, rest):
+def _speller_desc(B, Tp, D, Hs, V, M, L, use_mlp, relu, lstm, rest, heads=1):
     """Fill the C descriptor from (already contiguous fp32) parameter tensors; returns it (pointers only — the
-    caller keeps the tensors alive)."""
+    caller keeps the tensors alive).  ``rest`` = [phi.w, phi.b, psi.w, psi.b, (dim_reduce.w, dim_reduce.b),] c.w, c.b"""
     d = SpellerDesc()
     d.B, d.Tp, d.D, d.Hs, d.V, d.M, d.L = B, Tp, D, Hs, V, M, L
-    d.use_mlp, d.relu, d.multi_head = int(use_mlp), int(relu), 1
+    d.use_mlp, d.relu, d.multi_head = int(use_mlp), int(relu), int(heads)
     for l in range(L):
         d.w_ih[l], d.w_hh[l], d.b_ih[l], d.b_hh[l] = (ptr(lstm[4 * l + i]) for i in range(4))
+    rest = list(rest)
     if use_mlp:
-        w_phi, b_phi, w_psi, b_psi, w_c, b_c = rest
-        d.w_phi, d.b_phi, d.w_psi, d.b_psi = ptr(w_phi), ptr(b_phi), ptr(w_psi), ptr(b_psi)
-    else:
-        w_c, b_c = rest
-    d.w_c, d.b_c = ptr(w_c), ptr(b_c)
+        d.w_phi, d.b_phi, d.w_psi, d.b_psi = (ptr(t) for t in rest[:4])
+        rest = rest[4:]
+        if heads > 1:
+            d.w_dr, d.b_dr = ptr(rest[0]), ptr(rest[1])
+            rest = rest[2:]
+    d.w_c, d.b_c = ptr(rest[0]), ptr(rest[1])
     return d
 
 
 class _SpellerFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, cfg, feat, labels, *params):
-        (U, teacher_forced, decode_mode, L, use_mlp, relu, M, V) = cfg
+        (U, teacher_forced, decode_mode, L, use_mlp, relu, M, V, heads) = cfg
         feat = _f32c(feat)
         B, Tp, D = feat.shape
         params = [_f32c(p) for p in params]
-        lstm = params[:4 * L]
-        rest = params[4 * L:]
+        lstm, rest = params[:4 * L], params[4 * L:]
         Hs = lstm[1].shape[1]
-        dev = feat.device
-        Lh = lib()
-        d = SpellerDesc()
-        d.B, d.Tp, d.D, d.Hs, d.V, d.M, d.L = B, Tp, D, Hs, V, M, L
-        d.use_mlp, d.relu, d.multi_head = int(use_mlp), int(relu), 1
-        for l in range(L):
-            d.w_ih[l], d.w_hh[l], d.b_ih[l], d.b_hh[l] = (ptr(lstm[4 * l + i]) for i in range(4))
-        if use_mlp:
-            w_phi, b_phi, w_psi, b_psi, w_c, b_c = rest
-            d.w_phi, d.b_phi, d.w_psi, d.b_psi = ptr(w_phi), ptr(b_phi), ptr(w_psi), ptr(b_psi)
-        else:
-            w_c, b_c = rest
-        d.w_c, d.b_c = ptr(w_c), ptr(b_c)
         if D != Hs:
             raise RuntimeError(f"Speller hidden_size ({Hs}) must equal 2*listener_hidden_size ({D}) (reference las_model.py:198)")
+        dev = feat.device
+        Lh = lib()
+        d = _speller_desc(B, Tp, D, Hs, V, M, L, use_mlp, relu, lstm, rest, heads)
         stream = stream_ptr()
         keys = None
         if use_mlp:
@@ -240,7 +234,7 @@ class _SpellerFn(torch.autograd.Function):
             labels = labels.contiguous()
             u_lab = labels.shape[1]
         logp = torch.empty(U, B, V, device=dev, dtype=torch.float32)
-        att = torch.empty(U, B, Tp, device=dev, dtype=torch.float32)
+        att = torch.empty(U, heads, B, Tp, device=dev, dtype=torch.float32)
         reserve = torch.empty(Lh.las_speller_reserve_floats(d, U), device=dev, dtype=torch.float32)
         check(Lh.las_speller_fwd(d, ptr(feat), ptr(keys), ptr(labels) if teacher_forced else None, u_lab, U,
                                  int(teacher_forced), decode_mode, ptr(logp), ptr(att), None, ptr(reserve), FLAG_STASH, stream))
@@ -254,24 +248,13 @@ class _SpellerFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, dlogp, _datt):
         feat, keys, logp, att, reserve, *params = ctx.saved_tensors
-        (U, teacher_forced, decode_mode, L, use_mlp, relu, M, V) = ctx.cfg
+        (U, teacher_forced, decode_mode, L, use_mlp, relu, M, V, heads) = ctx.cfg
         B, Tp, D, Hs = ctx.dims
         dev = feat.device
         dlogp = _f32c(dlogp)
-        lstm = params[:4 * L]
-        rest = params[4 * L:]
+        lstm, rest = params[:4 * L], params[4 * L:]
         Lh = lib()
-        d = SpellerDesc()
-        d.B, d.Tp, d.D, d.Hs, d.V, d.M, d.L = B, Tp, D, Hs, V, M, L
-        d.use_mlp, d.relu, d.multi_head = int(use_mlp), int(relu), 1
-        for l in range(L):
-            d.w_ih[l], d.w_hh[l], d.b_ih[l], d.b_hh[l] = (ptr(lstm[4 * l + i]) for i in range(4))
-        if use_mlp:
-            w_phi, b_phi, w_psi, b_psi, w_c, b_c = rest
-            d.w_phi, d.b_phi, d.w_psi, d.b_psi = ptr(w_phi), ptr(b_phi), ptr(w_psi), ptr(b_psi)
-        else:
-            w_c, b_c = rest
-        d.w_c, d.b_c = ptr(w_c), ptr(b_c)
+        d = _speller_desc(B, Tp, D, Hs, V, M, L, use_mlp, relu, lstm, rest, heads)
         grads = [torch.empty_like(p) for p in params]
         dfeat = torch.empty_like(feat)
         g = SpellerGrads()
@@ -279,9 +262,12 @@ class _SpellerFn(torch.autograd.Function):
             g.dw_ih[l], g.dw_hh[l], g.db_ih[l], g.db_hh[l] = (ptr(grads[4 * l + i]) for i in range(4))
         rg = grads[4 * L:]
         if use_mlp:
-            g.dw_phi, g.db_phi, g.dw_psi, g.db_psi, g.dw_c, g.db_c = (ptr(t) for t in rg)
-        else:
-            g.dw_c, g.db_c = (ptr(t) for t in rg)
+            g.dw_phi, g.db_phi, g.dw_psi, g.db_psi = (ptr(t) for t in rg[:4])
+            rg = rg[4:]
+            if heads > 1:
+                g.dw_dr, g.db_dr = ptr(rg[0]), ptr(rg[1])
+                rg = rg[2:]
+        g.dw_c, g.db_c = ptr(rg[0]), ptr(rg[1])
         g.dfeat = ptr(dfeat)
         work = torch.empty(Lh.las_speller_bwd_workspace_floats(d, U), device=dev, dtype=torch.float32)
         mode0 = int((not teacher_forced) and decode_mode == 0)
@@ -323,6 +309,8 @@ class Speller(nn.Module):
         a = self.attention
         if a.mlp_preprocess_input:
             ps += [a.phi.weight, a.phi.bias, a.psi.weight, a.psi.bias]
+            if a.multi_head > 1:
+                ps += [a.dim_reduce.weight, a.dim_reduce.bias]
         ps += [self.character_distribution.weight, self.character_distribution.bias]
         return ps
 
@@ -330,7 +318,7 @@ class Speller(nn.Module):
         a = self.attention
         use_mlp = bool(a.mlp_preprocess_input)
         cfg = (int(steps), bool(teacher_force), int(self.decode_mode), int(self.num_layers), use_mlp,
-               a.activate == "relu", int(a.preprocess_mlp_dim) if use_mlp else 0, int(self.label_dim))
+               a.activate == "relu", int(a.preprocess_mlp_dim) if use_mlp else 0, int(self.label_dim), int(a.multi_head))
         if not teacher_force and self.decode_mode not in (0, 1):
             raise NotImplementedError("decode_mode 2 (Categorical sampling, reference las_model.py:229-234) is not implemented")
         return _SpellerFn.apply(cfg, listener_feature, ground_truth if teacher_force else None, *self._params())
@@ -346,7 +334,7 @@ class Speller(nn.Module):
             max_step = ground_truth.size()[1]
         logp, att = self._run(listener_feature, ground_truth, teacher_force, max_step)
         raw_pred_seq = list(logp.unbind(0))                 # list[U] of (B,V)   (callers cat them, solver.py:68)
-        attention_record = [[a] for a in att.unbind(0)]     # list[U] of [ (B,T') ]
+        attention_record = [list(a.unbind(0)) for a in att.unbind(0)]     # list[U] of list[heads] of (B,T')
         return raw_pred_seq, attention_record
 
     def forward_step(self, input_word, last_hidden_state, listener_feature):
@@ -361,7 +349,8 @@ class Speller(nn.Module):
         Hs, L, V = self.hidden_size, self.num_layers, self.label_dim
         M = int(a.preprocess_mlp_dim) if use_mlp else 0
         params = [_f32c(p.detach()) for p in self._params()]
-        d = _speller_desc(B, Tp, D, Hs, V, M, L, use_mlp, a.activate == "relu", params[:4 * L], params[4 * L:])
+        heads = int(a.multi_head)
+        d = _speller_desc(B, Tp, D, Hs, V, M, L, use_mlp, a.activate == "relu", params[:4 * L], params[4 * L:], heads)
         if D != Hs:
             raise RuntimeError(f"Speller hidden_size ({Hs}) must equal 2*listener_hidden_size ({D}) (reference las_model.py:198)")
         x = _f32c(input_word.detach().reshape(B, -1))
@@ -376,12 +365,12 @@ class Speller(nn.Module):
         h_in = c_in = None
         if last_hidden_state is not None:
             h_in, c_in = (_f32c(t.detach()) for t in last_hidden_state)
-        logp = torch.empty(B, V, device=dev); ctx = torch.empty(B, D, device=dev); att = torch.empty(B, Tp, device=dev)
+        logp = torch.empty(B, V, device=dev); ctx = torch.empty(B, D, device=dev); att = torch.empty(heads, B, Tp, device=dev)
         h_out = torch.empty(L, B, Hs, device=dev); c_out = torch.empty(L, B, Hs, device=dev)
         work = torch.empty(Lh.las_speller_step_workspace_floats(d), device=dev, dtype=torch.float32)
         check(Lh.las_speller_step_fwd(d, ptr(feat), ptr(keys), ptr(x), ptr(h_in), ptr(c_in), ptr(logp), ptr(h_out), ptr(c_out),
                                       ptr(ctx), ptr(att), ptr(work), stream))
-        return logp, (h_out, c_out), ctx, [att]
+        return logp, (h_out, c_out), ctx, list(att.unbind(0))
 
 
 class LAS(nn.Module):

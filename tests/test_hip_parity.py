@@ -10,7 +10,7 @@ from hip_util import assert_close, build_las
 
 pytestmark = pytest.mark.gpu
 
-HIP_CASES = [n for n in ALL_CASES if n != "tiny_mh4"]
+HIP_CASES = list(ALL_CASES)
 
 
 def _check_err():
@@ -23,7 +23,8 @@ def _check_err():
 def test_forward_golden(name):
     g, info, sd_np, x, idx, lens, onehot = load_case(name)
     c = info["cfg"]
-    las = build_las(c, sd_np, max_label_len=info["free_len"], use_mlp=info["use_mlp"], activate=info["activate"])
+    las = build_las(c, sd_np, max_label_len=info["free_len"], use_mlp=info["use_mlp"], activate=info["activate"],
+                    multi_head=info["multi_head"])
     xt = torch.from_numpy(x).cuda()
     lab = torch.from_numpy(onehot).cuda()
     with torch.no_grad():
@@ -35,7 +36,7 @@ def test_forward_golden(name):
         logp = torch.stack(preds).cpu().numpy()
         assert_close(logp, g["tf_logp"], f"{name}/tf_logp")
         assert (logp.argmax(-1) == g["tf_argmax"]).all(), f"{name}: teacher-forced argmax differs"
-        att = torch.stack([a[0] for a in atts]).cpu().numpy()[None]
+        att = np.stack([torch.stack([a[hd] for a in atts]).cpu().numpy() for hd in range(info["multi_head"])], 0)
         want = g["tf_att"]
         assert_close(att if info["full"] else att[:, :, :, ::info["sub_t"]], want, f"{name}/tf_att", atol=1e-6)
         preds, _ = las(batch_data=xt, batch_label=lab, teacher_force_rate=0.0, is_training=False)
@@ -58,7 +59,8 @@ def _loss_ls(preds, lab, U):
 def test_grads_golden(name):
     g, info, sd_np, x, idx, lens, onehot = load_case(name)
     c = info["cfg"]
-    las = build_las(c, sd_np, max_label_len=info["free_len"], use_mlp=info["use_mlp"], activate=info["activate"])
+    las = build_las(c, sd_np, max_label_len=info["free_len"], use_mlp=info["use_mlp"], activate=info["activate"],
+                    multi_head=info["multi_head"])
     xt = torch.from_numpy(x).cuda()
     lab = torch.from_numpy(onehot).cuda()
     preds, _ = las(batch_data=xt, batch_label=lab, teacher_force_rate=1.0, is_training=True)
