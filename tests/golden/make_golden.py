@@ -201,3 +201,9 @@ if __name__ == "__main__" and len(sys.argv) > 1 and sys.argv[1] == "init":
 if __name__ == "__main__" and len(sys.argv) == 1:
     main()
     make_init_golden()
+
+
+# tests/golden/ref_checkpoint_tiny.pth.tar: a checkpoint package written by the REFERENCE's own LAS.serialize
+# (model/las_model.py:42-63) after one reference batch_iterator step on the tiny config (seed 29, scale 0.2); produced with
+#   build_ref(...); batch_iterator(...); torch.save(las.serialize(opt, 3, 1.25, 2.5), "ref_checkpoint_tiny.pth.tar")
+# and consumed by tests/test_cabi_and_host.py::test_reference_checkpoint_loads (checkpoint interop).

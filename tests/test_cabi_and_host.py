@@ -102,3 +102,26 @@ def test_solver_counterpart_matches_oracle():
                                  dict(listener_layers=2, speller_layers=2, max_label_len=info["U"], decode_mode=1), teacher_force=True)
     loss = S.label_smoothing_loss(torch.stack(preds, 1), torch.from_numpy(oh).float(), 0.1)
     assert abs(loss.item() - gold["step_loss"][0]) < 2e-6
+
+
+def test_reference_checkpoint_loads():
+    """Checkpoint interop: a package written by the reference's LAS.serialize
+    (model/las_model.py:42-63; resume path train.py:83-90) loads into the drop-in modules, and a package written by
+    the drop-in has the same structure."""
+    pkg = torch.load(os.path.join(GOLDEN_DIR, "ref_checkpoint_tiny.pth.tar"), weights_only=False)
+    assert pkg["etype"] is torch.nn.LSTM and pkg["epoch"] == 3 and pkg["tr_loss"] == 1.25
+    c = synth.CONFIGS["tiny"]
+    listener = Listener(input_feature_dim=pkg["einput"], hidden_size=pkg["ehidden"], num_layers=pkg["elayer"], rnn_unit="LSTM",
+                        use_gpu=False, dropout_rate=pkg["edropout"])
+    speller = Speller(vocab_size=pkg["dvocab_size"], hidden_size=pkg["dhidden"], rnn_unit="LSTM", num_layers=pkg["dlayer"],
+                      max_label_len=6, use_mlp_in_attention=True, mlp_dim_in_attention=c["M"], mlp_activate_in_attention="relu",
+                      listener_hidden_size=pkg["ehidden"], multi_head=1, decode_mode=1, use_gpu=False)
+    las = LAS(listener, speller)
+    missing = las.load_state_dict(pkg["state_dict"], strict=True)
+    assert not missing.missing_keys and not missing.unexpected_keys
+    opt = torch.optim.Adam(las.parameters(), lr=2e-4)
+    opt.load_state_dict(pkg["optim_dict"])                      # train.py:87
+    mine = las.serialize(opt, pkg["epoch"], pkg["tr_loss"], pkg["val_loss"])
+    assert set(mine) == set(pkg)
+    for k, v in pkg["state_dict"].items():
+        assert torch.equal(mine["state_dict"][k], v)
