@@ -131,6 +131,21 @@ int las_speller_bwd(const las_speller_desc* d, const float* feat, const float* k
                     const float* reserve, float* workspace, const las_speller_grads* g, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
+ * Caller-side contract on device (the code that CALLS the hot path, reference solver/solver.py).
+ *   logp is addressed as logp[s*stride_u + b*stride_b + c] so both the (U,B,V) buffer of las_speller_fwd and the
+ *   (B,U,V) tensor solver.py:68 builds can be passed; labels_onehot int64 (B, U_lab, V); U = min(U_lab, max_label_len).
+ * las_ls_loss: label_smoothing_loss (solver.py:33-45) and, if dlogp != NULL, its gradient wrt logp (same addressing
+ *   with dstride_*).  loss: 1 float; scratch: B floats.
+ * las_letter_error_rate: LetterErrorRate (solver.py:11-24) of the argmax sequences; ler_out: B floats;
+ *   work: 4*B*(U+1) int32.
+ * ---------------------------------------------------------------------------------------------- */
+int las_ls_loss(const float* logp, int64_t stride_u, int64_t stride_b, const int64_t* labels_onehot, int U, int U_lab,
+                int B, int V, float smoothing, float* loss, float* dlogp, int64_t dstride_u, int64_t dstride_b,
+                float* scratch, void* stream);
+int las_letter_error_rate(const float* logp, int64_t stride_u, int64_t stride_b, const int64_t* labels_onehot, int U,
+                          int U_lab, int B, int V, float* ler_out, int32_t* work, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
  * Building blocks exported for tests / micro-benchmarks.
  * ---------------------------------------------------------------------------------------------- */
 /* C[M,N] (+)= act(A(M,K) B(K,N) + bias0 + bias1); a_kc: A(m,k)=A[m*lda+k] else A[k*lda+m];

@@ -49,6 +49,9 @@ PROTOTYPES = {
     "las_speller_bwd_workspace_floats": (C.c_size_t, [C.POINTER(SpellerDesc), C.c_int]),
     "las_speller_bwd": (C.c_int, [C.POINTER(SpellerDesc), _f, _f, _f, _f, _f, C.c_int, C.c_int, _f, _f,
                                   C.POINTER(SpellerGrads), _f]),
+    "las_ls_loss": (C.c_int, [_f, C.c_int64, C.c_int64, _f, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, _f, _f, C.c_int64,
+                              C.c_int64, _f, _f]),
+    "las_letter_error_rate": (C.c_int, [_f, C.c_int64, C.c_int64, _f, C.c_int, C.c_int, C.c_int, C.c_int, _f, _f, _f]),
     "las_gemm_f32": (C.c_int, [_f] * 5 + [C.c_int] * 3 + [C.c_int64] * 3 + [C.c_int, C.c_int, C.c_int]
                      + [C.c_int64] * 3 + [C.c_int, C.c_int, C.c_int, _f]),
     "las_rec_xbuf_bytes": (C.c_size_t, [C.c_int, C.c_int]),

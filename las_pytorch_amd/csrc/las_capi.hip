@@ -564,6 +564,22 @@ int las_speller_bwd(const las_speller_desc* d, const float* feat, const float* k
     return LAS_OK;
 }
 
+// ---------------------------------------------------------------------------------------------- caller-side contract
+int las_ls_loss(const float* logp, int64_t stride_u, int64_t stride_b, const int64_t* labels_onehot, int U, int U_lab, int B, int V,
+                float smoothing, float* loss, float* dlogp, int64_t dstride_u, int64_t dstride_b, float* scratch, void* stream) {
+    LAS_REQUIRE(logp && labels_onehot && loss && scratch, "loss pointers");
+    LAS_REQUIRE(U > 0 && U <= U_lab && B > 0 && V > 0, "loss dims");
+    return ls_loss(logp, stride_u, stride_b, (const long long*)labels_onehot, U, U_lab, B, V, smoothing, scratch, loss, dlogp,
+                   dstride_u, dstride_b, (hipStream_t)stream);
+}
+
+int las_letter_error_rate(const float* logp, int64_t stride_u, int64_t stride_b, const int64_t* labels_onehot, int U, int U_lab,
+                          int B, int V, float* ler_out, int32_t* work, void* stream) {
+    LAS_REQUIRE(logp && labels_onehot && ler_out && work, "LER pointers");
+    LAS_REQUIRE(U > 0 && U <= U_lab && B > 0 && V > 0, "LER dims");
+    return ler(logp, stride_u, stride_b, (const long long*)labels_onehot, U, U_lab, B, V, ler_out, work, (hipStream_t)stream);
+}
+
 // ---------------------------------------------------------------------------------------------- building blocks
 int las_gemm_f32(const float* A, const float* B, float* C, const float* bias0, const float* bias1, int M, int N, int K,
                  int64_t lda, int64_t ldb, int64_t ldc, int a_kc, int b_kc, int batch, int64_t sA, int64_t sB, int64_t sC,

@@ -130,6 +130,10 @@ int add_inplace(float* dst, const float* src, long n, hipStream_t stream);
 int copy2d(const float* src, long lds, float* dst, long ldd, int rows, int cols, int accumulate, hipStream_t stream);
 int log_softmax_rows(float* x, long rows, int V, hipStream_t stream);
 int log_softmax_bwd_rows(const float* dlogp, const float* logp, float* dz, long rows, int V, hipStream_t stream);
+int ls_loss(const float* logp, long sU, long sB, const long long* labels, int U, int U_lab, int B, int V, float eps, float* part,
+            float* loss, float* dlogp, long dU, long dB, hipStream_t stream);
+int ler(const float* logp, long sU, long sB, const long long* labels, int U, int U_lab, int B, int V, float* out, int* work,
+        hipStream_t stream);
 int labels_to_y(const long long* labels, float* y_all, int B, int U, int V, int Vp, int u_lab, hipStream_t stream);
 
 }  // namespace las

@@ -120,4 +120,92 @@ int log_softmax_bwd_rows(const float* dlogp, const float* logp, float* dz, long 
     return LAS_OK;
 }
 
+// ------------------------------------------------------------------------------------------------
+// Caller-side contract on device (reference solver/solver.py): label-smoothing loss with its gradient, and the
+// letter error rate, so a training step needs no host round trip per batch.
+// ------------------------------------------------------------------------------------------------
+// loss = -(1/B) sum_b sum_s ( sum_c smooth[b,s,c] logp[b,s,c] ) / len_b ,  smooth = ((1-eps) y + eps/V) * sum_c y,
+// len_b = sum_{s,c} y   (solver.py:33-45).  One workgroup per utterance; per-utterance partial losses are summed in a
+// fixed order by the last-launched tiny kernel (deterministic).  dlogp = -smooth / (B len_b) * gscale.
+__global__ __launch_bounds__(256) void ls_loss_kernel(const float* __restrict__ logp, long sU, long sB,
+                                                      const long long* __restrict__ labels, int U, int U_lab, int B, int V,
+                                                      float eps, float* __restrict__ part, float* __restrict__ dlogp,
+                                                      long dU, long dB) {
+    __shared__ float red[256];
+    const int b = blockIdx.x, tid = threadIdx.x;
+    const long long* yb = labels + (long)b * U_lab * V;
+    float len = 0.f;
+    for (int i = tid; i < U * V; i += 256) len += (float)yb[i];          // rows s < U of a (U_lab, V) slab are contiguous
+    red[tid] = len; __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) { if (tid < o) red[tid] += red[tid + o]; __syncthreads(); }
+    len = red[0]; __syncthreads();
+    float acc = 0.f;
+    for (int s = tid; s < U; s += 256) {
+        float rs = 0.f;
+        for (int c = 0; c < V; ++c) rs += (float)yb[(long)s * V + c];
+        for (int c = 0; c < V; ++c) {
+            const float sm = ((1.f - eps) * (float)yb[(long)s * V + c] + eps / V) * rs;
+            acc += sm * logp[(long)s * sU + (long)b * sB + c];
+            if (dlogp) dlogp[(long)s * dU + (long)b * dB + c] = -sm / (B * len);
+        }
+    }
+    red[tid] = acc; __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) { if (tid < o) red[tid] += red[tid + o]; __syncthreads(); }
+    if (tid == 0) part[b] = red[0] / len;
+}
+__global__ void ls_loss_finish_kernel(const float* __restrict__ part, int B, float* __restrict__ loss) {
+    float s = 0.f;
+    for (int b = 0; b < B; ++b) s += part[b];
+    loss[0] = -s / B;
+}
+int ls_loss(const float* logp, long sU, long sB, const long long* labels, int U, int U_lab, int B, int V, float eps, float* part,
+            float* loss, float* dlogp, long dU, long dB, hipStream_t stream) {
+    hipLaunchKernelGGL(ls_loss_kernel, dim3(B), dim3(256), 0, stream, logp, sU, sB, labels, U, U_lab, B, V, eps, part, dlogp, dU, dB);
+    hipLaunchKernelGGL(ls_loss_finish_kernel, dim3(1), dim3(1), 0, stream, part, B, loss);
+    LAS_LAUNCH_CHECK();
+    return LAS_OK;
+}
+
+// Letter error rate (solver.py:11-24): prediction = argmax over V per step, zeros skipped, stop at the first 1; truth =
+// argmax of the label rows with 0 and 1 dropped; Levenshtein distance / len(truth).  One thread per utterance
+// (U <= 1024 symbols; rolling DP row in `work`, 2*(U+1) ints per utterance).  len(truth) == 0 gives +inf where the
+// reference raises ZeroDivisionError.
+__global__ void ler_kernel(const float* __restrict__ logp, long sU, long sB, const long long* __restrict__ labels, int U,
+                           int U_lab, int B, int V, float* __restrict__ out, int* __restrict__ work) {
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= B) return;
+    int* seqp = work + (long)b * 4 * (U + 1);      // [pred | truth | row0 | row1]
+    int* seqt = seqp + (U + 1);
+    int* prev = seqt + (U + 1);
+    int* cur = prev + (U + 1);
+    int np = 0, nt = 0;
+    bool stop = false;
+    for (int s = 0; s < U; ++s) {
+        const float* lp = logp + (long)s * sU + (long)b * sB;
+        int am = 0; float best = lp[0];
+        for (int c = 1; c < V; ++c) if (lp[c] > best) { best = lp[c]; am = c; }
+        if (!stop) { if (am == 1) stop = true; else if (am != 0) seqp[np++] = am; }
+        const long long* y = labels + ((long)b * U_lab + s) * V;
+        int tm = 0; long long tb = y[0];
+        for (int c = 1; c < V; ++c) if (y[c] > tb) { tb = y[c]; tm = c; }
+        if (tm != 0 && tm != 1) seqt[nt++] = tm;
+    }
+    for (int j = 0; j <= nt; ++j) prev[j] = j;
+    for (int i = 1; i <= np; ++i) {
+        cur[0] = i;
+        for (int j = 1; j <= nt; ++j) {
+            const int sub = prev[j - 1] + (seqp[i - 1] != seqt[j - 1]);
+            cur[j] = min(min(prev[j] + 1, cur[j - 1] + 1), sub);
+        }
+        int* t = prev; prev = cur; cur = t;
+    }
+    out[b] = (float)prev[nt] / (float)nt;
+}
+int ler(const float* logp, long sU, long sB, const long long* labels, int U, int U_lab, int B, int V, float* out, int* work,
+        hipStream_t stream) {
+    hipLaunchKernelGGL(ler_kernel, dim3(cdiv(B, 64)), dim3(64), 0, stream, logp, sU, sB, labels, U, U_lab, B, V, out, work);
+    LAS_LAUNCH_CHECK();
+    return LAS_OK;
+}
+
 }  // namespace las

@@ -37,6 +37,49 @@ def LetterErrorRate(pred_y, true_y):
     return ed_accumalate
 
 
+class _LSLossFn(torch.autograd.Function):
+    """label_smoothing_loss and its gradient in one HIP kernel (las_ls_loss); pred_y (B,U,V) log-probs on the GPU,
+    labels int64 one-hot (B,U_lab,V)."""
+
+    @staticmethod
+    def forward(ctx, pred_y, labels, smoothing):
+        from .. import _cabi
+        pred_y = pred_y.contiguous()
+        B, U, V = pred_y.shape
+        labels = labels.contiguous()
+        L = _cabi.lib()
+        loss = torch.empty(1, device=pred_y.device)
+        scratch = torch.empty(B, device=pred_y.device)
+        dlogp = torch.empty_like(pred_y) if ctx.needs_input_grad[0] else None
+        _cabi.check(L.las_ls_loss(_cabi.ptr(pred_y), V, U * V, _cabi.ptr(labels), U, labels.shape[1], B, V, float(smoothing),
+                                  _cabi.ptr(loss), _cabi.ptr(dlogp), V, U * V, _cabi.ptr(scratch), _cabi.stream_ptr()))
+        ctx.dlogp = dlogp
+        return loss[0]
+
+    @staticmethod
+    def backward(ctx, g):
+        return ctx.dlogp * g, None, None
+
+
+def label_smoothing_loss_device(pred_y, labels_onehot_int64, label_smoothing=0.1):
+    """Fused on-device form of ``label_smoothing_loss`` (same value and gradient)."""
+    return _LSLossFn.apply(pred_y, labels_onehot_int64, label_smoothing)
+
+
+def LetterErrorRate_device(pred_y, labels_onehot_int64):
+    """LetterErrorRate (solver/solver.py:11-24) computed on the GPU from log-probs (B,U,V) and int64 one-hot labels;
+    returns a (B,) float tensor on the device (one host copy when the caller wants the list)."""
+    from .. import _cabi
+    pred_y = pred_y.detach().contiguous()
+    B, U, V = pred_y.shape
+    labels = labels_onehot_int64.contiguous()
+    out = torch.empty(B, device=pred_y.device)
+    work = torch.empty(4 * B * (U + 1), dtype=torch.int32, device=pred_y.device)
+    _cabi.check(_cabi.lib().las_letter_error_rate(_cabi.ptr(pred_y), V, U * V, _cabi.ptr(labels), U, labels.shape[1], B, V,
+                                                  _cabi.ptr(out), _cabi.ptr(work), _cabi.stream_ptr()))
+    return out
+
+
 def label_smoothing_loss(pred_y, true_y, label_smoothing=0.1):
     """solver/solver.py:33-45 (pred_y log-probs (B,U,V); true_y one-hot floats padded with all-zero rows)."""
     assert pred_y.size() == true_y.size()
@@ -62,6 +105,10 @@ def batch_iterator(batch_data, batch_label, las_model, optimizer, tf_rate, is_tr
         true_y = torch.max(batch_label, dim=2)[1][:, :max_label_len].contiguous()
         loss = criterion(pred_y, true_y)
         batch_ler = LetterErrorRate(torch.max(pred_y.permute(0, 2, 1), dim=2)[1].cpu().numpy(), true_y.cpu().data.numpy())
+    elif pred_y.is_cuda and batch_label.dtype == torch.int64:
+        # device path: fused loss(+gradient) kernel and on-device LER: one host copy per batch instead of three
+        loss = label_smoothing_loss_device(pred_y, batch_label, label_smoothing)
+        batch_ler = LetterErrorRate_device(pred_y, batch_label).cpu().tolist()
     else:
         true_y = batch_label[:, :max_label_len, :].contiguous().type(torch.float32)
         loss = label_smoothing_loss(pred_y, true_y, label_smoothing=label_smoothing)

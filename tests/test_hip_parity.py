@@ -208,3 +208,38 @@ def test_forward_step_matches_oracle_and_loop():
         preds, _ = las.speller(feat, ground_truth=None, teacher_force_rate=0)
         assert_close(preds[2].cpu().numpy(), lp.cpu().numpy(), "loop vs step", rtol=1e-5, atol=1e-6)
     _check_err()
+
+
+def test_device_loss_and_ler_match_solver_counterpart():
+    """las_ls_loss / las_letter_error_rate against the torch form of solver.py:33-45 and the
+    Python LetterErrorRate, value and gradient, ragged labels included; and a full batch_iterator step on the device path."""
+    from las_pytorch_amd import synth
+    from las_pytorch_amd.solver import solver as S
+    g = torch.Generator().manual_seed(4)
+    B, U, V = 7, 19, 30
+    idx, lens = synth.make_labels(B, U, V, seed=4, ragged=True)
+    onehot = torch.from_numpy(synth.onehot_labels(idx, lens, V))
+    logits = torch.randn(B, U, V, generator=g)
+    ref_in = torch.log_softmax(logits, -1).requires_grad_(True)
+    want = S.label_smoothing_loss(ref_in, onehot.float(), 0.1)
+    want.backward()
+    dev_in = torch.log_softmax(logits, -1).cuda().requires_grad_(True)
+    got = S.label_smoothing_loss_device(dev_in, onehot.cuda(), 0.1)
+    (got * 1.0).backward()
+    assert abs(got.item() - want.item()) < 1e-6 * abs(want.item()) + 1e-7
+    assert_close(dev_in.grad.cpu().numpy(), ref_in.grad.numpy(), "dlogp", rtol=1e-5, atol=1e-9)
+    ler_dev = S.LetterErrorRate_device(dev_in, onehot.cuda()).cpu().numpy()
+    ler_ref = S.LetterErrorRate(ref_in.detach().argmax(-1).numpy(), onehot.argmax(-1).numpy())
+    np.testing.assert_allclose(ler_dev, np.array(ler_ref), rtol=1e-6)
+    # whole caller step (fwd, fused loss, bwd, clip, Adam, LER) == the golden reference step
+    gold, info, sd_np, x, _, _, oh = load_case("tiny_default")
+    las = build_las(info["cfg"], sd_np, max_label_len=info["free_len"])
+    opt = torch.optim.Adam(las.parameters(), lr=2e-4)
+    np.random.seed(0)
+    loss, ler = S.batch_iterator(torch.from_numpy(x).cuda(), torch.from_numpy(oh).cuda(), las, opt, tf_rate=1.0, is_training=True,
+                                 max_label_len=info["U"], label_smoothing=0.1)
+    assert abs(float(loss) - gold["step_loss"][0]) < 2e-5
+    np.testing.assert_allclose(np.array(ler), gold["step_ler"], rtol=1e-6)
+    sums = np.array([p.detach().double().sum().item() for p in las.parameters()])
+    np.testing.assert_allclose(sums, gold["step_param_sum"], rtol=1e-4, atol=2e-4)
+    _check_err()
