@@ -126,7 +126,7 @@ template <int H, int UW, bool STASH>
 __global__ __launch_bounds__(UW * (H / 16)) void rec_fwd_fast(float* __restrict__ gates, const float* __restrict__ w_hh_f,
                                                               const float* __restrict__ w_hh_r, float* __restrict__ out,
                                                               float* __restrict__ cbuf, float* __restrict__ hprev, int B,
-                                                              int T, u64* xbuf, unsigned* err, int dbg) {
+                                                              int T, u64* xbuf, unsigned* err, int force_agent) {
     constexpr int LPU = H / 16;             // lanes cooperating on one hidden unit (16 k-values each)
     constexpr int NT = UW * LPU;            // threads: UW hidden units owned by this workgroup
     constexpr int G = H / UW;               // workgroups per (utterance, direction)
@@ -139,7 +139,7 @@ __global__ __launch_bounds__(UW * (H / 16)) void rec_fwd_fast(float* __restrict_
 
     int group, member;
     decode_block<G>(2 * B, group, member);
-    const bool l2x = !(dbg & 64) && same_xcd_group<G>(xbuf + (long)2 * B * 2 * H + (long)group * XID_SLOTS, member, err, &xcd_flag);
+    const bool l2x = !force_agent && same_xcd_group<G>(xbuf + (long)2 * B * 2 * H + (long)group * XID_SLOTS, member, err, &xcd_flag);
     const int dir = group & 1, b = group >> 1;
     const float* __restrict__ w_hh = dir ? w_hh_r : w_hh_f;
     const int tid = threadIdx.x;
@@ -209,7 +209,7 @@ __global__ __launch_bounds__(UW * (H / 16)) void rec_fwd_fast(float* __restrict_
             const float og = sigmoidf_acc(s4[3] + pre[3]);
             c = fg * c + ig * gg;
             const float h = og * tanhf_acc(c);
-            if (G > 1 && !(dbg & 1)) {
+            if (G > 1) {
                 u64* gp64 = xg + (step & 1) * H + jc;
                 if (l2x) publish_granule_l2(gp64, epoch, h); else publish_granule(gp64, epoch, h);
             }
@@ -224,7 +224,7 @@ __global__ __launch_bounds__(UW * (H / 16)) void rec_fwd_fast(float* __restrict_
             }
 #pragma unroll
             for (int g = 0; g < 4; ++g) pre[g] = nxt[g];
-        } else if (poller && !(dbg & 1)) {
+        } else if (poller) {
             for (int fidx = tid - PS; fidx < H - UW; fidx += NT - PS) {
                 const int fu = fidx < member * UW ? fidx : fidx + UW;       // foreign hidden unit index
                 hs[cur ^ 1][fu] = poll_granule(xg + (step & 1) * H + fu, epoch, err);
@@ -468,7 +468,8 @@ int pblstm_rec_fwd(float* gates, const float* w_hh_f, const float* w_hh_r, float
     const int ngroups = 2 * B;
     if (fast_h(H) && !force_generic) {
         LAS_REQUIRE(xbuf && err, "hand-off buffers");
-        static int dbg = getenv("LAS_REC_DBG") ? atoi(getenv("LAS_REC_DBG")) : 0;
+        // LAS_REC_AGENT_HANDOFF=1 forces the placement-independent agent-scope hand-off even when a group shares an XCD (A/B tests)
+        static int dbg = getenv("LAS_REC_AGENT_HANDOFF") ? atoi(getenv("LAS_REC_AGENT_HANDOFF")) : 0;
         static int nb_env = getenv("LAS_REC_NB") ? atoi(getenv("LAS_REC_NB")) : 0;
         static int uw_env = getenv("LAS_REC_UW") ? atoi(getenv("LAS_REC_UW")) : 0;
         // UW: hidden units per workgroup.  Smaller UW = more CUs per sequence; two half-size workgroups per CU

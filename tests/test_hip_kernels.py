@@ -108,3 +108,13 @@ def test_recurrence_fwd_vs_oracle(H, B, T, generic):
     hp = hprev.cpu().numpy(); o = out.cpu().numpy()
     assert np.array_equal(hp[0][:, 1:], o[:, :-1, :H]) and (hp[0][:, 0] == 0).all()
     assert np.array_equal(hp[1][:, :-1], o[:, 1:, H:]) and (hp[1][:, -1] == 0).all()
+
+
+def test_recurrence_agent_scope_handoff_path():
+    """The placement-independent agent-scope hand-off (used when a group spans XCDs) must give the same result as the
+    same-XCD L2 path: run the H=256 recurrence test in a child process with LAS_REC_AGENT_HANDOFF=1."""
+    import os, subprocess, sys
+    env = dict(os.environ, LAS_REC_AGENT_HANDOFF="1")
+    r = subprocess.run([sys.executable, "-m", "pytest", "-q", "-x", __file__, "-k", "recurrence_fwd_vs_oracle and 256 and False",
+                        "-p", "no:cacheprovider"], env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
