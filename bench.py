@@ -139,6 +139,7 @@ def main():
     ap.add_argument("--batch", type=int, default=32, help="utterances per GPU (weak scaling: fixed per-GPU batch)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--no-secondary", action="store_true")
     ap.add_argument("--graph", type=int, default=0, help="1: replay fwd+loss+bwd as one captured HIP graph per step")
     args = ap.parse_args()
 
@@ -251,6 +252,23 @@ def main():
             res["roofline"] = roofline_rec_fwd(c, B, T)
         if world == 1 and not args.no_cpu_baseline:
             res["cpu_baseline"] = cpu_baseline(cfg_name, B, T, U, train)
+        if world == 1 and args.workload == "P_train" and not args.no_secondary:
+            # BASELINE.json configs[1] (small 128/256 model, forward only) measured beside the headline for reference
+            del las
+            torch.cuda.empty_cache()
+            las_s, c_s, _ = build_model("S", U, device)
+            xs = torch.from_numpy(synth.make_inputs(B, T, c_s["F"], seed=17)).to(device)
+            with torch.no_grad():
+                for _ in range(3):
+                    las_s(batch_data=xs, batch_label=lab, teacher_force_rate=1.0, is_training=True)
+                torch.cuda.synchronize()
+                t1 = time.perf_counter()
+                for _ in range(10):
+                    las_s(batch_data=xs, batch_label=lab, teacher_force_rate=1.0, is_training=True)
+                torch.cuda.synchronize()
+                dts = (time.perf_counter() - t1) / 10
+            res["config"]["secondary"] = {"workload": "S_fwd (BASELINE configs[1]): Listener 128x2 / Speller 256x2, forward only, same inputs",
+                                          "value": round(B / dts, 1), "unit": "utt/s", "ms_per_step": round(dts * 1e3, 3)}
         print(json.dumps(res), flush=True)
     if use_dist:
         dist.barrier()
