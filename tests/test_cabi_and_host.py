@@ -125,3 +125,31 @@ def test_reference_checkpoint_loads():
     assert set(mine) == set(pkg)
     for k, v in pkg["state_dict"].items():
         assert torch.equal(mine["state_dict"][k], v)
+
+
+def test_collate_contract_matches_reference_collate():
+    """las_pytorch_amd.data.collate_fn_device against a NumPy restatement of the reference's collate_fn
+    (utils/data.py:116-149): T padded to a multiple of 32, one-hot int64 targets padded with onehot(0)."""
+    from las_pytorch_amd.data import collate_fn_device
+    rng = np.random.default_rng(3)
+    batch = []
+    for i, (t, u) in enumerate([(70, 5), (33, 9), (64, 1)]):
+        feat = rng.standard_normal((t, 8)).astype(np.float32)
+        idx = rng.integers(2, 30, size=u)
+        onehot_rows = [np.eye(30)[j] for j in idx]                      # reference format: list of one-hot rows
+        batch.append((f"utt{i}", feat, t, onehot_rows if i != 1 else idx, u))
+    ids, feature, label = collate_fn_device(batch, device="cpu")
+    # reference collate, restated
+    T = 96                                                              # max 70 -> next multiple of 2**5
+    want_x = np.zeros((3, T, 8), np.float32)
+    want_y = np.zeros((3, 9, 30), np.int64)
+    for b, (_, feat, t, tgt, u) in enumerate(batch):
+        want_x[b, :t] = feat
+        rows = np.asarray(tgt) if np.asarray(tgt).ndim == 2 else np.eye(30)[np.asarray(tgt)]
+        want_y[b, :u] = rows
+        want_y[b, u:, 0] = 1                                            # OneHotEncode(PAD, 30) padding rows (data.py:133)
+    assert ids == ["utt0", "utt1", "utt2"]
+    np.testing.assert_array_equal(feature["inputs"].numpy(), want_x)
+    np.testing.assert_array_equal(label["targets"].numpy(), want_y)
+    assert feature["inputs_length"].tolist() == [70, 33, 64] and label["targets_length"].tolist() == [5, 9, 1]
+    assert label["targets"].dtype == torch.int64 and feature["inputs"].dtype == torch.float32
