@@ -35,6 +35,7 @@ WORKLOADS = {
     "P_fwd": ("P", 800, 128, False),
     "S_fwd": ("S", 800, 128, False),       # BASELINE configs[1]
     "P_long": ("P", 3000, 128, True),      # BASELINE configs[4] (use --batch 8)
+    "Y_train": ("Y", 800, 128, True),      # config/librispeech-config.yaml sizes (512x3 / 1024x2, 40-mel; yaml batch 16)
 }
 HBM_PEAK_GBS = 8000.0    # MI355X HBM3E spec peak (guides/MI355X_MICROARCH.md)
 

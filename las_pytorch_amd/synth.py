@@ -103,6 +103,7 @@ CONFIGS = {
     "tiny": dict(F=8, H=16, L=2, Hs=32, Ls=2, V=30, M=8),
     "S": dict(F=80, H=128, L=2, Hs=256, Ls=2, V=30, M=64),      # README.md:11 / BASELINE configs[0-1]
     "P": dict(F=80, H=256, L=3, Hs=512, Ls=2, V=30, M=64),      # paper-size, BASELINE configs[2-4]
+    "Y": dict(F=40, H=512, L=3, Hs=1024, Ls=2, V=30, M=64),     # the reference's config/librispeech-config.yaml as shipped
 }
 
 

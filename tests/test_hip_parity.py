@@ -85,6 +85,7 @@ def test_grads_golden(name):
 
 
 @pytest.mark.parametrize("cfg_name,B,T,U,scale", [("S", 5, 96, 7, None), ("P", 6, 64, 6, 0.12), ("tiny", 3, 24, 4, 0.4),
+                                                  ("Y", 3, 64, 5, 0.08),
                                                   ("S", 32, 800, 16, None), ("P", 32, 800, 16, None)])
 def test_forward_backward_vs_oracle(cfg_name, B, T, U, scale):
     """Fresh seeded inputs, sizes the goldens do not cover (odd batch, full LibriSpeech shape)."""
