@@ -3,6 +3,7 @@
 #include "../../include/las_hip.h"
 #include "las_common.h"
 #include "las_kernels.h"
+#include <algorithm>
 
 using namespace las;
 
@@ -201,7 +202,16 @@ int las_attn_keys_fwd(const las_speller_desc* d, const float* feat, float* keys,
     g.A = feat; g.lda = d->D; g.a_kc = true;
     g.B = d->w_psi; g.ldb = d->D; g.b_kc = true;
     g.C = keys; g.ldc = d->M; g.bias0 = d->b_psi;
-    g.M = d->B * d->Tp; g.N = d->M; g.K = d->D; g.splitk = 1; g.relu = d->relu;
+    g.M = d->B * d->Tp; g.N = d->M; g.K = d->D;
+    // a 64-column output gives only B*T'/128 tiles: split K over the chip and apply the activation in a second tiny pass
+    const long tiles = (long)cdiv(g.M, 128) * cdiv(g.N, 128);
+    if (tiles < 64 && g.K >= 256) {
+        g.splitk = (int)std::min<long>(g.K / 64, std::max<long>(1, 256 / tiles));
+        LAS_TRY(gemm_f32(g, stream));
+        if (d->relu) LAS_TRY(relu_inplace(keys, (long)g.M * g.N, stream));
+        return LAS_OK;
+    }
+    g.splitk = 1; g.relu = d->relu;
     return gemm_f32(g, stream);
 }
 

@@ -127,6 +127,7 @@ int attn_step_bwd(const AttnBwdArgs& a, hipStream_t stream);
 int colsum(const float* src, long ld, int rows, int cols, float* dst, int accumulate, hipStream_t stream);  // dst[c] (+)= sum_r src[r][c]
 int relu_mask_inplace(float* grad, const float* act, long n, hipStream_t stream);                           // grad = act>0 ? grad : 0
 int add_inplace(float* dst, const float* src, long n, hipStream_t stream);
+int relu_inplace(float* x, long n, hipStream_t stream);
 int copy2d(const float* src, long lds, float* dst, long ldd, int rows, int cols, int accumulate, hipStream_t stream);
 int log_softmax_rows(float* x, long rows, int V, hipStream_t stream);
 int log_softmax_bwd_rows(const float* dlogp, const float* logp, float* dz, long rows, int V, hipStream_t stream);

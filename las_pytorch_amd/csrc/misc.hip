@@ -37,6 +37,16 @@ int relu_mask_inplace(float* grad, const float* act, long n, hipStream_t stream)
     return LAS_OK;
 }
 
+__global__ void relu_kernel(float* __restrict__ x, long n) {
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) x[i] = fmaxf(x[i], 0.f);
+}
+int relu_inplace(float* x, long n, hipStream_t stream) {
+    hipLaunchKernelGGL(relu_kernel, dim3(cdiv(n, 256)), dim3(256), 0, stream, x, n);
+    LAS_LAUNCH_CHECK();
+    return LAS_OK;
+}
+
 __global__ void add_kernel(float* __restrict__ dst, const float* __restrict__ src, long n) {
     const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) dst[i] += src[i];
