@@ -228,7 +228,7 @@ int gemm_f32(const GemmDesc& d, hipStream_t stream) {
     if (d.splitk == 0) {
         // auto: few output tiles and a long K -> split K so the launch covers the chip (256 CUs)
         const long tiles = (long)gx * gy * batch;
-        if (!d.relu && tiles < 128 && d.K >= 1024) {
+        if (!d.relu && tiles < 128 && d.K >= 256) {
             // few output tiles, long K: one workgroup per CU with at least 4 k-tiles (64 k) each
             splitk = (int)min((long)cdiv(d.K, 4 * BK), max(1L, 256 / tiles));
         }

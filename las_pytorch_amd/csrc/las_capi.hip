@@ -305,7 +305,7 @@ int las_speller_fwd(const las_speller_desc* d, const float* feat, const float* k
         GemmDesc q;
         q.A = h_all + (size_t)(L - 1) * U * sH; q.lda = Hs; q.a_kc = true;
         q.B = d->w_c; q.ldb = Hs + D; q.b_kc = true; q.bias0 = d->b_c;
-        q.C = logp; q.ldc = V; q.M = U * B; q.N = V; q.K = Hs; q.splitk = 1;
+        q.C = logp; q.ldc = V; q.M = U * B; q.N = V; q.K = Hs; q.splitk = 0;      // auto split-K: only U*B/128 output tiles
         LAS_TRY(gemm_f32(q, stream));
         q.A = ctx_all + (size_t)B * D; q.lda = D; q.B = d->w_c + Hs; q.bias0 = nullptr; q.K = D; q.accumulate = true;
         LAS_TRY(gemm_f32(q, stream));
