@@ -6,22 +6,32 @@ namespace las {
 
 thread_local char g_err[512] = {0};
 
-__global__ void colsum_kernel(const float* __restrict__ src, long ld, int rows, int cols, float* __restrict__ dst,
-                              int rows_per_block) {
-    const int c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c >= cols) return;
+// dst[c] (+)= sum_r src[r][c]: a workgroup covers 64 columns x a slab of rows; 4 row-lanes per column accumulate
+// with 4 independent loads in flight each, LDS-combine, one atomic per column per workgroup
+__global__ __launch_bounds__(256) void colsum_kernel(const float* __restrict__ src, long ld, int rows, int cols,
+                                                     float* __restrict__ dst, int rows_per_block) {
+    __shared__ float part[4][64];
+    const int cl = threadIdx.x & 63, rl = threadIdx.x >> 6;
+    const int c = blockIdx.x * 64 + cl;
     const int r0 = blockIdx.y * rows_per_block, r1 = min(rows, r0 + rows_per_block);
-    float a0 = 0.f, a1 = 0.f;
-    int r = r0;
-    for (; r + 1 < r1; r += 2) { a0 += src[(long)r * ld + c]; a1 += src[(long)(r + 1) * ld + c]; }
-    if (r < r1) a0 += src[(long)r * ld + c];
-    atomicAdd(dst + c, a0 + a1);
+    float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+    if (c < cols) {
+        int r = r0 + rl;
+        for (; r + 12 < r1; r += 16) {
+            a0 += src[(long)r * ld + c]; a1 += src[(long)(r + 4) * ld + c];
+            a2 += src[(long)(r + 8) * ld + c]; a3 += src[(long)(r + 12) * ld + c];
+        }
+        for (; r < r1; r += 4) a0 += src[(long)r * ld + c];
+    }
+    part[rl][cl] = (a0 + a1) + (a2 + a3);
+    __syncthreads();
+    if (rl == 0 && c < cols) atomicAdd(dst + c, (part[0][cl] + part[1][cl]) + (part[2][cl] + part[3][cl]));
 }
 
 int colsum(const float* src, long ld, int rows, int cols, float* dst, int accumulate, hipStream_t stream) {
     if (!accumulate) LAS_HIP_CHECK(hipMemsetAsync(dst, 0, sizeof(float) * cols, stream));
-    const int rpb = 128;
-    dim3 grid(cdiv(cols, 256), cdiv(rows, rpb)), block(256);
+    const int rpb = 256;
+    dim3 grid(cdiv(cols, 64), cdiv(rows, rpb)), block(256);
     hipLaunchKernelGGL(colsum_kernel, grid, block, 0, stream, src, ld, rows, cols, dst, rpb);
     LAS_LAUNCH_CHECK();
     return LAS_OK;
