@@ -244,3 +244,32 @@ def test_device_loss_and_ler_match_solver_counterpart():
     sums = np.array([p.detach().double().sum().item() for p in las.parameters()])
     np.testing.assert_allclose(sums, gold["step_param_sum"], rtol=1e-4, atol=2e-4)
     _check_err()
+
+
+@pytest.mark.parametrize("cfg_name,B,T,U", [("P", 1, 8, 1), ("S", 1, 4, 2), ("tiny", 1, 4, 1), ("P", 2, 16, 3)])
+def test_edge_shapes_vs_oracle(cfg_name, B, T, U):
+    """Smallest legal shapes: one utterance, one encoder frame after the pyramid (T = 2**L), a single decode step
+    (no recurrent weight gradient), forward + backward against the oracle."""
+    from las_pytorch_amd import synth
+    from oracle import las_oracle as O
+    c = synth.CONFIGS[cfg_name]
+    sd_np = synth.make_state_dict(synth.config_shapes(cfg_name), seed=13, scale=0.1)
+    x = synth.make_inputs(B, T, c["F"], seed=13)
+    idx, lens = synth.make_labels(B, U, c["V"], seed=13)
+    idx[:, -1] = 5                                   # keep at least one real symbol when U == 1
+    onehot = synth.onehot_labels(idx, lens, c["V"])
+    sd = O.to_torch_sd(sd_np, requires_grad=True)
+    lab = torch.from_numpy(onehot)
+    preds_o, _ = O.las_forward(torch.from_numpy(x), lab, sd, dict(listener_layers=c["L"], speller_layers=c["Ls"], max_label_len=U,
+                                                                  decode_mode=1), teacher_force=True)
+    loss_o, _ = O.solver_step_loss(preds_o, lab, U, 0.1)
+    loss_o.backward()
+    las = build_las(c, sd_np, max_label_len=U)
+    preds, _ = las(batch_data=torch.from_numpy(x).cuda(), batch_label=lab.cuda(), teacher_force_rate=1.0, is_training=True)
+    assert_close(torch.stack(preds).detach().cpu().numpy(), torch.stack(preds_o).detach().numpy(), "logp")
+    loss = _loss_ls(preds, lab.cuda(), U)
+    loss.backward()
+    for k, p in las.named_parameters():
+        want = sd[k].grad.numpy()
+        assert_close(p.grad.cpu().numpy(), want, f"grad/{k}", rtol=3e-3, atol=max(1e-5 * float(np.abs(want).max()) + 1e-9, 2e-7))
+    _check_err()
