@@ -27,12 +27,12 @@
 extern "C" {
 #endif
 
-#define LAS_ABI_VERSION 2
+#define LAS_ABI_VERSION 3
 #define LAS_MAX_SPELLER_LAYERS 4
 
 /* flags */
 #define LAS_FLAG_STASH          1   /* keep what the backward pass needs (training) */
-#define LAS_FLAG_FORCE_GENERIC  2   /* use the generic (L2-streaming) recurrence kernels: A/B tests */
+#define LAS_FLAG_FORCE_GENERIC  2   /* use the generic kernels (L2-streaming recurrence, per-step speller launches): A/B tests */
 
 int las_abi_version(void);
 const char* las_last_error(void);
@@ -110,10 +110,12 @@ size_t las_speller_reserve_floats(const las_speller_desc* d, int U);
  *   teacher_forced: 1 -> step s+1 is fed labels[:, s] (las_model.py:216-217); 0 -> free running with
  *   decode_mode 0 (feed log-probs, :220-221) or 1 (feed one-hot argmax, :223-227).  Mode 2 (sampling) is
  *   not implemented.
- *   logp (U,B,V), att (U,heads,B,Tp), argmax (U,B) int32 or NULL.  keys may be NULL when !use_mlp. */
+ *   logp (U,B,V), att (U,heads,B,Tp), argmax (U,B) int32 or NULL.  keys may be NULL when !use_mlp.
+ *   err_word: device uint32 (see las_pblstm_fwd) the persistent teacher-forced decode kernel reports hand-off timeouts
+ *   through; NULL (or LAS_FLAG_FORCE_GENERIC) selects the per-step launch chain, which needs none. */
 int las_speller_fwd(const las_speller_desc* d, const float* feat, const float* keys,
                     const int64_t* labels_onehot, int U_lab, int U, int teacher_forced, int decode_mode,
-                    float* logp, float* att, int32_t* argmax, float* reserve, int flags, void* stream);
+                    float* logp, float* att, int32_t* argmax, float* reserve, uint32_t* err_word, int flags, void* stream);
 
 /* One decode step with caller-managed state: Speller.forward_step, reference model/las_model.py:178-184.
  *   input_word (B, V+Hs) = [y | context] as the reference concatenates it (:198,:236); h_in/c_in (L,B,Hs) or both NULL

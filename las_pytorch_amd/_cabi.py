@@ -43,7 +43,7 @@ PROTOTYPES = {
     "las_attn_keys_fwd": (C.c_int, [C.POINTER(SpellerDesc), _f, _f, _f]),
     "las_speller_reserve_floats": (C.c_size_t, [C.POINTER(SpellerDesc), C.c_int]),
     "las_speller_fwd": (C.c_int, [C.POINTER(SpellerDesc), _f, _f, _f, C.c_int, C.c_int, C.c_int, C.c_int, _f, _f, _f, _f,
-                                  C.c_int, _f]),
+                                  _f, C.c_int, _f]),
     "las_speller_step_workspace_floats": (C.c_size_t, [C.POINTER(SpellerDesc)]),
     "las_speller_step_fwd": (C.c_int, [C.POINTER(SpellerDesc)] + [_f] * 12),
     "las_speller_bwd_workspace_floats": (C.c_size_t, [C.POINTER(SpellerDesc), C.c_int]),

@@ -35,7 +35,7 @@ struct PblstmBwdLayout {
 };
 
 struct SpellerLayout {
-    size_t y_all, ctx_all, h_all, c_all, gates_all, q_all, w0p, ctxcat_all, total;
+    size_t y_all, ctx_all, h_all, c_all, gates_all, q_all, w0p, ctxcat_all, hx, total;
     int Vp;                    // label width padded to a multiple of 16: every cell operand is aligned and tail-free
     SpellerLayout(const las_speller_desc* d, int U) {
         size_t o = 0;
@@ -49,6 +49,7 @@ struct SpellerLayout {
         q_all = o; if (d->use_mlp) o += r4((size_t)U * B * d->M * d->multi_head);
         ctxcat_all = o; if (d->multi_head > 1) o += r4((size_t)U * B * d->multi_head * d->D);   // per-head contexts (dim_reduce input)
         w0p = o; o += r4((size_t)4 * d->Hs * (Vp + d->Hs));      // W_ih0 re-laid as [W_y | 0 | W_ctx], ld = Vp + Hs
+        hx = o; if (d->L == 2) o += r4((size_t)2 * U * 32 * d->Hs);   // hand-off copy of h for the persistent decode kernel
         total = o;
     }
 };
@@ -217,9 +218,12 @@ int las_attn_keys_fwd(const las_speller_desc* d, const float* feat, float* keys,
 
 size_t las_speller_reserve_floats(const las_speller_desc* d, int U) { return SpellerLayout(d, U).total; }
 
+// Profiling aid, deliberately not part of include/las_hip.h: per-phase shader-clock stamps of the persistent decode kernel.
+extern "C" void las_debug_persist_trace(unsigned long long* dev_buf) { speller_persist_set_trace(dev_buf); }
+
 int las_speller_fwd(const las_speller_desc* d, const float* feat, const float* keys, const int64_t* labels_onehot, int U_lab,
                     int U, int teacher_forced, int decode_mode, float* logp, float* att, int32_t* argmax, float* reserve,
-                    int flags, void* stream_) {
+                    uint32_t* err_word, int flags, void* stream_) {
     hipStream_t stream = (hipStream_t)stream_;
     LAS_TRY(check_desc(d));
     LAS_REQUIRE(U > 0, "decode steps");
@@ -229,7 +233,6 @@ int las_speller_fwd(const las_speller_desc* d, const float* feat, const float* k
     if (!teacher_forced && decode_mode != 0 && decode_mode != 1)
         return fail(LAS_ERR_UNSUPPORTED, "decode_mode %s%ld is not implemented by the HIP path", "", (long)decode_mode);
     LAS_REQUIRE((uintptr_t)reserve % 16 == 0, "reserve alignment");
-    (void)flags;
     const int B = d->B, Hs = d->Hs, V = d->V, D = d->D, Tp = d->Tp, L = d->L;
     SpellerLayout lay(d, U);
     float* y_all = reserve + lay.y_all;
@@ -250,7 +253,23 @@ int las_speller_fwd(const las_speller_desc* d, const float* feat, const float* k
     LAS_TRY(copy2d(d->w_ih[0], V + Hs, w0p, Vp + Hs, 4 * Hs, V, 0, stream));
     LAS_TRY(copy2d(d->w_ih[0] + V, V + Hs, w0p + Vp, Vp + Hs, 4 * Hs, Hs, 0, stream));
 
-    for (int s = 0; s < U; ++s) {
+    static const bool persist_on = !(getenv("LAS_SPELLER_PERSIST") && atoi(getenv("LAS_SPELLER_PERSIST")) == 0);
+    const bool persist = persist_on && teacher_forced && err_word && !(flags & LAS_FLAG_FORCE_GENERIC) &&
+                         speller_persist_eligible(B, Tp, Hs, D, d->M, V, L, d->multi_head, d->use_mlp);
+    if (persist) {
+        PersistFwd p;
+        p.w0p = w0p; p.Vp = Vp;
+        p.w_hh0 = d->w_hh[0]; p.w_ih1 = d->w_ih[1]; p.w_hh1 = d->w_hh[1];
+        p.b_ih0 = d->b_ih[0]; p.b_hh0 = d->b_hh[0]; p.b_ih1 = d->b_ih[1]; p.b_hh1 = d->b_hh[1];
+        p.w_phi = d->w_phi; p.b_phi = d->b_phi;
+        p.feat = feat; p.keys = keys; p.y_all = y_all;
+        p.ctx_all = ctx_all; p.h_all = h_all; p.c_all = c_all; p.gates_all = gates_all; p.q_all = q_all; p.att = att;
+        p.B = B; p.Tp = Tp; p.U = U; p.Hs = Hs; p.V = V; p.relu = d->relu;
+        p.hx = reserve + lay.hx;
+        p.err = err_word;
+        LAS_TRY(speller_persist_fwd(p, stream));
+    }
+    for (int s = 0; s < (persist ? 0 : U); ++s) {
         for (int l = 0; l < L; ++l) {
             CellSeg segs[3];
             int n = 0;

@@ -96,6 +96,23 @@ struct AttnFwdArgs {
 };
 int attn_step_fwd(const AttnFwdArgs& a, hipStream_t stream);
 
+// Persistent teacher-forced decode loop (speller_persist.hip): one launch for all U steps.  Pointers are the
+// SpellerLayout stash arrays; eligibility (shape / residency) must be checked first.
+struct PersistFwd {
+    const float* w0p; int Vp;                       // [W_y | 0 | W_ctx] shadow of W_ih0, ld = Vp + Hs
+    const float* w_hh0; const float* w_ih1; const float* w_hh1;
+    const float* b_ih0; const float* b_hh0; const float* b_ih1; const float* b_hh1;
+    const float* w_phi; const float* b_phi;
+    const float* feat; const float* keys; const float* y_all;
+    float* ctx_all; float* h_all; float* c_all; float* gates_all; float* q_all; float* att;
+    float* hx;                                      // 2*U*32*Hs floats: tiled hand-off copy of h (see speller_persist.hip)
+    int B, Tp, U, Hs, V, relu;
+    unsigned* err;
+};
+bool speller_persist_eligible(int B, int Tp, int Hs, int D, int M, int V, int L, int heads, int use_mlp);
+int speller_persist_fwd(const PersistFwd& p, hipStream_t stream);
+void speller_persist_set_trace(unsigned long long* dev_buf);   // profiling aid, see tools/ubench_persist_trace.py
+
 struct AttnBwdArgs {
     const float* dlogp;    // (B,V) upstream gradient of this step's log-probs (may include mode-0 feedback grad)
     const float* dcat_pre; // (B,Hs+D) or null: dz W_c precomputed for all steps by one GEMM (no gradient through y)

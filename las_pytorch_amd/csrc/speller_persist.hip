@@ -1,0 +1,578 @@
+// Persistent teacher-forced Speller decode loop for gfx950: ONE launch runs all U decode steps.
+//
+// Replaces the per-step launch chain (lstm_cell_fwd x2 + attn_step_fwd, speller.hip) for the training forward of the
+// reference's Speller.forward (model/las_model.py:186-238, teacher-forced branch :207-209) when the shapes allow it.
+// The stepwise kernels stay the general path (free-running decode, multi-head, long T', large batches).
+//
+// Why: a decode step is a chain of three dependent phases.  As three kernels each phase pays ~4 us of launch/drain
+// floor plus ~4 us of L2->CU operand traffic (every workgroup re-reads the weights it used one step ago).  Here
+//   * Hs/4 "cell" workgroups each own 4 hidden units of BOTH LSTM layers for the whole utterance batch and keep their
+//     rows of W_ih/W_hh in VGPRs (36 floats per lane at Hs=512) for all U steps; the cell state c never leaves the
+//     workgroup.  The batch is the M dimension of v_mfma_f32_16x16x4_f32 (exact fp32), the 16 waves split K.
+//   * B "attention" workgroups each own one utterance and keep its listener features in VGPRs (<=13 float4 per lane),
+//     its keys in LDS and W_phi in VGPRs.
+//   * phases hand data over through the per-step stash arrays the backward pass needs anyway (h_all, ctx_all), which
+//     the host pre-fills with a sentinel bit pattern (0xFFFFFFFF, never produced by the kernels): producers write with
+//     agent-scope (write-through) stores, consumers poll the very words they need with agent-scope loads until no
+//     sentinel is left — the data is its own flag, no counters, no fences, no epochs.
+//   * only the operand the chain just produced is multiplied on the critical path: the recurrent halves
+//     (W_hh h_{s}) and the label half (W_y y_{s+1}) of the NEXT step's gates are accumulated while the attention
+//     workgroups are busy (the h_0 tile loaded for layer 1 is reused in registers for layer 0's recurrent half).
+// All spins are bounded and report through the device error word (results are then invalid, never a hang).
+#include "las_common.h"
+#include "las_kernels.h"
+#include <algorithm>
+#include <type_traits>
+
+namespace las {
+
+namespace {
+
+using u64 = unsigned long long;
+constexpr int PS_THREADS = 1024, PS_NW = 16;
+constexpr unsigned PS_SENT = 0xFFFFFFFFu;
+constexpr unsigned PS_SPIN_LIMIT = 1u << 21;
+constexpr int PS_NI = 7;           // listener frames held per attention lane
+constexpr int PS_SPLIT = 2;        // attention workgroups per utterance (each owns D/PS_SPLIT context columns)
+constexpr int PS_M = 64;           // attention MLP width handled by the persistent kernel
+constexpr int PS_KLD = PS_M + 4;   // LDS row stride of the keys (bank spread)
+
+__device__ __forceinline__ f32x4 ld4p(const float* p) { return *reinterpret_cast<const f32x4*>(p); }
+// Per-lane BYTE offset that the optimiser must treat as new in every loop iteration: without this it hoists one 64-bit
+// (pointer + lane offset) pair per access out of the step loop, which costs ~30 VGPRs and ends in scratch spills on the
+// critical path.  With it the access is `uniform base (SGPR pair) + 32-bit lane offset`.
+__device__ __forceinline__ unsigned opaque(unsigned v) { asm volatile("" : "+v"(v)); return v; }
+template <class T>
+__device__ __forceinline__ T* at_bytes(T* base, unsigned byte_off) {
+    return reinterpret_cast<T*>(reinterpret_cast<char*>(const_cast<typename std::remove_const<T>::type*>(base)) + byte_off);
+}
+
+__device__ __forceinline__ f32x4 ld4_agent(const float* p) {
+    const u64* q = reinterpret_cast<const u64*>(p);
+    const u64 lo = __hip_atomic_load(q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const u64 hi = __hip_atomic_load(q + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    f32x4 v;
+    v[0] = __uint_as_float((unsigned)lo); v[1] = __uint_as_float((unsigned)(lo >> 32));
+    v[2] = __uint_as_float((unsigned)hi); v[3] = __uint_as_float((unsigned)(hi >> 32));
+    return v;
+}
+__device__ __forceinline__ bool has_sentinel(const f32x4 v) {
+    return __float_as_uint(v[0]) == PS_SENT || __float_as_uint(v[1]) == PS_SENT || __float_as_uint(v[2]) == PS_SENT ||
+           __float_as_uint(v[3]) == PS_SENT;
+}
+// a value that is published must never look like the sentinel (only a NaN could): canonicalise NaNs
+__device__ __forceinline__ unsigned pub_bits(float v) { return (v != v) ? 0x7FC00000u : __float_as_uint(v); }
+__device__ __forceinline__ void st1_agent(float* p, float v) {
+    __hip_atomic_store(reinterpret_cast<unsigned*>(p), pub_bits(v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ void st4_agent(float* p, const f32x4 v) {
+    u64* q = reinterpret_cast<u64*>(p);
+    __hip_atomic_store(q, (u64)pub_bits(v[0]) | ((u64)pub_bits(v[1]) << 32), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __hip_atomic_store(q + 1, (u64)pub_bits(v[2]) | ((u64)pub_bits(v[3]) << 32), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ void lds_barrier() {     // orders LDS traffic only (does not wait for global stores)
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+}
+// bounded-spin bookkeeping shared by every poller; returns true when the caller must give up
+__device__ __forceinline__ bool spin_expired(unsigned& spins, unsigned* err, unsigned code) {
+    ++spins;
+    if ((spins & 127u) == 0) {
+        if (spins > PS_SPIN_LIMIT) { atomicExch(err, code); return true; }
+        if (__hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) return true;
+    }
+    __builtin_amdgcn_s_sleep(1);
+    return false;
+}
+// Reductions with DPP row operations (1 VALU instruction per level) instead of __shfl_xor (a ds_bpermute, i.e. an LDS
+// round trip, per level): these sit on the serial chain of every decode step.
+__device__ __forceinline__ float dpp_f(float v, int ctrl) {
+    switch (ctrl) {
+        case 0: return __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, v), 0xB1, 0xF, 0xF, true));    // quad_perm [1,0,3,2]
+        case 1: return __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, v), 0x4E, 0xF, 0xF, true));    // quad_perm [2,3,0,1]
+        case 2: return __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, v), 0x141, 0xF, 0xF, true));   // row_half_mirror
+        default: return __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, v), 0x140, 0xF, 0xF, true));  // row_mirror
+    }
+}
+template <int W>
+__device__ __forceinline__ float gsum(float v) {      // sum over aligned groups of W <= 16 lanes, result in every lane
+    if (W >= 2) v += dpp_f(v, 0);
+    if (W >= 4) v += dpp_f(v, 1);
+    if (W >= 8) v += dpp_f(v, 2);
+    if (W >= 16) v += dpp_f(v, 3);
+    return v;
+}
+__device__ __forceinline__ float lane_f(float v, int l) { return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), l)); }
+__device__ __forceinline__ float wsum(float v) {
+    v = gsum<16>(v);
+    return (lane_f(v, 0) + lane_f(v, 16)) + (lane_f(v, 32) + lane_f(v, 48));
+}
+__device__ __forceinline__ float wmax(float v) {
+    v = fmaxf(v, dpp_f(v, 0)); v = fmaxf(v, dpp_f(v, 1)); v = fmaxf(v, dpp_f(v, 2)); v = fmaxf(v, dpp_f(v, 3));
+    return fmaxf(fmaxf(lane_f(v, 0), lane_f(v, 16)), fmaxf(lane_f(v, 32), lane_f(v, 48)));
+}
+__device__ __forceinline__ float dot4p(const f32x4 a, const f32x4 b, float acc) {
+    acc = fmaf(a[0], b[0], acc); acc = fmaf(a[1], b[1], acc); acc = fmaf(a[2], b[2], acc); acc = fmaf(a[3], b[3], acc);
+    return acc;
+}
+
+}  // namespace
+
+struct PersistArgs {
+    const float* w0p; long ldw0; int Vp;      // [W_y | 0 | W_ctx] shadow of W_ih0 (ld = Vp + Hs)
+    const float* w_hh0; const float* w_ih1; const float* w_hh1;
+    const float* b_ih0; const float* b_hh0; const float* b_ih1; const float* b_hh1;
+    const float* w_phi; const float* b_phi;
+    const float* feat; const float* keys; const float* y_all;
+    float* ctx_all; float* h_all; float* c_all; float* gates_all; float* q_all; float* att;
+    float* hx;                     // hand-off copy of h: [layer][step][unit tile Hs/4][row 32][4], sentinel-prefilled
+    int B, Tp, U, relu;
+    unsigned* err;
+    unsigned long long* trace;     // profiling aid (tools/ubench_persist_trace.py): shader-clock stamps of workgroup 0 of each role
+};
+
+#define PS_STAMP(role, s, k) do { if (a.trace && first_wg && threadIdx.x == 0) a.trace[((size_t)(role) * a.U + (s)) * 8 + (k)] = wall_clock64(); } while (0)
+
+// ------------------------------------------------------------------------------------------------ cell workgroups
+template <int HS>
+struct CellRole {
+    static constexpr int NF = HS / 256;                 // 16-wide k-blocks of an Hs-wide operand per wave
+    static constexpr int RED = PS_NW * 2 * 16 * 17;     // floats of the per-wave partial tile buffer
+    static constexpr int RED2 = 2 * 2 * 16 * 17;
+    static constexpr int LDS_FLOATS = RED + RED2 + 2 * 4 * 128;       // + summed biases of the 128 cell lanes
+
+    // x tile of this wave: rows = utterances (two 16-row M-tiles), columns = its k-blocks.  Polls until no sentinel.
+    // KIND 0: tile of h (each 4-column group comes from one cell workgroup); KIND 1: tile of the context (each row half
+    // comes from one attention workgroup); KIND 2: data known to be published long ago (no canary).
+    //  1. canary: one agent-scope dword per lane, the lanes of the wave covering every producer of this wave's tile;
+    //  2. the tile itself with PLAIN loads: the 16 cell workgroups of an XCD share them through its L2 instead of each
+    //     pulling 64 KB over the fabric (agent-scope loads bypass the L2: 8.4 MB per phase, measured ~3.5 us);
+    //  3. every consumed word is still checked against the sentinel; a slot that raced ahead of its producer (its stale
+    //     line now sits in this XCD's L2) is re-read with agent-scope loads until it is complete.
+    struct TileAddr {            // element offsets of this lane inside a (B, HS) slab; identical for every tile
+        // unsigned 32-bit element offsets from a wave-uniform base: the loads use the SGPR-base + VGPR-offset form
+        // instead of one hoisted 64-bit address pair per slot
+        unsigned x[NF][2];       // (bytes) its float4 of k-block f, M-tile mt (row-major slab: the context)
+        unsigned hx[NF][2];      // the same float4 in the tiled hand-off copy of h
+        bool ok[2];              // row < B
+        unsigned canary[2];      // [KIND]: the dword this lane watches (KIND 0 in the tiled copy, KIND 1 row-major)
+    };
+    static __device__ __forceinline__ TileAddr tile_addr(int B, int wave, int lane) {
+        TileAddr t;
+        const int r = lane & 15, kq = lane >> 4;
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt) {
+            t.ok[mt] = mt * 16 + r < B;
+#pragma unroll
+            for (int f = 0; f < NF; ++f) {
+                t.x[f][mt] = 4u * ((t.ok[mt] ? mt * 16 + r : 0) * HS + (wave * NF + f) * 16 + kq * 4);
+                t.hx[f][mt] = 4u * ((((wave * NF + f) * 4 + kq) * 32 + (t.ok[mt] ? mt * 16 + r : 0)) * 4);
+            }
+        }
+        {
+            constexpr int NP = 4 * NF, RS = 64 / NP;          // producers per wave tile, row samples per producer
+            const int pidx = lane % NP, rs = lane / NP;
+            t.canary[0] = 4u * ((((wave * NF + (pidx >> 2)) * 4 + (pidx & 3)) * 32 + min(B - 1, (rs + 1) * (32 / RS) - 1)) * 4 + 3);
+            t.canary[1] = 4u * (min(B - 1, lane & 31) * HS + (wave * NF + ((lane >> 5) % NF)) * 16 + 15);
+        }
+        return t;
+    }
+    template <int KIND>
+    static __device__ __forceinline__ int poll_tile(const float* base, const TileAddr& t, f32x4 (&x)[NF][2],
+                                                    unsigned* err) {
+        unsigned spins = 0;
+        int slow = 0;
+        if (KIND != 2) {
+            const unsigned* cp = reinterpret_cast<const unsigned*>(at_bytes(base, opaque(t.canary[KIND == 0 ? 0 : 1])));
+            for (;;) {
+                const unsigned v = __hip_atomic_load(cp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (!__any(v == PS_SENT)) break;
+                if (spin_expired(spins, err, 0xDEAD0011u)) break;
+            }
+        }
+        asm volatile("" ::: "memory");
+        bool need[NF][2];
+        bool bad = false;
+#pragma unroll
+        for (int f = 0; f < NF; ++f)
+#pragma unroll
+            for (int mt = 0; mt < 2; ++mt) {
+                // ordinary (L2-cacheable) load; the compiler fences around this block keep it between canary and check
+                const f32x4 v = *reinterpret_cast<const f32x4*>(at_bytes(base, opaque(KIND == 0 ? t.hx[f][mt] : t.x[f][mt])));
+                const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+                x[f][mt] = t.ok[mt] ? v : z;
+                need[f][mt] = __any(t.ok[mt] && has_sentinel(v));
+                bad |= need[f][mt];
+            }
+        asm volatile("" ::: "memory");
+        // slow path: only the (wave-uniform) slots in which some lane still saw the sentinel, with L2-bypassing loads
+        while (bad) {
+            if (spin_expired(spins, err, 0xDEAD0012u)) break;
+            bad = false;
+            ++slow;
+#pragma unroll
+            for (int f = 0; f < NF; ++f)
+#pragma unroll
+                for (int mt = 0; mt < 2; ++mt) {
+                    if (need[f][mt]) {
+                        const f32x4 v = ld4_agent(at_bytes(base, opaque(KIND == 0 ? t.hx[f][mt] : t.x[f][mt])));
+                        const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+                        x[f][mt] = t.ok[mt] ? v : z;
+                        need[f][mt] = __any(t.ok[mt] && has_sentinel(v));
+                        bad |= need[f][mt];
+                    }
+                }
+        }
+        return slow;
+    }
+
+    static __device__ __forceinline__ void mfma_tile(const f32x4 (&x)[NF][2], const float (&w)[NF][4], f32x4 (&acc)[2]) {
+#pragma unroll
+        for (int f = 0; f < NF; ++f)
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+#pragma unroll
+                for (int mt = 0; mt < 2; ++mt)
+                    acc[mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(x[f][mt][e], w[f][e], acc[mt], 0, 0, 0);
+    }
+
+    static __device__ void run(const PersistArgs& a, float* smem) {
+        float (*red)[2][16][17] = reinterpret_cast<float (*)[2][16][17]>(smem);
+        float (*red2)[2][16][17] = reinterpret_cast<float (*)[2][16][17]>(smem + RED);
+        const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+        const int r = lane & 15, kq = lane >> 4;
+        const int j0 = blockIdx.x * 4;
+        const bool first_wg = blockIdx.x == 0;
+        const int B = a.B, U = a.U;
+        const long wrow = (long)(r >> 2) * HS + j0 + (r & 3);       // tile column n = gate*4 + unit
+        const size_t sH = (size_t)B * HS;
+        constexpr size_t HXS = (size_t)32 * HS;          // floats of one tiled hand-off slab
+
+        // ---- resident weights (MFMA B operands): W[wrow][16*blk + 4*kq + e]
+        float Wc0[NF][4], Wh0[NF][4], Wi1[NF][4], Wh1[NF][4], Wy[1][4];
+#pragma unroll
+        for (int f = 0; f < NF; ++f) {
+            const int k = (wave * NF + f) * 16 + kq * 4;
+            const f32x4 c0 = ld4p(a.w0p + wrow * a.ldw0 + a.Vp + k);
+            const f32x4 h0 = ld4p(a.w_hh0 + wrow * HS + k);
+            const f32x4 i1 = ld4p(a.w_ih1 + wrow * HS + k);
+            const f32x4 h1 = ld4p(a.w_hh1 + wrow * HS + k);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { Wc0[f][e] = c0[e]; Wh0[f][e] = h0[e]; Wi1[f][e] = i1[e]; Wh1[f][e] = h1[e]; }
+        }
+        const bool ywave = wave * 16 < a.Vp;            // label columns: one k-block per wave (Vp <= 256)
+        {
+            const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+            const f32x4 y = ywave ? ld4p(a.w0p + wrow * a.ldw0 + wave * 16 + kq * 4) : z;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) Wy[0][e] = y[e];
+        }
+        // ---- cell non-linearity lanes: (utterance pb, unit pu)
+        const int pb = tid >> 2, pu = tid & 3;
+        const bool pw = tid < 128 && pb < B;
+        const int pmt = (pb >> 4) & 1, pm = pb & 15;
+        float c0 = 0.f, c1 = 0.f;
+        float* bias = smem + RED + RED2;                 // [layer][gate][cell lane]: registers are for the weights
+        if (tid < 128) {
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const int row = g * HS + j0 + pu;
+                bias[g * 128 + tid] = a.b_ih0[row] + a.b_hh0[row];
+                bias[(4 + g) * 128 + tid] = a.b_ih1[row] + a.b_hh1[row];
+            }
+        }
+        // stage-1 reduction lane: sums 8 waves' partials of one tile element
+        const int rh = tid >> 9, ri = tid & 511;
+        const int rmt = ri >> 8, rm = (ri >> 4) & 15, rn = ri & 15;
+
+        auto load_y = [&](int s, f32x4 (&y)[1][2]) {
+#pragma unroll
+            for (int mt = 0; mt < 2; ++mt) {
+                const bool ok = ywave && mt * 16 + r < B;
+                const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+                const f32x4 v = ld4p(at_bytes(a.y_all + (size_t)s * B * a.Vp,
+                                              opaque(4u * ((ok ? mt * 16 + r : 0) * a.Vp + (ok ? wave * 16 + kq * 4 : 0)))));
+                y[0][mt] = ok ? v : z;
+            }
+        };
+        // gates of one layer: reduce the 16 waves' partial tiles, apply the cell, publish h, stash c / gates
+        auto finish = [&](const f32x4 (&acc)[2], float& c, int layer, int s) {
+#pragma unroll
+            for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+                for (int i = 0; i < 4; ++i) red[wave][mt][kq * 4 + i][r] = acc[mt][i];
+            lds_barrier();
+            {
+                float t = 0.f;
+#pragma unroll
+                for (int w = 0; w < 8; ++w) t += red[rh * 8 + w][rmt][rm][rn];
+                red2[rh][rmt][rm][rn] = t;
+            }
+            lds_barrier();
+            if (pw) {
+                float g4[4];
+#pragma unroll
+                for (int g = 0; g < 4; ++g)
+                    g4[g] = red2[0][pmt][pm][g * 4 + pu] + red2[1][pmt][pm][g * 4 + pu] + bias[(layer * 4 + g) * 128 + tid];
+                const float ig = sigmoidf_acc(g4[0]), fg = sigmoidf_acc(g4[1]), gg = tanhf_acc(g4[2]), og = sigmoidf_acc(g4[3]);
+                c = fg * c + ig * gg;
+                const float h = og * tanhf_acc(c);
+                const size_t slab = ((size_t)layer * U + s) * sH;           // wave-uniform
+                const unsigned o = opaque(4u * ((unsigned)pb * HS + j0 + pu));
+                *at_bytes(a.h_all + slab, o) = h;
+                st1_agent(at_bytes(a.hx + ((size_t)layer * U + s) * HXS, opaque(4u * (((unsigned)blockIdx.x * 32 + pb) * 4 + pu))), h);
+                *at_bytes(a.c_all + slab, o) = c;
+                float* go = at_bytes(a.gates_all + 4 * slab, opaque(4u * ((unsigned)pb * 4 * HS + j0 + pu)));
+                go[0] = ig; go[HS] = fg; go[2 * HS] = gg; go[3 * HS] = og;
+            }
+        };
+
+        // ---- prologue: label half of step 0's layer-0 gates
+        f32x4 accR0[2], accR1[2];
+        const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
+        accR0[0] = accR0[1] = accR1[0] = accR1[1] = zero;
+        {
+            f32x4 y[1][2];
+            load_y(0, y);
+            if (ywave) CellRole<256>::mfma_tile(y, Wy, accR0);
+        }
+        f32x4 x[NF][2];
+        const TileAddr ta = tile_addr(B, wave, lane);
+        int nslow[3] = {0, 0, 0};       // slow-path rounds per tile kind (reported through the trace buffer)
+        for (int s = 0; s < U; ++s) {
+            // next step's labels: issued now, consumed after layer 1 (plain load, its latency is off the chain)
+            f32x4 ynext[1][2];
+            if (s + 1 < U) load_y(s + 1, ynext);
+            // layer 0: gates = W_ctx ctx_{s-1} + [W_hh0 h0_{s-1} + W_y y_s  (accumulated ahead)]
+            PS_STAMP(0, s, 0);
+            nslow[1] += poll_tile<1>(a.ctx_all + (size_t)s * B * HS, ta, x, a.err);
+            PS_STAMP(0, s, 1);
+            mfma_tile(x, Wc0, accR0);
+            finish(accR0, c0, 0, s);
+            PS_STAMP(0, s, 2);
+            // layer 1: gates = W_ih1 h0_s + W_hh1 h1_{s-1}
+            nslow[0] += poll_tile<0>(a.hx + (size_t)s * HXS, ta, x, a.err);
+            PS_STAMP(0, s, 4);
+            mfma_tile(x, Wi1, accR1);
+            finish(accR1, c1, 1, s);
+            PS_STAMP(0, s, 5);
+            if (s + 1 == U) break;
+            // off the critical chain (the attention workgroups are working now): recurrent / label halves of layer 0
+            accR0[0] = accR0[1] = zero;
+            mfma_tile(x, Wh0, accR0);                              // the h0_s tile is still in registers
+            if (ywave) CellRole<256>::mfma_tile(ynext, Wy, accR0);
+            PS_STAMP(0, s, 6);
+            // ... and of layer 1, as soon as every cell workgroup's h1_s has arrived (still inside the attention window)
+            nslow[2] += poll_tile<0>(a.hx + ((size_t)U + s) * HXS, ta, x, a.err);
+            accR1[0] = accR1[1] = zero;
+            mfma_tile(x, Wh1, accR1);
+            PS_STAMP(0, s, 7);
+        }
+        if (a.trace && first_wg && tid == 0)
+            for (int k = 0; k < 3; ++k) a.trace[((size_t)a.U + k) * 8 + 7] = (unsigned long long)nslow[k];
+    }
+};
+
+// ------------------------------------------------------------------------------------------------ attention workgroups
+template <int HS>
+struct AttnRole {
+    static constexpr int D = HS, DW = D / PS_SPLIT;                      // this workgroup's slice of the context columns
+    static constexpr int C4 = DW / 4, TQ = PS_THREADS / C4;              // context lanes: (column group, time slice)
+    static constexpr int NJ = HS / 64;                                   // float4 of W_phi per lane (16 lanes per row)
+    static constexpr int MAX_TP = PS_NI * TQ;
+    static constexpr int EP = (MAX_TP + 63) & ~63;                       // energies padded to whole waves (pad = -inf)
+    static __host__ __device__ constexpr int lds_floats(int Tp) { return HS + PS_M + EP + MAX_TP + TQ * DW + Tp * PS_KLD; }
+
+    static __device__ void run(const PersistArgs& a, float* smem, const int widx) {
+        const int b = widx / PS_SPLIT, part_id = widx % PS_SPLIT;
+        const int col0 = part_id * DW;
+        const bool first_wg = widx == 0;
+        const int tid = threadIdx.x, lane = tid & 63;
+        const int B = a.B, U = a.U, Tp = a.Tp;
+        float* hs = smem;
+        float* qs = hs + HS;
+        float* es = qs + PS_M;
+        float* as = es + EP;
+        float* part = as + MAX_TP;
+        float* ks = part + TQ * DW;
+        const size_t sH = (size_t)B * HS;
+
+        // ---- resident operands
+        const int c4 = tid % C4, tq = tid / C4;
+        f32x4 f[PS_NI];
+        const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int i = 0; i < PS_NI; ++i) {
+            const int t = tq + TQ * i;
+            const f32x4 v = ld4p(a.feat + ((size_t)b * Tp + (t < Tp ? t : 0)) * D + col0 + c4 * 4);
+            f[i] = t < Tp ? v : zero;
+        }
+        if (tid >= Tp && tid < MAX_TP) as[tid] = 0.f;         // frames past T' carry zero weight
+        if (tid >= Tp && tid < EP) es[tid] = -INFINITY;
+        for (int idx = tid; idx < Tp * (PS_M / 4); idx += PS_THREADS) {
+            const int t = idx / (PS_M / 4), m4 = idx % (PS_M / 4);
+            *reinterpret_cast<f32x4*>(ks + t * PS_KLD + m4 * 4) = ld4p(a.keys + ((size_t)b * Tp + t) * PS_M + m4 * 4);
+        }
+        const int prow = tid >> 4, pk = tid & 15;         // phi: 64 rows x 16 lanes
+        f32x4 wphi[NJ];
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) wphi[j] = ld4p(a.w_phi + (size_t)prow * HS + 4 * (pk + 16 * j));
+        const float bphi = a.b_phi[prow];
+        lds_barrier();
+
+        for (int s = 0; s < U; ++s) {
+            PS_STAMP(1, s, 0);
+            // ---- decoder state of this utterance (published by the cell workgroups)
+            if (tid < HS / 4) {
+                const float* p = a.hx + ((size_t)U + s) * ((size_t)32 * HS) + ((size_t)tid * 32 + b) * 4;
+                unsigned spins = 0;
+                f32x4 v;
+                for (;;) {
+                    v = ld4_agent(p);
+                    if (!__any(has_sentinel(v))) break;
+                    if (spin_expired(spins, a.err, 0xDEAD0013u)) break;
+                }
+                *reinterpret_cast<f32x4*>(hs + tid * 4) = v;
+            }
+            PS_STAMP(1, s, 1);
+            lds_barrier();
+            // ---- query q = act(W_phi h + b_phi)
+            {
+                float acc = 0.f;
+#pragma unroll
+                for (int j = 0; j < NJ; ++j) acc = dot4p(wphi[j], *reinterpret_cast<const f32x4*>(hs + 4 * (pk + 16 * j)), acc);
+                acc = gsum<16>(acc);
+                if (pk == 0) {
+                    acc += bphi;
+                    if (a.relu) acc = fmaxf(acc, 0.f);
+                    qs[prow] = acc;
+                    if (part_id == 0) a.q_all[((size_t)s * B + b) * PS_M + prow] = acc;
+                }
+            }
+            lds_barrier();
+            PS_STAMP(1, s, 2);
+            // ---- energies e[t] = q . keys[t]: 8 lanes per frame
+            {
+                const int sub = tid & 7;
+                const f32x4 q0 = *reinterpret_cast<const f32x4*>(qs + sub * 8), q1 = *reinterpret_cast<const f32x4*>(qs + sub * 8 + 4);
+#pragma unroll
+                for (int t = tid >> 3; t < EP; t += PS_THREADS / 8) {
+                    if (t >= Tp) break;
+                    const float* kr = ks + t * PS_KLD + sub * 8;
+                    float acc = dot4p(*reinterpret_cast<const f32x4*>(kr), q0, 0.f);
+                    acc = dot4p(*reinterpret_cast<const f32x4*>(kr + 4), q1, acc);
+                    acc = gsum<8>(acc);
+                    if (sub == 0) es[t] = acc;
+                }
+            }
+            lds_barrier();
+            PS_STAMP(1, s, 3);
+            // ---- softmax over ALL frames (no mask, reference las_model.py:292), statistics redundantly per wave
+            float ev[EP / 64];
+            float mx = -INFINITY;
+#pragma unroll
+            for (int k = 0; k < EP / 64; ++k) { ev[k] = es[lane + 64 * k]; mx = fmaxf(mx, ev[k]); }
+            mx = wmax(mx);
+            float sm = 0.f;
+#pragma unroll
+            for (int k = 0; k < EP / 64; ++k) sm += expf(ev[k] - mx);
+            const float inv = 1.0f / wsum(sm);
+            if (tid < Tp) {
+                const float w = expf(es[tid] - mx) * inv;
+                as[tid] = w;
+                if (part_id == 0) a.att[((size_t)s * B + b) * Tp + tid] = w;
+            }
+            lds_barrier();
+            PS_STAMP(1, s, 4);
+            // ---- context = sum_t a_t feat_t from the register-resident features
+            {
+                f32x4 acc = zero;
+#pragma unroll
+                for (int i = 0; i < PS_NI; ++i) {
+                    const float w = as[tq + TQ * i];
+                    acc[0] = fmaf(w, f[i][0], acc[0]); acc[1] = fmaf(w, f[i][1], acc[1]);
+                    acc[2] = fmaf(w, f[i][2], acc[2]); acc[3] = fmaf(w, f[i][3], acc[3]);
+                }
+                *reinterpret_cast<f32x4*>(part + tq * DW + c4 * 4) = acc;
+            }
+            lds_barrier();
+            if (tid < C4) {
+                f32x4 acc = zero;
+#pragma unroll 4
+                for (int q = 0; q < TQ; ++q) {
+                    const f32x4 v = *reinterpret_cast<const f32x4*>(part + q * DW + tid * 4);
+                    acc[0] += v[0]; acc[1] += v[1]; acc[2] += v[2]; acc[3] += v[3];
+                }
+                st4_agent(a.ctx_all + ((size_t)(s + 1) * B + b) * D + col0 + tid * 4, acc);
+            }
+            PS_STAMP(1, s, 5);
+        }
+    }
+};
+
+template <int HS>
+__global__ __launch_bounds__(PS_THREADS) void speller_persist_fwd_kernel(PersistArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    constexpr int NC = HS / 4;
+#if defined(PS_ONLY_CELL)
+    CellRole<HS>::run(a, smem);
+#elif defined(PS_ONLY_ATTN)
+    AttnRole<HS>::run(a, smem, blockIdx.x - NC);
+#else
+    if ((int)blockIdx.x < NC) CellRole<HS>::run(a, smem);
+    else AttnRole<HS>::run(a, smem, blockIdx.x - NC);
+#endif
+}
+
+// ------------------------------------------------------------------------------------------------ host side
+static unsigned long long* g_persist_trace = nullptr;      // device buffer of 2*U*8 stamps, or null (normal operation)
+void speller_persist_set_trace(unsigned long long* dev_buf) { g_persist_trace = dev_buf; }
+
+bool speller_persist_eligible(int B, int Tp, int Hs, int D, int M, int V, int L, int heads, int use_mlp) {
+    if (L != 2 || heads != 1 || !use_mlp || M != PS_M || D != Hs) return false;
+    if (Hs != 256 && Hs != 512) return false;
+    if (B < 1 || B > 32 || ((V + 15) & ~15) > 256) return false;
+    const int max_tp = Hs == 512 ? AttnRole<512>::MAX_TP : AttnRole<256>::MAX_TP;
+    if (Tp > max_tp) return false;
+    int cus = 0;
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess)
+        return false;
+    return Hs / 4 + PS_SPLIT * B <= cus;           // every workgroup must be resident at once (one per CU)
+}
+
+int speller_persist_fwd(const PersistFwd& p, hipStream_t stream) {
+    LAS_REQUIRE(speller_persist_eligible(p.B, p.Tp, p.Hs, p.Hs, PS_M, p.V, 2, 1, 1), "persistent speller shape");
+    PersistArgs a;
+    a.w0p = p.w0p; a.ldw0 = p.Vp + p.Hs; a.Vp = p.Vp;
+    a.w_hh0 = p.w_hh0; a.w_ih1 = p.w_ih1; a.w_hh1 = p.w_hh1;
+    a.b_ih0 = p.b_ih0; a.b_hh0 = p.b_hh0; a.b_ih1 = p.b_ih1; a.b_hh1 = p.b_hh1;
+    a.w_phi = p.w_phi; a.b_phi = p.b_phi;
+    a.feat = p.feat; a.keys = p.keys; a.y_all = p.y_all;
+    a.ctx_all = p.ctx_all; a.h_all = p.h_all; a.c_all = p.c_all; a.gates_all = p.gates_all; a.q_all = p.q_all; a.att = p.att;
+    a.hx = p.hx;
+    a.B = p.B; a.Tp = p.Tp; a.U = p.U; a.relu = p.relu; a.err = p.err;
+    a.trace = g_persist_trace;
+    LAS_REQUIRE(p.err != nullptr, "the persistent speller needs the device error word");
+    // sentinel-fill what the phases hand over: every h of both layers and the contexts of steps 1..U
+    const size_t sH = (size_t)p.B * p.Hs;
+    LAS_HIP_CHECK(hipMemsetAsync(p.hx, 0xFF, sizeof(float) * 2 * p.U * 32 * p.Hs, stream));
+    LAS_HIP_CHECK(hipMemsetAsync(p.ctx_all + sH, 0xFF, sizeof(float) * p.U * sH, stream));
+    const int grid = p.Hs / 4 + PS_SPLIT * p.B;
+    if (p.Hs == 512) {
+        const size_t smem = sizeof(float) * (size_t)std::max(CellRole<512>::LDS_FLOATS, AttnRole<512>::lds_floats(p.Tp));
+        LAS_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&speller_persist_fwd_kernel<512>),
+                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
+        hipLaunchKernelGGL((speller_persist_fwd_kernel<512>), dim3(grid), dim3(PS_THREADS), smem, stream, a);
+    } else {
+        const size_t smem = sizeof(float) * (size_t)std::max(CellRole<256>::LDS_FLOATS, AttnRole<256>::lds_floats(p.Tp));
+        LAS_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&speller_persist_fwd_kernel<256>),
+                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
+        hipLaunchKernelGGL((speller_persist_fwd_kernel<256>), dim3(grid), dim3(PS_THREADS), smem, stream, a);
+    }
+    LAS_LAUNCH_CHECK();
+    return LAS_OK;
+}
+
+}  // namespace las

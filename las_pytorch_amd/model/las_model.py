@@ -237,7 +237,8 @@ class _SpellerFn(torch.autograd.Function):
         att = torch.empty(U, heads, B, Tp, device=dev, dtype=torch.float32)
         reserve = torch.empty(Lh.las_speller_reserve_floats(d, U), device=dev, dtype=torch.float32)
         check(Lh.las_speller_fwd(d, ptr(feat), ptr(keys), ptr(labels) if teacher_forced else None, u_lab, U,
-                                 int(teacher_forced), decode_mode, ptr(logp), ptr(att), None, ptr(reserve), FLAG_STASH, stream))
+                                 int(teacher_forced), decode_mode, ptr(logp), ptr(att), None, ptr(reserve),
+                                 ptr(_cabi.err_word(dev)), _flags(True), stream))
         ctx.mark_non_differentiable(att)
         if any(ctx.needs_input_grad):
             ctx.save_for_backward(feat, keys, logp, att, reserve, *params)

@@ -273,3 +273,54 @@ def test_edge_shapes_vs_oracle(cfg_name, B, T, U):
         want = sd[k].grad.numpy()
         assert_close(p.grad.cpu().numpy(), want, f"grad/{k}", rtol=3e-3, atol=max(1e-5 * float(np.abs(want).max()) + 1e-9, 2e-7))
     _check_err()
+
+
+@pytest.mark.parametrize("cfg_name,B,Tp,U,scale", [("P", 32, 100, 24, None), ("P", 5, 37, 7, 0.1), ("S", 17, 200, 9, None),
+                                                    ("S", 32, 100, 12, 0.1), ("P", 1, 1, 3, None)])
+def test_persistent_decode_kernel_matches_stepwise(cfg_name, B, Tp, U, scale):
+    """The one-launch teacher-forced decode loop (speller_persist.hip) against the per-step launch chain it replaces:
+    outputs and every gradient (the backward pass consumes the stash the forward kernel wrote).  The larger-weight
+    cases stay at U(-0.1,0.1): with the U(-0.5,0.5) set the attention softmax is an arg-max over energies of order 1e3
+    and two correct fp32 summation orders legitimately pick different frames on near-ties (the saturating set is
+    covered against the reference's own outputs by the *_sat golden cases, which run through this kernel too)."""
+    import ctypes
+    from las_pytorch_amd import Speller, _cabi, synth
+    from las_pytorch_amd.model import las_model
+    c = synth.CONFIGS[cfg_name]
+    torch.manual_seed(5)
+    sp = Speller(vocab_size=c["V"], hidden_size=c["Hs"], rnn_unit="LSTM", num_layers=c["Ls"], max_label_len=U,
+                 use_mlp_in_attention=True, mlp_dim_in_attention=c["M"], mlp_activate_in_attention="relu",
+                 listener_hidden_size=c["H"], multi_head=1, decode_mode=1).cuda()
+    if scale is not None:
+        with torch.no_grad():
+            for p in sp.parameters():
+                p.uniform_(-scale, scale)
+    feat0 = torch.randn(B, Tp, 2 * c["H"], device="cuda") * 0.5
+    idx, lens = synth.make_labels(B, U, c["V"], seed=11, ragged=True)
+    lab = torch.from_numpy(synth.onehot_labels(idx, lens, c["V"])).cuda()
+    w = torch.randn(U, B, c["V"], device="cuda")
+    L = _cabi.lib()
+    L.las_debug_persist_trace.argtypes = [ctypes.c_void_p]
+    L.las_debug_persist_trace.restype = None
+    trace = torch.zeros(2 * U * 8, dtype=torch.int64, device="cuda")
+    res = []
+    for force in (False, True):
+        las_model.FORCE_GENERIC_RECURRENCE = force
+        L.las_debug_persist_trace(trace.data_ptr() if not force else None)
+        try:
+            sp.zero_grad(set_to_none=True)
+            feat = feat0.clone().requires_grad_(True)
+            preds, att = sp(feat, ground_truth=lab, teacher_force_rate=1.0)
+            logp = torch.stack(preds)
+            (logp * w).sum().backward()
+            res.append(dict(logp=logp.detach().cpu().numpy(), att=torch.stack([a[0] for a in att]).detach().cpu().numpy(),
+                            dfeat=feat.grad.cpu().numpy(), **{"d" + n: p.grad.cpu().numpy() for n, p in sp.named_parameters()}))
+        finally:
+            las_model.FORCE_GENERIC_RECURRENCE = False
+            L.las_debug_persist_trace(None)
+    torch.cuda.synchronize()
+    assert int(trace.abs().sum().item()) != 0, "the persistent kernel did not run (shape not eligible?)"
+    for k in res[0]:
+        scale_k = float(np.abs(res[1][k]).max()) + 1e-30
+        assert_close(res[0][k], res[1][k], f"persistent vs stepwise {k}", rtol=1e-3, atol=1e-5 * max(1.0, scale_k))
+    _check_err()
