@@ -47,13 +47,11 @@ __device__ __forceinline__ T* at_bytes(T* base, unsigned byte_off) {
     return reinterpret_cast<T*>(reinterpret_cast<char*>(const_cast<typename std::remove_const<T>::type*>(base)) + byte_off);
 }
 
+// 16-byte agent-scope (sc1: L2 write-through / L2-bypassing) accesses as ONE instruction: a wave then moves whole 128 B
+// lines.  (Two 8-byte atomics per lane make every line arrive at the memory side as two partial writes.)
 __device__ __forceinline__ f32x4 ld4_agent(const float* p) {
-    const u64* q = reinterpret_cast<const u64*>(p);
-    const u64 lo = __hip_atomic_load(q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    const u64 hi = __hip_atomic_load(q + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     f32x4 v;
-    v[0] = __uint_as_float((unsigned)lo); v[1] = __uint_as_float((unsigned)(lo >> 32));
-    v[2] = __uint_as_float((unsigned)hi); v[3] = __uint_as_float((unsigned)(hi >> 32));
+    asm volatile("global_load_dwordx4 %0, %1, off sc1\n\ts_waitcnt vmcnt(0)" : "=v"(v) : "v"(p) : "memory");
     return v;
 }
 __device__ __forceinline__ bool has_sentinel(const f32x4 v) {
@@ -66,9 +64,10 @@ __device__ __forceinline__ void st1_agent(float* p, float v) {
     __hip_atomic_store(reinterpret_cast<unsigned*>(p), pub_bits(v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 __device__ __forceinline__ void st4_agent(float* p, const f32x4 v) {
-    u64* q = reinterpret_cast<u64*>(p);
-    __hip_atomic_store(q, (u64)pub_bits(v[0]) | ((u64)pub_bits(v[1]) << 32), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    __hip_atomic_store(q + 1, (u64)pub_bits(v[2]) | ((u64)pub_bits(v[3]) << 32), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    f32x4 b;
+    b[0] = __uint_as_float(pub_bits(v[0])); b[1] = __uint_as_float(pub_bits(v[1]));
+    b[2] = __uint_as_float(pub_bits(v[2])); b[3] = __uint_as_float(pub_bits(v[3]));
+    asm volatile("global_store_dwordx4 %0, %1, off sc1" : : "v"(p), "v"(b) : "memory");
 }
 __device__ __forceinline__ void lds_barrier() {     // orders LDS traffic only (does not wait for global stores)
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -138,9 +137,9 @@ struct PersistArgs {
 template <int HS>
 struct CellRole {
     static constexpr int NF = HS / 256;                 // 16-wide k-blocks of an Hs-wide operand per wave
-    static constexpr int RED = PS_NW * 2 * 16 * 17;     // floats of the per-wave partial tile buffer
-    static constexpr int RED2 = 2 * 2 * 16 * 17;
-    static constexpr int LDS_FLOATS = RED + RED2 + 2 * 4 * 128;       // + summed biases of the 128 cell lanes
+    static constexpr int RLD = 20;                      // row stride of a partial tile: 16 columns + pad, 16-byte aligned
+    static constexpr int RED = PS_NW * 2 * 16 * RLD;    // floats of the per-wave partial tile buffer
+    static constexpr int LDS_FLOATS = 2 * RED + 2 * 4 * 128;          // one buffer per layer + summed biases of the cell lanes
 
     // x tile of this wave: rows = utterances (two 16-row M-tiles), columns = its k-blocks.  Polls until no sentinel.
     // KIND 0: tile of h (each 4-column group comes from one cell workgroup); KIND 1: tile of the context (each row half
@@ -238,8 +237,6 @@ struct CellRole {
     }
 
     static __device__ void run(const PersistArgs& a, float* smem) {
-        float (*red)[2][16][17] = reinterpret_cast<float (*)[2][16][17]>(smem);
-        float (*red2)[2][16][17] = reinterpret_cast<float (*)[2][16][17]>(smem + RED);
         const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
         const int r = lane & 15, kq = lane >> 4;
         const int j0 = blockIdx.x * 4;
@@ -273,7 +270,7 @@ struct CellRole {
         const bool pw = tid < 128 && pb < B;
         const int pmt = (pb >> 4) & 1, pm = pb & 15;
         float c0 = 0.f, c1 = 0.f;
-        float* bias = smem + RED + RED2;                 // [layer][gate][cell lane]: registers are for the weights
+        float* bias = smem + 2 * RED;                 // [layer][gate][cell lane]: registers are for the weights
         if (tid < 128) {
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
@@ -282,10 +279,8 @@ struct CellRole {
                 bias[(4 + g) * 128 + tid] = a.b_ih1[row] + a.b_hh1[row];
             }
         }
-        // stage-1 reduction lane: sums 8 waves' partials of one tile element
-        const int rh = tid >> 9, ri = tid & 511;
-        const int rmt = ri >> 8, rm = (ri >> 4) & 15, rn = ri & 15;
-
+        const int rcol = (r & 3) * 4 + (r >> 2);        // tile column (gate*4 + unit) stored as unit*4 + gate: a cell lane
+                                                        // reads the four gates of its unit as one 16-byte LDS word
         auto load_y = [&](int s, f32x4 (&y)[1][2]) {
 #pragma unroll
             for (int mt = 0; mt < 2; ++mt) {
@@ -298,30 +293,29 @@ struct CellRole {
         };
         // gates of one layer: reduce the 16 waves' partial tiles, apply the cell, publish h, stash c / gates
         auto finish = [&](const f32x4 (&acc)[2], float& c, int layer, int s) {
+            // one buffer per layer: the single barrier below then also separates this buffer's readers from its next writers
+            float (*red)[2][16][RLD] = reinterpret_cast<float (*)[2][16][RLD]>(smem + layer * RED);
 #pragma unroll
             for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
-                for (int i = 0; i < 4; ++i) red[wave][mt][kq * 4 + i][r] = acc[mt][i];
-            lds_barrier();
-            {
-                float t = 0.f;
-#pragma unroll
-                for (int w = 0; w < 8; ++w) t += red[rh * 8 + w][rmt][rm][rn];
-                red2[rh][rmt][rm][rn] = t;
-            }
+                for (int i = 0; i < 4; ++i) red[wave][mt][kq * 4 + i][rcol] = acc[mt][i];
             lds_barrier();
             if (pw) {
-                float g4[4];
+                f32x4 g4 = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-                for (int g = 0; g < 4; ++g)
-                    g4[g] = red2[0][pmt][pm][g * 4 + pu] + red2[1][pmt][pm][g * 4 + pu] + bias[(layer * 4 + g) * 128 + tid];
+                for (int w = 0; w < PS_NW; ++w) {
+                    const f32x4 v = *reinterpret_cast<const f32x4*>(&red[w][pmt][pm][pu * 4]);
+                    g4[0] += v[0]; g4[1] += v[1]; g4[2] += v[2]; g4[3] += v[3];
+                }
+#pragma unroll
+                for (int g = 0; g < 4; ++g) g4[g] += bias[(layer * 4 + g) * 128 + tid];
                 const float ig = sigmoidf_acc(g4[0]), fg = sigmoidf_acc(g4[1]), gg = tanhf_acc(g4[2]), og = sigmoidf_acc(g4[3]);
                 c = fg * c + ig * gg;
                 const float h = og * tanhf_acc(c);
                 const size_t slab = ((size_t)layer * U + s) * sH;           // wave-uniform
                 const unsigned o = opaque(4u * ((unsigned)pb * HS + j0 + pu));
-                *at_bytes(a.h_all + slab, o) = h;
                 st1_agent(at_bytes(a.hx + ((size_t)layer * U + s) * HXS, opaque(4u * (((unsigned)blockIdx.x * 32 + pb) * 4 + pu))), h);
+                *at_bytes(a.h_all + slab, o) = h;
                 *at_bytes(a.c_all + slab, o) = c;
                 float* go = at_bytes(a.gates_all + 4 * slab, opaque(4u * ((unsigned)pb * 4 * HS + j0 + pu)));
                 go[0] = ig; go[HS] = fg; go[2 * HS] = gg; go[3 * HS] = og;
@@ -476,10 +470,10 @@ struct AttnRole {
             mx = wmax(mx);
             float sm = 0.f;
 #pragma unroll
-            for (int k = 0; k < EP / 64; ++k) sm += expf(ev[k] - mx);
+            for (int k = 0; k < EP / 64; ++k) sm += __builtin_amdgcn_exp2f((ev[k] - mx) * 1.4426950408889634f);
             const float inv = 1.0f / wsum(sm);
             if (tid < Tp) {
-                const float w = expf(es[tid] - mx) * inv;
+                const float w = __builtin_amdgcn_exp2f((es[tid] - mx) * 1.4426950408889634f) * inv;
                 as[tid] = w;
                 if (part_id == 0) a.att[((size_t)s * B + b) * Tp + tid] = w;
             }
