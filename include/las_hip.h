@@ -127,10 +127,13 @@ int las_speller_step_fwd(const las_speller_desc* d, const float* feat, const flo
 
 size_t las_speller_bwd_workspace_floats(const las_speller_desc* d, int U);
 /* dlogp (U,B,V): gradient of the loss wrt the returned log-probs.  feedback_mode0: the forward ran
- * free-running with decode_mode 0 (gradient flows through the fed-back log-probs). */
+ * free-running with decode_mode 0 (gradient flows through the fed-back log-probs).
+ * err_word / flags: as las_speller_fwd (the persistent backward kernel needs the error word; NULL or
+ * LAS_FLAG_FORCE_GENERIC selects the per-step launch chain). */
 int las_speller_bwd(const las_speller_desc* d, const float* feat, const float* keys,
                     const float* logp, const float* att, const float* dlogp, int U, int feedback_mode0,
-                    const float* reserve, float* workspace, const las_speller_grads* g, void* stream);
+                    const float* reserve, float* workspace, const las_speller_grads* g, uint32_t* err_word, int flags,
+                    void* stream);
 
 /* ------------------------------------------------------------------------------------------------
  * Caller-side contract on device (the code that CALLS the hot path, reference solver/solver.py).

@@ -48,7 +48,7 @@ PROTOTYPES = {
     "las_speller_step_fwd": (C.c_int, [C.POINTER(SpellerDesc)] + [_f] * 12),
     "las_speller_bwd_workspace_floats": (C.c_size_t, [C.POINTER(SpellerDesc), C.c_int]),
     "las_speller_bwd": (C.c_int, [C.POINTER(SpellerDesc), _f, _f, _f, _f, _f, C.c_int, C.c_int, _f, _f,
-                                  C.POINTER(SpellerGrads), _f]),
+                                  C.POINTER(SpellerGrads), _f, C.c_int, _f]),
     "las_ls_loss": (C.c_int, [_f, C.c_int64, C.c_int64, _f, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, _f, _f, C.c_int64,
                               C.c_int64, _f, _f]),
     "las_letter_error_rate": (C.c_int, [_f, C.c_int64, C.c_int64, _f, C.c_int, C.c_int, C.c_int, C.c_int, _f, _f, _f]),

@@ -55,7 +55,8 @@ struct SpellerLayout {
 };
 
 struct SpellerBwdLayout {
-    size_t dG_all, dz_all, dctx_all, de_all, dqpre_all, dh_top, dh_below, dh_carry, dc_carry, dx0, dK, dcat_all, dctxcat_all, total;
+    size_t dG_all, dz_all, dctx_all, de_all, dqpre_all, dh_top, dh_below, dh_carry, dc_carry, dx0, dK, dcat_all, dctxcat_all,
+        dqpre_part, pxbuf, total;
     SpellerBwdLayout(const las_speller_desc* d, int U) {
         size_t o = 0;
         const size_t B = d->B;
@@ -73,6 +74,12 @@ struct SpellerBwdLayout {
         dK = o; o += r4(B * d->Tp * Mq);
         dcat_all = o; o += r4((size_t)U * B * (d->Hs + d->D));    // dz W_c for every step (teacher forcing / mode 1)
         dctxcat_all = o; if (d->multi_head > 1) o += r4((size_t)U * B * d->multi_head * d->D);
+        // persistent backward kernel: the attention halves' dqpre parts and the sentinel-prefilled hand-off slabs
+        dqpre_part = o; pxbuf = o;
+        if (d->L == 2 && d->multi_head == 1 && d->Hs % 16 == 0 && d->use_mlp) {
+            o += r4((size_t)2 * U * B * d->M);
+            pxbuf = o; o += r4(speller_persist_bwd_workspace_floats(d->B, U, d->Hs));
+        }
         total = o;
     }
 };
@@ -220,6 +227,7 @@ size_t las_speller_reserve_floats(const las_speller_desc* d, int U) { return Spe
 
 // Profiling aid, deliberately not part of include/las_hip.h: per-phase shader-clock stamps of the persistent decode kernel.
 extern "C" void las_debug_persist_trace(unsigned long long* dev_buf) { speller_persist_set_trace(dev_buf); }
+extern "C" void las_debug_persist_bwd_trace(unsigned long long* dev_buf) { speller_persist_bwd_set_trace(dev_buf); }
 
 int las_speller_fwd(const las_speller_desc* d, const float* feat, const float* keys, const int64_t* labels_onehot, int U_lab,
                     int U, int teacher_forced, int decode_mode, float* logp, float* att, int32_t* argmax, float* reserve,
@@ -401,7 +409,7 @@ size_t las_speller_bwd_workspace_floats(const las_speller_desc* d, int U) { retu
 
 int las_speller_bwd(const las_speller_desc* d, const float* feat, const float* keys, const float* logp, const float* att,
                     const float* dlogp, int U, int feedback_mode0, const float* reserve, float* workspace,
-                    const las_speller_grads* g, void* stream_) {
+                    const las_speller_grads* g, uint32_t* err_word, int flags, void* stream_) {
     hipStream_t stream = (hipStream_t)stream_;
     LAS_TRY(check_desc(d));
     LAS_REQUIRE(U > 0 && feat && logp && att && dlogp && reserve && workspace && g, "speller bwd pointers");
@@ -455,7 +463,24 @@ int las_speller_bwd(const las_speller_desc* d, const float* feat, const float* k
     const int NH = d->multi_head;
     float* dctxcat_all = NH > 1 ? workspace + wl.dctxcat_all : nullptr;
     const float* ctxcat_all = NH > 1 ? reserve + lay.ctxcat_all : nullptr;
-    for (int s = U - 1; s >= 0; --s) {
+    static const bool persist_on = !(getenv("LAS_SPELLER_PERSIST_BWD") && atoi(getenv("LAS_SPELLER_PERSIST_BWD")) == 0);
+    const bool persist = persist_on && hoist && err_word && !(flags & LAS_FLAG_FORCE_GENERIC) &&
+                         speller_persist_bwd_eligible(B, Tp, Hs, D, M, V, L, NH, d->use_mlp);
+    if (persist) {
+        PersistBwd p;
+        p.w_ih0 = d->w_ih[0]; p.w_hh0 = d->w_hh[0]; p.w_ih1 = d->w_ih[1]; p.w_hh1 = d->w_hh[1]; p.w_phi = d->w_phi;
+        p.feat = feat; p.keys = keys; p.att = att; p.q_all = q_all; p.ctx_all = ctx_all;
+        p.gates_all = gates_all; p.c_all = c_all; p.dcat_all = dcat_all;
+        p.dG_all = dG_all; p.dctx_all = dctx_all; p.de_all = de_all; p.dqpre_part = workspace + wl.dqpre_part;
+        p.dx0 = dx0; p.xbuf = workspace + wl.pxbuf;
+        p.B = B; p.Tp = Tp; p.U = U; p.Hs = Hs; p.V = V; p.relu = d->relu; p.err = err_word;
+        LAS_TRY(speller_persist_bwd(p, stream));
+        // dqpre = sum of the two attention halves' parts (the relu mask is linear in dq)
+        const size_t nq = (size_t)U * B * M;
+        LAS_HIP_CHECK(hipMemcpyAsync(dqpre_all, workspace + wl.dqpre_part, sizeof(float) * nq, hipMemcpyDeviceToDevice, stream));
+        LAS_TRY(add_inplace(dqpre_all, workspace + wl.dqpre_part + nq, (long)nq, stream));
+    }
+    for (int s = persist ? -1 : U - 1; s >= 0; --s) {
         const bool last = (s == U - 1);
         AttnBwdArgs a;
         a.dlogp = dlogp + (size_t)s * B * V; a.logp = logp + (size_t)s * B * V;

@@ -21,101 +21,14 @@
 // All spins are bounded and report through the device error word (results are then invalid, never a hang).
 #include "las_common.h"
 #include "las_kernels.h"
+#include "persist_common.h"
 #include <algorithm>
-#include <type_traits>
 
 namespace las {
 
 namespace {
-
-using u64 = unsigned long long;
-constexpr int PS_THREADS = 1024, PS_NW = 16;
-constexpr unsigned PS_SENT = 0xFFFFFFFFu;
-constexpr unsigned PS_SPIN_LIMIT = 1u << 21;
 constexpr int PS_NI = 7;           // listener frames held per attention lane
 constexpr int PS_SPLIT = 2;        // attention workgroups per utterance (each owns D/PS_SPLIT context columns)
-constexpr int PS_M = 64;           // attention MLP width handled by the persistent kernel
-constexpr int PS_KLD = PS_M + 4;   // LDS row stride of the keys (bank spread)
-
-__device__ __forceinline__ f32x4 ld4p(const float* p) { return *reinterpret_cast<const f32x4*>(p); }
-// Per-lane BYTE offset that the optimiser must treat as new in every loop iteration: without this it hoists one 64-bit
-// (pointer + lane offset) pair per access out of the step loop, which costs ~30 VGPRs and ends in scratch spills on the
-// critical path.  With it the access is `uniform base (SGPR pair) + 32-bit lane offset`.
-__device__ __forceinline__ unsigned opaque(unsigned v) { asm volatile("" : "+v"(v)); return v; }
-template <class T>
-__device__ __forceinline__ T* at_bytes(T* base, unsigned byte_off) {
-    return reinterpret_cast<T*>(reinterpret_cast<char*>(const_cast<typename std::remove_const<T>::type*>(base)) + byte_off);
-}
-
-// 16-byte agent-scope (sc1: L2 write-through / L2-bypassing) accesses as ONE instruction: a wave then moves whole 128 B
-// lines.  (Two 8-byte atomics per lane make every line arrive at the memory side as two partial writes.)
-__device__ __forceinline__ f32x4 ld4_agent(const float* p) {
-    f32x4 v;
-    asm volatile("global_load_dwordx4 %0, %1, off sc1\n\ts_waitcnt vmcnt(0)" : "=v"(v) : "v"(p) : "memory");
-    return v;
-}
-__device__ __forceinline__ bool has_sentinel(const f32x4 v) {
-    return __float_as_uint(v[0]) == PS_SENT || __float_as_uint(v[1]) == PS_SENT || __float_as_uint(v[2]) == PS_SENT ||
-           __float_as_uint(v[3]) == PS_SENT;
-}
-// a value that is published must never look like the sentinel (only a NaN could): canonicalise NaNs
-__device__ __forceinline__ unsigned pub_bits(float v) { return (v != v) ? 0x7FC00000u : __float_as_uint(v); }
-__device__ __forceinline__ void st1_agent(float* p, float v) {
-    __hip_atomic_store(reinterpret_cast<unsigned*>(p), pub_bits(v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-}
-__device__ __forceinline__ void st4_agent(float* p, const f32x4 v) {
-    f32x4 b;
-    b[0] = __uint_as_float(pub_bits(v[0])); b[1] = __uint_as_float(pub_bits(v[1]));
-    b[2] = __uint_as_float(pub_bits(v[2])); b[3] = __uint_as_float(pub_bits(v[3]));
-    asm volatile("global_store_dwordx4 %0, %1, off sc1" : : "v"(p), "v"(b) : "memory");
-}
-__device__ __forceinline__ void lds_barrier() {     // orders LDS traffic only (does not wait for global stores)
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();
-    asm volatile("" ::: "memory");
-}
-// bounded-spin bookkeeping shared by every poller; returns true when the caller must give up
-__device__ __forceinline__ bool spin_expired(unsigned& spins, unsigned* err, unsigned code) {
-    ++spins;
-    if ((spins & 127u) == 0) {
-        if (spins > PS_SPIN_LIMIT) { atomicExch(err, code); return true; }
-        if (__hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) return true;
-    }
-    __builtin_amdgcn_s_sleep(1);
-    return false;
-}
-// Reductions with DPP row operations (1 VALU instruction per level) instead of __shfl_xor (a ds_bpermute, i.e. an LDS
-// round trip, per level): these sit on the serial chain of every decode step.
-__device__ __forceinline__ float dpp_f(float v, int ctrl) {
-    switch (ctrl) {
-        case 0: return __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, v), 0xB1, 0xF, 0xF, true));    // quad_perm [1,0,3,2]
-        case 1: return __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, v), 0x4E, 0xF, 0xF, true));    // quad_perm [2,3,0,1]
-        case 2: return __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, v), 0x141, 0xF, 0xF, true));   // row_half_mirror
-        default: return __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, v), 0x140, 0xF, 0xF, true));  // row_mirror
-    }
-}
-template <int W>
-__device__ __forceinline__ float gsum(float v) {      // sum over aligned groups of W <= 16 lanes, result in every lane
-    if (W >= 2) v += dpp_f(v, 0);
-    if (W >= 4) v += dpp_f(v, 1);
-    if (W >= 8) v += dpp_f(v, 2);
-    if (W >= 16) v += dpp_f(v, 3);
-    return v;
-}
-__device__ __forceinline__ float lane_f(float v, int l) { return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), l)); }
-__device__ __forceinline__ float wsum(float v) {
-    v = gsum<16>(v);
-    return (lane_f(v, 0) + lane_f(v, 16)) + (lane_f(v, 32) + lane_f(v, 48));
-}
-__device__ __forceinline__ float wmax(float v) {
-    v = fmaxf(v, dpp_f(v, 0)); v = fmaxf(v, dpp_f(v, 1)); v = fmaxf(v, dpp_f(v, 2)); v = fmaxf(v, dpp_f(v, 3));
-    return fmaxf(fmaxf(lane_f(v, 0), lane_f(v, 16)), fmaxf(lane_f(v, 32), lane_f(v, 48)));
-}
-__device__ __forceinline__ float dot4p(const f32x4 a, const f32x4 b, float acc) {
-    acc = fmaf(a[0], b[0], acc); acc = fmaf(a[1], b[1], acc); acc = fmaf(a[2], b[2], acc); acc = fmaf(a[3], b[3], acc);
-    return acc;
-}
-
 }  // namespace
 
 struct PersistArgs {

@@ -1,0 +1,526 @@
+// Persistent backward of the teacher-forced Speller decode loop for gfx950: ONE launch walks all U steps in reverse.
+//
+// Replaces the per-step launch chain attn_step_bwd -> smallm_gemm_nn (layer 1) -> smallm_gemm_nn (layer 0) of
+// las_speller_bwd (autograd of the reference's Speller.forward / Attention.forward, model/las_model.py:178-238,
+// 275-297, driven by solver/solver.py:95) when the shapes allow it; the per-step kernels remain the general path.
+// Loop-invariant-shaped work stays outside exactly as before: dz W_c for all steps (one GEMM before the loop) and every
+// weight gradient / dfeat / dK contraction (GEMMs after the loop over the per-step gradients this kernel stashes).
+//
+// Per step s (descending) the dependent chain is
+//     A: attention backward of utterance b         -> decoder-state gradient part (two workgroups per utterance,
+//                                                     each owning half of the T' frames; the softmax-backward
+//                                                     statistic sum_t a_t da_t equals ctx_s . dctx, so the halves
+//                                                     never talk to each other)
+//     Y: top-layer cell backward (pointwise)       -> dG1_s
+//     X: dh0 = dG1_s W_ih1 (MFMA), bottom-layer cell backward -> dG0_s
+//     Y: dctx = dG0_s W_ctx (MFMA)                 -> context gradient carried to step s-1's attention backward
+// and, off that chain, the recurrent carries dG1_s W_hh1 (Y) and dG0_s W_hh0 (X) for step s-1.
+// X and Y workgroups own 16 hidden units x 16 utterances (one 16x16 MFMA tile of every product) and keep their columns
+// of two weight matrices in VGPRs (64 floats per lane) for the whole launch; cell-state gradients never leave them.
+// Hand-off uses the protocol of speller_persist.hip (persist_common.h): sentinel-prefilled per-step slabs, agent-scope
+// producers writing whole cache lines, a one-dword-per-producer canary and L2-shared plain loads for the big tiles.
+#include "las_common.h"
+#include "las_kernels.h"
+#include "persist_common.h"
+#include <algorithm>
+
+namespace las {
+
+struct PersistBwdArgs {
+    const float* w_ih0; long ldw0; int V;         // (4Hs, V+Hs): the context columns start at V
+    const float* w_hh0; const float* w_ih1; const float* w_hh1;      // (4Hs, Hs)
+    const float* w_phi;                           // (M, Hs)
+    const float* feat; const float* keys; const float* att; const float* q_all; const float* ctx_all;
+    const float* gates_all; const float* c_all; const float* dcat_all;
+    float* dG_all; float* dctx_all; float* de_all; float* dqpre_part;
+    float* dx0; long ldx0;
+    float* dhA;      // [U][B][2][Hs]            decoder-state gradient parts of the two attention halves
+    float* dGx;      // [2][U][Hs/16][32][64]    tiled gate gradients (layer, step, unit tile, row, unit*4+gate)
+    float* dcx;      // [U][Hs/16][32][16]       context gradient carried to the previous step
+    int B, Tp, U, relu;
+    unsigned* err;
+    unsigned long long* trace;
+};
+
+#define PB_STAMP(role, s, k) do { if (a.trace && first_wg && threadIdx.x == 0) a.trace[((size_t)(role) * a.U + (s)) * 8 + (k)] = wall_clock64(); } while (0)
+
+// ------------------------------------------------------------------------------------------------ X / Y workgroups
+template <int HS>
+struct ProdRole {
+    static constexpr int NJ = HS / 16;                     // 16-unit tiles
+    static constexpr int KB = (4 * HS / 16) / PS_NW;       // 16-wide k-blocks per wave of the 4Hs-long contraction
+    static constexpr int JPW = KB / 4;                     // unit tiles per wave (a tile is 64 k = 4 blocks)
+    static constexpr size_t GXS = (size_t)NJ * 32 * 64;    // floats of one tiled dG slab
+    static constexpr size_t CXS = (size_t)NJ * 32 * 16;    // floats of one dcx slab
+    static constexpr int RED = PS_NW * 16 * 17;
+    static constexpr int LDS_FLOATS = 2 * RED + PS_NW * (KB / 2) * 64 * 4;     // two reduction buffers + half of W_rec
+
+    struct Lane {
+        unsigned x[JPW];       // byte offset of this lane's float4 of the first k-block of unit tile i inside a dG slab
+                               // (the other three blocks of the tile are +64, +128, +192 bytes: instruction offsets)
+        unsigned canary;       // byte offset of the dword this lane watches
+        bool ok;               // its utterance row exists
+    };
+    static __device__ __forceinline__ Lane lane_addr(int B, int mt, int wave, int lane) {
+        Lane t;
+        const int r = lane & 15, kq = lane >> 4;
+        t.ok = mt * 16 + r < B;
+        const int row = t.ok ? mt * 16 + r : mt * 16;
+#pragma unroll
+        for (int i = 0; i < JPW; ++i) t.x[i] = 4u * (((wave * JPW + i) * 32 + row) * 64 + 4 * kq);
+        // one dword per (producer tile, row): lanes [32*i, 32*i+16) cover the 16 rows of the wave's i-th unit tile
+        const int cj = wave * JPW + (lane >> 5) % JPW;
+        const int crow = mt * 16 + min(lane & 15, max(B - 1 - mt * 16, 0));
+        t.canary = 4u * ((cj * 32 + crow) * 64 + 63);
+        return t;
+    }
+    // resident MFMA B operand: W[(gate e)*HS + unit(k)][cb + 16 j + n] for this wave's k-blocks, k = unit*4 + gate
+    static __device__ __forceinline__ void load_w(const float* w, long ld, int cb, int j, int wave, int lane, float (&W)[KB][4]) {
+        const int r = lane & 15, kq = lane >> 4;
+#pragma unroll
+        for (int blk = 0; blk < KB; ++blk) {
+            const int unit = (wave * JPW + blk / 4) * 16 + (blk % 4) * 4 + kq;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) W[blk][e] = w[((long)e * HS + unit) * ld + cb + 16 * j + r];
+        }
+    }
+    // tile of dG rows (this M-tile, all 4Hs gate columns): canary, L2-shared plain loads, per-word check, slow path
+    static __device__ __forceinline__ void poll_tile(const float* base, const Lane& t, f32x4 (&x)[KB], unsigned* err) {
+        unsigned spins = 0;
+        {
+            const unsigned* cp = reinterpret_cast<const unsigned*>(at_bytes(base, opaque(t.canary)));
+            for (;;) {
+                const unsigned v = __hip_atomic_load(cp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (!__any(v == PS_SENT)) break;
+                if (spin_expired(spins, err, 0xDEAD0021u)) break;
+            }
+        }
+        asm volatile("" ::: "memory");
+        bool need[KB];
+        bool bad = false;
+        unsigned xo[JPW];
+#pragma unroll
+        for (int i = 0; i < JPW; ++i) xo[i] = opaque(t.x[i]);
+        // rows past B hold the sentinel for ever: they only feed output rows nobody reads (MFMA rows are independent)
+#pragma unroll
+        for (int blk = 0; blk < KB; ++blk)
+#ifdef PB_DEBUG_SC1
+            x[blk] = ld4_agent(at_bytes(base, xo[blk / 4]) + 16 * (blk % 4));
+#else
+            x[blk] = *reinterpret_cast<const f32x4*>(at_bytes(base, xo[blk / 4]) + 16 * (blk % 4));
+#endif
+        __builtin_amdgcn_sched_barrier(0);             // all loads of the tile are in flight before the first check
+#pragma unroll
+        for (int blk = 0; blk < KB; ++blk) {
+            need[blk] = __any(t.ok && has_sentinel(x[blk]));
+            bad |= need[blk];
+        }
+        asm volatile("" ::: "memory");
+        while (bad) {
+            if (spin_expired(spins, err, 0xDEAD0022u)) break;
+            bad = false;
+#pragma unroll
+            for (int blk = 0; blk < KB; ++blk) {
+                if (need[blk]) {
+                    x[blk] = ld4_agent(at_bytes(base, opaque(t.x[blk / 4])) + 16 * (blk % 4));
+                    need[blk] = __any(t.ok && has_sentinel(x[blk]));
+                    bad |= need[blk];
+                }
+            }
+        }
+    }
+    static __device__ __forceinline__ f32x4 mfma_tile(const f32x4 (&x)[KB], const float (&W)[KB][4]) {
+        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int blk = 0; blk < KB; ++blk)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(x[blk][e], W[blk][e], acc, 0, 0, 0);
+        return acc;
+    }
+    // sum the 16 waves' partial 16x16 tiles; the result for (utterance m, unit n) lands in thread m*16+n (< 256)
+    static __device__ __forceinline__ float reduce_tile(float* red, const f32x4 acc, int wave, int lane, int tid) {
+        const int r = lane & 15, kq = lane >> 4;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) red[(wave * 16 + kq * 4 + i) * 17 + r] = acc[i];
+        lds_barrier();
+        float s = 0.f;
+        if (tid < 256) {
+#pragma unroll
+            for (int w = 0; w < PS_NW; ++w) s += red[(w * 16 + (tid >> 4)) * 17 + (tid & 15)];
+        }
+        return s;
+    }
+
+    // cell backward of one (utterance, unit): reference semantics = autograd of nn.LSTM's cell
+    struct CellIn { float ig, fg, gg, og, c, cp; };
+    static __device__ __forceinline__ CellIn load_cell(const PersistBwdArgs& a, int layer, int s, unsigned o4, unsigned o1) {
+        const size_t slab = ((size_t)layer * a.U + s) * (size_t)a.B * HS;
+        CellIn ci;
+        const float* gp = at_bytes(a.gates_all + 4 * slab, o4);
+        ci.ig = gp[0]; ci.fg = gp[HS]; ci.gg = gp[2 * HS]; ci.og = gp[3 * HS];
+        ci.c = *at_bytes(a.c_all + slab, o1);
+        ci.cp = s > 0 ? *at_bytes(a.c_all + slab - (size_t)a.B * HS, o1) : 0.f;
+        return ci;
+    }
+    static __device__ __forceinline__ f32x4 cell_bwd(const CellIn& ci, float dh, float& dc) {
+        const float tc = tanhf_acc(ci.c);
+        const float dct = dc + dh * ci.og * (1.f - tc * tc);
+        f32x4 g;
+        g[0] = dct * ci.gg * ci.ig * (1.f - ci.ig);
+        g[1] = dct * ci.cp * ci.fg * (1.f - ci.fg);
+        g[2] = dct * ci.ig * (1.f - ci.gg * ci.gg);
+        g[3] = dh * tc * ci.og * (1.f - ci.og);
+        dc = dct * ci.fg;
+        return g;
+    }
+    static __device__ __forceinline__ void stash_dG(const PersistBwdArgs& a, int layer, int s, unsigned o4, const f32x4 g) {
+        float* dp = at_bytes(a.dG_all + 4 * (((size_t)layer * a.U + s) * (size_t)a.B * HS), o4);
+        dp[0] = g[0]; dp[HS] = g[1]; dp[2 * HS] = g[2]; dp[3 * HS] = g[3];
+    }
+
+    template <bool IS_Y>
+    static __device__ void run(const PersistBwdArgs& a, float* smem, const int widx) {
+        const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+        const int j = widx >> 1, mt = widx & 1;
+        const int B = a.B, U = a.U;
+        if (mt * 16 >= B) return;                         // no utterance in this M-tile: nobody waits for its rows
+        const bool first_wg = widx == 0;
+        float* redA = smem;
+        float* redB = smem + RED;
+        // resident weights: Y = [W_ctx | W_hh1] (inputs dG0 / dG1), X = [W_ih1 | W_hh0] (inputs dG1 / dG0)
+        // The chain product's columns stay in VGPRs (32 floats per lane at Hs=512); the recurrent product (off the chain)
+        // keeps half of its columns in VGPRs and half in LDS — 64 resident weights per lane end in scratch spills.
+        float Wc[KB][4], Wo[KB / 2][4];
+        float* wlds = smem + 2 * RED + (wave * (KB / 2) * 64 + lane) * 4;      // [wave][block][lane][gate]
+        {
+            float Wt[KB][4];
+            load_w(IS_Y ? a.w_hh1 : a.w_hh0, HS, 0, j, wave, lane, Wt);
+#pragma unroll
+            for (int blk = 0; blk < KB / 2; ++blk) {
+                f32x4 v;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) { Wo[blk][e] = Wt[blk][e]; v[e] = Wt[KB / 2 + blk][e]; }
+                *reinterpret_cast<f32x4*>(wlds + blk * 256) = v;
+            }
+        }
+        if (IS_Y) load_w(a.w_ih0, a.ldw0, a.V, j, wave, lane, Wc);
+        else load_w(a.w_ih1, HS, 0, j, wave, lane, Wc);
+        auto mfma_rec = [&](const f32x4 (&xt)[KB]) {
+            f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int blk = 0; blk < KB / 2; ++blk)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(xt[blk][e], Wo[blk][e], acc, 0, 0, 0);
+#pragma unroll
+            for (int blk = 0; blk < KB / 2; ++blk) {
+                const f32x4 w = *reinterpret_cast<const f32x4*>(wlds + blk * 256);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(xt[KB / 2 + blk][e], w[e], acc, 0, 0, 0);
+            }
+            return acc;
+        };
+        const Lane la = lane_addr(B, mt, wave, lane);
+        // cell lane: (utterance pb, unit pu) of this workgroup's tile
+        const int pb = mt * 16 + (tid >> 4), pu = tid & 15;
+        const bool pw = tid < 256 && pb < B;
+        const unsigned o1 = 4u * ((unsigned)pb * HS + 16 * j + pu);           // byte offset in a (B,Hs) slab
+        const unsigned o4 = 4u * ((unsigned)pb * 4 * HS + 16 * j + pu);       // ... in a (B,4Hs) slab
+        const unsigned ox = 4u * ((((unsigned)j * 32 + pb) * 16 + pu) * 4);   // its float4 in a tiled dG slab
+        const unsigned oc = 4u * (((unsigned)j * 32 + pb) * 16 + pu);         // its dword in a dcx slab
+        const int layer = IS_Y ? 1 : 0;
+        const float* dGx_in_chain = a.dGx + (size_t)(IS_Y ? 0 : 1) * U * GXS;   // Y multiplies dG0, X multiplies dG1
+        const float* dGx_in_rec = a.dGx + (size_t)(IS_Y ? 1 : 0) * U * GXS;     // recurrent product: the layer's own dG
+        float* dGx_out = a.dGx + (size_t)layer * U * GXS;
+        float dc = 0.f, dh_carry = 0.f;
+        f32x4 x[KB];
+        for (int s = U - 1; s >= 0; --s) {
+            CellIn ci;
+            float dcat = 0.f;
+            if (pw) {
+                ci = load_cell(a, layer, s, opaque(o4), opaque(o1));
+                if (IS_Y) dcat = *at_bytes(a.dcat_all + (size_t)s * B * 2 * HS, opaque(4u * ((unsigned)pb * 2 * HS + 16 * j + pu)));
+            }
+            if (IS_Y) {
+                // ---- Y1: decoder-state gradient parts of the two attention halves -> top-layer cell backward -> dG1_s
+                PB_STAMP(1, s, 0);
+                if (pw) {
+                    const unsigned* p0 = reinterpret_cast<const unsigned*>(
+                        at_bytes(a.dhA + (size_t)s * B * 2 * HS, opaque(4u * ((unsigned)pb * 2 * HS + 16 * j + pu))));
+                    unsigned spins = 0, v0, v1;
+                    for (;;) {
+                        v0 = __hip_atomic_load(p0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        v1 = __hip_atomic_load(p0 + HS, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        if (v0 != PS_SENT && v1 != PS_SENT) break;
+                        if (spin_expired(spins, a.err, 0xDEAD0023u)) break;
+                    }
+                    PB_STAMP(1, s, 1);
+                    const float dh = dcat + __uint_as_float(v0) + __uint_as_float(v1) + dh_carry;
+                    const f32x4 g = cell_bwd(ci, dh, dc);
+                    st4_agent(at_bytes(dGx_out + (size_t)s * GXS, opaque(ox)), g);
+                    stash_dG(a, 1, s, opaque(o4), g);
+                }
+                PB_STAMP(1, s, 2);
+                // ---- Y2 (off the chain): recurrent carry of the top layer for step s-1
+                if (s > 0) {
+                    poll_tile(dGx_in_rec + (size_t)s * GXS, la, x, a.err);
+                    dh_carry = reduce_tile(redB, mfma_rec(x), wave, lane, tid);
+                }
+                PB_STAMP(1, s, 3);
+                // ---- Y3: context gradient of step s-1's attention = dG0_s W_ctx
+                poll_tile(dGx_in_chain + (size_t)s * GXS, la, x, a.err);
+                PB_STAMP(1, s, 4);
+#ifdef PB_DEBUG_CHECK
+                for (int blk = 0; blk < KB; ++blk) for (int e = 0; e < 4; ++e) if (la.ok && !(fabsf(x[blk][e]) < 1e10f)) atomicOr(a.err, 0xDEAD0001u);
+                for (int blk = 0; blk < KB; ++blk) for (int e = 0; e < 4; ++e) if (!(fabsf(Wc[blk][e]) < 1e10f)) atomicOr(a.err, 0xDEAD0002u);
+#endif
+                const float dctx = reduce_tile(redA, mfma_tile(x, Wc), wave, lane, tid);
+#ifdef PB_DEBUG_CHECK
+                if (pw && !(fabsf(dctx) < 1e10f)) atomicOr(a.err, 0xDEAD0004u);
+#endif
+                if (pw) {
+                    st1_agent(at_bytes(a.dcx + (size_t)s * CXS, opaque(oc)), dctx);
+                    if (s == 0) a.dx0[(size_t)pb * a.ldx0 + a.V + 16 * j + pu] = dctx;
+                }
+                PB_STAMP(1, s, 5);
+            } else {
+                // ---- X1: dh0 = dG1_s W_ih1 -> bottom-layer cell backward -> dG0_s
+                PB_STAMP(0, s, 0);
+                poll_tile(dGx_in_chain + (size_t)s * GXS, la, x, a.err);
+                PB_STAMP(0, s, 1);
+                const float dh0 = reduce_tile(redA, mfma_tile(x, Wc), wave, lane, tid);
+                if (pw) {
+                    const f32x4 g = cell_bwd(ci, dh0 + dh_carry, dc);
+                    st4_agent(at_bytes(dGx_out + (size_t)s * GXS, opaque(ox)), g);
+#ifdef PB_DEBUG_CHECK
+                    if (!(fabsf(g[0]) < 1e10f) || !(fabsf(g[3]) < 1e10f)) atomicOr(a.err, 0xDEAD0008u);
+                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                    const f32x4 rb = ld4_agent(at_bytes(dGx_out + (size_t)s * GXS, opaque(ox)));
+                    if (rb[0] != g[0] || rb[3] != g[3]) atomicOr(a.err, 0xDEAD0010u);
+#endif
+                    stash_dG(a, 0, s, opaque(o4), g);
+                }
+                PB_STAMP(0, s, 2);
+                // ---- X2 (off the chain): recurrent carry of the bottom layer for step s-1
+                if (s > 0) {
+                    poll_tile(dGx_in_rec + (size_t)s * GXS, la, x, a.err);
+                    dh_carry = reduce_tile(redB, mfma_rec(x), wave, lane, tid);
+                }
+                PB_STAMP(0, s, 3);
+            }
+        }
+    }
+};
+
+// ------------------------------------------------------------------------------------------------ attention backward
+template <int HS>
+struct AttnBwdRole {
+    static constexpr int D = HS;
+    static constexpr int CW = HS / 16, NF4 = CW / 4;        // columns per lane (16 lanes per frame)
+    static constexpr int RP = 512 / HS;                     // frames per lane group
+    static constexpr int TH = 64 * RP;                      // frames per workgroup
+    static constexpr int NMH = PS_THREADS / HS, MPT = PS_M / NMH;   // dh = W_phi^T dqpre: (column, m-slice) per thread
+    static __host__ __device__ constexpr int lds_floats() { return 2 * HS + PS_M + TH + 16 * PS_M + PS_M + NMH * HS + TH * PS_KLD; }
+
+    static __device__ void run(const PersistBwdArgs& a, float* smem, const int widx) {
+        const int b = widx >> 1, half = widx & 1;
+        const bool first_wg = widx == 0;
+        const int tid = threadIdx.x;
+        const int B = a.B, U = a.U, Tp = a.Tp;
+        const int th = (Tp + 1) / 2, t0 = half * th, nt = max(0, min(th, Tp - t0));     // this workgroup's frames
+        float* dctx = smem;
+        float* ctxs = dctx + HS;
+        float* qs = ctxs + HS;
+        float* de = qs + PS_M;
+        float* dqp = de + TH;
+        float* dqpre = dqp + 16 * PS_M;
+        float* dhp = dqpre + PS_M;
+        float* ks = dhp + NMH * HS;
+        const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
+
+        // ---- resident operands: listener features of its frames (registers), keys (LDS), W_phi columns (registers)
+        const int tl = tid >> 4, l16 = tid & 15;
+        f32x4 fr[RP][NF4];
+#pragma unroll
+        for (int p = 0; p < RP; ++p) {
+            const int t = tl + 64 * p;
+#pragma unroll
+            for (int i = 0; i < NF4; ++i) {
+                const f32x4 v = ld4p(a.feat + ((size_t)b * Tp + (t < nt ? t0 + t : 0)) * D + l16 * CW + 4 * i);
+                fr[p][i] = t < nt ? v : zero;
+            }
+        }
+        for (int idx = tid; idx < nt * (PS_M / 4); idx += PS_THREADS) {
+            const int t = idx / (PS_M / 4), m4 = idx % (PS_M / 4);
+            *reinterpret_cast<f32x4*>(ks + t * PS_KLD + m4 * 4) = ld4p(a.keys + ((size_t)b * Tp + t0 + t) * PS_M + m4 * 4);
+        }
+        const int pc = tid % HS, pmh = tid / HS;
+        float wph[MPT];
+#pragma unroll
+        for (int i = 0; i < MPT; ++i) wph[i] = a.w_phi[(size_t)(pmh * MPT + i) * HS + pc];
+        lds_barrier();
+
+        for (int s = U - 1; s >= 0; --s) {
+            // ---- stash operands of this step (plain loads, issued before the wait)
+            float at[RP];
+#pragma unroll
+            for (int p = 0; p < RP; ++p) {
+                const int t = tl + 64 * p;
+                at[p] = t < nt ? a.att[((size_t)s * B + b) * Tp + t0 + t] : 0.f;
+            }
+            if (tid < PS_M) qs[tid] = a.q_all[((size_t)s * B + b) * PS_M + tid];
+            f32x4 dcv = zero;
+            if (tid < HS / 4) {
+                *reinterpret_cast<f32x4*>(ctxs + tid * 4) = ld4p(a.ctx_all + ((size_t)(s + 1) * B + b) * D + tid * 4);
+                dcv = ld4p(a.dcat_all + ((size_t)s * B + b) * 2 * HS + HS + tid * 4);
+            }
+            PB_STAMP(2, s, 0);
+            // ---- total context gradient = character-distribution part + what step s+1's bottom cell passed back
+            if (tid < HS / 4) {
+                f32x4 v = zero;
+                if (s < U - 1) {
+                    const float* p = a.dcx + (size_t)(s + 1) * ((size_t)(HS / 16) * 32 * 16) + ((size_t)(tid >> 2) * 32 + b) * 16 + (tid & 3) * 4;
+                    unsigned spins = 0;
+                    for (;;) {
+                        v = ld4_agent(p);
+                        if (!__any(has_sentinel(v))) break;
+                        if (spin_expired(spins, a.err, 0xDEAD0024u)) break;
+                    }
+                }
+                v[0] += dcv[0]; v[1] += dcv[1]; v[2] += dcv[2]; v[3] += dcv[3];
+                *reinterpret_cast<f32x4*>(dctx + tid * 4) = v;
+                if (half == 0) *reinterpret_cast<f32x4*>(a.dctx_all + ((size_t)s * B + b) * D + tid * 4) = v;
+            }
+            PB_STAMP(2, s, 1);
+            lds_barrier();
+            // ---- da_t = feat_t . dctx ; softmax backward de_t = a_t (da_t - ctx . dctx)   (16 lanes per frame)
+            {
+                float sd = 0.f, da[RP];
+#pragma unroll
+                for (int p = 0; p < RP; ++p) da[p] = 0.f;
+#pragma unroll
+                for (int i = 0; i < NF4; ++i) {
+                    const f32x4 dv = *reinterpret_cast<const f32x4*>(dctx + l16 * CW + 4 * i);
+                    sd = dot4p(*reinterpret_cast<const f32x4*>(ctxs + l16 * CW + 4 * i), dv, sd);
+#pragma unroll
+                    for (int p = 0; p < RP; ++p) da[p] = dot4p(fr[p][i], dv, da[p]);
+                }
+                sd = gsum<16>(sd);
+#pragma unroll
+                for (int p = 0; p < RP; ++p) {
+                    const float v = at[p] * (gsum<16>(da[p]) - sd);
+                    const int t = tl + 64 * p;
+                    if (l16 == 0) {
+                        de[t] = v;                                           // zero beyond nt (at = 0)
+                        if (t < nt) a.de_all[((size_t)s * B + b) * Tp + t0 + t] = v;
+                    }
+                }
+            }
+            lds_barrier();
+            PB_STAMP(2, s, 2);
+            // ---- dq[m] = sum_t de_t keys[t][m] over this half's frames
+            {
+                const int m = tid & 63, tg = tid >> 6;
+                float acc = 0.f;
+                for (int t = tg; t < nt; t += 16) acc = fmaf(de[t], ks[t * PS_KLD + m], acc);
+                dqp[tg * PS_M + m] = acc;
+            }
+            lds_barrier();
+            if (tid < PS_M) {
+                float v = 0.f;
+#pragma unroll
+                for (int g = 0; g < 16; ++g) v += dqp[g * PS_M + tid];
+                if (a.relu && !(qs[tid] > 0.f)) v = 0.f;
+                dqpre[tid] = v;
+                a.dqpre_part[(((size_t)half * U + s) * B + b) * PS_M + tid] = v;
+            }
+            lds_barrier();
+            PB_STAMP(2, s, 3);
+            // ---- decoder-state gradient part: W_phi^T dqpre
+            {
+                float acc = 0.f;
+#pragma unroll
+                for (int i = 0; i < MPT; ++i) acc = fmaf(wph[i], dqpre[pmh * MPT + i], acc);
+                dhp[pmh * HS + pc] = acc;
+            }
+            lds_barrier();
+            if (tid < HS / 4) {
+                f32x4 v = zero;
+#pragma unroll
+                for (int q = 0; q < NMH; ++q) {
+                    const f32x4 w = *reinterpret_cast<const f32x4*>(dhp + q * HS + tid * 4);
+                    v[0] += w[0]; v[1] += w[1]; v[2] += w[2]; v[3] += w[3];
+                }
+                st4_agent(a.dhA + (((size_t)s * B + b) * 2 + half) * HS + tid * 4, v);
+            }
+            PB_STAMP(2, s, 4);
+        }
+    }
+};
+
+template <int HS>
+__global__ __launch_bounds__(PS_THREADS) void speller_persist_bwd_kernel(PersistBwdArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    constexpr int NXY = (HS / 16) * 2;
+    const int bx = blockIdx.x;
+#if defined(PB_ONLY_PROD)
+    ProdRole<HS>::template run<true>(a, smem, bx);
+#elif defined(PB_ONLY_ATTN)
+    AttnBwdRole<HS>::run(a, smem, bx);
+#else
+    if (bx < NXY) ProdRole<HS>::template run<false>(a, smem, bx);
+    else if (bx < 2 * NXY) ProdRole<HS>::template run<true>(a, smem, bx - NXY);
+    else AttnBwdRole<HS>::run(a, smem, bx - 2 * NXY);
+#endif
+}
+
+// ------------------------------------------------------------------------------------------------ host side
+static unsigned long long* g_persist_bwd_trace = nullptr;
+void speller_persist_bwd_set_trace(unsigned long long* dev_buf) { g_persist_bwd_trace = dev_buf; }
+
+bool speller_persist_bwd_eligible(int B, int Tp, int Hs, int D, int M, int V, int L, int heads, int use_mlp) {
+    if (L != 2 || heads != 1 || !use_mlp || M != PS_M || D != Hs) return false;
+    if (Hs != 256 && Hs != 512) return false;
+    if (B < 1 || B > 32) return false;
+    if (Tp > 2 * 64 * (512 / Hs)) return false;
+    int cus = 0, dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess)
+        return false;
+    return 2 * (Hs / 16) * 2 + 2 * B <= cus;
+}
+
+size_t speller_persist_bwd_workspace_floats(int B, int U, int Hs) {
+    return (size_t)U * B * 2 * Hs + (size_t)2 * U * (Hs / 16) * 32 * 64 + (size_t)U * (Hs / 16) * 32 * 16;
+}
+
+int speller_persist_bwd(const PersistBwd& p, hipStream_t stream) {
+    LAS_REQUIRE(speller_persist_bwd_eligible(p.B, p.Tp, p.Hs, p.Hs, PS_M, p.V, 2, 1, 1), "persistent speller backward shape");
+    LAS_REQUIRE(p.err != nullptr && p.xbuf != nullptr, "persistent speller backward buffers");
+    PersistBwdArgs a;
+    a.w_ih0 = p.w_ih0; a.ldw0 = p.V + p.Hs; a.V = p.V;
+    a.w_hh0 = p.w_hh0; a.w_ih1 = p.w_ih1; a.w_hh1 = p.w_hh1; a.w_phi = p.w_phi;
+    a.feat = p.feat; a.keys = p.keys; a.att = p.att; a.q_all = p.q_all; a.ctx_all = p.ctx_all;
+    a.gates_all = p.gates_all; a.c_all = p.c_all; a.dcat_all = p.dcat_all;
+    a.dG_all = p.dG_all; a.dctx_all = p.dctx_all; a.de_all = p.de_all; a.dqpre_part = p.dqpre_part;
+    a.dx0 = p.dx0; a.ldx0 = p.V + p.Hs;
+    a.dhA = p.xbuf;
+    a.dGx = a.dhA + (size_t)p.U * p.B * 2 * p.Hs;
+    a.dcx = a.dGx + (size_t)2 * p.U * (p.Hs / 16) * 32 * 64;
+    a.B = p.B; a.Tp = p.Tp; a.U = p.U; a.relu = p.relu; a.err = p.err; a.trace = g_persist_bwd_trace;
+    LAS_HIP_CHECK(hipMemsetAsync(p.xbuf, 0xFF, sizeof(float) * speller_persist_bwd_workspace_floats(p.B, p.U, p.Hs), stream));
+    const int grid = 2 * (p.Hs / 16) * 2 + 2 * p.B;
+    if (p.Hs == 512) {
+        const size_t smem = sizeof(float) * (size_t)std::max(ProdRole<512>::LDS_FLOATS, AttnBwdRole<512>::lds_floats());
+        LAS_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&speller_persist_bwd_kernel<512>),
+                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
+        hipLaunchKernelGGL((speller_persist_bwd_kernel<512>), dim3(grid), dim3(PS_THREADS), smem, stream, a);
+    } else {
+        const size_t smem = sizeof(float) * (size_t)std::max(ProdRole<256>::LDS_FLOATS, AttnBwdRole<256>::lds_floats());
+        LAS_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&speller_persist_bwd_kernel<256>),
+                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
+        hipLaunchKernelGGL((speller_persist_bwd_kernel<256>), dim3(grid), dim3(PS_THREADS), smem, stream, a);
+    }
+    LAS_LAUNCH_CHECK();
+    return LAS_OK;
+}
+
+}  // namespace las

@@ -273,7 +273,7 @@ class _SpellerFn(torch.autograd.Function):
         work = torch.empty(Lh.las_speller_bwd_workspace_floats(d, U), device=dev, dtype=torch.float32)
         mode0 = int((not teacher_forced) and decode_mode == 0)
         check(Lh.las_speller_bwd(d, ptr(feat), ptr(keys), ptr(logp), ptr(att), ptr(dlogp), U, mode0, ptr(reserve),
-                                 ptr(work), g, stream_ptr()))
+                                 ptr(work), g, ptr(_cabi.err_word(dev)), _flags(True), stream_ptr()))
         return (None, dfeat, None, *grads)
 
 
