@@ -37,6 +37,7 @@ struct PersistBwdArgs {
     float* dhA;      // [U][B][2][Hs]            decoder-state gradient parts of the two attention halves
     float* dGx;      // [2][U][Hs/16][32][64]    tiled gate gradients (layer, step, unit tile, row, unit*4+gate)
     float* dcx;      // [U][Hs/16][32][16]       context gradient carried to the previous step
+    float* dhc;      // [U][Hs/16][32][16]       top-layer recurrent carry (R -> Y)
     int B, Tp, U, relu;
     unsigned* err;
     unsigned long long* trace;
@@ -53,7 +54,7 @@ struct ProdRole {
     static constexpr size_t GXS = (size_t)NJ * 32 * 64;    // floats of one tiled dG slab
     static constexpr size_t CXS = (size_t)NJ * 32 * 16;    // floats of one dcx slab
     static constexpr int RED = PS_NW * 16 * 17;
-    static constexpr int LDS_FLOATS = 2 * RED + PS_NW * (KB / 2) * 64 * 4;     // two reduction buffers + half of W_rec
+    static constexpr int LDS_FLOATS = RED + PS_NW * KB * 64 * 4;       // reduction buffer + (X role) the columns of W_hh0
 
     struct Lane {
         unsigned x[JPW];       // byte offset of this lane's float4 of the first k-block of unit tile i inside a dG slab
@@ -140,6 +141,7 @@ struct ProdRole {
     // sum the 16 waves' partial 16x16 tiles; the result for (utterance m, unit n) lands in thread m*16+n (< 256)
     static __device__ __forceinline__ float reduce_tile(float* red, const f32x4 acc, int wave, int lane, int tid) {
         const int r = lane & 15, kq = lane >> 4;
+        lds_barrier();                                   // the previous reduction's readers are done with the buffer
 #pragma unroll
         for (int i = 0; i < 4; ++i) red[(wave * 16 + kq * 4 + i) * 17 + r] = acc[i];
         lds_barrier();
@@ -178,44 +180,42 @@ struct ProdRole {
         dp[0] = g[0]; dp[HS] = g[1]; dp[2 * HS] = g[2]; dp[3 * HS] = g[3];
     }
 
-    template <bool IS_Y>
+    // ROLE 0 (X): dh0 = dG1 W_ih1 -> bottom cell backward -> dG0 ; recurrent carry dG0 W_hh0 (own, off the chain, W in LDS)
+    // ROLE 1 (Y): top cell backward -> dG1 ; dctx = dG0 W_ctx
+    // ROLE 2 (R): recurrent carry of the top layer dG1 W_hh1, handed to the Y workgroup of the same tile (off the chain)
+    template <int ROLE>
     static __device__ void run(const PersistBwdArgs& a, float* smem, const int widx) {
+        constexpr bool IS_X = ROLE == 0, IS_Y = ROLE == 1, IS_R = ROLE == 2;
         const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
         const int j = widx >> 1, mt = widx & 1;
         const int B = a.B, U = a.U;
         if (mt * 16 >= B) return;                         // no utterance in this M-tile: nobody waits for its rows
         const bool first_wg = widx == 0;
-        float* redA = smem;
-        float* redB = smem + RED;
-        // resident weights: Y = [W_ctx | W_hh1] (inputs dG0 / dG1), X = [W_ih1 | W_hh0] (inputs dG1 / dG0)
-        // The chain product's columns stay in VGPRs (32 floats per lane at Hs=512); the recurrent product (off the chain)
-        // keeps half of its columns in VGPRs and half in LDS — 64 resident weights per lane end in scratch spills.
-        float Wc[KB][4], Wo[KB / 2][4];
-        float* wlds = smem + 2 * RED + (wave * (KB / 2) * 64 + lane) * 4;      // [wave][block][lane][gate]
-        {
+        float* red = smem;
+        // one weight matrix resident in VGPRs per role (32 floats per lane at Hs=512); X also keeps W_hh0 in LDS
+        float Wc[KB][4];
+        if (IS_X) load_w(a.w_ih1, HS, 0, j, wave, lane, Wc);
+        else if (IS_Y) load_w(a.w_ih0, a.ldw0, a.V, j, wave, lane, Wc);
+        else load_w(a.w_hh1, HS, 0, j, wave, lane, Wc);
+        float* wlds = smem + RED + (wave * KB * 64 + lane) * 4;              // [wave][block][lane][gate]
+        if (IS_X) {
             float Wt[KB][4];
-            load_w(IS_Y ? a.w_hh1 : a.w_hh0, HS, 0, j, wave, lane, Wt);
+            load_w(a.w_hh0, HS, 0, j, wave, lane, Wt);
 #pragma unroll
-            for (int blk = 0; blk < KB / 2; ++blk) {
+            for (int blk = 0; blk < KB; ++blk) {
                 f32x4 v;
 #pragma unroll
-                for (int e = 0; e < 4; ++e) { Wo[blk][e] = Wt[blk][e]; v[e] = Wt[KB / 2 + blk][e]; }
+                for (int e = 0; e < 4; ++e) v[e] = Wt[blk][e];
                 *reinterpret_cast<f32x4*>(wlds + blk * 256) = v;
             }
         }
-        if (IS_Y) load_w(a.w_ih0, a.ldw0, a.V, j, wave, lane, Wc);
-        else load_w(a.w_ih1, HS, 0, j, wave, lane, Wc);
-        auto mfma_rec = [&](const f32x4 (&xt)[KB]) {
+        auto mfma_lds = [&](const f32x4 (&xt)[KB]) {
             f32x4 acc = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-            for (int blk = 0; blk < KB / 2; ++blk)
-#pragma unroll
-                for (int e = 0; e < 4; ++e) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(xt[blk][e], Wo[blk][e], acc, 0, 0, 0);
-#pragma unroll
-            for (int blk = 0; blk < KB / 2; ++blk) {
+            for (int blk = 0; blk < KB; ++blk) {
                 const f32x4 w = *reinterpret_cast<const f32x4*>(wlds + blk * 256);
 #pragma unroll
-                for (int e = 0; e < 4; ++e) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(xt[KB / 2 + blk][e], w[e], acc, 0, 0, 0);
+                for (int e = 0; e < 4; ++e) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(xt[blk][e], w[e], acc, 0, 0, 0);
             }
             return acc;
         };
@@ -226,14 +226,32 @@ struct ProdRole {
         const unsigned o1 = 4u * ((unsigned)pb * HS + 16 * j + pu);           // byte offset in a (B,Hs) slab
         const unsigned o4 = 4u * ((unsigned)pb * 4 * HS + 16 * j + pu);       // ... in a (B,4Hs) slab
         const unsigned ox = 4u * ((((unsigned)j * 32 + pb) * 16 + pu) * 4);   // its float4 in a tiled dG slab
-        const unsigned oc = 4u * (((unsigned)j * 32 + pb) * 16 + pu);         // its dword in a dcx slab
+        const unsigned oc = 4u * (((unsigned)j * 32 + pb) * 16 + pu);         // its dword in a dcx / dhc slab
         const int layer = IS_Y ? 1 : 0;
-        const float* dGx_in_chain = a.dGx + (size_t)(IS_Y ? 0 : 1) * U * GXS;   // Y multiplies dG0, X multiplies dG1
-        const float* dGx_in_rec = a.dGx + (size_t)(IS_Y ? 1 : 0) * U * GXS;     // recurrent product: the layer's own dG
+        const float* dG1x = a.dGx + (size_t)U * GXS;
+        const float* dG0x = a.dGx;
         float* dGx_out = a.dGx + (size_t)layer * U * GXS;
         float dc = 0.f, dh_carry = 0.f;
         f32x4 x[KB];
         for (int s = U - 1; s >= 0; --s) {
+            if (IS_R) {
+                // ---- recurrent carry of the top layer for step s-1: dG1_s W_hh1 -> Y workgroup (j, mt)
+                if (s == 0) break;
+                PB_STAMP(3, s, 0);
+                {   // start once the X workgroup of the same tile has published dG0_s, i.e. consumed dG1_s: the chain's
+                    // consumers get the fabric and the L2 to themselves (this carry is only needed a whole step later)
+                    const unsigned* cp = reinterpret_cast<const unsigned*>(dG0x + (size_t)s * GXS) + (((unsigned)j * 32 + mt * 16) * 64 + 63);
+                    unsigned spins = 0;
+                    while (__hip_atomic_load(cp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == PS_SENT)
+                        if (spin_expired(spins, a.err, 0xDEAD0026u)) break;
+                }
+                poll_tile(dG1x + (size_t)s * GXS, la, x, a.err);
+                PB_STAMP(3, s, 1);
+                const float v = reduce_tile(red, mfma_tile(x, Wc), wave, lane, tid);
+                if (pw) st1_agent(at_bytes(a.dhc + (size_t)s * CXS, opaque(oc)), v);
+                PB_STAMP(3, s, 2);
+                continue;
+            }
             CellIn ci;
             float dcat = 0.f;
             if (pw) {
@@ -241,42 +259,32 @@ struct ProdRole {
                 if (IS_Y) dcat = *at_bytes(a.dcat_all + (size_t)s * B * 2 * HS, opaque(4u * ((unsigned)pb * 2 * HS + 16 * j + pu)));
             }
             if (IS_Y) {
-                // ---- Y1: decoder-state gradient parts of the two attention halves -> top-layer cell backward -> dG1_s
+                // ---- Y1: decoder-state gradient parts of the two attention halves (+ carry from R) -> top cell backward -> dG1_s
                 PB_STAMP(1, s, 0);
                 if (pw) {
                     const unsigned* p0 = reinterpret_cast<const unsigned*>(
                         at_bytes(a.dhA + (size_t)s * B * 2 * HS, opaque(4u * ((unsigned)pb * 2 * HS + 16 * j + pu))));
-                    unsigned spins = 0, v0, v1;
+                    const unsigned* pc = reinterpret_cast<const unsigned*>(at_bytes(a.dhc + (size_t)(s + 1) * CXS, opaque(oc)));
+                    unsigned spins = 0, v0, v1, vc = 0u;
                     for (;;) {
                         v0 = __hip_atomic_load(p0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                         v1 = __hip_atomic_load(p0 + HS, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                        if (v0 != PS_SENT && v1 != PS_SENT) break;
+                        if (s < U - 1) vc = __hip_atomic_load(pc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        if (v0 != PS_SENT && v1 != PS_SENT && vc != PS_SENT) break;
                         if (spin_expired(spins, a.err, 0xDEAD0023u)) break;
                     }
                     PB_STAMP(1, s, 1);
-                    const float dh = dcat + __uint_as_float(v0) + __uint_as_float(v1) + dh_carry;
+                    const float dh = dcat + __uint_as_float(v0) + __uint_as_float(v1) + __uint_as_float(vc);
                     const f32x4 g = cell_bwd(ci, dh, dc);
                     st4_agent(at_bytes(dGx_out + (size_t)s * GXS, opaque(ox)), g);
                     stash_dG(a, 1, s, opaque(o4), g);
                 }
                 PB_STAMP(1, s, 2);
-                // ---- Y2 (off the chain): recurrent carry of the top layer for step s-1
-                if (s > 0) {
-                    poll_tile(dGx_in_rec + (size_t)s * GXS, la, x, a.err);
-                    dh_carry = reduce_tile(redB, mfma_rec(x), wave, lane, tid);
-                }
-                PB_STAMP(1, s, 3);
                 // ---- Y3: context gradient of step s-1's attention = dG0_s W_ctx
-                poll_tile(dGx_in_chain + (size_t)s * GXS, la, x, a.err);
+                PB_STAMP(1, s, 3);
+                poll_tile(dG0x + (size_t)s * GXS, la, x, a.err);
                 PB_STAMP(1, s, 4);
-#ifdef PB_DEBUG_CHECK
-                for (int blk = 0; blk < KB; ++blk) for (int e = 0; e < 4; ++e) if (la.ok && !(fabsf(x[blk][e]) < 1e10f)) atomicOr(a.err, 0xDEAD0001u);
-                for (int blk = 0; blk < KB; ++blk) for (int e = 0; e < 4; ++e) if (!(fabsf(Wc[blk][e]) < 1e10f)) atomicOr(a.err, 0xDEAD0002u);
-#endif
-                const float dctx = reduce_tile(redA, mfma_tile(x, Wc), wave, lane, tid);
-#ifdef PB_DEBUG_CHECK
-                if (pw && !(fabsf(dctx) < 1e10f)) atomicOr(a.err, 0xDEAD0004u);
-#endif
+                const float dctx = reduce_tile(red, mfma_tile(x, Wc), wave, lane, tid);
                 if (pw) {
                     st1_agent(at_bytes(a.dcx + (size_t)s * CXS, opaque(oc)), dctx);
                     if (s == 0) a.dx0[(size_t)pb * a.ldx0 + a.V + 16 * j + pu] = dctx;
@@ -285,25 +293,29 @@ struct ProdRole {
             } else {
                 // ---- X1: dh0 = dG1_s W_ih1 -> bottom-layer cell backward -> dG0_s
                 PB_STAMP(0, s, 0);
-                poll_tile(dGx_in_chain + (size_t)s * GXS, la, x, a.err);
+                poll_tile(dG1x + (size_t)s * GXS, la, x, a.err);
                 PB_STAMP(0, s, 1);
-                const float dh0 = reduce_tile(redA, mfma_tile(x, Wc), wave, lane, tid);
+                const f32x4 accx = mfma_tile(x, Wc);
+                if (a.trace && first_wg && tid == 0) { asm volatile("s_nop 0" :: "v"(accx[0])); }
+                PB_STAMP(0, s, 6);
+                const float dh0 = reduce_tile(red, accx, wave, lane, tid);
+                PB_STAMP(0, s, 7);
                 if (pw) {
                     const f32x4 g = cell_bwd(ci, dh0 + dh_carry, dc);
                     st4_agent(at_bytes(dGx_out + (size_t)s * GXS, opaque(ox)), g);
-#ifdef PB_DEBUG_CHECK
-                    if (!(fabsf(g[0]) < 1e10f) || !(fabsf(g[3]) < 1e10f)) atomicOr(a.err, 0xDEAD0008u);
-                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                    const f32x4 rb = ld4_agent(at_bytes(dGx_out + (size_t)s * GXS, opaque(ox)));
-                    if (rb[0] != g[0] || rb[3] != g[3]) atomicOr(a.err, 0xDEAD0010u);
-#endif
                     stash_dG(a, 0, s, opaque(o4), g);
                 }
                 PB_STAMP(0, s, 2);
                 // ---- X2 (off the chain): recurrent carry of the bottom layer for step s-1
                 if (s > 0) {
-                    poll_tile(dGx_in_rec + (size_t)s * GXS, la, x, a.err);
-                    dh_carry = reduce_tile(redB, mfma_rec(x), wave, lane, tid);
+                    {   // start once the Y workgroup of the same tile has consumed dG0_s: both would pull the same 8 MB
+                        const unsigned* cp = reinterpret_cast<const unsigned*>(a.dcx + (size_t)s * CXS) + ((unsigned)j * 32 + mt * 16) * 16;
+                        unsigned spins = 0;
+                        while (__hip_atomic_load(cp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == PS_SENT)
+                            if (spin_expired(spins, a.err, 0xDEAD0025u)) break;
+                    }
+                    poll_tile(dG0x + (size_t)s * GXS, la, x, a.err);
+                    dh_carry = reduce_tile(red, mfma_lds(x), wave, lane, tid);
                 }
                 PB_STAMP(0, s, 3);
             }
@@ -345,7 +357,7 @@ struct AttnBwdRole {
             const int t = tl + 64 * p;
 #pragma unroll
             for (int i = 0; i < NF4; ++i) {
-                const f32x4 v = ld4p(a.feat + ((size_t)b * Tp + (t < nt ? t0 + t : 0)) * D + l16 * CW + 4 * i);
+                const f32x4 v = ld4p(a.feat + ((size_t)b * Tp + (t < nt ? t0 + t : 0)) * D + 4 * (l16 + 16 * i));
                 fr[p][i] = t < nt ? v : zero;
             }
         }
@@ -399,8 +411,9 @@ struct AttnBwdRole {
                 for (int p = 0; p < RP; ++p) da[p] = 0.f;
 #pragma unroll
                 for (int i = 0; i < NF4; ++i) {
-                    const f32x4 dv = *reinterpret_cast<const f32x4*>(dctx + l16 * CW + 4 * i);
-                    sd = dot4p(*reinterpret_cast<const f32x4*>(ctxs + l16 * CW + 4 * i), dv, sd);
+                    // lane l16 owns the float4 columns l16, l16+16, ...: consecutive lanes hit consecutive LDS banks
+                    const f32x4 dv = *reinterpret_cast<const f32x4*>(dctx + 4 * (l16 + 16 * i));
+                    sd = dot4p(*reinterpret_cast<const f32x4*>(ctxs + 4 * (l16 + 16 * i)), dv, sd);
 #pragma unroll
                     for (int p = 0; p < RP; ++p) da[p] = dot4p(fr[p][i], dv, da[p]);
                 }
@@ -463,13 +476,14 @@ __global__ __launch_bounds__(PS_THREADS) void speller_persist_bwd_kernel(Persist
     constexpr int NXY = (HS / 16) * 2;
     const int bx = blockIdx.x;
 #if defined(PB_ONLY_PROD)
-    ProdRole<HS>::template run<true>(a, smem, bx);
+    ProdRole<HS>::template run<PB_ONLY_PROD>(a, smem, bx);
 #elif defined(PB_ONLY_ATTN)
     AttnBwdRole<HS>::run(a, smem, bx);
 #else
-    if (bx < NXY) ProdRole<HS>::template run<false>(a, smem, bx);
-    else if (bx < 2 * NXY) ProdRole<HS>::template run<true>(a, smem, bx - NXY);
-    else AttnBwdRole<HS>::run(a, smem, bx - 2 * NXY);
+    if (bx < NXY) ProdRole<HS>::template run<0>(a, smem, bx);
+    else if (bx < 2 * NXY) ProdRole<HS>::template run<1>(a, smem, bx - NXY);
+    else if (bx < 3 * NXY) ProdRole<HS>::template run<2>(a, smem, bx - 2 * NXY);
+    else AttnBwdRole<HS>::run(a, smem, bx - 3 * NXY);
 #endif
 }
 
@@ -485,11 +499,11 @@ bool speller_persist_bwd_eligible(int B, int Tp, int Hs, int D, int M, int V, in
     int cus = 0, dev = 0;
     if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess)
         return false;
-    return 2 * (Hs / 16) * 2 + 2 * B <= cus;
+    return 3 * (Hs / 16) * 2 + 2 * B <= cus;          // every workgroup resident at once, one per CU
 }
 
 size_t speller_persist_bwd_workspace_floats(int B, int U, int Hs) {
-    return (size_t)U * B * 2 * Hs + (size_t)2 * U * (Hs / 16) * 32 * 64 + (size_t)U * (Hs / 16) * 32 * 16;
+    return (size_t)U * B * 2 * Hs + (size_t)2 * U * (Hs / 16) * 32 * 64 + (size_t)2 * (U + 1) * (Hs / 16) * 32 * 16;
 }
 
 int speller_persist_bwd(const PersistBwd& p, hipStream_t stream) {
@@ -505,9 +519,10 @@ int speller_persist_bwd(const PersistBwd& p, hipStream_t stream) {
     a.dhA = p.xbuf;
     a.dGx = a.dhA + (size_t)p.U * p.B * 2 * p.Hs;
     a.dcx = a.dGx + (size_t)2 * p.U * (p.Hs / 16) * 32 * 64;
+    a.dhc = a.dcx + (size_t)(p.U + 1) * (p.Hs / 16) * 32 * 16;
     a.B = p.B; a.Tp = p.Tp; a.U = p.U; a.relu = p.relu; a.err = p.err; a.trace = g_persist_bwd_trace;
     LAS_HIP_CHECK(hipMemsetAsync(p.xbuf, 0xFF, sizeof(float) * speller_persist_bwd_workspace_floats(p.B, p.U, p.Hs), stream));
-    const int grid = 2 * (p.Hs / 16) * 2 + 2 * p.B;
+    const int grid = 3 * (p.Hs / 16) * 2 + 2 * p.B;
     if (p.Hs == 512) {
         const size_t smem = sizeof(float) * (size_t)std::max(ProdRole<512>::LDS_FLOATS, AttnBwdRole<512>::lds_floats());
         LAS_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&speller_persist_bwd_kernel<512>),
