@@ -63,6 +63,29 @@ __device__ __forceinline__ bool spin_expired(unsigned& spins, unsigned* err, uns
     __builtin_amdgcn_s_sleep(1);
     return false;
 }
+// Workgroup-level canary.  Every consumer tile is guarded by one dword per PRODUCER workgroup; the first ceil(P/64)
+// waves of the consumer watch them (one lane per producer, agent-scope loads) and post the verdict on an LDS flag that
+// all 16 waves wait for.  Letting each wave watch its own producers multiplied the agent-scope poll traffic by the number
+// of waves and rows (~10^5 32-byte transactions per microsecond over the chip — the memory system's whole transaction
+// rate), which is what the hops were actually waiting for.  `ep` is a per-workgroup call counter (monotonic, so a wave
+// that runs ahead cannot make a slower one miss its epoch).
+__device__ __forceinline__ void wg_canary_wait(volatile unsigned* flags, unsigned ep, int npw, int wave, int lane,
+                                               const unsigned* cp, bool active, unsigned* err, unsigned code) {
+    unsigned spins = 0;
+    if (wave < npw) {
+        for (;;) {
+            const unsigned v = __hip_atomic_load(cp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (!__any(active && v == PS_SENT)) break;
+            if (spin_expired(spins, err, code)) break;
+        }
+        if (lane == 0) flags[wave] = ep;
+    }
+    for (int k = 0; k < npw; ++k) {
+        while ((int)(flags[k] - ep) < 0)
+            if (spin_expired(spins, err, code)) return;
+    }
+}
+
 // Reductions with DPP row operations (1 VALU instruction per level) instead of __shfl_xor (a ds_bpermute, i.e. an LDS
 // round trip, per level): these sit on the serial chain of every decode step.
 __device__ __forceinline__ float dpp_f(float v, int ctrl) {

@@ -52,7 +52,7 @@ struct CellRole {
     static constexpr int NF = HS / 256;                 // 16-wide k-blocks of an Hs-wide operand per wave
     static constexpr int RLD = 20;                      // row stride of a partial tile: 16 columns + pad, 16-byte aligned
     static constexpr int RED = PS_NW * 2 * 16 * RLD;    // floats of the per-wave partial tile buffer
-    static constexpr int LDS_FLOATS = 2 * RED + 2 * 4 * 128;          // one buffer per layer + summed biases of the cell lanes
+    static constexpr int LDS_FLOATS = 2 * RED + 2 * 4 * 128 + 4;      // one buffer per layer + summed biases of the cell lanes + canary flags
 
     // x tile of this wave: rows = utterances (two 16-row M-tiles), columns = its k-blocks.  Polls until no sentinel.
     // KIND 0: tile of h (each 4-column group comes from one cell workgroup); KIND 1: tile of the context (each row half
@@ -68,7 +68,8 @@ struct CellRole {
         unsigned x[NF][2];       // (bytes) its float4 of k-block f, M-tile mt (row-major slab: the context)
         unsigned hx[NF][2];      // the same float4 in the tiled hand-off copy of h
         bool ok[2];              // row < B
-        unsigned canary[2];      // [KIND]: the dword this lane watches (KIND 0 in the tiled copy, KIND 1 row-major)
+        unsigned canary[2];      // [KIND]: the producer dword this lane watches when its wave is a canary wave
+        bool cact[2];            // ... and whether that producer exists
     };
     static __device__ __forceinline__ TileAddr tile_addr(int B, int wave, int lane) {
         TileAddr t;
@@ -83,25 +84,27 @@ struct CellRole {
             }
         }
         {
-            constexpr int NP = 4 * NF, RS = 64 / NP;          // producers per wave tile, row samples per producer
-            const int pidx = lane % NP, rs = lane / NP;
-            t.canary[0] = 4u * ((((wave * NF + (pidx >> 2)) * 4 + (pidx & 3)) * 32 + min(B - 1, (rs + 1) * (32 / RS) - 1)) * 4 + 3);
-            t.canary[1] = 4u * (min(B - 1, lane & 31) * HS + (wave * NF + ((lane >> 5) % NF)) * 16 + 15);
+            // KIND 0: producer p = cell workgroup p (its 4 units of every row); watch the last row's last unit
+            const int p0 = wave * 64 + lane;
+            t.cact[0] = p0 < HS / 4;
+            t.canary[0] = 4u * (((t.cact[0] ? p0 : 0) * 32 + (B - 1)) * 4 + 3);
+            // KIND 1: producer p = attention workgroup (utterance p / PS_SPLIT, column part p % PS_SPLIT)
+            t.cact[1] = lane < PS_SPLIT * B;
+            const int pb = t.cact[1] ? lane / PS_SPLIT : 0, pp = lane % PS_SPLIT;
+            t.canary[1] = 4u * (pb * HS + (pp + 1) * (HS / PS_SPLIT) - 1);
         }
         return t;
     }
     template <int KIND>
     static __device__ __forceinline__ int poll_tile(const float* base, const TileAddr& t, f32x4 (&x)[NF][2],
-                                                    unsigned* err) {
+                                                    unsigned* err, volatile unsigned* flags, unsigned& ep) {
         unsigned spins = 0;
         int slow = 0;
         if (KIND != 2) {
-            const unsigned* cp = reinterpret_cast<const unsigned*>(at_bytes(base, opaque(t.canary[KIND == 0 ? 0 : 1])));
-            for (;;) {
-                const unsigned v = __hip_atomic_load(cp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                if (!__any(v == PS_SENT)) break;
-                if (spin_expired(spins, err, 0xDEAD0011u)) break;
-            }
+            constexpr int K = KIND == 0 ? 0 : 1;
+            constexpr int NPW = KIND == 0 ? (HS / 4 + 63) / 64 : 1;       // canary waves: one lane per producer workgroup
+            const unsigned* cp = reinterpret_cast<const unsigned*>(at_bytes(base, opaque(t.canary[K])));
+            wg_canary_wait(flags, ++ep, NPW, threadIdx.x >> 6, threadIdx.x & 63, cp, t.cact[K], err, 0xDEAD0011u);
         }
         asm volatile("" ::: "memory");
         bool need[NF][2];
@@ -246,6 +249,10 @@ struct CellRole {
         }
         f32x4 x[NF][2];
         const TileAddr ta = tile_addr(B, wave, lane);
+        volatile unsigned* cflags = reinterpret_cast<volatile unsigned*>(smem + 2 * RED + 2 * 4 * 128);
+        unsigned cep = 0;
+        if (tid < 4) cflags[tid] = 0u;
+        lds_barrier();
         int nslow[3] = {0, 0, 0};       // slow-path rounds per tile kind (reported through the trace buffer)
         for (int s = 0; s < U; ++s) {
             // next step's labels: issued now, consumed after layer 1 (plain load, its latency is off the chain)
@@ -253,13 +260,13 @@ struct CellRole {
             if (s + 1 < U) load_y(s + 1, ynext);
             // layer 0: gates = W_ctx ctx_{s-1} + [W_hh0 h0_{s-1} + W_y y_s  (accumulated ahead)]
             PS_STAMP(0, s, 0);
-            nslow[1] += poll_tile<1>(a.ctx_all + (size_t)s * B * HS, ta, x, a.err);
+            nslow[1] += poll_tile<1>(a.ctx_all + (size_t)s * B * HS, ta, x, a.err, cflags, cep);
             PS_STAMP(0, s, 1);
             mfma_tile(x, Wc0, accR0);
             finish(accR0, c0, 0, s);
             PS_STAMP(0, s, 2);
             // layer 1: gates = W_ih1 h0_s + W_hh1 h1_{s-1}
-            nslow[0] += poll_tile<0>(a.hx + (size_t)s * HXS, ta, x, a.err);
+            nslow[0] += poll_tile<0>(a.hx + (size_t)s * HXS, ta, x, a.err, cflags, cep);
             PS_STAMP(0, s, 4);
             mfma_tile(x, Wi1, accR1);
             finish(accR1, c1, 1, s);
@@ -271,7 +278,7 @@ struct CellRole {
             if (ywave) CellRole<256>::mfma_tile(ynext, Wy, accR0);
             PS_STAMP(0, s, 6);
             // ... and of layer 1, as soon as every cell workgroup's h1_s has arrived (still inside the attention window)
-            nslow[2] += poll_tile<0>(a.hx + ((size_t)U + s) * HXS, ta, x, a.err);
+            nslow[2] += poll_tile<0>(a.hx + ((size_t)U + s) * HXS, ta, x, a.err, cflags, cep);
             accR1[0] = accR1[1] = zero;
             mfma_tile(x, Wh1, accR1);
             PS_STAMP(0, s, 7);

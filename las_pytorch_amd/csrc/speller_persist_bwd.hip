@@ -54,12 +54,13 @@ struct ProdRole {
     static constexpr size_t GXS = (size_t)NJ * 32 * 64;    // floats of one tiled dG slab
     static constexpr size_t CXS = (size_t)NJ * 32 * 16;    // floats of one dcx slab
     static constexpr int RED = PS_NW * 16 * 17;
-    static constexpr int LDS_FLOATS = RED + PS_NW * KB * 64 * 4;       // reduction buffer + (X role) the columns of W_hh0
+    static constexpr int LDS_FLOATS = RED + PS_NW * KB * 64 * 4 + 4;   // reduction buffer + (X role) the columns of W_hh0 + canary flags
 
     struct Lane {
         unsigned x[JPW];       // byte offset of this lane's float4 of the first k-block of unit tile i inside a dG slab
                                // (the other three blocks of the tile are +64, +128, +192 bytes: instruction offsets)
-        unsigned canary;       // byte offset of the dword this lane watches
+        unsigned canary;       // byte offset of the producer dword this lane watches when its wave is the canary wave
+        bool cact;             // ... and whether that producer exists
         bool ok;               // its utterance row exists
     };
     static __device__ __forceinline__ Lane lane_addr(int B, int mt, int wave, int lane) {
@@ -69,10 +70,9 @@ struct ProdRole {
         const int row = t.ok ? mt * 16 + r : mt * 16;
 #pragma unroll
         for (int i = 0; i < JPW; ++i) t.x[i] = 4u * (((wave * JPW + i) * 32 + row) * 64 + 4 * kq);
-        // one dword per (producer tile, row): lanes [32*i, 32*i+16) cover the 16 rows of the wave's i-th unit tile
-        const int cj = wave * JPW + (lane >> 5) % JPW;
-        const int crow = mt * 16 + min(lane & 15, max(B - 1 - mt * 16, 0));
-        t.canary = 4u * ((cj * 32 + crow) * 64 + 63);
+        // one dword per producer workgroup (unit tile `lane`, same M-tile): the last gate of its last row
+        t.cact = lane < NJ;
+        t.canary = 4u * (((t.cact ? lane : 0) * 32 + mt * 16 + min(15, B - 1 - mt * 16)) * 64 + 63);
         return t;
     }
     // resident MFMA B operand: W[(gate e)*HS + unit(k)][cb + 16 j + n] for this wave's k-blocks, k = unit*4 + gate
@@ -86,15 +86,12 @@ struct ProdRole {
         }
     }
     // tile of dG rows (this M-tile, all 4Hs gate columns): canary, L2-shared plain loads, per-word check, slow path
-    static __device__ __forceinline__ void poll_tile(const float* base, const Lane& t, f32x4 (&x)[KB], unsigned* err) {
+    static __device__ __forceinline__ void poll_tile(const float* base, const Lane& t, f32x4 (&x)[KB], unsigned* err,
+                                                     volatile unsigned* flags, unsigned& ep) {
         unsigned spins = 0;
         {
             const unsigned* cp = reinterpret_cast<const unsigned*>(at_bytes(base, opaque(t.canary)));
-            for (;;) {
-                const unsigned v = __hip_atomic_load(cp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                if (!__any(v == PS_SENT)) break;
-                if (spin_expired(spins, err, 0xDEAD0021u)) break;
-            }
+            wg_canary_wait(flags, ++ep, 1, threadIdx.x >> 6, threadIdx.x & 63, cp, t.cact, err, 0xDEAD0021u);
         }
         asm volatile("" ::: "memory");
         bool need[KB];
@@ -220,6 +217,10 @@ struct ProdRole {
             return acc;
         };
         const Lane la = lane_addr(B, mt, wave, lane);
+        volatile unsigned* cflags = reinterpret_cast<volatile unsigned*>(smem + RED + PS_NW * KB * 64 * 4);
+        unsigned cep = 0;
+        if (tid < 4) cflags[tid] = 0u;
+        lds_barrier();
         // cell lane: (utterance pb, unit pu) of this workgroup's tile
         const int pb = mt * 16 + (tid >> 4), pu = tid & 15;
         const bool pw = tid < 256 && pb < B;
@@ -245,7 +246,7 @@ struct ProdRole {
                     while (__hip_atomic_load(cp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == PS_SENT)
                         if (spin_expired(spins, a.err, 0xDEAD0026u)) break;
                 }
-                poll_tile(dG1x + (size_t)s * GXS, la, x, a.err);
+                poll_tile(dG1x + (size_t)s * GXS, la, x, a.err, cflags, cep);
                 PB_STAMP(3, s, 1);
                 const float v = reduce_tile(red, mfma_tile(x, Wc), wave, lane, tid);
                 if (pw) st1_agent(at_bytes(a.dhc + (size_t)s * CXS, opaque(oc)), v);
@@ -282,7 +283,7 @@ struct ProdRole {
                 PB_STAMP(1, s, 2);
                 // ---- Y3: context gradient of step s-1's attention = dG0_s W_ctx
                 PB_STAMP(1, s, 3);
-                poll_tile(dG0x + (size_t)s * GXS, la, x, a.err);
+                poll_tile(dG0x + (size_t)s * GXS, la, x, a.err, cflags, cep);
                 PB_STAMP(1, s, 4);
                 const float dctx = reduce_tile(red, mfma_tile(x, Wc), wave, lane, tid);
                 if (pw) {
@@ -293,7 +294,7 @@ struct ProdRole {
             } else {
                 // ---- X1: dh0 = dG1_s W_ih1 -> bottom-layer cell backward -> dG0_s
                 PB_STAMP(0, s, 0);
-                poll_tile(dG1x + (size_t)s * GXS, la, x, a.err);
+                poll_tile(dG1x + (size_t)s * GXS, la, x, a.err, cflags, cep);
                 PB_STAMP(0, s, 1);
                 const f32x4 accx = mfma_tile(x, Wc);
                 if (a.trace && first_wg && tid == 0) { asm volatile("s_nop 0" :: "v"(accx[0])); }
@@ -314,7 +315,7 @@ struct ProdRole {
                         while (__hip_atomic_load(cp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == PS_SENT)
                             if (spin_expired(spins, a.err, 0xDEAD0025u)) break;
                     }
-                    poll_tile(dG0x + (size_t)s * GXS, la, x, a.err);
+                    poll_tile(dG0x + (size_t)s * GXS, la, x, a.err, cflags, cep);
                     dh_carry = reduce_tile(red, mfma_lds(x), wave, lane, tid);
                 }
                 PB_STAMP(0, s, 3);

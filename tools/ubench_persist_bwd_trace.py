@@ -41,3 +41,4 @@ print("X wg0 : wait dG1 %.2f | W_ih1 product + cell bwd + publish dG0 %.2f | rec
 print("chain : A publishes -> Y has parts %.2f | Y published dG1 -> X has it %.2f | X published dG0 -> Y has it %.2f | Y published dctx -> A(s-1) has it %.2f | period %.2f" % (
     us(Y[:, 1] - A[:, 4]), us(X[:, 1] - Y[:, 2]), us(Y[:, 4] - X[:, 2]), us(A[:-1, 1] - Y[1:, 5]), us(A[:-1, 4] - A[1:, 4])))
 print("X1 detail: mfma %.2f | reduce %.2f | cell bwd + stores %.2f" % (us(X[:, 6] - X[:, 1]), us(X[:, 7] - X[:, 6]), us(X[:, 2] - X[:, 7])))
+print("Y3 detail: mfma %.2f | reduce %.2f | publish %.2f" % (us(Y[:, 6] - Y[:, 4]), us(Y[:, 7] - Y[:, 6]), us(Y[:, 5] - Y[:, 7])))
