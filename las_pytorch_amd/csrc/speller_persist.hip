@@ -95,9 +95,12 @@ struct CellRole {
         }
         return t;
     }
+    // acc += tile * W.  The product is started speculatively as the tile's loads land (load and MFMA time overlap); the
+    // sentinel check comes afterwards and a tile that was not complete is repaired and multiplied again.
     template <int KIND>
-    static __device__ __forceinline__ int poll_tile(const float* base, const TileAddr& t, f32x4 (&x)[NF][2],
-                                                    unsigned* err, volatile unsigned* flags, unsigned& ep) {
+    static __device__ __forceinline__ int poll_mul(const float* base, const TileAddr& t, f32x4 (&x)[NF][2],
+                                                   const float (&W)[NF][4], f32x4 (&acc)[2],
+                                                   unsigned* err, volatile unsigned* flags, unsigned& ep) {
         unsigned spins = 0;
         int slow = 0;
         if (KIND != 2) {
@@ -109,18 +112,24 @@ struct CellRole {
         asm volatile("" ::: "memory");
         bool need[NF][2];
         bool bad = false;
+        // ordinary (L2-cacheable) loads; rows past B keep the sentinel for ever and only feed output rows nobody reads
+#pragma unroll
+        for (int f = 0; f < NF; ++f)
+#pragma unroll
+            for (int mt = 0; mt < 2; ++mt)
+                x[f][mt] = *reinterpret_cast<const f32x4*>(at_bytes(base, opaque(KIND == 0 ? t.hx[f][mt] : t.x[f][mt])));
+        const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
+        f32x4 p[2] = {zero, zero};
+        mfma_tile(x, W, p);
 #pragma unroll
         for (int f = 0; f < NF; ++f)
 #pragma unroll
             for (int mt = 0; mt < 2; ++mt) {
-                // ordinary (L2-cacheable) load; the compiler fences around this block keep it between canary and check
-                const f32x4 v = *reinterpret_cast<const f32x4*>(at_bytes(base, opaque(KIND == 0 ? t.hx[f][mt] : t.x[f][mt])));
-                const f32x4 z = {0.f, 0.f, 0.f, 0.f};
-                x[f][mt] = t.ok[mt] ? v : z;
-                need[f][mt] = __any(t.ok[mt] && has_sentinel(v));
+                need[f][mt] = __any(t.ok[mt] && has_sentinel(x[f][mt]));
                 bad |= need[f][mt];
             }
         asm volatile("" ::: "memory");
+        const bool redo = bad;
         // slow path: only the (wave-uniform) slots in which some lane still saw the sentinel, with L2-bypassing loads
         while (bad) {
             if (spin_expired(spins, err, 0xDEAD0012u)) break;
@@ -131,14 +140,17 @@ struct CellRole {
 #pragma unroll
                 for (int mt = 0; mt < 2; ++mt) {
                     if (need[f][mt]) {
-                        const f32x4 v = ld4_agent(at_bytes(base, opaque(KIND == 0 ? t.hx[f][mt] : t.x[f][mt])));
-                        const f32x4 z = {0.f, 0.f, 0.f, 0.f};
-                        x[f][mt] = t.ok[mt] ? v : z;
-                        need[f][mt] = __any(t.ok[mt] && has_sentinel(v));
+                        x[f][mt] = ld4_agent(at_bytes(base, opaque(KIND == 0 ? t.hx[f][mt] : t.x[f][mt])));
+                        need[f][mt] = __any(t.ok[mt] && has_sentinel(x[f][mt]));
                         bad |= need[f][mt];
                     }
                 }
         }
+        if (redo) { p[0] = p[1] = zero; mfma_tile(x, W, p); }
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) acc[mt][i] += p[mt][i];
         return slow;
     }
 
@@ -260,15 +272,13 @@ struct CellRole {
             if (s + 1 < U) load_y(s + 1, ynext);
             // layer 0: gates = W_ctx ctx_{s-1} + [W_hh0 h0_{s-1} + W_y y_s  (accumulated ahead)]
             PS_STAMP(0, s, 0);
-            nslow[1] += poll_tile<1>(a.ctx_all + (size_t)s * B * HS, ta, x, a.err, cflags, cep);
+            nslow[1] += poll_mul<1>(a.ctx_all + (size_t)s * B * HS, ta, x, Wc0, accR0, a.err, cflags, cep);
             PS_STAMP(0, s, 1);
-            mfma_tile(x, Wc0, accR0);
             finish(accR0, c0, 0, s);
             PS_STAMP(0, s, 2);
             // layer 1: gates = W_ih1 h0_s + W_hh1 h1_{s-1}
-            nslow[0] += poll_tile<0>(a.hx + (size_t)s * HXS, ta, x, a.err, cflags, cep);
+            nslow[0] += poll_mul<0>(a.hx + (size_t)s * HXS, ta, x, Wi1, accR1, a.err, cflags, cep);
             PS_STAMP(0, s, 4);
-            mfma_tile(x, Wi1, accR1);
             finish(accR1, c1, 1, s);
             PS_STAMP(0, s, 5);
             if (s + 1 == U) break;
@@ -278,9 +288,8 @@ struct CellRole {
             if (ywave) CellRole<256>::mfma_tile(ynext, Wy, accR0);
             PS_STAMP(0, s, 6);
             // ... and of layer 1, as soon as every cell workgroup's h1_s has arrived (still inside the attention window)
-            nslow[2] += poll_tile<0>(a.hx + ((size_t)U + s) * HXS, ta, x, a.err, cflags, cep);
             accR1[0] = accR1[1] = zero;
-            mfma_tile(x, Wh1, accR1);
+            nslow[2] += poll_mul<0>(a.hx + ((size_t)U + s) * HXS, ta, x, Wh1, accR1, a.err, cflags, cep);
             PS_STAMP(0, s, 7);
         }
         if (a.trace && first_wg && tid == 0)

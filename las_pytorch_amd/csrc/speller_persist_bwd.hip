@@ -86,8 +86,12 @@ struct ProdRole {
         }
     }
     // tile of dG rows (this M-tile, all 4Hs gate columns): canary, L2-shared plain loads, per-word check, slow path
-    static __device__ __forceinline__ void poll_tile(const float* base, const Lane& t, f32x4 (&x)[KB], unsigned* err,
-                                                     volatile unsigned* flags, unsigned& ep) {
+    // Returns mul(tile).  The product is started speculatively as the tile's loads land (load and MFMA time overlap);
+    // the sentinel check comes afterwards and, if a word had not been published yet, the tile is repaired with
+    // L2-bypassing loads and the product redone.
+    template <class Mul>
+    static __device__ __forceinline__ f32x4 poll_mul(const float* base, const Lane& t, f32x4 (&x)[KB], unsigned* err,
+                                                     volatile unsigned* flags, unsigned& ep, Mul mul) {
         unsigned spins = 0;
         {
             const unsigned* cp = reinterpret_cast<const unsigned*>(at_bytes(base, opaque(t.canary)));
@@ -107,13 +111,14 @@ struct ProdRole {
 #else
             x[blk] = *reinterpret_cast<const f32x4*>(at_bytes(base, xo[blk / 4]) + 16 * (blk % 4));
 #endif
-        __builtin_amdgcn_sched_barrier(0);             // all loads of the tile are in flight before the first check
+        f32x4 acc = mul(x);
 #pragma unroll
         for (int blk = 0; blk < KB; ++blk) {
             need[blk] = __any(t.ok && has_sentinel(x[blk]));
             bad |= need[blk];
         }
         asm volatile("" ::: "memory");
+        const bool redo = bad;
         while (bad) {
             if (spin_expired(spins, err, 0xDEAD0022u)) break;
             bad = false;
@@ -126,6 +131,8 @@ struct ProdRole {
                 }
             }
         }
+        if (redo) acc = mul(x);
+        return acc;
     }
     static __device__ __forceinline__ f32x4 mfma_tile(const f32x4 (&x)[KB], const float (&W)[KB][4]) {
         f32x4 acc = {0.f, 0.f, 0.f, 0.f};
@@ -216,6 +223,7 @@ struct ProdRole {
             }
             return acc;
         };
+        auto mul_reg = [&](const f32x4 (&xt)[KB]) { return mfma_tile(xt, Wc); };
         const Lane la = lane_addr(B, mt, wave, lane);
         volatile unsigned* cflags = reinterpret_cast<volatile unsigned*>(smem + RED + PS_NW * KB * 64 * 4);
         unsigned cep = 0;
@@ -246,9 +254,9 @@ struct ProdRole {
                     while (__hip_atomic_load(cp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == PS_SENT)
                         if (spin_expired(spins, a.err, 0xDEAD0026u)) break;
                 }
-                poll_tile(dG1x + (size_t)s * GXS, la, x, a.err, cflags, cep);
+                const f32x4 accr = poll_mul(dG1x + (size_t)s * GXS, la, x, a.err, cflags, cep, mul_reg);
                 PB_STAMP(3, s, 1);
-                const float v = reduce_tile(red, mfma_tile(x, Wc), wave, lane, tid);
+                const float v = reduce_tile(red, accr, wave, lane, tid);
                 if (pw) st1_agent(at_bytes(a.dhc + (size_t)s * CXS, opaque(oc)), v);
                 PB_STAMP(3, s, 2);
                 continue;
@@ -283,9 +291,9 @@ struct ProdRole {
                 PB_STAMP(1, s, 2);
                 // ---- Y3: context gradient of step s-1's attention = dG0_s W_ctx
                 PB_STAMP(1, s, 3);
-                poll_tile(dG0x + (size_t)s * GXS, la, x, a.err, cflags, cep);
+                const f32x4 accy = poll_mul(dG0x + (size_t)s * GXS, la, x, a.err, cflags, cep, mul_reg);
                 PB_STAMP(1, s, 4);
-                const float dctx = reduce_tile(red, mfma_tile(x, Wc), wave, lane, tid);
+                const float dctx = reduce_tile(red, accy, wave, lane, tid);
                 if (pw) {
                     st1_agent(at_bytes(a.dcx + (size_t)s * CXS, opaque(oc)), dctx);
                     if (s == 0) a.dx0[(size_t)pb * a.ldx0 + a.V + 16 * j + pu] = dctx;
@@ -294,10 +302,9 @@ struct ProdRole {
             } else {
                 // ---- X1: dh0 = dG1_s W_ih1 -> bottom-layer cell backward -> dG0_s
                 PB_STAMP(0, s, 0);
-                poll_tile(dG1x + (size_t)s * GXS, la, x, a.err, cflags, cep);
-                PB_STAMP(0, s, 1);
-                const f32x4 accx = mfma_tile(x, Wc);
+                const f32x4 accx = poll_mul(dG1x + (size_t)s * GXS, la, x, a.err, cflags, cep, mul_reg);
                 if (a.trace && first_wg && tid == 0) { asm volatile("s_nop 0" :: "v"(accx[0])); }
+                PB_STAMP(0, s, 1);
                 PB_STAMP(0, s, 6);
                 const float dh0 = reduce_tile(red, accx, wave, lane, tid);
                 PB_STAMP(0, s, 7);
@@ -315,8 +322,7 @@ struct ProdRole {
                         while (__hip_atomic_load(cp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == PS_SENT)
                             if (spin_expired(spins, a.err, 0xDEAD0025u)) break;
                     }
-                    poll_tile(dG0x + (size_t)s * GXS, la, x, a.err, cflags, cep);
-                    dh_carry = reduce_tile(red, mfma_lds(x), wave, lane, tid);
+                    dh_carry = reduce_tile(red, poll_mul(dG0x + (size_t)s * GXS, la, x, a.err, cflags, cep, mfma_lds), wave, lane, tid);
                 }
                 PB_STAMP(0, s, 3);
             }
