@@ -173,7 +173,7 @@ def main():
     labf = lab.float()
 
     if train:
-        reducer = dp.FlatGradAllReducer(las, force=os.environ.get("LAS_FORCE_DIST") == "1")
+        reducer = dp.FlatGradAllReducer(las, force=os.environ.get("LAS_FORCE_DIST") == "1", direct=True)
         opt = torch.optim.Adam(las.parameters(), lr=2e-4, fused=True)
 
         def step():

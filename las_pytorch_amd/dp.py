@@ -19,8 +19,14 @@ class FlatGradAllReducer:
     """Makes every ``p.grad`` a view into one contiguous fp32 buffer so the whole gradient crosses the fabric as a
     single collective (message: S 7.96 MB, P 39.9 MB)."""
 
-    def __init__(self, module: torch.nn.Module, force: bool = False):
+    def __init__(self, module: torch.nn.Module, force: bool = False, direct: bool = False):
         self.force = force          # all-reduce even in a 1-rank group (exercises the collective path)
+        # direct=True: the HIP backward kernels write each parameter gradient straight into its view of the flat buffer
+        # (no per-parameter AccumulateGrad add kernel).  Requires one use of every parameter per backward and one
+        # backward per step — what solver/solver.py:95-97 does.  See las_model.DIRECT_GRAD_WRITE.
+        if direct:
+            from .model import las_model
+            las_model.DIRECT_GRAD_WRITE = True
         self.params = [p for p in module.parameters() if p.requires_grad]
         n = sum(p.numel() for p in self.params)
         dev = self.params[0].device

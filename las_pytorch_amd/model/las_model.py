@@ -29,6 +29,27 @@ from .._cabi import FLAG_FORCE_GENERIC, FLAG_STASH, SpellerDesc, SpellerGrads, c
 FORCE_GENERIC_RECURRENCE = False
 
 
+# Opt-in (las_pytorch_amd.dp.FlatGradAllReducer(direct=True)): the backward kernels write the parameter gradients
+# straight into the existing ``p.grad`` tensors (the views of the flat all-reduce buffer) and autograd is handed ``None``
+# for them, instead of fresh tensors that AccumulateGrad then adds into ``p.grad`` with one small kernel per parameter
+# (36 launches per step at the reference's sizes).  Valid when every parameter is used once per backward and the
+# gradients are re-initialised every step — the training loop of solver/solver.py:95-97.
+DIRECT_GRAD_WRITE = False
+
+
+def _direct_targets(params):
+    if not DIRECT_GRAD_WRITE:
+        return None
+    out = []
+    for p in params:
+        g = getattr(p, "grad", None)
+        if (g is None or g.dtype != torch.float32 or not g.is_contiguous() or g.shape != p.shape or g.device != p.device
+                or not p.requires_grad):
+            return None
+        out.append(g)
+    return out
+
+
 def _flags(stash):
     return (FLAG_STASH if stash else 0) | (FLAG_FORCE_GENERIC if FORCE_GENERIC_RECURRENCE else 0)
 
@@ -91,6 +112,7 @@ class _PBLSTMFn(torch.autograd.Function):
                                ptr(_cabi.err_word(x.device)), flags, stream_ptr()))
         if stash:
             ctx.save_for_backward(x, ws[0], ws[1], ws[4], ws[5], reserve)
+            ctx.direct = _direct_targets((w_ih_f, w_hh_f, b_ih_f, b_hh_f, w_ih_r, w_hh_r, b_ih_r, b_hh_r))
             ctx.dims = (B, T_in, D_in, H)
             ctx.need_dx = ctx.needs_input_grad[0]
             ctx.flags = flags
@@ -105,12 +127,13 @@ class _PBLSTMFn(torch.autograd.Function):
         dev = x.device
         work = torch.empty(L.las_pblstm_bwd_workspace_floats(B, T_in, H), device=dev, dtype=torch.float32)
         dx = torch.empty_like(x) if ctx.need_dx else None
-        g = [torch.empty_like(w_ih_f), torch.empty_like(w_hh_f), torch.empty(4 * H, device=dev), torch.empty(4 * H, device=dev),
-             torch.empty_like(w_ih_r), torch.empty_like(w_hh_r), torch.empty(4 * H, device=dev), torch.empty(4 * H, device=dev)]
+        g = ctx.direct or [torch.empty_like(w_ih_f), torch.empty_like(w_hh_f), torch.empty(4 * H, device=dev),
+                           torch.empty(4 * H, device=dev), torch.empty_like(w_ih_r), torch.empty_like(w_hh_r),
+                           torch.empty(4 * H, device=dev), torch.empty(4 * H, device=dev)]
         check(L.las_pblstm_bwd(ptr(x), ptr(dout), B, T_in, D_in, H, ptr(w_ih_f), ptr(w_hh_f), ptr(w_ih_r), ptr(w_hh_r),
                                ptr(reserve), ptr(work), ptr(dx), *[ptr(t) for t in g], ptr(_cabi.err_word(dev)),
                                ctx.flags, stream_ptr()))
-        return (dx, *g)
+        return (dx, *([None] * 8 if ctx.direct else g))
 
 
 class pBLSTMLayer(nn.Module):
@@ -214,6 +237,7 @@ class _SpellerFn(torch.autograd.Function):
         (U, teacher_forced, decode_mode, L, use_mlp, relu, M, V, heads) = cfg
         feat = _f32c(feat)
         B, Tp, D = feat.shape
+        direct = _direct_targets(params)
         params = [_f32c(p) for p in params]
         lstm, rest = params[:4 * L], params[4 * L:]
         Hs = lstm[1].shape[1]
@@ -242,6 +266,7 @@ class _SpellerFn(torch.autograd.Function):
         ctx.mark_non_differentiable(att)
         if any(ctx.needs_input_grad):
             ctx.save_for_backward(feat, keys, logp, att, reserve, *params)
+            ctx.direct = direct
             ctx.cfg = cfg
             ctx.dims = (B, Tp, D, Hs)
         return logp, att
@@ -256,7 +281,7 @@ class _SpellerFn(torch.autograd.Function):
         lstm, rest = params[:4 * L], params[4 * L:]
         Lh = lib()
         d = _speller_desc(B, Tp, D, Hs, V, M, L, use_mlp, relu, lstm, rest, heads)
-        grads = [torch.empty_like(p) for p in params]
+        grads = ctx.direct or [torch.empty_like(p) for p in params]
         dfeat = torch.empty_like(feat)
         g = SpellerGrads()
         for l in range(L):
@@ -274,7 +299,7 @@ class _SpellerFn(torch.autograd.Function):
         mode0 = int((not teacher_forced) and decode_mode == 0)
         check(Lh.las_speller_bwd(d, ptr(feat), ptr(keys), ptr(logp), ptr(att), ptr(dlogp), U, mode0, ptr(reserve),
                                  ptr(work), g, ptr(_cabi.err_word(dev)), _flags(True), stream_ptr()))
-        return (None, dfeat, None, *grads)
+        return (None, dfeat, None, *([None] * len(grads) if ctx.direct else grads))
 
 
 class Speller(nn.Module):

@@ -324,3 +324,33 @@ def test_persistent_decode_kernel_matches_stepwise(cfg_name, B, Tp, U, scale):
         scale_k = float(np.abs(res[1][k]).max()) + 1e-30
         assert_close(res[0][k], res[1][k], f"persistent vs stepwise {k}", rtol=1e-3, atol=1e-5 * max(1.0, scale_k))
     _check_err()
+
+
+def test_direct_gradient_write_matches_autograd_accumulation():
+    """FlatGradAllReducer(direct=True): the backward kernels fill the flat gradient buffer themselves; the result must
+    equal what autograd's per-parameter accumulation produces, also on a second step after zero()."""
+    from las_pytorch_amd import dp, synth
+    from las_pytorch_amd.model import las_model
+    c = synth.CONFIGS["S"]
+    sd_np = synth.make_state_dict(synth.config_shapes("S"), seed=4)
+    x = torch.from_numpy(synth.make_inputs(4, 64, c["F"], seed=4)).cuda()
+    idx, lens = synth.make_labels(4, 6, c["V"], seed=4)
+    lab = torch.from_numpy(synth.onehot_labels(idx, lens, c["V"])).cuda()
+    flats = []
+    try:
+        for direct in (False, True):
+            las_model.DIRECT_GRAD_WRITE = False
+            las = build_las(c, sd_np, max_label_len=6)
+            red = dp.FlatGradAllReducer(las, direct=direct)
+            assert las_model.DIRECT_GRAD_WRITE == direct
+            for _ in range(2):
+                red.zero()
+                preds, _ = las(x, lab, 1.0, True)
+                torch.stack(preds).square().mean().backward()
+                red.check_views()
+            flats.append(red.flat.detach().cpu().numpy().copy())
+    finally:
+        las_model.DIRECT_GRAD_WRITE = False
+    assert np.abs(flats[0]).max() > 0
+    assert_close(flats[1], flats[0], "direct vs accumulated flat gradient", rtol=1e-5, atol=1e-7 * float(np.abs(flats[0]).max()))
+    _check_err()
