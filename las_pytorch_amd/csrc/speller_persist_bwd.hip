@@ -106,11 +106,7 @@ struct ProdRole {
         // rows past B hold the sentinel for ever: they only feed output rows nobody reads (MFMA rows are independent)
 #pragma unroll
         for (int blk = 0; blk < KB; ++blk)
-#ifdef PB_DEBUG_SC1
-            x[blk] = ld4_agent(at_bytes(base, xo[blk / 4]) + 16 * (blk % 4));
-#else
             x[blk] = *reinterpret_cast<const f32x4*>(at_bytes(base, xo[blk / 4]) + 16 * (blk % 4));
-#endif
         f32x4 acc = mul(x);
 #pragma unroll
         for (int blk = 0; blk < KB; ++blk) {
