@@ -56,7 +56,7 @@ struct SpellerLayout {
 
 struct SpellerBwdLayout {
     size_t dG_all, dz_all, dctx_all, de_all, dqpre_all, dh_top, dh_below, dh_carry, dc_carry, dx0, dK, dcat_all, dctxcat_all,
-        dqpre_part, pxbuf, total;
+        pxbuf, total;
     SpellerBwdLayout(const las_speller_desc* d, int U) {
         size_t o = 0;
         const size_t B = d->B;
@@ -74,12 +74,9 @@ struct SpellerBwdLayout {
         dK = o; o += r4(B * d->Tp * Mq);
         dcat_all = o; o += r4((size_t)U * B * (d->Hs + d->D));    // dz W_c for every step (teacher forcing / mode 1)
         dctxcat_all = o; if (d->multi_head > 1) o += r4((size_t)U * B * d->multi_head * d->D);
-        // persistent backward kernel: the attention halves' dqpre parts and the sentinel-prefilled hand-off slabs
-        dqpre_part = o; pxbuf = o;
-        if (d->L == 2 && d->multi_head == 1 && d->Hs % 16 == 0 && d->use_mlp) {
-            o += r4((size_t)2 * U * B * d->M);
-            pxbuf = o; o += r4(speller_persist_bwd_workspace_floats(d->B, U, d->Hs));
-        }
+        // persistent backward kernel: the attention workgroups' dqpre parts and the sentinel-prefilled hand-off slabs
+        pxbuf = o;
+        if (d->L == 2 && d->multi_head == 1 && d->use_mlp) o += r4(speller_persist_bwd_workspace_floats(d->B, d->Tp, U, d->Hs, d->M));
         total = o;
     }
 };
@@ -99,7 +96,6 @@ int check_desc(const las_speller_desc* d) {
     return LAS_OK;
 }
 
-#define LAS_TRY(expr) do { int _rc = (expr); if (_rc != LAS_OK) return _rc; } while (0)
 
 }  // namespace
 
@@ -471,14 +467,10 @@ int las_speller_bwd(const las_speller_desc* d, const float* feat, const float* k
         p.w_ih0 = d->w_ih[0]; p.w_hh0 = d->w_hh[0]; p.w_ih1 = d->w_ih[1]; p.w_hh1 = d->w_hh[1]; p.w_phi = d->w_phi;
         p.feat = feat; p.keys = keys; p.att = att; p.q_all = q_all; p.ctx_all = ctx_all;
         p.gates_all = gates_all; p.c_all = c_all; p.dcat_all = dcat_all;
-        p.dG_all = dG_all; p.dctx_all = dctx_all; p.de_all = de_all; p.dqpre_part = workspace + wl.dqpre_part;
+        p.dG_all = dG_all; p.dctx_all = dctx_all; p.de_all = de_all; p.dqpre_all = dqpre_all;
         p.dx0 = dx0; p.xbuf = workspace + wl.pxbuf;
         p.B = B; p.Tp = Tp; p.U = U; p.Hs = Hs; p.V = V; p.relu = d->relu; p.err = err_word;
         LAS_TRY(speller_persist_bwd(p, stream));
-        // dqpre = sum of the two attention halves' parts (the relu mask is linear in dq)
-        const size_t nq = (size_t)U * B * M;
-        LAS_HIP_CHECK(hipMemcpyAsync(dqpre_all, workspace + wl.dqpre_part, sizeof(float) * nq, hipMemcpyDeviceToDevice, stream));
-        LAS_TRY(add_inplace(dqpre_all, workspace + wl.dqpre_part + nq, (long)nq, stream));
     }
     for (int s = persist ? -1 : U - 1; s >= 0; --s) {
         const bool last = (s == U - 1);

@@ -33,6 +33,7 @@ inline int fail(int code, const char* fmt, const char* a = "", long x = 0, long 
         }                                                                                \
     } while (0)
 
+#define LAS_TRY(expr) do { int _rc = (expr); if (_rc != LAS_OK) return _rc; } while (0)
 #define LAS_REQUIRE(cond, msg)                                                           \
     do {                                                                                 \
         if (!(cond)) {                                                                   \

@@ -118,15 +118,14 @@ struct PersistBwd {
     const float* w_ih0; const float* w_hh0; const float* w_ih1; const float* w_hh1; const float* w_phi;
     const float* feat; const float* keys; const float* att; const float* q_all; const float* ctx_all;
     const float* gates_all; const float* c_all; const float* dcat_all;      // forward stash + dz W_c of every step
-    float* dG_all; float* dctx_all; float* de_all;                          // per-step gradients for the deferred GEMMs
-    float* dqpre_part;                                                      // (2,U,B,M): the two attention halves' parts
+    float* dG_all; float* dctx_all; float* de_all; float* dqpre_all;        // per-step gradients for the deferred GEMMs
     float* dx0;                                                             // (B,V+D): context part written at step 0
     float* xbuf;                                                            // speller_persist_bwd_workspace_floats()
     int B, Tp, U, Hs, V, relu;
     unsigned* err;
 };
 bool speller_persist_bwd_eligible(int B, int Tp, int Hs, int D, int M, int V, int L, int heads, int use_mlp);
-size_t speller_persist_bwd_workspace_floats(int B, int U, int Hs);
+size_t speller_persist_bwd_workspace_floats(int B, int Tp, int U, int Hs, int M);
 int speller_persist_bwd(const PersistBwd& p, hipStream_t stream);
 void speller_persist_bwd_set_trace(unsigned long long* dev_buf);
 

@@ -28,7 +28,6 @@ namespace las {
 
 namespace {
 constexpr int PS_NI = 7;           // listener frames held per attention lane
-constexpr int PS_SPLIT = 2;        // attention workgroups per utterance (each owns D/PS_SPLIT context columns)
 }  // namespace
 
 struct PersistArgs {
@@ -40,6 +39,7 @@ struct PersistArgs {
     float* ctx_all; float* h_all; float* c_all; float* gates_all; float* q_all; float* att;
     float* hx;                     // hand-off copy of h: [layer][step][unit tile Hs/4][row 32][4], sentinel-prefilled
     int B, Tp, U, relu;
+    int split;                     // attention workgroups per utterance (each owns D/split context columns)
     unsigned* err;
     unsigned long long* trace;     // profiling aid (tools/ubench_persist_trace.py): shader-clock stamps of workgroup 0 of each role
 };
@@ -70,8 +70,9 @@ struct CellRole {
         bool ok[2];              // row < B
         unsigned canary[2];      // [KIND]: the producer dword this lane watches when its wave is a canary wave
         bool cact[2];            // ... and whether that producer exists
+        int npw1;                // canary waves of a context tile: ceil(split*B / 64)
     };
-    static __device__ __forceinline__ TileAddr tile_addr(int B, int wave, int lane) {
+    static __device__ __forceinline__ TileAddr tile_addr(int B, int split, int wave, int lane) {
         TileAddr t;
         const int r = lane & 15, kq = lane >> 4;
 #pragma unroll
@@ -88,10 +89,11 @@ struct CellRole {
             const int p0 = wave * 64 + lane;
             t.cact[0] = p0 < HS / 4;
             t.canary[0] = 4u * (((t.cact[0] ? p0 : 0) * 32 + (B - 1)) * 4 + 3);
-            // KIND 1: producer p = attention workgroup (utterance p / PS_SPLIT, column part p % PS_SPLIT)
-            t.cact[1] = lane < PS_SPLIT * B;
-            const int pb = t.cact[1] ? lane / PS_SPLIT : 0, pp = lane % PS_SPLIT;
-            t.canary[1] = 4u * (pb * HS + (pp + 1) * (HS / PS_SPLIT) - 1);
+            // KIND 1: producer p = attention workgroup (utterance p / split, column part p % split)
+            t.npw1 = (split * B + 63) / 64;
+            t.cact[1] = p0 < split * B;
+            const int pb = t.cact[1] ? p0 / split : 0, pp = p0 % split;
+            t.canary[1] = 4u * (pb * HS + (pp + 1) * (HS / split) - 1);
         }
         return t;
     }
@@ -105,9 +107,9 @@ struct CellRole {
         int slow = 0;
         if (KIND != 2) {
             constexpr int K = KIND == 0 ? 0 : 1;
-            constexpr int NPW = KIND == 0 ? (HS / 4 + 63) / 64 : 1;       // canary waves: one lane per producer workgroup
+            const int npw = KIND == 0 ? (HS / 4 + 63) / 64 : t.npw1;      // canary waves: one lane per producer workgroup
             const unsigned* cp = reinterpret_cast<const unsigned*>(at_bytes(base, opaque(t.canary[K])));
-            wg_canary_wait(flags, ++ep, NPW, threadIdx.x >> 6, threadIdx.x & 63, cp, t.cact[K], err, 0xDEAD0011u);
+            wg_canary_wait(flags, ++ep, npw, threadIdx.x >> 6, threadIdx.x & 63, cp, t.cact[K], err, 0xDEAD0011u);
         }
         asm volatile("" ::: "memory");
         bool need[NF][2];
@@ -228,6 +230,7 @@ struct CellRole {
 #pragma unroll
                 for (int i = 0; i < 4; ++i) red[wave][mt][kq * 4 + i][rcol] = acc[mt][i];
             lds_barrier();
+            if (layer == 1) PS_STAMP(1, s, 6); else PS_STAMP(1, s, 7);       // (cell wg 0) all 16 waves' products are in
             if (pw) {
                 f32x4 g4 = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
@@ -260,7 +263,7 @@ struct CellRole {
             if (ywave) CellRole<256>::mfma_tile(y, Wy, accR0);
         }
         f32x4 x[NF][2];
-        const TileAddr ta = tile_addr(B, wave, lane);
+        const TileAddr ta = tile_addr(B, a.split, wave, lane);
         volatile unsigned* cflags = reinterpret_cast<volatile unsigned*>(smem + 2 * RED + 2 * 4 * 128);
         unsigned cep = 0;
         if (tid < 4) cflags[tid] = 0u;
@@ -298,17 +301,19 @@ struct CellRole {
 };
 
 // ------------------------------------------------------------------------------------------------ attention workgroups
-template <int HS>
+template <int HS, int SPLIT>
 struct AttnRole {
-    static constexpr int D = HS, DW = D / PS_SPLIT;                      // this workgroup's slice of the context columns
+    static constexpr int D = HS, DW = D / SPLIT;                         // this workgroup's slice of the context columns
     static constexpr int C4 = DW / 4, TQ = PS_THREADS / C4;              // context lanes: (column group, time slice)
+    static constexpr int TQW = C4 >= 64 ? 1 : 64 / C4;                   // time slices that share a wave
+    static constexpr int NPART = TQ / TQW;                               // partial contexts that meet in LDS (<= 16 waves)
     static constexpr int NJ = HS / 64;                                   // float4 of W_phi per lane (16 lanes per row)
     static constexpr int MAX_TP = PS_NI * TQ;
     static constexpr int EP = (MAX_TP + 63) & ~63;                       // energies padded to whole waves (pad = -inf)
-    static __host__ __device__ constexpr int lds_floats(int Tp) { return HS + PS_M + EP + MAX_TP + TQ * DW + Tp * PS_KLD; }
+    static __host__ __device__ constexpr int lds_floats(int Tp) { return HS + PS_M + EP + MAX_TP + NPART * DW + Tp * PS_KLD; }
 
     static __device__ void run(const PersistArgs& a, float* smem, const int widx) {
-        const int b = widx / PS_SPLIT, part_id = widx % PS_SPLIT;
+        const int b = widx / SPLIT, part_id = widx % SPLIT;
         const int col0 = part_id * DW;
         const bool first_wg = widx == 0;
         const int tid = threadIdx.x, lane = tid & 63;
@@ -318,7 +323,7 @@ struct AttnRole {
         float* es = qs + PS_M;
         float* as = es + EP;
         float* part = as + MAX_TP;
-        float* ks = part + TQ * DW;
+        float* ks = part + NPART * DW;
         const size_t sH = (size_t)B * HS;
 
         // ---- resident operands
@@ -417,13 +422,19 @@ struct AttnRole {
                     acc[0] = fmaf(w, f[i][0], acc[0]); acc[1] = fmaf(w, f[i][1], acc[1]);
                     acc[2] = fmaf(w, f[i][2], acc[2]); acc[3] = fmaf(w, f[i][3], acc[3]);
                 }
-                *reinterpret_cast<f32x4*>(part + tq * DW + c4 * 4) = acc;
+                // time slices that share a wave meet by cross-lane adds, the rest through LDS
+#pragma unroll
+                for (int off = C4; off < 64; off <<= 1) {
+                    acc[0] += __shfl_xor(acc[0], off); acc[1] += __shfl_xor(acc[1], off);
+                    acc[2] += __shfl_xor(acc[2], off); acc[3] += __shfl_xor(acc[3], off);
+                }
+                if (TQW == 1 || lane < C4) *reinterpret_cast<f32x4*>(part + (tq / TQW) * DW + c4 * 4) = acc;
             }
             lds_barrier();
             if (tid < C4) {
                 f32x4 acc = zero;
 #pragma unroll 4
-                for (int q = 0; q < TQ; ++q) {
+                for (int q = 0; q < NPART; ++q) {
                     const f32x4 v = *reinterpret_cast<const f32x4*>(part + q * DW + tid * 4);
                     acc[0] += v[0]; acc[1] += v[1]; acc[2] += v[2]; acc[3] += v[3];
                 }
@@ -434,17 +445,17 @@ struct AttnRole {
     }
 };
 
-template <int HS>
+template <int HS, int SPLIT>
 __global__ __launch_bounds__(PS_THREADS) void speller_persist_fwd_kernel(PersistArgs a) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     constexpr int NC = HS / 4;
 #if defined(PS_ONLY_CELL)
     CellRole<HS>::run(a, smem);
 #elif defined(PS_ONLY_ATTN)
-    AttnRole<HS>::run(a, smem, blockIdx.x - NC);
+    AttnRole<HS, SPLIT>::run(a, smem, blockIdx.x - NC);
 #else
     if ((int)blockIdx.x < NC) CellRole<HS>::run(a, smem);
-    else AttnRole<HS>::run(a, smem, blockIdx.x - NC);
+    else AttnRole<HS, SPLIT>::run(a, smem, blockIdx.x - NC);
 #endif
 }
 
@@ -452,17 +463,37 @@ __global__ __launch_bounds__(PS_THREADS) void speller_persist_fwd_kernel(Persist
 static unsigned long long* g_persist_trace = nullptr;      // device buffer of 2*U*8 stamps, or null (normal operation)
 void speller_persist_set_trace(unsigned long long* dev_buf) { g_persist_trace = dev_buf; }
 
+// attention workgroups per utterance: the smallest split whose lanes can hold T' frames (7 float4 per lane) and that
+// leaves every workgroup resident at once (one per CU); 0 = the persistent kernel does not apply
+static int persist_split(int B, int Tp, int Hs) {
+    int cus = 0, dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess)
+        return 0;
+    for (int split = 2; split <= 8; split *= 2) {
+        const int dw = Hs / split, c4 = dw / 4, tq = PS_THREADS / c4, max_tp = PS_NI * tq;
+        const int npart = tq / (c4 >= 64 ? 1 : 64 / c4);
+        const long lds = Hs + PS_M + ((max_tp + 63) & ~63) + max_tp + (long)npart * dw + (long)Tp * PS_KLD;   // AttnRole::lds_floats
+        if (Tp <= max_tp && Hs / 4 + split * B <= cus && lds * 4 <= 160 * 1024) return split;
+    }
+    return 0;
+}
+
 bool speller_persist_eligible(int B, int Tp, int Hs, int D, int M, int V, int L, int heads, int use_mlp) {
     if (L != 2 || heads != 1 || !use_mlp || M != PS_M || D != Hs) return false;
     if (Hs != 256 && Hs != 512) return false;
     if (B < 1 || B > 32 || ((V + 15) & ~15) > 256) return false;
-    const int max_tp = Hs == 512 ? AttnRole<512>::MAX_TP : AttnRole<256>::MAX_TP;
-    if (Tp > max_tp) return false;
-    int cus = 0;
-    int dev = 0;
-    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess)
-        return false;
-    return Hs / 4 + PS_SPLIT * B <= cus;           // every workgroup must be resident at once (one per CU)
+    return persist_split(B, Tp, Hs) != 0;
+}
+
+template <int HS, int SPLIT>
+static int launch_persist_fwd(const PersistArgs& a, int grid, hipStream_t stream) {
+    const size_t smem = sizeof(float) * (size_t)std::max(CellRole<HS>::LDS_FLOATS, AttnRole<HS, SPLIT>::lds_floats(a.Tp));
+    LAS_REQUIRE(smem <= 160 * 1024, "persistent speller LDS budget");
+    LAS_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&speller_persist_fwd_kernel<HS, SPLIT>),
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
+    hipLaunchKernelGGL((speller_persist_fwd_kernel<HS, SPLIT>), dim3(grid), dim3(PS_THREADS), smem, stream, a);
+    LAS_LAUNCH_CHECK();
+    return LAS_OK;
 }
 
 int speller_persist_fwd(const PersistFwd& p, hipStream_t stream) {
@@ -476,26 +507,22 @@ int speller_persist_fwd(const PersistFwd& p, hipStream_t stream) {
     a.ctx_all = p.ctx_all; a.h_all = p.h_all; a.c_all = p.c_all; a.gates_all = p.gates_all; a.q_all = p.q_all; a.att = p.att;
     a.hx = p.hx;
     a.B = p.B; a.Tp = p.Tp; a.U = p.U; a.relu = p.relu; a.err = p.err;
+    a.split = persist_split(p.B, p.Tp, p.Hs);
     a.trace = g_persist_trace;
     LAS_REQUIRE(p.err != nullptr, "the persistent speller needs the device error word");
     // sentinel-fill what the phases hand over: every h of both layers and the contexts of steps 1..U
     const size_t sH = (size_t)p.B * p.Hs;
     LAS_HIP_CHECK(hipMemsetAsync(p.hx, 0xFF, sizeof(float) * 2 * p.U * 32 * p.Hs, stream));
     LAS_HIP_CHECK(hipMemsetAsync(p.ctx_all + sH, 0xFF, sizeof(float) * p.U * sH, stream));
-    const int grid = p.Hs / 4 + PS_SPLIT * p.B;
+    const int grid = p.Hs / 4 + a.split * p.B;
     if (p.Hs == 512) {
-        const size_t smem = sizeof(float) * (size_t)std::max(CellRole<512>::LDS_FLOATS, AttnRole<512>::lds_floats(p.Tp));
-        LAS_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&speller_persist_fwd_kernel<512>),
-                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
-        hipLaunchKernelGGL((speller_persist_fwd_kernel<512>), dim3(grid), dim3(PS_THREADS), smem, stream, a);
-    } else {
-        const size_t smem = sizeof(float) * (size_t)std::max(CellRole<256>::LDS_FLOATS, AttnRole<256>::lds_floats(p.Tp));
-        LAS_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&speller_persist_fwd_kernel<256>),
-                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
-        hipLaunchKernelGGL((speller_persist_fwd_kernel<256>), dim3(grid), dim3(PS_THREADS), smem, stream, a);
+        if (a.split == 2) return launch_persist_fwd<512, 2>(a, grid, stream);
+        if (a.split == 4) return launch_persist_fwd<512, 4>(a, grid, stream);
+        return launch_persist_fwd<512, 8>(a, grid, stream);
     }
-    LAS_LAUNCH_CHECK();
-    return LAS_OK;
+    if (a.split == 2) return launch_persist_fwd<256, 2>(a, grid, stream);
+    if (a.split == 4) return launch_persist_fwd<256, 4>(a, grid, stream);
+    return launch_persist_fwd<256, 8>(a, grid, stream);
 }
 
 }  // namespace las

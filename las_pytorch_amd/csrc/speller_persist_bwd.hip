@@ -34,11 +34,12 @@ struct PersistBwdArgs {
     const float* gates_all; const float* c_all; const float* dcat_all;
     float* dG_all; float* dctx_all; float* de_all; float* dqpre_part;
     float* dx0; long ldx0;
-    float* dhA;      // [U][B][2][Hs]            decoder-state gradient parts of the two attention halves
+    float* dhA;      // [U][B][ns][Hs]           decoder-state gradient parts of the attention workgroups of an utterance
     float* dGx;      // [2][U][Hs/16][32][64]    tiled gate gradients (layer, step, unit tile, row, unit*4+gate)
     float* dcx;      // [U][Hs/16][32][16]       context gradient carried to the previous step
     float* dhc;      // [U][Hs/16][32][16]       top-layer recurrent carry (R -> Y)
     int B, Tp, U, relu;
+    int ns;          // attention-backward workgroups per utterance (each owns ceil(T'/ns) frames)
     unsigned* err;
     unsigned long long* trace;
 };
@@ -268,18 +269,24 @@ struct ProdRole {
                 PB_STAMP(1, s, 0);
                 if (pw) {
                     const unsigned* p0 = reinterpret_cast<const unsigned*>(
-                        at_bytes(a.dhA + (size_t)s * B * 2 * HS, opaque(4u * ((unsigned)pb * 2 * HS + 16 * j + pu))));
+                        at_bytes(a.dhA + (size_t)s * B * a.ns * HS, opaque(4u * ((unsigned)pb * a.ns * HS + 16 * j + pu))));
                     const unsigned* pc = reinterpret_cast<const unsigned*>(at_bytes(a.dhc + (size_t)(s + 1) * CXS, opaque(oc)));
-                    unsigned spins = 0, v0, v1, vc = 0u;
+                    unsigned spins = 0, vc = 0u;
+                    float parts = 0.f;
                     for (;;) {
-                        v0 = __hip_atomic_load(p0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                        v1 = __hip_atomic_load(p0 + HS, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        bool ok = true;
+                        parts = 0.f;
+                        for (int k = 0; k < a.ns; ++k) {
+                            const unsigned v = __hip_atomic_load(p0 + k * HS, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                            ok &= v != PS_SENT;
+                            parts += __uint_as_float(v);
+                        }
                         if (s < U - 1) vc = __hip_atomic_load(pc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                        if (v0 != PS_SENT && v1 != PS_SENT && vc != PS_SENT) break;
+                        if (ok && vc != PS_SENT) break;
                         if (spin_expired(spins, a.err, 0xDEAD0023u)) break;
                     }
                     PB_STAMP(1, s, 1);
-                    const float dh = dcat + __uint_as_float(v0) + __uint_as_float(v1) + __uint_as_float(vc);
+                    const float dh = dcat + parts + __uint_as_float(vc);
                     const f32x4 g = cell_bwd(ci, dh, dc);
                     st4_agent(at_bytes(dGx_out + (size_t)s * GXS, opaque(ox)), g);
                     stash_dG(a, 1, s, opaque(o4), g);
@@ -337,11 +344,12 @@ struct AttnBwdRole {
     static __host__ __device__ constexpr int lds_floats() { return 2 * HS + PS_M + TH + 16 * PS_M + PS_M + NMH * HS + TH * PS_KLD; }
 
     static __device__ void run(const PersistBwdArgs& a, float* smem, const int widx) {
-        const int b = widx >> 1, half = widx & 1;
+        const int ns = a.ns;
+        const int b = widx / ns, half = widx % ns;          // `half`: which slice of the T' frames
         const bool first_wg = widx == 0;
         const int tid = threadIdx.x;
         const int B = a.B, U = a.U, Tp = a.Tp;
-        const int th = (Tp + 1) / 2, t0 = half * th, nt = max(0, min(th, Tp - t0));     // this workgroup's frames
+        const int th = (Tp + ns - 1) / ns, t0 = half * th, nt = max(0, min(th, Tp - t0));     // this workgroup's frames
         float* dctx = smem;
         float* ctxs = dctx + HS;
         float* qs = ctxs + HS;
@@ -466,7 +474,7 @@ struct AttnBwdRole {
                     const f32x4 w = *reinterpret_cast<const f32x4*>(dhp + q * HS + tid * 4);
                     v[0] += w[0]; v[1] += w[1]; v[2] += w[2]; v[3] += w[3];
                 }
-                st4_agent(a.dhA + (((size_t)s * B + b) * 2 + half) * HS + tid * 4, v);
+                st4_agent(a.dhA + (((size_t)s * B + b) * ns + half) * HS + tid * 4, v);
             }
             PB_STAMP(2, s, 4);
         }
@@ -494,50 +502,75 @@ __global__ __launch_bounds__(PS_THREADS) void speller_persist_bwd_kernel(Persist
 static unsigned long long* g_persist_bwd_trace = nullptr;
 void speller_persist_bwd_set_trace(unsigned long long* dev_buf) { g_persist_bwd_trace = dev_buf; }
 
+// attention-backward workgroups per utterance: the smallest count whose 64*(512/Hs)-frame slices cover T' and that leaves
+// every workgroup resident at once (one per CU); 0 = not applicable.  cus < 0: shape check only (workspace sizing).
+static int persist_bwd_ns(int B, int Tp, int Hs, int cus) {
+    for (int ns = 2; ns <= 8; ns *= 2)
+        if (Tp <= ns * 64 * (512 / Hs) && (cus < 0 || 3 * (Hs / 16) * 2 + ns * B <= cus)) return ns;
+    return 0;
+}
+static bool persist_bwd_shape(int B, int Hs, int D, int M, int L, int heads, int use_mlp) {
+    return L == 2 && heads == 1 && use_mlp && M == PS_M && D == Hs && (Hs == 256 || Hs == 512) && B >= 1 && B <= 32;
+}
+
 bool speller_persist_bwd_eligible(int B, int Tp, int Hs, int D, int M, int V, int L, int heads, int use_mlp) {
-    if (L != 2 || heads != 1 || !use_mlp || M != PS_M || D != Hs) return false;
-    if (Hs != 256 && Hs != 512) return false;
-    if (B < 1 || B > 32) return false;
-    if (Tp > 2 * 64 * (512 / Hs)) return false;
+    (void)V;
+    if (!persist_bwd_shape(B, Hs, D, M, L, heads, use_mlp)) return false;
     int cus = 0, dev = 0;
     if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess)
         return false;
-    return 3 * (Hs / 16) * 2 + 2 * B <= cus;          // every workgroup resident at once, one per CU
+    return persist_bwd_ns(B, Tp, Hs, cus) != 0;
 }
 
-size_t speller_persist_bwd_workspace_floats(int B, int U, int Hs) {
-    return (size_t)U * B * 2 * Hs + (size_t)2 * U * (Hs / 16) * 32 * 64 + (size_t)2 * (U + 1) * (Hs / 16) * 32 * 16;
+// floats of the hand-off slabs + the attention workgroups' dqpre parts; 0 when the shape is not covered
+size_t speller_persist_bwd_workspace_floats(int B, int Tp, int U, int Hs, int M) {
+    if (Hs != 256 && Hs != 512) return 0;
+    const int ns = persist_bwd_ns(B, Tp, Hs, -1);
+    if (ns == 0) return 0;
+    return (size_t)ns * U * B * M + (size_t)U * B * ns * Hs + (size_t)2 * U * (Hs / 16) * 32 * 64 + (size_t)2 * (U + 1) * (Hs / 16) * 32 * 16;
+}
+
+template <int HS>
+static int launch_persist_bwd(const PersistBwdArgs& a, int grid, hipStream_t stream) {
+    const size_t smem = sizeof(float) * (size_t)std::max(ProdRole<HS>::LDS_FLOATS, AttnBwdRole<HS>::lds_floats());
+    LAS_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&speller_persist_bwd_kernel<HS>),
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
+    hipLaunchKernelGGL((speller_persist_bwd_kernel<HS>), dim3(grid), dim3(PS_THREADS), smem, stream, a);
+    LAS_LAUNCH_CHECK();
+    return LAS_OK;
 }
 
 int speller_persist_bwd(const PersistBwd& p, hipStream_t stream) {
     LAS_REQUIRE(speller_persist_bwd_eligible(p.B, p.Tp, p.Hs, p.Hs, PS_M, p.V, 2, 1, 1), "persistent speller backward shape");
-    LAS_REQUIRE(p.err != nullptr && p.xbuf != nullptr, "persistent speller backward buffers");
+    LAS_REQUIRE(p.err != nullptr && p.xbuf != nullptr && p.dqpre_all != nullptr, "persistent speller backward buffers");
+    int cus = 0, dev = 0;
+    LAS_HIP_CHECK(hipGetDevice(&dev));
+    LAS_HIP_CHECK(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
     PersistBwdArgs a;
+    a.ns = persist_bwd_ns(p.B, p.Tp, p.Hs, cus);
     a.w_ih0 = p.w_ih0; a.ldw0 = p.V + p.Hs; a.V = p.V;
     a.w_hh0 = p.w_hh0; a.w_ih1 = p.w_ih1; a.w_hh1 = p.w_hh1; a.w_phi = p.w_phi;
     a.feat = p.feat; a.keys = p.keys; a.att = p.att; a.q_all = p.q_all; a.ctx_all = p.ctx_all;
     a.gates_all = p.gates_all; a.c_all = p.c_all; a.dcat_all = p.dcat_all;
-    a.dG_all = p.dG_all; a.dctx_all = p.dctx_all; a.de_all = p.de_all; a.dqpre_part = p.dqpre_part;
+    a.dG_all = p.dG_all; a.dctx_all = p.dctx_all; a.de_all = p.de_all;
     a.dx0 = p.dx0; a.ldx0 = p.V + p.Hs;
-    a.dhA = p.xbuf;
-    a.dGx = a.dhA + (size_t)p.U * p.B * 2 * p.Hs;
+    // carve the workspace: [dqpre parts | sentinel-prefilled slabs: dhA | tiled dG (2 layers) | dcx | dhc]
+    const size_t nq = (size_t)p.U * p.B * PS_M;
+    a.dqpre_part = p.xbuf;
+    float* slabs = p.xbuf + (size_t)a.ns * nq;
+    a.dhA = slabs;
+    a.dGx = a.dhA + (size_t)p.U * p.B * a.ns * p.Hs;
     a.dcx = a.dGx + (size_t)2 * p.U * (p.Hs / 16) * 32 * 64;
     a.dhc = a.dcx + (size_t)(p.U + 1) * (p.Hs / 16) * 32 * 16;
+    const size_t slab_floats = (size_t)p.U * p.B * a.ns * p.Hs + (size_t)2 * p.U * (p.Hs / 16) * 32 * 64 + (size_t)2 * (p.U + 1) * (p.Hs / 16) * 32 * 16;
     a.B = p.B; a.Tp = p.Tp; a.U = p.U; a.relu = p.relu; a.err = p.err; a.trace = g_persist_bwd_trace;
-    LAS_HIP_CHECK(hipMemsetAsync(p.xbuf, 0xFF, sizeof(float) * speller_persist_bwd_workspace_floats(p.B, p.U, p.Hs), stream));
-    const int grid = 3 * (p.Hs / 16) * 2 + 2 * p.B;
-    if (p.Hs == 512) {
-        const size_t smem = sizeof(float) * (size_t)std::max(ProdRole<512>::LDS_FLOATS, AttnBwdRole<512>::lds_floats());
-        LAS_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&speller_persist_bwd_kernel<512>),
-                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
-        hipLaunchKernelGGL((speller_persist_bwd_kernel<512>), dim3(grid), dim3(PS_THREADS), smem, stream, a);
-    } else {
-        const size_t smem = sizeof(float) * (size_t)std::max(ProdRole<256>::LDS_FLOATS, AttnBwdRole<256>::lds_floats());
-        LAS_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&speller_persist_bwd_kernel<256>),
-                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
-        hipLaunchKernelGGL((speller_persist_bwd_kernel<256>), dim3(grid), dim3(PS_THREADS), smem, stream, a);
-    }
-    LAS_LAUNCH_CHECK();
+    LAS_HIP_CHECK(hipMemsetAsync(slabs, 0xFF, sizeof(float) * slab_floats, stream));
+    const int grid = 3 * (p.Hs / 16) * 2 + a.ns * p.B;
+    if (p.Hs == 512) LAS_TRY(launch_persist_bwd<512>(a, grid, stream));
+    else LAS_TRY(launch_persist_bwd<256>(a, grid, stream));
+    // dqpre = sum of the attention workgroups' parts (the relu mask is linear in dq)
+    LAS_HIP_CHECK(hipMemcpyAsync(p.dqpre_all, a.dqpre_part, sizeof(float) * nq, hipMemcpyDeviceToDevice, stream));
+    for (int k = 1; k < a.ns; ++k) LAS_TRY(add_inplace(p.dqpre_all, a.dqpre_part + (size_t)k * nq, (long)nq, stream));
     return LAS_OK;
 }
 

@@ -276,7 +276,9 @@ def test_edge_shapes_vs_oracle(cfg_name, B, T, U):
 
 
 @pytest.mark.parametrize("cfg_name,B,Tp,U,scale", [("P", 32, 100, 24, None), ("P", 5, 37, 7, 0.1), ("S", 17, 200, 9, None),
-                                                    ("S", 32, 100, 12, 0.1), ("P", 1, 1, 3, None)])
+                                                    ("S", 32, 100, 12, 0.1), ("P", 1, 1, 3, None),
+                                                    ("P", 8, 375, 5, None), ("P", 32, 200, 4, None), ("S", 8, 500, 4, None),
+                                                    ("S", 16, 300, 4, None)])
 def test_persistent_decode_kernel_matches_stepwise(cfg_name, B, Tp, U, scale):
     """The one-launch teacher-forced decode loop (speller_persist.hip) against the per-step launch chain it replaces:
     outputs and every gradient (the backward pass consumes the stash the forward kernel wrote).  The larger-weight
