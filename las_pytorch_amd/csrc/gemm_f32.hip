@@ -27,7 +27,7 @@ struct GemmParams {
     const float* A; const float* B; float* C; const float* bias0; const float* bias1;
     int M, N, K;
     long lda, ldb, ldc;
-    long sA, sB, sC;
+    long sA, sB, sC, sBias0, sBias1;
     int splitk, kper;
     int accumulate, relu, atomic;
     int a_vec, b_vec;   // 16-byte vector loads legal for this operand
@@ -192,8 +192,8 @@ __global__ __launch_bounds__(GEMM_THREADS) void gemm_f32_kernel(GemmParams p) {
         if (n >= p.N) continue;
         float bsum = 0.f;
         if (add_bias) {
-            if (p.bias0) bsum += p.bias0[n];
-            if (p.bias1) bsum += p.bias1[n];
+            if (p.bias0) bsum += p.bias0[(long)bz * p.sBias0 + n];
+            if (p.bias1) bsum += p.bias1[(long)bz * p.sBias1 + n];
         }
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
@@ -221,7 +221,7 @@ int gemm_f32(const GemmDesc& d, hipStream_t stream) {
     GemmParams p;
     p.A = d.A; p.B = d.B; p.C = d.C; p.bias0 = d.bias0; p.bias1 = d.bias1;
     p.M = d.M; p.N = d.N; p.K = d.K; p.lda = d.lda; p.ldb = d.ldb; p.ldc = d.ldc;
-    p.sA = d.sA; p.sB = d.sB; p.sC = d.sC;
+    p.sA = d.sA; p.sB = d.sB; p.sC = d.sC; p.sBias0 = d.sBias0; p.sBias1 = d.sBias1;
     const int batch = d.batch > 0 ? d.batch : 1;
     int splitk = d.splitk > 0 ? d.splitk : 1;
     const int gx = cdiv(d.N, BN), gy = cdiv(d.M, BM);

@@ -16,6 +16,7 @@ struct GemmDesc {
     bool a_kc = true, b_kc = true;
     int batch = 1;
     long sA = 0, sB = 0, sC = 0;   // batch strides (elements)
+    long sBias0 = 0, sBias1 = 0;   // batch strides of the biases (elements; may be a pointer difference between two tensors)
     int splitk = 0;                // 0 = auto, 1 = none, >1 = forced (atomic accumulation)
     bool accumulate = false;       // C += ...
     bool relu = false;

@@ -354,5 +354,6 @@ def test_direct_gradient_write_matches_autograd_accumulation():
     finally:
         las_model.DIRECT_GRAD_WRITE = False
     assert np.abs(flats[0]).max() > 0
-    assert_close(flats[1], flats[0], "direct vs accumulated flat gradient", rtol=1e-5, atol=1e-7 * float(np.abs(flats[0]).max()))
+    # split-K GEMMs accumulate with atomics, so two runs agree only to fp32 rounding of the sum order
+    assert_close(flats[1], flats[0], "direct vs accumulated flat gradient", rtol=1e-4, atol=1e-6 * float(np.abs(flats[0]).max()))
     _check_err()
