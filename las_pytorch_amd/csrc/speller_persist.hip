@@ -2,19 +2,20 @@
 //
 // Replaces the per-step launch chain (lstm_cell_fwd x2 + attn_step_fwd, speller.hip) for the training forward of the
 // reference's Speller.forward (model/las_model.py:186-238, teacher-forced branch :207-209) when the shapes allow it.
-// The stepwise kernels stay the general path (free-running decode, multi-head, long T', large batches).
+// The stepwise kernels stay the general path (free-running decode, multi-head, very long T', batches above 32).
 //
 // Why: a decode step is a chain of three dependent phases.  As three kernels each phase pays ~4 us of launch/drain
 // floor plus ~4 us of L2->CU operand traffic (every workgroup re-reads the weights it used one step ago).  Here
 //   * Hs/4 "cell" workgroups each own 4 hidden units of BOTH LSTM layers for the whole utterance batch and keep their
 //     rows of W_ih/W_hh in VGPRs (36 floats per lane at Hs=512) for all U steps; the cell state c never leaves the
 //     workgroup.  The batch is the M dimension of v_mfma_f32_16x16x4_f32 (exact fp32), the 16 waves split K.
-//   * B "attention" workgroups each own one utterance and keep its listener features in VGPRs (<=13 float4 per lane),
-//     its keys in LDS and W_phi in VGPRs.
-//   * phases hand data over through the per-step stash arrays the backward pass needs anyway (h_all, ctx_all), which
-//     the host pre-fills with a sentinel bit pattern (0xFFFFFFFF, never produced by the kernels): producers write with
-//     agent-scope (write-through) stores, consumers poll the very words they need with agent-scope loads until no
-//     sentinel is left — the data is its own flag, no counters, no fences, no epochs.
+//   * split*B "attention" workgroups (split = 2, 4 or 8 per utterance, each owning D/split context columns) keep their
+//     slice of the listener features in VGPRs (7 float4 per lane), the keys in LDS and W_phi in VGPRs.
+//   * phases hand data over through per-step slabs (ctx_all, which the backward pass needs anyway, and a tiled copy of
+//     h) that the host pre-fills with a sentinel bit pattern (0xFFFFFFFF, never produced by the kernels): producers
+//     write whole cache lines with agent-scope (write-through) stores; one wave of a consumer workgroup watches one
+//     dword per producer workgroup, then every wave reads its tile with ordinary (L2-shared) loads, multiplies, and
+//     checks every consumed word against the sentinel — the data is its own flag, no counters, no fences, no epochs.
 //   * only the operand the chain just produced is multiplied on the critical path: the recurrent halves
 //     (W_hh h_{s}) and the label half (W_y y_{s+1}) of the NEXT step's gates are accumulated while the attention
 //     workgroups are busy (the h_0 tile loaded for layer 1 is reused in registers for layer 0's recurrent half).
@@ -54,10 +55,10 @@ struct CellRole {
     static constexpr int RED = PS_NW * 2 * 16 * RLD;    // floats of the per-wave partial tile buffer
     static constexpr int LDS_FLOATS = 2 * RED + 2 * 4 * 128 + 4;      // one buffer per layer + summed biases of the cell lanes + canary flags
 
-    // x tile of this wave: rows = utterances (two 16-row M-tiles), columns = its k-blocks.  Polls until no sentinel.
-    // KIND 0: tile of h (each 4-column group comes from one cell workgroup); KIND 1: tile of the context (each row half
+    // x tile of this wave: rows = utterances (two 16-row M-tiles), columns = its k-blocks.
+    // KIND 0: tile of h (each 4-column group comes from one cell workgroup); KIND 1: tile of the context (each row part
     // comes from one attention workgroup); KIND 2: data known to be published long ago (no canary).
-    //  1. canary: one agent-scope dword per lane, the lanes of the wave covering every producer of this wave's tile;
+    //  1. canary (wg_canary_wait): the first wave(s) watch one agent-scope dword per producer workgroup;
     //  2. the tile itself with PLAIN loads: the 16 cell workgroups of an XCD share them through its L2 instead of each
     //     pulling 64 KB over the fabric (agent-scope loads bypass the L2: 8.4 MB per phase, measured ~3.5 us);
     //  3. every consumed word is still checked against the sentinel; a slot that raced ahead of its producer (its stale
