@@ -35,7 +35,7 @@ struct PblstmBwdLayout {
 };
 
 struct SpellerLayout {
-    size_t y_all, ctx_all, h_all, c_all, gates_all, q_all, w0p, ctxcat_all, hx, total;
+    size_t y_all, ctx_all, h_all, c_all, gates_all, q_all, w0p, ctxcat_all, hx, lgx, total;
     int Vp;                    // label width padded to a multiple of 16: every cell operand is aligned and tail-free
     SpellerLayout(const las_speller_desc* d, int U) {
         size_t o = 0;
@@ -50,6 +50,7 @@ struct SpellerLayout {
         ctxcat_all = o; if (d->multi_head > 1) o += r4((size_t)U * B * d->multi_head * d->D);   // per-head contexts (dim_reduce input)
         w0p = o; o += r4((size_t)4 * d->Hs * (Vp + d->Hs));      // W_ih0 re-laid as [W_y | 0 | W_ctx], ld = Vp + Hs
         hx = o; if (d->L == 2) o += r4((size_t)2 * U * 32 * d->Hs);   // hand-off copy of h for the persistent decode kernel
+        lgx = o; if (d->L == 2) o += r4((size_t)U * B * 8 * 32);      // ... and its partial logits (free-running decode)
         total = o;
     }
 };
@@ -266,8 +267,8 @@ int las_speller_fwd(const las_speller_desc* d, const float* feat, const float* k
     LAS_TRY(copy2d(d->w_ih[0] + V, V + Hs, w0p + Vp, Vp + Hs, 4 * Hs, Hs, 0, stream));
 
     static const bool persist_on = !(getenv("LAS_SPELLER_PERSIST") && atoi(getenv("LAS_SPELLER_PERSIST")) == 0);
-    const bool persist = persist_on && teacher_forced && err_word && !(flags & LAS_FLAG_FORCE_GENERIC) &&
-                         speller_persist_eligible(B, Tp, Hs, D, d->M, V, L, d->multi_head, d->use_mlp);
+    const bool persist = persist_on && err_word && !(flags & LAS_FLAG_FORCE_GENERIC) &&
+                         speller_persist_eligible(B, Tp, Hs, D, d->M, V, L, d->multi_head, d->use_mlp, !teacher_forced);
     if (persist) {
         PersistFwd p;
         p.w0p = w0p; p.Vp = Vp;
@@ -279,6 +280,10 @@ int las_speller_fwd(const las_speller_desc* d, const float* feat, const float* k
         p.B = B; p.Tp = Tp; p.U = U; p.Hs = Hs; p.V = V; p.relu = d->relu;
         p.hx = reserve + lay.hx;
         p.err = err_word;
+        if (!teacher_forced) {      // the kernel produces log-probabilities, arg-max and the fed-back inputs itself
+            p.mode = decode_mode == 1 ? 1 : 2;
+            p.w_c = d->w_c; p.b_c = d->b_c; p.logp = logp; p.argmax = argmax; p.lgx = reserve + lay.lgx;
+        }
         LAS_TRY(speller_persist_fwd(p, stream));
     }
     for (int s = 0; s < (persist ? 0 : U); ++s) {

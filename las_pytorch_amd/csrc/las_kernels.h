@@ -104,13 +104,17 @@ struct PersistFwd {
     const float* w_hh0; const float* w_ih1; const float* w_hh1;
     const float* b_ih0; const float* b_hh0; const float* b_ih1; const float* b_hh1;
     const float* w_phi; const float* b_phi;
-    const float* feat; const float* keys; const float* y_all;
+    const float* feat; const float* keys; float* y_all;
     float* ctx_all; float* h_all; float* c_all; float* gates_all; float* q_all; float* att;
     float* hx;                                      // 2*U*32*Hs floats: tiled hand-off copy of h (see speller_persist.hip)
+    int mode = 0;                                   // 0 teacher forcing, 1 feed one-hot arg-max, 2 feed log-probabilities
+    const float* w_c = nullptr; const float* b_c = nullptr;
+    float* logp = nullptr; int* argmax = nullptr;   // free-running outputs (U,B,V), (U,B)
+    float* lgx = nullptr;                           // U*B*8*32 floats: partial logits of the attention workgroups
     int B, Tp, U, Hs, V, relu;
     unsigned* err;
 };
-bool speller_persist_eligible(int B, int Tp, int Hs, int D, int M, int V, int L, int heads, int use_mlp);
+bool speller_persist_eligible(int B, int Tp, int Hs, int D, int M, int V, int L, int heads, int use_mlp, int free_running);
 int speller_persist_fwd(const PersistFwd& p, hipStream_t stream);
 void speller_persist_set_trace(unsigned long long* dev_buf);   // profiling aid, see tools/ubench_persist_trace.py
 

@@ -36,9 +36,15 @@ struct PersistArgs {
     const float* w_hh0; const float* w_ih1; const float* w_hh1;
     const float* b_ih0; const float* b_hh0; const float* b_ih1; const float* b_hh1;
     const float* w_phi; const float* b_phi;
-    const float* feat; const float* keys; const float* y_all;
+    const float* feat; const float* keys; float* y_all;
     float* ctx_all; float* h_all; float* c_all; float* gates_all; float* q_all; float* att;
     float* hx;                     // hand-off copy of h: [layer][step][unit tile Hs/4][row 32][4], sentinel-prefilled
+    // free-running decode (mode 1: feed the one-hot arg-max, reference decode_mode 1, las_model.py:223-227;
+    // mode 2: feed the log-probabilities, decode_mode 0, :220-221; mode 0: teacher forcing)
+    int mode, V;
+    const float* w_c; const float* b_c;   // (V, 2Hs), (V)
+    float* logp; int* argmax_out;          // (U,B,V), (U,B) or null
+    float* lgx;                            // [U][B][split][32] partial logits of the attention workgroups, sentinel-prefilled
     int B, Tp, U, relu;
     int split;                     // attention workgroups per utterance (each owns D/split context columns)
     unsigned* err;
@@ -48,12 +54,13 @@ struct PersistArgs {
 #define PS_STAMP(role, s, k) do { if (a.trace && first_wg && threadIdx.x == 0) a.trace[((size_t)(role) * a.U + (s)) * 8 + (k)] = wall_clock64(); } while (0)
 
 // ------------------------------------------------------------------------------------------------ cell workgroups
-template <int HS>
+template <int HS, bool GREEDY>
 struct CellRole {
     static constexpr int NF = HS / 256;                 // 16-wide k-blocks of an Hs-wide operand per wave
     static constexpr int RLD = 20;                      // row stride of a partial tile: 16 columns + pad, 16-byte aligned
     static constexpr int RED = PS_NW * 2 * 16 * RLD;    // floats of the per-wave partial tile buffer
-    static constexpr int LDS_FLOATS = 2 * RED + 2 * 4 * 128 + 4;      // one buffer per layer + summed biases of the cell lanes + canary flags
+    static constexpr int GREEDY_FLOATS = 32 * 32 + 32 * 32 + 32 + 16 * 32;    // logits, fed-back input, arg-max, W_y rows
+    static constexpr int LDS_FLOATS = 2 * RED + 2 * 4 * 128 + 4 + GREEDY_FLOATS;   // reduction buffer per layer + biases + canary flags
 
     // x tile of this wave: rows = utterances (two 16-row M-tiles), columns = its k-blocks.
     // KIND 0: tile of h (each 4-column group comes from one cell workgroup); KIND 1: tile of the context (each row part
@@ -210,6 +217,72 @@ struct CellRole {
                 bias[(4 + g) * 128 + tid] = a.b_ih1[row] + a.b_hh1[row];
             }
         }
+        // ---- free-running decode state (LDS): summed logits of the previous step, the input fed back, its arg-max, W_y rows
+        const int mode = GREEDY ? a.mode : 0;        // compile-time 0 in the teacher-forced instantiation
+        float* lsum = smem + 2 * RED + 2 * 4 * 128 + 4;
+        float* yv = lsum + 32 * 32;
+        int* amax = reinterpret_cast<int*>(yv + 32 * 32);
+        float* wy = yv + 32 * 32 + 32;
+        if (GREEDY) {
+            if (tid < 512) {
+                const int n = tid >> 5, v = tid & 31;
+                wy[n * 32 + v] = v < a.Vp ? a.w0p[((long)(n >> 2) * HS + j0 + (n & 3)) * a.ldw0 + v] : 0.f;
+            }
+            yv[tid] = (tid & 31) == 0 ? 1.f : 0.f;       // step 0 is fed <sos> = one-hot(0) (las_model.py:193-195)
+            if (tid < 32) amax[tid] = 0;
+        }
+        // the attention workgroups' partial logits of step sp -> lsum (threads 768..1023: 8 float4 per utterance)
+        auto collect_logits = [&](int sp) {
+            if (tid >= 768) {
+                const int t = tid - 768, b = t >> 3, q = t & 7;
+                if (b < B) {
+                    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+                    for (int p = 0; p < a.split; ++p) {
+                        const float* src = a.lgx + (((size_t)sp * B + b) * a.split + p) * 32 + q * 4;
+                        unsigned spins = 0;
+                        f32x4 v;
+                        for (;;) {
+                            v = ld4_agent(src);
+                            if (!has_sentinel(v)) break;
+                            if (spin_expired(spins, a.err, 0xDEAD0014u)) break;
+                        }
+                        acc[0] += v[0]; acc[1] += v[1]; acc[2] += v[2]; acc[3] += v[3];
+                    }
+                    *reinterpret_cast<f32x4*>(lsum + b * 32 + q * 4) = acc;
+                }
+            }
+        };
+        // logits of step sp (in lsum) -> arg-max / log-probabilities and the next input (LDS): one 32-lane group per
+        // utterance.  The outputs of utterance b (log-probs, arg-max, the fed-back input for the backward pass) are
+        // written by cell workgroup b, so that no single workgroup carries all of that off-chip traffic.
+        auto choose_next = [&](int sp) {
+            const int b = tid >> 5, v = tid & 31;
+            const float val = v < a.V ? lsum[b * 32 + v] : -INFINITY;
+            float m = val;
+            m = fmaxf(m, dpp_f(m, 0)); m = fmaxf(m, dpp_f(m, 1)); m = fmaxf(m, dpp_f(m, 2)); m = fmaxf(m, dpp_f(m, 3));
+            m = fmaxf(m, __shfl_xor(m, 16));
+            int best = val == m ? v : 64;                                                 // first maximal index
+            best = min(best, __shfl_xor(best, 1)); best = min(best, __shfl_xor(best, 2)); best = min(best, __shfl_xor(best, 4));
+            best = min(best, __shfl_xor(best, 8)); best = min(best, __shfl_xor(best, 16));
+            const bool writer = (int)blockIdx.x == b;
+            float lp = 0.f;
+            if (mode == 2 || writer) {
+                float se = v < a.V ? expf(val - m) : 0.f;
+                se = gsum<16>(se);
+                se += __shfl_xor(se, 16);
+                lp = val - (m + logf(se));
+            }
+            const float y = v < a.V ? (mode == 1 ? (v == best ? 1.f : 0.f) : lp) : 0.f;
+            if (b < B) {
+                yv[b * 32 + v] = y;
+                if (v == 0) amax[b] = best;
+                if (writer) {
+                    if (v < a.V) a.logp[((size_t)sp * B + b) * a.V + v] = lp;
+                    if (v < a.Vp) a.y_all[((size_t)(sp + 1) * B + b) * a.Vp + v] = y;
+                    if (v == 0 && a.argmax_out) a.argmax_out[(size_t)sp * B + b] = best;
+                }
+            }
+        };
         const int rcol = (r & 3) * 4 + (r >> 2);        // tile column (gate*4 + unit) stored as unit*4 + gate: a cell lane
                                                         // reads the four gates of its unit as one 16-byte LDS word
         auto load_y = [&](int s, f32x4 (&y)[1][2]) {
@@ -241,6 +314,20 @@ struct CellRole {
                 }
 #pragma unroll
                 for (int g = 0; g < 4; ++g) g4[g] += bias[(layer * 4 + g) * 128 + tid];
+                if (GREEDY && layer == 0) {
+                    // free-running: the label half of the gates comes from what the previous step produced
+                    if (mode == 1) {
+                        const int am = amax[pb];
+#pragma unroll
+                        for (int g = 0; g < 4; ++g) g4[g] += wy[(g * 4 + pu) * 32 + am];
+                    } else {
+                        for (int v = 0; v < a.V; ++v) {
+                            const float yvv = yv[pb * 32 + v];
+#pragma unroll
+                            for (int g = 0; g < 4; ++g) g4[g] = fmaf(wy[(g * 4 + pu) * 32 + v], yvv, g4[g]);
+                        }
+                    }
+                }
                 const float ig = sigmoidf_acc(g4[0]), fg = sigmoidf_acc(g4[1]), gg = tanhf_acc(g4[2]), og = sigmoidf_acc(g4[3]);
                 c = fg * c + ig * gg;
                 const float h = og * tanhf_acc(c);
@@ -258,10 +345,10 @@ struct CellRole {
         f32x4 accR0[2], accR1[2];
         const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
         accR0[0] = accR0[1] = accR1[0] = accR1[1] = zero;
-        {
+        if (!GREEDY) {
             f32x4 y[1][2];
             load_y(0, y);
-            if (ywave) CellRole<256>::mfma_tile(y, Wy, accR0);
+            if (ywave) CellRole<256, GREEDY>::mfma_tile(y, Wy, accR0);
         }
         f32x4 x[NF][2];
         const TileAddr ta = tile_addr(B, a.split, wave, lane);
@@ -273,10 +360,15 @@ struct CellRole {
         for (int s = 0; s < U; ++s) {
             // next step's labels: issued now, consumed after layer 1 (plain load, its latency is off the chain)
             f32x4 ynext[1][2];
-            if (s + 1 < U) load_y(s + 1, ynext);
+            if (!GREEDY && s + 1 < U) load_y(s + 1, ynext);
             // layer 0: gates = W_ctx ctx_{s-1} + [W_hh0 h0_{s-1} + W_y y_s  (accumulated ahead)]
             PS_STAMP(0, s, 0);
             nslow[1] += poll_mul<1>(a.ctx_all + (size_t)s * B * HS, ta, x, Wc0, accR0, a.err, cflags, cep);
+            if (GREEDY && s > 0) {      // the logits of step s-1 land just after its context: fetched behind the product
+                collect_logits(s - 1);
+                lds_barrier();
+                choose_next(s - 1);
+            }
             PS_STAMP(0, s, 1);
             finish(accR0, c0, 0, s);
             PS_STAMP(0, s, 2);
@@ -289,12 +381,18 @@ struct CellRole {
             // off the critical chain (the attention workgroups are working now): recurrent / label halves of layer 0
             accR0[0] = accR0[1] = zero;
             mfma_tile(x, Wh0, accR0);                              // the h0_s tile is still in registers
-            if (ywave) CellRole<256>::mfma_tile(ynext, Wy, accR0);
+            if (!GREEDY && ywave) CellRole<256, GREEDY>::mfma_tile(ynext, Wy, accR0);
             PS_STAMP(0, s, 6);
             // ... and of layer 1, as soon as every cell workgroup's h1_s has arrived (still inside the attention window)
             accR1[0] = accR1[1] = zero;
             nslow[2] += poll_mul<0>(a.hx + ((size_t)U + s) * HXS, ta, x, Wh1, accR1, a.err, cflags, cep);
             PS_STAMP(0, s, 7);
+        }
+        if (GREEDY && (int)blockIdx.x < B) {        // the last step's character distribution (writer workgroups only)
+            lds_barrier();
+            collect_logits(U - 1);
+            lds_barrier();
+            choose_next(U - 1);
         }
         if (a.trace && first_wg && tid == 0)
             for (int k = 0; k < 3; ++k) a.trace[((size_t)a.U + k) * 8 + 7] = (unsigned long long)nslow[k];
@@ -302,7 +400,7 @@ struct CellRole {
 };
 
 // ------------------------------------------------------------------------------------------------ attention workgroups
-template <int HS, int SPLIT>
+template <int HS, int SPLIT, bool GREEDY>
 struct AttnRole {
     static constexpr int D = HS, DW = D / SPLIT;                         // this workgroup's slice of the context columns
     static constexpr int C4 = DW / 4, TQ = PS_THREADS / C4;              // context lanes: (column group, time slice)
@@ -311,7 +409,10 @@ struct AttnRole {
     static constexpr int NJ = HS / 64;                                   // float4 of W_phi per lane (16 lanes per row)
     static constexpr int MAX_TP = PS_NI * TQ;
     static constexpr int EP = (MAX_TP + 63) & ~63;                       // energies padded to whole waves (pad = -inf)
-    static __host__ __device__ constexpr int lds_floats(int Tp) { return HS + PS_M + EP + MAX_TP + NPART * DW + Tp * PS_KLD; }
+    static constexpr int WCL = HS + DW;                                  // W_c columns a workgroup multiplies: [h | its context slice]
+    static __host__ __device__ constexpr int lds_floats(int Tp, int V, bool greedy) {
+        return HS + PS_M + EP + MAX_TP + NPART * DW + Tp * PS_KLD + (greedy ? V * WCL + DW + 32 : 0);
+    }
 
     static __device__ void run(const PersistArgs& a, float* smem, const int widx) {
         const int b = widx / SPLIT, part_id = widx % SPLIT;
@@ -325,7 +426,9 @@ struct AttnRole {
         float* as = es + EP;
         float* part = as + MAX_TP;
         float* ks = part + NPART * DW;
-        const size_t sH = (size_t)B * HS;
+        float* wcl = ks + Tp * PS_KLD;                 // free-running only: W_c rows [h columns | own context columns]
+        float* ctxl = wcl + a.V * WCL;
+        float* lgl = ctxl + DW;
 
         // ---- resident operands
         const int c4 = tid % C4, tq = tid / C4;
@@ -348,6 +451,12 @@ struct AttnRole {
 #pragma unroll
         for (int j = 0; j < NJ; ++j) wphi[j] = ld4p(a.w_phi + (size_t)prow * HS + 4 * (pk + 16 * j));
         const float bphi = a.b_phi[prow];
+        if (GREEDY) {
+            for (int idx = tid; idx < a.V * WCL; idx += PS_THREADS) {
+                const int v = idx / WCL, k = idx % WCL;
+                wcl[idx] = a.w_c[(size_t)v * 2 * HS + (k < HS ? k : HS + col0 + (k - HS))];
+            }
+        }
         lds_barrier();
 
         for (int s = 0; s < U; ++s) {
@@ -440,23 +549,48 @@ struct AttnRole {
                     acc[0] += v[0]; acc[1] += v[1]; acc[2] += v[2]; acc[3] += v[3];
                 }
                 st4_agent(a.ctx_all + ((size_t)(s + 1) * B + b) * D + col0 + tid * 4, acc);
+                if (GREEDY) *reinterpret_cast<f32x4*>(ctxl + tid * 4) = acc;
             }
             PS_STAMP(1, s, 5);
+            if (GREEDY) {
+                // ---- free-running: this workgroup's part of the character-distribution logits W_c [h | ctx] + b_c
+                // (the context columns are split over the workgroups of an utterance, part 0 also takes the h columns and
+                //  the bias); the cell workgroups sum the parts, pick the arg-max and feed it back
+                lds_barrier();
+                {
+                    const int v = tid >> 5, l = tid & 31;
+                    float acc = 0.f;
+                    if (v < a.V) {
+                        const float* wr = wcl + v * WCL;
+#pragma unroll 4
+                        for (int k = l; k < DW; k += 32) acc = fmaf(wr[HS + k], ctxl[k], acc);
+                        if (part_id == 0) {
+#pragma unroll 4
+                            for (int k = l; k < HS; k += 32) acc = fmaf(wr[k], hs[k], acc);
+                        }
+                    }
+                    acc = gsum<16>(acc);
+                    acc += __shfl_xor(acc, 16);
+                    if (l == 0 && v < 32) lgl[v] = v < a.V ? acc + (part_id == 0 ? a.b_c[v] : 0.f) : 0.f;
+                }
+                lds_barrier();
+                if (tid < 32) st1_agent(a.lgx + (((size_t)s * B + b) * SPLIT + part_id) * 32 + tid, lgl[tid]);
+            }
         }
     }
 };
 
-template <int HS, int SPLIT>
+template <int HS, int SPLIT, bool GREEDY>
 __global__ __launch_bounds__(PS_THREADS) void speller_persist_fwd_kernel(PersistArgs a) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     constexpr int NC = HS / 4;
 #if defined(PS_ONLY_CELL)
-    CellRole<HS>::run(a, smem);
+    CellRole<HS, GREEDY>::run(a, smem);
 #elif defined(PS_ONLY_ATTN)
-    AttnRole<HS, SPLIT>::run(a, smem, blockIdx.x - NC);
+    AttnRole<HS, SPLIT, GREEDY>::run(a, smem, blockIdx.x - NC);
 #else
-    if ((int)blockIdx.x < NC) CellRole<HS>::run(a, smem);
-    else AttnRole<HS, SPLIT>::run(a, smem, blockIdx.x - NC);
+    if ((int)blockIdx.x < NC) CellRole<HS, GREEDY>::run(a, smem);
+    else AttnRole<HS, SPLIT, GREEDY>::run(a, smem, blockIdx.x - NC);
 #endif
 }
 
@@ -466,40 +600,49 @@ void speller_persist_set_trace(unsigned long long* dev_buf) { g_persist_trace = 
 
 // attention workgroups per utterance: the smallest split whose lanes can hold T' frames (7 float4 per lane) and that
 // leaves every workgroup resident at once (one per CU); 0 = the persistent kernel does not apply
-static int persist_split(int B, int Tp, int Hs) {
+static int persist_split(int B, int Tp, int Hs, int V, bool greedy) {
     int cus = 0, dev = 0;
     if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess)
         return 0;
     for (int split = 2; split <= 8; split *= 2) {
         const int dw = Hs / split, c4 = dw / 4, tq = PS_THREADS / c4, max_tp = PS_NI * tq;
         const int npart = tq / (c4 >= 64 ? 1 : 64 / c4);
-        const long lds = Hs + PS_M + ((max_tp + 63) & ~63) + max_tp + (long)npart * dw + (long)Tp * PS_KLD;   // AttnRole::lds_floats
+        const long lds = Hs + PS_M + ((max_tp + 63) & ~63) + max_tp + (long)npart * dw + (long)Tp * PS_KLD +
+                         (greedy ? (long)V * (Hs + dw) + dw + 32 : 0);                                          // AttnRole::lds_floats
         if (Tp <= max_tp && Hs / 4 + split * B <= cus && lds * 4 <= 160 * 1024) return split;
     }
     return 0;
 }
 
-bool speller_persist_eligible(int B, int Tp, int Hs, int D, int M, int V, int L, int heads, int use_mlp) {
+bool speller_persist_eligible(int B, int Tp, int Hs, int D, int M, int V, int L, int heads, int use_mlp, int free_running) {
     if (L != 2 || heads != 1 || !use_mlp || M != PS_M || D != Hs) return false;
     if (Hs != 256 && Hs != 512) return false;
     if (B < 1 || B > 32 || ((V + 15) & ~15) > 256) return false;
-    return persist_split(B, Tp, Hs) != 0;
+    if (free_running && V > 32) return false;                 // the fed-back symbol rows are 32 floats wide
+    return persist_split(B, Tp, Hs, V, free_running != 0) != 0;
 }
 
-template <int HS, int SPLIT>
-static int launch_persist_fwd(const PersistArgs& a, int grid, hipStream_t stream) {
-    const size_t smem = sizeof(float) * (size_t)std::max(CellRole<HS>::LDS_FLOATS, AttnRole<HS, SPLIT>::lds_floats(a.Tp));
+template <int HS, int SPLIT, bool GREEDY>
+static int launch_persist_fwd2(const PersistArgs& a, int grid, hipStream_t stream) {
+    const size_t smem = sizeof(float) * (size_t)std::max(CellRole<HS, GREEDY>::LDS_FLOATS, AttnRole<HS, SPLIT, GREEDY>::lds_floats(a.Tp, a.V, GREEDY));
     LAS_REQUIRE(smem <= 160 * 1024, "persistent speller LDS budget");
-    LAS_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&speller_persist_fwd_kernel<HS, SPLIT>),
+    LAS_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&speller_persist_fwd_kernel<HS, SPLIT, GREEDY>),
                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
-    hipLaunchKernelGGL((speller_persist_fwd_kernel<HS, SPLIT>), dim3(grid), dim3(PS_THREADS), smem, stream, a);
+    hipLaunchKernelGGL((speller_persist_fwd_kernel<HS, SPLIT, GREEDY>), dim3(grid), dim3(PS_THREADS), smem, stream, a);
     LAS_LAUNCH_CHECK();
     return LAS_OK;
 }
+template <int HS, int SPLIT>
+static int launch_persist_fwd(const PersistArgs& a, int grid, hipStream_t stream) {
+    return a.mode != 0 ? launch_persist_fwd2<HS, SPLIT, true>(a, grid, stream) : launch_persist_fwd2<HS, SPLIT, false>(a, grid, stream);
+}
 
 int speller_persist_fwd(const PersistFwd& p, hipStream_t stream) {
-    LAS_REQUIRE(speller_persist_eligible(p.B, p.Tp, p.Hs, p.Hs, PS_M, p.V, 2, 1, 1), "persistent speller shape");
+    LAS_REQUIRE(speller_persist_eligible(p.B, p.Tp, p.Hs, p.Hs, PS_M, p.V, 2, 1, 1, p.mode != 0), "persistent speller shape");
+    LAS_REQUIRE(p.mode >= 0 && p.mode <= 2, "persistent speller mode");
+    LAS_REQUIRE(p.mode == 0 || (p.w_c && p.b_c && p.logp && p.lgx), "free-running decode needs the character distribution");
     PersistArgs a;
+    a.mode = p.mode; a.V = p.V; a.w_c = p.w_c; a.b_c = p.b_c; a.logp = p.logp; a.argmax_out = p.argmax; a.lgx = p.lgx;
     a.w0p = p.w0p; a.ldw0 = p.Vp + p.Hs; a.Vp = p.Vp;
     a.w_hh0 = p.w_hh0; a.w_ih1 = p.w_ih1; a.w_hh1 = p.w_hh1;
     a.b_ih0 = p.b_ih0; a.b_hh0 = p.b_hh0; a.b_ih1 = p.b_ih1; a.b_hh1 = p.b_hh1;
@@ -508,13 +651,14 @@ int speller_persist_fwd(const PersistFwd& p, hipStream_t stream) {
     a.ctx_all = p.ctx_all; a.h_all = p.h_all; a.c_all = p.c_all; a.gates_all = p.gates_all; a.q_all = p.q_all; a.att = p.att;
     a.hx = p.hx;
     a.B = p.B; a.Tp = p.Tp; a.U = p.U; a.relu = p.relu; a.err = p.err;
-    a.split = persist_split(p.B, p.Tp, p.Hs);
+    a.split = persist_split(p.B, p.Tp, p.Hs, p.V, p.mode != 0);
     a.trace = g_persist_trace;
     LAS_REQUIRE(p.err != nullptr, "the persistent speller needs the device error word");
     // sentinel-fill what the phases hand over: every h of both layers and the contexts of steps 1..U
     const size_t sH = (size_t)p.B * p.Hs;
     LAS_HIP_CHECK(hipMemsetAsync(p.hx, 0xFF, sizeof(float) * 2 * p.U * 32 * p.Hs, stream));
     LAS_HIP_CHECK(hipMemsetAsync(p.ctx_all + sH, 0xFF, sizeof(float) * p.U * sH, stream));
+    if (p.mode != 0) LAS_HIP_CHECK(hipMemsetAsync(p.lgx, 0xFF, sizeof(float) * (size_t)p.U * p.B * a.split * 32, stream));
     const int grid = p.Hs / 4 + a.split * p.B;
     if (p.Hs == 512) {
         if (a.split == 2) return launch_persist_fwd<512, 2>(a, grid, stream);

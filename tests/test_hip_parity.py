@@ -357,3 +357,48 @@ def test_direct_gradient_write_matches_autograd_accumulation():
     # split-K GEMMs accumulate with atomics, so two runs agree only to fp32 rounding of the sum order
     assert_close(flats[1], flats[0], "direct vs accumulated flat gradient", rtol=1e-4, atol=1e-6 * float(np.abs(flats[0]).max()))
     _check_err()
+
+
+@pytest.mark.parametrize("cfg_name,B,Tp,U,decode_mode", [("P", 32, 100, 20, 1), ("P", 32, 100, 20, 0), ("S", 7, 150, 9, 1),
+                                                          ("S", 32, 60, 6, 0), ("P", 3, 30, 5, 1)])
+def test_persistent_free_running_decode_matches_stepwise(cfg_name, B, Tp, U, decode_mode):
+    """Greedy (decode_mode 1) and log-prob-feedback (decode_mode 0) decoding inside the one-launch kernel against the
+    per-step launch chain: log-probabilities, attention, arg-max sequences, and (mode 1) the gradients."""
+    import ctypes
+    from las_pytorch_amd import Speller, _cabi, synth
+    from las_pytorch_amd.model import las_model
+    c = synth.CONFIGS[cfg_name]
+    torch.manual_seed(6)
+    sp = Speller(vocab_size=c["V"], hidden_size=c["Hs"], rnn_unit="LSTM", num_layers=c["Ls"], max_label_len=U,
+                 use_mlp_in_attention=True, mlp_dim_in_attention=c["M"], mlp_activate_in_attention="relu",
+                 listener_hidden_size=c["H"], multi_head=1, decode_mode=decode_mode).cuda()
+    feat0 = torch.randn(B, Tp, 2 * c["H"], device="cuda") * 0.5
+    w = torch.randn(U, B, c["V"], device="cuda")
+    L = _cabi.lib()
+    L.las_debug_persist_trace.argtypes = [ctypes.c_void_p]
+    L.las_debug_persist_trace.restype = None
+    trace = torch.zeros(2 * U * 8, dtype=torch.int64, device="cuda")
+    res = []
+    for force in (False, True):
+        las_model.FORCE_GENERIC_RECURRENCE = force
+        L.las_debug_persist_trace(trace.data_ptr() if not force else None)
+        try:
+            sp.zero_grad(set_to_none=True)
+            feat = feat0.clone().requires_grad_(True)
+            preds, att = sp(feat, ground_truth=None, teacher_force_rate=0.0)
+            logp = torch.stack(preds)
+            (logp * w).sum().backward()
+            out = dict(logp=logp.detach().cpu().numpy(), att=torch.stack([a[0] for a in att]).detach().cpu().numpy(),
+                       dfeat=feat.grad.cpu().numpy())
+            out.update({"d" + n: p.grad.cpu().numpy() for n, p in sp.named_parameters() if p.grad is not None})
+            res.append(out)
+        finally:
+            las_model.FORCE_GENERIC_RECURRENCE = False
+            L.las_debug_persist_trace(None)
+    torch.cuda.synchronize()
+    assert int(trace.abs().sum().item()) != 0, "the persistent kernel did not run (shape not eligible?)"
+    assert (res[0]["logp"].argmax(-1) == res[1]["logp"].argmax(-1)).all(), "arg-max sequences differ"
+    for k in res[0]:
+        scale_k = float(np.abs(res[1][k]).max()) + 1e-30
+        assert_close(res[0][k], res[1][k], f"persistent vs stepwise free-running {k}", rtol=1e-3, atol=1e-5 * max(1.0, scale_k))
+    _check_err()
