@@ -301,8 +301,17 @@ __global__ __launch_bounds__(REC_THREADS) void rec_bwd_fast(const float* __restr
     constexpr int LPU = H / 16;
     constexpr int UW = REC_THREADS / LPU;
     constexpr int G = H / UW;
+    // Thread roles besides the mat-vec that every thread does.  The step's dependent chain runs through the H "cell"
+    // threads (dh_t -> dG_t) — everything else is kept off them: other waves poll the foreign dh components, compute the
+    // dh-independent factors of the NEXT step's cell backward (tanh(c), gate derivatives) from the prefetched stash and
+    // leave them in LDS, and write this workgroup's share of dG to memory.
+    constexpr bool SPLIT = 4 * H <= REC_THREADS;          // enough waves for separate roles (H <= 256)
+    constexpr int PB = SPLIT ? H : 0;                     // pollers: threads [H, 2H), or the cell threads themselves
+    constexpr int QB = SPLIT ? 2 * H : 0;                 // factor threads: [2H, 3H), or the cell threads themselves
+    constexpr int SB = SPLIT ? 3 * H : 0;                 // stash writers: [3H, 4H), or the cell threads themselves
     __shared__ __attribute__((aligned(16))) float dhs[2][H];
     __shared__ __attribute__((aligned(16))) float dgs[4 * H];
+    __shared__ float fac[2][7][H];
     __shared__ int xcd_flag;
 
     int group, member;
@@ -326,43 +335,47 @@ __global__ __launch_bounds__(REC_THREADS) void rec_bwd_fast(const float* __restr
     u64* xg = xbuf + (long)group * 2 * H;
 
     for (int i = tid; i < H; i += REC_THREADS) dhs[0][i] = 0.f;
-    __syncthreads();
 
-    const bool pw = tid < H;                             // pointwise role: unit j = tid
-    const int j = tid;
-    const bool mine = pw && (j / UW == member);
+    const bool cellt = tid < H;                          // cell role: unit j = tid
+    const bool fact = tid >= QB && tid < QB + H;         // factor role: unit tid - QB
+    const int jf = fact ? tid - QB : 0;
     float dc = 0.f;
-    // prefetch registers for the first processed step
+    // raw stash values of a coming step (factor threads), fetched one step ahead
     float p_i = 0, p_f = 0, p_g = 0, p_o = 0, p_c = 0, p_cp = 0, p_do = 0;
-    auto load_step = [&](int t) {
-        const float* gp = gb + (long)t * 4 * H + j;
+    auto load_step = [&](int st) {                       // st: step in processing order
+        if (st >= T) return;
+        const int t = dir ? st : T - 1 - st;
+        const float* gp = gb + (long)t * 4 * H + jf;
         p_i = gp[0]; p_f = gp[H]; p_g = gp[2 * H]; p_o = gp[3 * H];
-        p_c = cb[(long)t * H + j];
+        p_c = cb[(long)t * H + jf];
         const int tp = dir ? t + 1 : t - 1;              // previously processed time in the FORWARD pass
-        p_cp = (tp >= 0 && tp < T) ? cb[(long)tp * H + j] : 0.f;
-        p_do = dob[(long)t * 2 * H + j];
+        p_cp = (tp >= 0 && tp < T) ? cb[(long)tp * H + jf] : 0.f;
+        p_do = dob[(long)t * 2 * H + jf];
     };
-    if (pw) load_step(dir ? 0 : T - 1);
+    auto prepare = [&](int par) {                        // factors of the step whose raw values are in p_*
+        const float tc = tanhf_acc(p_c);
+        fac[par][0][jf] = p_o * (1.f - tc * tc);
+        fac[par][1][jf] = p_g * p_i * (1.f - p_i);
+        fac[par][2][jf] = p_cp * p_f * (1.f - p_f);
+        fac[par][3][jf] = p_i * (1.f - p_g * p_g);
+        fac[par][4][jf] = tc * p_o * (1.f - p_o);
+        fac[par][5][jf] = p_f;
+        fac[par][6][jf] = p_do;
+    };
+    if (fact) { load_step(0); prepare(0); load_step(1); }
+    __syncthreads();
 
     int cur = 0;
     for (int step = 0; step < T; ++step) {
         const int t = dir ? step : T - 1 - step;         // reverse of the forward processing order
-        if (pw) {
-            const float ig = p_i, fg = p_f, gg = p_g, og = p_o, c_t = p_c, c_prev = p_cp;
-            const float dh = p_do + dhs[cur][j];
-            if (step + 1 < T) load_step(dir ? t + 1 : t - 1);
-            const float tc = tanhf_acc(c_t);
-            const float dct = dc + dh * og * (1.f - tc * tc);
-            const float dGi = dct * gg * ig * (1.f - ig);
-            const float dGf = dct * c_prev * fg * (1.f - fg);
-            const float dGg = dct * ig * (1.f - gg * gg);
-            const float dGo = dh * tc * og * (1.f - og);
-            dc = dct * fg;
-            dgs[j] = dGi; dgs[H + j] = dGf; dgs[2 * H + j] = dGg; dgs[3 * H + j] = dGo;
-            if (mine) {
-                float* dp = dgb + (long)t * 4 * H + j;
-                dp[0] = dGi; dp[H] = dGf; dp[2 * H] = dGg; dp[3 * H] = dGo;
-            }
+        const int par = step & 1;
+        if (cellt) {
+            const int j = tid;
+            const float dh = fac[par][6][j] + dhs[cur][j];
+            const float dct = dc + dh * fac[par][0][j];
+            dc = dct * fac[par][5][j];
+            dgs[j] = dct * fac[par][1][j]; dgs[H + j] = dct * fac[par][2][j];
+            dgs[2 * H + j] = dct * fac[par][3][j]; dgs[3 * H + j] = dh * fac[par][4][j];
         }
         lds_barrier();
         float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
@@ -382,9 +395,20 @@ __global__ __launch_bounds__(REC_THREADS) void rec_bwd_fast(const float* __restr
             }
             dhs[cur ^ 1][k] = acc;
         }
+        if (fact && step + 1 < T) {                      // next step's factors, then fetch the stash of the step after it
+            prepare(par ^ 1);
+            load_step(step + 2);
+        }
+        if (tid >= SB && tid < SB + H) {                 // this workgroup's dG rows of step t -> memory (off the chain)
+            for (int e = tid - SB; e < 4 * UW; e += H) {
+                const int g = e / UW, j = member * UW + e % UW;
+                dgb[(long)t * 4 * H + g * H + j] = dgs[g * H + j];
+            }
+        }
         if (G > 1) {
-            if (tid < H && tid / UW != member)
-                dhs[cur ^ 1][tid] = poll_granule(xg + (step & 1) * H + tid, (unsigned)step + 1u, err);
+            const int u = tid - PB;
+            if (tid >= PB && u < H && u / UW != member)
+                dhs[cur ^ 1][u] = poll_granule(xg + (step & 1) * H + u, (unsigned)step + 1u, err);
         }
         lds_barrier();
         cur ^= 1;
