@@ -233,6 +233,9 @@ size_t las_speller_reserve_floats(const las_speller_desc* d, int U) { return Spe
 // Profiling aid, deliberately not part of include/las_hip.h: per-phase shader-clock stamps of the persistent decode kernel.
 extern "C" void las_debug_persist_trace(unsigned long long* dev_buf) { speller_persist_set_trace(dev_buf); }
 extern "C" void las_debug_persist_bwd_trace(unsigned long long* dev_buf) { speller_persist_bwd_set_trace(dev_buf); }
+#ifdef LAS_REC_TRACE
+extern "C" void las_debug_rec_trace(unsigned long long* dev_buf) { rec_set_trace(dev_buf); }
+#endif
 
 int las_speller_fwd(const las_speller_desc* d, const float* feat, const float* keys, const int64_t* labels_onehot, int U_lab,
                     int U, int teacher_forced, int decode_mode, float* logp, float* att, int32_t* argmax, float* reserve,

@@ -41,6 +41,9 @@ int pblstm_rec_bwd(const float* dout, const float* gates, const float* cbuf, con
                    int B, int T, int H, unsigned long long* xbuf, unsigned* err, int force_generic,
                    hipStream_t stream);
 size_t rec_xbuf_bytes(int B, int H);
+#ifdef LAS_REC_TRACE
+void rec_set_trace(unsigned long long* dev_buf);    // profiling build only, see tools/ubench_rec_trace.py
+#endif
 int transpose2d(const float* src, float* dst, int rows, int cols, hipStream_t stream);  // dst[c][r] = src[r][c]
 
 // ---- speller.hip -----------------------------------------------------------------------

@@ -24,6 +24,14 @@
 namespace las {
 
 constexpr int REC_THREADS = 1024;
+#ifdef LAS_REC_TRACE
+// Profiling build only (make CXXFLAGS_EXTRA=-DLAS_REC_TRACE): per-phase wall-clock stamps of workgroup 0 of the backward
+// kernel (tools/ubench_rec_trace.py).  Each stamp costs ~0.15 us: read ratios, not absolute times.
+__device__ unsigned long long* g_rec_trace = nullptr;
+#define REC_STAMP(who, step, k) do { if (g_rec_trace && blockIdx.x == 0 && threadIdx.x == (who)) g_rec_trace[(((who) ? 1 : 0) * 4096 + (step)) * 8 + (k)] = wall_clock64(); } while (0)
+#else
+#define REC_STAMP(who, step, k) do { } while (0)
+#endif
 constexpr unsigned SPIN_LIMIT = 1u << 22;
 using u64 = unsigned long long;
 
@@ -369,6 +377,7 @@ __global__ __launch_bounds__(REC_THREADS) void rec_bwd_fast(const float* __restr
     for (int step = 0; step < T; ++step) {
         const int t = dir ? step : T - 1 - step;         // reverse of the forward processing order
         const int par = step & 1;
+        REC_STAMP(0, step, 0); REC_STAMP(512, step, 0);
         if (cellt) {
             const int j = tid;
             const float dh = fac[par][6][j] + dhs[cur][j];
@@ -377,7 +386,9 @@ __global__ __launch_bounds__(REC_THREADS) void rec_bwd_fast(const float* __restr
             dgs[j] = dct * fac[par][1][j]; dgs[H + j] = dct * fac[par][2][j];
             dgs[2 * H + j] = dct * fac[par][3][j]; dgs[3 * H + j] = dh * fac[par][4][j];
         }
+        REC_STAMP(0, step, 1);
         lds_barrier();
+        REC_STAMP(0, step, 2); REC_STAMP(512, step, 2);
         float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
 #pragma unroll
         for (int i = 0; i < 16; ++i) {
@@ -388,6 +399,7 @@ __global__ __launch_bounds__(REC_THREADS) void rec_bwd_fast(const float* __restr
         float acc = (a0 + a1) + (a2 + a3);
         acc = row_sum<(LPU < 16 ? LPU : 16)>(acc);
         if (LPU > 16) acc += __shfl_xor(acc, 16);
+        REC_STAMP(0, step, 3); REC_STAMP(512, step, 3);
         if (rc == 0) {
             if (G > 1) {
                 u64* gp64 = xg + (step & 1) * H + k;
@@ -410,7 +422,9 @@ __global__ __launch_bounds__(REC_THREADS) void rec_bwd_fast(const float* __restr
             if (tid >= PB && u < H && u / UW != member)
                 dhs[cur ^ 1][u] = poll_granule(xg + (step & 1) * H + u, (unsigned)step + 1u, err);
         }
+        REC_STAMP(0, step, 4); REC_STAMP(512, step, 4);
         lds_barrier();
+        REC_STAMP(0, step, 5); REC_STAMP(512, step, 5);
         cur ^= 1;
     }
 }
@@ -547,5 +561,9 @@ int pblstm_rec_bwd(const float* dout, const float* gates, const float* cbuf, con
     LAS_LAUNCH_CHECK();
     return LAS_OK;
 }
+
+#ifdef LAS_REC_TRACE
+void rec_set_trace(unsigned long long* dev_buf) { (void)hipMemcpyToSymbol(HIP_SYMBOL(g_rec_trace), &dev_buf, sizeof(dev_buf)); }
+#endif
 
 }  // namespace las

@@ -21,7 +21,7 @@ n = T // 2
 t = trace.cpu().numpy().reshape(2, 4096, 8)[:, 5:n - 5].astype(np.float64) / 100.0     # microseconds
 a, w = t[0], t[1]
 print(f"backward call {e0.elapsed_time(e1):.3f} ms (with stamps); step period {np.diff(a[:, 0]).mean():.3f} us")
-print("thread 0 (cell+poll wave): cell backward %.3f | barrier wait %.3f | mat-vec + reduce %.3f | publish + poll %.3f | barrier wait %.3f" % (
+print("thread 0   (cell wave):   dh -> dG %.3f | barrier wait %.3f | mat-vec + reduce %.3f | publish %.3f | barrier wait %.3f" % (
     (a[:, 1] - a[:, 0]).mean(), (a[:, 2] - a[:, 1]).mean(), (a[:, 3] - a[:, 2]).mean(), (a[:, 4] - a[:, 3]).mean(), (a[:, 5] - a[:, 4]).mean()))
-print("thread 512 (mat-vec only):  wait for dG %.3f | mat-vec + reduce %.3f | wait for the hand-off %.3f" % (
-    (w[:, 2] - w[:, 0]).mean(), (w[:, 3] - w[:, 2]).mean(), (w[:, 5] - w[:, 3]).mean()))
+print("thread 512 (factor wave): wait for dG %.3f | mat-vec + reduce %.3f | publish + next step's factors + prefetch %.3f | barrier wait %.3f" % (
+    (w[:, 2] - w[:, 0]).mean(), (w[:, 3] - w[:, 2]).mean(), (w[:, 4] - w[:, 3]).mean(), (w[:, 5] - w[:, 4]).mean()))
