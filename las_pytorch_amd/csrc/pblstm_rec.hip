@@ -319,7 +319,7 @@ __global__ __launch_bounds__(REC_THREADS) void rec_bwd_fast(const float* __restr
     constexpr int SB = SPLIT ? 3 * H : 0;                 // stash writers: [3H, 4H), or the cell threads themselves
     __shared__ __attribute__((aligned(16))) float dhs[2][H];
     __shared__ __attribute__((aligned(16))) float dgs[4 * H];
-    __shared__ float fac[2][7][H];
+    __shared__ __attribute__((aligned(16))) float fac[2][H][8];      // per unit: beta, a_i, a_f, a_g | a_o, f, dout, -
     __shared__ int xcd_flag;
 
     int group, member;
@@ -362,13 +362,10 @@ __global__ __launch_bounds__(REC_THREADS) void rec_bwd_fast(const float* __restr
     };
     auto prepare = [&](int par) {                        // factors of the step whose raw values are in p_*
         const float tc = tanhf_acc(p_c);
-        fac[par][0][jf] = p_o * (1.f - tc * tc);
-        fac[par][1][jf] = p_g * p_i * (1.f - p_i);
-        fac[par][2][jf] = p_cp * p_f * (1.f - p_f);
-        fac[par][3][jf] = p_i * (1.f - p_g * p_g);
-        fac[par][4][jf] = tc * p_o * (1.f - p_o);
-        fac[par][5][jf] = p_f;
-        fac[par][6][jf] = p_do;
+        const f32x4 lo = {p_o * (1.f - tc * tc), p_g * p_i * (1.f - p_i), p_cp * p_f * (1.f - p_f), p_i * (1.f - p_g * p_g)};
+        const f32x4 hi = {tc * p_o * (1.f - p_o), p_f, p_do, 0.f};
+        *reinterpret_cast<f32x4*>(&fac[par][jf][0]) = lo;
+        *reinterpret_cast<f32x4*>(&fac[par][jf][4]) = hi;
     };
     if (fact) { load_step(0); prepare(0); load_step(1); }
     __syncthreads();
@@ -380,11 +377,13 @@ __global__ __launch_bounds__(REC_THREADS) void rec_bwd_fast(const float* __restr
         REC_STAMP(0, step, 0); REC_STAMP(512, step, 0);
         if (cellt) {
             const int j = tid;
-            const float dh = fac[par][6][j] + dhs[cur][j];
-            const float dct = dc + dh * fac[par][0][j];
-            dc = dct * fac[par][5][j];
-            dgs[j] = dct * fac[par][1][j]; dgs[H + j] = dct * fac[par][2][j];
-            dgs[2 * H + j] = dct * fac[par][3][j]; dgs[3 * H + j] = dh * fac[par][4][j];
+            const f32x4 lo = *reinterpret_cast<const f32x4*>(&fac[par][j][0]);
+            const f32x4 hi = *reinterpret_cast<const f32x4*>(&fac[par][j][4]);
+            const float dh = hi[2] + dhs[cur][j];
+            const float dct = dc + dh * lo[0];
+            dc = dct * hi[1];
+            dgs[j] = dct * lo[1]; dgs[H + j] = dct * lo[2];
+            dgs[2 * H + j] = dct * lo[3]; dgs[3 * H + j] = dh * hi[0];
         }
         REC_STAMP(0, step, 1);
         lds_barrier();
