@@ -13,6 +13,7 @@
 // Either operand may be K-contiguous or M/N-contiguous (all four transposition cases of the backward pass).
 #include "las_common.h"
 #include "las_kernels.h"
+#include <stdlib.h>
 
 namespace las {
 
@@ -229,8 +230,9 @@ int gemm_f32(const GemmDesc& d, hipStream_t stream) {
         // auto: few output tiles and a long K -> split K so the launch covers the chip (256 CUs)
         const long tiles = (long)gx * gy * batch;
         if (!d.relu && tiles < 128 && d.K >= 256) {
-            // few output tiles, long K: one workgroup per CU with at least 4 k-tiles (64 k) each
-            splitk = (int)min((long)cdiv(d.K, 4 * BK), max(1L, 256 / tiles));
+            // few output tiles, long K: about two workgroups per CU (they hide each other's barrier stalls) with at least 4 k-tiles each
+            static const long target = getenv("LAS_GEMM_SPLIT_TARGET") ? atol(getenv("LAS_GEMM_SPLIT_TARGET")) : 512;   // ~2 workgroups per CU: measured best
+            splitk = (int)min((long)cdiv(d.K, 4 * BK), max(1L, target / tiles));
         }
     }
     int kper = cdiv(cdiv(d.K, splitk), BK) * BK;
