@@ -15,7 +15,13 @@
  *     message.  Never throws, never exits.
  *   - `err_word` is a caller-owned, zero-initialised device uint32: kernels that hand data between
  *     workgroups write a nonzero code there if a bounded spin expires (results are then invalid).
- *   - Re-entrant per device; no global mutable state.
+ *   - Re-entrant per device; no global mutable state (the undeclared las_debug_* profiling hooks aside).
+ *   - The persistent kernels (Listener recurrences; the one-launch Speller decode loop, chosen automatically for
+ *     2-layer single-head MLP-attention spellers with Hs in {256,512}, B <= 32) need every workgroup resident at
+ *     once, up to all compute units of the device: do not run other kernels concurrently on other streams while a
+ *     las_pblstm_* / las_speller_* call is in flight.  If the device exposes too few compute units the library
+ *     falls back to the per-step kernels by itself; a violated assumption ends in a bounded-spin timeout reported
+ *     through `err_word`, never in a hang.
  */
 #ifndef LAS_HIP_H
 #define LAS_HIP_H
