@@ -507,12 +507,10 @@ int pblstm_rec_fwd(float* gates, const float* w_hh_f, const float* w_hh_r, float
         LAS_REQUIRE(xbuf && err, "hand-off buffers");
         // LAS_REC_AGENT_HANDOFF=1 forces the placement-independent agent-scope hand-off even when a group shares an XCD (A/B tests)
         static int dbg = getenv("LAS_REC_AGENT_HANDOFF") ? atoi(getenv("LAS_REC_AGENT_HANDOFF")) : 0;
-        static int nb_env = getenv("LAS_REC_NB") ? atoi(getenv("LAS_REC_NB")) : 0;
         static int uw_env = getenv("LAS_REC_UW") ? atoi(getenv("LAS_REC_UW")) : 0;
         // UW: hidden units per workgroup.  Smaller UW = more CUs per sequence; two half-size workgroups per CU
         // (UW=32 at H=256) let the hardware overlap one group's hand-off wait with the other's compute.
         int uw = uw_env > 0 ? uw_env : (H == 128 ? 128 : (H == 256 ? 64 : 32));   // measured best on MI355X at B=32
-        (void)nb_env;
         LAS_HIP_CHECK(hipMemsetAsync(xbuf, 0, rec_xbuf_bytes(B, H), stream));
         const int G = H / uw;
         dim3 grid(2 * B * G), block(uw * (H / 16));

@@ -64,7 +64,7 @@ struct CellRole {
 
     // x tile of this wave: rows = utterances (two 16-row M-tiles), columns = its k-blocks.
     // KIND 0: tile of h (each 4-column group comes from one cell workgroup); KIND 1: tile of the context (each row part
-    // comes from one attention workgroup); KIND 2: data known to be published long ago (no canary).
+    // comes from one attention workgroup).
     //  1. canary (wg_canary_wait): the first wave(s) watch one agent-scope dword per producer workgroup;
     //  2. the tile itself with PLAIN loads: the 16 cell workgroups of an XCD share them through its L2 instead of each
     //     pulling 64 KB over the fabric (agent-scope loads bypass the L2: 8.4 MB per phase, measured ~3.5 us);
@@ -113,7 +113,7 @@ struct CellRole {
                                                    unsigned* err, volatile unsigned* flags, unsigned& ep) {
         unsigned spins = 0;
         int slow = 0;
-        if (KIND != 2) {
+        {
             constexpr int K = KIND == 0 ? 0 : 1;
             const int npw = KIND == 0 ? (HS / 4 + 63) / 64 : t.npw1;      // canary waves: one lane per producer workgroup
             const unsigned* cp = reinterpret_cast<const unsigned*>(at_bytes(base, opaque(t.canary[K])));

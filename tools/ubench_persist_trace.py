@@ -35,5 +35,4 @@ print("attn wg0:  wait h1 %.2f | (barrier) %.2f.. phi %.2f | energies %.2f | sof
 print("chain:     h1 published(cell stamp5) -> ctx published(attn stamp5): %.2f ; ctx published -> cell has ctx (stamp1 next step): %.2f ; step period %.2f" % (
     us(at[:, 5] - cl[:, 5]), us(cl[1:, 1] - at[:-1, 5]), us(cl[1:, 1] - cl[:-1, 1])))
 print("slow-path (agent-scope re-read) rounds of cell wg0 wave0 over %d steps: h0 tiles %d, ctx tiles %d, h1 tiles %d" % (U, t[1, 0, 7], t[1, 1, 7], t[1, 2, 7]))
-print("finish detail (cell wg0): layer0 wait-for-slowest-wave %.2f + cell %.2f | layer1 wait %.2f + cell %.2f" % (
-    us(at[:, 7] - cl[:, 1]), us(cl[:, 2] - at[:, 7]), us(at[:, 6] - cl[:, 4]), us(cl[:, 5] - at[:, 6])))
+print("finish detail (cell wg0): layer1 wait-for-slowest-wave %.2f + cell %.2f" % (us(at[:, 6] - cl[:, 4]), us(cl[:, 5] - at[:, 6])))
