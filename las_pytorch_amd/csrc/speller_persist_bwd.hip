@@ -7,18 +7,21 @@
 // weight gradient / dfeat / dK contraction (GEMMs after the loop over the per-step gradients this kernel stashes).
 //
 // Per step s (descending) the dependent chain is
-//     A: attention backward of utterance b         -> decoder-state gradient part (two workgroups per utterance,
-//                                                     each owning half of the T' frames; the softmax-backward
-//                                                     statistic sum_t a_t da_t equals ctx_s . dctx, so the halves
-//                                                     never talk to each other)
+//     A: attention backward of utterance b         -> decoder-state gradient part (ns = 2, 4 or 8 workgroups per
+//                                                     utterance, each owning a slice of the T' frames; the softmax-
+//                                                     backward statistic sum_t a_t da_t equals ctx_s . dctx, so the
+//                                                     slices never talk to each other)
 //     Y: top-layer cell backward (pointwise)       -> dG1_s
 //     X: dh0 = dG1_s W_ih1 (MFMA), bottom-layer cell backward -> dG0_s
 //     Y: dctx = dG0_s W_ctx (MFMA)                 -> context gradient carried to step s-1's attention backward
-// and, off that chain, the recurrent carries dG1_s W_hh1 (Y) and dG0_s W_hh0 (X) for step s-1.
-// X and Y workgroups own 16 hidden units x 16 utterances (one 16x16 MFMA tile of every product) and keep their columns
-// of two weight matrices in VGPRs (64 floats per lane) for the whole launch; cell-state gradients never leave them.
+// and, off that chain, the recurrent carries dG0_s W_hh0 (X itself, W_hh0 in LDS) and dG1_s W_hh1 (a fourth role R that
+// starts once X has consumed dG1_s and hands its tile to Y) for step s-1.
+// X, Y and R workgroups own 16 hidden units x 16 utterances (one 16x16 MFMA tile, K = 4Hs split over the 16 waves) and
+// keep the columns of ONE weight matrix in VGPRs (32 floats per lane at Hs=512) for the whole launch — two resident
+// matrices spilled; cell-state gradients never leave them.
 // Hand-off uses the protocol of speller_persist.hip (persist_common.h): sentinel-prefilled per-step slabs, agent-scope
-// producers writing whole cache lines, a one-dword-per-producer canary and L2-shared plain loads for the big tiles.
+// producers writing whole cache lines, one canary wave per consumer workgroup watching one dword per producer
+// workgroup, L2-shared plain loads for the big tiles with the MFMA product started while they land.
 #include "las_common.h"
 #include "las_kernels.h"
 #include "persist_common.h"
