@@ -344,7 +344,7 @@ struct AttnBwdRole {
     static constexpr int RP = 512 / HS;                     // frames per lane group
     static constexpr int TH = 64 * RP;                      // frames per workgroup
     static constexpr int NMH = PS_THREADS / HS, MPT = PS_M / NMH;   // dh = W_phi^T dqpre: (column, m-slice) per thread
-    static __host__ __device__ constexpr int lds_floats() { return 2 * HS + PS_M + TH + 16 * PS_M + PS_M + NMH * HS + TH * PS_KLD; }
+    static __host__ __device__ constexpr int lds_floats() { return 3 * HS + PS_M + TH + PS_M + TH * PS_KLD; }
 
     static __device__ void run(const PersistBwdArgs& a, float* smem, const int widx) {
         const int ns = a.ns;
@@ -357,10 +357,9 @@ struct AttnBwdRole {
         float* ctxs = dctx + HS;
         float* qs = ctxs + HS;
         float* de = qs + PS_M;
-        float* dqp = de + TH;
-        float* dqpre = dqp + 16 * PS_M;
-        float* dhp = dqpre + PS_M;
-        float* ks = dhp + NMH * HS;
+        float* dqpre = de + TH;
+        float* dhl = dqpre + PS_M;
+        float* ks = dhl + HS;
         const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
 
         // ---- resident operands: listener features of its frames (registers), keys (LDS), W_phi columns (registers)
@@ -379,7 +378,7 @@ struct AttnBwdRole {
             const int t = idx / (PS_M / 4), m4 = idx % (PS_M / 4);
             *reinterpret_cast<f32x4*>(ks + t * PS_KLD + m4 * 4) = ld4p(a.keys + ((size_t)b * Tp + t0 + t) * PS_M + m4 * 4);
         }
-        const int pc = tid % HS, pmh = tid / HS;
+        const int pmh = tid % NMH, pc = tid / NMH;        // the NMH lanes of a column are adjacent: DPP sum, no LDS
         float wph[MPT];
 #pragma unroll
         for (int i = 0; i < MPT; ++i) wph[i] = a.w_phi[(size_t)(pmh * MPT + i) * HS + pc];
@@ -444,40 +443,34 @@ struct AttnBwdRole {
             }
             lds_barrier();
             PB_STAMP(2, s, 2);
-            // ---- dq[m] = sum_t de_t keys[t][m] over this half's frames
+            // ---- dq[m] = sum_t de_t keys[t][m] over this slice's frames: 16 adjacent lanes per m, DPP row sum
             {
-                const int m = tid & 63, tg = tid >> 6;
+                const int m = tid >> 4, tg = tid & 15;
                 float acc = 0.f;
                 for (int t = tg; t < nt; t += 16) acc = fmaf(de[t], ks[t * PS_KLD + m], acc);
-                dqp[tg * PS_M + m] = acc;
-            }
-            lds_barrier();
-            if (tid < PS_M) {
-                float v = 0.f;
-#pragma unroll
-                for (int g = 0; g < 16; ++g) v += dqp[g * PS_M + tid];
-                if (a.relu && !(qs[tid] > 0.f)) v = 0.f;
-                dqpre[tid] = v;
-                a.dqpre_part[(((size_t)half * U + s) * B + b) * PS_M + tid] = v;
+                acc = gsum<16>(acc);
+                if (tg == 0) {
+                    if (a.relu && !(qs[m] > 0.f)) acc = 0.f;
+                    dqpre[m] = acc;
+                    a.dqpre_part[(((size_t)half * U + s) * B + b) * PS_M + m] = acc;
+                }
             }
             lds_barrier();
             PB_STAMP(2, s, 3);
-            // ---- decoder-state gradient part: W_phi^T dqpre
+            // ---- decoder-state gradient part W_phi^T dqpre: NMH adjacent lanes per column, published straight from registers
             {
                 float acc = 0.f;
 #pragma unroll
                 for (int i = 0; i < MPT; ++i) acc = fmaf(wph[i], dqpre[pmh * MPT + i], acc);
-                dhp[pmh * HS + pc] = acc;
-            }
-            lds_barrier();
-            if (tid < HS / 4) {
-                f32x4 v = zero;
-#pragma unroll
-                for (int q = 0; q < NMH; ++q) {
-                    const f32x4 w = *reinterpret_cast<const f32x4*>(dhp + q * HS + tid * 4);
-                    v[0] += w[0]; v[1] += w[1]; v[2] += w[2]; v[3] += w[3];
+                acc = gsum<NMH>(acc);
+                if (NMH == 2) {          // a wave's 32 columns are one whole 128-byte line
+                    if (pmh == 0) st1_agent(a.dhA + (((size_t)s * B + b) * ns + half) * HS + pc, acc);
+                } else {                 // gather through LDS so that the publication still moves whole lines
+                    if (pmh == 0) dhl[pc] = acc;
+                    lds_barrier();
+                    if (tid < HS / 4)
+                        st4_agent(a.dhA + (((size_t)s * B + b) * ns + half) * HS + tid * 4, *reinterpret_cast<const f32x4*>(dhl + tid * 4));
                 }
-                st4_agent(a.dhA + (((size_t)s * B + b) * ns + half) * HS + tid * 4, v);
             }
             PB_STAMP(2, s, 4);
         }
