@@ -143,9 +143,12 @@ struct ProdRole {
         return acc;
     }
     // sum the 16 waves' partial 16x16 tiles; the result for (utterance m, unit n) lands in thread m*16+n (< 256)
+    // ENTRY: the buffer is reused by consecutive calls, so a barrier must first retire the previous call's readers (X role,
+    // whose LDS is taken by W_hh0); Y and R alternate between two buffers instead and need only the one barrier.
+    template <bool ENTRY>
     static __device__ __forceinline__ float reduce_tile(float* red, const f32x4 acc, int wave, int lane, int tid) {
         const int r = lane & 15, kq = lane >> 4;
-        lds_barrier();                                   // the previous reduction's readers are done with the buffer
+        if (ENTRY) lds_barrier();
 #pragma unroll
         for (int i = 0; i < 4; ++i) red[(wave * 16 + kq * 4 + i) * 17 + r] = acc[i];
         lds_barrier();
@@ -256,7 +259,7 @@ struct ProdRole {
                 }
                 const f32x4 accr = poll_mul(dG1x + (size_t)s * GXS, la, x, a.err, cflags, cep, mul_reg);
                 PB_STAMP(3, s, 1);
-                const float v = reduce_tile(red, accr, wave, lane, tid);
+                const float v = reduce_tile<false>(red + (s & 1) * RED, accr, wave, lane, tid);
                 if (pw) st1_agent(at_bytes(a.dhc + (size_t)s * CXS, opaque(oc)), v);
                 PB_STAMP(3, s, 2);
                 continue;
@@ -299,7 +302,7 @@ struct ProdRole {
                 PB_STAMP(1, s, 3);
                 const f32x4 accy = poll_mul(dG0x + (size_t)s * GXS, la, x, a.err, cflags, cep, mul_reg);
                 PB_STAMP(1, s, 4);
-                const float dctx = reduce_tile(red, accy, wave, lane, tid);
+                const float dctx = reduce_tile<false>(red + (s & 1) * RED, accy, wave, lane, tid);
                 if (pw) {
                     st1_agent(at_bytes(a.dcx + (size_t)s * CXS, opaque(oc)), dctx);
                     if (s == 0) a.dx0[(size_t)pb * a.ldx0 + a.V + 16 * j + pu] = dctx;
@@ -312,7 +315,7 @@ struct ProdRole {
                 if (a.trace && first_wg && tid == 0) { asm volatile("s_nop 0" :: "v"(accx[0])); }
                 PB_STAMP(0, s, 1);
                 PB_STAMP(0, s, 6);
-                const float dh0 = reduce_tile(red, accx, wave, lane, tid);
+                const float dh0 = reduce_tile<true>(red, accx, wave, lane, tid);
                 PB_STAMP(0, s, 7);
                 if (pw) {
                     const f32x4 g = cell_bwd(ci, dh0 + dh_carry, dc);
@@ -328,7 +331,7 @@ struct ProdRole {
                         while (__hip_atomic_load(cp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == PS_SENT)
                             if (spin_expired(spins, a.err, 0xDEAD0025u)) break;
                     }
-                    dh_carry = reduce_tile(red, poll_mul(dG0x + (size_t)s * GXS, la, x, a.err, cflags, cep, mfma_lds), wave, lane, tid);
+                    dh_carry = reduce_tile<true>(red, poll_mul(dG0x + (size_t)s * GXS, la, x, a.err, cflags, cep, mfma_lds), wave, lane, tid);
                 }
                 PB_STAMP(0, s, 3);
             }
