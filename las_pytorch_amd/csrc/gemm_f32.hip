@@ -246,7 +246,7 @@ int gemm_f32(const GemmDesc& d, hipStream_t stream) {
     };
     p.a_vec = aligned(d.A, d.lda, d.sA);
     p.b_vec = aligned(d.B, d.ldb, d.sB);
-    if (p.atomic && !d.accumulate) {
+    if (p.atomic && !d.accumulate && !d.c_zeroed) {
         // split-K partials are summed with atomics: C must start from zero
         if (d.ldc == d.N) {
             LAS_HIP_CHECK(hipMemsetAsync(d.C, 0, sizeof(float) * ((size_t)(batch - 1) * d.sC + (size_t)d.M * d.N), stream));

@@ -4,6 +4,9 @@
 #include "las_common.h"
 #include "las_kernels.h"
 #include <algorithm>
+#include <utility>
+#include <vector>
+#include <algorithm>
 
 using namespace las;
 
@@ -81,6 +84,20 @@ struct SpellerBwdLayout {
         total = o;
     }
 };
+
+// Gradient outputs that lie back to back in memory (the views of one flat gradient buffer, las_pytorch_amd/dp.py) are zeroed
+// with ONE memset; the split-K GEMMs and column sums that fill them then skip theirs (a launch-bound ~5 us each).
+// Returns false (and does nothing) when the outputs are separate allocations.
+static bool zero_if_contiguous(std::vector<std::pair<float*, size_t>> outs, hipStream_t stream) {
+    std::sort(outs.begin(), outs.end(), [](const std::pair<float*, size_t>& a, const std::pair<float*, size_t>& b) { return a.first < b.first; });
+    size_t total = 0;
+    for (size_t i = 0; i < outs.size(); ++i) {
+        if (outs[i].first == nullptr) return false;
+        if (i + 1 < outs.size() && outs[i].first + outs[i].second != outs[i + 1].first) return false;
+        total += outs[i].second;
+    }
+    return hipMemsetAsync(outs[0].first, 0, sizeof(float) * total, stream) == hipSuccess;
+}
 
 int check_desc(const las_speller_desc* d) {
     LAS_REQUIRE(d != nullptr, "descriptor");
@@ -170,6 +187,9 @@ int las_pblstm_bwd(const float* x, const float* dout, int B, int T_in, int D_in,
     LAS_TRY(pblstm_rec_bwd(dout, gates, cbuf, wt, dgates, B, T, H, (unsigned long long*)(workspace + wl.xbuf), err_word,
                            flags & LAS_FLAG_FORCE_GENERIC, stream));
     const int BT = B * T;
+    const size_t n_ih = (size_t)4 * H * D, n_hh = (size_t)4 * H * H, n_b = (size_t)4 * H;
+    const bool zg = zero_if_contiguous({{dw_ih_f, n_ih}, {dw_hh_f, n_hh}, {db_ih_f, n_b}, {db_hh_f, n_b},
+                                        {dw_ih_r, n_ih}, {dw_hh_r, n_hh}, {db_ih_r, n_b}, {db_hh_r, n_b}}, stream);
     for (int dir = 0; dir < 2; ++dir) {
         const float* dG = dgates + (size_t)dir * BT * 4 * H;
         const float* hp = hprev + (size_t)dir * BT * H;
@@ -181,18 +201,17 @@ int las_pblstm_bwd(const float* x, const float* dout, int B, int T_in, int D_in,
             GemmDesc g;
             g.A = dG; g.lda = 4 * H; g.a_kc = false;
             g.B = x; g.ldb = D; g.b_kc = false;
-            g.C = dw_ih; g.ldc = D; g.M = 4 * H; g.N = D; g.K = BT;
+            g.C = dw_ih; g.ldc = D; g.M = 4 * H; g.N = D; g.K = BT; g.c_zeroed = zg;
             LAS_TRY(gemm_f32(g, stream));
         }
         {   // dW_hh = dG^T H_prev
             GemmDesc g;
             g.A = dG; g.lda = 4 * H; g.a_kc = false;
             g.B = hp; g.ldb = H; g.b_kc = false;
-            g.C = dw_hh; g.ldc = H; g.M = 4 * H; g.N = H; g.K = BT;
+            g.C = dw_hh; g.ldc = H; g.M = 4 * H; g.N = H; g.K = BT; g.c_zeroed = zg;
             LAS_TRY(gemm_f32(g, stream));
         }
-        LAS_TRY(colsum(dG, 4 * H, BT, 4 * H, db_ih, 0, stream));
-        LAS_HIP_CHECK(hipMemcpyAsync(db_hh, db_ih, sizeof(float) * 4 * H, hipMemcpyDeviceToDevice, stream));
+        LAS_TRY(colsum(dG, 4 * H, BT, 4 * H, db_ih, zg, stream, db_hh));
         if (dx) {   // dX (+)= dG W_ih
             GemmDesc g;
             g.A = dG; g.lda = 4 * H; g.a_kc = true;
@@ -537,6 +556,23 @@ int las_speller_bwd(const las_speller_desc* d, const float* feat, const float* k
 
     // ---- deferred (loop-invariant-shaped) contractions, all MFMA GEMMs -------------------------
     const int UB = U * B;
+    bool zg;
+    {
+        std::vector<std::pair<float*, size_t>> outs;
+        for (int l = 0; l < L; ++l) {
+            outs.push_back({g->dw_ih[l], (size_t)4 * Hs * (l == 0 ? V + Hs : Hs)});
+            outs.push_back({g->dw_hh[l], (size_t)4 * Hs * Hs});
+            outs.push_back({g->db_ih[l], (size_t)4 * Hs});
+            outs.push_back({g->db_hh[l], (size_t)4 * Hs});
+        }
+        if (d->use_mlp) {
+            outs.push_back({g->dw_phi, (size_t)M * NH * Hs}); outs.push_back({g->db_phi, (size_t)M * NH});
+            outs.push_back({g->dw_psi, (size_t)M * D}); outs.push_back({g->db_psi, (size_t)M});
+        }
+        if (NH > 1) { outs.push_back({g->dw_dr, (size_t)D * NH * D}); outs.push_back({g->db_dr, (size_t)D}); }
+        outs.push_back({g->dw_c, (size_t)V * (Hs + D)}); outs.push_back({g->db_c, (size_t)V});
+        zg = zero_if_contiguous(outs, stream);
+    }
     for (int hd = 0; hd < NH; ++hd) {   // dfeat[b] (+)= att_h[:,b,:]^T dctx_h[:,b,:]   (context path, las_model.py:293-297,307-313)
         GemmDesc q;
         q.A = att + (size_t)hd * B * Tp; q.lda = (long)NH * B * Tp; q.a_kc = false; q.sA = Tp;
@@ -561,9 +597,9 @@ int las_speller_bwd(const las_speller_desc* d, const float* feat, const float* k
     if (NH > 1) {   // dim_reduce gradients: dW_dr = dctx^T ctxcat, db_dr = sum dctx
         GemmDesc q;
         q.A = dctx_all; q.lda = D; q.a_kc = false; q.B = ctxcat_all; q.ldb = (long)NH * D; q.b_kc = false;
-        q.C = g->dw_dr; q.ldc = (long)NH * D; q.M = D; q.N = NH * D; q.K = U * B;
+        q.C = g->dw_dr; q.ldc = (long)NH * D; q.M = D; q.N = NH * D; q.K = U * B; q.c_zeroed = zg;
         LAS_TRY(gemm_f32(q, stream));
-        LAS_TRY(colsum(dctx_all, D, U * B, D, g->db_dr, 0, stream));
+        LAS_TRY(colsum(dctx_all, D, U * B, D, g->db_dr, zg, stream));
     }
     if (d->use_mlp) {
         const int BT = B * Tp;
@@ -571,10 +607,10 @@ int las_speller_bwd(const las_speller_desc* d, const float* feat, const float* k
         {   // dW_psi = dKpre^T feat
             GemmDesc q;
             q.A = dK; q.lda = M; q.a_kc = false; q.B = feat; q.ldb = D; q.b_kc = false;
-            q.C = g->dw_psi; q.ldc = D; q.M = M; q.N = D; q.K = BT;
+            q.C = g->dw_psi; q.ldc = D; q.M = M; q.N = D; q.K = BT; q.c_zeroed = zg;
             LAS_TRY(gemm_f32(q, stream));
         }
-        LAS_TRY(colsum(dK, M, BT, M, g->db_psi, 0, stream));
+        LAS_TRY(colsum(dK, M, BT, M, g->db_psi, zg, stream));
         {   // dfeat += dKpre W_psi
             GemmDesc q;
             q.A = dK; q.lda = M; q.a_kc = true; q.B = d->w_psi; q.ldb = D; q.b_kc = false;
@@ -584,24 +620,24 @@ int las_speller_bwd(const las_speller_desc* d, const float* feat, const float* k
         {   // dW_phi = dqpre^T h_top
             GemmDesc q;
             q.A = dqpre_all; q.lda = (long)M * NH; q.a_kc = false; q.B = h_top_all; q.ldb = Hs; q.b_kc = false;
-            q.C = g->dw_phi; q.ldc = Hs; q.M = M * NH; q.N = Hs; q.K = UB;
+            q.C = g->dw_phi; q.ldc = Hs; q.M = M * NH; q.N = Hs; q.K = UB; q.c_zeroed = zg;
             LAS_TRY(gemm_f32(q, stream));
         }
-        LAS_TRY(colsum(dqpre_all, (long)M * NH, UB, M * NH, g->db_phi, 0, stream));
+        LAS_TRY(colsum(dqpre_all, (long)M * NH, UB, M * NH, g->db_phi, zg, stream));
     }
     {   // dW_c = dz^T [h_top | ctx]
         GemmDesc q;
         q.A = dz_all; q.lda = V; q.a_kc = false; q.B = h_top_all; q.ldb = Hs; q.b_kc = false;
-        q.C = g->dw_c; q.ldc = Hs + D; q.M = V; q.N = Hs; q.K = UB;
+        q.C = g->dw_c; q.ldc = Hs + D; q.M = V; q.N = Hs; q.K = UB; q.c_zeroed = zg;
         LAS_TRY(gemm_f32(q, stream));
         q.B = ctx_all + (size_t)B * D; q.ldb = D; q.C = g->dw_c + Hs; q.N = D;
         LAS_TRY(gemm_f32(q, stream));
-        LAS_TRY(colsum(dz_all, V, UB, V, g->db_c, 0, stream));
+        LAS_TRY(colsum(dz_all, V, UB, V, g->db_c, zg, stream));
     }
     for (int l = 0; l < L; ++l) {
         const float* dGl = dG_all + (size_t)l * U * 4 * sH;
         GemmDesc q;
-        q.A = dGl; q.lda = 4 * Hs; q.a_kc = false; q.b_kc = false; q.M = 4 * Hs; q.K = UB;
+        q.A = dGl; q.lda = 4 * Hs; q.a_kc = false; q.b_kc = false; q.M = 4 * Hs; q.K = UB; q.c_zeroed = zg;
         if (l == 0) {
             q.B = y_all; q.ldb = lay.Vp; q.C = g->dw_ih[0]; q.ldc = V + Hs; q.N = V;
             LAS_TRY(gemm_f32(q, stream));
@@ -615,13 +651,12 @@ int las_speller_bwd(const las_speller_desc* d, const float* feat, const float* k
             GemmDesc r;
             r.A = dGl + 4 * sH; r.lda = 4 * Hs; r.a_kc = false;
             r.B = h_all + (size_t)l * U * sH; r.ldb = Hs; r.b_kc = false;
-            r.C = g->dw_hh[l]; r.ldc = Hs; r.M = 4 * Hs; r.N = Hs; r.K = (U - 1) * B;
+            r.C = g->dw_hh[l]; r.ldc = Hs; r.M = 4 * Hs; r.N = Hs; r.K = (U - 1) * B; r.c_zeroed = zg;
             LAS_TRY(gemm_f32(r, stream));
-        } else {
+        } else if (!zg) {
             LAS_HIP_CHECK(hipMemsetAsync(g->dw_hh[l], 0, sizeof(float) * 4 * Hs * Hs, stream));
         }
-        LAS_TRY(colsum(dGl, 4 * Hs, UB, 4 * Hs, g->db_ih[l], 0, stream));
-        LAS_HIP_CHECK(hipMemcpyAsync(g->db_hh[l], g->db_ih[l], sizeof(float) * 4 * Hs, hipMemcpyDeviceToDevice, stream));
+        LAS_TRY(colsum(dGl, 4 * Hs, UB, 4 * Hs, g->db_ih[l], zg, stream, g->db_hh[l]));
     }
     return LAS_OK;
 }

@@ -19,6 +19,7 @@ struct GemmDesc {
     long sBias0 = 0, sBias1 = 0;   // batch strides of the biases (elements; may be a pointer difference between two tensors)
     int splitk = 0;                // 0 = auto, 1 = none, >1 = forced (atomic accumulation)
     bool accumulate = false;       // C += ...
+    bool c_zeroed = false;         // the caller has already zeroed C (split-K then skips its own memset)
     bool relu = false;
 };
 int gemm_f32(const GemmDesc& d, hipStream_t stream);
@@ -165,7 +166,8 @@ struct AttnBwdArgs {
 int attn_step_bwd(const AttnBwdArgs& a, hipStream_t stream);
 
 // ---- misc.hip --------------------------------------------------------------------------
-int colsum(const float* src, long ld, int rows, int cols, float* dst, int accumulate, hipStream_t stream);  // dst[c] (+)= sum_r src[r][c]
+int colsum(const float* src, long ld, int rows, int cols, float* dst, int accumulate, hipStream_t stream,
+           float* dst2 = nullptr);  // dst[c] (+)= sum_r src[r][c]; dst2 (optional) receives the same sums
 int relu_mask_inplace(float* grad, const float* act, long n, hipStream_t stream);                           // grad = act>0 ? grad : 0
 int add_inplace(float* dst, const float* src, long n, hipStream_t stream);
 int relu_inplace(float* x, long n, hipStream_t stream);

@@ -9,7 +9,7 @@ thread_local char g_err[512] = {0};
 // dst[c] (+)= sum_r src[r][c]: a workgroup covers 64 columns x a slab of rows; 4 row-lanes per column accumulate
 // with 4 independent loads in flight each, LDS-combine, one atomic per column per workgroup
 __global__ __launch_bounds__(256) void colsum_kernel(const float* __restrict__ src, long ld, int rows, int cols,
-                                                     float* __restrict__ dst, int rows_per_block) {
+                                                     float* __restrict__ dst, float* __restrict__ dst2, int rows_per_block) {
     __shared__ float part[4][64];
     const int cl = threadIdx.x & 63, rl = threadIdx.x >> 6;
     const int c = blockIdx.x * 64 + cl;
@@ -25,14 +25,21 @@ __global__ __launch_bounds__(256) void colsum_kernel(const float* __restrict__ s
     }
     part[rl][cl] = (a0 + a1) + (a2 + a3);
     __syncthreads();
-    if (rl == 0 && c < cols) atomicAdd(dst + c, (part[0][cl] + part[1][cl]) + (part[2][cl] + part[3][cl]));
+    if (rl == 0 && c < cols) {
+        const float v = (part[0][cl] + part[1][cl]) + (part[2][cl] + part[3][cl]);
+        atomicAdd(dst + c, v);
+        if (dst2) atomicAdd(dst2 + c, v);           // b_ih and b_hh of an LSTM receive the same gradient
+    }
 }
 
-int colsum(const float* src, long ld, int rows, int cols, float* dst, int accumulate, hipStream_t stream) {
-    if (!accumulate) LAS_HIP_CHECK(hipMemsetAsync(dst, 0, sizeof(float) * cols, stream));
+int colsum(const float* src, long ld, int rows, int cols, float* dst, int accumulate, hipStream_t stream, float* dst2) {
+    if (!accumulate) {
+        LAS_HIP_CHECK(hipMemsetAsync(dst, 0, sizeof(float) * cols, stream));
+        if (dst2) LAS_HIP_CHECK(hipMemsetAsync(dst2, 0, sizeof(float) * cols, stream));
+    }
     const int rpb = 256;
     dim3 grid(cdiv(cols, 64), cdiv(rows, rpb)), block(256);
-    hipLaunchKernelGGL(colsum_kernel, grid, block, 0, stream, src, ld, rows, cols, dst, rpb);
+    hipLaunchKernelGGL(colsum_kernel, grid, block, 0, stream, src, ld, rows, cols, dst, dst2, rpb);
     LAS_LAUNCH_CHECK();
     return LAS_OK;
 }
