@@ -280,6 +280,16 @@ def test_edge_shapes_vs_oracle(cfg_name, B, T, U):
                                                     ("P", 8, 375, 5, None), ("P", 32, 200, 4, None), ("S", 8, 500, 4, None),
                                                     ("S", 16, 300, 4, None)])
 def test_persistent_decode_kernel_matches_stepwise(cfg_name, B, Tp, U, scale):
+    _persistent_vs_stepwise(cfg_name, B, Tp, U, scale, "relu")
+
+
+def test_persistent_decode_kernel_without_attention_activation():
+    """mlp_activate_in_attention=None (reference las_model.py:262-264: no activation on phi/psi): the relu masks of the
+    forward query and of its backward are switched off by a run-time flag in the persistent kernels."""
+    _persistent_vs_stepwise("S", 9, 40, 6, None, "None")
+
+
+def _persistent_vs_stepwise(cfg_name, B, Tp, U, scale, activate):
     """The one-launch teacher-forced decode loop (speller_persist.hip) against the per-step launch chain it replaces:
     outputs and every gradient (the backward pass consumes the stash the forward kernel wrote).  The larger-weight
     cases stay at U(-0.1,0.1): with the U(-0.5,0.5) set the attention softmax is an arg-max over energies of order 1e3
@@ -291,7 +301,7 @@ def test_persistent_decode_kernel_matches_stepwise(cfg_name, B, Tp, U, scale):
     c = synth.CONFIGS[cfg_name]
     torch.manual_seed(5)
     sp = Speller(vocab_size=c["V"], hidden_size=c["Hs"], rnn_unit="LSTM", num_layers=c["Ls"], max_label_len=U,
-                 use_mlp_in_attention=True, mlp_dim_in_attention=c["M"], mlp_activate_in_attention="relu",
+                 use_mlp_in_attention=True, mlp_dim_in_attention=c["M"], mlp_activate_in_attention=activate,
                  listener_hidden_size=c["H"], multi_head=1, decode_mode=1).cuda()
     if scale is not None:
         with torch.no_grad():
