@@ -7,12 +7,15 @@ A "step" is one pass of the hot path over one synthetic batch per GPU: Listener 
 (teacher-forced decode, U=128) forward, the reference's label-smoothing loss (solver/solver.py:33-45), backward
 through every HIP kernel, ONE flat gradient all-reduce (N>1), global-norm clip at 1.0 (solver.py:96) and an
 Adam step (lr 2e-4, train.py:82) — i.e. everything solver.batch_iterator does per batch except the host-side
-LER bookkeeping.  Inputs are resident in HBM before the timed region.  One process per GPU; for N>1 launch with
-``python -m torch.distributed.run --nproc-per-node N bench.py --gpus N ...`` (RCCL over xGMI).
+LER bookkeeping.  Inputs are resident in HBM before the timed region.  One process per GPU over RCCL / xGMI: under
+``python -m torch.distributed.run --nproc-per-node N bench.py --gpus N ...`` every rank runs this file; started bare
+with ``--gpus N`` (N > 1) it launches those N ranks itself as child processes before touching the GPU and relays rank 0's
+JSON line.
 
 Rank 0 prints ONE JSON line with ``roofline`` (dominant kernel: the layer-0 pBLSTM forward recurrence, timed with
-HIP events on the launch stream) and ``cpu_baseline`` (oracle/cpu_baseline.py — the nn.LSTM-module port of the
-reference's CPU path — timed on this box's host cores on a bounded sample).
+HIP events on the launch stream), ``roofline_mfma`` (the step's MFMA GEMMs against the 157.3 TF fp32-MFMA peak),
+``sweep`` (the recurrence at larger per-GPU batches) and ``cpu_baseline`` (oracle/cpu_baseline.py — the
+nn.LSTM-module port of the reference's CPU path — timed on this box's host cores on a bounded sample).
 """
 import argparse
 import json
@@ -38,6 +41,12 @@ WORKLOADS = {
     "Y_train": ("Y", 800, 128, True),      # config/librispeech-config.yaml sizes (512x3 / 1024x2, 40-mel; yaml batch 16)
 }
 HBM_PEAK_GBS = 8000.0    # MI355X HBM3E spec peak (guides/MI355X_MICROARCH.md)
+MFMA_F32_PEAK_TF = 157.3  # dense fp32-input MFMA peak (same guide)
+
+
+def _sha16(path):
+    import hashlib
+    return hashlib.sha256(open(path, "rb").read()).hexdigest()[:16]
 
 
 def build_model(cfg_name, U, device):
@@ -53,7 +62,7 @@ def build_model(cfg_name, U, device):
     return las.to(device), c, sd_np
 
 
-def roofline_rec_fwd(c, B, T, iters=20):
+def roofline_rec_fwd(c, B, T, iters=20, with_traffic=True):
     """Times the dominant kernel (layer-0 forward recurrence, rec_fwd_fast<H>) alone with HIP events on the stream it
     is launched on, on real pre-activations, and prices it against the HBM roofline with the ALGORITHMIC bytes of the
     pBLSTM layer it belongs to: B*4*T_l*(D_l+2H) + weights."""
@@ -101,15 +110,89 @@ def roofline_rec_fwd(c, B, T, iters=20):
     achieved = alg_bytes / (ms * 1e-3) / 1e9
     # HBM bytes per launch from the PMC counters (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes): measured
     # offline on this kernel and shape and committed under profiles/ (a counter run cannot nest inside this process)
+    # The JSON names the kernel source it was measured on (sha256 of pblstm_rec.hip): a stale file is refused, not quoted.
     traffic, traffic_src = None, None
-    pmc = os.path.join(ROOT, "profiles", "r01_pmc_rec_fwd.json")
-    if os.path.exists(pmc):
-        j = json.load(open(pmc))
-        if j["shape"] == dict(B=B, T_l=T_l, H=H):
-            traffic, traffic_src = int(j["traffic_bytes"]), "profiles/r01_pmc_rec_fwd.json"
+    if with_traffic:
+        src_hash = _sha16(os.path.join(ROOT, "las_pytorch_amd", "csrc", "pblstm_rec.hip"))
+        for name in sorted(os.listdir(os.path.join(ROOT, "profiles")), reverse=True):
+            if not (name.endswith(".json") and "pmc_rec_fwd" in name):
+                continue
+            j = json.load(open(os.path.join(ROOT, "profiles", name)))
+            if j.get("shape") == dict(B=B, T_l=T_l, H=H):
+                if j.get("kernel_source_sha16") == src_hash:
+                    traffic, traffic_src = int(j["traffic_bytes"]), "profiles/" + name
+                else:
+                    traffic_src = f"profiles/{name} is stale (kernel source changed since it was measured): not quoted"
+                break
     return dict(bound="hbm", kernel=f"rec_fwd_fast<{H}> layer0 (B={B},T_l={T_l})", achieved=round(achieved, 2), peak=HBM_PEAK_GBS,
                 unit="GB/s", frac=round(achieved / HBM_PEAK_GBS, 5), traffic=traffic, traffic_source=traffic_src,
                 kernel_ms=round(ms, 4), us_per_step=round(ms * 1e3 / T_l, 3), algorithmic_bytes=alg_bytes)
+
+
+def step_gemm_shapes(c, B, T, U):
+    """(name, M, N, K, a_kc, b_kc, batch, splitk, count) of every MFMA GEMM of one training step (las_capi.hip)."""
+    H, F, L, Hs, V, M = c["H"], c["F"], c["L"], c["Hs"], c["V"], c["M"]
+    out = []
+    for l in range(L):
+        BT, D = B * (T >> (l + 1)), (2 * F if l == 0 else 4 * H)
+        out.append((f"L{l} X W_ih^T (2 dirs batched)", BT, 4 * H, D, 1, 1, 2, 1, 1))
+        out.append((f"L{l} dW_ih", 4 * H, D, BT, 0, 0, 1, 0, 2))
+        out.append((f"L{l} dW_hh", 4 * H, H, BT, 0, 0, 1, 0, 2))
+        if l > 0:
+            out.append((f"L{l} dX", BT, D, 4 * H, 1, 0, 1, 1, 2))
+    Tp, UB = T >> L, U * B
+    out += [("keys psi", B * Tp, M, 2 * H, 1, 1, 1, 0, 1), ("logits [h|ctx] W_c^T", UB, V, Hs, 1, 1, 1, 0, 2),
+            ("dcat = dz W_c", UB, 2 * Hs, V, 1, 0, 1, 1, 1),
+            ("dfeat (per utterance)", Tp, Hs, U, 0, 0, B, 1, 1), ("dK (per utterance)", Tp, M, U, 0, 0, B, 1, 1),
+            ("dW_psi", M, Hs, B * Tp, 0, 0, 1, 0, 1), ("dfeat += dK W_psi", B * Tp, Hs, M, 1, 0, 1, 1, 1),
+            ("dW_phi", M, Hs, UB, 0, 0, 1, 0, 1), ("dW_c halves", V, Hs, UB, 0, 0, 1, 0, 2),
+            ("dW_ih0[:, :V]", 4 * Hs, V, UB, 0, 0, 1, 0, 1), ("dW_ih0[:, V:]", 4 * Hs, Hs, UB, 0, 0, 1, 0, 1),
+            ("dW_ih1", 4 * Hs, Hs, UB, 0, 0, 1, 0, 1), ("dW_hh0/1", 4 * Hs, Hs, UB - B, 0, 0, 1, 0, 2)]
+    return out
+
+
+def roofline_mfma(c, B, T, U, reps=10):
+    """Every GEMM shape of one training step through the exported las_gemm_f32, HIP-event timed on the launch stream:
+    flops / time against the dense fp32-MFMA peak.  (The step's 2*M*N*K flops are ALGORITHMIC: split-K atomics, bias
+    and activation epilogues are not counted.)"""
+    from las_pytorch_amd import _cabi
+    L = _cabi.lib()
+    tot_us, tot_fl, rows = 0.0, 0.0, []
+    for name, M, N, K, a_kc, b_kc, batch, splitk, count in step_gemm_shapes(c, B, T, U):
+        A = torch.randn(batch * M * K, device="cuda"); Bm = torch.randn(batch * N * K, device="cuda")
+        C = torch.zeros(batch * M * N, device="cuda")
+        lda = K if a_kc else M; ldb = K if b_kc else N
+
+        def call():
+            _cabi.check(L.las_gemm_f32(A.data_ptr(), Bm.data_ptr(), C.data_ptr(), None, None, M, N, K, lda, ldb, N, a_kc, b_kc, batch,
+                                       M * K, N * K, M * N, splitk, 0, 0, _cabi.stream_ptr()))
+        for _ in range(2):
+            call()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(reps):
+            call()
+        e1.record(); torch.cuda.synchronize()
+        us = e0.elapsed_time(e1) * 1e3 / reps
+        fl = 2.0 * batch * M * N * K
+        tot_us += us * count; tot_fl += fl * count
+        rows.append({"gemm": name, "M": M, "N": N, "K": K, "batch": batch, "count": count, "us": round(us, 1), "tflops": round(fl / us / 1e6, 1)})
+    tf = tot_fl / tot_us / 1e6
+    return dict(bound="mfma", kernel="gemm_f32_kernel: all MFMA GEMMs of one training step (v_mfma_f32_32x32x2_f32, exact fp32)",
+                achieved=round(tf, 1), peak=MFMA_F32_PEAK_TF, unit="TFLOP/s", frac=round(tf / MFMA_F32_PEAK_TF, 4),
+                flops_per_step=int(tot_fl), gemm_ms_per_step=round(tot_us / 1e3, 3), shapes=rows)
+
+
+def sweep_rec(c, T, batches=(32, 128, 512)):
+    """The layer-0 forward recurrence alone at growing per-GPU batch (SURVEY.md section 8d asks for the batch sweep next to
+    the B=32 headline: at B=32 the kernel is a latency-bound 400-step chain, larger batches amortise the hand-off)."""
+    out = []
+    for Bs in batches:
+        r = roofline_rec_fwd(c, Bs, T, iters=5, with_traffic=False)
+        out.append({"B": Bs, "kernel_ms": r["kernel_ms"], "achieved_GBs": r["achieved"], "frac": r["frac"],
+                    "us_per_step": r["us_per_step"], "us_per_utterance_step": round(r["us_per_step"] / Bs, 4)})
+        torch.cuda.empty_cache()
+    return out
 
 
 def cpu_baseline(cfg_name, B, T, U, train):
@@ -131,6 +214,23 @@ def cpu_baseline(cfg_name, B, T, U, train):
                 ms_per_step=round(r["ms_per_step"], 1))
 
 
+def launch_ranks(n):
+    """Bare ``python bench.py --gpus N``: start the N ranks as children of this process (one per GPU, torch.distributed.run
+    with a loopback rendezvous) BEFORE anything here initialises the GPU, let them write to our stdout/stderr, and return
+    their exit status.  ``device_count()`` does not create a HIP context on this image."""
+    import socket
+    import subprocess
+    have = torch.cuda.device_count()
+    if have < n:
+        print(f"bench.py: --gpus {n} requested but only {have} GPU(s) are visible on this node", file=sys.stderr)
+        return 3
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", MASTER_ADDR="127.0.0.1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    return subprocess.call(cmd, env=env)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -141,16 +241,18 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--no-secondary", action="store_true")
+    ap.add_argument("--no-sweep", action="store_true")
+    ap.add_argument("--no-mfma", action="store_true")
     ap.add_argument("--graph", type=int, default=0, help="1: replay fwd+loss+bwd as one captured HIP graph per step")
     args = ap.parse_args()
 
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        return launch_ranks(args.gpus)
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("launch with: python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 "
-                             "bench.py --gpus N ...")
+        raise SystemExit(f"bench.py: --gpus {args.gpus} but the launcher started WORLD_SIZE={world} ranks")
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
     use_dist = world > 1 or os.environ.get("LAS_FORCE_DIST") == "1"      # the latter: exercise the RCCL path on one GPU
@@ -162,7 +264,7 @@ def main():
 
     import las_pytorch_amd
     from las_pytorch_amd import dp, synth
-    from las_pytorch_amd.solver.solver import label_smoothing_loss_device
+    from las_pytorch_amd.solver.solver import label_smoothing_loss_device, stack_steps
 
     cfg_name, T, U, train = WORKLOADS[args.workload]
     B = args.batch
@@ -179,7 +281,7 @@ def main():
         def step():
             reducer.zero()
             preds, _ = las(batch_data=x, batch_label=lab, teacher_force_rate=1.0, is_training=True)
-            loss = label_smoothing_loss_device(torch.stack(preds, 1), lab, 0.1)     # fused loss + gradient kernel
+            loss = label_smoothing_loss_device(stack_steps(preds), lab, 0.1)      # fused loss + gradient kernel, no copies
             loss.backward()
             reducer.allreduce_mean()
             reducer.clip_(1.0)
@@ -204,7 +306,7 @@ def main():
         with torch.cuda.graph(graph):
             reducer.zero()
             preds, _ = las(batch_data=x, batch_label=lab, teacher_force_rate=1.0, is_training=True)
-            static_loss = label_smoothing_loss_device(torch.stack(preds, 1), lab, 0.1)
+            static_loss = label_smoothing_loss_device(stack_steps(preds), lab, 0.1)
             static_loss.backward()
 
         def step():  # noqa: F811
@@ -247,6 +349,7 @@ def main():
             "metric": metric_name, "value": round(world * B * args.steps / dt, 2), "unit": "utt/s", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms, 3), "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "rccl_ranks": dist.get_world_size() if use_dist else 0,
             "config": {"workload": f"{args.workload}: Listener {c['H']}x{c['L']} / Speller {c['Hs']}x{c['Ls']}, "
                                    f"(B={B},T={T},F={c['F']}) log-mel per GPU, teacher-forced U={U}, "
                                    + ("fwd + label-smoothing loss + bwd + grad all-reduce + clip(1.0) + Adam" if train else "fwd only"),
@@ -255,6 +358,10 @@ def main():
         }
         if not args.no_roofline:
             res["roofline"] = roofline_rec_fwd(c, B, T)
+        if world == 1 and train and not args.no_mfma:
+            res["roofline_mfma"] = roofline_mfma(c, B, T, U)
+        if world == 1 and not args.no_sweep and not args.no_roofline:
+            res["sweep"] = {"kernel": f"rec_fwd_fast<{c['H']}> layer0, T_l={T // 2}", "points": sweep_rec(c, T)}
         if world == 1 and not args.no_cpu_baseline:
             res["cpu_baseline"] = cpu_baseline(cfg_name, B, T, U, train)
         if world == 1 and args.workload == "P_train" and not args.no_secondary:
@@ -281,4 +388,4 @@ def main():
 
 
 if __name__ == "__main__":
-    main()
+    sys.exit(main() or 0)

@@ -33,7 +33,7 @@
 extern "C" {
 #endif
 
-#define LAS_ABI_VERSION 3
+#define LAS_ABI_VERSION 4
 #define LAS_MAX_SPELLER_LAYERS 4
 
 /* flags */
@@ -114,14 +114,18 @@ size_t las_speller_reserve_floats(const las_speller_desc* d, int U);
 /* Decode U steps.
  *   labels_onehot : int64 (B, U_lab, V) one-hot ground truth as utils/data.py:141-143 delivers it, or NULL
  *   teacher_forced: 1 -> step s+1 is fed labels[:, s] (las_model.py:216-217); 0 -> free running with
- *   decode_mode 0 (feed log-probs, :220-221) or 1 (feed one-hot argmax, :223-227).  Mode 2 (sampling) is
- *   not implemented.
+ *   decode_mode 0 (feed log-probs, :220-221), 1 (feed one-hot argmax, :223-227) or 2 (feed a one-hot sample of
+ *   Categorical(raw_pred), :229-234).  Mode 2 reproduces the reference exactly as torch evaluates it: the
+ *   log-probabilities are renormalised as if they were probabilities (p_v = logp_v / sum_v logp_v, i.e. proportional
+ *   to |log p|) and the sample is argmax_v p_v / q_v with q ~ Exp(1) (torch.multinomial's single-draw path);
+ *   sample_noise (U,B,V) holds the caller's q draws (fp32, > 0) and may be NULL for the other modes.
  *   logp (U,B,V), att (U,heads,B,Tp), argmax (U,B) int32 or NULL.  keys may be NULL when !use_mlp.
  *   err_word: device uint32 (see las_pblstm_fwd) the persistent teacher-forced decode kernel reports hand-off timeouts
  *   through; NULL (or LAS_FLAG_FORCE_GENERIC) selects the per-step launch chain, which needs none. */
 int las_speller_fwd(const las_speller_desc* d, const float* feat, const float* keys,
                     const int64_t* labels_onehot, int U_lab, int U, int teacher_forced, int decode_mode,
-                    float* logp, float* att, int32_t* argmax, float* reserve, uint32_t* err_word, int flags, void* stream);
+                    const float* sample_noise, float* logp, float* att, int32_t* argmax, float* reserve, uint32_t* err_word,
+                    int flags, void* stream);
 
 /* One decode step with caller-managed state: Speller.forward_step, reference model/las_model.py:178-184.
  *   input_word (B, V+Hs) = [y | context] as the reference concatenates it (:198,:236); h_in/c_in (L,B,Hs) or both NULL
@@ -155,6 +159,34 @@ int las_ls_loss(const float* logp, int64_t stride_u, int64_t stride_b, const int
                 float* scratch, void* stream);
 int las_letter_error_rate(const float* logp, int64_t stride_u, int64_t stride_b, const int64_t* labels_onehot, int U,
                           int U_lab, int B, int V, float* ler_out, int32_t* work, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Input side: the collate contract on device (reference utils/data.py:116-149, collate_fn).
+ *   packed_feat (sum_b len_b, F) fp32: the utterances' frames back to back; feat_offsets int64 (B+1) frame offsets.
+ *   packed_labels int64 (sum_b n_b) character indices back to back; label_offsets int64 (B+1).
+ *   inputs (B,T,F): frames then zero padding (np.pad constant 0, data.py:128); T is chosen by the caller (the reference
+ *   rounds max len up to a multiple of 2**listener_layers = 32, data.py:124-125).
+ *   targets int64 (B,U,V): one-hot rows, padding rows = onehot(PAD=0) (data.py:129,133).
+ * ---------------------------------------------------------------------------------------------- */
+int las_collate_pad(const float* packed_feat, const int64_t* feat_offsets, const int64_t* packed_labels,
+                    const int64_t* label_offsets, int B, int T, int F, int U, int V, float* inputs, int64_t* targets,
+                    void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Data-parallel gradient exchange: ONE all-reduce of the flat fp32 gradient per step over RCCL / xGMI.
+ * Replaces nn.DataParallel's per-step broadcast / gather / reduce, reference train.py:76-78.
+ * One communicator per device and process (mutex-guarded handle; librccl is opened on first use, so the library
+ * itself has no link-time dependency on it).
+ *   las_comm_uid   : rank 0 creates the 128-byte unique id and ships it to the other ranks by any host channel
+ *   las_comm_init  : collective over all ranks; binds the communicator to the CURRENT device
+ *   las_allreduce_f32 : in place on `buf` (count floats), enqueued on `stream`; average != 0 divides by the world size
+ *                       inside the collective (ncclAvg)
+ *   las_comm_destroy : releases the current device's communicator
+ * ---------------------------------------------------------------------------------------------- */
+int las_comm_uid(void* uid_out128);
+int las_comm_init(int rank, int world, const void* uid128);
+int las_allreduce_f32(float* buf, size_t count, int average, void* stream);
+int las_comm_destroy(void);
 
 /* ------------------------------------------------------------------------------------------------
  * Building blocks exported for tests / micro-benchmarks.

@@ -42,7 +42,7 @@ PROTOTYPES = {
                        + [_f, C.c_int, _f]),
     "las_attn_keys_fwd": (C.c_int, [C.POINTER(SpellerDesc), _f, _f, _f]),
     "las_speller_reserve_floats": (C.c_size_t, [C.POINTER(SpellerDesc), C.c_int]),
-    "las_speller_fwd": (C.c_int, [C.POINTER(SpellerDesc), _f, _f, _f, C.c_int, C.c_int, C.c_int, C.c_int, _f, _f, _f, _f,
+    "las_speller_fwd": (C.c_int, [C.POINTER(SpellerDesc), _f, _f, _f, C.c_int, C.c_int, C.c_int, C.c_int, _f, _f, _f, _f, _f,
                                   _f, C.c_int, _f]),
     "las_speller_step_workspace_floats": (C.c_size_t, [C.POINTER(SpellerDesc)]),
     "las_speller_step_fwd": (C.c_int, [C.POINTER(SpellerDesc)] + [_f] * 12),
@@ -52,6 +52,11 @@ PROTOTYPES = {
     "las_ls_loss": (C.c_int, [_f, C.c_int64, C.c_int64, _f, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, _f, _f, C.c_int64,
                               C.c_int64, _f, _f]),
     "las_letter_error_rate": (C.c_int, [_f, C.c_int64, C.c_int64, _f, C.c_int, C.c_int, C.c_int, C.c_int, _f, _f, _f]),
+    "las_collate_pad": (C.c_int, [_f, _f, _f, _f] + [C.c_int] * 5 + [_f, _f, _f]),
+    "las_comm_uid": (C.c_int, [C.c_char_p]),
+    "las_comm_init": (C.c_int, [C.c_int, C.c_int, C.c_char_p]),
+    "las_allreduce_f32": (C.c_int, [_f, C.c_size_t, C.c_int, _f]),
+    "las_comm_destroy": (C.c_int, []),
     "las_gemm_f32": (C.c_int, [_f] * 5 + [C.c_int] * 3 + [C.c_int64] * 3 + [C.c_int, C.c_int, C.c_int]
                      + [C.c_int64] * 3 + [C.c_int, C.c_int, C.c_int, _f]),
     "las_rec_xbuf_bytes": (C.c_size_t, [C.c_int, C.c_int]),
@@ -95,16 +100,31 @@ def ptr(t):
     return t.data_ptr()
 
 
+def ptr_strided(t):
+    """Device address of a tensor whose strides the callee is told explicitly (no contiguity requirement)."""
+    if t is None:
+        return None
+    if not t.is_cuda:
+        raise RuntimeError("the LAS HIP path needs CUDA(ROCm) tensors; there is no CPU fallback")
+    return t.data_ptr()
+
+
 def stream_ptr():
     return torch.cuda.current_stream().cuda_stream
 
 
 _err_words = {}
+_err_snap = {}      # device index -> (pinned host copy, event): the asynchronous snapshot poll_device_errors() looks at
+
+
+def _dev_index(device):
+    d = torch.device(device)
+    return d.index if d.index is not None else torch.cuda.current_device()
 
 
 def err_word(device):
     """Per-device uint32 the kernels write a nonzero code into when a bounded hand-off spin expires."""
-    key = torch.device(device).index if torch.device(device).index is not None else torch.cuda.current_device()
+    key = _dev_index(device)
     w = _err_words.get(key)
     if w is None:
         w = torch.zeros(4, dtype=torch.int32, device=f"cuda:{key}")
@@ -112,11 +132,49 @@ def err_word(device):
     return w
 
 
+def _raise_device_error(key, v):
+    raise RuntimeError(f"liblas_hip device-side failure 0x{v & 0xffffffff:08x} on cuda:{key} "
+                       "(an inter-workgroup hand-off of a persistent kernel timed out: another kernel was resident on the "
+                       "GPU, or fewer compute units were available than the launch assumed; the results of that call are "
+                       "invalid).  The error word has been cleared; LAS_FLAG_FORCE_GENERIC / force_generic selects the "
+                       "per-step kernels, which need no co-residency.")
+
+
 def check_device_errors():
-    """Synchronising check of the device error words (tests, smoke and bench call this after timing)."""
+    """Synchronising check of the device error words: raises if any persistent kernel reported a hand-off timeout and
+    clears the word so later launches run normally.  ``solver.batch_iterator`` calls this right after the loss reaches
+    the host (the step's existing synchronisation point); tests, smoke and bench call it after their timed regions."""
     for key, w in _err_words.items():
         v = int(w[0].item())
         if v != 0:
             w.zero_()
-            raise RuntimeError(f"liblas_hip device-side failure 0x{v & 0xffffffff:08x} on cuda:{key} "
-                               "(inter-workgroup hand-off timed out; results are invalid)")
+            _err_snap.pop(key, None)
+            _raise_device_error(key, v)
+
+
+def poll_device_errors(device):
+    """Non-blocking form used at the top of every ``Listener`` / ``Speller`` forward: looks at the snapshot of the
+    error word copied to pinned host memory behind the PREVIOUS call's kernels (raising if it is nonzero) and
+    enqueues the next snapshot.  Detection is one call late but costs no host synchronisation."""
+    key = _dev_index(device)
+    w = _err_words.get(key)
+    if w is None or torch.cuda.is_current_stream_capturing():
+        return
+    snap = _err_snap.get(key)
+    if snap is not None:
+        host, ev = snap
+        if not ev.query():
+            return                        # the previous snapshot has not landed yet: look again next call
+        v = int(host[0])
+        if v != 0:
+            w.zero_()
+            _err_snap.pop(key, None)
+            _raise_device_error(key, v)
+    else:
+        host = torch.zeros(4, dtype=torch.int32).pin_memory()
+        ev = torch.cuda.Event()
+        _err_snap[key] = (host, ev)
+    host, ev = _err_snap[key]
+    with torch.cuda.device(key):
+        host.copy_(w, non_blocking=True)
+        ev.record()

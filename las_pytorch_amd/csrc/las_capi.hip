@@ -257,16 +257,17 @@ extern "C" void las_debug_rec_trace(unsigned long long* dev_buf) { rec_set_trace
 #endif
 
 int las_speller_fwd(const las_speller_desc* d, const float* feat, const float* keys, const int64_t* labels_onehot, int U_lab,
-                    int U, int teacher_forced, int decode_mode, float* logp, float* att, int32_t* argmax, float* reserve,
-                    uint32_t* err_word, int flags, void* stream_) {
+                    int U, int teacher_forced, int decode_mode, const float* sample_noise, float* logp, float* att,
+                    int32_t* argmax, float* reserve, uint32_t* err_word, int flags, void* stream_) {
     hipStream_t stream = (hipStream_t)stream_;
     LAS_TRY(check_desc(d));
     LAS_REQUIRE(U > 0, "decode steps");
     LAS_REQUIRE(feat && logp && att && reserve, "speller pointers");
     LAS_REQUIRE(!d->use_mlp || keys, "attention keys");
     LAS_REQUIRE(!teacher_forced || (labels_onehot && U_lab >= U), "teacher forcing needs labels for every step");
-    if (!teacher_forced && decode_mode != 0 && decode_mode != 1)
-        return fail(LAS_ERR_UNSUPPORTED, "decode_mode %s%ld is not implemented by the HIP path", "", (long)decode_mode);
+    if (!teacher_forced && (decode_mode < 0 || decode_mode > 2))
+        return fail(LAS_ERR_UNSUPPORTED, "decode_mode %s%ld does not exist (reference las_model.py:219-234)", "", (long)decode_mode);
+    LAS_REQUIRE(teacher_forced || decode_mode != 2 || sample_noise, "decode_mode 2 needs the caller's Exp(1) draws (sample_noise)");
     LAS_REQUIRE((uintptr_t)reserve % 16 == 0, "reserve alignment");
     const int B = d->B, Hs = d->Hs, V = d->V, D = d->D, Tp = d->Tp, L = d->L;
     SpellerLayout lay(d, U);
@@ -289,7 +290,7 @@ int las_speller_fwd(const las_speller_desc* d, const float* feat, const float* k
     LAS_TRY(copy2d(d->w_ih[0] + V, V + Hs, w0p + Vp, Vp + Hs, 4 * Hs, Hs, 0, stream));
 
     static const bool persist_on = !(getenv("LAS_SPELLER_PERSIST") && atoi(getenv("LAS_SPELLER_PERSIST")) == 0);
-    const bool persist = persist_on && err_word && !(flags & LAS_FLAG_FORCE_GENERIC) &&
+    const bool persist = persist_on && err_word && !(flags & LAS_FLAG_FORCE_GENERIC) && (teacher_forced || decode_mode != 2) &&
                          speller_persist_eligible(B, Tp, Hs, D, d->M, V, L, d->multi_head, d->use_mlp, !teacher_forced);
     if (persist) {
         PersistFwd p;
@@ -338,6 +339,7 @@ int las_speller_fwd(const las_speller_desc* d, const float* feat, const float* k
         a.argmax_out = argmax ? argmax + (size_t)s * B : nullptr;
         a.y_next = teacher_forced ? nullptr : y_all + (size_t)(s + 1) * B * Vp; a.ldy = Vp;
         a.y_mode = decode_mode;
+        a.sample_noise = (!teacher_forced && decode_mode == 2) ? sample_noise + (size_t)s * B * V : nullptr;
         a.B = B; a.Tp = Tp; a.D = D; a.M = d->M; a.V = V; a.Hs = Hs; a.use_mlp = d->use_mlp; a.relu = d->relu;
         a.heads = NH;
         float* ctx_next = ctx_all + (size_t)(s + 1) * B * D;
@@ -675,6 +677,16 @@ int las_letter_error_rate(const float* logp, int64_t stride_u, int64_t stride_b,
     LAS_REQUIRE(logp && labels_onehot && ler_out && work, "LER pointers");
     LAS_REQUIRE(U > 0 && U <= U_lab && B > 0 && V > 0, "LER dims");
     return ler(logp, stride_u, stride_b, (const long long*)labels_onehot, U, U_lab, B, V, ler_out, work, (hipStream_t)stream);
+}
+
+// ---------------------------------------------------------------------------------------------- input side
+int las_collate_pad(const float* packed_feat, const int64_t* feat_offsets, const int64_t* packed_labels,
+                    const int64_t* label_offsets, int B, int T, int F, int U, int V, float* inputs, int64_t* targets,
+                    void* stream) {
+    LAS_REQUIRE(B > 0 && T > 0 && F > 0 && U > 0 && V > 0, "collate dims");
+    LAS_REQUIRE(packed_feat && feat_offsets && packed_labels && label_offsets && inputs && targets, "collate pointers");
+    return collate_pad(packed_feat, (const long long*)feat_offsets, (const long long*)packed_labels, (const long long*)label_offsets,
+                       B, T, F, U, V, inputs, (long long*)targets, (hipStream_t)stream);
 }
 
 // ---------------------------------------------------------------------------------------------- building blocks

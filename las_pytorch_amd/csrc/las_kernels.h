@@ -89,7 +89,8 @@ struct AttnFwdArgs {
     float* logp_out;       // (B,V); null = character distribution deferred to one GEMM after the loop (teacher forcing)
     int* argmax_out;       // (B) or null
     float* y_next; long ldy; // (B,ldy) or null: next-step input written on device (free-running decode)
-    int y_mode;            // 0: feed log-probs back, 1: feed one-hot argmax
+    int y_mode;            // 0: feed log-probs back, 1: feed one-hot argmax, 2: feed a one-hot sample (needs sample_noise)
+    const float* sample_noise = nullptr;   // (B,V) Exp(1) draws of this step (decode_mode 2)
     int B, Tp, D, M, V, Hs;
     int use_mlp, relu;
     // multi-head (reference las_model.py:298-314): grid (B, heads); head h uses rows [h*M,(h+1)*M) of phi and writes its
@@ -179,5 +180,7 @@ int ls_loss(const float* logp, long sU, long sB, const long long* labels, int U,
 int ler(const float* logp, long sU, long sB, const long long* labels, int U, int U_lab, int B, int V, float* out, int* work,
         hipStream_t stream);
 int labels_to_y(const long long* labels, float* y_all, int B, int U, int V, int Vp, int u_lab, hipStream_t stream);
+int collate_pad(const float* packed, const long long* foff, const long long* plab, const long long* loff, int B, int T, int F, int U,
+                int V, float* inputs, long long* targets, hipStream_t stream);
 
 }  // namespace las

@@ -1,6 +1,7 @@
 // Small memory-bound helpers around the hot path (bias gradients, masks, label conversion).
 #include "las_common.h"
 #include "las_kernels.h"
+#include <algorithm>
 
 namespace las {
 
@@ -110,6 +111,48 @@ __global__ void labels_to_y_kernel(const long long* __restrict__ labels, float* 
 int labels_to_y(const long long* labels, float* y_all, int B, int U, int V, int Vp, int u_lab, hipStream_t stream) {
     const long n = (long)(U + 1) * B * Vp;
     hipLaunchKernelGGL(labels_to_y_kernel, dim3(cdiv(n, 256)), dim3(256), 0, stream, labels, y_all, B, U, V, Vp, u_lab);
+    LAS_LAUNCH_CHECK();
+    return LAS_OK;
+}
+
+// Collate contract on device (reference utils/data.py:116-149): ragged frames -> zero-padded (B,T,F); character indices ->
+// int64 one-hot (B,U,V) whose padding rows are onehot(PAD=0).  Pure HBM streaming: every output element is written once,
+// 16 bytes per lane when the row length allows it.
+__global__ __launch_bounds__(256) void collate_feat_kernel(const float* __restrict__ packed, const long long* __restrict__ foff,
+                                                           float* __restrict__ inputs, int T, int F, int vec) {
+    const int b = blockIdx.y;
+    const long long off = foff[b], len = foff[b + 1] - off;
+    const long n = (long)T * F, valid = (long)len * F;
+    const float* src = packed + off * F;
+    float* dst = inputs + (long)b * n;
+    if (vec) {       // F % 4 == 0 and 16-byte aligned bases: float4 lanes
+        const long n4 = n / 4, v4 = valid / 4;
+        for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long)gridDim.x * 256) {
+            f32x4 v = {0.f, 0.f, 0.f, 0.f};
+            if (i < v4) v = *reinterpret_cast<const f32x4*>(src + i * 4);
+            *reinterpret_cast<f32x4*>(dst + i * 4) = v;
+        }
+    } else {
+        for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) dst[i] = i < valid ? src[i] : 0.f;
+    }
+}
+__global__ void collate_label_kernel(const long long* __restrict__ plab, const long long* __restrict__ loff,
+                                     long long* __restrict__ targets, int B, int U, int V) {
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (long)B * U * V) return;
+    const int v = i % V, u = (i / V) % U, b = i / ((long)V * U);
+    const long long off = loff[b], len = loff[b + 1] - off;
+    const long long sym = u < len ? plab[off + u] : 0;      // PAD = 0
+    targets[i] = (sym == v) ? 1 : 0;
+}
+int collate_pad(const float* packed, const long long* foff, const long long* plab, const long long* loff, int B, int T, int F, int U,
+                int V, float* inputs, long long* targets, hipStream_t stream) {
+    const int vec = (F % 4 == 0) && ((uintptr_t)packed % 16 == 0) && ((uintptr_t)inputs % 16 == 0);
+    const long per = (long)T * F / (vec ? 4 : 1);
+    dim3 grid((unsigned)std::min<long>(cdiv(per, 256), 64), B);
+    hipLaunchKernelGGL(collate_feat_kernel, grid, dim3(256), 0, stream, packed, foff, inputs, T, F, vec);
+    const long n = (long)B * U * V;
+    hipLaunchKernelGGL(collate_label_kernel, dim3(cdiv(n, 256)), dim3(256), 0, stream, plab, loff, targets, B, U, V);
     LAS_LAUNCH_CHECK();
     return LAS_OK;
 }

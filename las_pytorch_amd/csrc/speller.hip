@@ -505,9 +505,30 @@ __global__ __launch_bounds__(ATT_THREADS) void attn_step_fwd_kernel(AttnFwdArgs 
         for (int mm = 32; mm >= 1; mm >>= 1) best = min(best, __shfl_xor(best, mm));
         if (lane == 0 && a.argmax_out) a.argmax_out[b] = best;
         if (a.y_next) {
-            // next-step input: log-probs (decode_mode 0, las_model.py:220-221) or one-hot argmax (mode 1, :223-227)
+            int pick = best;
+            if (a.y_mode == 2) {
+                // decode_mode 2 (las_model.py:229-234): Categorical(raw_pred) is handed LOG-probabilities as `probs`; torch
+                // renormalises them (p_v = logp_v / sum_v logp_v, i.e. proportional to |log p|) and draws one sample as
+                // argmax_v p_v / q_v with q ~ Exp(1) (torch.multinomial's single-sample path).  The caller supplies q.
+                float sl = 0.f;
+                for (int v = lane; v < a.V; v += 64) sl += lg[v] - lse;
+                sl = wave_sum(sl);
+                float kbest = -INFINITY;
+                pick = 0x7fffffff;
+                for (int v = lane; v < a.V; v += 64) {
+                    const float key = ((lg[v] - lse) / sl) / a.sample_noise[(long)b * a.V + v];
+                    if (key > kbest) { kbest = key; pick = v; }
+                }
+#pragma unroll
+                for (int mm = 32; mm >= 1; mm >>= 1) {
+                    const float ok = __shfl_xor(kbest, mm);
+                    const int op = __shfl_xor(pick, mm);
+                    if (ok > kbest || (ok == kbest && op < pick)) { kbest = ok; pick = op; }
+                }
+            }
+            // next-step input: log-probs (decode_mode 0, las_model.py:220-221), one-hot argmax (mode 1, :223-227) or one-hot sample
             for (int v = lane; v < a.V; v += 64)
-                a.y_next[(long)b * a.ldy + v] = (a.y_mode == 0) ? (lg[v] - lse) : (v == best ? 1.0f : 0.f);
+                a.y_next[(long)b * a.ldy + v] = (a.y_mode == 0) ? (lg[v] - lse) : (v == pick ? 1.0f : 0.f);
         }
     }
 }

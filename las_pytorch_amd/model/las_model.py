@@ -25,33 +25,36 @@ import torch.nn as nn
 from .. import _cabi
 from .._cabi import FLAG_FORCE_GENERIC, FLAG_STASH, SpellerDesc, SpellerGrads, check, lib, ptr, stream_ptr
 
-# set by tests to A/B the generic recurrence kernels against the register-resident ones
-FORCE_GENERIC_RECURRENCE = False
-
-
-# Opt-in (las_pytorch_amd.dp.FlatGradAllReducer(direct=True)): the backward kernels write the parameter gradients
-# straight into the existing ``p.grad`` tensors (the views of the flat all-reduce buffer) and autograd is handed ``None``
-# for them, instead of fresh tensors that AccumulateGrad then adds into ``p.grad`` with one small kernel per parameter
-# (36 launches per step at the reference's sizes).  Valid when every parameter is used once per backward and the
-# gradients are re-initialised every step — the training loop of solver/solver.py:95-97.
-DIRECT_GRAD_WRITE = False
+def set_force_generic(module, flag=True):
+    """A/B switch for tests and profiling: every pBLSTM layer / Speller under ``module`` uses the generic kernels
+    (L2-streaming recurrence, per-step decode launches; ``LAS_FLAG_FORCE_GENERIC``) instead of the persistent ones.
+    Per-module state: two models in one process do not influence each other."""
+    for m in module.modules():
+        if isinstance(m, (pBLSTMLayer, Speller)):
+            m.force_generic = bool(flag)
 
 
 def _direct_targets(params):
-    if not DIRECT_GRAD_WRITE:
-        return None
+    """``las_pytorch_amd.dp.FlatGradAllReducer(direct=True)`` tags the parameters it owns with the address of its flat
+    buffer; for those (and only those) the backward kernels write the gradient straight into ``p.grad`` (a view of that
+    buffer) and autograd is handed ``None``, instead of fresh tensors that AccumulateGrad adds into ``p.grad`` with one
+    small kernel per parameter (36 launches per step at the reference's sizes).  Valid when every parameter is used
+    once per backward and the buffer is re-zeroed every step — the loop of solver/solver.py:95-97.  Any parameter
+    whose ``.grad`` is no longer that view (``zero_grad(set_to_none=True)``, a foreign module) switches the whole call
+    back to ordinary autograd accumulation."""
     out = []
     for p in params:
+        base = getattr(p, "_las_direct_base", None)
         g = getattr(p, "grad", None)
-        if (g is None or g.dtype != torch.float32 or not g.is_contiguous() or g.shape != p.shape or g.device != p.device
-                or not p.requires_grad):
+        if (base is None or g is None or not p.requires_grad or g.dtype != torch.float32 or not g.is_contiguous()
+                or g.shape != p.shape or g.device != p.device or g.untyped_storage().data_ptr() != base):
             return None
         out.append(g)
     return out
 
 
-def _flags(stash):
-    return (FLAG_STASH if stash else 0) | (FLAG_FORCE_GENERIC if FORCE_GENERIC_RECURRENCE else 0)
+def _flags(stash, force_generic=False):
+    return (FLAG_STASH if stash else 0) | (FLAG_FORCE_GENERIC if force_generic else 0)
 
 
 def _f32c(t):
@@ -96,7 +99,7 @@ def _require_lstm(rnn_unit):
 # --------------------------------------------------------------------------------------------------
 class _PBLSTMFn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, w_ih_f, w_hh_f, b_ih_f, b_hh_f, w_ih_r, w_hh_r, b_ih_r, b_hh_r):
+    def forward(ctx, force_generic, x, w_ih_f, w_hh_f, b_ih_f, b_hh_f, w_ih_r, w_hh_r, b_ih_r, b_hh_r):
         x = _f32c(x)
         B, T_in, D_in = x.shape
         H = w_hh_f.shape[1]
@@ -104,7 +107,7 @@ class _PBLSTMFn(torch.autograd.Function):
             raise RuntimeError(f"pBLSTM needs an even number of frames, got {T_in} (reference las_model.py:86-87)")
         ws = [_f32c(w) for w in (w_ih_f, w_hh_f, b_ih_f, b_hh_f, w_ih_r, w_hh_r, b_ih_r, b_hh_r)]
         stash = any(ctx.needs_input_grad)      # grad mode is off inside Function.forward; this is the reliable signal
-        flags = _flags(stash)
+        flags = _flags(stash, force_generic)
         L = lib()
         out = torch.empty(B, T_in // 2, 2 * H, device=x.device, dtype=torch.float32)
         reserve = torch.empty(L.las_pblstm_reserve_floats(B, T_in, H, flags), device=x.device, dtype=torch.float32)
@@ -114,7 +117,7 @@ class _PBLSTMFn(torch.autograd.Function):
             ctx.save_for_backward(x, ws[0], ws[1], ws[4], ws[5], reserve)
             ctx.direct = _direct_targets((w_ih_f, w_hh_f, b_ih_f, b_hh_f, w_ih_r, w_hh_r, b_ih_r, b_hh_r))
             ctx.dims = (B, T_in, D_in, H)
-            ctx.need_dx = ctx.needs_input_grad[0]
+            ctx.need_dx = ctx.needs_input_grad[1]
             ctx.flags = flags
         return out
 
@@ -133,7 +136,7 @@ class _PBLSTMFn(torch.autograd.Function):
         check(L.las_pblstm_bwd(ptr(x), ptr(dout), B, T_in, D_in, H, ptr(w_ih_f), ptr(w_hh_f), ptr(w_ih_r), ptr(w_hh_r),
                                ptr(reserve), ptr(work), ptr(dx), *[ptr(t) for t in g], ptr(_cabi.err_word(dev)),
                                ctx.flags, stream_ptr()))
-        return (dx, *([None] * 8 if ctx.direct else g))
+        return (None, dx, *([None] * 8 if ctx.direct else g))
 
 
 class pBLSTMLayer(nn.Module):
@@ -147,10 +150,13 @@ class pBLSTMLayer(nn.Module):
         self.rnn_unit = nn.LSTM          # attribute kept for parity with the reference (class object, :69)
         self.BLSTM = _LSTMParams(input_feature_dim * 2, hidden_dim, 1, bidirectional=True)
         self.dropout_rate = dropout_rate  # dropout on a 1-layer LSTM is a no-op in torch as well
+        self.force_generic = False        # see set_force_generic()
 
     def forward(self, input_x):
         p = self.BLSTM
-        out = _PBLSTMFn.apply(input_x, p.weight_ih_l0, p.weight_hh_l0, p.bias_ih_l0, p.bias_hh_l0,
+        if input_x.is_cuda:
+            _cabi.poll_device_errors(input_x.device)
+        out = _PBLSTMFn.apply(self.force_generic, input_x, p.weight_ih_l0, p.weight_hh_l0, p.bias_ih_l0, p.bias_hh_l0,
                               p.weight_ih_l0_reverse, p.weight_hh_l0_reverse, p.bias_ih_l0_reverse, p.bias_hh_l0_reverse)
         return out, None
 
@@ -233,8 +239,8 @@ def _speller_desc(B, Tp, D, Hs, V, M, L, use_mlp, relu, lstm, rest, heads=1):
 
 class _SpellerFn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, cfg, feat, labels, *params):
-        (U, teacher_forced, decode_mode, L, use_mlp, relu, M, V, heads) = cfg
+    def forward(ctx, cfg, feat, labels, noise, *params):
+        (U, teacher_forced, decode_mode, L, use_mlp, relu, M, V, heads, force_generic) = cfg
         feat = _f32c(feat)
         B, Tp, D = feat.shape
         direct = _direct_targets(params)
@@ -260,9 +266,13 @@ class _SpellerFn(torch.autograd.Function):
         logp = torch.empty(U, B, V, device=dev, dtype=torch.float32)
         att = torch.empty(U, heads, B, Tp, device=dev, dtype=torch.float32)
         reserve = torch.empty(Lh.las_speller_reserve_floats(d, U), device=dev, dtype=torch.float32)
+        if noise is not None:
+            noise = _f32c(noise)
+            if tuple(noise.shape) != (U, B, V):
+                raise RuntimeError(f"decode_mode 2 needs Exp(1) draws of shape {(U, B, V)}, got {tuple(noise.shape)}")
         check(Lh.las_speller_fwd(d, ptr(feat), ptr(keys), ptr(labels) if teacher_forced else None, u_lab, U,
-                                 int(teacher_forced), decode_mode, ptr(logp), ptr(att), None, ptr(reserve),
-                                 ptr(_cabi.err_word(dev)), _flags(True), stream))
+                                 int(teacher_forced), decode_mode, ptr(noise), ptr(logp), ptr(att), None, ptr(reserve),
+                                 ptr(_cabi.err_word(dev)), _flags(True, force_generic), stream))
         ctx.mark_non_differentiable(att)
         if any(ctx.needs_input_grad):
             ctx.save_for_backward(feat, keys, logp, att, reserve, *params)
@@ -274,7 +284,7 @@ class _SpellerFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, dlogp, _datt):
         feat, keys, logp, att, reserve, *params = ctx.saved_tensors
-        (U, teacher_forced, decode_mode, L, use_mlp, relu, M, V, heads) = ctx.cfg
+        (U, teacher_forced, decode_mode, L, use_mlp, relu, M, V, heads, force_generic) = ctx.cfg
         B, Tp, D, Hs = ctx.dims
         dev = feat.device
         dlogp = _f32c(dlogp)
@@ -298,8 +308,8 @@ class _SpellerFn(torch.autograd.Function):
         work = torch.empty(Lh.las_speller_bwd_workspace_floats(d, U), device=dev, dtype=torch.float32)
         mode0 = int((not teacher_forced) and decode_mode == 0)
         check(Lh.las_speller_bwd(d, ptr(feat), ptr(keys), ptr(logp), ptr(att), ptr(dlogp), U, mode0, ptr(reserve),
-                                 ptr(work), g, ptr(_cabi.err_word(dev)), _flags(True), stream_ptr()))
-        return (None, dfeat, None, *([None] * len(grads) if ctx.direct else grads))
+                                 ptr(work), g, ptr(_cabi.err_word(dev)), _flags(True, force_generic), stream_ptr()))
+        return (None, dfeat, None, None, *([None] * len(grads) if ctx.direct else grads))
 
 
 class Speller(nn.Module):
@@ -326,6 +336,8 @@ class Speller(nn.Module):
                                    multi_head=multi_head)
         self.character_distribution = nn.Linear(hidden_size * 2, vocab_size)
         self.softmax = nn.LogSoftmax(dim=-1)   # attribute parity only; the log-softmax is fused in the step kernel
+        self.force_generic = False             # see set_force_generic()
+        self.sample_noise = None               # decode_mode 2: optional caller-supplied Exp(1) draws (U,B,V)
 
     def _params(self):
         ps = []
@@ -344,10 +356,19 @@ class Speller(nn.Module):
         a = self.attention
         use_mlp = bool(a.mlp_preprocess_input)
         cfg = (int(steps), bool(teacher_force), int(self.decode_mode), int(self.num_layers), use_mlp,
-               a.activate == "relu", int(a.preprocess_mlp_dim) if use_mlp else 0, int(self.label_dim), int(a.multi_head))
+               a.activate == "relu", int(a.preprocess_mlp_dim) if use_mlp else 0, int(self.label_dim), int(a.multi_head),
+               bool(self.force_generic))
+        noise = None
         if not teacher_force and self.decode_mode not in (0, 1):
-            raise NotImplementedError("decode_mode 2 (Categorical sampling, reference las_model.py:229-234) is not implemented")
-        return _SpellerFn.apply(cfg, listener_feature, ground_truth if teacher_force else None, *self._params())
+            # decode_mode 2 (reference las_model.py:229-234): one Categorical(raw_pred).sample() per step, which torch
+            # evaluates as argmax_v p_v / q_v with q ~ Exp(1) drawn from the device's generator, one (B,V) draw per step.
+            # ``sample_noise`` (U,B,V) lets a caller (or a test pinning the reference's stream) supply the draws.
+            noise = self.sample_noise
+            if noise is None:
+                B = listener_feature.shape[0]
+                noise = torch.stack([torch.empty(B, self.label_dim, device=listener_feature.device).exponential_(1)
+                                     for _ in range(int(steps))])
+        return _SpellerFn.apply(cfg, listener_feature, ground_truth if teacher_force else None, noise, *self._params())
 
     def forward(self, listener_feature, ground_truth=None, teacher_force_rate=0.9):
         if ground_truth is None:
@@ -358,6 +379,8 @@ class Speller(nn.Module):
             max_step = self.max_label_len
         else:
             max_step = ground_truth.size()[1]
+        if listener_feature.is_cuda:
+            _cabi.poll_device_errors(listener_feature.device)
         logp, att = self._run(listener_feature, ground_truth, teacher_force, max_step)
         raw_pred_seq = list(logp.unbind(0))                 # list[U] of (B,V)   (callers cat them, solver.py:68)
         attention_record = [list(a.unbind(0)) for a in att.unbind(0)]     # list[U] of list[heads] of (B,T')

@@ -1,123 +1,229 @@
-"""Caller-side counterpart of the reference's ``solver/solver.py`` (the code that CALLS the hot path):
-``batch_iterator`` (fwd -> loss -> bwd -> clip 1.0 -> optimizer step), ``label_smoothing_loss`` and
-``LetterErrorRate``.  Same names, argument meaning and return values as the reference
-(solver/solver.py:11-24,33-45,48-101), so a ``train.py``-style driver can import it unchanged.
-The reference's ``editdistance`` C extension is replaced by a small Levenshtein (not installed here)."""
+"""The code that CALLS the hot path: this build's counterpart of the reference's ``solver/solver.py``.
+
+Only the public names, argument meaning and return values follow the reference (``LetterErrorRate`` :11-24,
+``label_smoothing_loss`` :33-45, ``batch_iterator`` :48-101) so that a ``train.py``-style driver imports it unchanged;
+the bodies are organised around the device path:
+
+* the loss of a training step and its gradient come from ONE HIP kernel (``las_ls_loss``) reading the ``(U,B,V)``
+  log-prob buffer the decode kernel wrote and the int64 one-hot labels as the collate function delivers them,
+* the letter error rate is computed on the GPU (``las_letter_error_rate``), so a step costs one small device-to-host
+  copy instead of the reference's three ``.cpu().numpy()`` round trips,
+* with a ``FlatGradAllReducer`` attached to the model (data parallel, or just to get the flat gradient buffer) the
+  gradients are zeroed / all-reduced / clipped on that one buffer,
+* the device error word of the persistent kernels is read where the host synchronises anyway (the loss copy).
+"""
 from __future__ import annotations
 
 import numpy as np
 import torch
-import torch.nn as nn
+import torch.nn.functional as F
+
+CLIP_NORM = 1.0     # the reference hard-codes clip_grad_norm_(..., 1) (solver/solver.py:96; the YAML's max_norm is unused)
 
 
-def _edit_distance(a, b):
-    a, b = list(a), list(b)
-    prev = list(range(len(b) + 1))
-    for i, ca in enumerate(a, 1):
-        cur = [i]
-        for j, cb in enumerate(b, 1):
-            cur.append(min(prev[j] + 1, cur[j - 1] + 1, prev[j - 1] + (ca != cb)))
-        prev = cur
-    return prev[-1]
+# --------------------------------------------------------------------------------------------------
+# letter error rate
+# --------------------------------------------------------------------------------------------------
+def _levenshtein(a: np.ndarray, b: np.ndarray) -> int:
+    """Edit distance between two symbol arrays, one DP row at a time, vectorised over the row (the reference calls
+    the ``editdistance`` C extension, which is not installed here)."""
+    if len(a) < len(b):
+        a, b = b, a
+    if len(b) == 0:
+        return int(len(a))
+    row = np.arange(len(b) + 1)
+    for sym in a:
+        diag = row[:-1] + (b != sym)                    # substitution / match
+        up = row[1:] + 1                                # deletion
+        best = np.minimum(diag, up)
+        new = np.empty_like(row)
+        new[0] = row[0] + 1
+        # insertion is a running "previous + 1" minimum: new[j] = min(best[j-1], new[j-1] + 1)
+        shifted = np.concatenate(([new[0]], best)) - np.arange(len(b) + 1)
+        new = np.minimum.accumulate(shifted) + np.arange(len(b) + 1)
+        row = new
+    return int(row[-1])
+
+
+def _strip_prediction(seq: np.ndarray) -> np.ndarray:
+    """Symbols of a decoded row up to (excluding) the first <eos>=1, with the <sos>/pad symbol 0 removed."""
+    stop = np.flatnonzero(seq == 1)
+    if stop.size:
+        seq = seq[:stop[0]]
+    return seq[seq != 0]
 
 
 def LetterErrorRate(pred_y, true_y):
-    """solver/solver.py:11-24."""
-    ed_accumalate = []
-    for p, t in zip(pred_y, true_y):
-        compressed_t = [w for w in t if (w != 1 and w != 0)]
-        compressed_p = []
-        for p_w in p:
-            if p_w == 0:
-                continue
-            if p_w == 1:
-                break
-            compressed_p.append(p_w)
-        ed_accumalate.append(_edit_distance(compressed_p, compressed_t) / len(compressed_t))
-    return ed_accumalate
-
-
-class _LSLossFn(torch.autograd.Function):
-    """label_smoothing_loss and its gradient in one HIP kernel (las_ls_loss); pred_y (B,U,V) log-probs on the GPU,
-    labels int64 one-hot (B,U_lab,V)."""
-
-    @staticmethod
-    def forward(ctx, pred_y, labels, smoothing):
-        from .. import _cabi
-        pred_y = pred_y.contiguous()
-        B, U, V = pred_y.shape
-        labels = labels.contiguous()
-        L = _cabi.lib()
-        loss = torch.empty(1, device=pred_y.device)
-        scratch = torch.empty(B, device=pred_y.device)
-        dlogp = torch.empty_like(pred_y) if ctx.needs_input_grad[0] else None
-        _cabi.check(L.las_ls_loss(_cabi.ptr(pred_y), V, U * V, _cabi.ptr(labels), U, labels.shape[1], B, V, float(smoothing),
-                                  _cabi.ptr(loss), _cabi.ptr(dlogp), V, U * V, _cabi.ptr(scratch), _cabi.stream_ptr()))
-        ctx.dlogp = dlogp
-        return loss[0]
-
-    @staticmethod
-    def backward(ctx, g):
-        return ctx.dlogp * g, None, None
-
-
-def label_smoothing_loss_device(pred_y, labels_onehot_int64, label_smoothing=0.1):
-    """Fused on-device form of ``label_smoothing_loss`` (same value and gradient; SURVEY.md section 8f-1)."""
-    return _LSLossFn.apply(pred_y, labels_onehot_int64, label_smoothing)
+    """Per-utterance edit distance between the decoded and the true character sequence, divided by the true length
+    (reference solver/solver.py:11-24: 0 and 1 are dropped from the truth; the prediction skips 0 and stops at the
+    first 1).  ``pred_y`` / ``true_y``: integer arrays (B, U).  Returns a list of B floats; an utterance whose label
+    holds no symbol >= 2 raises ZeroDivisionError, as in the reference."""
+    rates = []
+    for hyp, ref in zip(np.asarray(pred_y), np.asarray(true_y)):
+        ref = ref[ref > 1]
+        if ref.size == 0:
+            raise ZeroDivisionError("LetterErrorRate: a label without any character (solver/solver.py:23)")
+        rates.append(_levenshtein(_strip_prediction(hyp), ref) / int(ref.size))
+    return rates
 
 
 def LetterErrorRate_device(pred_y, labels_onehot_int64):
-    """LetterErrorRate (solver/solver.py:11-24) computed on the GPU from log-probs (B,U,V) and int64 one-hot labels;
-    returns a (B,) float tensor on the device (one host copy when the caller wants the list)."""
+    """The same quantity from log-probs (B,U,V) and int64 one-hot labels without leaving the GPU; returns a (B,)
+    float tensor on the device."""
     from .. import _cabi
-    pred_y = pred_y.detach().contiguous()
+    pred_y = pred_y.detach()
+    if pred_y.dtype != torch.float32:
+        raise RuntimeError("LetterErrorRate_device needs fp32 log-probs")
     B, U, V = pred_y.shape
     labels = labels_onehot_int64.contiguous()
     out = torch.empty(B, device=pred_y.device)
     work = torch.empty(4 * B * (U + 1), dtype=torch.int32, device=pred_y.device)
-    _cabi.check(_cabi.lib().las_letter_error_rate(_cabi.ptr(pred_y), V, U * V, _cabi.ptr(labels), U, labels.shape[1], B, V,
-                                                  _cabi.ptr(out), _cabi.ptr(work), _cabi.stream_ptr()))
+    _cabi.check(_cabi.lib().las_letter_error_rate(_cabi.ptr_strided(pred_y), pred_y.stride(1), pred_y.stride(0), _cabi.ptr(labels), U,
+                                                  labels.shape[1], B, V, _cabi.ptr(out), _cabi.ptr(work), _cabi.stream_ptr()))
     return out
 
 
+# --------------------------------------------------------------------------------------------------
+# losses
+# --------------------------------------------------------------------------------------------------
 def label_smoothing_loss(pred_y, true_y, label_smoothing=0.1):
-    """solver/solver.py:33-45 (pred_y log-probs (B,U,V); true_y one-hot floats padded with all-zero rows)."""
-    assert pred_y.size() == true_y.size()
-    seq_len = torch.sum(torch.sum(true_y, dim=-1), dim=-1, keepdim=True)
-    class_dim = true_y.size()[-1]
-    smooth_y = ((1.0 - label_smoothing) * true_y + (label_smoothing / class_dim)) * torch.sum(true_y, dim=-1, keepdim=True)
-    loss = -torch.mean(torch.sum((torch.sum(smooth_y * pred_y, dim=-1) / seq_len), dim=-1))
-    return loss
+    """Label-smoothed cross entropy of the reference (solver/solver.py:33-45) for log-probs ``pred_y`` (B,U,V) and
+    one-hot float labels ``true_y`` (B,U,V) whose padding rows are all zero:
+
+        target[b,u,:] = ((1-eps) * y + eps/V) on labelled steps, 0 on padded ones
+        loss = - mean_b  sum_u <target[b,u], logp[b,u]> / (number of labelled steps of b)
+
+    Plain torch (any device); the training step uses the fused HIP form below."""
+    if pred_y.shape != true_y.shape:
+        raise AssertionError(f"label_smoothing_loss: {tuple(pred_y.shape)} vs {tuple(true_y.shape)}")
+    V = true_y.shape[-1]
+    labelled = true_y.sum(dim=-1, keepdim=True)                        # (B,U,1): 1 on real steps, 0 on padding
+    target = labelled * ((1.0 - label_smoothing) * true_y + label_smoothing / V)
+    per_step = (target * pred_y).sum(dim=-1)                            # (B,U)
+    per_utt = per_step.sum(dim=-1, keepdim=True) / labelled.sum(dim=(1, 2)).unsqueeze(-1)
+    return -per_utt.sum(dim=-1).mean()
+
+
+class _FusedSmoothedLoss(torch.autograd.Function):
+    """``las_ls_loss``: value and d(loss)/d(logp) in one launch.  ``logp`` may be any (B,U,V) view with unit stride
+    along V — in particular the transposed view of the decode kernel's (U,B,V) buffer — so no copy is made."""
+
+    @staticmethod
+    def forward(ctx, logp, labels, smoothing):
+        from .. import _cabi
+        if logp.dtype != torch.float32 or logp.stride(2) != 1:
+            logp = logp.float().contiguous()
+        B, U, V = logp.shape
+        labels = labels.contiguous()
+        dev = logp.device
+        loss = torch.empty(1, device=dev)
+        scratch = torch.empty(B, device=dev)
+        # the gradient is laid out like its input (for the (U,B,V)-based view: step-major), so that it reaches the decode
+        # kernel's backward as a contiguous (U,B,V) tensor without a transposing copy
+        grad = torch.empty_like(logp) if ctx.needs_input_grad[0] else None
+        if grad is not None and grad.stride(2) != 1:
+            grad = torch.empty(B, U, V, device=dev)
+        gs = (grad.stride(1), grad.stride(0)) if grad is not None else (V, U * V)
+        _cabi.check(_cabi.lib().las_ls_loss(_cabi.ptr_strided(logp), logp.stride(1), logp.stride(0), _cabi.ptr(labels), U,
+                                            labels.shape[1], B, V, float(smoothing), _cabi.ptr(loss), _cabi.ptr_strided(grad),
+                                            gs[0], gs[1], _cabi.ptr(scratch), _cabi.stream_ptr()))
+        ctx.grad = grad
+        return loss[0]
+
+    @staticmethod
+    def backward(ctx, upstream):
+        return ctx.grad * upstream, None, None
+
+
+def label_smoothing_loss_device(pred_y, labels_onehot_int64, label_smoothing=0.1):
+    """Fused on-device form of ``label_smoothing_loss`` (same value and gradient; SURVEY.md section 8f-1)."""
+    return _FusedSmoothedLoss.apply(pred_y, labels_onehot_int64, label_smoothing)
+
+
+# --------------------------------------------------------------------------------------------------
+# one step
+# --------------------------------------------------------------------------------------------------
+def stack_steps(step_logp, steps=None):
+    """The list of per-step ``(B,V)`` log-prob tensors as one ``(B,steps,V)`` tensor (what the reference builds with
+    ``torch.cat([unsqueeze(each, 1) ...])``, solver/solver.py:68).  When the steps are the ``unbind`` views of one
+    ``(U,B,V)`` buffer — the HIP Speller returns exactly that — the result is a transposed VIEW of the buffer: no copy
+    forward, and the gradient flows back into the buffer's own layout."""
+    steps = len(step_logp) if steps is None else steps
+    first = step_logp[0]
+    base = getattr(first, "_base", None)
+    if (base is not None and base.dim() == 3 and base.shape[0] >= steps and base.is_contiguous()
+            and all(t._base is base and t.data_ptr() == base.data_ptr() + i * base.stride(0) * base.element_size()
+                    for i, t in enumerate(step_logp[:steps]))):
+        return (base if steps == base.shape[0] else base[:steps]).transpose(0, 1)
+    return torch.stack(list(step_logp[:steps]), dim=1)
+
+
+def _on_hip_path(logp, labels):
+    return logp.is_cuda and labels.dtype == torch.int64 and logp.dtype == torch.float32
+
+
+def _attached_reducer(model):
+    return getattr(model, "_las_flat_reducer", None)
+
+
+def _loss_and_ler(logp, labels, steps, smoothed, label_smoothing):
+    """``logp`` (B,steps,V) log-probs, ``labels`` (B,U_lab,V) one-hot (int64 from the collate function, or float)."""
+    if _on_hip_path(logp, labels):
+        ler = LetterErrorRate_device(logp, labels)
+        if smoothed:
+            return label_smoothing_loss_device(logp, labels, label_smoothing), ler
+        target_idx = labels[:, :steps].argmax(dim=-1)
+        return F.nll_loss(logp.transpose(1, 2), target_idx, ignore_index=0), ler
+    # host / float-label path: the torch forms (used by the CPU tests of this module against the golden vectors)
+    onehot = labels[:, :steps].to(torch.float32)
+    target_idx = onehot.argmax(dim=-1)
+    ler = LetterErrorRate(logp.argmax(dim=-1).cpu().numpy(), target_idx.cpu().numpy())
+    if smoothed:
+        return label_smoothing_loss(logp, onehot, label_smoothing=label_smoothing), ler
+    return F.nll_loss(logp.transpose(1, 2), target_idx, ignore_index=0), ler
 
 
 def batch_iterator(batch_data, batch_label, las_model, optimizer, tf_rate, is_training, max_label_len, label_smoothing,
                    use_gpu=True, vocab_dict=None, grad_hook=None):
-    """solver/solver.py:48-101.  ``grad_hook`` (optional, not in the reference) runs between backward and the
-    clip — the data-parallel driver all-reduces the flat gradient there."""
-    max_label_len = min([batch_label.size()[1], max_label_len])
-    criterion = nn.NLLLoss(ignore_index=0)
-    optimizer.zero_grad()
-    raw_pred_seq, _ = las_model(batch_data=batch_data, batch_label=batch_label, teacher_force_rate=tf_rate,
-                                is_training=is_training)
-    pred_y = (torch.cat([torch.unsqueeze(each_y, 1) for each_y in raw_pred_seq], 1)[:, :max_label_len, :]).contiguous()
-    if label_smoothing == 0.0 or not (is_training):
-        pred_y = pred_y.permute(0, 2, 1)
-        true_y = torch.max(batch_label, dim=2)[1][:, :max_label_len].contiguous()
-        loss = criterion(pred_y, true_y)
-        batch_ler = LetterErrorRate(torch.max(pred_y.permute(0, 2, 1), dim=2)[1].cpu().numpy(), true_y.cpu().data.numpy())
-    elif pred_y.is_cuda and batch_label.dtype == torch.int64:
-        # device path: fused loss(+gradient) kernel and on-device LER: one host copy per batch instead of three
-        loss = label_smoothing_loss_device(pred_y, batch_label, label_smoothing)
-        batch_ler = LetterErrorRate_device(pred_y, batch_label).cpu().tolist()
+    """One batch through the model: forward, loss, and when ``is_training`` backward, clip at 1.0 and the optimizer
+    step (reference solver/solver.py:48-101; same arguments, returns ``(loss as a NumPy scalar, list of per-utterance
+    letter error rates)``).  ``use_gpu`` / ``vocab_dict`` are accepted for signature parity; tensors stay on the device
+    they arrive on.
+
+    Data parallel: attach a ``las_pytorch_amd.dp.FlatGradAllReducer`` to the model (its constructor does) and this
+    function zeroes, all-reduces and clips the flat gradient buffer; the teacher-forcing coin is synchronised across
+    ranks first.  ``grad_hook(model)`` (optional) runs between backward and the clip for callers that exchange
+    gradients themselves."""
+    from .. import _cabi, dp
+    steps = min(int(batch_label.shape[1]), int(max_label_len))
+    reducer = _attached_reducer(las_model)
+    if reducer is not None:
+        reducer.zero()                        # keeps every p.grad a view of the flat buffer
     else:
-        true_y = batch_label[:, :max_label_len, :].contiguous().type(torch.float32)
-        loss = label_smoothing_loss(pred_y, true_y, label_smoothing=label_smoothing)
-        batch_ler = LetterErrorRate(torch.max(pred_y, dim=2)[1].cpu().numpy(), torch.max(true_y, dim=2)[1].cpu().data.numpy())
+        optimizer.zero_grad()
+    dp.sync_coin()                            # no-op outside a multi-rank process group
+
+    step_logp, _ = las_model(batch_data=batch_data, batch_label=batch_label, teacher_force_rate=tf_rate, is_training=is_training)
+    if len(step_logp) < steps:
+        raise RuntimeError(f"the model decoded {len(step_logp)} steps but {steps} are scored")
+    logp = stack_steps(step_logp, steps)                     # (B,steps,V); a strided view when the steps share one buffer
+    smoothed = bool(is_training) and label_smoothing != 0.0
+    loss, ler = _loss_and_ler(logp, batch_label, steps, smoothed, label_smoothing)
+
     if is_training:
         loss.backward()
         if grad_hook is not None:
             grad_hook(las_model)
-        torch.nn.utils.clip_grad_norm_(las_model.parameters(), 1)
+        if reducer is not None:
+            reducer.allreduce_mean()
+            reducer.clip_(CLIP_NORM)
+        else:
+            torch.nn.utils.clip_grad_norm_(las_model.parameters(), CLIP_NORM)
         optimizer.step()
-    batch_loss = loss.cpu().data.numpy()
-    return batch_loss, batch_ler
+
+    batch_loss = loss.detach().cpu().numpy()                 # the step's host synchronisation point
+    if torch.is_tensor(ler):
+        ler = ler.cpu().tolist()
+    if logp.is_cuda:
+        _cabi.check_device_errors()           # a hand-off timeout in a persistent kernel invalidates this step: raise
+    return batch_loss, ler

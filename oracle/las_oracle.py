@@ -208,7 +208,21 @@ def speller_step(input_word, hidden, feat, sd, *, num_layers, use_mlp=True, acti
     return torch.log_softmax(logits, dim=-1), (torch.stack(h), torch.stack(c)), ctx, scores
 
 
-def las_forward(x, labels, sd, cfg, *, teacher_force, is_training=True):
+def categorical_sampler(noise):
+    """decode_mode 2 (model/las_model.py:229-234) as torch evaluates ``Categorical(raw_pred).sample()``: the log-probs
+    passed as ``probs`` are renormalised (p = logp / sum logp, proportional to |log p|) and one sample is drawn as
+    argmax_v p_v / q_v with q ~ Exp(1) (torch.multinomial's single-draw path).  ``noise`` (U,B,V) holds the q draws in
+    the order the reference consumes them (one (B,V) draw per decode step); returns a ``sample_fn`` for
+    ``speller_forward``."""
+    it = iter(noise)
+
+    def sample(logp):
+        p = logp / logp.sum(dim=-1, keepdim=True)
+        return (p / next(it)).argmax(dim=-1)
+    return sample
+
+
+def las_forward(x, labels, sd, cfg, *, teacher_force, is_training=True, sample_fn=None):
     """model/las_model.py:30-40.  ``cfg`` keys: listener_layers, speller_layers,
     max_label_len, decode_mode, use_mlp, activate, multi_head."""
     feat = listener_forward(x, sd, cfg["listener_layers"])
@@ -217,7 +231,7 @@ def las_forward(x, labels, sd, cfg, *, teacher_force, is_training=True):
                            decode_mode=cfg["decode_mode"], ground_truth=gt,
                            teacher_force=teacher_force and is_training,
                            use_mlp=cfg.get("use_mlp", True), activate=cfg.get("activate", "relu"),
-                           multi_head=cfg.get("multi_head", 1))
+                           multi_head=cfg.get("multi_head", 1), sample_fn=sample_fn)
 
 
 # --------------------------------------------------------------------------------------

@@ -68,7 +68,7 @@ def stack(lst):
 
 
 def run_case(refmods, name, cfg_name, B, T, U, *, scale=None, seed=17, multi_head=1, use_mlp=True,
-             activate="relu", free_len=None, full=True, with_grads=True, ragged=False, sub_t=1, sub_d=1):
+             activate="relu", free_len=None, full=True, with_grads=True, ragged=False, sub_t=1, sub_d=1, light=False):
     LAS, Listener, Speller, batch_iterator, ls_loss = refmods
     c = synth.CONFIGS[cfg_name]
     shapes = synth.config_shapes(cfg_name, multi_head=multi_head, use_mlp=use_mlp)
@@ -109,15 +109,16 @@ def run_case(refmods, name, cfg_name, B, T, U, *, scale=None, seed=17, multi_hea
     top2 = np.sort(out["greedy_logp"], axis=-1)[..., -2:]
     out["greedy_margin"] = np.array([float((top2[..., 1] - top2[..., 0]).min())])
 
-    # G4: decode_mode 0 free-run (feeds log-probs back)
-    las.speller.decode_mode = 0
-    preds, _ = las(batch_data=x, batch_label=labels, teacher_force_rate=0.0, is_training=False)
-    out["mode0_logp"] = stack(preds)
-    las.speller.decode_mode = 1
+    # G4: decode_mode 0 free-run (feeds log-probs back); the headline-size ("light") cases keep the fixture small
+    if not light:
+        las.speller.decode_mode = 0
+        preds, _ = las(batch_data=x, batch_label=labels, teacher_force_rate=0.0, is_training=False)
+        out["mode0_logp"] = stack(preds)
+        las.speller.decode_mode = 1
 
     # G5: losses, grads, clip, Adam step
     if with_grads:
-        for kind, ls in (("ls", 0.1), ("nll", 0.0)):
+        for kind, ls in ((("ls", 0.1),) if light else (("ls", 0.1), ("nll", 0.0))):
             las.zero_grad()
             preds, _ = las(batch_data=x, batch_label=labels, teacher_force_rate=1.0, is_training=True)
             pred_y = torch.cat([p.unsqueeze(1) for p in preds], 1)
@@ -170,8 +171,76 @@ def main():
     # S / P LibriSpeech-shaped T=800: subsampled listener output, full log-probs
     run_case(refmods, "S_T800", "S", B=2, T=800, U=12, full=False, with_grads=False, sub_t=10, sub_d=8)
     run_case(refmods, "P_T800", "P", B=2, T=800, U=12, full=False, with_grads=False, sub_t=5, sub_d=16)
+    main_big(refmods)
 
 
+def main_big(refmods):
+    """Headline-size cases (BASELINE.json configs[1], [2], [4]): the backward pass of the persistent kernels at the sizes
+    the benchmark runs — 400-step BPTT chains on 256 resident workgroups, the attention backward split over 2 / 4 / 8
+    workgroups per utterance — pinned to the reference's loss, per-parameter gradient norms and 64-element gradient
+    slices, plus one whole solver step.  Stored subsampled ("light": no decode_mode-0 run, no NLL loss)."""
+    big = dict(full=False, light=True, sub_t=10, sub_d=32)
+    run_case(refmods, "P_B32_T800_U32", "P", B=32, T=800, U=32, **big)              # T'=100: 2 attention slices
+    run_case(refmods, "P_B16_T1600_U8", "P", B=16, T=1600, U=8, ragged=True, **big)  # T'=200: 4 slices
+    run_case(refmods, "P_B8_T3000_U16", "P", B=8, T=3000, U=16, **big)               # T'=375: 8 slices (configs[4])
+    run_case(refmods, "S_B32_T800_U32", "S", B=32, T=800, U=32, ragged=True, **big)  # T'=200
+    run_case(refmods, "S_B8_T3000_U8", "S", B=8, T=3000, U=8, **big)                 # T'=750
+
+
+
+
+def make_mode2_golden(refmods):
+    """decode_mode 2 (reference las_model.py:229-234, ``Categorical(raw_pred).sample()``): run the UNMODIFIED reference
+    with a seeded torch generator and store its log-probs together with the Exp(1) draws torch.multinomial consumed
+    (re-drawn from the same seed: one (B,V) ``exponential_`` per decode step is the loop's only use of the generator).
+    A consumer that evaluates the sample as argmax_v p_v / q_v, p = logp / sum logp, must reproduce the stream."""
+    LAS, Listener, Speller, _, _ = refmods
+    for name, cfg_name, B, T, U, scale, seed in (("tiny_mode2", "tiny", 3, 16, 9, 0.3, 41), ("S_mode2", "S", 4, 64, 12, None, 43)):
+        c = synth.CONFIGS[cfg_name]
+        sd_np = synth.make_state_dict(synth.config_shapes(cfg_name), seed=17, scale=scale)
+        x = torch.from_numpy(synth.make_inputs(B, T, c["F"], seed=17))
+        las = build_ref(LAS, Listener, Speller, c, sd_np, max_label_len=U, decode_mode=2)
+        torch.manual_seed(seed)
+        with torch.no_grad():
+            preds, _ = las(batch_data=x, batch_label=None, teacher_force_rate=0.0, is_training=False)
+        torch.manual_seed(seed)
+        noise = torch.stack([torch.empty(B, c["V"]).exponential_(1) for _ in range(U)])
+        logp = stack(preds)
+        # (tests/test_oracle_golden.py::test_decode_mode2_sampling_semantics replays the samples from the stored draws and
+        # must reproduce these log-probs at every step — that is what pins the stated semantics)
+        np.savez_compressed(os.path.join(HERE, name + ".npz"), cfg=np.array(cfg_name), dims=np.array([B, T, U, seed]),
+                            scale=np.array([-1.0 if scale is None else scale]), mode2_logp=logp, mode2_noise=noise.numpy())
+        print(f"{name}: argmax path {logp.argmax(-1)[:, 0].tolist()}")
+
+
+def make_collate_golden():
+    """The reference's own ``collate_fn`` (utils/data.py:116-149) on a synthetic ragged batch.  ``utils/data.py`` imports
+    torchaudio / enlighten / pydub at module top (unused by collate_fn): stubbed in sys.modules, nothing else is touched."""
+    for name in ("pydub", "python_speech_features", "editdistance", "enlighten", "torchaudio"):
+        if name not in sys.modules:
+            sys.modules[name] = types.ModuleType(name)
+    ta = sys.modules["torchaudio"]
+    ta.compliance = types.SimpleNamespace(kaldi=types.SimpleNamespace(fbank=None))
+    sys.modules["pydub"].AudioSegment = object
+    sys.modules["python_speech_features"].logfbank = None
+    sys.path.insert(0, REF)
+    from utils.data import OneHotEncode, collate_fn          # noqa: E402
+    rng = np.random.default_rng(7)
+    lens = [(211, 17), (96, 30), (160, 1), (33, 8), (200, 22)]
+    batch = []
+    for i, (t, u) in enumerate(lens):
+        feat = rng.standard_normal((t, 40)).astype(np.float32)
+        idx = rng.integers(2, 30, size=u)
+        targets = [OneHotEncode(j, 30) for j in idx]              # AudioDataset.__getitem__ (data.py:78-79)
+        batch.append((f"utt{i}", feat, t, targets, [len(r) for r in targets]))
+    ids, feature, label = collate_fn(batch)
+    np.savez_compressed(os.path.join(HERE, "collate_case.npz"), seed=np.array([7]), lens=np.array(lens),
+                        inputs_sum=np.array([feature["inputs"].double().sum().item(), feature["inputs"].double().abs().sum().item()]),
+                        inputs_shape=np.array(feature["inputs"].shape), inputs_tail=feature["inputs"][:, -8:, :4].numpy(),
+                        inputs_head=feature["inputs"][:, :4, :4].numpy(),
+                        inputs_length=feature["inputs_length"].numpy(), targets=label["targets"].numpy(),
+                        targets_length=label["targets_length"].numpy())
+    print("collate_case written:", tuple(feature["inputs"].shape), tuple(label["targets"].shape), feature["inputs"].dtype, label["targets"].dtype)
 
 
 def make_init_golden():
@@ -197,10 +266,22 @@ def make_init_golden():
 if __name__ == "__main__" and len(sys.argv) > 1 and sys.argv[1] == "init":
     make_init_golden()
 
+if __name__ == "__main__" and len(sys.argv) > 1 and sys.argv[1] == "extra":
+    torch.set_num_threads(8)
+    make_mode2_golden(import_reference())
+    make_collate_golden()
+
+if __name__ == "__main__" and len(sys.argv) > 1 and sys.argv[1] == "big":
+    torch.manual_seed(0)
+    torch.set_num_threads(8)
+    main_big(import_reference())
+
 
 if __name__ == "__main__" and len(sys.argv) == 1:
     main()
     make_init_golden()
+    make_mode2_golden(import_reference())
+    make_collate_golden()
 
 
 # tests/golden/ref_checkpoint_tiny.pth.tar: a checkpoint package written by the REFERENCE's own LAS.serialize

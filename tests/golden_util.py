@@ -8,6 +8,8 @@ from las_pytorch_amd import synth
 GOLDEN_DIR = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 ALL_CASES = ["tiny_default", "tiny_sat", "tiny_mh4", "tiny_nomlp", "tiny_noact",
              "S_short", "S_short_sat", "P_short", "P_short_sat", "S_T800", "P_T800"]
+# headline-size cases (BASELINE.json configs[1], [2], [4]); "light" fixtures: no decode_mode-0 run, no NLL loss
+BIG_CASES = ["P_B32_T800_U32", "P_B16_T1600_U8", "P_B8_T3000_U16", "S_B32_T800_U32", "S_B8_T3000_U8"]
 
 
 def load_case(name):
@@ -33,3 +35,29 @@ def oracle_cfg(info, max_label_len=None, decode_mode=1):
     return dict(listener_layers=c["L"], speller_layers=c["Ls"], max_label_len=max_label_len or info["free_len"],
                 decode_mode=decode_mode, use_mlp=info["use_mlp"], activate=info["activate"],
                 multi_head=info["multi_head"])
+
+
+def load_mode2_case(name):
+    """decode_mode-2 fixtures (tests/golden/make_golden.py::make_mode2_golden): returns (npz dict, config, weights, inputs)."""
+    g = dict(np.load(os.path.join(GOLDEN_DIR, name + ".npz")))
+    B, T, U, seed = [int(v) for v in g["dims"]]
+    scale = float(g["scale"][0])
+    cfg_name = str(g["cfg"])
+    c = synth.CONFIGS[cfg_name]
+    sd = synth.make_state_dict(synth.config_shapes(cfg_name), seed=17, scale=None if scale < 0 else scale)
+    x = synth.make_inputs(B, T, c["F"], seed=17)
+    return g, c, sd, x
+
+
+def collate_case_batch():
+    """The synthetic ragged batch of tests/golden/collate_case.npz, rebuilt from its recipe (seed + lengths): items as the
+    reference's AudioDataset.__getitem__ yields them (utils/data.py:63-82)."""
+    g = dict(np.load(os.path.join(GOLDEN_DIR, "collate_case.npz")))
+    rng = np.random.default_rng(int(g["seed"][0]))
+    batch = []
+    for i, (t, u) in enumerate(g["lens"]):
+        feat = rng.standard_normal((int(t), 40)).astype(np.float32)
+        idx = rng.integers(2, 30, size=int(u))
+        rows = [np.eye(30)[j] for j in idx]
+        batch.append((f"utt{i}", feat, int(t), rows, [len(r) for r in rows]))
+    return g, batch

@@ -82,6 +82,70 @@ def test_two_rank_allreduce_equals_full_batch_gradient(tmp_path):
     assert abs(float(t) - want_total) < 1e-5 * want_total
 
 
+class OracleLASModel(torch.nn.Module):
+    """The oracle behind the reference's LAS call signature (batch_data=, batch_label=, teacher_force_rate=, is_training=),
+    drawing the teacher-forcing coin from NumPy's global RNG exactly once per call like Speller.forward (las_model.py:189)."""
+
+    def __init__(self, sd_np, max_label_len):
+        super().__init__()
+        self.keys = list(sd_np.keys())
+        self.params = torch.nn.ParameterList([torch.nn.Parameter(torch.from_numpy(v.copy())) for v in sd_np.values()])
+        self.max_label_len = max_label_len
+        self.coins = []
+
+    def forward(self, batch_data, batch_label, teacher_force_rate, is_training=True):
+        sd = dict(zip(self.keys, self.params))
+        coin = bool(np.random.random_sample() < teacher_force_rate)
+        self.coins.append(coin)
+        return O.las_forward(batch_data, batch_label, sd, dict(listener_layers=2, speller_layers=2, max_label_len=self.max_label_len,
+                                                               decode_mode=1), teacher_force=coin, is_training=is_training)
+
+
+def _solver_worker(rank, world, port, out_dir):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    torch.set_num_threads(1)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from las_pytorch_amd.solver import solver as S
+        sd_np, x, onehot, U = _data()
+        model = OracleLASModel(sd_np, max_label_len=U)
+        dp.FlatGradAllReducer(model)                         # attaches itself: batch_iterator zeroes / all-reduces / clips it
+        opt = torch.optim.Adam(model.parameters(), lr=2e-4)
+        sl = dp.shard_batch(x.shape[0], rank, world)
+        np.random.seed(100 + rank)                           # different host RNG streams: only sync_coin keeps the coins equal
+        losses = []
+        for step in range(3):
+            loss, ler = S.batch_iterator(x[sl], onehot[sl], model, opt, tf_rate=0.5, is_training=True, max_label_len=U,
+                                         label_smoothing=0.1, use_gpu=False)
+            losses.append(float(loss))
+        # the documented foot-gun: zero_grad() with set_to_none drops the views -> the reducer refuses instead of reducing zeros
+        opt.zero_grad()
+        refused = False
+        try:
+            model._las_flat_reducer.allreduce_mean()
+        except RuntimeError:
+            refused = True
+        flat = torch.cat([p.detach().reshape(-1) for p in model.parameters()]).numpy()
+        np.savez(os.path.join(out_dir, f"s{rank}.npz"), params=flat, coins=np.array(model.coins), losses=np.array(losses), refused=refused)
+    finally:
+        dist.destroy_process_group()
+
+
+def test_batch_iterator_two_ranks_keeps_replicas_identical(tmp_path):
+    """solver.batch_iterator on two gloo ranks for three Adam steps with tf_rate=0.5: the teacher-forcing coin is shared,
+    the flat gradient is averaged before the clip, and the replicas end bit-identical (the zero_grad / stale
+    flat buffer divergence)."""
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    mp.start_processes(_solver_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True, start_method="spawn")
+    r0, r1 = np.load(tmp_path / "s0.npz"), np.load(tmp_path / "s1.npz")
+    assert r0["coins"].tolist() == r1["coins"].tolist() and len(r0["coins"]) == 3
+    np.testing.assert_array_equal(r0["params"], r1["params"])
+    assert bool(r0["refused"]) and bool(r1["refused"])
+    sd_np, _, _, _ = _data()
+    start = np.concatenate([v.reshape(-1) for v in sd_np.values()])
+    assert np.abs(r0["params"] - start).max() > 1e-5          # the optimizer really stepped
+
+
 def test_shard_batch():
     assert dp.shard_batch(32, 3, 8) == slice(12, 16)
     try:

@@ -5,12 +5,12 @@ import numpy as np
 import pytest
 import torch
 
-from golden_util import ALL_CASES, load_case, oracle_cfg
-from hip_util import assert_close, build_las
+from golden_util import ALL_CASES, BIG_CASES, load_case, oracle_cfg
+from hip_util import assert_close, build_las, grad_close, record
 
 pytestmark = pytest.mark.gpu
 
-HIP_CASES = list(ALL_CASES)
+HIP_CASES = list(ALL_CASES) + list(BIG_CASES)
 
 
 def _check_err():
@@ -43,10 +43,21 @@ def test_forward_golden(name):
         logp = torch.stack(preds).cpu().numpy()
         assert (logp.argmax(-1) == g["greedy_argmax"]).all(), f"{name}: greedy argmax sequence differs"
         assert_close(logp, g["greedy_logp"], f"{name}/greedy_logp")
-        las.speller.decode_mode = 0
-        preds, _ = las(batch_data=xt, batch_label=lab, teacher_force_rate=0.0, is_training=False)
-        assert_close(torch.stack(preds).cpu().numpy(), g["mode0_logp"], f"{name}/mode0_logp", rtol=2e-3, atol=2e-5)
+        if "mode0_logp" in g:
+            # decode_mode 0 feeds the log-probs back as the next input (las_model.py:220-221): rounding differences are
+            # re-amplified every step, so the deviation grows with the step index; observed worst is recorded
+            las.speller.decode_mode = 0
+            preds, _ = las(batch_data=xt, batch_label=lab, teacher_force_rate=0.0, is_training=False)
+            got = torch.stack(preds).cpu().numpy()
+            record(f"{name}/mode0_logp", max_abs_err=float(np.abs(got - g["mode0_logp"]).max()))
+            assert_close(got, g["mode0_logp"], f"{name}/mode0_logp")
     _check_err()
+
+
+# gradient tolerance: north-star 1e-3 relative + a floor of 1e-5 of the tensor's largest element (see hip_util.grad_close;
+# observed worst ratios per case are written to gpurun_out/parity_observed.jsonl and kept under profiles/)
+GRAD_RTOL = 1e-3
+GRAD_FLOOR = 1e-5
 
 
 def _loss_ls(preds, lab, U):
@@ -73,14 +84,15 @@ def test_grads_golden(name):
     total = np.sqrt((norms ** 2).sum())
     assert abs(total - g["gradtotal_ls"][0]) <= 2e-3 * g["gradtotal_ls"][0], (total, g["gradtotal_ls"][0])
     scale = float(g["gradnorm_ls"].max())
+    np.testing.assert_allclose(norms, g["gradnorm_ls"], rtol=1e-3, atol=1e-6 * scale)
     for (k, p), want_norm in zip(las.named_parameters(), g["gradnorm_ls"]):
         got = p.grad.cpu().numpy()
         want = g["grad/" + k]
         if not info["full"]:
             got = got.reshape(-1)[:: max(1, got.size // 64)][:64]
-        # gradients span orders of magnitude: tolerance relative to the element plus a floor tied to the tensor's norm
-        atol = 1e-5 * max(want_norm / np.sqrt(max(1, p.numel())), 1e-3 * scale / np.sqrt(max(1, p.numel()))) + 1e-9
-        assert_close(got, want, f"{name}/grad/{k}", rtol=3e-3, atol=max(atol, 2e-7))
+        # the 64-element slice of a big tensor can miss its large entries: scale the floor by the tensor's RMS as well
+        rms = want_norm / np.sqrt(max(1, p.numel()))
+        grad_close(got, want, f"{name}/grad/{k}", rtol=GRAD_RTOL, floor=GRAD_FLOOR * max(1.0, rms / (np.abs(want).max() + 1e-30)))
     _check_err()
 
 
@@ -96,7 +108,7 @@ def test_forward_backward_vs_oracle(cfg_name, B, T, U, scale):
     x = synth.make_inputs(B, T, c["F"], seed=5)
     idx, lens = synth.make_labels(B, U, c["V"], seed=5, ragged=True)
     onehot = synth.onehot_labels(idx, lens, c["V"])
-    big = B * T > 4000
+    big = False      # gradients are compared at every size, the full (32,800,80) LibriSpeech shape included
     # oracle (CPU)
     sd = O.to_torch_sd(sd_np, requires_grad=not big)
     xt = torch.from_numpy(x)
@@ -124,29 +136,25 @@ def test_forward_backward_vs_oracle(cfg_name, B, T, U, scale):
         assert abs(loss.item() - loss_o.item()) <= 1e-4 * abs(loss_o.item()) + 1e-6
         for k, p in las.named_parameters():
             want = sd[k].grad.numpy()
-            floor = 1e-5 * float(np.abs(want).max()) + 1e-9
-            assert_close(p.grad.cpu().numpy(), want, f"{cfg_name}/grad/{k}", rtol=3e-3, atol=max(floor, 2e-7))
+            grad_close(p.grad.cpu().numpy(), want, f"oracle_{cfg_name}_B{B}_T{T}/grad/{k}", rtol=GRAD_RTOL, floor=GRAD_FLOOR)
     _check_err()
 
 
 @pytest.mark.parametrize("cfg_name", ["S", "P"])
 def test_generic_and_fast_recurrence_agree(cfg_name):
     from las_pytorch_amd import synth
-    from las_pytorch_amd.model import las_model
+    from las_pytorch_amd.model.las_model import set_force_generic
     c = synth.CONFIGS[cfg_name]
     sd_np = synth.make_state_dict(synth.config_shapes(cfg_name), seed=9)
     x = torch.from_numpy(synth.make_inputs(4, 64, c["F"], seed=9)).cuda()
     las = build_las(c, sd_np, max_label_len=4)
     outs = []
     for force in (False, True):
-        las_model.FORCE_GENERIC_RECURRENCE = force
-        try:
-            xg = x.clone().requires_grad_(True)
-            feat = las.listener(xg)
-            feat.square().sum().backward()
-            outs.append((feat.detach().cpu().numpy(), xg.grad.cpu().numpy()))
-        finally:
-            las_model.FORCE_GENERIC_RECURRENCE = False
+        set_force_generic(las, force)
+        xg = x.clone().requires_grad_(True)
+        feat = las.listener(xg)
+        feat.square().sum().backward()
+        outs.append((feat.detach().cpu().numpy(), xg.grad.cpu().numpy()))
     assert_close(outs[0][0], outs[1][0], "feat fast vs generic", rtol=1e-4, atol=1e-6)
     assert_close(outs[0][1], outs[1][1], "dx fast vs generic", rtol=1e-3, atol=1e-5 * float(np.abs(outs[1][1]).max()))
     _check_err()
@@ -271,7 +279,7 @@ def test_edge_shapes_vs_oracle(cfg_name, B, T, U):
     loss.backward()
     for k, p in las.named_parameters():
         want = sd[k].grad.numpy()
-        assert_close(p.grad.cpu().numpy(), want, f"grad/{k}", rtol=3e-3, atol=max(1e-5 * float(np.abs(want).max()) + 1e-9, 2e-7))
+        grad_close(p.grad.cpu().numpy(), want, f"edge_{cfg_name}_B{B}_T{T}_U{U}/grad/{k}", rtol=GRAD_RTOL, floor=GRAD_FLOOR)
     _check_err()
 
 
@@ -297,7 +305,6 @@ def _persistent_vs_stepwise(cfg_name, B, Tp, U, scale, activate):
     covered against the reference's own outputs by the *_sat golden cases, which run through this kernel too)."""
     import ctypes
     from las_pytorch_amd import Speller, _cabi, synth
-    from las_pytorch_amd.model import las_model
     c = synth.CONFIGS[cfg_name]
     torch.manual_seed(5)
     sp = Speller(vocab_size=c["V"], hidden_size=c["Hs"], rnn_unit="LSTM", num_layers=c["Ls"], max_label_len=U,
@@ -317,7 +324,7 @@ def _persistent_vs_stepwise(cfg_name, B, Tp, U, scale, activate):
     trace = torch.zeros(2 * U * 8, dtype=torch.int64, device="cuda")
     res = []
     for force in (False, True):
-        las_model.FORCE_GENERIC_RECURRENCE = force
+        sp.force_generic = force
         L.las_debug_persist_trace(trace.data_ptr() if not force else None)
         try:
             sp.zero_grad(set_to_none=True)
@@ -328,7 +335,7 @@ def _persistent_vs_stepwise(cfg_name, B, Tp, U, scale, activate):
             res.append(dict(logp=logp.detach().cpu().numpy(), att=torch.stack([a[0] for a in att]).detach().cpu().numpy(),
                             dfeat=feat.grad.cpu().numpy(), **{"d" + n: p.grad.cpu().numpy() for n, p in sp.named_parameters()}))
         finally:
-            las_model.FORCE_GENERIC_RECURRENCE = False
+            sp.force_generic = False
             L.las_debug_persist_trace(None)
     torch.cuda.synchronize()
     assert int(trace.abs().sum().item()) != 0, "the persistent kernel did not run (shape not eligible?)"
@@ -349,20 +356,31 @@ def test_direct_gradient_write_matches_autograd_accumulation():
     idx, lens = synth.make_labels(4, 6, c["V"], seed=4)
     lab = torch.from_numpy(synth.onehot_labels(idx, lens, c["V"])).cuda()
     flats = []
-    try:
-        for direct in (False, True):
-            las_model.DIRECT_GRAD_WRITE = False
-            las = build_las(c, sd_np, max_label_len=6)
-            red = dp.FlatGradAllReducer(las, direct=direct)
-            assert las_model.DIRECT_GRAD_WRITE == direct
-            for _ in range(2):
-                red.zero()
-                preds, _ = las(x, lab, 1.0, True)
-                torch.stack(preds).square().mean().backward()
-                red.check_views()
-            flats.append(red.flat.detach().cpu().numpy().copy())
-    finally:
-        las_model.DIRECT_GRAD_WRITE = False
+    other = build_las(c, sd_np, max_label_len=6)       # a second model in the process: never tagged, must keep accumulating
+    for direct in (False, True):
+        las = build_las(c, sd_np, max_label_len=6)
+        red = dp.FlatGradAllReducer(las, direct=direct)
+        assert (las_model._direct_targets(list(las.parameters())) is not None) == direct
+        assert las_model._direct_targets(list(other.parameters())) is None
+        for _ in range(2):
+            red.zero()
+            preds, _ = las(x, lab, 1.0, True)
+            torch.stack(preds).square().mean().backward()
+            red.check_views()
+        flats.append(red.flat.detach().cpu().numpy().copy())
+    # the untagged model accumulates over two backward passes (micro-batching) even while a direct reducer exists
+    for _ in range(2):
+        preds, _ = other(x, lab, 1.0, True)
+        torch.stack(preds).square().mean().backward()
+    acc = torch.cat([p.grad.reshape(-1) for p in other.parameters()]).cpu().numpy()
+    assert_close(acc, 2 * flats[0], "accumulation of an untagged model", rtol=1e-4, atol=1e-6 * float(np.abs(flats[0]).max()))
+    # zero_grad() with set_to_none drops the views: the next backward falls back to autograd accumulation and the
+    # reducer refuses to all-reduce a stale buffer
+    las.zero_grad(set_to_none=True)
+    preds, _ = las(x, lab, 1.0, True)
+    torch.stack(preds).square().mean().backward()
+    with pytest.raises(RuntimeError):
+        red.allreduce_mean()
     assert np.abs(flats[0]).max() > 0
     # split-K GEMMs accumulate with atomics, so two runs agree only to fp32 rounding of the sum order
     assert_close(flats[1], flats[0], "direct vs accumulated flat gradient", rtol=1e-4, atol=1e-6 * float(np.abs(flats[0]).max()))
@@ -376,7 +394,6 @@ def test_persistent_free_running_decode_matches_stepwise(cfg_name, B, Tp, U, dec
     per-step launch chain: log-probabilities, attention, arg-max sequences, and (mode 1) the gradients."""
     import ctypes
     from las_pytorch_amd import Speller, _cabi, synth
-    from las_pytorch_amd.model import las_model
     c = synth.CONFIGS[cfg_name]
     torch.manual_seed(6)
     sp = Speller(vocab_size=c["V"], hidden_size=c["Hs"], rnn_unit="LSTM", num_layers=c["Ls"], max_label_len=U,
@@ -390,7 +407,7 @@ def test_persistent_free_running_decode_matches_stepwise(cfg_name, B, Tp, U, dec
     trace = torch.zeros(2 * U * 8, dtype=torch.int64, device="cuda")
     res = []
     for force in (False, True):
-        las_model.FORCE_GENERIC_RECURRENCE = force
+        sp.force_generic = force
         L.las_debug_persist_trace(trace.data_ptr() if not force else None)
         try:
             sp.zero_grad(set_to_none=True)
@@ -403,7 +420,7 @@ def test_persistent_free_running_decode_matches_stepwise(cfg_name, B, Tp, U, dec
             out.update({"d" + n: p.grad.cpu().numpy() for n, p in sp.named_parameters() if p.grad is not None})
             res.append(out)
         finally:
-            las_model.FORCE_GENERIC_RECURRENCE = False
+            sp.force_generic = False
             L.las_debug_persist_trace(None)
     torch.cuda.synchronize()
     assert int(trace.abs().sum().item()) != 0, "the persistent kernel did not run (shape not eligible?)"
@@ -411,4 +428,28 @@ def test_persistent_free_running_decode_matches_stepwise(cfg_name, B, Tp, U, dec
     for k in res[0]:
         scale_k = float(np.abs(res[1][k]).max()) + 1e-30
         assert_close(res[0][k], res[1][k], f"persistent vs stepwise free-running {k}", rtol=1e-3, atol=1e-5 * max(1.0, scale_k))
+    _check_err()
+
+
+@pytest.mark.parametrize("name", ["tiny_mode2", "S_mode2"])
+def test_decode_mode2_golden(name):
+    """decode_mode 2 (reference las_model.py:229-234) on the device from the reference's own Exp(1) draws: the sampled
+    symbols, hence the log-probs of every later step, equal the reference's."""
+    from golden_util import load_mode2_case
+    g, c, sd_np, x = load_mode2_case(name)
+    U = g["mode2_logp"].shape[0]
+    las = build_las(c, sd_np, max_label_len=U, decode_mode=2)
+    xt = torch.from_numpy(x).cuda()
+    las.speller.sample_noise = torch.from_numpy(g["mode2_noise"]).cuda()
+    with torch.no_grad():
+        preds, _ = las(batch_data=xt, batch_label=None, teacher_force_rate=0.0, is_training=False)
+    assert_close(torch.stack(preds).cpu().numpy(), g["mode2_logp"], f"{name}/mode2_logp")
+    # without caller-supplied draws the module draws its own (one (B,V) exponential_ per step on the device generator)
+    las.speller.sample_noise = None
+    torch.manual_seed(3)
+    with torch.no_grad():
+        a, _ = las(batch_data=xt, batch_label=None, teacher_force_rate=0.0, is_training=False)
+        torch.manual_seed(3)
+        b, _ = las(batch_data=xt, batch_label=None, teacher_force_rate=0.0, is_training=False)
+    assert torch.isfinite(torch.stack(a)).all() and torch.equal(torch.stack(a), torch.stack(b))
     _check_err()
