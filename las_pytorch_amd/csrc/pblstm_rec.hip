@@ -20,6 +20,7 @@
 #include "las_common.h"
 #include "las_kernels.h"
 #include <stdlib.h>
+#include <algorithm>
 
 namespace las {
 
@@ -243,6 +244,143 @@ __global__ __launch_bounds__(UW * (H / 16)) void rec_fwd_fast(float* __restrict_
     }
 }
 
+
+// ------------------------------------------------------------------------------------------------
+// Forward, register-resident W_hh, NB utterances per group ("multi").
+// One group (G workgroups, one per CU) keeps its W_hh slice in VGPRs and steps NB utterances of the same direction in
+// lock-step: per round every wave does its share of NB mat-vecs against the SAME resident weights, then NB*UW cell
+// threads (one wave per utterance at UW = 64) apply the cells and publish, while the remaining waves gather the other
+// members' h for all NB utterances.  The two barriers and the inter-CU hand-off latency of a step are paid once per NB
+// utterances, and the launch never needs more than 2*ceil(B/NB)*G <= #CU resident workgroups, whatever the batch.
+// ------------------------------------------------------------------------------------------------
+template <int H, int UW, int NB, bool STASH>
+__global__ __launch_bounds__(UW * (H / 16)) void rec_fwd_multi(float* __restrict__ gates, const float* __restrict__ w_hh_f,
+                                                               const float* __restrict__ w_hh_r, float* __restrict__ out,
+                                                               float* __restrict__ cbuf, float* __restrict__ hprev, int B,
+                                                               int T, u64* xbuf, unsigned* err, int force_agent, int b0,
+                                                               int Bc) {
+    // b0 / Bc: this launch steps utterances [b0, b0 + Bc) of the B in the buffers (host-side chunking of very large batches)
+    constexpr int LPU = H / 16;
+    constexpr int NT = UW * LPU;
+    constexpr int G = H / UW;
+    constexpr int NC = NB * UW;                 // cell threads: (utterance u, unit) = (tid / UW, tid % UW)
+    constexpr int PS = (NC + 63) / 64 * 64;     // pollers start on a wave boundary (see rec_fwd_fast)
+    static_assert(NC <= NT, "more cells than threads");
+    static_assert(G == 1 || NT > PS, "no polling threads");
+    __shared__ __attribute__((aligned(16))) float hs[2][NB][H];
+    __shared__ __attribute__((aligned(16))) float gsum[NB][UW][4];
+    __shared__ int xcd_flag;
+
+    const int nblk = (Bc + NB - 1) / NB;        // utterance blocks per direction
+    int group, member;
+    decode_block<G>(2 * nblk, group, member);
+    const bool l2x = !force_agent && same_xcd_group<G>(xbuf + (long)2 * nblk * 2 * NB * H + (long)group * XID_SLOTS, member, err, &xcd_flag);
+    const int dir = group & 1, blk = group >> 1;
+    const float* __restrict__ w_hh = dir ? w_hh_r : w_hh_f;
+    const int tid = threadIdx.x;
+    const int kc = tid % LPU, ul = tid / LPU;
+
+    f32x4 w[4][4];
+    {
+        const int j = member * UW + ul;
+#pragma unroll
+        for (int g = 0; g < 4; ++g)
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+                w[g][i] = *reinterpret_cast<const f32x4*>(w_hh + (long)(g * H + j) * H + i * 4 * LPU + kc * 4);
+    }
+    for (int i = tid; i < 2 * NB * H; i += NT) (&hs[0][0][0])[i] = 0.f;
+    __syncthreads();
+
+    const bool cellt = tid < NC;
+    const int cu = cellt ? tid / UW : 0;
+    const int jc = member * UW + (cellt ? tid % UW : 0);
+    const int b = b0 + blk * NB + cu;
+    const bool cell = cellt && blk * NB + cu < Bc;   // utterances past the chunk end are idle slots of the last block
+    const long seq = (long)(dir * B + (cell ? b : 0)) * T;
+    float* gb = gates + seq * 4 * H + jc;
+    float c = 0.f;
+    float pre[4] = {0.f, 0.f, 0.f, 0.f};
+    if (cell) {
+        const int t0 = dir ? T - 1 : 0;
+#pragma unroll
+        for (int g = 0; g < 4; ++g) pre[g] = gb[(long)t0 * 4 * H + g * H];
+    }
+    const bool poller = G > 1 && tid >= PS;
+    u64* xg = xbuf + (long)group * 2 * NB * H;   // [step parity][utterance][unit]
+    const int nvalid = min(NB, Bc - blk * NB);   // live utterances of this block
+
+    int cur = 0;
+    for (int step = 0; step < T; ++step) {
+        const int t = dir ? T - 1 - step : step;
+        const unsigned epoch = (unsigned)step + 1u;
+        REC_STAMP(0, step, 0); REC_STAMP(512, step, 0);
+        float nxt[4] = {0.f, 0.f, 0.f, 0.f};
+        if (cell && step + 1 < T) {
+            const int tn = dir ? t - 1 : t + 1;
+#pragma unroll
+            for (int g = 0; g < 4; ++g) nxt[g] = gb[(long)tn * 4 * H + g * H];
+        }
+#pragma unroll
+        for (int u = 0; u < NB; ++u) {
+            f32x4 hv[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) hv[i] = *reinterpret_cast<const f32x4*>(&hs[cur][u][i * 4 * LPU + kc * 4]);
+            float acc[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+#pragma unroll
+                    for (int g = 0; g < 4; ++g) acc[g] = fmaf(w[g][i][e], hv[i][e], acc[g]);
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                acc[g] = row_sum<(LPU < 16 ? LPU : 16)>(acc[g]);
+                if (LPU > 16) acc[g] += __shfl_xor(acc[g], 16);
+            }
+            if (kc == 0) *reinterpret_cast<f32x4*>(&gsum[u][ul][0]) = f32x4{acc[0], acc[1], acc[2], acc[3]};
+        }
+        REC_STAMP(0, step, 1); REC_STAMP(512, step, 1);
+        lds_barrier();
+        REC_STAMP(0, step, 2); REC_STAMP(512, step, 2);
+
+        if (cell) {
+            const f32x4 s4 = *reinterpret_cast<const f32x4*>(&gsum[cu][tid % UW][0]);
+            const float ig = sigmoidf_acc(s4[0] + pre[0]);
+            const float fg = sigmoidf_acc(s4[1] + pre[1]);
+            const float gg = tanhf_acc(s4[2] + pre[2]);
+            const float og = sigmoidf_acc(s4[3] + pre[3]);
+            c = fg * c + ig * gg;
+            const float h = og * tanhf_acc(c);
+            if (G > 1) {
+                u64* gp64 = xg + ((long)(step & 1) * NB + cu) * H + jc;
+                if (l2x) publish_granule_l2(gp64, epoch, h); else publish_granule(gp64, epoch, h);
+            }
+            const float hp = hs[cur][cu][jc];
+            hs[cur ^ 1][cu][jc] = h;
+            out[((long)b * T + t) * 2 * H + dir * H + jc] = h;
+            if (STASH) {
+                hprev[(seq + t) * H + jc] = hp;
+                cbuf[(seq + t) * H + jc] = c;
+                float* gp = gb + (long)t * 4 * H;
+                gp[0] = ig; gp[H] = fg; gp[2 * H] = gg; gp[3 * H] = og;
+            }
+#pragma unroll
+            for (int g = 0; g < 4; ++g) pre[g] = nxt[g];
+        } else if (poller) {
+            for (int fidx = tid - PS; fidx < nvalid * (H - UW); fidx += NT - PS) {
+                const int u = fidx / (H - UW), f = fidx % (H - UW);
+                const int fu = f < member * UW ? f : f + UW;                // foreign hidden unit index
+                hs[cur ^ 1][u][fu] = poll_granule(xg + ((long)(step & 1) * NB + u) * H + fu, epoch, err);
+            }
+        }
+        REC_STAMP(0, step, 3); REC_STAMP(512, step, 3);
+        lds_barrier();
+        REC_STAMP(0, step, 4); REC_STAMP(512, step, 4);
+        cur ^= 1;
+    }
+}
+
 // ------------------------------------------------------------------------------------------------
 // Forward, generic fallback: one workgroup per (utterance, direction), W_hh streamed from L2
 // ------------------------------------------------------------------------------------------------
@@ -428,6 +566,139 @@ __global__ __launch_bounds__(REC_THREADS) void rec_bwd_fast(const float* __restr
     }
 }
 
+
+// ------------------------------------------------------------------------------------------------
+// Backward (BPTT), register-resident W_hh^T, NB utterances per group.  Per round: every thread applies the cell
+// backward of its (utterance, unit) items (factors of the step were prepared in registers during the previous round),
+// barrier, NB mat-vecs dG_t W_hh against the resident weights, then — off the chain — the factors of the next step and
+// the gather of the other members' dh.  Same residency guarantee as rec_fwd_multi.
+// ------------------------------------------------------------------------------------------------
+template <int H, int NB>
+__global__ __launch_bounds__(REC_THREADS) void rec_bwd_multi(const float* __restrict__ dout, const float* __restrict__ gates,
+                                                             const float* __restrict__ cbuf, const float* __restrict__ w_hh_t,
+                                                             float* __restrict__ dgates, int B, int T, u64* xbuf,
+                                                             unsigned* err, int b0, int Bc) {
+    constexpr int LPU = H / 16;
+    constexpr int UW = REC_THREADS / LPU;
+    constexpr int G = H / UW;
+    constexpr int NI = NB * H;                                   // (utterance, unit) items per round
+    constexpr int CI = (NI + REC_THREADS - 1) / REC_THREADS;     // items per thread
+    extern __shared__ __attribute__((aligned(16))) float smem_rb[];
+    float (*dhs)[NB][H] = reinterpret_cast<float (*)[NB][H]>(smem_rb);                       // [2][NB][H]
+    float (*dgs)[4 * H] = reinterpret_cast<float (*)[4 * H]>(smem_rb + 2 * NB * H);          // [NB][4H]
+    __shared__ int xcd_flag;
+
+    const int nblk = (Bc + NB - 1) / NB;
+    int group, member;
+    decode_block<G>(2 * nblk, group, member);
+    const bool l2x = same_xcd_group<G>(xbuf + (long)2 * nblk * 2 * NB * H + (long)group * XID_SLOTS, member, err, &xcd_flag);
+    const int dir = group & 1, blk = group >> 1;
+    const int tid = threadIdx.x;
+    const int rc = tid % LPU, kl = tid / LPU;
+    const int k = member * UW + kl;
+    const float* __restrict__ wt = w_hh_t + ((long)dir * H + k) * 4 * H;
+
+    f32x4 w[16];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) w[i] = *reinterpret_cast<const f32x4*>(wt + i * 4 * LPU + rc * 4);
+
+    for (int i = tid; i < 2 * NB * H; i += REC_THREADS) (&dhs[0][0][0])[i] = 0.f;
+    u64* xg = xbuf + (long)group * 2 * NB * H;
+    const int nvalid = min(NB, Bc - blk * NB);
+
+    // per-item state: item index it = tid + q*REC_THREADS -> (u, j) = (it / H, it % H)
+    float dc[CI], fa[CI][7], p[CI][7];
+    bool live[CI];
+    long seqs[CI];
+#pragma unroll
+    for (int q = 0; q < CI; ++q) {
+        const int it = tid + q * REC_THREADS;
+        const int u = it / H;
+        live[q] = it < NI && blk * NB + u < Bc;
+        seqs[q] = (long)(dir * B + (live[q] ? b0 + blk * NB + u : 0)) * T;
+        dc[q] = 0.f;
+#pragma unroll
+        for (int e = 0; e < 7; ++e) { fa[q][e] = 0.f; p[q][e] = 0.f; }
+    }
+    auto load_step = [&](int q, int st) {                 // raw stash of processing step st -> p[q]
+        if (!live[q] || st >= T) return;
+        const int j = (tid + q * REC_THREADS) % H;
+        const int b = b0 + blk * NB + (tid + q * REC_THREADS) / H;
+        const int t = dir ? st : T - 1 - st;
+        const float* gp = gates + (seqs[q] + t) * 4 * H + j;
+        p[q][0] = gp[0]; p[q][1] = gp[H]; p[q][2] = gp[2 * H]; p[q][3] = gp[3 * H];
+        p[q][4] = cbuf[(seqs[q] + t) * H + j];
+        const int tp = dir ? t + 1 : t - 1;
+        p[q][5] = (tp >= 0 && tp < T) ? cbuf[(seqs[q] + tp) * H + j] : 0.f;
+        p[q][6] = dout[((long)b * T + t) * 2 * H + dir * H + j];
+    };
+    auto prepare = [&](int q) {                           // p[q] -> factors fa[q]: beta, a_i, a_f, a_g, a_o, f, dout
+        const float pi = p[q][0], pf = p[q][1], pg = p[q][2], po = p[q][3];
+        const float tc = tanhf_acc(p[q][4]);
+        fa[q][0] = po * (1.f - tc * tc); fa[q][1] = pg * pi * (1.f - pi); fa[q][2] = p[q][5] * pf * (1.f - pf);
+        fa[q][3] = pi * (1.f - pg * pg); fa[q][4] = tc * po * (1.f - po); fa[q][5] = pf; fa[q][6] = p[q][6];
+    };
+#pragma unroll
+    for (int q = 0; q < CI; ++q) { load_step(q, 0); prepare(q); load_step(q, 1); }
+    __syncthreads();
+
+    int cur = 0;
+    for (int step = 0; step < T; ++step) {
+        const int t = dir ? step : T - 1 - step;
+        const unsigned epoch = (unsigned)step + 1u;
+#pragma unroll
+        for (int q = 0; q < CI; ++q) {
+            const int it = tid + q * REC_THREADS;
+            if (it < NI) {
+                const int u = it / H, j = it % H;
+                const float dh = fa[q][6] + dhs[cur][u][j];
+                const float dct = dc[q] + dh * fa[q][0];
+                dc[q] = dct * fa[q][5];
+                const float gi = dct * fa[q][1], gf = dct * fa[q][2], gg = dct * fa[q][3], go = dh * fa[q][4];
+                dgs[u][j] = gi; dgs[u][H + j] = gf; dgs[u][2 * H + j] = gg; dgs[u][3 * H + j] = go;
+                if (live[q] && j / UW == member) {            // this workgroup's share of dG_t -> memory
+                    float* dp = dgates + (seqs[q] + t) * 4 * H + j;
+                    dp[0] = gi; dp[H] = gf; dp[2 * H] = gg; dp[3 * H] = go;
+                }
+            }
+        }
+        lds_barrier();
+#pragma unroll
+        for (int u = 0; u < NB; ++u) {
+            float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                const f32x4 d = *reinterpret_cast<const f32x4*>(&dgs[u][i * 4 * LPU + rc * 4]);
+                a0 = fmaf(w[i][0], d[0], a0); a1 = fmaf(w[i][1], d[1], a1);
+                a2 = fmaf(w[i][2], d[2], a2); a3 = fmaf(w[i][3], d[3], a3);
+            }
+            float acc = (a0 + a1) + (a2 + a3);
+            acc = row_sum<(LPU < 16 ? LPU : 16)>(acc);
+            if (LPU > 16) acc += __shfl_xor(acc, 16);
+            if (rc == 0) {
+                if (G > 1 && u < nvalid) {
+                    u64* gp64 = xg + ((long)(step & 1) * NB + u) * H + k;
+                    if (l2x) publish_granule_l2(gp64, epoch, acc); else publish_granule(gp64, epoch, acc);
+                }
+                dhs[cur ^ 1][u][k] = acc;
+            }
+        }
+        if (step + 1 < T) {
+#pragma unroll
+            for (int q = 0; q < CI; ++q) { prepare(q); load_step(q, step + 2); }
+        }
+        if (G > 1) {
+            for (int fidx = tid; fidx < nvalid * (H - UW); fidx += REC_THREADS) {
+                const int u = fidx / (H - UW), f = fidx % (H - UW);
+                const int fu = f < member * UW ? f : f + UW;
+                dhs[cur ^ 1][u][fu] = poll_granule(xg + ((long)(step & 1) * NB + u) * H + fu, epoch, err);
+            }
+        }
+        lds_barrier();
+        cur ^= 1;
+    }
+}
+
 __global__ __launch_bounds__(256) void rec_bwd_generic(const float* __restrict__ dout, const float* __restrict__ gates,
                                                        const float* __restrict__ cbuf, const float* __restrict__ w_hh_t,
                                                        float* __restrict__ dgates, int B, int T, int H) {
@@ -494,40 +765,86 @@ int transpose2d(const float* src, float* dst, int rows, int cols, hipStream_t st
     return LAS_OK;
 }
 
-size_t rec_xbuf_bytes(int B, int H) { return ((size_t)2 * B * 2 * H + (size_t)2 * B * XID_SLOTS) * sizeof(u64); }
+// granules [group][parity][utterance][unit] + XCC-id slots per group; groups*NB <= 2*(B + 15) for every NB <= 16
+size_t rec_xbuf_bytes(int B, int H) { return ((size_t)2 * (B + 15) * 2 * H + (size_t)2 * (B + 15) * XID_SLOTS) * sizeof(u64); }
 
 static bool fast_h(int H) { return H == 128 || H == 256 || H == 512; }
+
+static int device_cus() {
+    int dev = 0, cus = 0;
+    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) return 0;
+    return cus;
+}
+
+// Residency plan of the persistent recurrences: every workgroup of a launch must be resident at once (the members of a
+// group spin on each other), one workgroup per CU (1024 threads at >= 100 VGPRs).  Utterances per group (NB) are raised
+// until 2*ceil(Bc/NB)*G workgroups fit the device's CU count; batches beyond NB_max per group are stepped in several
+// launches of `chunk` utterances.  nb == 0: the device cannot hold even one group -> generic kernels.
+struct RecPlan { int nb, chunk; };
+static RecPlan rec_plan(int B, int G, int nb_min, int nb_max, int cus) {
+    const int blocks = cus / (2 * G);              // utterance blocks per direction that fit
+    if (blocks < 1) return {0, 0};
+    for (int nb = std::max(1, nb_min); nb <= nb_max; nb *= 2)
+        if ((B + nb - 1) / nb <= blocks) return {nb, B};
+    return {nb_max, blocks * nb_max};
+}
+static int env_int(const char* name, int dflt) { const char* v = getenv(name); return v ? atoi(v) : dflt; }
 
 int pblstm_rec_fwd(float* gates, const float* w_hh_f, const float* w_hh_r, float* out, float* cbuf, float* hprev, int B,
                    int T, int H, int stash, u64* xbuf, unsigned* err, int force_generic, hipStream_t stream) {
     LAS_REQUIRE(B > 0 && T > 0 && H > 0, "rec dims");
     LAS_REQUIRE(!stash || (cbuf && hprev), "stash buffers");
     const int ngroups = 2 * B;
-    if (fast_h(H) && !force_generic) {
+    // LAS_REC_AGENT_HANDOFF=1 forces the placement-independent agent-scope hand-off even when a group shares an XCD (A/B tests)
+    static const int dbg = env_int("LAS_REC_AGENT_HANDOFF", 0);
+    static const int uw_env = env_int("LAS_REC_UW", 0);
+    static const int nb_env = env_int("LAS_REC_NB", 0);          // force the utterances per group (A/B tests)
+    // UW: hidden units per workgroup (measured best on MI355X: one CU holds 256 KB of W_hh)
+    const int uw = uw_env > 0 ? uw_env : (H == 128 ? 128 : (H == 256 ? 64 : 32));
+    RecPlan plan = {0, 0};
+    if (fast_h(H) && !force_generic && H % uw == 0) {
+        const int nb_max = H == 128 ? 8 : (H == 256 ? 8 : 4);
+        plan = rec_plan(B, H / uw, std::min(nb_env, nb_max), nb_max, device_cus());
+        if (plan.nb > 1 && uw != (H == 128 ? 128 : (H == 256 ? 64 : 32))) plan.nb = 0;      // multi kernels exist for the default UW only
+    }
+    if (plan.nb > 0) {
         LAS_REQUIRE(xbuf && err, "hand-off buffers");
-        // LAS_REC_AGENT_HANDOFF=1 forces the placement-independent agent-scope hand-off even when a group shares an XCD (A/B tests)
-        static int dbg = getenv("LAS_REC_AGENT_HANDOFF") ? atoi(getenv("LAS_REC_AGENT_HANDOFF")) : 0;
-        static int uw_env = getenv("LAS_REC_UW") ? atoi(getenv("LAS_REC_UW")) : 0;
-        // UW: hidden units per workgroup.  Smaller UW = more CUs per sequence; two half-size workgroups per CU
-        // (UW=32 at H=256) let the hardware overlap one group's hand-off wait with the other's compute.
-        int uw = uw_env > 0 ? uw_env : (H == 128 ? 128 : (H == 256 ? 64 : 32));   // measured best on MI355X at B=32
-        LAS_HIP_CHECK(hipMemsetAsync(xbuf, 0, rec_xbuf_bytes(B, H), stream));
         const int G = H / uw;
-        dim3 grid(2 * B * G), block(uw * (H / 16));
-        bool launched = false;
+        for (int b0 = 0; b0 < B; b0 += plan.chunk) {
+            const int Bc = std::min(plan.chunk, B - b0);
+            const int nblk = (Bc + plan.nb - 1) / plan.nb;
+            LAS_HIP_CHECK(hipMemsetAsync(xbuf, 0, rec_xbuf_bytes(B, H), stream));
+            dim3 grid(2 * nblk * G), block(uw * (H / 16));
+            bool launched = false;
 #define TRY_FWD(HH, UWV)                                                                                                  \
-    if (!launched && H == HH && uw == UWV) {                                                                             \
+    if (!launched && plan.nb == 1 && H == HH && uw == UWV) {                                                             \
         launched = true;                                                                                                  \
+        float* g0 = gates; (void)g0;                                                                                      \
+        if (b0 != 0 || Bc != B) return fail(LAS_ERR_UNSUPPORTED, "chunked launch needs the multi kernel%s", "");          \
         if (stash) hipLaunchKernelGGL((rec_fwd_fast<HH, UWV, true>), grid, block, 0, stream, gates, w_hh_f, w_hh_r, out,  \
                                       cbuf, hprev, B, T, xbuf, err, dbg);                                                 \
         else hipLaunchKernelGGL((rec_fwd_fast<HH, UWV, false>), grid, block, 0, stream, gates, w_hh_f, w_hh_r, out, cbuf, \
                                 hprev, B, T, xbuf, err, dbg);                                                             \
     }
-        TRY_FWD(128, 128) TRY_FWD(128, 64) TRY_FWD(128, 32) TRY_FWD(128, 16)
-        TRY_FWD(256, 64) TRY_FWD(256, 32) TRY_FWD(256, 16)
-        TRY_FWD(512, 32) TRY_FWD(512, 16)
+#define TRY_FWD_M(HH, UWV, NBV)                                                                                           \
+    if (!launched && plan.nb == NBV && H == HH && uw == UWV) {                                                           \
+        launched = true;                                                                                                  \
+        if (stash) hipLaunchKernelGGL((rec_fwd_multi<HH, UWV, NBV, true>), grid, block, 0, stream, gates, w_hh_f, w_hh_r, \
+                                      out, cbuf, hprev, B, T, xbuf, err, dbg, b0, Bc);                                    \
+        else hipLaunchKernelGGL((rec_fwd_multi<HH, UWV, NBV, false>), grid, block, 0, stream, gates, w_hh_f, w_hh_r, out, \
+                                cbuf, hprev, B, T, xbuf, err, dbg, b0, Bc);                                               \
+    }
+            TRY_FWD(128, 128) TRY_FWD(128, 64) TRY_FWD(128, 32) TRY_FWD(128, 16)
+            TRY_FWD(256, 64) TRY_FWD(256, 32) TRY_FWD(256, 16)
+            TRY_FWD(512, 32) TRY_FWD(512, 16)
+            TRY_FWD_M(128, 128, 2) TRY_FWD_M(128, 128, 4) TRY_FWD_M(128, 128, 8)
+            TRY_FWD_M(256, 64, 2) TRY_FWD_M(256, 64, 4) TRY_FWD_M(256, 64, 8)
+            TRY_FWD_M(512, 32, 2) TRY_FWD_M(512, 32, 4)
 #undef TRY_FWD
-        if (!launched) return fail(LAS_ERR_UNSUPPORTED, "no recurrence kernel for %s H=%ld uw=%ld", "", (long)H, (long)uw);
+#undef TRY_FWD_M
+            if (!launched) return fail(LAS_ERR_UNSUPPORTED, "no recurrence kernel for %s H=%ld uw=%ld", "", (long)H, (long)uw);
+            LAS_LAUNCH_CHECK();
+        }
     } else {
         const size_t smem = sizeof(float) * 3 * H;
         if (stash) hipLaunchKernelGGL((rec_fwd_generic<true>), dim3(ngroups), dim3(256), smem, stream, gates, w_hh_f, w_hh_r,
@@ -539,18 +856,50 @@ int pblstm_rec_fwd(float* gates, const float* w_hh_f, const float* w_hh_r, float
     return LAS_OK;
 }
 
+template <int H, int NB>
+static int launch_bwd_multi(const float* dout, const float* gates, const float* cbuf, const float* w_hh_t, float* dgates, int B, int T,
+                            u64* xbuf, unsigned* err, int b0, int Bc, int grid, hipStream_t stream) {
+    const size_t smem = sizeof(float) * ((size_t)2 * NB * H + (size_t)NB * 4 * H);
+    LAS_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&rec_bwd_multi<H, NB>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
+    hipLaunchKernelGGL((rec_bwd_multi<H, NB>), dim3(grid), dim3(REC_THREADS), smem, stream, dout, gates, cbuf, w_hh_t, dgates, B, T, xbuf,
+                       err, b0, Bc);
+    LAS_LAUNCH_CHECK();
+    return LAS_OK;
+}
+
 int pblstm_rec_bwd(const float* dout, const float* gates, const float* cbuf, const float* w_hh_t, float* dgates, int B,
                    int T, int H, u64* xbuf, unsigned* err, int force_generic, hipStream_t stream) {
     LAS_REQUIRE(B > 0 && T > 0 && H > 0, "rec dims");
     const int ngroups = 2 * B;
+    static const int nb_env = env_int("LAS_REC_NB", 0);
+    RecPlan plan = {0, 0};
+    const int G = H * H / 16384 > 0 ? H * H / 16384 : 1;
     if (fast_h(H) && !force_generic) {
+        const int nb_max = H == 128 ? 8 : (H == 256 ? 8 : 4);
+        plan = rec_plan(B, G, std::min(nb_env, nb_max), nb_max, device_cus());
+    }
+    if (plan.nb > 0) {
         LAS_REQUIRE(xbuf && err, "hand-off buffers");
-        const int G = H * H / 16384;
-        if (G > 1) LAS_HIP_CHECK(hipMemsetAsync(xbuf, 0, rec_xbuf_bytes(B, H), stream));
-        dim3 grid(ngroups * G), block(REC_THREADS);
-        if (H == 128) hipLaunchKernelGGL((rec_bwd_fast<128>), grid, block, 0, stream, dout, gates, cbuf, w_hh_t, dgates, B, T, xbuf, err);
-        else if (H == 256) hipLaunchKernelGGL((rec_bwd_fast<256>), grid, block, 0, stream, dout, gates, cbuf, w_hh_t, dgates, B, T, xbuf, err);
-        else hipLaunchKernelGGL((rec_bwd_fast<512>), grid, block, 0, stream, dout, gates, cbuf, w_hh_t, dgates, B, T, xbuf, err);
+        for (int b0 = 0; b0 < B; b0 += plan.chunk) {
+            const int Bc = std::min(plan.chunk, B - b0);
+            const int nblk = (Bc + plan.nb - 1) / plan.nb;
+            const int grid = 2 * nblk * G;
+            if (G > 1) LAS_HIP_CHECK(hipMemsetAsync(xbuf, 0, rec_xbuf_bytes(B, H), stream));
+            if (plan.nb == 1) {
+                if (b0 != 0 || Bc != B) return fail(LAS_ERR_UNSUPPORTED, "chunked launch needs the multi kernel%s", "");
+                if (H == 128) hipLaunchKernelGGL((rec_bwd_fast<128>), dim3(grid), dim3(REC_THREADS), 0, stream, dout, gates, cbuf, w_hh_t, dgates, B, T, xbuf, err);
+                else if (H == 256) hipLaunchKernelGGL((rec_bwd_fast<256>), dim3(grid), dim3(REC_THREADS), 0, stream, dout, gates, cbuf, w_hh_t, dgates, B, T, xbuf, err);
+                else hipLaunchKernelGGL((rec_bwd_fast<512>), dim3(grid), dim3(REC_THREADS), 0, stream, dout, gates, cbuf, w_hh_t, dgates, B, T, xbuf, err);
+                LAS_LAUNCH_CHECK();
+                continue;
+            }
+#define TRY_BWD_M(HH, NBV) if (H == HH && plan.nb == NBV) { LAS_TRY((launch_bwd_multi<HH, NBV>(dout, gates, cbuf, w_hh_t, dgates, B, T, xbuf, err, b0, Bc, grid, stream))); continue; }
+            TRY_BWD_M(128, 2) TRY_BWD_M(128, 4) TRY_BWD_M(128, 8)
+            TRY_BWD_M(256, 2) TRY_BWD_M(256, 4) TRY_BWD_M(256, 8)
+            TRY_BWD_M(512, 2) TRY_BWD_M(512, 4)
+#undef TRY_BWD_M
+            return fail(LAS_ERR_UNSUPPORTED, "no backward recurrence kernel for %s H=%ld nb=%ld", "", (long)H, (long)plan.nb);
+        }
     } else {
         const size_t smem = sizeof(float) * 7 * H;
         hipLaunchKernelGGL(rec_bwd_generic, dim3(ngroups), dim3(256), smem, stream, dout, gates, cbuf, w_hh_t, dgates, B, T, H);

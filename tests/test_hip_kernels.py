@@ -118,3 +118,58 @@ def test_recurrence_agent_scope_handoff_path():
     r = subprocess.run([sys.executable, "-m", "pytest", "-q", "-x", __file__, "-k", "recurrence_fwd_vs_oracle and 256 and False",
                         "-p", "no:cacheprovider"], env=env, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+
+
+@pytest.mark.parametrize("H,B,T", [(256, 40, 12), (256, 100, 10), (256, 200, 6), (256, 300, 5), (256, 33, 9),
+                                    (128, 200, 12), (128, 600, 4), (512, 12, 6), (512, 30, 5), (512, 40, 4)])
+def test_multi_utterance_recurrence_matches_generic(H, B, T):
+    """Batches beyond one utterance per resident group: the register-resident recurrences step NB = 2 / 4 / 8 utterances per
+    group (and very large batches in several launches) so that every launch fits the CU count.  Forward output, stash-driven
+    backward (dx and all eight parameter gradients) against the generic L2-streaming kernels, which know nothing of groups."""
+    import las_pytorch_amd
+    from las_pytorch_amd import pBLSTMLayer
+    from las_pytorch_amd.model.las_model import set_force_generic
+    torch.manual_seed(H + B)
+    D = 24
+    layer = pBLSTMLayer(D, H).cuda()
+    x0 = torch.randn(B, 2 * T, D, device="cuda")
+    w = torch.randn(B, T, 2 * H, device="cuda")
+    res = []
+    for force in (False, True):
+        set_force_generic(layer, force)
+        layer.zero_grad(set_to_none=True)
+        x = x0.clone().requires_grad_(True)
+        out, _ = layer(x)
+        (out * w).sum().backward()
+        res.append(dict(out=out.detach().cpu().numpy(), dx=x.grad.cpu().numpy(),
+                        **{n: p.grad.cpu().numpy() for n, p in layer.named_parameters()}))
+    torch.cuda.synchronize()
+    las_pytorch_amd.check_device_errors()
+    for k in res[0]:
+        scale = float(np.abs(res[1][k]).max()) + 1e-30
+        assert_close(res[0][k], res[1][k], f"multi-utterance recurrence H={H} B={B}: {k}", rtol=1e-3, atol=2e-5 * scale)
+
+
+def test_multi_utterance_recurrence_vs_oracle():
+    """P listener at B=40 (two utterances per group at H=256) against the CPU oracle, forward and gradients."""
+    import las_pytorch_amd
+    from hip_util import build_las, grad_close
+    from las_pytorch_amd import synth
+    from oracle import las_oracle as O
+    c = synth.CONFIGS["P"]
+    B, T = 40, 32
+    sd_np = synth.make_state_dict(synth.config_shapes("P"), seed=21, scale=0.1)
+    x = synth.make_inputs(B, T, c["F"], seed=21)
+    sd = O.to_torch_sd(sd_np, requires_grad=True)
+    feat_o = O.listener_forward(torch.from_numpy(x), sd, c["L"])
+    wgt = torch.randn(feat_o.shape, generator=torch.Generator().manual_seed(1))
+    (feat_o * wgt).sum().backward()
+    las = build_las(c, sd_np, max_label_len=4)
+    feat = las.listener(torch.from_numpy(x).cuda())
+    (feat * wgt.cuda()).sum().backward()
+    assert_close(feat.detach().cpu().numpy(), feat_o.detach().numpy(), "listener B=40")
+    gs = max(float(sd[k].grad.norm()) for k in sd if sd[k].grad is not None)
+    for k, p in las.listener.named_parameters():
+        grad_close(p.grad.cpu().numpy(), sd["listener." + k].grad.numpy(), f"multi_oracle/grad/{k}", global_scale=gs)
+    torch.cuda.synchronize()
+    las_pytorch_amd.check_device_errors()
