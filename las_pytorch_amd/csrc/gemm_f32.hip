@@ -14,6 +14,7 @@
 #include "las_common.h"
 #include "las_kernels.h"
 #include <stdlib.h>
+#include <algorithm>
 
 namespace las {
 
@@ -32,7 +33,13 @@ struct GemmParams {
     int splitk, kper;
     int accumulate, relu, atomic;
     int a_vec, b_vec;   // 16-byte vector loads legal for this operand
+    // optional second source along K: k >= K1 reads A2 / B2 at k - K1 (same leading dimensions and layouts; K1 % BK == 0):
+    // C = [A | A2] [B ; B2] in one pass instead of a second accumulating GEMM
+    const float* A2; const float* B2; int K1;
     int gx, swz;
+    // persistent (data-parallel + stream-K) schedule
+    int persistent, gy, kt, dp_tiles, sk_atomic_whole;
+    long sk_iters, sk_per;
 };
 
 // Load one BK x BM(BN) operand tile into registers (NLD float4 per thread).
@@ -109,23 +116,27 @@ __device__ __forceinline__ void store_tile(float (*S)[BM + PAD], const f32x4 (&r
     }
 }
 
+// One output tile over the k-iterations [it0, it1) (BK each): main loop + epilogue.  `atomic`: this segment is one of several
+// contributors to the tile (split-K / stream-K): accumulate with atomics onto a C that starts from zero (or from the
+// value to accumulate onto); the contributor that owns k-iteration 0 adds the biases.
 template <bool A_KC, bool B_KC>
-__global__ __launch_bounds__(GEMM_THREADS) void gemm_f32_kernel(GemmParams p) {
-    __shared__ __attribute__((aligned(16))) float As[2][BK][BM + PAD];
-    __shared__ __attribute__((aligned(16))) float Bs[2][BK][BN + PAD];
-
-    const int bz = blockIdx.z / p.splitk, kz = blockIdx.z % p.splitk;
+__device__ __forceinline__ void gemm_segment(const GemmParams& p, float (*As)[BK][BM + PAD], float (*Bs)[BK][BN + PAD], int bz, int m0,
+                                             int n0, int kbeg, int kend, bool atomic, bool add_bias) {
     const float* A = p.A + (long)bz * p.sA;
     const float* B = p.B + (long)bz * p.sB;
     float* C = p.C + (long)bz * p.sC;
-    // XCD-aware tile order: workgroups are dispatched round-robin over the 8 XCDs (private L2 each); remap so that
-    // each XCD works on a contiguous run of tiles (the N-tiles of one M-tile share the A panel in that XCD's L2).
-    int tile = blockIdx.x;
-    if (p.swz) tile = (tile & 7) * (gridDim.x >> 3) + (tile >> 3);
-    const int m0 = (tile / p.gx) * BM, n0 = (tile % p.gx) * BN;
-    const int kbeg = kz * p.kper;
-    const int kend = min(p.K, kbeg + p.kper);
     const int ntiles = (kend - kbeg + BK - 1) / BK;
+    // k-tile loader with the optional second K source (a k-tile never straddles K1)
+    auto load_ab = [&](int k0, f32x4 (&ra_)[NLD], f32x4 (&rb_)[NLD]) {
+        if (p.A2 != nullptr && k0 >= p.K1) {
+            load_tile<A_KC>(p.A2, p.lda, p.M, p.K - p.K1, m0, k0 - p.K1, kend - p.K1, p.a_vec, ra_);
+            load_tile<B_KC>(p.B2, p.ldb, p.N, p.K - p.K1, n0, k0 - p.K1, kend - p.K1, p.b_vec, rb_);
+        } else {
+            const int ke = (p.A2 != nullptr) ? min(kend, p.K1) : kend;
+            load_tile<A_KC>(A, p.lda, p.M, p.K, m0, k0, ke, p.a_vec, ra_);
+            load_tile<B_KC>(B, p.ldb, p.N, p.K, n0, k0, ke, p.b_vec, rb_);
+        }
+    };
 
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int wm = (wave >> 1) * 64, wn = (wave & 1) * 64;
@@ -141,8 +152,7 @@ __global__ __launch_bounds__(GEMM_THREADS) void gemm_f32_kernel(GemmParams p) {
 
     f32x4 ra[NLD], rb[NLD];
     if (ntiles > 0) {
-        load_tile<A_KC>(A, p.lda, p.M, p.K, m0, kbeg, kend, p.a_vec, ra);
-        load_tile<B_KC>(B, p.ldb, p.N, p.K, n0, kbeg, kend, p.b_vec, rb);
+        load_ab(kbeg, ra, rb);
         store_tile<A_KC>(As[0], ra);
         store_tile<B_KC>(Bs[0], rb);
     }
@@ -151,10 +161,7 @@ __global__ __launch_bounds__(GEMM_THREADS) void gemm_f32_kernel(GemmParams p) {
     for (int kt = 0; kt < ntiles; ++kt) {
         const int cur = kt & 1;
         const bool more = kt + 1 < ntiles;
-        if (more) {
-            load_tile<A_KC>(A, p.lda, p.M, p.K, m0, kbeg + (kt + 1) * BK, kend, p.a_vec, ra);
-            load_tile<B_KC>(B, p.ldb, p.N, p.K, n0, kbeg + (kt + 1) * BK, kend, p.b_vec, rb);
-        }
+        if (more) load_ab(kbeg + (kt + 1) * BK, ra, rb);
         // fragments of k-step kk+1 are read from LDS before the MFMAs of k-step kk are issued (software pipeline):
         // a single wave per SIMD then keeps the matrix pipe busy instead of idling for an LDS latency per k-step
         float a[2], b[2];
@@ -186,7 +193,6 @@ __global__ __launch_bounds__(GEMM_THREADS) void gemm_f32_kernel(GemmParams p) {
     }
 
     // Epilogue.  C/D map of 32x32 MFMA: col(n) = lane&31, row(m) = (r&3) + 8*(r>>2) + 4*(lane>>5).
-    const bool add_bias = (kz == 0);
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
         const int n = n0 + wn + j * 32 + lr;
@@ -204,7 +210,7 @@ __global__ __launch_bounds__(GEMM_THREADS) void gemm_f32_kernel(GemmParams p) {
                 if (m >= p.M) continue;
                 float v = acc[i][j][r] + bsum;
                 float* c = C + (long)m * p.ldc + n;
-                if (p.atomic) {
+                if (atomic) {
                     atomicAdd(c, v);
                 } else {
                     if (p.accumulate) v += *c;
@@ -216,19 +222,191 @@ __global__ __launch_bounds__(GEMM_THREADS) void gemm_f32_kernel(GemmParams p) {
     }
 }
 
+// Two schedules share the segment code:
+//  * classic (p.persistent == 0): grid (tiles, 1, batch*splitk); every workgroup owns one tile and one k-slice.
+//  * persistent (p.persistent == 1): grid = W resident workgroups.  The first p.dp_tiles tiles are done whole, round-robin
+//    (data parallel, plain stores); the k-iterations of the remaining tiles — the tail that would leave most CUs idle for
+//    a whole tile time — are cut into W equal runs (stream-K): a run may end one tile and start the next, partial
+//    tiles are combined with atomics on a C window zeroed beforehand.
+template <bool A_KC, bool B_KC>
+__global__ __launch_bounds__(GEMM_THREADS) void gemm_f32_kernel(GemmParams p) {
+    __shared__ __attribute__((aligned(16))) float As[2][BK][BM + PAD];
+    __shared__ __attribute__((aligned(16))) float Bs[2][BK][BN + PAD];
+    if (!p.persistent) {
+        const int bz = blockIdx.z / p.splitk, kz = blockIdx.z % p.splitk;
+        // XCD-aware tile order: workgroups are dispatched round-robin over the 8 XCDs (private L2 each); remap so that
+        // each XCD works on a contiguous run of tiles (the N-tiles of one M-tile share the A panel in that XCD's L2).
+        int tile = blockIdx.x;
+        if (p.swz) tile = (tile & 7) * (gridDim.x >> 3) + (tile >> 3);
+        const int kbeg = kz * p.kper;
+        gemm_segment<A_KC, B_KC>(p, As, Bs, bz, (tile / p.gx) * BM, (tile % p.gx) * BN, kbeg, min(p.K, kbeg + p.kper), p.atomic, kz == 0);
+        return;
+    }
+    const int W = gridDim.x, w = blockIdx.x;
+    const int per_batch = p.gx * p.gy;
+    for (int tile = w; tile < p.dp_tiles; tile += W) {
+        const int bz = tile / per_batch, t = tile % per_batch;
+        gemm_segment<A_KC, B_KC>(p, As, Bs, bz, (t / p.gx) * BM, (t % p.gx) * BN, 0, p.K, false, true);
+    }
+    long i0 = (long)w * p.sk_per, i1 = min(i0 + p.sk_per, p.sk_iters);
+    while (i0 < i1) {
+        const int tile = p.dp_tiles + (int)(i0 / p.kt);
+        const int it0 = (int)(i0 % p.kt), it1 = (int)min((long)p.kt, it0 + (i1 - i0));
+        const int bz = tile / per_batch, t = tile % per_batch;
+        const bool whole = it0 == 0 && it1 == p.kt;
+        gemm_segment<A_KC, B_KC>(p, As, Bs, bz, (t / p.gx) * BM, (t % p.gx) * BN, it0 * BK, min(p.K, it1 * BK), !whole || p.sk_atomic_whole,
+                                 it0 == 0);
+        i0 += it1 - it0;
+    }
+}
+
+// Several independent GEMMs of the same operand layout in ONE launch (the weight-gradient contractions of a backward pass:
+// few output tiles each, long K).  Every problem is cut stream-K fashion into equal runs of k-iterations over as many of
+// the W resident workgroups as its size warrants (>= GROUP_MIN_ITERS iterations per run); small problems start at rotating
+// workgroup offsets.  A workgroup walks through its share of every problem without any grid-wide synchronisation, so there
+// is no tail between the GEMMs and a 16-tile problem no longer holds the chip.  All outputs accumulate with atomics onto
+// buffers the caller has zeroed (the flat gradient buffer).
+constexpr int GROUP_MAX = 8, GROUP_MIN_ITERS = 8;
+struct GemmGroupParams { GemmParams prob[GROUP_MAX]; int n; };
+
+template <bool A_KC, bool B_KC>
+__global__ __launch_bounds__(GEMM_THREADS) void gemm_group_kernel(GemmGroupParams g) {
+    __shared__ __attribute__((aligned(16))) float As[2][BK][BM + PAD];
+    __shared__ __attribute__((aligned(16))) float Bs[2][BK][BN + PAD];
+    const int W = gridDim.x, w = blockIdx.x;
+    int rot = 0;
+    for (int pi = 0; pi < g.n; ++pi) {
+        const GemmParams& p = g.prob[pi];
+        const long iters = (long)p.gx * p.gy * p.kt;
+        const int parts = (int)min((long)W, max(1L, iters / GROUP_MIN_ITERS));
+        const long per = (iters + parts - 1) / parts;
+        const int slot = (w + W - rot % W) % W;
+        rot += parts;
+        if (slot >= parts) continue;
+        long i0 = (long)slot * per, i1 = min(i0 + per, iters);
+        while (i0 < i1) {
+            const int t = (int)(i0 / p.kt);
+            const int it0 = (int)(i0 % p.kt), it1 = (int)min((long)p.kt, it0 + (i1 - i0));
+            gemm_segment<A_KC, B_KC>(p, As, Bs, 0, (t / p.gx) * BM, (t % p.gx) * BN, it0 * BK, min(p.K, it1 * BK), true, false);
+            i0 += it1 - it0;
+        }
+    }
+}
+
+// zero the C windows of the stream-K tiles (they are accumulated with atomics)
+__global__ __launch_bounds__(256) void gemm_zero_tiles_kernel(GemmParams p) {
+    const int per_batch = p.gx * p.gy;
+    const int tile = p.dp_tiles + blockIdx.x;
+    const int bz = tile / per_batch, t = tile % per_batch;
+    const int m0 = (t / p.gx) * BM, n0 = (t % p.gx) * BN;
+    float* C = p.C + (long)bz * p.sC;
+    for (int i = threadIdx.x; i < BM * BN; i += 256) {
+        const int m = m0 + i / BN, n = n0 + i % BN;
+        if (m < p.M && n < p.N) C[(long)m * p.ldc + n] = 0.f;
+    }
+}
+
+static int gemm_resident_slots() {      // persistent grid: two 256-thread workgroups per CU (34 KB LDS, <= 128 VGPRs each)
+    static int slots = -1;
+    if (slots < 0) {
+        int dev = 0, cus = 0;
+        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) cus = 0;
+        slots = 2 * cus;
+    }
+    return slots;
+}
+
+static bool gemm_aligned(const float* ptr, long ld, long bs) { return ((uintptr_t)ptr % 16 == 0) && (ld % 4 == 0) && (bs % 4 == 0); }
+
+int gemm_f32_group(const GemmDesc* ds, int n, hipStream_t stream) {
+    static const int group_on = getenv("LAS_GEMM_GROUP") ? atoi(getenv("LAS_GEMM_GROUP")) : 1;
+    const int W = gemm_resident_slots();
+    bool ok = group_on && W > 0 && n >= 1 && n <= GROUP_MAX;
+    for (int i = 0; ok && i < n; ++i) {
+        const GemmDesc& d = ds[i];
+        ok = d.batch <= 1 && !d.relu && !d.bias0 && !d.bias1 && (d.c_zeroed || d.accumulate) && d.a_kc == ds[0].a_kc && d.b_kc == ds[0].b_kc &&
+             d.A2 == nullptr && d.M > 0 && d.N > 0 && d.K > 0;
+    }
+    if (!ok) {      // not groupable (or switched off): one launch per problem
+        for (int i = 0; i < n; ++i) LAS_TRY(gemm_f32(ds[i], stream));
+        return LAS_OK;
+    }
+    GemmGroupParams g;
+    g.n = n;
+    for (int i = 0; i < n; ++i) {
+        const GemmDesc& d = ds[i];
+        GemmParams& p = g.prob[i];
+        memset(&p, 0, sizeof(p));
+        p.A = d.A; p.B = d.B; p.C = d.C; p.M = d.M; p.N = d.N; p.K = d.K; p.lda = d.lda; p.ldb = d.ldb; p.ldc = d.ldc;
+        p.a_vec = gemm_aligned(d.A, d.lda, 0); p.b_vec = gemm_aligned(d.B, d.ldb, 0);
+        p.gx = cdiv(d.N, BN); p.gy = cdiv(d.M, BM); p.kt = std::max(1, cdiv(d.K, BK));
+        p.splitk = 1; p.kper = d.K;
+    }
+    dim3 grid(W), block(GEMM_THREADS);
+    const bool a_kc = ds[0].a_kc, b_kc = ds[0].b_kc;
+    if (a_kc && b_kc) hipLaunchKernelGGL((gemm_group_kernel<true, true>), grid, block, 0, stream, g);
+    else if (a_kc && !b_kc) hipLaunchKernelGGL((gemm_group_kernel<true, false>), grid, block, 0, stream, g);
+    else if (!a_kc && b_kc) hipLaunchKernelGGL((gemm_group_kernel<false, true>), grid, block, 0, stream, g);
+    else hipLaunchKernelGGL((gemm_group_kernel<false, false>), grid, block, 0, stream, g);
+    LAS_LAUNCH_CHECK();
+    return LAS_OK;
+}
+
 int gemm_f32(const GemmDesc& d, hipStream_t stream) {
     LAS_REQUIRE(d.M > 0 && d.N > 0 && d.K >= 0, "gemm dims");
     LAS_REQUIRE(d.A && d.B && d.C, "gemm pointers");
+    LAS_REQUIRE(d.A2 == nullptr || (d.B2 != nullptr && d.K1 > 0 && d.K1 < d.K && d.K1 % BK == 0 && d.batch <= 1), "second K source");
     GemmParams p;
+    p.A2 = d.A2; p.B2 = d.B2; p.K1 = d.K1;
     p.A = d.A; p.B = d.B; p.C = d.C; p.bias0 = d.bias0; p.bias1 = d.bias1;
     p.M = d.M; p.N = d.N; p.K = d.K; p.lda = d.lda; p.ldb = d.ldb; p.ldc = d.ldc;
     p.sA = d.sA; p.sB = d.sB; p.sC = d.sC; p.sBias0 = d.sBias0; p.sBias1 = d.sBias1;
     const int batch = d.batch > 0 ? d.batch : 1;
-    int splitk = d.splitk > 0 ? d.splitk : 1;
     const int gx = cdiv(d.N, BN), gy = cdiv(d.M, BM);
+    const long tiles = (long)gx * gy * batch;
+    const int kt = std::max(1, cdiv(d.K, BK));
+    p.a_vec = gemm_aligned(d.A, d.lda, d.sA) && (d.A2 == nullptr || gemm_aligned(d.A2, d.lda, 0));
+    p.b_vec = gemm_aligned(d.B, d.ldb, d.sB) && (d.B2 == nullptr || gemm_aligned(d.B2, d.ldb, 0));
+    p.gx = gx; p.gy = gy; p.kt = kt;
+    p.accumulate = d.accumulate; p.relu = d.relu;
+    p.persistent = 0; p.dp_tiles = 0; p.sk_iters = 0; p.sk_per = 0; p.sk_atomic_whole = 0; p.atomic = 0; p.swz = 0; p.splitk = 1; p.kper = d.K;
+
+    // ---- schedule --------------------------------------------------------------------------------------------------
+    static const int sk_on = getenv("LAS_GEMM_STREAMK") ? atoi(getenv("LAS_GEMM_STREAMK")) : 1;
+    const int W = gemm_resident_slots();
+    const bool may_split = !d.relu && d.K >= 4 * BK;         // a relu epilogue needs the whole sum in one place
+    if (sk_on && d.splitk <= 1 && W > 0 && may_split && kt >= 32 && tiles % W != 0 && tiles * kt >= 4L * W) {
+        // persistent: whole tiles while they fill every slot, the ragged tail (or everything, when there are fewer tiles than
+        // slots) as equal runs of k-iterations
+        const long full = (tiles / W) * W;
+        // keep the stream-K part at least half a wave of work so that its runs are not dominated by prologue/epilogue
+        long dp = full;
+        if (dp > 0 && (tiles - dp) * 2 < W) dp -= W;
+        p.persistent = 1;
+        p.dp_tiles = (int)dp;
+        p.sk_iters = (tiles - dp) * kt;
+        p.sk_per = (p.sk_iters + W - 1) / W;
+        p.sk_atomic_whole = d.accumulate ? 0 : 0;
+        const int sk_tiles = (int)(tiles - dp);
+        if (!d.accumulate && !d.c_zeroed && sk_tiles > 0) {
+            if (dp == 0 && batch == 1 && d.ldc == d.N) {
+                LAS_HIP_CHECK(hipMemsetAsync(d.C, 0, sizeof(float) * (size_t)d.M * d.N, stream));
+            } else {
+                hipLaunchKernelGGL(gemm_zero_tiles_kernel, dim3(sk_tiles), dim3(256), 0, stream, p);
+            }
+        }
+        dim3 grid((unsigned)std::min<long>(W, std::max<long>(dp > 0 ? W : 1, cdiv(p.sk_iters, std::max<long>(1, p.sk_per))))), block(GEMM_THREADS);
+        if (d.a_kc && d.b_kc) hipLaunchKernelGGL((gemm_f32_kernel<true, true>), grid, block, 0, stream, p);
+        else if (d.a_kc && !d.b_kc) hipLaunchKernelGGL((gemm_f32_kernel<true, false>), grid, block, 0, stream, p);
+        else if (!d.a_kc && d.b_kc) hipLaunchKernelGGL((gemm_f32_kernel<false, true>), grid, block, 0, stream, p);
+        else hipLaunchKernelGGL((gemm_f32_kernel<false, false>), grid, block, 0, stream, p);
+        LAS_LAUNCH_CHECK();
+        return LAS_OK;
+    }
+
+    int splitk = d.splitk > 0 ? d.splitk : 1;
     if (d.splitk == 0) {
         // auto: few output tiles and a long K -> split K so the launch covers the chip (256 CUs)
-        const long tiles = (long)gx * gy * batch;
         if (!d.relu && tiles < 128 && d.K >= 256) {
             // few output tiles, long K: about two workgroups per CU (they hide each other's barrier stalls) with at least 4 k-tiles each
             static const long target = getenv("LAS_GEMM_SPLIT_TARGET") ? atol(getenv("LAS_GEMM_SPLIT_TARGET")) : 512;   // ~2 workgroups per CU: measured best
@@ -240,12 +418,7 @@ int gemm_f32(const GemmDesc& d, hipStream_t stream) {
     splitk = max(1, cdiv(d.K, kper));
     LAS_REQUIRE(!(splitk > 1 && d.relu), "relu epilogue needs splitk==1");
     p.splitk = splitk; p.kper = kper;
-    p.accumulate = d.accumulate; p.relu = d.relu; p.atomic = splitk > 1;
-    auto aligned = [](const float* ptr, long ld, long bs) {
-        return ((uintptr_t)ptr % 16 == 0) && (ld % 4 == 0) && (bs % 4 == 0);
-    };
-    p.a_vec = aligned(d.A, d.lda, d.sA);
-    p.b_vec = aligned(d.B, d.ldb, d.sB);
+    p.atomic = splitk > 1;
     if (p.atomic && !d.accumulate && !d.c_zeroed) {
         // split-K partials are summed with atomics: C must start from zero
         if (d.ldc == d.N) {
@@ -255,7 +428,7 @@ int gemm_f32(const GemmDesc& d, hipStream_t stream) {
             LAS_REQUIRE(batch == 1, "split-K with strided C and batch>1");
         }
     }
-    p.gx = gx; p.swz = ((gx * gy) % 8 == 0) && (gx * gy >= 64);
+    p.swz = ((gx * gy) % 8 == 0) && (gx * gy >= 64);
     dim3 grid(gx * gy, 1, batch * splitk), block(GEMM_THREADS);
     if (d.a_kc && d.b_kc) hipLaunchKernelGGL((gemm_f32_kernel<true, true>), grid, block, 0, stream, p);
     else if (d.a_kc && !d.b_kc) hipLaunchKernelGGL((gemm_f32_kernel<true, false>), grid, block, 0, stream, p);

@@ -190,36 +190,30 @@ int las_pblstm_bwd(const float* x, const float* dout, int B, int T_in, int D_in,
     const size_t n_ih = (size_t)4 * H * D, n_hh = (size_t)4 * H * H, n_b = (size_t)4 * H;
     const bool zg = zero_if_contiguous({{dw_ih_f, n_ih}, {dw_hh_f, n_hh}, {db_ih_f, n_b}, {db_hh_f, n_b},
                                         {dw_ih_r, n_ih}, {dw_hh_r, n_hh}, {db_ih_r, n_b}, {db_hh_r, n_b}}, stream);
+    // the four weight-gradient contractions (few output tiles, K = B*T) go out as ONE grouped stream-K launch
+    GemmDesc dw[4];
     for (int dir = 0; dir < 2; ++dir) {
         const float* dG = dgates + (size_t)dir * BT * 4 * H;
         const float* hp = hprev + (size_t)dir * BT * H;
-        float* dw_ih = dir ? dw_ih_r : dw_ih_f;
-        float* dw_hh = dir ? dw_hh_r : dw_hh_f;
-        float* db_ih = dir ? db_ih_r : db_ih_f;
-        float* db_hh = dir ? db_hh_r : db_hh_f;
-        {   // dW_ih = dG^T X
-            GemmDesc g;
-            g.A = dG; g.lda = 4 * H; g.a_kc = false;
-            g.B = x; g.ldb = D; g.b_kc = false;
-            g.C = dw_ih; g.ldc = D; g.M = 4 * H; g.N = D; g.K = BT; g.c_zeroed = zg;
-            LAS_TRY(gemm_f32(g, stream));
-        }
-        {   // dW_hh = dG^T H_prev
-            GemmDesc g;
-            g.A = dG; g.lda = 4 * H; g.a_kc = false;
-            g.B = hp; g.ldb = H; g.b_kc = false;
-            g.C = dw_hh; g.ldc = H; g.M = 4 * H; g.N = H; g.K = BT; g.c_zeroed = zg;
-            LAS_TRY(gemm_f32(g, stream));
-        }
-        LAS_TRY(colsum(dG, 4 * H, BT, 4 * H, db_ih, zg, stream, db_hh));
-        if (dx) {   // dX (+)= dG W_ih
-            GemmDesc g;
-            g.A = dG; g.lda = 4 * H; g.a_kc = true;
-            g.B = dir ? w_ih_r : w_ih_f; g.ldb = D; g.b_kc = false;
-            g.C = dx; g.ldc = D; g.M = BT; g.N = D; g.K = 4 * H; g.splitk = 1;
-            g.accumulate = dir == 1;
-            LAS_TRY(gemm_f32(g, stream));
-        }
+        GemmDesc& gi = dw[2 * dir];          // dW_ih = dG^T X
+        gi.A = dG; gi.lda = 4 * H; gi.a_kc = false;
+        gi.B = x; gi.ldb = D; gi.b_kc = false;
+        gi.C = dir ? dw_ih_r : dw_ih_f; gi.ldc = D; gi.M = 4 * H; gi.N = D; gi.K = BT; gi.c_zeroed = zg;
+        GemmDesc& gh = dw[2 * dir + 1];      // dW_hh = dG^T H_prev
+        gh.A = dG; gh.lda = 4 * H; gh.a_kc = false;
+        gh.B = hp; gh.ldb = H; gh.b_kc = false;
+        gh.C = dir ? dw_hh_r : dw_hh_f; gh.ldc = H; gh.M = 4 * H; gh.N = H; gh.K = BT; gh.c_zeroed = zg;
+    }
+    LAS_TRY(gemm_f32_group(dw, 4, stream));
+    for (int dir = 0; dir < 2; ++dir)
+        LAS_TRY(colsum(dgates + (size_t)dir * BT * 4 * H, 4 * H, BT, 4 * H, dir ? db_ih_r : db_ih_f, zg, stream, dir ? db_hh_r : db_hh_f));
+    if (dx) {   // dX = [dG_f | dG_r] [W_ih_f ; W_ih_r]: both directions in one pass over K = 2 * 4H
+        GemmDesc g;
+        g.A = dgates; g.lda = 4 * H; g.a_kc = true;
+        g.B = w_ih_f; g.ldb = D; g.b_kc = false;
+        g.A2 = dgates + (size_t)BT * 4 * H; g.B2 = w_ih_r; g.K1 = 4 * H;
+        g.C = dx; g.ldc = D; g.M = BT; g.N = D; g.K = 8 * H; g.splitk = 1;
+        LAS_TRY(gemm_f32(g, stream));
     }
     return LAS_OK;
 }
@@ -365,9 +359,8 @@ int las_speller_fwd(const las_speller_desc* d, const float* feat, const float* k
         GemmDesc q;
         q.A = h_all + (size_t)(L - 1) * U * sH; q.lda = Hs; q.a_kc = true;
         q.B = d->w_c; q.ldb = Hs + D; q.b_kc = true; q.bias0 = d->b_c;
-        q.C = logp; q.ldc = V; q.M = U * B; q.N = V; q.K = Hs; q.splitk = 0;      // auto split-K: only U*B/128 output tiles
-        LAS_TRY(gemm_f32(q, stream));
-        q.A = ctx_all + (size_t)B * D; q.lda = D; q.B = d->w_c + Hs; q.bias0 = nullptr; q.K = D; q.accumulate = true;
+        q.C = logp; q.ldc = V; q.M = U * B; q.N = V; q.K = Hs + D; q.splitk = 0;      // auto split-K: only U*B/128 output tiles
+        q.A2 = ctx_all + (size_t)B * D; q.B2 = d->w_c + Hs; q.K1 = Hs;                   // [h | ctx] as two K sources (D == Hs)
         LAS_TRY(gemm_f32(q, stream));
         LAS_TRY(log_softmax_rows(logp, (long)U * B, V, stream));
     }
@@ -619,7 +612,7 @@ int las_speller_bwd(const las_speller_desc* d, const float* feat, const float* k
             q.C = g->dfeat; q.ldc = D; q.M = BT; q.N = D; q.K = M; q.splitk = 1; q.accumulate = true;
             LAS_TRY(gemm_f32(q, stream));
         }
-        {   // dW_phi = dqpre^T h_top
+        if (NH > 1) {   // dW_phi = dqpre^T h_top (single head: part of the grouped launch below)
             GemmDesc q;
             q.A = dqpre_all; q.lda = (long)M * NH; q.a_kc = false; q.B = h_top_all; q.ldb = Hs; q.b_kc = false;
             q.C = g->dw_phi; q.ldc = Hs; q.M = M * NH; q.N = Hs; q.K = UB; q.c_zeroed = zg;
@@ -627,38 +620,38 @@ int las_speller_bwd(const las_speller_desc* d, const float* feat, const float* k
         }
         LAS_TRY(colsum(dqpre_all, (long)M * NH, UB, M * NH, g->db_phi, zg, stream));
     }
-    {   // dW_c = dz^T [h_top | ctx]
-        GemmDesc q;
-        q.A = dz_all; q.lda = V; q.a_kc = false; q.B = h_top_all; q.ldb = Hs; q.b_kc = false;
-        q.C = g->dw_c; q.ldc = Hs + D; q.M = V; q.N = Hs; q.K = UB; q.c_zeroed = zg;
-        LAS_TRY(gemm_f32(q, stream));
-        q.B = ctx_all + (size_t)B * D; q.ldb = D; q.C = g->dw_c + Hs; q.N = D;
-        LAS_TRY(gemm_f32(q, stream));
+    {   // every remaining weight gradient (K = U*B rows each) in ONE grouped stream-K launch
+        GemmDesc gs[8];
+        int n = 0;
+        auto add = [&](const float* A, long lda, const float* Bm, long ldb, float* C, long ldc, int Mv, int Nv, int Kv) {
+            GemmDesc& q = gs[n++];
+            q.A = A; q.lda = lda; q.a_kc = false; q.B = Bm; q.ldb = ldb; q.b_kc = false; q.C = C; q.ldc = ldc; q.M = Mv; q.N = Nv; q.K = Kv;
+            q.c_zeroed = zg;
+        };
+        auto flush = [&]() { const int rc = gemm_f32_group(gs, n, stream); n = 0; return rc; };
+        // dW_c = dz^T [h_top | ctx]
+        add(dz_all, V, h_top_all, Hs, g->dw_c, Hs + D, V, Hs, UB);
+        add(dz_all, V, ctx_all + (size_t)B * D, D, g->dw_c + Hs, Hs + D, V, D, UB);
+        if (d->use_mlp && NH == 1) add(dqpre_all, M, h_top_all, Hs, g->dw_phi, Hs, M, Hs, UB);      // dW_phi = dqpre^T h_top
+        for (int l = 0; l < L; ++l) {
+            const float* dGl = dG_all + (size_t)l * U * 4 * sH;
+            if (n + 3 > 8) LAS_TRY(flush());
+            if (l == 0) {
+                add(dGl, 4 * Hs, y_all, lay.Vp, g->dw_ih[0], V + Hs, 4 * Hs, V, UB);
+                add(dGl, 4 * Hs, ctx_all, D, g->dw_ih[0] + V, V + Hs, 4 * Hs, D, UB);
+            } else {
+                add(dGl, 4 * Hs, h_all + (size_t)(l - 1) * U * sH, Hs, g->dw_ih[l], Hs, 4 * Hs, Hs, UB);
+            }
+            if (U > 1) {   // dW_hh = sum_{s>=1} dG_s^T h_{s-1}
+                add(dGl + 4 * sH, 4 * Hs, h_all + (size_t)l * U * sH, Hs, g->dw_hh[l], Hs, 4 * Hs, Hs, (U - 1) * B);
+            } else if (!zg) {
+                LAS_HIP_CHECK(hipMemsetAsync(g->dw_hh[l], 0, sizeof(float) * 4 * Hs * Hs, stream));
+            }
+        }
+        LAS_TRY(flush());
         LAS_TRY(colsum(dz_all, V, UB, V, g->db_c, zg, stream));
-    }
-    for (int l = 0; l < L; ++l) {
-        const float* dGl = dG_all + (size_t)l * U * 4 * sH;
-        GemmDesc q;
-        q.A = dGl; q.lda = 4 * Hs; q.a_kc = false; q.b_kc = false; q.M = 4 * Hs; q.K = UB; q.c_zeroed = zg;
-        if (l == 0) {
-            q.B = y_all; q.ldb = lay.Vp; q.C = g->dw_ih[0]; q.ldc = V + Hs; q.N = V;
-            LAS_TRY(gemm_f32(q, stream));
-            q.B = ctx_all; q.ldb = D; q.C = g->dw_ih[0] + V; q.N = D;
-            LAS_TRY(gemm_f32(q, stream));
-        } else {
-            q.B = h_all + (size_t)(l - 1) * U * sH; q.ldb = Hs; q.C = g->dw_ih[l]; q.ldc = Hs; q.N = Hs;
-            LAS_TRY(gemm_f32(q, stream));
-        }
-        if (U > 1) {   // dW_hh = sum_{s>=1} dG_s^T h_{s-1}
-            GemmDesc r;
-            r.A = dGl + 4 * sH; r.lda = 4 * Hs; r.a_kc = false;
-            r.B = h_all + (size_t)l * U * sH; r.ldb = Hs; r.b_kc = false;
-            r.C = g->dw_hh[l]; r.ldc = Hs; r.M = 4 * Hs; r.N = Hs; r.K = (U - 1) * B; r.c_zeroed = zg;
-            LAS_TRY(gemm_f32(r, stream));
-        } else if (!zg) {
-            LAS_HIP_CHECK(hipMemsetAsync(g->dw_hh[l], 0, sizeof(float) * 4 * Hs * Hs, stream));
-        }
-        LAS_TRY(colsum(dGl, 4 * Hs, UB, 4 * Hs, g->db_ih[l], zg, stream, g->db_hh[l]));
+        for (int l = 0; l < L; ++l)
+            LAS_TRY(colsum(dG_all + (size_t)l * U * 4 * sH, 4 * Hs, UB, 4 * Hs, g->db_ih[l], zg, stream, g->db_hh[l]));
     }
     return LAS_OK;
 }

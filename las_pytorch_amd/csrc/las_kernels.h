@@ -21,8 +21,13 @@ struct GemmDesc {
     bool accumulate = false;       // C += ...
     bool c_zeroed = false;         // the caller has already zeroed C (split-K then skips its own memset)
     bool relu = false;
+    // optional second source along K (C = [A | A2][B ; B2]): k >= K1 reads A2 / B2 at k - K1; same layouts and leading dimensions
+    const float* A2 = nullptr; const float* B2 = nullptr; int K1 = 0;
 };
 int gemm_f32(const GemmDesc& d, hipStream_t stream);
+// n independent GEMMs of one operand layout, no bias / activation, outputs pre-zeroed (or accumulated onto): ONE launch, the
+// k-iterations of all problems spread evenly over the resident workgroups.  Falls back to n launches when not groupable.
+int gemm_f32_group(const GemmDesc* ds, int n, hipStream_t stream);
 
 // ---- pblstm_rec.hip --------------------------------------------------------------------
 // Forward time recurrence of one bidirectional LSTM layer, both directions in one launch.

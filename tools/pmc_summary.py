@@ -19,20 +19,27 @@ def short(name):
 
 def main(argv):
     match = None
+    by_grid = False
     paths = []
     it = iter(argv)
     for a in it:
         if a == "--match":
             match = next(it)
+        elif a == "--by-grid":       # separate the dispatches of one kernel by launch geometry (one shape per grid size)
+            by_grid = True
         else:
             paths.append(a)
     out = {}
     for p in paths:
         db = sqlite3.connect(p)
-        for name, counter, value in db.execute("select kernel_name, counter_name, value from counters_collection"):
+        for name, counter, value, grid, dur in db.execute("select kernel_name, counter_name, value, grid_size, duration from counters_collection"):
             k = short(name)
             if match and match not in k:
                 continue
+            if by_grid:
+                k = f"{k} grid={grid}"
+            dd = out.setdefault(k, {}).setdefault("duration_ns", [0.0, 0])
+            dd[0] += dur; dd[1] += 1
             d = out.setdefault(k, {}).setdefault(counter, [0.0, 0])
             d[0] += value; d[1] += 1
     res = {}

@@ -41,3 +41,14 @@ if os.environ.get("BIG"):
     run("4096^3 NN", 4096, 4096, 4096, True, False, splitk=1, reps=5)
     run("4096^3 TN", 4096, 4096, 4096, False, False, splitk=1, reps=5)
     run("8192x1024x1024 NT", 8192, 1024, 1024, True, True, splitk=1, reps=10)
+if os.environ.get("TORCH_REF"):
+    # measuring stick only (never on the product path): what the vendor library reaches on the same shapes
+    for (M, N, K) in [(6400, 1024, 1024), (3200, 1024, 1024), (12800, 1024, 160), (1024, 1024, 6400), (2048, 512, 4096), (4096, 4096, 4096)]:
+        a = torch.randn(M, K, device="cuda"); b = torch.randn(N, K, device="cuda")
+        for _ in range(3): c = a @ b.t()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(10): c = a @ b.t()
+        e1.record(); torch.cuda.synchronize()
+        us = e0.elapsed_time(e1) * 100
+        print(f"torch.matmul NT {M}x{N}x{K}: {us:8.1f} us {2.0*M*N*K/us/1e6:7.1f} TF")
