@@ -129,11 +129,35 @@ int las_speller_fwd(const las_speller_desc* d, const float* feat, const float* k
 
 /* One decode step with caller-managed state: Speller.forward_step, reference model/las_model.py:178-184.
  *   input_word (B, V+Hs) = [y | context] as the reference concatenates it (:198,:236); h_in/c_in (L,B,Hs) or both NULL
- *   (zero state).  Outputs: logp (B,V), h_out/c_out (L,B,Hs), ctx (B,D), att (B,Tp).  Inference only (no stash). */
+ *   (zero state).  Outputs: logp (B,V), h_out/c_out (L,B,Hs), ctx (B,D), att (heads,B,Tp).
+ *   reserve: NULL for inference; las_speller_step_reserve_floats() floats to keep what las_speller_step_bwd needs. */
 size_t las_speller_step_workspace_floats(const las_speller_desc* d);
+size_t las_speller_step_reserve_floats(const las_speller_desc* d);
 int las_speller_step_fwd(const las_speller_desc* d, const float* feat, const float* keys, const float* input_word,
                          const float* h_in, const float* c_in, float* logp, float* h_out, float* c_out, float* ctx,
-                         float* att, float* workspace, void* stream);
+                         float* att, float* workspace, float* reserve, void* stream);
+/* Backward of that step (the reference differentiates forward_step through autograd, solver/solver.py:95).
+ *   dlogp (B,V), dh_out / dc_out (L,B,Hs), dctx (B,D): gradients wrt the step's outputs, each may be NULL (= zero).
+ *   Outputs (overwritten): dinput_word (B,V+Hs), dh_in / dc_in (L,B,Hs), every member of g incl. g->dfeat (B,Tp,D)
+ *   — the contribution of THIS step; a caller chaining steps sums them (autograd does). */
+size_t las_speller_step_bwd_workspace_floats(const las_speller_desc* d);
+int las_speller_step_bwd(const las_speller_desc* d, const float* feat, const float* keys, const float* input_word,
+                         const float* h_in, const float* c_in, const float* logp, const float* h_out, const float* c_out,
+                         const float* ctx, const float* att, const float* reserve, const float* dlogp, const float* dh_out,
+                         const float* dc_out, const float* dctx, float* dinput_word, float* dh_in, float* dc_in,
+                         const las_speller_grads* g, float* workspace, void* stream);
+
+/* Attention.forward on its own (reference model/las_model.py:275-318): decoder_state (B,Hs) -> att (heads,B,Tp), ctx (B,D)
+ * (after dim_reduce when multi_head > 1), and its backward from dctx (the attention scores are returned for inspection and
+ * carry no gradient).  reserve: las_attention_reserve_floats(); g: dw_phi/db_phi/dw_psi/db_psi(/dw_dr/db_dr)/dfeat are
+ * overwritten, the LSTM / character-distribution members are ignored. */
+size_t las_attention_reserve_floats(const las_speller_desc* d);
+int las_attention_fwd(const las_speller_desc* d, const float* feat, const float* keys, const float* decoder_state, float* att,
+                      float* ctx, float* reserve, void* stream);
+size_t las_attention_bwd_workspace_floats(const las_speller_desc* d);
+int las_attention_bwd(const las_speller_desc* d, const float* feat, const float* keys, const float* decoder_state,
+                      const float* att, const float* reserve, const float* dctx, float* ddecoder_state,
+                      const las_speller_grads* g, float* workspace, void* stream);
 
 size_t las_speller_bwd_workspace_floats(const las_speller_desc* d, int U);
 /* dlogp (U,B,V): gradient of the loss wrt the returned log-probs.  feedback_mode0: the forward ran

@@ -45,7 +45,14 @@ PROTOTYPES = {
     "las_speller_fwd": (C.c_int, [C.POINTER(SpellerDesc), _f, _f, _f, C.c_int, C.c_int, C.c_int, C.c_int, _f, _f, _f, _f, _f,
                                   _f, C.c_int, _f]),
     "las_speller_step_workspace_floats": (C.c_size_t, [C.POINTER(SpellerDesc)]),
-    "las_speller_step_fwd": (C.c_int, [C.POINTER(SpellerDesc)] + [_f] * 12),
+    "las_speller_step_reserve_floats": (C.c_size_t, [C.POINTER(SpellerDesc)]),
+    "las_speller_step_fwd": (C.c_int, [C.POINTER(SpellerDesc)] + [_f] * 13),
+    "las_speller_step_bwd_workspace_floats": (C.c_size_t, [C.POINTER(SpellerDesc)]),
+    "las_speller_step_bwd": (C.c_int, [C.POINTER(SpellerDesc)] + [_f] * 18 + [C.POINTER(SpellerGrads), _f, _f]),
+    "las_attention_reserve_floats": (C.c_size_t, [C.POINTER(SpellerDesc)]),
+    "las_attention_fwd": (C.c_int, [C.POINTER(SpellerDesc)] + [_f] * 7),
+    "las_attention_bwd_workspace_floats": (C.c_size_t, [C.POINTER(SpellerDesc)]),
+    "las_attention_bwd": (C.c_int, [C.POINTER(SpellerDesc)] + [_f] * 7 + [C.POINTER(SpellerGrads), _f, _f]),
     "las_speller_bwd_workspace_floats": (C.c_size_t, [C.POINTER(SpellerDesc), C.c_int]),
     "las_speller_bwd": (C.c_int, [C.POINTER(SpellerDesc), _f, _f, _f, _f, _f, C.c_int, C.c_int, _f, _f,
                                   C.POINTER(SpellerGrads), _f, C.c_int, _f]),

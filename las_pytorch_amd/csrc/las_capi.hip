@@ -99,6 +99,18 @@ static bool zero_if_contiguous(std::vector<std::pair<float*, size_t>> outs, hipS
     return hipMemsetAsync(outs[0].first, 0, sizeof(float) * total, stream) == hipSuccess;
 }
 
+// attention-only entry points (keys, stand-alone attention): no LSTM / character-distribution weights needed
+int check_attn_desc(const las_speller_desc* d) {
+    LAS_REQUIRE(d != nullptr, "descriptor");
+    LAS_REQUIRE(d->B > 0 && d->Tp > 0 && d->D > 0 && d->Hs > 0, "attention dims");
+    LAS_REQUIRE(d->D == d->Hs, "decoder state width must equal the listener feature width (reference las_model.py:266)");
+    LAS_REQUIRE(d->multi_head >= 1 && d->multi_head <= 16, "attention heads");
+    LAS_REQUIRE(d->multi_head == 1 || (d->use_mlp && d->w_dr && d->b_dr),
+                "multi-head attention needs the phi/psi MLP and dim_reduce (reference las_model.py:266-269)");
+    LAS_REQUIRE(!d->use_mlp || (d->M > 0 && d->w_phi && d->b_phi && d->w_psi && d->b_psi), "attention MLP weights");
+    return LAS_OK;
+}
+
 int check_desc(const las_speller_desc* d) {
     LAS_REQUIRE(d != nullptr, "descriptor");
     LAS_REQUIRE(d->B > 0 && d->Tp > 0 && d->D > 0 && d->Hs > 0 && d->V > 0, "speller dims");
@@ -114,6 +126,78 @@ int check_desc(const las_speller_desc* d) {
     return LAS_OK;
 }
 
+
+
+// The loop-invariant-shaped contractions of the attention backward, shared by the decode loop (U steps), one differentiable
+// decode step and the stand-alone attention (U = 1):  dfeat (context path + psi path), dK -> dW_psi / db_psi, dW_phi / db_phi,
+// dim_reduce gradients.  All pointers are step-major slabs as las_speller_bwd lays them out.
+struct AttnDeferred {
+    const float* feat; const float* keys; const float* att; const float* q_all; const float* de_all; const float* dqpre_all;
+    const float* dctx_all; const float* dctxcat_all = nullptr; const float* ctxcat_all = nullptr; const float* h_top_all;
+    float* dK; int U; bool zg;
+    const float* dx0_ctx = nullptr; long ld_dx0 = 0;      // gradient of the FIRST decoder input's context = feat[:,0,:] (las_model.py:198)
+    bool skip_dw_phi = false;
+};
+static int attention_deferred(const las_speller_desc* d, const AttnDeferred& x, const las_speller_grads* g, hipStream_t stream) {
+    const int B = d->B, Hs = d->Hs, D = d->D, Tp = d->Tp, M = d->M, NH = d->multi_head, U = x.U, UB = U * B;
+    const float* feat = x.feat; const float* keys = x.keys; const float* att = x.att; const float* q_all = x.q_all;
+    const float* de_all = x.de_all; const float* dqpre_all = x.dqpre_all; const float* dctx_all = x.dctx_all;
+    const float* dctxcat_all = x.dctxcat_all; const float* ctxcat_all = x.ctxcat_all; const float* h_top_all = x.h_top_all;
+    float* dK = x.dK; const bool zg = x.zg;
+    for (int hd = 0; hd < NH; ++hd) {   // dfeat[b] (+)= att_h[:,b,:]^T dctx_h[:,b,:]   (context path, las_model.py:293-297,307-313)
+        GemmDesc q;
+        q.A = att + (size_t)hd * B * Tp; q.lda = (long)NH * B * Tp; q.a_kc = false; q.sA = Tp;
+        if (NH == 1) { q.B = dctx_all; q.ldb = (long)B * D; q.sB = D; }
+        else { q.B = dctxcat_all + (size_t)hd * D; q.ldb = (long)B * NH * D; q.sB = (long)NH * D; }
+        q.b_kc = false;
+        q.C = g->dfeat; q.ldc = D; q.sC = (long)Tp * D; q.batch = B;
+        q.M = Tp; q.N = D; q.K = U; q.splitk = 1; q.accumulate = hd > 0;
+        LAS_TRY(gemm_f32(q, stream));
+    }
+    // first decoder input used feat[:,0,:] as context (las_model.py:198)
+    if (x.dx0_ctx) LAS_TRY(copy2d(x.dx0_ctx, x.ld_dx0, g->dfeat, (long)Tp * D, B, D, 1, stream));
+    const int Mq = d->use_mlp ? M : Hs;
+    for (int hd = 0; hd < NH; ++hd) {   // dK[b] (+)= de_h[:,b,:]^T q_h[:,b,:]   (energy path)
+        GemmDesc q;
+        q.A = de_all + (size_t)hd * B * Tp; q.lda = (long)NH * B * Tp; q.a_kc = false; q.sA = Tp;
+        q.B = d->use_mlp ? q_all + (size_t)hd * M : h_top_all; q.ldb = (long)B * Mq * NH; q.b_kc = false; q.sB = (long)Mq * NH;
+        q.C = d->use_mlp ? dK : g->dfeat; q.ldc = Mq; q.sC = (long)Tp * Mq; q.batch = B;
+        q.M = Tp; q.N = Mq; q.K = U; q.splitk = 1; q.accumulate = !d->use_mlp || hd > 0;
+        LAS_TRY(gemm_f32(q, stream));
+    }
+    if (NH > 1) {   // dim_reduce gradients: dW_dr = dctx^T ctxcat, db_dr = sum dctx
+        GemmDesc q;
+        q.A = dctx_all; q.lda = D; q.a_kc = false; q.B = ctxcat_all; q.ldb = (long)NH * D; q.b_kc = false;
+        q.C = g->dw_dr; q.ldc = (long)NH * D; q.M = D; q.N = NH * D; q.K = U * B; q.c_zeroed = zg;
+        LAS_TRY(gemm_f32(q, stream));
+        LAS_TRY(colsum(dctx_all, D, U * B, D, g->db_dr, zg, stream));
+    }
+    if (d->use_mlp) {
+        const int BT = B * Tp;
+        if (d->relu) LAS_TRY(relu_mask_inplace(dK, keys, (long)BT * M, stream));
+        {   // dW_psi = dKpre^T feat
+            GemmDesc q;
+            q.A = dK; q.lda = M; q.a_kc = false; q.B = feat; q.ldb = D; q.b_kc = false;
+            q.C = g->dw_psi; q.ldc = D; q.M = M; q.N = D; q.K = BT; q.c_zeroed = zg;
+            LAS_TRY(gemm_f32(q, stream));
+        }
+        LAS_TRY(colsum(dK, M, BT, M, g->db_psi, zg, stream));
+        {   // dfeat += dKpre W_psi
+            GemmDesc q;
+            q.A = dK; q.lda = M; q.a_kc = true; q.B = d->w_psi; q.ldb = D; q.b_kc = false;
+            q.C = g->dfeat; q.ldc = D; q.M = BT; q.N = D; q.K = M; q.splitk = 1; q.accumulate = true;
+            LAS_TRY(gemm_f32(q, stream));
+        }
+        if (!x.skip_dw_phi) {   // dW_phi = dqpre^T h_top (decode loop, single head: part of its grouped launch instead)
+            GemmDesc q;
+            q.A = dqpre_all; q.lda = (long)M * NH; q.a_kc = false; q.B = h_top_all; q.ldb = Hs; q.b_kc = false;
+            q.C = g->dw_phi; q.ldc = Hs; q.M = M * NH; q.N = Hs; q.K = UB; q.c_zeroed = zg;
+            LAS_TRY(gemm_f32(q, stream));
+        }
+        LAS_TRY(colsum(dqpre_all, (long)M * NH, UB, M * NH, g->db_phi, zg, stream));
+    }
+    return LAS_OK;
+}
 
 }  // namespace
 
@@ -221,7 +305,7 @@ int las_pblstm_bwd(const float* x, const float* dout, int B, int T_in, int D_in,
 // ---------------------------------------------------------------------------------------------- Speller
 int las_attn_keys_fwd(const las_speller_desc* d, const float* feat, float* keys, void* stream_) {
     hipStream_t stream = (hipStream_t)stream_;
-    LAS_TRY(check_desc(d));
+    LAS_TRY(check_attn_desc(d));
     LAS_REQUIRE(d->use_mlp, "keys are the listener features themselves when the attention MLP is off");
     LAS_REQUIRE(feat && keys, "keys pointers");
     GemmDesc g;
@@ -286,6 +370,7 @@ int las_speller_fwd(const las_speller_desc* d, const float* feat, const float* k
     static const bool persist_on = !(getenv("LAS_SPELLER_PERSIST") && atoi(getenv("LAS_SPELLER_PERSIST")) == 0);
     const bool persist = persist_on && err_word && !(flags & LAS_FLAG_FORCE_GENERIC) && (teacher_forced || decode_mode != 2) &&
                          speller_persist_eligible(B, Tp, Hs, D, d->M, V, L, d->multi_head, d->use_mlp, !teacher_forced);
+    bool persist_ran = persist;
     if (persist) {
         PersistFwd p;
         p.w0p = w0p; p.Vp = Vp;
@@ -301,9 +386,11 @@ int las_speller_fwd(const las_speller_desc* d, const float* feat, const float* k
             p.mode = decode_mode == 1 ? 1 : 2;
             p.w_c = d->w_c; p.b_c = d->b_c; p.logp = logp; p.argmax = argmax; p.lgx = reserve + lay.lgx;
         }
-        LAS_TRY(speller_persist_fwd(p, stream));
+        const int rc = speller_persist_fwd(p, stream);
+        if (rc == LAS_ERR_UNSUPPORTED) persist_ran = false;      // residency check failed: the per-step kernels below run instead
+        else LAS_TRY(rc);
     }
-    for (int s = 0; s < (persist ? 0 : U); ++s) {
+    for (int s = 0; s < (persist_ran ? 0 : U); ++s) {
         for (int l = 0; l < L; ++l) {
             CellSeg segs[3];
             int n = 0;
@@ -374,9 +461,24 @@ size_t las_speller_step_workspace_floats(const las_speller_desc* d) {
            r4((size_t)d->B * d->multi_head * d->D);
 }
 
+namespace {
+struct StepReserve {       // stash of one differentiable decode step: post-activation gates, queries, per-head contexts
+    size_t gates, q, ctxcat, total;
+    explicit StepReserve(const las_speller_desc* d) {
+        size_t o = 0;
+        gates = o; o += r4((size_t)d->L * d->B * 4 * d->Hs);
+        q = o; o += r4((size_t)d->B * (d->use_mlp ? d->M : 0) * d->multi_head);
+        ctxcat = o; o += r4(d->multi_head > 1 ? (size_t)d->B * d->multi_head * d->D : 0);
+        total = o;
+    }
+};
+}  // namespace
+
+size_t las_speller_step_reserve_floats(const las_speller_desc* d) { return StepReserve(d).total; }
+
 int las_speller_step_fwd(const las_speller_desc* d, const float* feat, const float* keys, const float* input_word,
                          const float* h_in, const float* c_in, float* logp, float* h_out, float* c_out, float* ctx, float* att,
-                         float* workspace, void* stream_) {
+                         float* workspace, float* reserve, void* stream_) {
     hipStream_t stream = (hipStream_t)stream_;
     LAS_TRY(check_desc(d));
     LAS_REQUIRE(feat && input_word && logp && h_out && c_out && ctx && att && workspace, "step pointers");
@@ -407,15 +509,16 @@ int las_speller_step_fwd(const las_speller_desc* d, const float* feat, const flo
         }
         if (h_in) { segs[n].x = h_in + (size_t)l * sH; segs[n].ldx = Hs; segs[n].w = d->w_hh[l]; segs[n].ldw = Hs; segs[n].K = Hs; ++n; }
         LAS_TRY(lstm_cell_fwd(segs, n, d->b_ih[l], d->b_hh[l], c_in ? c_in + (size_t)l * sH : nullptr, h_out + (size_t)l * sH,
-                              c_out + (size_t)l * sH, nullptr, B, Hs, stream));
+                              c_out + (size_t)l * sH, reserve ? reserve + StepReserve(d).gates + (size_t)l * 4 * sH : nullptr, B, Hs, stream));
     }
     const int NH = d->multi_head;
-    float* ctxcat = w0p + r4((size_t)4 * Hs * (Vp + Hs));
+    float* ctxcat = (reserve && NH > 1) ? reserve + StepReserve(d).ctxcat : w0p + r4((size_t)4 * Hs * (Vp + Hs));
     AttnFwdArgs a;
     a.h_top = h_out + (size_t)(L - 1) * sH;
     a.feat = feat; a.keys = d->use_mlp ? keys : feat;
     a.w_phi = d->w_phi; a.b_phi = d->b_phi; a.w_c = d->w_c; a.b_c = d->b_c;
-    a.q_out = nullptr; a.att_out = att; a.att_hs = (long)B * Tp; a.logp_out = logp; a.argmax_out = nullptr; a.y_next = nullptr; a.ldy = 0;
+    a.q_out = (reserve && d->use_mlp) ? reserve + StepReserve(d).q : nullptr; a.ldq = (long)d->M * NH;
+    a.att_out = att; a.att_hs = (long)B * Tp; a.logp_out = logp; a.argmax_out = nullptr; a.y_next = nullptr; a.ldy = 0;
     a.y_mode = 1;
     a.B = B; a.Tp = Tp; a.D = D; a.M = d->M; a.V = V; a.Hs = Hs; a.use_mlp = d->use_mlp; a.relu = d->relu;
     a.heads = NH;
@@ -492,6 +595,7 @@ int las_speller_bwd(const las_speller_desc* d, const float* feat, const float* k
     static const bool persist_on = !(getenv("LAS_SPELLER_PERSIST_BWD") && atoi(getenv("LAS_SPELLER_PERSIST_BWD")) == 0);
     const bool persist = persist_on && hoist && err_word && !(flags & LAS_FLAG_FORCE_GENERIC) &&
                          speller_persist_bwd_eligible(B, Tp, Hs, D, M, V, L, NH, d->use_mlp);
+    bool persist_ran = persist;
     if (persist) {
         PersistBwd p;
         p.w_ih0 = d->w_ih[0]; p.w_hh0 = d->w_hh[0]; p.w_ih1 = d->w_ih[1]; p.w_hh1 = d->w_hh[1]; p.w_phi = d->w_phi;
@@ -500,9 +604,11 @@ int las_speller_bwd(const las_speller_desc* d, const float* feat, const float* k
         p.dG_all = dG_all; p.dctx_all = dctx_all; p.de_all = de_all; p.dqpre_all = dqpre_all;
         p.dx0 = dx0; p.xbuf = workspace + wl.pxbuf;
         p.B = B; p.Tp = Tp; p.U = U; p.Hs = Hs; p.V = V; p.relu = d->relu; p.err = err_word;
-        LAS_TRY(speller_persist_bwd(p, stream));
+        const int rc = speller_persist_bwd(p, stream);
+        if (rc == LAS_ERR_UNSUPPORTED) persist_ran = false;      // residency check failed: the per-step kernels below run instead
+        else LAS_TRY(rc);
     }
-    for (int s = persist ? -1 : U - 1; s >= 0; --s) {
+    for (int s = persist_ran ? -1 : U - 1; s >= 0; --s) {
         const bool last = (s == U - 1);
         AttnBwdArgs a;
         a.dlogp = dlogp + (size_t)s * B * V; a.logp = logp + (size_t)s * B * V;
@@ -568,57 +674,12 @@ int las_speller_bwd(const las_speller_desc* d, const float* feat, const float* k
         outs.push_back({g->dw_c, (size_t)V * (Hs + D)}); outs.push_back({g->db_c, (size_t)V});
         zg = zero_if_contiguous(outs, stream);
     }
-    for (int hd = 0; hd < NH; ++hd) {   // dfeat[b] (+)= att_h[:,b,:]^T dctx_h[:,b,:]   (context path, las_model.py:293-297,307-313)
-        GemmDesc q;
-        q.A = att + (size_t)hd * B * Tp; q.lda = (long)NH * B * Tp; q.a_kc = false; q.sA = Tp;
-        if (NH == 1) { q.B = dctx_all; q.ldb = (long)B * D; q.sB = D; }
-        else { q.B = dctxcat_all + (size_t)hd * D; q.ldb = (long)B * NH * D; q.sB = (long)NH * D; }
-        q.b_kc = false;
-        q.C = g->dfeat; q.ldc = D; q.sC = (long)Tp * D; q.batch = B;
-        q.M = Tp; q.N = D; q.K = U; q.splitk = 1; q.accumulate = hd > 0;
-        LAS_TRY(gemm_f32(q, stream));
-    }
-    // first decoder input used feat[:,0,:] as context (las_model.py:198)
-    LAS_TRY(copy2d(dx0 + V, V + D, g->dfeat, (long)Tp * D, B, D, 1, stream));
-    const int Mq = d->use_mlp ? M : Hs;
-    for (int hd = 0; hd < NH; ++hd) {   // dK[b] (+)= de_h[:,b,:]^T q_h[:,b,:]   (energy path)
-        GemmDesc q;
-        q.A = de_all + (size_t)hd * B * Tp; q.lda = (long)NH * B * Tp; q.a_kc = false; q.sA = Tp;
-        q.B = d->use_mlp ? q_all + (size_t)hd * M : h_top_all; q.ldb = (long)B * Mq * NH; q.b_kc = false; q.sB = (long)Mq * NH;
-        q.C = d->use_mlp ? dK : g->dfeat; q.ldc = Mq; q.sC = (long)Tp * Mq; q.batch = B;
-        q.M = Tp; q.N = Mq; q.K = U; q.splitk = 1; q.accumulate = !d->use_mlp || hd > 0;
-        LAS_TRY(gemm_f32(q, stream));
-    }
-    if (NH > 1) {   // dim_reduce gradients: dW_dr = dctx^T ctxcat, db_dr = sum dctx
-        GemmDesc q;
-        q.A = dctx_all; q.lda = D; q.a_kc = false; q.B = ctxcat_all; q.ldb = (long)NH * D; q.b_kc = false;
-        q.C = g->dw_dr; q.ldc = (long)NH * D; q.M = D; q.N = NH * D; q.K = U * B; q.c_zeroed = zg;
-        LAS_TRY(gemm_f32(q, stream));
-        LAS_TRY(colsum(dctx_all, D, U * B, D, g->db_dr, zg, stream));
-    }
-    if (d->use_mlp) {
-        const int BT = B * Tp;
-        if (d->relu) LAS_TRY(relu_mask_inplace(dK, keys, (long)BT * M, stream));
-        {   // dW_psi = dKpre^T feat
-            GemmDesc q;
-            q.A = dK; q.lda = M; q.a_kc = false; q.B = feat; q.ldb = D; q.b_kc = false;
-            q.C = g->dw_psi; q.ldc = D; q.M = M; q.N = D; q.K = BT; q.c_zeroed = zg;
-            LAS_TRY(gemm_f32(q, stream));
-        }
-        LAS_TRY(colsum(dK, M, BT, M, g->db_psi, zg, stream));
-        {   // dfeat += dKpre W_psi
-            GemmDesc q;
-            q.A = dK; q.lda = M; q.a_kc = true; q.B = d->w_psi; q.ldb = D; q.b_kc = false;
-            q.C = g->dfeat; q.ldc = D; q.M = BT; q.N = D; q.K = M; q.splitk = 1; q.accumulate = true;
-            LAS_TRY(gemm_f32(q, stream));
-        }
-        if (NH > 1) {   // dW_phi = dqpre^T h_top (single head: part of the grouped launch below)
-            GemmDesc q;
-            q.A = dqpre_all; q.lda = (long)M * NH; q.a_kc = false; q.B = h_top_all; q.ldb = Hs; q.b_kc = false;
-            q.C = g->dw_phi; q.ldc = Hs; q.M = M * NH; q.N = Hs; q.K = UB; q.c_zeroed = zg;
-            LAS_TRY(gemm_f32(q, stream));
-        }
-        LAS_TRY(colsum(dqpre_all, (long)M * NH, UB, M * NH, g->db_phi, zg, stream));
+    {
+        AttnDeferred x;
+        x.feat = feat; x.keys = keys; x.att = att; x.q_all = q_all; x.de_all = de_all; x.dqpre_all = dqpre_all; x.dctx_all = dctx_all;
+        x.dctxcat_all = dctxcat_all; x.ctxcat_all = ctxcat_all; x.h_top_all = h_top_all; x.dK = dK; x.U = U; x.zg = zg;
+        x.dx0_ctx = dx0 + V; x.ld_dx0 = V + D; x.skip_dw_phi = NH == 1;       // single head: dW_phi rides in the grouped launch below
+        LAS_TRY(attention_deferred(d, x, g, stream));
     }
     {   // every remaining weight gradient (K = U*B rows each) in ONE grouped stream-K launch
         GemmDesc gs[8];
@@ -654,6 +715,233 @@ int las_speller_bwd(const las_speller_desc* d, const float* feat, const float* k
             LAS_TRY(colsum(dG_all + (size_t)l * U * 4 * sH, 4 * Hs, UB, 4 * Hs, g->db_ih[l], zg, stream, g->db_hh[l]));
     }
     return LAS_OK;
+}
+
+
+// ---------------------------------------------------------------------------------------------- differentiable decode step
+namespace {
+struct StepBwdLayout {
+    size_t dG, dz, dctx, de, dqpre, dh_top, dh_carry, dc_carry, dK, dctxcat, zeros, total;
+    explicit StepBwdLayout(const las_speller_desc* d) {
+        size_t o = 0;
+        const size_t B = d->B, NH = d->multi_head, Mq = d->use_mlp ? d->M : d->Hs;
+        dG = o; o += r4((size_t)d->L * B * 4 * d->Hs);
+        dz = o; o += r4(B * d->V);
+        dctx = o; o += r4(B * d->D);
+        de = o; o += r4(NH * B * d->Tp);
+        dqpre = o; o += r4(B * d->M * NH + 4);
+        dh_top = o; o += r4((NH + 1) * B * d->Hs);
+        dh_carry = o; o += r4((size_t)d->L * B * d->Hs);
+        dc_carry = o; o += r4((size_t)d->L * B * d->Hs);
+        dK = o; o += r4(B * d->Tp * Mq);
+        dctxcat = o; o += r4(NH > 1 ? B * NH * d->D : 0);
+        zeros = o; o += r4(std::max<size_t>(B * d->V, B * d->D));
+        total = o;
+    }
+};
+
+// zero every gradient output that lies in one contiguous block with one memset (the views of a flat gradient buffer)
+bool zero_speller_grads(const las_speller_desc* d, const las_speller_grads* g, bool lstm, hipStream_t stream) {
+    const int Hs = d->Hs, V = d->V, D = d->D, M = d->M, NH = d->multi_head, L = d->L;
+    std::vector<std::pair<float*, size_t>> outs;
+    if (lstm) {
+        for (int l = 0; l < L; ++l) {
+            outs.push_back({g->dw_ih[l], (size_t)4 * Hs * (l == 0 ? V + Hs : Hs)});
+            outs.push_back({g->dw_hh[l], (size_t)4 * Hs * Hs});
+            outs.push_back({g->db_ih[l], (size_t)4 * Hs});
+            outs.push_back({g->db_hh[l], (size_t)4 * Hs});
+        }
+        outs.push_back({g->dw_c, (size_t)V * (Hs + D)}); outs.push_back({g->db_c, (size_t)V});
+    }
+    if (d->use_mlp) {
+        outs.push_back({g->dw_phi, (size_t)M * NH * Hs}); outs.push_back({g->db_phi, (size_t)M * NH});
+        outs.push_back({g->dw_psi, (size_t)M * D}); outs.push_back({g->db_psi, (size_t)M});
+    }
+    if (NH > 1) { outs.push_back({g->dw_dr, (size_t)D * NH * D}); outs.push_back({g->db_dr, (size_t)D}); }
+    return outs.empty() ? false : zero_if_contiguous(outs, stream);
+}
+}  // namespace
+
+size_t las_speller_step_bwd_workspace_floats(const las_speller_desc* d) { return StepBwdLayout(d).total; }
+
+int las_speller_step_bwd(const las_speller_desc* d, const float* feat, const float* keys, const float* input_word, const float* h_in,
+                         const float* c_in, const float* logp, const float* h_out, const float* c_out, const float* ctx,
+                         const float* att, const float* reserve, const float* dlogp, const float* dh_out, const float* dc_out,
+                         const float* dctx_in, float* dinput_word, float* dh_in, float* dc_in, const las_speller_grads* g,
+                         float* workspace, void* stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    LAS_TRY(check_desc(d));
+    LAS_REQUIRE(feat && input_word && logp && h_out && c_out && ctx && att && reserve && workspace && g, "step bwd pointers");
+    LAS_REQUIRE((h_in == nullptr) == (c_in == nullptr), "h/c state must both be given or both be NULL");
+    LAS_REQUIRE(dinput_word && dh_in && dc_in && g->dfeat && g->dw_c && g->db_c, "step bwd outputs");
+    LAS_REQUIRE(!d->use_mlp || (keys && g->dw_phi && g->db_phi && g->dw_psi && g->db_psi), "attention grad outputs");
+    LAS_REQUIRE(d->multi_head == 1 || (g->dw_dr && g->db_dr), "dim_reduce grad outputs");
+    const int B = d->B, Hs = d->Hs, V = d->V, D = d->D, Tp = d->Tp, L = d->L, M = d->M, NH = d->multi_head;
+    for (int l = 0; l < L; ++l) LAS_REQUIRE(g->dw_ih[l] && g->dw_hh[l] && g->db_ih[l] && g->db_hh[l], "LSTM grad outputs");
+    StepReserve rl(d);
+    StepBwdLayout wl(d);
+    const size_t sH = (size_t)B * Hs;
+    const float* gates = reserve + rl.gates;
+    const float* q = d->use_mlp ? reserve + rl.q : nullptr;
+    const float* ctxcat = NH > 1 ? reserve + rl.ctxcat : nullptr;
+    float* dG = workspace + wl.dG; float* dz = workspace + wl.dz; float* dctx = workspace + wl.dctx; float* de = workspace + wl.de;
+    float* dqpre = workspace + wl.dqpre; float* dh_top = workspace + wl.dh_top; float* dh_carry = workspace + wl.dh_carry;
+    float* dc_carry = workspace + wl.dc_carry; float* dK = workspace + wl.dK; float* dctxcat = workspace + wl.dctxcat;
+    float* zeros = workspace + wl.zeros;
+    const float* h_top = h_out + (size_t)(L - 1) * sH;
+    const float* keys_eff = d->use_mlp ? keys : feat;
+    // carries = gradients flowing into this step's outputs (from the next step or from the caller's loss)
+    LAS_HIP_CHECK(hipMemsetAsync(zeros, 0, sizeof(float) * std::max<size_t>((size_t)B * V, (size_t)B * D), stream));
+    if (dh_out) LAS_HIP_CHECK(hipMemcpyAsync(dh_carry, dh_out, sizeof(float) * L * sH, hipMemcpyDeviceToDevice, stream));
+    else LAS_HIP_CHECK(hipMemsetAsync(dh_carry, 0, sizeof(float) * L * sH, stream));
+    if (dc_out) LAS_HIP_CHECK(hipMemcpyAsync(dc_carry, dc_out, sizeof(float) * L * sH, hipMemcpyDeviceToDevice, stream));
+    else LAS_HIP_CHECK(hipMemsetAsync(dc_carry, 0, sizeof(float) * L * sH, stream));
+    auto cell_pw = [&](int l) {
+        CellPw pw;
+        pw.gates = gates + (size_t)l * 4 * sH; pw.c = c_out + (size_t)l * sH; pw.c_prev = c_in ? c_in + (size_t)l * sH : nullptr;
+        pw.dh_carry = dh_carry + (size_t)l * sH; pw.dc_in = dc_carry + (size_t)l * sH;
+        pw.dG = dG + (size_t)l * 4 * sH; pw.dc_out = dc_carry + (size_t)l * sH;
+        return pw;
+    };
+    AttnBwdArgs a;
+    a.dlogp = dlogp ? dlogp : zeros; a.logp = logp; a.dcat_pre = nullptr;
+    a.h_top = h_top; a.ctx = ctx; a.att = att; a.att_hs = (long)B * Tp;
+    a.q = q; a.ldq = (long)M * NH;
+    a.feat = feat; a.keys = keys_eff; a.w_phi = d->w_phi; a.w_c = d->w_c;
+    a.dctx_carry = dctx_in; a.ldc = D; a.dy_carry = nullptr; a.ldy = 0;
+    a.dz_out = dz; a.dctx_out = dctx; a.de_out = de; a.dqpre_out = dqpre;
+    a.B = B; a.Tp = Tp; a.D = D; a.M = M; a.V = V; a.Hs = Hs; a.use_mlp = d->use_mlp; a.relu = d->relu; a.heads = NH;
+    if (NH == 1) {
+        a.dh_top_out = nullptr; a.pw = cell_pw(L - 1);
+        LAS_TRY(attn_step_bwd(a, stream));
+    } else {
+        a.phases = 1; a.dh_top_out = dh_top; a.dh_hs = 0;
+        LAS_TRY(attn_step_bwd(a, stream));
+        LAS_TRY(smallm_gemm_nn2(dctx, D, B, D, d->w_dr, (long)NH * D, dctxcat, (long)NH * D, NH * D, nullptr, 0, nullptr, 0, 0, CellPw(), Hs, stream));
+        a.phases = 2; a.dctx_in = dctxcat; a.ld_dctx_in = (long)NH * D; a.dh_top_out = dh_top + sH; a.dh_hs = (long)sH;
+        LAS_TRY(attn_step_bwd(a, stream));
+        const CellPw pw = cell_pw(L - 1);
+        LAS_TRY(lstm_cell_bwd_pointwise(dh_top, NH + 1, (long)sH, pw.dh_carry, pw.dc_in, pw.gates, pw.c, pw.c_prev, pw.dG, pw.dc_out, B, Hs, stream));
+    }
+    for (int l = L - 1; l >= 0; --l) {
+        const float* dGl = dG + (size_t)l * 4 * sH;
+        if (l > 0) {
+            LAS_TRY(smallm_gemm_nn2(dGl, 4 * Hs, B, 4 * Hs, d->w_ih[l], Hs, nullptr, Hs, Hs, d->w_hh[l], Hs, dh_carry + (size_t)l * sH, Hs, Hs,
+                                    cell_pw(l - 1), Hs, stream));
+        } else {
+            LAS_TRY(smallm_gemm_nn2(dGl, 4 * Hs, B, 4 * Hs, d->w_ih[0], V + Hs, dinput_word, V + Hs, V + Hs, d->w_hh[0], Hs, dh_carry, Hs, Hs,
+                                    CellPw(), Hs, stream));
+        }
+    }
+    LAS_HIP_CHECK(hipMemcpyAsync(dh_in, dh_carry, sizeof(float) * L * sH, hipMemcpyDeviceToDevice, stream));
+    LAS_HIP_CHECK(hipMemcpyAsync(dc_in, dc_carry, sizeof(float) * L * sH, hipMemcpyDeviceToDevice, stream));
+
+    // ---- parameter gradients and dfeat of this one step (K = B rows)
+    const bool zg = zero_speller_grads(d, g, true, stream);
+    {
+        AttnDeferred x;
+        x.feat = feat; x.keys = keys; x.att = att; x.q_all = q; x.de_all = de; x.dqpre_all = dqpre; x.dctx_all = dctx;
+        x.dctxcat_all = dctxcat; x.ctxcat_all = ctxcat; x.h_top_all = h_top; x.dK = dK; x.U = 1; x.zg = zg;
+        LAS_TRY(attention_deferred(d, x, g, stream));
+    }
+    auto tn = [&](const float* A, long lda, const float* Bm, long ldb, float* C, long ldc, int Mv, int Nv) {
+        GemmDesc q2;
+        q2.A = A; q2.lda = lda; q2.a_kc = false; q2.B = Bm; q2.ldb = ldb; q2.b_kc = false; q2.C = C; q2.ldc = ldc; q2.M = Mv; q2.N = Nv; q2.K = B;
+        q2.c_zeroed = zg; q2.splitk = 1;
+        return gemm_f32(q2, stream);
+    };
+    LAS_TRY(tn(dz, V, h_top, Hs, g->dw_c, Hs + D, V, Hs));
+    LAS_TRY(tn(dz, V, ctx, D, g->dw_c + Hs, Hs + D, V, D));
+    LAS_TRY(colsum(dz, V, B, V, g->db_c, zg, stream));
+    for (int l = 0; l < L; ++l) {
+        const float* dGl = dG + (size_t)l * 4 * sH;
+        if (l == 0) LAS_TRY(tn(dGl, 4 * Hs, input_word, V + Hs, g->dw_ih[0], V + Hs, 4 * Hs, V + Hs));
+        else LAS_TRY(tn(dGl, 4 * Hs, h_out + (size_t)(l - 1) * sH, Hs, g->dw_ih[l], Hs, 4 * Hs, Hs));
+        if (h_in) LAS_TRY(tn(dGl, 4 * Hs, h_in + (size_t)l * sH, Hs, g->dw_hh[l], Hs, 4 * Hs, Hs));
+        else if (!zg) LAS_HIP_CHECK(hipMemsetAsync(g->dw_hh[l], 0, sizeof(float) * 4 * Hs * Hs, stream));
+        LAS_TRY(colsum(dGl, 4 * Hs, B, 4 * Hs, g->db_ih[l], zg, stream, g->db_hh[l]));
+    }
+    return LAS_OK;
+}
+
+// ---------------------------------------------------------------------------------------------- stand-alone attention
+size_t las_attention_reserve_floats(const las_speller_desc* d) {
+    return r4((size_t)d->B * (d->use_mlp ? d->M : 0) * d->multi_head) + r4(d->multi_head > 1 ? (size_t)d->B * d->multi_head * d->D : 0);
+}
+
+int las_attention_fwd(const las_speller_desc* d, const float* feat, const float* keys, const float* decoder_state, float* att,
+                      float* ctx, float* reserve, void* stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    LAS_TRY(check_attn_desc(d));
+    LAS_REQUIRE(feat && decoder_state && att && ctx && reserve, "attention pointers");
+    LAS_REQUIRE(!d->use_mlp || keys, "attention keys");
+    const int B = d->B, NH = d->multi_head, D = d->D;
+    float* q = reserve;
+    float* ctxcat = reserve + r4((size_t)B * (d->use_mlp ? d->M : 0) * NH);
+    AttnFwdArgs a;
+    a.h_top = decoder_state; a.feat = feat; a.keys = d->use_mlp ? keys : feat;
+    a.w_phi = d->w_phi; a.b_phi = d->b_phi; a.w_c = d->w_c; a.b_c = d->b_c;
+    a.q_out = d->use_mlp ? q : nullptr; a.ldq = (long)d->M * NH;
+    a.att_out = att; a.att_hs = (long)B * d->Tp; a.logp_out = nullptr; a.argmax_out = nullptr; a.y_next = nullptr; a.ldy = 0; a.y_mode = 1;
+    a.B = B; a.Tp = d->Tp; a.D = D; a.M = d->M; a.V = d->V; a.Hs = d->Hs; a.use_mlp = d->use_mlp; a.relu = d->relu; a.heads = NH;
+    if (NH == 1) {
+        a.ctx_out = ctx; a.ldctx = D;
+        return attn_step_fwd(a, stream);
+    }
+    a.ctx_out = ctxcat; a.ldctx = (long)NH * D; a.phases = 1;
+    LAS_TRY(attn_step_fwd(a, stream));
+    CellSeg sg; sg.x = ctxcat; sg.ldx = (long)NH * D; sg.w = d->w_dr; sg.ldw = (long)NH * D; sg.K = NH * D;
+    return smallm_linear_nt(&sg, 1, d->b_dr, ctx, D, B, D, stream);
+}
+
+size_t las_attention_bwd_workspace_floats(const las_speller_desc* d) {
+    const size_t B = d->B, NH = d->multi_head, Mq = d->use_mlp ? d->M : d->Hs;
+    return r4(NH * B * d->Tp) + r4(B * d->M * NH + 4) + r4(NH * B * d->Hs) + r4(B * d->Tp * Mq) + r4(NH > 1 ? B * NH * d->D : 0);
+}
+
+int las_attention_bwd(const las_speller_desc* d, const float* feat, const float* keys, const float* decoder_state, const float* att,
+                      const float* reserve, const float* dctx, float* ddecoder_state, const las_speller_grads* g, float* workspace,
+                      void* stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    LAS_TRY(check_attn_desc(d));
+    LAS_REQUIRE(feat && decoder_state && att && reserve && dctx && ddecoder_state && g && g->dfeat && workspace, "attention bwd pointers");
+    LAS_REQUIRE(!d->use_mlp || (keys && g->dw_phi && g->db_phi && g->dw_psi && g->db_psi), "attention grad outputs");
+    LAS_REQUIRE(d->multi_head == 1 || (g->dw_dr && g->db_dr), "dim_reduce grad outputs");
+    const int B = d->B, Hs = d->Hs, D = d->D, Tp = d->Tp, M = d->M, NH = d->multi_head;
+    const size_t sH = (size_t)B * Hs;
+    const size_t Mq = d->use_mlp ? M : Hs;
+    const float* q = d->use_mlp ? reserve : nullptr;
+    const float* ctxcat = reserve + r4((size_t)B * (d->use_mlp ? M : 0) * NH);
+    float* de = workspace;
+    float* dqpre = de + r4((size_t)NH * B * Tp);
+    float* dh_parts = dqpre + r4((size_t)B * M * NH + 4);
+    float* dK = dh_parts + r4((size_t)NH * sH);
+    float* dctxcat = dK + r4((size_t)B * Tp * Mq);
+    const float* dctx_heads = dctx;
+    long ld_dctx = D;
+    if (NH > 1) {      // dim_reduce backward: gradient of the concatenated per-head contexts
+        LAS_TRY(smallm_gemm_nn2(dctx, D, B, D, d->w_dr, (long)NH * D, dctxcat, (long)NH * D, NH * D, nullptr, 0, nullptr, 0, 0, CellPw(), Hs, stream));
+        dctx_heads = dctxcat; ld_dctx = (long)NH * D;
+    }
+    AttnBwdArgs a;
+    a.dlogp = nullptr; a.logp = nullptr; a.dcat_pre = nullptr; a.h_top = decoder_state; a.ctx = nullptr;
+    a.att = att; a.att_hs = (long)B * Tp; a.q = q; a.ldq = (long)M * NH;
+    a.feat = feat; a.keys = d->use_mlp ? keys : feat; a.w_phi = d->w_phi; a.w_c = d->w_c;
+    a.dctx_carry = nullptr; a.ldc = 0; a.dy_carry = nullptr; a.ldy = 0;
+    a.dz_out = nullptr; a.dctx_out = nullptr; a.de_out = de; a.dqpre_out = dqpre;
+    a.B = B; a.Tp = Tp; a.D = D; a.M = M; a.V = d->V; a.Hs = Hs; a.use_mlp = d->use_mlp; a.relu = d->relu; a.heads = NH;
+    a.phases = 2; a.dctx_in = dctx_heads; a.ld_dctx_in = ld_dctx;
+    a.dh_top_out = NH == 1 ? ddecoder_state : dh_parts; a.dh_hs = (long)sH;
+    LAS_TRY(attn_step_bwd(a, stream));
+    if (NH > 1) {
+        LAS_HIP_CHECK(hipMemcpyAsync(ddecoder_state, dh_parts, sizeof(float) * sH, hipMemcpyDeviceToDevice, stream));
+        for (int hd = 1; hd < NH; ++hd) LAS_TRY(add_inplace(ddecoder_state, dh_parts + (size_t)hd * sH, (long)sH, stream));
+    }
+    const bool zg = zero_speller_grads(d, g, false, stream);
+    AttnDeferred x;
+    x.feat = feat; x.keys = keys; x.att = att; x.q_all = q; x.de_all = de; x.dqpre_all = dqpre; x.dctx_all = dctx;
+    x.dctxcat_all = dctxcat; x.ctxcat_all = ctxcat; x.h_top_all = decoder_state; x.dK = dK; x.U = 1; x.zg = zg;
+    return attention_deferred(d, x, g, stream);
 }
 
 // ---------------------------------------------------------------------------------------------- caller-side contract

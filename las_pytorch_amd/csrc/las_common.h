@@ -71,4 +71,16 @@ using f32x16 = __attribute__((ext_vector_type(16))) float;
 
 static inline int cdiv(long a, long b) { return (int)((a + b - 1) / b); }
 
+// Co-residency check of a persistent launch whose workgroups spin on each other: the occupancy calculator must admit at
+// least one workgroup of this kernel per CU with the launch's REAL dynamic LDS size (register / LDS footprint), and the
+// grid must not exceed the CU count.  The caller falls back to kernels without inter-workgroup waits otherwise.
+template <class Kern>
+inline bool persistent_launch_fits(Kern kernel, int threads, size_t dyn_lds, int grid) {
+    int dev = 0, cus = 0, nb = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return false;
+    if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) return false;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, kernel, threads, dyn_lds) != hipSuccess) return false;
+    return nb >= 1 && grid <= cus;
+}
+
 }  // namespace las

@@ -807,6 +807,7 @@ int pblstm_rec_fwd(float* gates, const float* w_hh_f, const float* w_hh_r, float
         plan = rec_plan(B, H / uw, std::min(nb_env, nb_max), nb_max, device_cus());
         if (plan.nb > 1 && uw != (H == 128 ? 128 : (H == 256 ? 64 : 32))) plan.nb = 0;      // multi kernels exist for the default UW only
     }
+    bool fits = true;       // occupancy calculator admits one workgroup of the chosen kernel per CU
     if (plan.nb > 0) {
         LAS_REQUIRE(xbuf && err, "hand-off buffers");
         const int G = H / uw;
@@ -819,8 +820,9 @@ int pblstm_rec_fwd(float* gates, const float* w_hh_f, const float* w_hh_r, float
 #define TRY_FWD(HH, UWV)                                                                                                  \
     if (!launched && plan.nb == 1 && H == HH && uw == UWV) {                                                             \
         launched = true;                                                                                                  \
-        float* g0 = gates; (void)g0;                                                                                      \
         if (b0 != 0 || Bc != B) return fail(LAS_ERR_UNSUPPORTED, "chunked launch needs the multi kernel%s", "");          \
+        fits = persistent_launch_fits(rec_fwd_fast<HH, UWV, true>, block.x, 0, grid.x);                                   \
+        if (!fits) break;                                                                                                 \
         if (stash) hipLaunchKernelGGL((rec_fwd_fast<HH, UWV, true>), grid, block, 0, stream, gates, w_hh_f, w_hh_r, out,  \
                                       cbuf, hprev, B, T, xbuf, err, dbg);                                                 \
         else hipLaunchKernelGGL((rec_fwd_fast<HH, UWV, false>), grid, block, 0, stream, gates, w_hh_f, w_hh_r, out, cbuf, \
@@ -829,6 +831,8 @@ int pblstm_rec_fwd(float* gates, const float* w_hh_f, const float* w_hh_r, float
 #define TRY_FWD_M(HH, UWV, NBV)                                                                                           \
     if (!launched && plan.nb == NBV && H == HH && uw == UWV) {                                                           \
         launched = true;                                                                                                  \
+        fits = persistent_launch_fits(rec_fwd_multi<HH, UWV, NBV, true>, block.x, 0, grid.x);                             \
+        if (!fits) break;                                                                                                 \
         if (stash) hipLaunchKernelGGL((rec_fwd_multi<HH, UWV, NBV, true>), grid, block, 0, stream, gates, w_hh_f, w_hh_r, \
                                       out, cbuf, hprev, B, T, xbuf, err, dbg, b0, Bc);                                    \
         else hipLaunchKernelGGL((rec_fwd_multi<HH, UWV, NBV, false>), grid, block, 0, stream, gates, w_hh_f, w_hh_r, out, \
@@ -845,7 +849,8 @@ int pblstm_rec_fwd(float* gates, const float* w_hh_f, const float* w_hh_r, float
             if (!launched) return fail(LAS_ERR_UNSUPPORTED, "no recurrence kernel for %s H=%ld uw=%ld", "", (long)H, (long)uw);
             LAS_LAUNCH_CHECK();
         }
-    } else {
+    }
+    if (plan.nb == 0 || !fits) {
         const size_t smem = sizeof(float) * 3 * H;
         if (stash) hipLaunchKernelGGL((rec_fwd_generic<true>), dim3(ngroups), dim3(256), smem, stream, gates, w_hh_f, w_hh_r,
                                       out, cbuf, hprev, B, T, H);
@@ -861,6 +866,7 @@ static int launch_bwd_multi(const float* dout, const float* gates, const float* 
                             u64* xbuf, unsigned* err, int b0, int Bc, int grid, hipStream_t stream) {
     const size_t smem = sizeof(float) * ((size_t)2 * NB * H + (size_t)NB * 4 * H);
     LAS_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&rec_bwd_multi<H, NB>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
+    if (!persistent_launch_fits(rec_bwd_multi<H, NB>, REC_THREADS, smem, grid)) return fail(LAS_ERR_UNSUPPORTED, "backward recurrence: %s%ld workgroups cannot all be resident", "", (long)grid);
     hipLaunchKernelGGL((rec_bwd_multi<H, NB>), dim3(grid), dim3(REC_THREADS), smem, stream, dout, gates, cbuf, w_hh_t, dgates, B, T, xbuf,
                        err, b0, Bc);
     LAS_LAUNCH_CHECK();
@@ -878,29 +884,38 @@ int pblstm_rec_bwd(const float* dout, const float* gates, const float* cbuf, con
         const int nb_max = H == 128 ? 8 : (H == 256 ? 8 : 4);
         plan = rec_plan(B, G, std::min(nb_env, nb_max), nb_max, device_cus());
     }
+    bool fits = true;
     if (plan.nb > 0) {
         LAS_REQUIRE(xbuf && err, "hand-off buffers");
-        for (int b0 = 0; b0 < B; b0 += plan.chunk) {
+        for (int b0 = 0; b0 < B && fits; b0 += plan.chunk) {
             const int Bc = std::min(plan.chunk, B - b0);
             const int nblk = (Bc + plan.nb - 1) / plan.nb;
             const int grid = 2 * nblk * G;
             if (G > 1) LAS_HIP_CHECK(hipMemsetAsync(xbuf, 0, rec_xbuf_bytes(B, H), stream));
             if (plan.nb == 1) {
                 if (b0 != 0 || Bc != B) return fail(LAS_ERR_UNSUPPORTED, "chunked launch needs the multi kernel%s", "");
+                fits = H == 128 ? persistent_launch_fits(rec_bwd_fast<128>, REC_THREADS, 0, grid)
+                     : H == 256 ? persistent_launch_fits(rec_bwd_fast<256>, REC_THREADS, 0, grid)
+                                : persistent_launch_fits(rec_bwd_fast<512>, REC_THREADS, 0, grid);
+                if (!fits) break;
                 if (H == 128) hipLaunchKernelGGL((rec_bwd_fast<128>), dim3(grid), dim3(REC_THREADS), 0, stream, dout, gates, cbuf, w_hh_t, dgates, B, T, xbuf, err);
                 else if (H == 256) hipLaunchKernelGGL((rec_bwd_fast<256>), dim3(grid), dim3(REC_THREADS), 0, stream, dout, gates, cbuf, w_hh_t, dgates, B, T, xbuf, err);
                 else hipLaunchKernelGGL((rec_bwd_fast<512>), dim3(grid), dim3(REC_THREADS), 0, stream, dout, gates, cbuf, w_hh_t, dgates, B, T, xbuf, err);
                 LAS_LAUNCH_CHECK();
                 continue;
             }
-#define TRY_BWD_M(HH, NBV) if (H == HH && plan.nb == NBV) { LAS_TRY((launch_bwd_multi<HH, NBV>(dout, gates, cbuf, w_hh_t, dgates, B, T, xbuf, err, b0, Bc, grid, stream))); continue; }
+#define TRY_BWD_M(HH, NBV) if (H == HH && plan.nb == NBV) {                                                                          \
+        const int rc = launch_bwd_multi<HH, NBV>(dout, gates, cbuf, w_hh_t, dgates, B, T, xbuf, err, b0, Bc, grid, stream);           \
+        if (rc == LAS_ERR_UNSUPPORTED) { fits = false; break; }                                                                       \
+        LAS_TRY(rc); continue; }
             TRY_BWD_M(128, 2) TRY_BWD_M(128, 4) TRY_BWD_M(128, 8)
             TRY_BWD_M(256, 2) TRY_BWD_M(256, 4) TRY_BWD_M(256, 8)
             TRY_BWD_M(512, 2) TRY_BWD_M(512, 4)
 #undef TRY_BWD_M
             return fail(LAS_ERR_UNSUPPORTED, "no backward recurrence kernel for %s H=%ld nb=%ld", "", (long)H, (long)plan.nb);
         }
-    } else {
+    }
+    if (plan.nb == 0 || !fits) {
         const size_t smem = sizeof(float) * 7 * H;
         hipLaunchKernelGGL(rec_bwd_generic, dim3(ngroups), dim3(256), smem, stream, dout, gates, cbuf, w_hh_t, dgates, B, T, H);
     }

@@ -628,6 +628,8 @@ static int launch_persist_fwd2(const PersistArgs& a, int grid, hipStream_t strea
     LAS_REQUIRE(smem <= 160 * 1024, "persistent speller LDS budget");
     LAS_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&speller_persist_fwd_kernel<HS, SPLIT, GREEDY>),
                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
+    if (!persistent_launch_fits(speller_persist_fwd_kernel<HS, SPLIT, GREEDY>, PS_THREADS, smem, grid))
+        return fail(LAS_ERR_UNSUPPORTED, "persistent decode kernel: %s%ld workgroups cannot all be resident", "", (long)grid);
     hipLaunchKernelGGL((speller_persist_fwd_kernel<HS, SPLIT, GREEDY>), dim3(grid), dim3(PS_THREADS), smem, stream, a);
     LAS_LAUNCH_CHECK();
     return LAS_OK;

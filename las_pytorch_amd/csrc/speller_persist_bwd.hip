@@ -534,6 +534,8 @@ static int launch_persist_bwd(const PersistBwdArgs& a, int grid, hipStream_t str
     const size_t smem = sizeof(float) * (size_t)std::max(ProdRole<HS>::LDS_FLOATS, AttnBwdRole<HS>::lds_floats());
     LAS_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&speller_persist_bwd_kernel<HS>),
                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
+    if (!persistent_launch_fits(speller_persist_bwd_kernel<HS>, PS_THREADS, smem, grid))
+        return fail(LAS_ERR_UNSUPPORTED, "persistent decode backward: %s%ld workgroups cannot all be resident", "", (long)grid);
     hipLaunchKernelGGL((speller_persist_bwd_kernel<HS>), dim3(grid), dim3(PS_THREADS), smem, stream, a);
     LAS_LAUNCH_CHECK();
     return LAS_OK;

@@ -58,6 +58,8 @@ def _flags(stash, force_generic=False):
 
 
 def _f32c(t):
+    if not t.is_cuda:
+        raise RuntimeError("the LAS HIP path needs CUDA(ROCm) tensors; there is no CPU fallback")
     if t.dtype != torch.float32:
         raise RuntimeError("the LAS HIP path computes in fp32; got " + str(t.dtype))
     return t.contiguous()
@@ -214,8 +216,24 @@ class Attention(nn.Module):
                     raise NotImplementedError(f"mlp_activate_in_attention={activate!r}: the HIP path implements 'relu' and 'None'")
                 self.activate = activate
 
+    def _params(self):
+        ps = []
+        if self.mlp_preprocess_input:
+            ps += [self.phi.weight, self.phi.bias, self.psi.weight, self.psi.bias]
+            if self.multi_head > 1:
+                ps += [self.dim_reduce.weight, self.dim_reduce.bias]
+        return ps
+
     def forward(self, decoder_state, listener_feature):
-        raise RuntimeError("Attention is fused into the Speller step kernels; call Speller.forward / forward_step")
+        """Reference las_model.py:275-318: ``decoder_state`` (B,1,2H) [or (B,2H)], ``listener_feature`` (B,T',2H) ->
+        ``([attention_score (B,T') per head], context (B,2H))``.  Differentiable wrt the decoder state, the listener
+        features and phi / psi / dim_reduce (``las_attention_fwd`` / ``las_attention_bwd``); the returned scores are
+        for inspection and carry no gradient.  Inside ``Speller.forward`` the same arithmetic runs fused in the decode
+        kernels; this entry point serves callers that use the module on its own."""
+        use_mlp = bool(self.mlp_preprocess_input)
+        cfg = (use_mlp, self.activate == "relu", int(self.preprocess_mlp_dim) if use_mlp else 0, int(self.multi_head))
+        ctx, att = _AttentionFn.apply(cfg, decoder_state.reshape(decoder_state.shape[0], -1), listener_feature, *self._params())
+        return list(att.unbind(0)), ctx
 
 
 def _speller_desc(B, Tp, D, Hs, V, M, L, use_mlp, relu, lstm, rest, heads=1):
@@ -235,6 +253,155 @@ def _speller_desc(B, Tp, D, Hs, V, M, L, use_mlp, relu, lstm, rest, heads=1):
             rest = rest[2:]
     d.w_c, d.b_c = ptr(rest[0]), ptr(rest[1])
     return d
+
+
+
+def _attn_desc(B, Tp, D, use_mlp, relu, M, heads, params):
+    """Descriptor for the attention-only entry points (no LSTM / character-distribution weights)."""
+    d = SpellerDesc()
+    d.B, d.Tp, d.D, d.Hs, d.V, d.M, d.L = B, Tp, D, D, 1, M, 1
+    d.use_mlp, d.relu, d.multi_head = int(use_mlp), int(relu), int(heads)
+    if use_mlp:
+        d.w_phi, d.b_phi, d.w_psi, d.b_psi = (ptr(t) for t in params[:4])
+        if heads > 1:
+            d.w_dr, d.b_dr = ptr(params[4]), ptr(params[5])
+    return d
+
+
+class _AttentionFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, cfg, state, feat, *params):
+        use_mlp, relu, M, heads = cfg
+        state, feat = _f32c(state), _f32c(feat)
+        B, Tp, D = feat.shape
+        if state.shape != (B, D):
+            raise RuntimeError(f"decoder_state must be (B,1,{D}) / (B,{D}), got {tuple(state.shape)}")
+        direct = _direct_targets(params)
+        params = [_f32c(p) for p in params]
+        dev = feat.device
+        Lh, stream = lib(), stream_ptr()
+        d = _attn_desc(B, Tp, D, use_mlp, relu, M, heads, params)
+        keys = None
+        if use_mlp:
+            keys = torch.empty(B, Tp, M, device=dev, dtype=torch.float32)
+            check(Lh.las_attn_keys_fwd(d, ptr(feat), ptr(keys), stream))
+        att = torch.empty(heads, B, Tp, device=dev, dtype=torch.float32)
+        context = torch.empty(B, D, device=dev, dtype=torch.float32)
+        reserve = torch.empty(max(4, Lh.las_attention_reserve_floats(d)), device=dev, dtype=torch.float32)
+        check(Lh.las_attention_fwd(d, ptr(feat), ptr(keys), ptr(state), ptr(att), ptr(context), ptr(reserve), stream))
+        ctx.mark_non_differentiable(att)
+        if any(ctx.needs_input_grad):
+            ctx.save_for_backward(state, feat, keys, att, reserve, *params)
+            ctx.cfg, ctx.direct = cfg, direct
+        return context, att
+
+    @staticmethod
+    def backward(ctx, dctx, _datt):
+        state, feat, keys, att, reserve, *params = ctx.saved_tensors
+        use_mlp, relu, M, heads = ctx.cfg
+        B, Tp, D = feat.shape
+        dev = feat.device
+        Lh = lib()
+        d = _attn_desc(B, Tp, D, use_mlp, relu, M, heads, params)
+        grads = ctx.direct or [torch.empty_like(p) for p in params]
+        g = SpellerGrads()
+        if use_mlp:
+            g.dw_phi, g.db_phi, g.dw_psi, g.db_psi = (ptr(t) for t in grads[:4])
+            if heads > 1:
+                g.dw_dr, g.db_dr = ptr(grads[4]), ptr(grads[5])
+        dfeat = torch.empty_like(feat)
+        dstate = torch.empty_like(state)
+        g.dfeat = ptr(dfeat)
+        work = torch.empty(Lh.las_attention_bwd_workspace_floats(d), device=dev, dtype=torch.float32)
+        check(Lh.las_attention_bwd(d, ptr(feat), ptr(keys), ptr(state), ptr(att), ptr(reserve), ptr(_f32c(dctx)), ptr(dstate), g,
+                                   ptr(work), stream_ptr()))
+        return (None, dstate, dfeat, *([None] * len(grads) if ctx.direct else grads))
+
+
+class _SpellerStepFn(torch.autograd.Function):
+    """One decode step with caller-managed state and its backward (``las_speller_step_fwd`` / ``las_speller_step_bwd``)."""
+
+    @staticmethod
+    def forward(ctx, cfg, feat, x, h_in, c_in, *params):
+        (L, use_mlp, relu, M, V, heads) = cfg
+        feat, x = _f32c(feat), _f32c(x)
+        B, Tp, D = feat.shape
+        direct = _direct_targets(params)
+        params = [_f32c(p) for p in params]
+        lstm, rest = params[:4 * L], params[4 * L:]
+        Hs = lstm[1].shape[1]
+        if D != Hs:
+            raise RuntimeError(f"Speller hidden_size ({Hs}) must equal 2*listener_hidden_size ({D}) (reference las_model.py:198)")
+        if x.shape != (B, V + Hs):
+            raise RuntimeError(f"input_word must be (B,1,{V + Hs}), got {tuple(x.shape)}")
+        dev = feat.device
+        Lh, stream = lib(), stream_ptr()
+        d = _speller_desc(B, Tp, D, Hs, V, M, L, use_mlp, relu, lstm, rest, heads)
+        keys = None
+        if use_mlp:
+            keys = torch.empty(B, Tp, M, device=dev, dtype=torch.float32)
+            check(Lh.las_attn_keys_fwd(d, ptr(feat), ptr(keys), stream))
+        if h_in is not None:
+            h_in, c_in = _f32c(h_in), _f32c(c_in)
+        train = any(ctx.needs_input_grad)
+        logp = torch.empty(B, V, device=dev); context = torch.empty(B, D, device=dev); att = torch.empty(heads, B, Tp, device=dev)
+        h_out = torch.empty(L, B, Hs, device=dev); c_out = torch.empty(L, B, Hs, device=dev)
+        work = torch.empty(Lh.las_speller_step_workspace_floats(d), device=dev, dtype=torch.float32)
+        reserve = torch.empty(max(4, Lh.las_speller_step_reserve_floats(d)), device=dev, dtype=torch.float32) if train else None
+        check(Lh.las_speller_step_fwd(d, ptr(feat), ptr(keys), ptr(x), ptr(h_in), ptr(c_in), ptr(logp), ptr(h_out), ptr(c_out),
+                                      ptr(context), ptr(att), ptr(work), ptr(reserve), stream))
+        ctx.mark_non_differentiable(att)
+        if train:
+            ctx.has_state = h_in is not None
+            saved = [feat, keys, x, logp, h_out, c_out, context, att, reserve] + ([h_in, c_in] if ctx.has_state else []) + params
+            ctx.save_for_backward(*saved)
+            ctx.cfg, ctx.direct = cfg, direct
+        return logp, h_out, c_out, context, att
+
+    @staticmethod
+    def backward(ctx, dlogp, dh_out, dc_out, dctx, _datt):
+        feat, keys, x, logp, h_out, c_out, context, att, reserve, *rest_saved = ctx.saved_tensors
+        (L, use_mlp, relu, M, V, heads) = ctx.cfg
+        h_in = c_in = None
+        if ctx.has_state:
+            h_in, c_in, *params = rest_saved
+        else:
+            params = rest_saved
+        B, Tp, D = feat.shape
+        Hs = params[1].shape[1]
+        dev = feat.device
+        Lh = lib()
+        lstm, rest = params[:4 * L], params[4 * L:]
+        d = _speller_desc(B, Tp, D, Hs, V, M, L, use_mlp, relu, lstm, rest, heads)
+        grads = ctx.direct or [torch.empty_like(p) for p in params]
+        g = _speller_grads(grads, L, use_mlp, heads)
+        dfeat = torch.empty_like(feat)
+        g.dfeat = ptr(dfeat)
+        dx = torch.empty_like(x)
+        dh_in = torch.empty(L, B, Hs, device=dev); dc_in = torch.empty(L, B, Hs, device=dev)
+        work = torch.empty(Lh.las_speller_step_bwd_workspace_floats(d), device=dev, dtype=torch.float32)
+        opt = lambda t: ptr(_f32c(t)) if t is not None else None
+        keep = [t if t is None else _f32c(t) for t in (dlogp, dh_out, dc_out, dctx)]      # keep the contiguous copies alive
+        check(Lh.las_speller_step_bwd(d, ptr(feat), ptr(keys), ptr(x), ptr(h_in), ptr(c_in), ptr(logp), ptr(h_out), ptr(c_out),
+                                      ptr(context), ptr(att), ptr(reserve), *[ptr(t) for t in keep], ptr(dx), ptr(dh_in), ptr(dc_in),
+                                      g, ptr(work), stream_ptr()))
+        return (None, dfeat, dx, dh_in if ctx.has_state else None, dc_in if ctx.has_state else None,
+                *([None] * len(grads) if ctx.direct else grads))
+
+
+def _speller_grads(grads, L, use_mlp, heads):
+    g = SpellerGrads()
+    for l in range(L):
+        g.dw_ih[l], g.dw_hh[l], g.db_ih[l], g.db_hh[l] = (ptr(grads[4 * l + i]) for i in range(4))
+    rg = grads[4 * L:]
+    if use_mlp:
+        g.dw_phi, g.db_phi, g.dw_psi, g.db_psi = (ptr(t) for t in rg[:4])
+        rg = rg[4:]
+        if heads > 1:
+            g.dw_dr, g.db_dr = ptr(rg[0]), ptr(rg[1])
+            rg = rg[2:]
+    g.dw_c, g.db_c = ptr(rg[0]), ptr(rg[1])
+    return g
 
 
 class _SpellerFn(torch.autograd.Function):
@@ -389,36 +556,20 @@ class Speller(nn.Module):
     def forward_step(self, input_word, last_hidden_state, listener_feature):
         """One decode step with caller-managed state (reference las_model.py:178-184): ``input_word`` (B,1,V+Hs),
         ``last_hidden_state`` = (h, c) each (L,B,Hs) or None, returns (raw_pred (B,V), (h, c), context (B,2H),
-        [attention_score (B,T')]).  Inference only: the step API keeps no stash, so its outputs carry no autograd
-        history (``Speller.forward`` is the differentiable path; it is the reference's only caller, :210)."""
+        [attention_score (B,T')]).  Differentiable like the reference's (autograd flows into ``input_word``, the state,
+        the listener features and every parameter through ``las_speller_step_bwd``); under ``torch.no_grad()`` no stash
+        is kept.  ``Speller.forward`` does not go through here: it runs the whole loop in the decode kernels."""
         a = self.attention
         use_mlp = bool(a.mlp_preprocess_input)
-        feat = _f32c(listener_feature.detach())
-        B, Tp, D = feat.shape
-        Hs, L, V = self.hidden_size, self.num_layers, self.label_dim
-        M = int(a.preprocess_mlp_dim) if use_mlp else 0
-        params = [_f32c(p.detach()) for p in self._params()]
-        heads = int(a.multi_head)
-        d = _speller_desc(B, Tp, D, Hs, V, M, L, use_mlp, a.activate == "relu", params[:4 * L], params[4 * L:], heads)
-        if D != Hs:
-            raise RuntimeError(f"Speller hidden_size ({Hs}) must equal 2*listener_hidden_size ({D}) (reference las_model.py:198)")
-        x = _f32c(input_word.detach().reshape(B, -1))
-        if x.shape[1] != V + Hs:
-            raise RuntimeError(f"input_word must be (B,1,{V + Hs}), got {tuple(input_word.shape)}")
-        dev = feat.device
-        Lh, stream = lib(), stream_ptr()
-        keys = None
-        if use_mlp:
-            keys = torch.empty(B, Tp, M, device=dev, dtype=torch.float32)
-            check(Lh.las_attn_keys_fwd(d, ptr(feat), ptr(keys), stream))
+        if listener_feature.is_cuda:
+            _cabi.poll_device_errors(listener_feature.device)
+        B = listener_feature.shape[0]
+        cfg = (int(self.num_layers), use_mlp, a.activate == "relu", int(a.preprocess_mlp_dim) if use_mlp else 0, int(self.label_dim),
+               int(a.multi_head))
         h_in = c_in = None
         if last_hidden_state is not None:
-            h_in, c_in = (_f32c(t.detach()) for t in last_hidden_state)
-        logp = torch.empty(B, V, device=dev); ctx = torch.empty(B, D, device=dev); att = torch.empty(heads, B, Tp, device=dev)
-        h_out = torch.empty(L, B, Hs, device=dev); c_out = torch.empty(L, B, Hs, device=dev)
-        work = torch.empty(Lh.las_speller_step_workspace_floats(d), device=dev, dtype=torch.float32)
-        check(Lh.las_speller_step_fwd(d, ptr(feat), ptr(keys), ptr(x), ptr(h_in), ptr(c_in), ptr(logp), ptr(h_out), ptr(c_out),
-                                      ptr(ctx), ptr(att), ptr(work), stream))
+            h_in, c_in = last_hidden_state
+        logp, h_out, c_out, ctx, att = _SpellerStepFn.apply(cfg, listener_feature, input_word.reshape(B, -1), h_in, c_in, *self._params())
         return logp, (h_out, c_out), ctx, list(att.unbind(0))
 
 

@@ -32,7 +32,7 @@ def record(name, **kv):
         pass
 
 
-def grad_close(got, want, name, rtol=1e-3, floor=1e-5, global_scale=0.0):
+def grad_close(got, want, name, rtol=1e-3, floor=1e-5, global_scale=0.0, global_floor=1e-7):
     """Gradient comparison at the north-star tolerance, scaled to the tensor: |a-b| <= rtol*|b| + floor*max|b|
     (gradient tensors span 1e-2 .. 1e-8 in magnitude, so the absolute term of SURVEY.md section 8c's
     ``1e-3*|b| + 1e-5`` is taken relative to the tensor's largest element) + 1e-7 * ``global_scale`` (the largest
@@ -43,7 +43,7 @@ def grad_close(got, want, name, rtol=1e-3, floor=1e-5, global_scale=0.0):
     want = np.asarray(want, dtype=np.float64)
     scale = float(np.abs(want).max()) + 1e-30
     err = np.abs(got - want)
-    atol = floor * scale + 1e-7 * global_scale
+    atol = floor * scale + global_floor * global_scale
     ratio = float((err / (rtol * np.abs(want) + atol)).max())
     record(name, max_abs_err=float(err.max()), max_abs_want=scale, worst_ratio=ratio, rel_to_max=float(err.max() / scale))
     return assert_close(got, want, name, rtol=rtol, atol=atol)

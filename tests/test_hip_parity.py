@@ -461,3 +461,89 @@ def test_decode_mode2_golden(name):
     a, b = torch.stack(a), torch.stack(b)
     assert torch.isfinite(a).all() and torch.allclose(a, b, rtol=1e-5, atol=1e-6)
     _check_err()
+
+
+@pytest.mark.parametrize("cfg_name,heads,use_mlp,activate", [("S", 1, True, "relu"), ("tiny", 4, True, "relu"), ("tiny", 1, False, "None"),
+                                                             ("P", 1, True, "None")])
+def test_forward_step_is_differentiable_like_the_reference(cfg_name, heads, use_mlp, activate):
+    """Speller.forward_step under autograd (reference las_model.py:178-184 is the autograd path there): three chained steps
+    with caller-managed state, a loss on every output, against the oracle's step function differentiated by torch —
+    gradients wrt the listener features, the initial input and every speller parameter."""
+    from las_pytorch_amd import synth
+    from oracle import las_oracle as O
+    c = synth.CONFIGS[cfg_name]
+    shapes = synth.config_shapes(cfg_name, multi_head=heads, use_mlp=use_mlp)
+    sd_np = synth.make_state_dict(shapes, seed=31, scale=0.15)
+    las = build_las(c, sd_np, max_label_len=3, multi_head=heads, use_mlp=use_mlp, activate=activate)
+    sd = O.to_torch_sd(sd_np, requires_grad=True)
+    B, Tp, V, Hs = 3, 9, c["V"], c["Hs"]
+    g = torch.Generator().manual_seed(7)
+    feat_o = (torch.randn(B, Tp, Hs, generator=g) * 0.5).requires_grad_(True)
+    feat = feat_o.detach().clone().cuda().requires_grad_(True)
+    x0_o = (torch.randn(B, V + Hs, generator=g) * 0.5).requires_grad_(True)
+    x0 = x0_o.detach().clone().cuda().requires_grad_(True)
+    w = [torch.randn(B, V, generator=g) for _ in range(3)]
+    wc = torch.randn(B, Hs, generator=g)
+    wh = torch.randn(c["Ls"], B, Hs, generator=g)
+    kw = dict(num_layers=c["Ls"], use_mlp=use_mlp, activate=activate, multi_head=heads)
+    # oracle chain
+    inp, hid, loss_o = x0_o, None, 0.0
+    for s in range(3):
+        lp, hid, ctx, sc = O.speller_step(inp, hid, feat_o, sd, **kw)
+        loss_o = loss_o + (lp * w[s]).sum()
+        inp = torch.cat([lp.exp(), ctx], -1)                 # a differentiable feedback (gradient flows through y and ctx)
+    loss_o = loss_o + (ctx * wc).sum() + (hid[0] * wh).sum() + (hid[1] * wh).sum() * 0.5
+    loss_o.backward()
+    # HIP chain
+    inp, hid, loss = x0.unsqueeze(1), None, 0.0
+    for s in range(3):
+        lp, hid, ctx, sc = las.speller.forward_step(inp, hid, feat)
+        loss = loss + (lp * w[s].cuda()).sum()
+        inp = torch.cat([lp.exp(), ctx], -1).unsqueeze(1)
+    loss = loss + (ctx * wc.cuda()).sum() + (hid[0] * wh.cuda()).sum() + (hid[1] * wh.cuda()).sum() * 0.5
+    loss.backward()
+    assert abs(loss.item() - loss_o.item()) <= 1e-4 * abs(loss_o.item()) + 1e-5
+    gs = max(float(t.grad.norm()) for k, t in sd.items() if k.startswith("speller.") and t.grad is not None)
+    grad_close(feat.grad.cpu().numpy(), feat_o.grad.numpy(), f"step_{cfg_name}_h{heads}/dfeat", global_scale=gs)
+    grad_close(x0.grad.cpu().numpy(), x0_o.grad.numpy(), f"step_{cfg_name}_h{heads}/dinput", global_scale=gs)
+    for k, p in las.speller.named_parameters():
+        want = sd["speller." + k].grad
+        want = torch.zeros_like(sd["speller." + k]) if want is None else want
+        grad_close(p.grad.cpu().numpy(), want.numpy(), f"step_{cfg_name}_h{heads}/grad/{k}", global_scale=gs)
+    _check_err()
+
+
+@pytest.mark.parametrize("heads,use_mlp,activate", [(1, True, "relu"), (4, True, "relu"), (1, False, "None"), (1, True, "None")])
+def test_attention_module_forward_backward(heads, use_mlp, activate):
+    """Attention.forward as a module of its own (reference las_model.py:275-318), value and gradients vs the oracle."""
+    from las_pytorch_amd import synth
+    from oracle import las_oracle as O
+    c = synth.CONFIGS["tiny"]
+    shapes = synth.config_shapes("tiny", multi_head=heads, use_mlp=use_mlp)
+    sd_np = synth.make_state_dict(shapes, seed=33, scale=0.3)
+    las = build_las(c, sd_np, max_label_len=3, multi_head=heads, use_mlp=use_mlp, activate=activate)
+    sd = O.to_torch_sd(sd_np, requires_grad=True)
+    B, Tp, Hs = 4, 11, c["Hs"]
+    g = torch.Generator().manual_seed(9)
+    feat_o = torch.randn(B, Tp, Hs, generator=g).requires_grad_(True)
+    st_o = torch.randn(B, Hs, generator=g).requires_grad_(True)
+    wc = torch.randn(B, Hs, generator=g)
+    sc_o, ctx_o = O.attention_forward(st_o, feat_o, sd, "speller.attention.", use_mlp, activate, heads)
+    (ctx_o * wc).sum().backward()
+    feat = feat_o.detach().clone().cuda().requires_grad_(True)
+    st = st_o.detach().clone().cuda().requires_grad_(True)
+    sc, ctx = las.speller.attention(st.unsqueeze(1), feat)
+    assert isinstance(sc, list) and len(sc) == heads and sc[0].shape == (B, Tp)
+    (ctx * wc.cuda()).sum().backward()
+    assert_close(ctx.detach().cpu().numpy(), ctx_o.detach().numpy(), "attention context")
+    for h in range(heads):
+        assert_close(sc[h].cpu().numpy(), sc_o[h].detach().numpy(), f"attention score head {h}", atol=1e-6)
+    gs = float(feat_o.grad.norm())
+    grad_close(feat.grad.cpu().numpy(), feat_o.grad.numpy(), f"attn_h{heads}_{use_mlp}/dfeat", global_scale=gs)
+    grad_close(st.grad.cpu().numpy(), st_o.grad.numpy(), f"attn_h{heads}_{use_mlp}/dstate", global_scale=gs)
+    for k, p in las.speller.attention.named_parameters():
+        # psi.bias has an identically zero gradient under the shift-invariant softmax when there is no activation: what is
+        # compared there is the cancellation noise of a sum of O(1) terms, hence the floor relative to the other gradients
+        grad_close(p.grad.cpu().numpy(), sd["speller.attention." + k].grad.numpy(), f"attn_h{heads}_{use_mlp}/grad/{k}", global_scale=gs,
+                   global_floor=1e-6)
+    _check_err()
