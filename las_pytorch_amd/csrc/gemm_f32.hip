@@ -311,7 +311,8 @@ static int gemm_resident_slots() {      // persistent grid: two 256-thread workg
     if (slots < 0) {
         int dev = 0, cus = 0;
         if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) cus = 0;
-        slots = 2 * cus;
+        const int per_cu = getenv("LAS_GEMM_SLOTS_PER_CU") ? atoi(getenv("LAS_GEMM_SLOTS_PER_CU")) : 2;
+        slots = per_cu * cus;
     }
     return slots;
 }
