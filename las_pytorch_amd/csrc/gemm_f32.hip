@@ -21,7 +21,10 @@ namespace las {
 #ifndef LAS_GEMM_BK
 #define LAS_GEMM_BK 16
 #endif
-constexpr int BM = 128, BN = 128, BK = LAS_GEMM_BK, PAD = 4, GEMM_THREADS = 256;
+#ifndef LAS_GEMM_PF
+#define LAS_GEMM_PF 1
+#endif
+constexpr int BM = 128, BN = 128, BK = LAS_GEMM_BK, PAD = 4, GEMM_THREADS = 256, PF = LAS_GEMM_PF;
 constexpr int NLD = BM * BK / 4 / GEMM_THREADS;     // float4 loads per thread per operand tile
 constexpr int KQ = BK / 4;                           // float4 per K-contiguous row segment
 
@@ -38,7 +41,7 @@ struct GemmParams {
     const float* A2; const float* B2; int K1;
     int gx, swz;
     // persistent (data-parallel + stream-K) schedule
-    int persistent, gy, kt, dp_tiles, sk_atomic_whole;
+    int persistent, gy, kt, dp_tiles, sk_atomic_whole, xcd_swz;
     long sk_iters, sk_per;
 };
 
@@ -150,48 +153,138 @@ __device__ __forceinline__ void gemm_segment(const GemmParams& p, float (*As)[BK
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-    f32x4 ra[NLD], rb[NLD];
-    if (ntiles > 0) {
-        load_ab(kbeg, ra, rb);
+    // Interior segments (whole tile inside M x N, vector-aligned operands, k range a multiple of BK — every large GEMM of the
+    // training step) take a loop without per-element guards: per-thread element offsets are computed once, a k-tile costs
+    // four 16-byte loads, and the only branch is the loop itself.  Everything else (edge tiles, odd K, unaligned operands)
+    // goes through the guarded loader below.
+    const bool fast = p.a_vec && p.b_vec && (m0 + BM <= p.M) && (n0 + BN <= p.N) && ((kend - kbeg) % BK == 0) && ntiles > 0;
+    if (fast) {
+        long offA[NLD], offB[NLD];
+#pragma unroll
+        for (int i = 0; i < NLD; ++i) {
+            const int idx = threadIdx.x + i * GEMM_THREADS;
+            offA[i] = A_KC ? (long)(m0 + idx / KQ) * p.lda + (idx % KQ) * 4 : (long)(idx >> 5) * p.lda + m0 + (idx & 31) * 4;
+            offB[i] = B_KC ? (long)(n0 + idx / KQ) * p.ldb + (idx % KQ) * 4 : (long)(idx >> 5) * p.ldb + n0 + (idx & 31) * 4;
+        }
+        const long strideA = A_KC ? 1 : p.lda, strideB = B_KC ? 1 : p.ldb;
+        auto load_fast = [&](int k0, f32x4 (&ra_)[NLD], f32x4 (&rb_)[NLD]) {
+            const bool second = p.A2 != nullptr && k0 >= p.K1;          // wave-uniform
+            const float* Ab = second ? p.A2 : A;
+            const float* Bb = second ? p.B2 : B;
+            const long kk = second ? k0 - p.K1 : k0;
+#pragma unroll
+            for (int i = 0; i < NLD; ++i) ra_[i] = *reinterpret_cast<const f32x4*>(Ab + offA[i] + kk * strideA);
+#pragma unroll
+            for (int i = 0; i < NLD; ++i) rb_[i] = *reinterpret_cast<const f32x4*>(Bb + offB[i] + kk * strideB);
+        };
+        f32x4 ra[NLD], rb[NLD];
+        load_fast(kbeg, ra, rb);
         store_tile<A_KC>(As[0], ra);
         store_tile<B_KC>(Bs[0], rb);
-    }
-    __syncthreads();
-
-    for (int kt = 0; kt < ntiles; ++kt) {
-        const int cur = kt & 1;
-        const bool more = kt + 1 < ntiles;
-        if (more) load_ab(kbeg + (kt + 1) * BK, ra, rb);
-        // fragments of k-step kk+1 are read from LDS before the MFMAs of k-step kk are issued (software pipeline):
-        // a single wave per SIMD then keeps the matrix pipe busy instead of idling for an LDS latency per k-step
-        float a[2], b[2];
+        __syncthreads();
+        // Software pipeline across k-steps AND across the tile boundary, pinned with sched_barrier (left alone, hipcc sinks the
+        // fragment reads of k-step kk+1 behind the MFMAs of kk and the matrix pipe idles for an LDS latency per k-step):
+        //   k-step kk:  [ds_read fragments kk+1] [4 MFMAs of kk]
+        //   kk = NK-2:  ... then the next tile's registers -> LDS (the stores issue while the MFMAs execute)
+        //   kk = NK-1:  barrier FIRST, then [ds_read fragments 0 of the next tile] [4 MFMAs of NK-1]:
+        //               the barrier wait hides behind the MFMAs of NK-2, the first LDS latency behind those of NK-1.
+        constexpr int NK = BK / 2;
+        float a[2], b[2], an[2], bn[2];
+        auto frag = [&](int buf, int kk, float (&fa)[2], float (&fb)[2]) {
 #pragma unroll
-        for (int i = 0; i < 2; ++i) a[i] = As[cur][lk][wm + i * 32 + lr];
+            for (int i = 0; i < 2; ++i) fa[i] = As[buf][kk * 2 + lk][wm + i * 32 + lr];
 #pragma unroll
-        for (int j = 0; j < 2; ++j) b[j] = Bs[cur][lk][wn + j * 32 + lr];
-#pragma unroll
-        for (int kk = 0; kk < BK / 2; ++kk) {
-            float an[2] = {0.f, 0.f}, bn[2] = {0.f, 0.f};
-            if (kk + 1 < BK / 2) {
-#pragma unroll
-                for (int i = 0; i < 2; ++i) an[i] = As[cur][(kk + 1) * 2 + lk][wm + i * 32 + lr];
-#pragma unroll
-                for (int j = 0; j < 2; ++j) bn[j] = Bs[cur][(kk + 1) * 2 + lk][wn + j * 32 + lr];
-            }
+            for (int j = 0; j < 2; ++j) fb[j] = Bs[buf][kk * 2 + lk][wn + j * 32 + lr];
+        };
+        auto mma = [&]() {
 #pragma unroll
             for (int i = 0; i < 2; ++i)
 #pragma unroll
                 for (int j = 0; j < 2; ++j)
                     acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], b[j], acc[i][j], 0, 0, 0);
+        };
+        frag(0, 0, a, b);
+        for (int kt = 0; kt < ntiles; ++kt) {
+            const int cur = kt & 1;
+            const bool more = kt + 1 < ntiles;
+#if !defined(LAS_GEMM_EXP) || LAS_GEMM_EXP != 1
+            if (more) load_fast(kbeg + (kt + 1) * BK, ra, rb);
+#endif
+#pragma unroll
+            for (int kk = 0; kk < NK - 1; ++kk) {
+                frag(cur, kk + 1, an, bn);
+                __builtin_amdgcn_sched_barrier(0);
+                mma();
+                __builtin_amdgcn_sched_barrier(0);
+                a[0] = an[0]; a[1] = an[1]; b[0] = bn[0]; b[1] = bn[1];
+            }
+#if !defined(LAS_GEMM_EXP) || LAS_GEMM_EXP != 2
+            if (more) {
+                store_tile<A_KC>(As[cur ^ 1], ra);
+                store_tile<B_KC>(Bs[cur ^ 1], rb);
+            }
+#endif
+            __syncthreads();
+            if (more) frag(cur ^ 1, 0, an, bn);
+            __builtin_amdgcn_sched_barrier(0);
+            mma();                                   // k-step NK-1 of tile kt (its fragments were read before the barrier)
+            __builtin_amdgcn_sched_barrier(0);
             a[0] = an[0]; a[1] = an[1]; b[0] = bn[0]; b[1] = bn[1];
         }
-        if (more) {
-            store_tile<A_KC>(As[cur ^ 1], ra);
-            store_tile<B_KC>(Bs[cur ^ 1], rb);
+        __syncthreads();                             // the segment's last reads precede the next segment's first LDS writes
+    } else {
+    // Register-staged prefetch PF k-tiles ahead (the loads of tile kt+PF are issued before tile kt is multiplied): one tile
+    // of MFMA work (2048 cycles per wave) does not cover an L2-miss round trip under load, and with two resident workgroups
+    // per CU there are 256 VGPRs per lane to spend.  LDS stays double-buffered (tile kt+1 is written while kt is read).
+    f32x4 ra[PF][NLD], rb[PF][NLD];
+#pragma unroll
+    for (int i = 0; i < PF; ++i)
+        if (i < ntiles) load_ab(kbeg + i * BK, ra[i], rb[i]);
+    if (ntiles > 0) {
+        store_tile<A_KC>(As[0], ra[0]);
+        store_tile<B_KC>(Bs[0], rb[0]);
+    }
+    __syncthreads();
+
+    for (int kt0 = 0; kt0 < ntiles; kt0 += PF) {
+#pragma unroll
+        for (int u = 0; u < PF; ++u) {
+            const int kt = kt0 + u;
+            if (kt >= ntiles) break;
+            const int cur = kt & 1;
+            if (kt + PF < ntiles) load_ab(kbeg + (kt + PF) * BK, ra[u], rb[u]);      // stage u held tile kt: already in LDS
+            // fragments of k-step kk+1 are read from LDS before the MFMAs of k-step kk are issued (software pipeline):
+            // a single wave per SIMD then keeps the matrix pipe busy instead of idling for an LDS latency per k-step
+            float a[2], b[2];
+#pragma unroll
+            for (int i = 0; i < 2; ++i) a[i] = As[cur][lk][wm + i * 32 + lr];
+#pragma unroll
+            for (int j = 0; j < 2; ++j) b[j] = Bs[cur][lk][wn + j * 32 + lr];
+#pragma unroll
+            for (int kk = 0; kk < BK / 2; ++kk) {
+                float an[2] = {0.f, 0.f}, bn[2] = {0.f, 0.f};
+                if (kk + 1 < BK / 2) {
+#pragma unroll
+                    for (int i = 0; i < 2; ++i) an[i] = As[cur][(kk + 1) * 2 + lk][wm + i * 32 + lr];
+#pragma unroll
+                    for (int j = 0; j < 2; ++j) bn[j] = Bs[cur][(kk + 1) * 2 + lk][wn + j * 32 + lr];
+                }
+#pragma unroll
+                for (int i = 0; i < 2; ++i)
+#pragma unroll
+                    for (int j = 0; j < 2; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], b[j], acc[i][j], 0, 0, 0);
+                a[0] = an[0]; a[1] = an[1]; b[0] = bn[0]; b[1] = bn[1];
+            }
+            if (kt + 1 < ntiles) {
+                store_tile<A_KC>(As[cur ^ 1], ra[(u + 1) % PF]);
+                store_tile<B_KC>(Bs[cur ^ 1], rb[(u + 1) % PF]);
+            }
+            __syncthreads();
         }
-        __syncthreads();
     }
 
+    }
     // Epilogue.  C/D map of 32x32 MFMA: col(n) = lane&31, row(m) = (r&3) + 8*(r>>2) + 4*(lane>>5).
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
@@ -228,8 +321,10 @@ __device__ __forceinline__ void gemm_segment(const GemmParams& p, float (*As)[BK
 //    (data parallel, plain stores); the k-iterations of the remaining tiles — the tail that would leave most CUs idle for
 //    a whole tile time — are cut into W equal runs (stream-K): a run may end one tile and start the next, partial
 //    tiles are combined with atomics on a C window zeroed beforehand.
+// (The parameter block is passed by value: ~100 of its SGPRs spill into VGPR lanes, which measured FASTER than fetching
+// the fields from the kernel-argument segment inside the loop.)
 template <bool A_KC, bool B_KC>
-__global__ __launch_bounds__(GEMM_THREADS) void gemm_f32_kernel(GemmParams p) {
+__global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_f32_kernel(GemmParams p) {
     __shared__ __attribute__((aligned(16))) float As[2][BK][BM + PAD];
     __shared__ __attribute__((aligned(16))) float Bs[2][BK][BN + PAD];
     if (!p.persistent) {
@@ -242,7 +337,11 @@ __global__ __launch_bounds__(GEMM_THREADS) void gemm_f32_kernel(GemmParams p) {
         gemm_segment<A_KC, B_KC>(p, As, Bs, bz, (tile / p.gx) * BM, (tile % p.gx) * BN, kbeg, min(p.K, kbeg + p.kper), p.atomic, kz == 0);
         return;
     }
-    const int W = gridDim.x, w = blockIdx.x;
+    // workgroup -> slot: blocks are dispatched round-robin over the 8 XCDs (block b on XCD b % 8, observed; speed only), so
+    // slot = (b % 8) * W/8 + b / 8 gives every XCD a CONTIGUOUS run of tiles / k-runs: the N-tiles of one M-panel share the
+    // A panel through that XCD's L2 instead of every XCD streaming all of A
+    const int W = gridDim.x;
+    const int w = (W % 8 == 0 && p.xcd_swz) ? (int)(blockIdx.x & 7) * (W >> 3) + (int)(blockIdx.x >> 3) : (int)blockIdx.x;
     const int per_batch = p.gx * p.gy;
     for (int tile = w; tile < p.dp_tiles; tile += W) {
         const int bz = tile / per_batch, t = tile % per_batch;
@@ -267,16 +366,18 @@ __global__ __launch_bounds__(GEMM_THREADS) void gemm_f32_kernel(GemmParams p) {
 // is no tail between the GEMMs and a 16-tile problem no longer holds the chip.  All outputs accumulate with atomics onto
 // buffers the caller has zeroed (the flat gradient buffer).
 constexpr int GROUP_MAX = 8, GROUP_MIN_ITERS = 8;
-struct GemmGroupParams { GemmParams prob[GROUP_MAX]; int n; };
+struct GemmGroupParams { GemmParams prob[GROUP_MAX]; int n; int xcd_swz; };
 
 template <bool A_KC, bool B_KC>
-__global__ __launch_bounds__(GEMM_THREADS) void gemm_group_kernel(GemmGroupParams g) {
+__global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_group_kernel(GemmGroupParams g) {
     __shared__ __attribute__((aligned(16))) float As[2][BK][BM + PAD];
     __shared__ __attribute__((aligned(16))) float Bs[2][BK][BN + PAD];
-    const int W = gridDim.x, w = blockIdx.x;
+    const int W = gridDim.x;
+    const int w = (W % 8 == 0 && g.xcd_swz) ? (int)(blockIdx.x & 7) * (W >> 3) + (int)(blockIdx.x >> 3) : (int)blockIdx.x;
     int rot = 0;
     for (int pi = 0; pi < g.n; ++pi) {
-        const GemmParams& p = g.prob[pi];
+        const GemmParams p = g.prob[pi];       // by value: the fields live in SGPRs across the k-loop (fetching them from the
+                                               // kernel-argument segment inside the loop measured slower)
         const long iters = (long)p.gx * p.gy * p.kt;
         const int parts = (int)min((long)W, max(1L, iters / GROUP_MIN_ITERS));
         const long per = (iters + parts - 1) / parts;
@@ -334,6 +435,8 @@ int gemm_f32_group(const GemmDesc* ds, int n, hipStream_t stream) {
     }
     GemmGroupParams g;
     g.n = n;
+    static const int xcd_swz = getenv("LAS_GEMM_XCD_SWZ") ? atoi(getenv("LAS_GEMM_XCD_SWZ")) : 1;
+    g.xcd_swz = xcd_swz;
     for (int i = 0; i < n; ++i) {
         const GemmDesc& d = ds[i];
         GemmParams& p = g.prob[i];
@@ -370,6 +473,8 @@ int gemm_f32(const GemmDesc& d, hipStream_t stream) {
     p.b_vec = gemm_aligned(d.B, d.ldb, d.sB) && (d.B2 == nullptr || gemm_aligned(d.B2, d.ldb, 0));
     p.gx = gx; p.gy = gy; p.kt = kt;
     p.accumulate = d.accumulate; p.relu = d.relu;
+    static const int xcd_swz = getenv("LAS_GEMM_XCD_SWZ") ? atoi(getenv("LAS_GEMM_XCD_SWZ")) : 1;
+    p.xcd_swz = xcd_swz;
     p.persistent = 0; p.dp_tiles = 0; p.sk_iters = 0; p.sk_per = 0; p.sk_atomic_whole = 0; p.atomic = 0; p.swz = 0; p.splitk = 1; p.kper = d.K;
 
     // ---- schedule --------------------------------------------------------------------------------------------------
