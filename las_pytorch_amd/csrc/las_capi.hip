@@ -266,14 +266,18 @@ int las_pblstm_bwd(const float* x, const float* dout, int B, int T_in, int D_in,
     const float* hprev = reserve + lay.hprev;
     float* dgates = workspace + wl.dgates;
     float* wt = workspace + wl.wt;
-    LAS_TRY(transpose2d(w_hh_f, wt, 4 * H, H, stream));
-    LAS_TRY(transpose2d(w_hh_r, wt + (size_t)H * 4 * H, 4 * H, H, stream));
-    LAS_TRY(pblstm_rec_bwd(dout, gates, cbuf, wt, dgates, B, T, H, (unsigned long long*)(workspace + wl.xbuf), err_word,
-                           flags & LAS_FLAG_FORCE_GENERIC, stream));
+    LAS_TRY(transpose2d(w_hh_f, wt, 4 * H, H, stream, w_hh_r, wt + (size_t)H * 4 * H));
     const int BT = B * T;
     const size_t n_ih = (size_t)4 * H * D, n_hh = (size_t)4 * H * H, n_b = (size_t)4 * H;
     const bool zg = zero_if_contiguous({{dw_ih_f, n_ih}, {dw_hh_f, n_hh}, {db_ih_f, n_b}, {db_hh_f, n_b},
                                         {dw_ih_r, n_ih}, {dw_hh_r, n_hh}, {db_ih_r, n_b}, {db_hh_r, n_b}}, stream);
+    // the persistent backward recurrences sum the bias gradients themselves when each direction's [b_ih | b_hh] pair is one
+    // zeroed 8H block (the layout of the flat gradient buffer); otherwise a column-sum kernel runs below
+    const bool db_in_kernel = zg && db_hh_f == db_ih_f + n_b && db_hh_r == db_ih_r + n_b;
+    int db_done = 0;
+    LAS_TRY(pblstm_rec_bwd(dout, gates, cbuf, wt, dgates, B, T, H, (unsigned long long*)(workspace + wl.xbuf), err_word,
+                           flags & LAS_FLAG_FORCE_GENERIC, stream, db_in_kernel ? db_ih_f : nullptr, db_in_kernel ? db_ih_r : nullptr,
+                           &db_done));
     // the four weight-gradient contractions (few output tiles, K = B*T) go out as ONE grouped stream-K launch
     GemmDesc dw[4];
     for (int dir = 0; dir < 2; ++dir) {
@@ -289,7 +293,7 @@ int las_pblstm_bwd(const float* x, const float* dout, int B, int T_in, int D_in,
         gh.C = dir ? dw_hh_r : dw_hh_f; gh.ldc = H; gh.M = 4 * H; gh.N = H; gh.K = BT; gh.c_zeroed = zg;
     }
     LAS_TRY(gemm_f32_group(dw, 4, stream));
-    for (int dir = 0; dir < 2; ++dir)
+    for (int dir = 0; dir < 2 && !db_done; ++dir)
         LAS_TRY(colsum(dgates + (size_t)dir * BT * 4 * H, 4 * H, BT, 4 * H, dir ? db_ih_r : db_ih_f, zg, stream, dir ? db_hh_r : db_hh_f));
     if (dx) {   // dX = [dG_f | dG_r] [W_ih_f ; W_ih_r]: both directions in one pass over K = 2 * 4H
         GemmDesc g;
@@ -362,10 +366,9 @@ int las_speller_fwd(const las_speller_desc* d, const float* feat, const float* k
     LAS_REQUIRE(Hs % 16 == 0, "speller hidden size must be a multiple of 16");
     LAS_TRY(labels_to_y(teacher_forced ? (const long long*)labels_onehot : nullptr, y_all, B, U, V, Vp, U_lab, stream));
     LAS_TRY(copy2d(feat, (long)Tp * D, ctx_all, D, B, D, 0, stream));     // ctx_{-1} = feat[:,0,:] (las_model.py:198)
-    // 16-byte aligned, tail-free shadow of W_ih0: columns [0,V) = label part, [V,Vp) = 0, [Vp,Vp+Hs) = context part
-    LAS_HIP_CHECK(hipMemsetAsync(w0p, 0, sizeof(float) * (size_t)4 * Hs * (Vp + Hs), stream));
-    LAS_TRY(copy2d(d->w_ih[0], V + Hs, w0p, Vp + Hs, 4 * Hs, V, 0, stream));
-    LAS_TRY(copy2d(d->w_ih[0] + V, V + Hs, w0p + Vp, Vp + Hs, 4 * Hs, Hs, 0, stream));
+    // 16-byte aligned, tail-free shadow of W_ih0: columns [0,V) = label part, [V,Vp) = 0, [Vp,Vp+Hs) = context part (rebuilt
+    // every call: in training the parameters change every step, so there is nothing to cache across calls)
+    LAS_TRY(build_w0p(d->w_ih[0], w0p, Hs, V, Vp, stream));
 
     static const bool persist_on = !(getenv("LAS_SPELLER_PERSIST") && atoi(getenv("LAS_SPELLER_PERSIST")) == 0);
     const bool persist = persist_on && err_word && !(flags & LAS_FLAG_FORCE_GENERIC) && (teacher_forced || decode_mode != 2) &&
@@ -495,9 +498,7 @@ int las_speller_step_fwd(const las_speller_desc* d, const float* feat, const flo
     LAS_HIP_CHECK(hipMemsetAsync(y, 0, sizeof(float) * (size_t)B * Vp, stream));
     LAS_TRY(copy2d(input_word, V + Hs, y, Vp, B, V, 0, stream));
     LAS_TRY(copy2d(input_word + V, V + Hs, cin, D, B, D, 0, stream));
-    LAS_HIP_CHECK(hipMemsetAsync(w0p, 0, sizeof(float) * (size_t)4 * Hs * (Vp + Hs), stream));
-    LAS_TRY(copy2d(d->w_ih[0], V + Hs, w0p, Vp + Hs, 4 * Hs, V, 0, stream));
-    LAS_TRY(copy2d(d->w_ih[0] + V, V + Hs, w0p + Vp, Vp + Hs, 4 * Hs, Hs, 0, stream));
+    LAS_TRY(build_w0p(d->w_ih[0], w0p, Hs, V, Vp, stream));
     for (int l = 0; l < L; ++l) {
         CellSeg segs[3];
         int n = 0;

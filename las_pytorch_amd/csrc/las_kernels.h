@@ -43,14 +43,17 @@ int pblstm_rec_fwd(float* gates, const float* w_hh_f, const float* w_hh_r, float
 //   dout  : (B, T, 2H) upstream gradient ; gates/cbuf/hprev: the forward stash
 //   dgates: (2, B, T, 4H) out: dG_t (pre-activation gradients, PyTorch row order)
 //   w_hh_t: (2, H, 4H) transposed recurrent weights (see transpose_w_hh)
+// db_f / db_r (optional, pre-zeroed): (2, 4H) bias gradients [b_ih | b_hh] of each direction, summed inside the persistent
+// kernels; *db_done reports whether that happened (0: the generic kernels ran — the caller column-sums dgates itself).
 int pblstm_rec_bwd(const float* dout, const float* gates, const float* cbuf, const float* w_hh_t, float* dgates,
                    int B, int T, int H, unsigned long long* xbuf, unsigned* err, int force_generic,
-                   hipStream_t stream);
+                   hipStream_t stream, float* db_f = nullptr, float* db_r = nullptr, int* db_done = nullptr);
 size_t rec_xbuf_bytes(int B, int H);
 #ifdef LAS_REC_TRACE
 void rec_set_trace(unsigned long long* dev_buf);    // profiling build only, see tools/ubench_rec_trace.py
 #endif
-int transpose2d(const float* src, float* dst, int rows, int cols, hipStream_t stream);  // dst[c][r] = src[r][c]
+// dst[c][r] = src[r][c]; an optional second (src1, dst1) pair of the same shape rides in the same launch
+int transpose2d(const float* src, float* dst, int rows, int cols, hipStream_t stream, const float* src1 = nullptr, float* dst1 = nullptr);
 
 // ---- speller.hip -----------------------------------------------------------------------
 struct CellSeg {            // one dense input segment of an LSTM cell step:  gates += x(B,K) * W(4Hs,K)^T
@@ -184,6 +187,7 @@ int ls_loss(const float* logp, long sU, long sB, const long long* labels, int U,
             float* loss, float* dlogp, long dU, long dB, hipStream_t stream);
 int ler(const float* logp, long sU, long sB, const long long* labels, int U, int U_lab, int B, int V, float* out, int* work,
         hipStream_t stream);
+int build_w0p(const float* w_ih0, float* w0p, int Hs, int V, int Vp, hipStream_t stream);
 int labels_to_y(const long long* labels, float* y_all, int B, int U, int V, int Vp, int u_lab, hipStream_t stream);
 int collate_pad(const float* packed, const long long* foff, const long long* plab, const long long* loff, int B, int T, int F, int U,
                 int V, float* inputs, long long* targets, hipStream_t stream);

@@ -91,6 +91,25 @@ int copy2d(const float* src, long lds, float* dst, long ldd, int rows, int cols,
     return LAS_OK;
 }
 
+// 16-byte aligned, tail-free shadow of the Speller's W_ih0 (4Hs, V+Hs) as (4Hs, Vp+Hs): columns [0,V) = label part,
+// [V,Vp) = 0, [Vp,Vp+Hs) = context part.  One launch (it used to be a memset and two strided copies per forward).
+__global__ void build_w0p_kernel(const float* __restrict__ w, float* __restrict__ w0p, int rows, int V, int Vp, int Hs) {
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    const int ld = Vp + Hs;
+    if (i >= (long)rows * ld) return;
+    const int r = i / ld, c = i % ld;
+    float v = 0.f;
+    if (c < V) v = w[(long)r * (V + Hs) + c];
+    else if (c >= Vp) v = w[(long)r * (V + Hs) + V + (c - Vp)];
+    w0p[i] = v;
+}
+int build_w0p(const float* w_ih0, float* w0p, int Hs, int V, int Vp, hipStream_t stream) {
+    const long n = (long)4 * Hs * (Vp + Hs);
+    hipLaunchKernelGGL(build_w0p_kernel, dim3(cdiv(n, 256)), dim3(256), 0, stream, w_ih0, w0p, 4 * Hs, V, Vp, Hs);
+    LAS_LAUNCH_CHECK();
+    return LAS_OK;
+}
+
 // Teacher-forcing inputs: y_all[0] = onehot(<sos>=0) (reference las_model.py:193-195),
 // y_all[1+s][b][:] = float(ground_truth[b][s][:]) (las_model.py:216-217; any label rows, incl. all-zero padding)
 __global__ void labels_to_y_kernel(const long long* __restrict__ labels, float* __restrict__ y_all, int B, int U, int V,

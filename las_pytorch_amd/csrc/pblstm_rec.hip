@@ -168,6 +168,9 @@ __global__ __launch_bounds__(UW * (H / 16)) void rec_fwd_fast(float* __restrict_
 
     // cell role: thread tid < UW owns hidden unit jc
     const bool cell = tid < UW;
+#ifdef LAS_REC_PRIO
+    if (cell) __builtin_amdgcn_s_setprio(LAS_REC_PRIO);      // the step's dependent chain runs through this wave
+#endif
     const int jc = member * UW + (cell ? tid : 0);
     const long seq = (long)(dir * B + b) * T;
     float* gb = gates + seq * 4 * H + jc;
@@ -443,7 +446,10 @@ template <int H>
 __global__ __launch_bounds__(REC_THREADS) void rec_bwd_fast(const float* __restrict__ dout, const float* __restrict__ gates,
                                                             const float* __restrict__ cbuf, const float* __restrict__ w_hh_t,
                                                             float* __restrict__ dgates, int B, int T, u64* xbuf,
-                                                            unsigned* err) {
+                                                            unsigned* err, float* __restrict__ db_f, float* __restrict__ db_r) {
+    // db_f / db_r (optional): 2 x (4H) bias gradients per direction [b_ih | b_hh], pre-zeroed by the caller: the threads
+    // that copy this workgroup's dG rows to memory also sum them over time and add the totals once at the end
+    // (replaces a column-sum kernel over the (B*T, 4H) gate gradients per direction).
     constexpr int LPU = H / 16;
     constexpr int UW = REC_THREADS / LPU;
     constexpr int G = H / UW;
@@ -483,6 +489,9 @@ __global__ __launch_bounds__(REC_THREADS) void rec_bwd_fast(const float* __restr
     for (int i = tid; i < H; i += REC_THREADS) dhs[0][i] = 0.f;
 
     const bool cellt = tid < H;                          // cell role: unit j = tid
+#ifdef LAS_REC_PRIO
+    if (cellt) __builtin_amdgcn_s_setprio(LAS_REC_PRIO);
+#endif
     const bool fact = tid >= QB && tid < QB + H;         // factor role: unit tid - QB
     const int jf = fact ? tid - QB : 0;
     float dc = 0.f;
@@ -507,6 +516,11 @@ __global__ __launch_bounds__(REC_THREADS) void rec_bwd_fast(const float* __restr
     };
     if (fact) { load_step(0); prepare(0); load_step(1); }
     __syncthreads();
+
+    constexpr int NBS = (4 * UW + H - 1) / H;             // dG entries per stash-writer thread
+    float bsum[NBS];
+#pragma unroll
+    for (int i = 0; i < NBS; ++i) bsum[i] = 0.f;
 
     int cur = 0;
     for (int step = 0; step < T; ++step) {
@@ -549,9 +563,15 @@ __global__ __launch_bounds__(REC_THREADS) void rec_bwd_fast(const float* __restr
             load_step(step + 2);
         }
         if (tid >= SB && tid < SB + H) {                 // this workgroup's dG rows of step t -> memory (off the chain)
-            for (int e = tid - SB; e < 4 * UW; e += H) {
-                const int g = e / UW, j = member * UW + e % UW;
-                dgb[(long)t * 4 * H + g * H + j] = dgs[g * H + j];
+#pragma unroll
+            for (int i = 0; i < NBS; ++i) {
+                const int e = tid - SB + i * H;
+                if (e < 4 * UW) {
+                    const int g = e / UW, j = member * UW + e % UW;
+                    const float v = dgs[g * H + j];
+                    dgb[(long)t * 4 * H + g * H + j] = v;
+                    bsum[i] += v;
+                }
             }
         }
         if (G > 1) {
@@ -563,6 +583,18 @@ __global__ __launch_bounds__(REC_THREADS) void rec_bwd_fast(const float* __restr
         lds_barrier();
         REC_STAMP(0, step, 5); REC_STAMP(512, step, 5);
         cur ^= 1;
+    }
+    float* db = dir ? db_r : db_f;
+    if (db != nullptr && tid >= SB && tid < SB + H) {
+#pragma unroll
+        for (int i = 0; i < NBS; ++i) {
+            const int e = tid - SB + i * H;
+            if (e < 4 * UW) {
+                const int g = e / UW, j = member * UW + e % UW;
+                atomicAdd(db + g * H + j, bsum[i]);              // b_ih
+                atomicAdd(db + 4 * H + g * H + j, bsum[i]);      // b_hh receives the same gradient
+            }
+        }
     }
 }
 
@@ -577,7 +609,8 @@ template <int H, int NB>
 __global__ __launch_bounds__(REC_THREADS) void rec_bwd_multi(const float* __restrict__ dout, const float* __restrict__ gates,
                                                              const float* __restrict__ cbuf, const float* __restrict__ w_hh_t,
                                                              float* __restrict__ dgates, int B, int T, u64* xbuf,
-                                                             unsigned* err, int b0, int Bc) {
+                                                             unsigned* err, int b0, int Bc, float* __restrict__ db_f,
+                                                             float* __restrict__ db_r) {
     constexpr int LPU = H / 16;
     constexpr int UW = REC_THREADS / LPU;
     constexpr int G = H / UW;
@@ -607,7 +640,7 @@ __global__ __launch_bounds__(REC_THREADS) void rec_bwd_multi(const float* __rest
     const int nvalid = min(NB, Bc - blk * NB);
 
     // per-item state: item index it = tid + q*REC_THREADS -> (u, j) = (it / H, it % H)
-    float dc[CI], fa[CI][7], p[CI][7];
+    float dc[CI], fa[CI][7], p[CI][7], bs[CI][4];
     bool live[CI];
     long seqs[CI];
 #pragma unroll
@@ -619,6 +652,8 @@ __global__ __launch_bounds__(REC_THREADS) void rec_bwd_multi(const float* __rest
         dc[q] = 0.f;
 #pragma unroll
         for (int e = 0; e < 7; ++e) { fa[q][e] = 0.f; p[q][e] = 0.f; }
+#pragma unroll
+        for (int e = 0; e < 4; ++e) bs[q][e] = 0.f;
     }
     auto load_step = [&](int q, int st) {                 // raw stash of processing step st -> p[q]
         if (!live[q] || st >= T) return;
@@ -656,9 +691,10 @@ __global__ __launch_bounds__(REC_THREADS) void rec_bwd_multi(const float* __rest
                 dc[q] = dct * fa[q][5];
                 const float gi = dct * fa[q][1], gf = dct * fa[q][2], gg = dct * fa[q][3], go = dh * fa[q][4];
                 dgs[u][j] = gi; dgs[u][H + j] = gf; dgs[u][2 * H + j] = gg; dgs[u][3 * H + j] = go;
-                if (live[q] && j / UW == member) {            // this workgroup's share of dG_t -> memory
+                if (live[q] && j / UW == member) {            // this workgroup's share of dG_t -> memory (+ bias-gradient sums)
                     float* dp = dgates + (seqs[q] + t) * 4 * H + j;
                     dp[0] = gi; dp[H] = gf; dp[2 * H] = gg; dp[3 * H] = go;
+                    bs[q][0] += gi; bs[q][1] += gf; bs[q][2] += gg; bs[q][3] += go;
                 }
             }
         }
@@ -696,6 +732,18 @@ __global__ __launch_bounds__(REC_THREADS) void rec_bwd_multi(const float* __rest
         }
         lds_barrier();
         cur ^= 1;
+    }
+    float* db = dir ? db_r : db_f;
+    if (db != nullptr) {
+#pragma unroll
+        for (int q = 0; q < CI; ++q) {
+            const int it = tid + q * REC_THREADS;
+            const int j = it % H;
+            if (it < NI && live[q] && j / UW == member) {
+#pragma unroll
+                for (int g = 0; g < 4; ++g) { atomicAdd(db + g * H + j, bs[q][g]); atomicAdd(db + 4 * H + g * H + j, bs[q][g]); }
+            }
+        }
     }
 }
 
@@ -744,8 +792,12 @@ __global__ __launch_bounds__(256) void rec_bwd_generic(const float* __restrict__
     }
 }
 
-__global__ void transpose2d_kernel(const float* __restrict__ src, float* __restrict__ dst, int rows, int cols) {
+// blockIdx.z selects (src, dst) pair 0 or 1: both directions' W_hh in one launch
+__global__ void transpose2d_kernel(const float* __restrict__ src0, float* __restrict__ dst0, const float* __restrict__ src1,
+                                   float* __restrict__ dst1, int rows, int cols) {
     __shared__ float tile[32][33];
+    const float* __restrict__ src = blockIdx.z ? src1 : src0;
+    float* __restrict__ dst = blockIdx.z ? dst1 : dst0;
     const int c0 = blockIdx.x * 32, r0 = blockIdx.y * 32;
     for (int i = threadIdx.y; i < 32; i += blockDim.y) {
         const int r = r0 + i, c = c0 + threadIdx.x;
@@ -758,9 +810,9 @@ __global__ void transpose2d_kernel(const float* __restrict__ src, float* __restr
     }
 }
 
-int transpose2d(const float* src, float* dst, int rows, int cols, hipStream_t stream) {
-    dim3 grid(cdiv(cols, 32), cdiv(rows, 32)), block(32, 8);
-    hipLaunchKernelGGL(transpose2d_kernel, grid, block, 0, stream, src, dst, rows, cols);
+int transpose2d(const float* src, float* dst, int rows, int cols, hipStream_t stream, const float* src1, float* dst1) {
+    dim3 grid(cdiv(cols, 32), cdiv(rows, 32), src1 ? 2 : 1), block(32, 8);
+    hipLaunchKernelGGL(transpose2d_kernel, grid, block, 0, stream, src, dst, src1, dst1, rows, cols);
     LAS_LAUNCH_CHECK();
     return LAS_OK;
 }
@@ -863,19 +915,21 @@ int pblstm_rec_fwd(float* gates, const float* w_hh_f, const float* w_hh_r, float
 
 template <int H, int NB>
 static int launch_bwd_multi(const float* dout, const float* gates, const float* cbuf, const float* w_hh_t, float* dgates, int B, int T,
-                            u64* xbuf, unsigned* err, int b0, int Bc, int grid, hipStream_t stream) {
+                            u64* xbuf, unsigned* err, int b0, int Bc, int grid, float* db_f, float* db_r, hipStream_t stream) {
     const size_t smem = sizeof(float) * ((size_t)2 * NB * H + (size_t)NB * 4 * H);
     LAS_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&rec_bwd_multi<H, NB>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
     if (!persistent_launch_fits(rec_bwd_multi<H, NB>, REC_THREADS, smem, grid)) return fail(LAS_ERR_UNSUPPORTED, "backward recurrence: %s%ld workgroups cannot all be resident", "", (long)grid);
     hipLaunchKernelGGL((rec_bwd_multi<H, NB>), dim3(grid), dim3(REC_THREADS), smem, stream, dout, gates, cbuf, w_hh_t, dgates, B, T, xbuf,
-                       err, b0, Bc);
+                       err, b0, Bc, db_f, db_r);
     LAS_LAUNCH_CHECK();
     return LAS_OK;
 }
 
 int pblstm_rec_bwd(const float* dout, const float* gates, const float* cbuf, const float* w_hh_t, float* dgates, int B,
-                   int T, int H, u64* xbuf, unsigned* err, int force_generic, hipStream_t stream) {
+                   int T, int H, u64* xbuf, unsigned* err, int force_generic, hipStream_t stream, float* db_f, float* db_r,
+                   int* db_done) {
     LAS_REQUIRE(B > 0 && T > 0 && H > 0, "rec dims");
+    if (db_done) *db_done = 0;
     const int ngroups = 2 * B;
     static const int nb_env = env_int("LAS_REC_NB", 0);
     RecPlan plan = {0, 0};
@@ -898,16 +952,17 @@ int pblstm_rec_bwd(const float* dout, const float* gates, const float* cbuf, con
                      : H == 256 ? persistent_launch_fits(rec_bwd_fast<256>, REC_THREADS, 0, grid)
                                 : persistent_launch_fits(rec_bwd_fast<512>, REC_THREADS, 0, grid);
                 if (!fits) break;
-                if (H == 128) hipLaunchKernelGGL((rec_bwd_fast<128>), dim3(grid), dim3(REC_THREADS), 0, stream, dout, gates, cbuf, w_hh_t, dgates, B, T, xbuf, err);
-                else if (H == 256) hipLaunchKernelGGL((rec_bwd_fast<256>), dim3(grid), dim3(REC_THREADS), 0, stream, dout, gates, cbuf, w_hh_t, dgates, B, T, xbuf, err);
-                else hipLaunchKernelGGL((rec_bwd_fast<512>), dim3(grid), dim3(REC_THREADS), 0, stream, dout, gates, cbuf, w_hh_t, dgates, B, T, xbuf, err);
+                if (H == 128) hipLaunchKernelGGL((rec_bwd_fast<128>), dim3(grid), dim3(REC_THREADS), 0, stream, dout, gates, cbuf, w_hh_t, dgates, B, T, xbuf, err, db_f, db_r);
+                else if (H == 256) hipLaunchKernelGGL((rec_bwd_fast<256>), dim3(grid), dim3(REC_THREADS), 0, stream, dout, gates, cbuf, w_hh_t, dgates, B, T, xbuf, err, db_f, db_r);
+                else hipLaunchKernelGGL((rec_bwd_fast<512>), dim3(grid), dim3(REC_THREADS), 0, stream, dout, gates, cbuf, w_hh_t, dgates, B, T, xbuf, err, db_f, db_r);
                 LAS_LAUNCH_CHECK();
+                if (db_done && db_f && db_r) *db_done = 1;
                 continue;
             }
 #define TRY_BWD_M(HH, NBV) if (H == HH && plan.nb == NBV) {                                                                          \
-        const int rc = launch_bwd_multi<HH, NBV>(dout, gates, cbuf, w_hh_t, dgates, B, T, xbuf, err, b0, Bc, grid, stream);           \
+        const int rc = launch_bwd_multi<HH, NBV>(dout, gates, cbuf, w_hh_t, dgates, B, T, xbuf, err, b0, Bc, grid, db_f, db_r, stream); \
         if (rc == LAS_ERR_UNSUPPORTED) { fits = false; break; }                                                                       \
-        LAS_TRY(rc); continue; }
+        LAS_TRY(rc); if (db_done && db_f && db_r) *db_done = 1; continue; }
             TRY_BWD_M(128, 2) TRY_BWD_M(128, 4) TRY_BWD_M(128, 8)
             TRY_BWD_M(256, 2) TRY_BWD_M(256, 4) TRY_BWD_M(256, 8)
             TRY_BWD_M(512, 2) TRY_BWD_M(512, 4)
@@ -916,6 +971,7 @@ int pblstm_rec_bwd(const float* dout, const float* gates, const float* cbuf, con
         }
     }
     if (plan.nb == 0 || !fits) {
+        if (db_done) *db_done = 0;          // the residency check fails before the first launch: no partial sums were added
         const size_t smem = sizeof(float) * 7 * H;
         hipLaunchKernelGGL(rec_bwd_generic, dim3(ngroups), dim3(256), smem, stream, dout, gates, cbuf, w_hh_t, dgates, B, T, H);
     }
