@@ -181,7 +181,10 @@ static int attention_deferred(const las_speller_desc* d, const AttnDeferred& x, 
             q.C = g->dw_psi; q.ldc = D; q.M = M; q.N = D; q.K = BT; q.c_zeroed = zg;
             LAS_TRY(gemm_f32(q, stream));
         }
-        LAS_TRY(colsum(dK, M, BT, M, g->db_psi, zg, stream));
+        {   // db_psi and db_phi in one launch
+            ColsumJob cj[2] = {{dK, (long)M, BT, M, g->db_psi, nullptr}, {dqpre_all, (long)M * NH, UB, M * NH, g->db_phi, nullptr}};
+            LAS_TRY(colsum_multi(cj, 2, zg, stream));
+        }
         {   // dfeat += dKpre W_psi
             GemmDesc q;
             q.A = dK; q.lda = M; q.a_kc = true; q.B = d->w_psi; q.ldb = D; q.b_kc = false;
@@ -194,7 +197,6 @@ static int attention_deferred(const las_speller_desc* d, const AttnDeferred& x, 
             q.C = g->dw_phi; q.ldc = Hs; q.M = M * NH; q.N = Hs; q.K = UB; q.c_zeroed = zg;
             LAS_TRY(gemm_f32(q, stream));
         }
-        LAS_TRY(colsum(dqpre_all, (long)M * NH, UB, M * NH, g->db_phi, zg, stream));
     }
     return LAS_OK;
 }
@@ -711,9 +713,11 @@ int las_speller_bwd(const las_speller_desc* d, const float* feat, const float* k
             }
         }
         LAS_TRY(flush());
-        LAS_TRY(colsum(dz_all, V, UB, V, g->db_c, zg, stream));
-        for (int l = 0; l < L; ++l)
-            LAS_TRY(colsum(dG_all + (size_t)l * U * 4 * sH, 4 * Hs, UB, 4 * Hs, g->db_ih[l], zg, stream, g->db_hh[l]));
+        ColsumJob cj[COLSUM_MAX_JOBS];
+        int nj = 0;
+        cj[nj++] = {dz_all, V, UB, V, g->db_c, nullptr};
+        for (int l = 0; l < L; ++l) cj[nj++] = {dG_all + (size_t)l * U * 4 * sH, (long)4 * Hs, UB, 4 * Hs, g->db_ih[l], g->db_hh[l]};
+        LAS_TRY(colsum_multi(cj, nj, zg, stream));       // every LSTM / character-distribution bias gradient in one launch
     }
     return LAS_OK;
 }

@@ -177,6 +177,10 @@ int attn_step_bwd(const AttnBwdArgs& a, hipStream_t stream);
 // ---- misc.hip --------------------------------------------------------------------------
 int colsum(const float* src, long ld, int rows, int cols, float* dst, int accumulate, hipStream_t stream,
            float* dst2 = nullptr);  // dst[c] (+)= sum_r src[r][c]; dst2 (optional) receives the same sums
+// up to COLSUM_MAX_JOBS independent column sums in one launch (dst (+)= column sums of src; dst2 optional copy)
+constexpr int COLSUM_MAX_JOBS = 8;
+struct ColsumJob { const float* src; long ld; int rows; int cols; float* dst; float* dst2; };
+int colsum_multi(const ColsumJob* jobs, int n, int zeroed, hipStream_t stream);
 int relu_mask_inplace(float* grad, const float* act, long n, hipStream_t stream);                           // grad = act>0 ? grad : 0
 int add_inplace(float* dst, const float* src, long n, hipStream_t stream);
 int relu_inplace(float* x, long n, hipStream_t stream);

@@ -45,6 +45,58 @@ int colsum(const float* src, long ld, int rows, int cols, float* dst, int accumu
     return LAS_OK;
 }
 
+// Several independent column sums in ONE launch (the bias gradients of the Speller backward: dz, dG of each layer, dqpre,
+// dK): blockIdx.z selects the job, the grid covers the largest one.
+struct ColsumJobs { const float* src[COLSUM_MAX_JOBS]; long ld[COLSUM_MAX_JOBS]; int rows[COLSUM_MAX_JOBS]; int cols[COLSUM_MAX_JOBS];
+                    float* dst[COLSUM_MAX_JOBS]; float* dst2[COLSUM_MAX_JOBS]; };
+__global__ __launch_bounds__(256) void colsum_multi_kernel(ColsumJobs j, int rows_per_block) {
+    __shared__ float part[4][64];
+    const int job = blockIdx.z;
+    const float* __restrict__ src = j.src[job];
+    const long ld = j.ld[job];
+    const int rows = j.rows[job], cols = j.cols[job];
+    const int cl = threadIdx.x & 63, rl = threadIdx.x >> 6;
+    const int c = blockIdx.x * 64 + cl;
+    const int r0 = blockIdx.y * rows_per_block, r1 = min(rows, r0 + rows_per_block);
+    if (blockIdx.x * 64 >= cols || r0 >= rows) return;        // workgroup-uniform
+    float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+    if (c < cols) {
+        int r = r0 + rl;
+        for (; r + 12 < r1; r += 16) {
+            a0 += src[(long)r * ld + c]; a1 += src[(long)(r + 4) * ld + c];
+            a2 += src[(long)(r + 8) * ld + c]; a3 += src[(long)(r + 12) * ld + c];
+        }
+        for (; r < r1; r += 4) a0 += src[(long)r * ld + c];
+    }
+    part[rl][cl] = (a0 + a1) + (a2 + a3);
+    __syncthreads();
+    if (rl == 0 && c < cols) {
+        const float v = (part[0][cl] + part[1][cl]) + (part[2][cl] + part[3][cl]);
+        atomicAdd(j.dst[job] + c, v);
+        if (j.dst2[job]) atomicAdd(j.dst2[job] + c, v);
+    }
+}
+int colsum_multi(const ColsumJob* jobs, int n, int zeroed, hipStream_t stream) {
+    if (n <= 0) return LAS_OK;
+    LAS_REQUIRE(n <= COLSUM_MAX_JOBS, "too many column-sum jobs");
+    ColsumJobs j;
+    int max_cols = 0, max_rows = 0;
+    for (int i = 0; i < n; ++i) {
+        j.src[i] = jobs[i].src; j.ld[i] = jobs[i].ld; j.rows[i] = jobs[i].rows; j.cols[i] = jobs[i].cols;
+        j.dst[i] = jobs[i].dst; j.dst2[i] = jobs[i].dst2;
+        max_cols = std::max(max_cols, jobs[i].cols); max_rows = std::max(max_rows, jobs[i].rows);
+        if (!zeroed) {
+            LAS_HIP_CHECK(hipMemsetAsync(jobs[i].dst, 0, sizeof(float) * jobs[i].cols, stream));
+            if (jobs[i].dst2) LAS_HIP_CHECK(hipMemsetAsync(jobs[i].dst2, 0, sizeof(float) * jobs[i].cols, stream));
+        }
+    }
+    const int rpb = 256;
+    dim3 grid(cdiv(max_cols, 64), cdiv(max_rows, rpb), n), block(256);
+    hipLaunchKernelGGL(colsum_multi_kernel, grid, block, 0, stream, j, rpb);
+    LAS_LAUNCH_CHECK();
+    return LAS_OK;
+}
+
 __global__ void relu_mask_kernel(float* __restrict__ grad, const float* __restrict__ act, long n) {
     const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n && !(act[i] > 0.f)) grad[i] = 0.f;
