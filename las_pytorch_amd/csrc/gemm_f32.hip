@@ -360,13 +360,14 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_f32_kernel(GemmParams p)
 }
 
 // Several independent GEMMs of the same operand layout in ONE launch (the weight-gradient contractions of a backward pass:
-// few output tiles each, long K).  Every problem is cut stream-K fashion into equal runs of k-iterations over as many of
-// the W resident workgroups as its size warrants (>= GROUP_MIN_ITERS iterations per run); small problems start at rotating
-// workgroup offsets.  A workgroup walks through its share of every problem without any grid-wide synchronisation, so there
-// is no tail between the GEMMs and a 16-tile problem no longer holds the chip.  All outputs accumulate with atomics onto
-// buffers the caller has zeroed (the flat gradient buffer).
-constexpr int GROUP_MAX = 8, GROUP_MIN_ITERS = 8;
-struct GemmGroupParams { GemmParams prob[GROUP_MAX]; int n; int xcd_swz; };
+// few output tiles each, long K).  The k-iterations of ALL problems are laid end to end and cut into W equal runs, one per
+// resident workgroup (stream-K across the problems): a workgroup walks through its run — the tail of one tile, whole tiles,
+// the head of the next, crossing from one problem into the following one — without any grid-wide synchronisation, so there
+// is no tail between the GEMMs, a 16-tile problem no longer holds the chip, and a tile is split between as few workgroups
+// as the balance allows (the atomic traffic is W + #tiles partial tiles, not W per problem).  Partial tiles accumulate with
+// atomics onto buffers the caller has zeroed (the flat gradient buffer); whole tiles are stored (or added) plainly.
+constexpr int GROUP_MAX = 8;
+struct GemmGroupParams { GemmParams prob[GROUP_MAX]; long first[GROUP_MAX + 1]; int n; int xcd_swz; };
 
 template <bool A_KC, bool B_KC>
 __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_group_kernel(GemmGroupParams g) {
@@ -374,23 +375,26 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_group_kernel(GemmGroupPa
     __shared__ __attribute__((aligned(16))) float Bs[2][BK][BN + PAD];
     const int W = gridDim.x;
     const int w = (W % 8 == 0 && g.xcd_swz) ? (int)(blockIdx.x & 7) * (W >> 3) + (int)(blockIdx.x >> 3) : (int)blockIdx.x;
-    int rot = 0;
-    for (int pi = 0; pi < g.n; ++pi) {
+    const long total = g.first[g.n];
+    const long per = (total + W - 1) / W;
+    long i0 = (long)w * per, i1 = min(i0 + per, total);
+    int pi = 0;
+    while (pi + 1 < g.n && g.first[pi + 1] <= i0) ++pi;
+    while (i0 < i1) {
         const GemmParams p = g.prob[pi];       // by value: the fields live in SGPRs across the k-loop (fetching them from the
                                                // kernel-argument segment inside the loop measured slower)
-        const long iters = (long)p.gx * p.gy * p.kt;
-        const int parts = (int)min((long)W, max(1L, iters / GROUP_MIN_ITERS));
-        const long per = (iters + parts - 1) / parts;
-        const int slot = (w + W - rot % W) % W;
-        rot += parts;
-        if (slot >= parts) continue;
-        long i0 = (long)slot * per, i1 = min(i0 + per, iters);
-        while (i0 < i1) {
-            const int t = (int)(i0 / p.kt);
-            const int it0 = (int)(i0 % p.kt), it1 = (int)min((long)p.kt, it0 + (i1 - i0));
-            gemm_segment<A_KC, B_KC>(p, As, Bs, 0, (t / p.gx) * BM, (t % p.gx) * BN, it0 * BK, min(p.K, it1 * BK), true, false);
-            i0 += it1 - it0;
+        const long pend = min(i1, g.first[pi + 1]);
+        long l0 = i0 - g.first[pi];
+        const long l1 = pend - g.first[pi];
+        while (l0 < l1) {
+            const int t = (int)(l0 / p.kt);
+            const int it0 = (int)(l0 % p.kt), it1 = (int)min((long)p.kt, it0 + (l1 - l0));
+            const bool whole = it0 == 0 && it1 == p.kt;
+            gemm_segment<A_KC, B_KC>(p, As, Bs, 0, (t / p.gx) * BM, (t % p.gx) * BN, it0 * BK, min(p.K, it1 * BK), !whole, false);
+            l0 += it1 - it0;
         }
+        i0 = pend;
+        ++pi;
     }
 }
 
@@ -435,6 +439,7 @@ int gemm_f32_group(const GemmDesc* ds, int n, hipStream_t stream) {
     }
     GemmGroupParams g;
     g.n = n;
+    g.first[0] = 0;
     static const int xcd_swz = getenv("LAS_GEMM_XCD_SWZ") ? atoi(getenv("LAS_GEMM_XCD_SWZ")) : 1;
     g.xcd_swz = xcd_swz;
     for (int i = 0; i < n; ++i) {
@@ -445,6 +450,8 @@ int gemm_f32_group(const GemmDesc* ds, int n, hipStream_t stream) {
         p.a_vec = gemm_aligned(d.A, d.lda, 0); p.b_vec = gemm_aligned(d.B, d.ldb, 0);
         p.gx = cdiv(d.N, BN); p.gy = cdiv(d.M, BM); p.kt = std::max(1, cdiv(d.K, BK));
         p.splitk = 1; p.kper = d.K;
+        p.accumulate = d.accumulate;           // whole tiles: plain add onto the caller's values instead of a plain store
+        g.first[i + 1] = g.first[i] + (long)p.gx * p.gy * p.kt;
     }
     dim3 grid(W), block(GEMM_THREADS);
     const bool a_kc = ds[0].a_kc, b_kc = ds[0].b_kc;
