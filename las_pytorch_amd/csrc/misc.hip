@@ -229,7 +229,27 @@ int collate_pad(const float* packed, const long long* foff, const long long* pla
 }
 
 // In-place log-softmax over rows of width V (teacher-forced decode: the character distribution of ALL steps is one
-// GEMM after the loop instead of a per-step phase; reference las_model.py:182)
+// GEMM after the loop instead of a per-step phase; reference las_model.py:182).  V <= 32 (the reference's 30 characters):
+// one 32-lane group per row, coalesced row reads, shuffle reductions; wider rows: one thread per row.
+__device__ __forceinline__ float group32_max(float v) {
+#pragma unroll
+    for (int m = 16; m >= 1; m >>= 1) v = fmaxf(v, __shfl_xor(v, m, 32));
+    return v;
+}
+__device__ __forceinline__ float group32_sum(float v) {
+#pragma unroll
+    for (int m = 16; m >= 1; m >>= 1) v += __shfl_xor(v, m, 32);
+    return v;
+}
+__global__ __launch_bounds__(256) void log_softmax_rows32_kernel(float* __restrict__ x, long rows, int V) {
+    const long r = (long)blockIdx.x * 8 + (threadIdx.x >> 5);
+    const int v = threadIdx.x & 31;
+    if (r >= rows) return;
+    const float val = v < V ? x[r * V + v] : -INFINITY;
+    const float m = group32_max(val);
+    const float s = group32_sum(v < V ? expf(val - m) : 0.f);
+    if (v < V) x[r * V + v] = val - (m + logf(s));
+}
 __global__ void log_softmax_rows_kernel(float* __restrict__ x, long rows, int V) {
     const long r = (long)blockIdx.x * blockDim.x + threadIdx.x;
     if (r >= rows) return;
@@ -242,11 +262,21 @@ __global__ void log_softmax_rows_kernel(float* __restrict__ x, long rows, int V)
     for (int v = 0; v < V; ++v) p[v] -= lse;
 }
 int log_softmax_rows(float* x, long rows, int V, hipStream_t stream) {
-    hipLaunchKernelGGL(log_softmax_rows_kernel, dim3(cdiv(rows, 128)), dim3(128), 0, stream, x, rows, V);
+    if (V <= 32) hipLaunchKernelGGL(log_softmax_rows32_kernel, dim3(cdiv(rows, 8)), dim3(256), 0, stream, x, rows, V);
+    else hipLaunchKernelGGL(log_softmax_rows_kernel, dim3(cdiv(rows, 128)), dim3(128), 0, stream, x, rows, V);
     LAS_LAUNCH_CHECK();
     return LAS_OK;
 }
 // dz = dlogp - exp(logp) * sum(dlogp) per row
+__global__ __launch_bounds__(256) void log_softmax_bwd_rows32_kernel(const float* __restrict__ dlogp, const float* __restrict__ logp,
+                                                                     float* __restrict__ dz, long rows, int V) {
+    const long r = (long)blockIdx.x * 8 + (threadIdx.x >> 5);
+    const int v = threadIdx.x & 31;
+    if (r >= rows) return;
+    const float g = v < V ? dlogp[r * V + v] : 0.f;
+    const float s = group32_sum(g);
+    if (v < V) dz[r * V + v] = g - expf(logp[r * V + v]) * s;
+}
 __global__ void log_softmax_bwd_rows_kernel(const float* __restrict__ dlogp, const float* __restrict__ logp,
                                             float* __restrict__ dz, long rows, int V) {
     const long r = (long)blockIdx.x * blockDim.x + threadIdx.x;
@@ -256,7 +286,8 @@ __global__ void log_softmax_bwd_rows_kernel(const float* __restrict__ dlogp, con
     for (int v = 0; v < V; ++v) dz[r * V + v] = dlogp[r * V + v] - expf(logp[r * V + v]) * s;
 }
 int log_softmax_bwd_rows(const float* dlogp, const float* logp, float* dz, long rows, int V, hipStream_t stream) {
-    hipLaunchKernelGGL(log_softmax_bwd_rows_kernel, dim3(cdiv(rows, 128)), dim3(128), 0, stream, dlogp, logp, dz, rows, V);
+    if (V <= 32) hipLaunchKernelGGL(log_softmax_bwd_rows32_kernel, dim3(cdiv(rows, 8)), dim3(256), 0, stream, dlogp, logp, dz, rows, V);
+    else hipLaunchKernelGGL(log_softmax_bwd_rows_kernel, dim3(cdiv(rows, 128)), dim3(128), 0, stream, dlogp, logp, dz, rows, V);
     LAS_LAUNCH_CHECK();
     return LAS_OK;
 }
@@ -272,23 +303,31 @@ __global__ __launch_bounds__(256) void ls_loss_kernel(const float* __restrict__ 
                                                       const long long* __restrict__ labels, int U, int U_lab, int B, int V,
                                                       float eps, float* __restrict__ part, float* __restrict__ dlogp,
                                                       long dU, long dB) {
+    // one workgroup per utterance, one element (step, class) per thread and pass: the label slab is read coalesced; the row
+    // sums the smoothing needs (1 on labelled steps, 0 on padding) are built in LDS first
+    extern __shared__ float rowsum[];                 // U floats
     __shared__ float red[256];
     const int b = blockIdx.x, tid = threadIdx.x;
     const long long* yb = labels + (long)b * U_lab * V;
+    const int n = U * V;
+    for (int s = tid; s < U; s += 256) rowsum[s] = 0.f;
+    __syncthreads();
     float len = 0.f;
-    for (int i = tid; i < U * V; i += 256) len += (float)yb[i];          // rows s < U of a (U_lab, V) slab are contiguous
+    for (int i = tid; i < n; i += 256) {
+        const float y = (float)yb[i];                 // rows s < U of a (U_lab, V) slab are contiguous
+        if (y != 0.f) atomicAdd(&rowsum[i / V], y);
+        len += y;
+    }
     red[tid] = len; __syncthreads();
     for (int o = 128; o > 0; o >>= 1) { if (tid < o) red[tid] += red[tid + o]; __syncthreads(); }
     len = red[0]; __syncthreads();
     float acc = 0.f;
-    for (int s = tid; s < U; s += 256) {
-        float rs = 0.f;
-        for (int c = 0; c < V; ++c) rs += (float)yb[(long)s * V + c];
-        for (int c = 0; c < V; ++c) {
-            const float sm = ((1.f - eps) * (float)yb[(long)s * V + c] + eps / V) * rs;
-            acc += sm * logp[(long)s * sU + (long)b * sB + c];
-            if (dlogp) dlogp[(long)s * dU + (long)b * dB + c] = -sm / (B * len);
-        }
+    const float scale = 1.f / (B * len);
+    for (int i = tid; i < n; i += 256) {
+        const int s = i / V, c = i - s * V;
+        const float sm = ((1.f - eps) * (float)yb[i] + eps / V) * rowsum[s];
+        acc += sm * logp[(long)s * sU + (long)b * sB + c];
+        if (dlogp) dlogp[(long)s * dU + (long)b * dB + c] = -sm * scale;
     }
     red[tid] = acc; __syncthreads();
     for (int o = 128; o > 0; o >>= 1) { if (tid < o) red[tid] += red[tid + o]; __syncthreads(); }
@@ -301,7 +340,8 @@ __global__ void ls_loss_finish_kernel(const float* __restrict__ part, int B, flo
 }
 int ls_loss(const float* logp, long sU, long sB, const long long* labels, int U, int U_lab, int B, int V, float eps, float* part,
             float* loss, float* dlogp, long dU, long dB, hipStream_t stream) {
-    hipLaunchKernelGGL(ls_loss_kernel, dim3(B), dim3(256), 0, stream, logp, sU, sB, labels, U, U_lab, B, V, eps, part, dlogp, dU, dB);
+    hipLaunchKernelGGL(ls_loss_kernel, dim3(B), dim3(256), sizeof(float) * U, stream, logp, sU, sB, labels, U, U_lab, B, V, eps, part, dlogp,
+                       dU, dB);
     hipLaunchKernelGGL(ls_loss_finish_kernel, dim3(1), dim3(1), 0, stream, part, B, loss);
     LAS_LAUNCH_CHECK();
     return LAS_OK;
