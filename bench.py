@@ -129,43 +129,67 @@ def roofline_rec_fwd(c, B, T, iters=20, with_traffic=True):
                 kernel_ms=round(ms, 4), us_per_step=round(ms * 1e3 / T_l, 3), algorithmic_bytes=alg_bytes)
 
 
-def step_gemm_shapes(c, B, T, U):
-    """(name, M, N, K, a_kc, b_kc, batch, splitk, count) of every MFMA GEMM of one training step (las_capi.hip)."""
+def step_gemm_launches(c, B, T, U):
+    """The MFMA GEMM LAUNCHES of one training step exactly as las_capi.hip issues them: each entry is
+    (name, kind, problems) with kind "single" (las_gemm_f32: batch / bias-capable path) or "group" (las_gemm_f32_group: one
+    launch for several weight-gradient GEMMs, or one dual-K-source GEMM).  problem = (M, N, K, a_kc, b_kc, batch, splitk, K1)."""
     H, F, L, Hs, V, M = c["H"], c["F"], c["L"], c["Hs"], c["V"], c["M"]
+    Tp, UB = T >> L, U * B
     out = []
     for l in range(L):
         BT, D = B * (T >> (l + 1)), (2 * F if l == 0 else 4 * H)
-        out.append((f"L{l} X W_ih^T (2 dirs batched)", BT, 4 * H, D, 1, 1, 2, 1, 1))
-        out.append((f"L{l} dW_ih", 4 * H, D, BT, 0, 0, 1, 0, 2))
-        out.append((f"L{l} dW_hh", 4 * H, H, BT, 0, 0, 1, 0, 2))
+        out.append((f"L{l} X W_ih^T (2 dirs batched)", "single", [(BT, 4 * H, D, 1, 1, 2, 1, 0)]))
+    out.append(("keys psi", "single", [(B * Tp, M, 2 * H, 1, 1, 1, max(1, min(2 * H // 64, 256 // max(1, -(-B * Tp // 128)))), 0)]))
+    out.append(("logits [h|ctx] W_c^T (dual K)", "group", [(UB, V, 2 * Hs, 1, 1, 1, 0, Hs)]))
+    out.append(("dcat = dz W_c", "single", [(UB, 2 * Hs, V, 1, 0, 1, 1, 0)]))
+    out.append(("dfeat (per utterance)", "single", [(Tp, Hs, U, 0, 0, B, 1, 0)]))
+    out.append(("dK (per utterance)", "single", [(Tp, M, U, 0, 0, B, 1, 0)]))
+    out.append(("dW_psi", "single", [(M, Hs, B * Tp, 0, 0, 1, 0, 0)]))
+    out.append(("dfeat += dK W_psi", "single", [(B * Tp, Hs, M, 1, 0, 1, 1, 0)]))
+    out.append(("speller dW group (8 GEMMs, one launch)", "group",
+                [(V, Hs, UB, 0, 0, 1, 0, 0), (V, Hs, UB, 0, 0, 1, 0, 0), (M, Hs, UB, 0, 0, 1, 0, 0), (4 * Hs, V, UB, 0, 0, 1, 0, 0),
+                 (4 * Hs, Hs, UB, 0, 0, 1, 0, 0), (4 * Hs, Hs, UB - B, 0, 0, 1, 0, 0), (4 * Hs, Hs, UB, 0, 0, 1, 0, 0),
+                 (4 * Hs, Hs, UB - B, 0, 0, 1, 0, 0)]))
+    for l in reversed(range(L)):
+        BT, D = B * (T >> (l + 1)), (2 * F if l == 0 else 4 * H)
+        out.append((f"L{l} dW group (4 GEMMs, one launch)", "group",
+                    [(4 * H, D, BT, 0, 0, 1, 0, 0), (4 * H, H, BT, 0, 0, 1, 0, 0), (4 * H, D, BT, 0, 0, 1, 0, 0), (4 * H, H, BT, 0, 0, 1, 0, 0)]))
         if l > 0:
-            out.append((f"L{l} dX", BT, D, 4 * H, 1, 0, 1, 1, 2))
-    Tp, UB = T >> L, U * B
-    out += [("keys psi", B * Tp, M, 2 * H, 1, 1, 1, 0, 1), ("logits [h|ctx] W_c^T", UB, V, Hs, 1, 1, 1, 0, 2),
-            ("dcat = dz W_c", UB, 2 * Hs, V, 1, 0, 1, 1, 1),
-            ("dfeat (per utterance)", Tp, Hs, U, 0, 0, B, 1, 1), ("dK (per utterance)", Tp, M, U, 0, 0, B, 1, 1),
-            ("dW_psi", M, Hs, B * Tp, 0, 0, 1, 0, 1), ("dfeat += dK W_psi", B * Tp, Hs, M, 1, 0, 1, 1, 1),
-            ("dW_phi", M, Hs, UB, 0, 0, 1, 0, 1), ("dW_c halves", V, Hs, UB, 0, 0, 1, 0, 2),
-            ("dW_ih0[:, :V]", 4 * Hs, V, UB, 0, 0, 1, 0, 1), ("dW_ih0[:, V:]", 4 * Hs, Hs, UB, 0, 0, 1, 0, 1),
-            ("dW_ih1", 4 * Hs, Hs, UB, 0, 0, 1, 0, 1), ("dW_hh0/1", 4 * Hs, Hs, UB - B, 0, 0, 1, 0, 2)]
+            out.append((f"L{l} dX (both directions, dual K)", "group", [(BT, D, 8 * H, 1, 0, 1, 0, 4 * H)]))
     return out
 
 
 def roofline_mfma(c, B, T, U, reps=10):
-    """Every GEMM shape of one training step through the exported las_gemm_f32, HIP-event timed on the launch stream:
-    flops / time against the dense fp32-MFMA peak.  (The step's 2*M*N*K flops are ALGORITHMIC: split-K atomics, bias
-    and activation epilogues are not counted.)"""
+    """Every MFMA GEMM launch of one training step, issued through the same entry points and in the same grouping as
+    las_capi.hip does, HIP-event timed on the launch stream: flops / time against the dense fp32-MFMA peak.  (2*M*N*K flops
+    are ALGORITHMIC: stream-K atomics, bias and activation epilogues are not counted.)"""
+    import ctypes
     from las_pytorch_amd import _cabi
     L = _cabi.lib()
     tot_us, tot_fl, rows = 0.0, 0.0, []
-    for name, M, N, K, a_kc, b_kc, batch, splitk, count in step_gemm_shapes(c, B, T, U):
-        A = torch.randn(batch * M * K, device="cuda"); Bm = torch.randn(batch * N * K, device="cuda")
-        C = torch.zeros(batch * M * N, device="cuda")
-        lda = K if a_kc else M; ldb = K if b_kc else N
+    for name, kind, probs in step_gemm_launches(c, B, T, U):
+        bufs, descs = [], (_cabi.GemmDescC * len(probs))()
+        for i, (M, N, K, a_kc, b_kc, batch, splitk, K1) in enumerate(probs):
+            A = torch.randn(batch * M * K, device="cuda"); Bm = torch.randn(batch * N * K, device="cuda")
+            C = torch.zeros(batch * M * N, device="cuda")
+            bufs.append((A, Bm, C))
+            Ka = K1 if K1 else K                          # dual K: the two sources are K1 and K-K1 wide with the same leading dimension
+            lda = Ka if a_kc else M; ldb = Ka if b_kc else N
+            d = descs[i]
+            d.A, d.B, d.C = A.data_ptr(), Bm.data_ptr(), C.data_ptr()
+            d.A2 = A.data_ptr() + 4 * (M * K1 if a_kc else K1 * M) if K1 else None
+            d.B2 = Bm.data_ptr() + 4 * (N * K1 if b_kc else K1 * N) if K1 else None
+            d.M, d.N, d.K, d.K1, d.lda, d.ldb, d.ldc = M, N, K, K1, lda, ldb, N
+            d.a_kc, d.b_kc, d.accumulate, d.c_zeroed = a_kc, b_kc, 0, int(kind == "group" and not K1)
 
         def call():
-            _cabi.check(L.las_gemm_f32(A.data_ptr(), Bm.data_ptr(), C.data_ptr(), None, None, M, N, K, lda, ldb, N, a_kc, b_kc, batch,
-                                       M * K, N * K, M * N, splitk, 0, 0, _cabi.stream_ptr()))
+            if kind == "group":
+                _cabi.check(L.las_gemm_f32_group(descs, len(probs), _cabi.stream_ptr()))
+            else:
+                M, N, K, a_kc, b_kc, batch, splitk, _ = probs[0]
+                A, Bm, C = bufs[0]
+                _cabi.check(L.las_gemm_f32(A.data_ptr(), Bm.data_ptr(), C.data_ptr(), None, None, M, N, K, K if a_kc else M, K if b_kc else N, N,
+                                           a_kc, b_kc, batch, M * K, N * K, M * N, splitk, 0, 0, _cabi.stream_ptr()))
         for _ in range(2):
             call()
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -174,13 +198,14 @@ def roofline_mfma(c, B, T, U, reps=10):
             call()
         e1.record(); torch.cuda.synchronize()
         us = e0.elapsed_time(e1) * 1e3 / reps
-        fl = 2.0 * batch * M * N * K
-        tot_us += us * count; tot_fl += fl * count
-        rows.append({"gemm": name, "M": M, "N": N, "K": K, "batch": batch, "count": count, "us": round(us, 1), "tflops": round(fl / us / 1e6, 1)})
+        fl = sum(2.0 * p[5] * p[0] * p[1] * p[2] for p in probs)
+        tot_us += us; tot_fl += fl
+        rows.append({"launch": name, "gemms": len(probs), "us": round(us, 1), "tflops": round(fl / us / 1e6, 1)})
+        del bufs
     tf = tot_fl / tot_us / 1e6
-    return dict(bound="mfma", kernel="gemm_f32_kernel: all MFMA GEMMs of one training step (v_mfma_f32_32x32x2_f32, exact fp32)",
+    return dict(bound="mfma", kernel="gemm_f32_kernel / gemm_group_kernel: every MFMA GEMM launch of one training step (v_mfma_f32_32x32x2_f32, exact fp32)",
                 achieved=round(tf, 1), peak=MFMA_F32_PEAK_TF, unit="TFLOP/s", frac=round(tf / MFMA_F32_PEAK_TF, 4),
-                flops_per_step=int(tot_fl), gemm_ms_per_step=round(tot_us / 1e3, 3), shapes=rows)
+                flops_per_step=int(tot_fl), gemm_ms_per_step=round(tot_us / 1e3, 3), launches=rows)
 
 
 def sweep_rec(c, T, batches=(32, 128, 512)):

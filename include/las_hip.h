@@ -220,6 +220,17 @@ int las_comm_destroy(void);
 int las_gemm_f32(const float* A, const float* B, float* C, const float* bias0, const float* bias1,
                  int M, int N, int K, int64_t lda, int64_t ldb, int64_t ldc, int a_kc, int b_kc,
                  int batch, int64_t sA, int64_t sB, int64_t sC, int splitk, int accumulate, int relu, void* stream);
+/* n independent GEMMs C_i (+)= A_i B_i in ONE launch (stream-K across the concatenated k-iterations of all problems) when they
+ * share the operand orientation and every output is pre-zeroed (c_zeroed) or accumulated onto; otherwise one launch each.
+ * A2/B2/K1: optional second source along K (k >= K1 reads A2/B2 at k-K1), single problems only.  This is how the backward
+ * passes issue their weight-gradient contractions; exported so that bench.py times exactly the launches a step makes. */
+typedef struct las_gemm_desc {
+    const float* A; const float* B; float* C; const float* A2; const float* B2;
+    int M, N, K, K1;
+    int64_t lda, ldb, ldc;
+    int a_kc, b_kc, accumulate, c_zeroed;
+} las_gemm_desc;
+int las_gemm_f32_group(const las_gemm_desc* descs, int n, void* stream);
 /* recurrence only: gates (2,B,T,4H) pre-activations in, see las_pblstm_fwd for the rest */
 size_t las_rec_xbuf_bytes(int B, int H);
 int las_pblstm_rec_fwd(float* gates, const float* w_hh_f, const float* w_hh_r, float* out, float* cbuf, float* hprev,

@@ -25,6 +25,12 @@ class SpellerDesc(C.Structure):
                 ("w_dr", _f), ("b_dr", _f)]
 
 
+class GemmDescC(C.Structure):
+    _fields_ = [("A", _f), ("B", _f), ("C", _f), ("A2", _f), ("B2", _f), ("M", C.c_int), ("N", C.c_int), ("K", C.c_int), ("K1", C.c_int),
+                ("lda", C.c_int64), ("ldb", C.c_int64), ("ldc", C.c_int64), ("a_kc", C.c_int), ("b_kc", C.c_int), ("accumulate", C.c_int),
+                ("c_zeroed", C.c_int)]
+
+
 class SpellerGrads(C.Structure):
     _fields_ = [("dw_ih", _f * MAX_L), ("dw_hh", _f * MAX_L), ("db_ih", _f * MAX_L), ("db_hh", _f * MAX_L),
                 ("dw_phi", _f), ("db_phi", _f), ("dw_psi", _f), ("db_psi", _f), ("dw_c", _f), ("db_c", _f),
@@ -66,6 +72,7 @@ PROTOTYPES = {
     "las_comm_destroy": (C.c_int, []),
     "las_gemm_f32": (C.c_int, [_f] * 5 + [C.c_int] * 3 + [C.c_int64] * 3 + [C.c_int, C.c_int, C.c_int]
                      + [C.c_int64] * 3 + [C.c_int, C.c_int, C.c_int, _f]),
+    "las_gemm_f32_group": (C.c_int, [C.POINTER(GemmDescC), C.c_int, _f]),
     "las_rec_xbuf_bytes": (C.c_size_t, [C.c_int, C.c_int]),
     "las_pblstm_rec_fwd": (C.c_int, [_f] * 6 + [C.c_int] * 3 + [_f, _f, C.c_int, _f]),
 }

@@ -986,6 +986,18 @@ int las_gemm_f32(const float* A, const float* B, float* C, const float* bias0, c
     return gemm_f32(g, (hipStream_t)stream);
 }
 
+int las_gemm_f32_group(const las_gemm_desc* descs, int n, void* stream) {
+    LAS_REQUIRE(descs != nullptr && n >= 1 && n <= 8, "gemm group");
+    GemmDesc g[8];
+    for (int i = 0; i < n; ++i) {
+        const las_gemm_desc& d = descs[i];
+        g[i].A = d.A; g[i].B = d.B; g[i].C = d.C; g[i].A2 = d.A2; g[i].B2 = d.B2; g[i].K1 = d.K1;
+        g[i].M = d.M; g[i].N = d.N; g[i].K = d.K; g[i].lda = d.lda; g[i].ldb = d.ldb; g[i].ldc = d.ldc;
+        g[i].a_kc = d.a_kc; g[i].b_kc = d.b_kc; g[i].accumulate = d.accumulate; g[i].c_zeroed = d.c_zeroed;
+    }
+    return gemm_f32_group(g, n, (hipStream_t)stream);
+}
+
 size_t las_rec_xbuf_bytes(int B, int H) { return rec_xbuf_bytes(B, H); }
 
 int las_pblstm_rec_fwd(float* gates, const float* w_hh_f, const float* w_hh_r, float* out, float* cbuf, float* hprev, int B,

@@ -1,0 +1,21 @@
+#!/bin/bash
+# Runs ON the GPU box (through gpurun): everything the round's profiles/ entries are generated from.
+#   gpurun --timeout 2400 -- 'bash tools/gpu_evidence.sh'
+# then locally:  python tools/collect_evidence.py
+R=${GRAFT_REPO_ROOT:-/root/repo}
+O=$R/gpurun_out/evidence
+rm -rf $O; mkdir -p $O
+cd $R
+rm -f gpurun_out/parity_observed.jsonl
+python -m pytest tests -m gpu -q > $O/pytest_gpu.log 2>&1
+python -c "import __graft_entry__ as g; g.smoke()" > $O/smoke.log 2>&1
+python bench.py --steps 20 --warmup 5 > $O/bench.json 2> $O/bench.err
+cd /tmp && export TMPDIR=/tmp
+rocprofv3 --kernel-trace --stats -d $O/stats -o x -- python3 $R/bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-sweep --no-mfma --no-roofline --no-secondary > $O/stats.log 2>&1
+rocprofv3 --pmc FETCH_SIZE -d $O/pmc_fetch -o x -- python3 $R/tools/ubench_rec.py > $O/pmc_fetch.log 2>&1
+rocprofv3 --pmc WRITE_SIZE -d $O/pmc_write -o x -- python3 $R/tools/ubench_rec.py > $O/pmc_write.log 2>&1
+rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU_MFMA_MOPS_F32 GRBM_GUI_ACTIVE -d $O/pmc_gemm_a -o x -- python3 $R/tools/ubench_gemm_pmc.py > $O/pmc_gemm_a.log 2>&1
+rocprofv3 --pmc SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_VMEM SQ_INSTS_LDS SQ_WAIT_INST_LDS SQ_ACTIVE_INST_VALU SQ_INSTS_VALU -d $O/pmc_gemm_b -o x -- python3 $R/tools/ubench_gemm_pmc.py > $O/pmc_gemm_b.log 2>&1
+cd $R
+python tools/ubench_rec_sweep.py > $O/rec_sweep.log 2>&1
+tail -3 $O/pytest_gpu.log; tail -1 $O/smoke.log; tail -c 300 $O/bench.json
