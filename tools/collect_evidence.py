@@ -42,6 +42,17 @@ def main():
               open(os.path.join(P, "r02_parity_observed.json"), "w"), indent=1)
     open(os.path.join(P, "r02_rec_sweep.txt"), "w").write(open(os.path.join(E, "rec_sweep.log")).read())
     open(os.path.join(P, "r02_pytest_gpu.txt"), "w").write("".join(open(os.path.join(E, "pytest_gpu.log")).readlines()[-6:]))
+    runs = []
+    for l in open(os.path.join(E, "variants.jsonl")):
+        if l.startswith("{"):
+            v = json.loads(l)
+            runs.append({"workload": v["config"]["workload"], "per_gpu_batch": v["config"]["per_gpu_batch"], "utt_per_s": v["value"],
+                         "ms_per_step": v["ms_per_step"], "steps": v["steps"]})
+    soak = json.loads(open(os.path.join(E, "soak.json")).read().strip().splitlines()[-1])
+    json.dump({"source": "python bench.py --workload W --batch B --steps 10 --warmup 3 on one MI355X (round 2 final)", "runs": runs,
+               "soak": {"steps": soak["steps"], "ms_per_step": soak["ms_per_step"], "utt_per_s": soak["value"],
+                        "note": "1500 consecutive training steps, device error word clean at the end (bench.py asserts it)"}},
+              open(os.path.join(P, "r02_bench_variants.json"), "w"), indent=1)
     print("value", j["value"], "ms", j["ms_per_step"], "roofline", j["roofline"]["frac"], j["roofline"]["traffic"], "mfma", j["roofline_mfma"]["achieved"])
 
 

@@ -18,4 +18,7 @@ rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES SQ_WAVE_CYCLES SQ_WAI
 rocprofv3 --pmc SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_VMEM SQ_INSTS_LDS SQ_WAIT_INST_LDS SQ_ACTIVE_INST_VALU SQ_INSTS_VALU -d $O/pmc_gemm_b -o x -- python3 $R/tools/ubench_gemm_pmc.py > $O/pmc_gemm_b.log 2>&1
 cd $R
 python tools/ubench_rec_sweep.py > $O/rec_sweep.log 2>&1
+# soak: 1500 consecutive training steps (~1e7 inter-workgroup hand-offs) must end without a device error word
+python bench.py --steps 1500 --warmup 5 --no-cpu-baseline --no-sweep --no-mfma --no-roofline --no-secondary > $O/soak.json 2> $O/soak.err
+for w in "P_long 8" "S_train 32" "Y_train 16" "P_fwd 32" "S_fwd 32" "P_train 128"; do set -- $w; python bench.py --workload $1 --batch $2 --steps 10 --warmup 3 --no-cpu-baseline --no-sweep --no-mfma --no-secondary --no-roofline 2>/dev/null | tail -1; done > $O/variants.jsonl
 tail -3 $O/pytest_gpu.log; tail -1 $O/smoke.log; tail -c 300 $O/bench.json
