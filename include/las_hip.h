@@ -82,7 +82,7 @@ typedef struct las_speller_desc {
     int M;            /* attention MLP dim (ignored when !use_mlp) */
     int L;            /* speller LSTM layers (1..LAS_MAX_SPELLER_LAYERS) */
     int use_mlp;      /* use_mlp_in_attention */
-    int relu;         /* 1: relu after phi/psi, 0: no activation */
+    int relu;         /* activation after phi/psi (mlp_activate_in_attention): 0 none, 1 relu, 2 tanh, 3 sigmoid */
     int multi_head;   /* attention heads (reference las_model.py:298-314); > 1 needs use_mlp and w_dr/b_dr */
     /* parameters, PyTorch layouts: w_ih[0] (4Hs, V+Hs), w_ih[l>0] (4Hs, Hs), w_hh (4Hs, Hs), biases (4Hs) */
     const float* w_ih[LAS_MAX_SPELLER_LAYERS];

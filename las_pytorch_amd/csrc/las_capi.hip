@@ -108,6 +108,7 @@ int check_attn_desc(const las_speller_desc* d) {
     LAS_REQUIRE(d->multi_head == 1 || (d->use_mlp && d->w_dr && d->b_dr),
                 "multi-head attention needs the phi/psi MLP and dim_reduce (reference las_model.py:266-269)");
     LAS_REQUIRE(!d->use_mlp || (d->M > 0 && d->w_phi && d->b_phi && d->w_psi && d->b_psi), "attention MLP weights");
+    LAS_REQUIRE(d->relu >= LAS_ACT_NONE && d->relu <= LAS_ACT_SIGMOID, "attention activation code");
     return LAS_OK;
 }
 
@@ -174,7 +175,7 @@ static int attention_deferred(const las_speller_desc* d, const AttnDeferred& x, 
     }
     if (d->use_mlp) {
         const int BT = B * Tp;
-        if (d->relu) LAS_TRY(relu_mask_inplace(dK, keys, (long)BT * M, stream));
+        if (d->relu) LAS_TRY(act_bwd_inplace(dK, keys, (long)BT * M, d->relu, stream));
         {   // dW_psi = dKpre^T feat
             GemmDesc q;
             q.A = dK; q.lda = M; q.a_kc = false; q.B = feat; q.ldb = D; q.b_kc = false;
@@ -324,11 +325,13 @@ int las_attn_keys_fwd(const las_speller_desc* d, const float* feat, float* keys,
     if (tiles < 64 && g.K >= 256) {
         g.splitk = (int)std::min<long>(g.K / 64, std::max<long>(1, 256 / tiles));
         LAS_TRY(gemm_f32(g, stream));
-        if (d->relu) LAS_TRY(relu_inplace(keys, (long)g.M * g.N, stream));
+        if (d->relu) LAS_TRY(act_inplace(keys, (long)g.M * g.N, d->relu, stream));
         return LAS_OK;
     }
-    g.splitk = 1; g.relu = d->relu;
-    return gemm_f32(g, stream);
+    g.splitk = 1; g.relu = d->relu == LAS_ACT_RELU;          // relu rides in the GEMM epilogue, other activations in a second pass
+    LAS_TRY(gemm_f32(g, stream));
+    if (d->relu > LAS_ACT_RELU) LAS_TRY(act_inplace(keys, (long)g.M * g.N, d->relu, stream));
+    return LAS_OK;
 }
 
 size_t las_speller_reserve_floats(const las_speller_desc* d, int U) { return SpellerLayout(d, U).total; }
@@ -374,6 +377,7 @@ int las_speller_fwd(const las_speller_desc* d, const float* feat, const float* k
 
     static const bool persist_on = !(getenv("LAS_SPELLER_PERSIST") && atoi(getenv("LAS_SPELLER_PERSIST")) == 0);
     const bool persist = persist_on && err_word && !(flags & LAS_FLAG_FORCE_GENERIC) && (teacher_forced || decode_mode != 2) &&
+                         d->relu <= LAS_ACT_RELU &&        // the persistent kernels implement relu / no activation
                          speller_persist_eligible(B, Tp, Hs, D, d->M, V, L, d->multi_head, d->use_mlp, !teacher_forced);
     bool persist_ran = persist;
     if (persist) {
@@ -596,7 +600,7 @@ int las_speller_bwd(const las_speller_desc* d, const float* feat, const float* k
     float* dctxcat_all = NH > 1 ? workspace + wl.dctxcat_all : nullptr;
     const float* ctxcat_all = NH > 1 ? reserve + lay.ctxcat_all : nullptr;
     static const bool persist_on = !(getenv("LAS_SPELLER_PERSIST_BWD") && atoi(getenv("LAS_SPELLER_PERSIST_BWD")) == 0);
-    const bool persist = persist_on && hoist && err_word && !(flags & LAS_FLAG_FORCE_GENERIC) &&
+    const bool persist = persist_on && hoist && err_word && !(flags & LAS_FLAG_FORCE_GENERIC) && d->relu <= LAS_ACT_RELU &&
                          speller_persist_bwd_eligible(B, Tp, Hs, D, M, V, L, NH, d->use_mlp);
     bool persist_ran = persist;
     if (persist) {

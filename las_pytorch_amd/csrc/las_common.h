@@ -66,6 +66,27 @@ __device__ __forceinline__ float tanhf_acc(float x) {      // 1 - 2/(e^{2x}+1): 
 }
 #endif
 
+// Attention MLP activation codes (las_speller_desc::relu): the reference accepts any torch.nn.functional name
+// (model/las_model.py:270-273); relu is what the configs use, tanh / sigmoid are provided with libm-accurate forms.
+enum : int { LAS_ACT_NONE = 0, LAS_ACT_RELU = 1, LAS_ACT_TANH = 2, LAS_ACT_SIGMOID = 3 };
+__device__ __forceinline__ float act_apply(float x, int code) {
+    switch (code) {
+        case LAS_ACT_RELU: return fmaxf(x, 0.f);
+        case LAS_ACT_TANH: return tanhf(x);
+        case LAS_ACT_SIGMOID: return 1.0f / (1.0f + expf(-x));
+        default: return x;
+    }
+}
+// derivative factor from the POST-activation value y = act(x)
+__device__ __forceinline__ float act_grad(float y, int code) {
+    switch (code) {
+        case LAS_ACT_RELU: return y > 0.f ? 1.f : 0.f;
+        case LAS_ACT_TANH: return 1.f - y * y;
+        case LAS_ACT_SIGMOID: return y * (1.f - y);
+        default: return 1.f;
+    }
+}
+
 using f32x4 = __attribute__((ext_vector_type(4))) float;
 using f32x16 = __attribute__((ext_vector_type(16))) float;
 

@@ -181,9 +181,9 @@ int colsum(const float* src, long ld, int rows, int cols, float* dst, int accumu
 constexpr int COLSUM_MAX_JOBS = 8;
 struct ColsumJob { const float* src; long ld; int rows; int cols; float* dst; float* dst2; };
 int colsum_multi(const ColsumJob* jobs, int n, int zeroed, hipStream_t stream);
-int relu_mask_inplace(float* grad, const float* act, long n, hipStream_t stream);                           // grad = act>0 ? grad : 0
+int act_bwd_inplace(float* grad, const float* act, long n, int code, hipStream_t stream);                    // grad *= act'(.) (LAS_ACT_* code)
 int add_inplace(float* dst, const float* src, long n, hipStream_t stream);
-int relu_inplace(float* x, long n, hipStream_t stream);
+int act_inplace(float* x, long n, int code, hipStream_t stream);
 int copy2d(const float* src, long lds, float* dst, long ldd, int rows, int cols, int accumulate, hipStream_t stream);
 int log_softmax_rows(float* x, long rows, int V, hipStream_t stream);
 int log_softmax_bwd_rows(const float* dlogp, const float* logp, float* dz, long rows, int V, hipStream_t stream);

@@ -97,22 +97,23 @@ int colsum_multi(const ColsumJob* jobs, int n, int zeroed, hipStream_t stream) {
     return LAS_OK;
 }
 
-__global__ void relu_mask_kernel(float* __restrict__ grad, const float* __restrict__ act, long n) {
+// grad *= act'(x) from the post-activation values (relu: mask)
+__global__ void act_bwd_kernel(float* __restrict__ grad, const float* __restrict__ act, long n, int code) {
     const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n && !(act[i] > 0.f)) grad[i] = 0.f;
+    if (i < n) grad[i] *= act_grad(act[i], code);
 }
-int relu_mask_inplace(float* grad, const float* act, long n, hipStream_t stream) {
-    hipLaunchKernelGGL(relu_mask_kernel, dim3(cdiv(n, 256)), dim3(256), 0, stream, grad, act, n);
+int act_bwd_inplace(float* grad, const float* act, long n, int code, hipStream_t stream) {
+    hipLaunchKernelGGL(act_bwd_kernel, dim3(cdiv(n, 256)), dim3(256), 0, stream, grad, act, n, code);
     LAS_LAUNCH_CHECK();
     return LAS_OK;
 }
 
-__global__ void relu_kernel(float* __restrict__ x, long n) {
+__global__ void act_kernel(float* __restrict__ x, long n, int code) {
     const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n) x[i] = fmaxf(x[i], 0.f);
+    if (i < n) x[i] = act_apply(x[i], code);
 }
-int relu_inplace(float* x, long n, hipStream_t stream) {
-    hipLaunchKernelGGL(relu_kernel, dim3(cdiv(n, 256)), dim3(256), 0, stream, x, n);
+int act_inplace(float* x, long n, int code, hipStream_t stream) {
+    hipLaunchKernelGGL(act_kernel, dim3(cdiv(n, 256)), dim3(256), 0, stream, x, n, code);
     LAS_LAUNCH_CHECK();
     return LAS_OK;
 }

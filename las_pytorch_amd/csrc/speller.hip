@@ -413,7 +413,7 @@ __global__ __launch_bounds__(ATT_THREADS) void attn_step_fwd_kernel(AttnFwdArgs 
             acc = group_sum<16>(acc);
             if (ks == 0) {
                 acc += b_phi[m];
-                if (a.relu) acc = fmaxf(acc, 0.f);
+                acc = act_apply(acc, a.relu);
                 qs[m] = acc;
                 if (a.q_out) a.q_out[(long)b * ldq + (long)hd * a.M + m] = acc;
             }
@@ -676,7 +676,7 @@ __global__ __launch_bounds__(ATT_THREADS) void attn_step_bwd_kernel(AttnBwdArgs 
         float v = 0.f;
         for (int q = 0; q < NTQ; ++q) v += part[(long)q * Mq + m];
         if (a.use_mlp) {
-            if (a.relu && !(a.q[(long)b * ldq + (long)hd * a.M + m] > 0.f)) v = 0.f;
+            if (a.relu) v *= act_grad(a.q[(long)b * ldq + (long)hd * a.M + m], a.relu);
             a.dqpre_out[(long)b * ldq + (long)hd * a.M + m] = v;
         }
         dq[m] = v;

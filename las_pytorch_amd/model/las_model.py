@@ -212,8 +212,9 @@ class Attention(nn.Module):
             if self.multi_head > 1:
                 self.dim_reduce = nn.Linear(input_feature_dim * multi_head, input_feature_dim)
             if activate != "None":
-                if activate != "relu":
-                    raise NotImplementedError(f"mlp_activate_in_attention={activate!r}: the HIP path implements 'relu' and 'None'")
+                if activate not in _ACT_CODES:
+                    raise NotImplementedError(f"mlp_activate_in_attention={activate!r}: the HIP path implements "
+                                              f"{sorted(k for k in _ACT_CODES if k)} and 'None'")
                 self.activate = activate
 
     def _params(self):
@@ -231,9 +232,13 @@ class Attention(nn.Module):
         for inspection and carry no gradient.  Inside ``Speller.forward`` the same arithmetic runs fused in the decode
         kernels; this entry point serves callers that use the module on its own."""
         use_mlp = bool(self.mlp_preprocess_input)
-        cfg = (use_mlp, self.activate == "relu", int(self.preprocess_mlp_dim) if use_mlp else 0, int(self.multi_head))
+        cfg = (use_mlp, _ACT_CODES[self.activate], int(self.preprocess_mlp_dim) if use_mlp else 0, int(self.multi_head))
         ctx, att = _AttentionFn.apply(cfg, decoder_state.reshape(decoder_state.shape[0], -1), listener_feature, *self._params())
         return list(att.unbind(0)), ctx
+
+
+# attention activation name (mlp_activate_in_attention, reference las_model.py:270-273) -> las_speller_desc::relu code
+_ACT_CODES = {None: 0, "relu": 1, "tanh": 2, "sigmoid": 3}
 
 
 def _speller_desc(B, Tp, D, Hs, V, M, L, use_mlp, relu, lstm, rest, heads=1):
@@ -523,7 +528,7 @@ class Speller(nn.Module):
         a = self.attention
         use_mlp = bool(a.mlp_preprocess_input)
         cfg = (int(steps), bool(teacher_force), int(self.decode_mode), int(self.num_layers), use_mlp,
-               a.activate == "relu", int(a.preprocess_mlp_dim) if use_mlp else 0, int(self.label_dim), int(a.multi_head),
+               _ACT_CODES[a.activate], int(a.preprocess_mlp_dim) if use_mlp else 0, int(self.label_dim), int(a.multi_head),
                bool(self.force_generic))
         noise = None
         if not teacher_force and self.decode_mode not in (0, 1):
@@ -564,7 +569,7 @@ class Speller(nn.Module):
         if listener_feature.is_cuda:
             _cabi.poll_device_errors(listener_feature.device)
         B = listener_feature.shape[0]
-        cfg = (int(self.num_layers), use_mlp, a.activate == "relu", int(a.preprocess_mlp_dim) if use_mlp else 0, int(self.label_dim),
+        cfg = (int(self.num_layers), use_mlp, _ACT_CODES[a.activate], int(a.preprocess_mlp_dim) if use_mlp else 0, int(self.label_dim),
                int(a.multi_head))
         h_in = c_in = None
         if last_hidden_state is not None:

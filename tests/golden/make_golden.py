@@ -163,6 +163,7 @@ def main():
     run_case(refmods, "tiny_mh4", "tiny", B=2, T=16, U=5, multi_head=4, scale=0.3)
     run_case(refmods, "tiny_nomlp", "tiny", B=2, T=16, U=5, use_mlp=False, scale=0.3)
     run_case(refmods, "tiny_noact", "tiny", B=2, T=16, U=5, activate="None", scale=0.3)
+    main_act(refmods)
     # S / P short utterances: full outputs, gradient slices
     run_case(refmods, "S_short", "S", B=4, T=64, U=8, full=False)
     run_case(refmods, "S_short_sat", "S", B=4, T=64, U=8, scale=0.2, full=False, ragged=True)
@@ -172,6 +173,12 @@ def main():
     run_case(refmods, "S_T800", "S", B=2, T=800, U=12, full=False, with_grads=False, sub_t=10, sub_d=8)
     run_case(refmods, "P_T800", "P", B=2, T=800, U=12, full=False, with_grads=False, sub_t=5, sub_d=16)
     main_big(refmods)
+
+
+def main_act(refmods):
+    """mlp_activate_in_attention other than relu (the reference resolves any torch.nn.functional name, las_model.py:270-273)."""
+    run_case(refmods, "tiny_tanh", "tiny", B=2, T=16, U=5, activate="tanh", scale=0.3)
+    run_case(refmods, "tiny_sigmoid", "tiny", B=3, T=16, U=4, activate="sigmoid", scale=0.3, multi_head=2)
 
 
 def main_big(refmods):
@@ -265,6 +272,10 @@ def make_init_golden():
 
 if __name__ == "__main__" and len(sys.argv) > 1 and sys.argv[1] == "init":
     make_init_golden()
+
+if __name__ == "__main__" and len(sys.argv) > 1 and sys.argv[1] == "act":
+    torch.manual_seed(0)
+    main_act(import_reference())
 
 if __name__ == "__main__" and len(sys.argv) > 1 and sys.argv[1] == "extra":
     torch.set_num_threads(8)
