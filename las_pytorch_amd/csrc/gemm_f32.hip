@@ -21,12 +21,18 @@ namespace las {
 #ifndef LAS_GEMM_BK
 #define LAS_GEMM_BK 16
 #endif
+#ifndef LAS_GEMM_DMA
+#define LAS_GEMM_DMA 0      // 1: M/N-contiguous operands via global_load_lds (correct, measured 8-10 % SLOWER than register staging)
+#endif
 #ifndef LAS_GEMM_PF
 #define LAS_GEMM_PF 1
 #endif
 constexpr int BM = 128, BN = 128, BK = LAS_GEMM_BK, PAD = 4, GEMM_THREADS = 256, PF = LAS_GEMM_PF;
 constexpr int NLD = BM * BK / 4 / GEMM_THREADS;     // float4 loads per thread per operand tile
 constexpr int KQ = BK / 4;                           // float4 per K-contiguous row segment
+
+typedef __attribute__((address_space(3))) void* lds_ptr_t;
+static __device__ __forceinline__ lds_ptr_t to_lds(float* p) { return (lds_ptr_t)p; }     // generic -> LDS address space
 
 struct GemmParams {
     const float* A; const float* B; float* C; const float* bias0; const float* bias1;
@@ -167,20 +173,47 @@ __device__ __forceinline__ void gemm_segment(const GemmParams& p, float (*As)[BK
             offB[i] = B_KC ? (long)(n0 + idx / KQ) * p.ldb + (idx % KQ) * 4 : (long)(idx >> 5) * p.ldb + n0 + (idx & 31) * 4;
         }
         const long strideA = A_KC ? 1 : p.lda, strideB = B_KC ? 1 : p.ldb;
-        auto load_fast = [&](int k0, f32x4 (&ra_)[NLD], f32x4 (&rb_)[NLD]) {
+        // M/N-contiguous operands (every operand of a weight-gradient GEMM) go global -> LDS directly (global_load_lds_dwordx4:
+        // 1 KB per wave-instruction, destination = wave-uniform base + lane*16): a 128-float k-row is exactly what 32 lanes write,
+        // so the K-major tile image is lane-linear with row stride 128 (no staging VGPRs, no ds_write pass, nothing to wait for
+        // before the LDS stores).  K-contiguous operands keep the register-staged transposing store.
+        constexpr bool A_DMA = !A_KC && LAS_GEMM_DMA, B_DMA = !B_KC && LAS_GEMM_DMA;
+        constexpr int LDA_S = A_DMA ? BM : BM + PAD, LDB_S = B_DMA ? BN : BN + PAD;     // LDS row strides (floats)
+        auto load_fast = [&](int k0, int buf, f32x4 (&ra_)[NLD], f32x4 (&rb_)[NLD]) {
             const bool second = p.A2 != nullptr && k0 >= p.K1;          // wave-uniform
             const float* Ab = second ? p.A2 : A;
             const float* Bb = second ? p.B2 : B;
             const long kk = second ? k0 - p.K1 : k0;
+            const int wv = threadIdx.x >> 6;
 #pragma unroll
-            for (int i = 0; i < NLD; ++i) ra_[i] = *reinterpret_cast<const f32x4*>(Ab + offA[i] + kk * strideA);
+            for (int i = 0; i < NLD; ++i) {
+                if constexpr (A_DMA) {
+                    __builtin_amdgcn_global_load_lds(Ab + offA[i] + kk * strideA,
+                                                     to_lds(&As[buf][0][0] + (wv * 64 + i * GEMM_THREADS) * 4),
+                                                     16, 0, 0);
+                } else {
+                    ra_[i] = *reinterpret_cast<const f32x4*>(Ab + offA[i] + kk * strideA);
+                }
+            }
 #pragma unroll
-            for (int i = 0; i < NLD; ++i) rb_[i] = *reinterpret_cast<const f32x4*>(Bb + offB[i] + kk * strideB);
+            for (int i = 0; i < NLD; ++i) {
+                if constexpr (B_DMA) {
+                    __builtin_amdgcn_global_load_lds(Bb + offB[i] + kk * strideB,
+                                                     to_lds(&Bs[buf][0][0] + (wv * 64 + i * GEMM_THREADS) * 4),
+                                                     16, 0, 0);
+                } else {
+                    rb_[i] = *reinterpret_cast<const f32x4*>(Bb + offB[i] + kk * strideB);
+                }
+            }
+        };
+        auto stash = [&](int buf, const f32x4 (&ra_)[NLD], const f32x4 (&rb_)[NLD]) {
+            if constexpr (!A_DMA) store_tile<A_KC>(As[buf], ra_);
+            if constexpr (!B_DMA) store_tile<B_KC>(Bs[buf], rb_);
+            if constexpr (A_DMA || B_DMA) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // the DMA pieces of this wave have landed
         };
         f32x4 ra[NLD], rb[NLD];
-        load_fast(kbeg, ra, rb);
-        store_tile<A_KC>(As[0], ra);
-        store_tile<B_KC>(Bs[0], rb);
+        load_fast(kbeg, 0, ra, rb);
+        stash(0, ra, rb);
         __syncthreads();
         // Software pipeline across k-steps AND across the tile boundary, pinned with sched_barrier (left alone, hipcc sinks the
         // fragment reads of k-step kk+1 behind the MFMAs of kk and the matrix pipe idles for an LDS latency per k-step):
@@ -191,10 +224,12 @@ __device__ __forceinline__ void gemm_segment(const GemmParams& p, float (*As)[BK
         constexpr int NK = BK / 2;
         float a[2], b[2], an[2], bn[2];
         auto frag = [&](int buf, int kk, float (&fa)[2], float (&fb)[2]) {
+            const float* Ap = &As[buf][0][0] + (kk * 2 + lk) * LDA_S + wm + lr;
+            const float* Bp = &Bs[buf][0][0] + (kk * 2 + lk) * LDB_S + wn + lr;
 #pragma unroll
-            for (int i = 0; i < 2; ++i) fa[i] = As[buf][kk * 2 + lk][wm + i * 32 + lr];
+            for (int i = 0; i < 2; ++i) fa[i] = Ap[i * 32];
 #pragma unroll
-            for (int j = 0; j < 2; ++j) fb[j] = Bs[buf][kk * 2 + lk][wn + j * 32 + lr];
+            for (int j = 0; j < 2; ++j) fb[j] = Bp[j * 32];
         };
         auto mma = [&]() {
 #pragma unroll
@@ -207,9 +242,7 @@ __device__ __forceinline__ void gemm_segment(const GemmParams& p, float (*As)[BK
         for (int kt = 0; kt < ntiles; ++kt) {
             const int cur = kt & 1;
             const bool more = kt + 1 < ntiles;
-#if !defined(LAS_GEMM_EXP) || LAS_GEMM_EXP != 1
-            if (more) load_fast(kbeg + (kt + 1) * BK, ra, rb);
-#endif
+            if (more) load_fast(kbeg + (kt + 1) * BK, cur ^ 1, ra, rb);
 #pragma unroll
             for (int kk = 0; kk < NK - 1; ++kk) {
                 frag(cur, kk + 1, an, bn);
@@ -218,12 +251,7 @@ __device__ __forceinline__ void gemm_segment(const GemmParams& p, float (*As)[BK
                 __builtin_amdgcn_sched_barrier(0);
                 a[0] = an[0]; a[1] = an[1]; b[0] = bn[0]; b[1] = bn[1];
             }
-#if !defined(LAS_GEMM_EXP) || LAS_GEMM_EXP != 2
-            if (more) {
-                store_tile<A_KC>(As[cur ^ 1], ra);
-                store_tile<B_KC>(Bs[cur ^ 1], rb);
-            }
-#endif
+            if (more) stash(cur ^ 1, ra, rb);
             __syncthreads();
             if (more) frag(cur ^ 1, 0, an, bn);
             __builtin_amdgcn_sched_barrier(0);
