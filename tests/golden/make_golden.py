@@ -220,6 +220,34 @@ def make_mode2_golden(refmods):
         print(f"{name}: argmax path {logp.argmax(-1)[:, 0].tolist()}")
 
 
+def make_trajectory_golden(refmods):
+    """A short TRAINING RUN of the unmodified reference: 8 consecutive ``batch_iterator`` steps (teacher forcing, label
+    smoothing 0.1, clip 1.0, Adam) on fixed data, S config.  Stored: the loss and the per-utterance letter error rates of
+    every step and the parameters' checksums at the end — the drop-in must walk the same trajectory (BASELINE metric: LER parity)."""
+    LAS, Listener, Speller, batch_iterator, _ = refmods
+    c = synth.CONFIGS["S"]
+    sd_np = synth.make_state_dict(synth.config_shapes("S"), seed=51, scale=0.08)
+    B, T, U, steps, lr = 6, 64, 9, 8, 3e-3
+    x = torch.from_numpy(synth.make_inputs(B, T, c["F"], seed=51))
+    idx, lens = synth.make_labels(B, U, c["V"], seed=51, ragged=True)
+    labels = torch.from_numpy(synth.onehot_labels(idx, lens, c["V"]))
+    las = build_ref(LAS, Listener, Speller, c, sd_np, max_label_len=U)
+    opt = torch.optim.Adam(las.parameters(), lr=lr)
+    losses, lers = [], []
+    np.random.seed(0)
+    for _ in range(steps):
+        loss, ler = batch_iterator(x, labels, las, opt, tf_rate=1.0, is_training=True, max_label_len=U, label_smoothing=0.1, use_gpu=False)
+        losses.append(float(loss)); lers.append(ler)
+    # validation call after training (free-running greedy decode, NLL loss)
+    vloss, vler = batch_iterator(x, labels, las, opt, tf_rate=0.0, is_training=False, max_label_len=U, label_smoothing=0.1, use_gpu=False)
+    np.savez_compressed(os.path.join(HERE, "S_trajectory.npz"), dims=np.array([B, T, U, steps, 51]), lr=np.array([lr]), scale=np.array([0.08]),
+                        losses=np.array(losses), lers=np.array(lers, dtype=np.float64), val_loss=np.array([float(vloss)]),
+                        val_ler=np.array(vler, dtype=np.float64),
+                        param_sum=np.array([p.detach().double().sum().item() for p in las.parameters()]),
+                        param_abs=np.array([p.detach().double().abs().sum().item() for p in las.parameters()]))
+    print("S_trajectory: losses", [round(l, 5) for l in losses], "val", float(vloss), "ler", lers[-1])
+
+
 def make_collate_golden():
     """The reference's own ``collate_fn`` (utils/data.py:116-149) on a synthetic ragged batch.  ``utils/data.py`` imports
     torchaudio / enlighten / pydub at module top (unused by collate_fn): stubbed in sys.modules, nothing else is touched."""
@@ -273,6 +301,11 @@ def make_init_golden():
 if __name__ == "__main__" and len(sys.argv) > 1 and sys.argv[1] == "init":
     make_init_golden()
 
+if __name__ == "__main__" and len(sys.argv) > 1 and sys.argv[1] == "traj":
+    torch.manual_seed(0)
+    torch.set_num_threads(8)
+    make_trajectory_golden(import_reference())
+
 if __name__ == "__main__" and len(sys.argv) > 1 and sys.argv[1] == "act":
     torch.manual_seed(0)
     main_act(import_reference())
@@ -280,6 +313,7 @@ if __name__ == "__main__" and len(sys.argv) > 1 and sys.argv[1] == "act":
 if __name__ == "__main__" and len(sys.argv) > 1 and sys.argv[1] == "extra":
     torch.set_num_threads(8)
     make_mode2_golden(import_reference())
+    make_trajectory_golden(import_reference())
     make_collate_golden()
 
 if __name__ == "__main__" and len(sys.argv) > 1 and sys.argv[1] == "big":
@@ -292,6 +326,7 @@ if __name__ == "__main__" and len(sys.argv) == 1:
     main()
     make_init_golden()
     make_mode2_golden(import_reference())
+    make_trajectory_golden(import_reference())
     make_collate_golden()
 
 

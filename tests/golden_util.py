@@ -61,3 +61,15 @@ def collate_case_batch():
         rows = [np.eye(30)[j] for j in idx]
         batch.append((f"utt{i}", feat, int(t), rows, [len(r) for r in rows]))
     return g, batch
+
+
+def load_trajectory_case():
+    """tests/golden/S_trajectory.npz (make_golden.py::make_trajectory_golden): 8 reference training steps on fixed data."""
+    g = dict(np.load(os.path.join(GOLDEN_DIR, "S_trajectory.npz")))
+    B, T, U, steps, seed = [int(v) for v in g["dims"]]
+    c = synth.CONFIGS["S"]
+    sd = synth.make_state_dict(synth.config_shapes("S"), seed=seed, scale=float(g["scale"][0]))
+    x = synth.make_inputs(B, T, c["F"], seed=seed)
+    idx, lens = synth.make_labels(B, U, c["V"], seed=seed, ragged=True)
+    onehot = synth.onehot_labels(idx, lens, c["V"])
+    return g, c, sd, x, onehot, U, steps, float(g["lr"][0])

@@ -159,3 +159,36 @@ def test_device_error_word_is_reported_and_cleared():
     assert torch.isfinite(torch.stack(preds)).all()
     torch.cuda.synchronize()
     las_pytorch_amd.check_device_errors()
+
+
+def test_training_trajectory_matches_reference():
+    """LER parity over a training run: eight solver steps of the HIP modules (fused loss, direct gradient writes into the flat
+    buffer, clip, Adam) against the trajectory of the unmodified reference on the same data (tests/golden/S_trajectory.npz):
+    loss of every step, letter error rates of every step, the validation call after training, final parameter checksums."""
+    from golden_util import load_trajectory_case
+    from hip_util import record
+    from las_pytorch_amd import dp
+    from las_pytorch_amd.solver import solver as S
+    import las_pytorch_amd
+    g, c, sd_np, x, onehot, U, steps, lr = load_trajectory_case()
+    for use_reducer in (True, False):
+        las = build_las(c, sd_np, max_label_len=U)
+        if use_reducer:
+            dp.FlatGradAllReducer(las, direct=True)
+        opt = torch.optim.Adam(las.parameters(), lr=lr)
+        xg, lab = torch.from_numpy(x).cuda(), torch.from_numpy(onehot).cuda()
+        np.random.seed(0)
+        worst = 0.0
+        for s in range(steps):
+            loss, ler = S.batch_iterator(xg, lab, las, opt, tf_rate=1.0, is_training=True, max_label_len=U, label_smoothing=0.1)
+            worst = max(worst, abs(float(loss) - g["losses"][s]) / abs(g["losses"][s]))
+            assert abs(float(loss) - g["losses"][s]) < 1e-3 * abs(g["losses"][s]), (s, float(loss), g["losses"][s])
+            np.testing.assert_allclose(np.array(ler), g["lers"][s], rtol=1e-6)
+        vloss, vler = S.batch_iterator(xg, lab, las, opt, tf_rate=0.0, is_training=False, max_label_len=U, label_smoothing=0.1)
+        assert abs(float(vloss) - g["val_loss"][0]) < 1e-3 * abs(g["val_loss"][0])
+        np.testing.assert_allclose(np.array(vler), g["val_ler"], rtol=1e-6)
+        sums = np.array([p.detach().double().sum().item() for p in las.parameters()])
+        np.testing.assert_allclose(sums, g["param_sum"], rtol=1e-3, atol=1e-3 * float(np.abs(g["param_abs"]).max()) * 1e-3)
+        record(f"S_trajectory/reducer={use_reducer}", max_abs_err=worst, worst_ratio=worst / 1e-3)
+    torch.cuda.synchronize()
+    las_pytorch_amd.check_device_errors()
