@@ -173,17 +173,20 @@ class Listener(nn.Module):
         self.num_layers = num_layers
         self.rnn_unit = rnn_unit
         self.dropout_rate = dropout_rate
-        assert self.num_layers >= 1, "Listener should have at least 1 layer"
-        self.pLSTM_layer0 = pBLSTMLayer(input_feature_dim, hidden_size, rnn_unit=rnn_unit, dropout_rate=dropout_rate)
-        for i in range(1, self.num_layers):
-            setattr(self, "pLSTM_layer" + str(i),
-                    pBLSTMLayer(hidden_size * 2, hidden_size, rnn_unit=rnn_unit, dropout_rate=dropout_rate))
+        assert num_layers >= 1, "Listener should have at least 1 layer"
+        # attribute names pLSTM_layer{l} are the checkpoint keys (reference las_model.py:116-127)
+        for l in range(num_layers):
+            in_dim = input_feature_dim if l == 0 else 2 * hidden_size
+            self.add_module(f"pLSTM_layer{l}", pBLSTMLayer(in_dim, hidden_size, rnn_unit=rnn_unit, dropout_rate=dropout_rate))
+
+    def _layers(self):
+        return [getattr(self, f"pLSTM_layer{l}") for l in range(self.num_layers)]
 
     def forward(self, input_x):
-        output, _ = self.pLSTM_layer0(input_x)
-        for i in range(1, self.num_layers):
-            output, _ = getattr(self, "pLSTM_layer" + str(i))(output)
-        return output
+        feat = input_x
+        for layer in self._layers():
+            feat, _hidden = layer(feat)          # the final (h_n, c_n) is dropped, as in the reference (:130,132)
+        return feat
 
 
 # --------------------------------------------------------------------------------------------------
@@ -596,21 +599,13 @@ class LAS(nn.Module):
         return raw_pred_seq, attention_record
 
     def serialize(self, optimizer, epoch, tr_loss, val_loss):
-        package = {
-            "einput": self.listener.input_feature_dim,
-            "ehidden": self.listener.hidden_size,
-            "elayer": self.listener.num_layers,
-            "edropout": self.listener.dropout_rate,
-            "etype": self.listener.rnn_unit,
-            "dvocab_size": self.speller.label_dim,
-            "dhidden": self.speller.hidden_size,
-            "dlayer": self.speller.num_layers,
-            "etype": self.speller.rnn_unit,     # duplicate key kept: the reference's second assignment wins (:54)
-            "state_dict": self.state_dict(),
-            "optim_dict": optimizer.state_dict(),
-            "epoch": epoch,
-        }
+        enc, dec = self.listener, self.speller
+        package = dict(einput=enc.input_feature_dim, ehidden=enc.hidden_size, elayer=enc.num_layers, edropout=enc.dropout_rate,
+                       dvocab_size=dec.label_dim, dhidden=dec.hidden_size, dlayer=dec.num_layers,
+                       state_dict=self.state_dict(), optim_dict=optimizer.state_dict(), epoch=epoch)
+        # the reference's dict literal writes "etype" twice (listener's string, then the speller's class, :50,54): the
+        # second assignment wins, so a package carries the Speller's rnn_unit class under "etype"
+        package["etype"] = dec.rnn_unit
         if tr_loss is not None:
-            package["tr_loss"] = tr_loss
-            package["val_loss"] = val_loss
+            package.update(tr_loss=tr_loss, val_loss=val_loss)
         return package
