@@ -189,6 +189,7 @@ __global__ __launch_bounds__(UW * (H / 16)) void rec_fwd_fast(float* __restrict_
     for (int step = 0; step < T; ++step) {
         const int t = dir ? T - 1 - step : step;
         const unsigned epoch = (unsigned)step + 1u;
+        REC_STAMP(0, step, 0); REC_STAMP(512, step, 0);
         float nxt[4] = {0.f, 0.f, 0.f, 0.f};
         if (cell && step + 1 < T) {
             const int tn = dir ? t - 1 : t + 1;
@@ -211,7 +212,9 @@ __global__ __launch_bounds__(UW * (H / 16)) void rec_fwd_fast(float* __restrict_
             if (LPU > 16) acc[g] += __shfl_xor(acc[g], 16);
         }
         if (kc == 0) *reinterpret_cast<f32x4*>(&gsum[ul][0]) = f32x4{acc[0], acc[1], acc[2], acc[3]};
+        REC_STAMP(0, step, 1); REC_STAMP(512, step, 1);
         lds_barrier();
+        REC_STAMP(0, step, 2); REC_STAMP(512, step, 2);
 
         if (cell) {
             const f32x4 s4 = *reinterpret_cast<const f32x4*>(&gsum[tid][0]);
@@ -225,6 +228,7 @@ __global__ __launch_bounds__(UW * (H / 16)) void rec_fwd_fast(float* __restrict_
                 u64* gp64 = xg + (step & 1) * H + jc;
                 if (l2x) publish_granule_l2(gp64, epoch, h); else publish_granule(gp64, epoch, h);
             }
+            REC_STAMP(0, step, 5);
             const float hp = hs[cur][jc];
             hs[cur ^ 1][jc] = h;
             out[((long)b * T + t) * 2 * H + dir * H + jc] = h;
@@ -242,7 +246,9 @@ __global__ __launch_bounds__(UW * (H / 16)) void rec_fwd_fast(float* __restrict_
                 hs[cur ^ 1][fu] = poll_granule(xg + (step & 1) * H + fu, epoch, err);
             }
         }
+        REC_STAMP(0, step, 3); REC_STAMP(512, step, 3);
         lds_barrier();
+        REC_STAMP(0, step, 4); REC_STAMP(512, step, 4);
         cur ^= 1;
     }
 }

@@ -22,4 +22,6 @@ for it in range(3):
 L.las_debug_rec_trace(None)
 t = trace.cpu().numpy().reshape(2, 4096, 8)[:, 5:T - 5].astype(np.float64) / 100.0
 for name, a in (("thread 0 (cell wave)", t[0]), ("thread 512 (poller)", t[1])):
+    if name.startswith("thread 0") and a[:, 5].any():
+        print(f"B={B} cell wave: barrier release -> h published {(a[:,5]-a[:,2]).mean():.3f} us")
     print(f"B={B} {name}: period {np.diff(a[:, 0]).mean():.3f} us | matvec {(a[:,1]-a[:,0]).mean():.3f} | barrier {(a[:,2]-a[:,1]).mean():.3f} | cell/poll {(a[:,3]-a[:,2]).mean():.3f} | barrier {(a[:,4]-a[:,3]).mean():.3f}")
