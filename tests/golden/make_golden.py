@@ -172,6 +172,7 @@ def main():
     # S / P LibriSpeech-shaped T=800: subsampled listener output, full log-probs
     run_case(refmods, "S_T800", "S", B=2, T=800, U=12, full=False, with_grads=False, sub_t=10, sub_d=8)
     run_case(refmods, "P_T800", "P", B=2, T=800, U=12, full=False, with_grads=False, sub_t=5, sub_d=16)
+    main_more(refmods)
     main_big(refmods)
 
 
@@ -179,6 +180,14 @@ def main_act(refmods):
     """mlp_activate_in_attention other than relu (the reference resolves any torch.nn.functional name, las_model.py:270-273)."""
     run_case(refmods, "tiny_tanh", "tiny", B=2, T=16, U=5, activate="tanh", scale=0.3)
     run_case(refmods, "tiny_sigmoid", "tiny", B=3, T=16, U=4, activate="sigmoid", scale=0.3, multi_head=2)
+
+
+def main_more(refmods):
+    """The reference's shipped YAML sizes (Listener 512x3 / Speller 1024x2: 16 workgroups per sequence, per-step decode path) and a
+    batch beyond one utterance per resident group at H=256 (B=40: the multi-utterance recurrence kernels), short utterances."""
+    run_case(refmods, "Y_short", "Y", B=3, T=64, U=6, scale=0.08, full=False, light=True, sub_d=8)
+    # seed chosen for a top-1 / top-2 log-prob margin well above fp32 noise (seed 17 gives 2.6e-6: a coin flip for any fp32 path)
+    run_case(refmods, "P_B40_T64_U6", "P", B=40, T=64, U=6, full=False, light=True, ragged=True, sub_t=2, sub_d=8, seed=29, scale=0.1)
 
 
 def main_big(refmods):
@@ -300,6 +309,11 @@ def make_init_golden():
 
 if __name__ == "__main__" and len(sys.argv) > 1 and sys.argv[1] == "init":
     make_init_golden()
+
+if __name__ == "__main__" and len(sys.argv) > 1 and sys.argv[1] == "more":
+    torch.manual_seed(0)
+    torch.set_num_threads(8)
+    main_more(import_reference())
 
 if __name__ == "__main__" and len(sys.argv) > 1 and sys.argv[1] == "traj":
     torch.manual_seed(0)

@@ -9,7 +9,7 @@ GOLDEN_DIR = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 ALL_CASES = ["tiny_default", "tiny_sat", "tiny_mh4", "tiny_nomlp", "tiny_noact", "tiny_tanh", "tiny_sigmoid",
              "S_short", "S_short_sat", "P_short", "P_short_sat", "S_T800", "P_T800"]
 # headline-size cases (BASELINE.json configs[1], [2], [4]); "light" fixtures: no decode_mode-0 run, no NLL loss
-BIG_CASES = ["P_B32_T800_U32", "P_B16_T1600_U8", "P_B8_T3000_U16", "S_B32_T800_U32", "S_B8_T3000_U8"]
+BIG_CASES = ["Y_short", "P_B40_T64_U6", "P_B32_T800_U32", "P_B16_T1600_U8", "P_B8_T3000_U16", "S_B32_T800_U32", "S_B8_T3000_U8"]
 
 
 def load_case(name):
