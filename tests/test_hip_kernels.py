@@ -173,3 +173,85 @@ def test_multi_utterance_recurrence_vs_oracle():
         grad_close(p.grad.cpu().numpy(), sd["listener." + k].grad.numpy(), f"multi_oracle/grad/{k}", global_scale=gs)
     torch.cuda.synchronize()
     las_pytorch_amd.check_device_errors()
+
+
+def _group_call(probs, layout, zeroed=True, accumulate=False):
+    """probs: list of (M, N, K).  Returns (results, references) through las_gemm_f32_group."""
+    import ctypes
+    from las_pytorch_amd import _cabi
+    L = _cabi.lib()
+    a_kc, b_kc = layout
+    g = torch.Generator().manual_seed(sum(m * 3 + n * 5 + k for m, n, k in probs))
+    descs = (_cabi.GemmDescC * len(probs))()
+    keep, want, outs = [], [], []
+    for i, (M, N, K) in enumerate(probs):
+        A = torch.rand(M, K, generator=g) - 0.4
+        Bm = torch.rand(K, N, generator=g) - 0.7
+        C0 = torch.rand(M, N, generator=g) if accumulate else torch.zeros(M, N)
+        want.append((C0.double() + A.double() @ Bm.double()).numpy())
+        Ad = (A if a_kc else A.t()).contiguous().cuda()
+        Bd = (Bm.t() if b_kc else Bm).contiguous().cuda()
+        C = (C0.clone() if (accumulate or zeroed) else torch.full((M, N), float("nan"))).cuda()
+        keep += [Ad, Bd]
+        outs.append(C)
+        d = descs[i]
+        d.A, d.B, d.C, d.A2, d.B2 = Ad.data_ptr(), Bd.data_ptr(), C.data_ptr(), None, None
+        d.M, d.N, d.K, d.K1 = M, N, K, 0
+        d.lda, d.ldb, d.ldc = (K if a_kc else M), (K if b_kc else N), N
+        d.a_kc, d.b_kc, d.accumulate, d.c_zeroed = int(a_kc), int(b_kc), int(accumulate), int(zeroed and not accumulate)
+    _cabi.check(L.las_gemm_f32_group(descs, len(probs), _cabi.stream_ptr()))
+    torch.cuda.synchronize()
+    return [c.cpu().numpy() for c in outs], want
+
+
+@pytest.mark.parametrize("layout", [(False, False), (True, False), (True, True), (False, True)])
+@pytest.mark.parametrize("probs", [
+    [(1024, 160, 3200), (1024, 256, 3200), (1024, 160, 3200), (1024, 256, 3200)],          # a Listener layer's dW group
+    [(30, 512, 4096), (30, 512, 4096), (64, 512, 4096), (2048, 30, 4096), (2048, 512, 1024), (2048, 512, 1008)],
+    [(130, 70, 100), (5, 3, 17), (257, 129, 33)],                                            # edge tiles, odd K (guarded loader)
+    [(128, 128, 16)],                                                                        # one tile, one k-iteration
+    [(256, 256, 4096), (128, 128, 16), (384, 128, 2048), (128, 640, 512), (64, 64, 64), (1000, 200, 300), (8, 8, 8), (512, 512, 512)],
+])
+def test_gemm_group_stream_k(layout, probs):
+    """las_gemm_f32_group: several GEMMs of one layout in one launch, k-iterations of all problems laid end to end and cut into
+    equal runs (partial tiles combined with atomics, whole tiles stored) against fp64, pre-zeroed and accumulating outputs."""
+    for accumulate in (False, True):
+        got, want = _group_call(probs, layout, zeroed=True, accumulate=accumulate)
+        for i, (gi, wi) in enumerate(zip(got, want)):
+            K = probs[i][2]
+            assert_close(gi, wi, f"group gemm problem {i} {probs[i]} layout {layout} acc {accumulate}", rtol=1e-4, atol=2e-4 * np.sqrt(K))
+
+
+def test_gemm_group_falls_back_when_not_groupable():
+    """Outputs that are neither pre-zeroed nor accumulated onto cannot share the atomic-combining launch: one launch per problem
+    (which zeroes what it needs itself); the results are the same."""
+    probs = [(300, 200, 1000), (128, 128, 2048)]
+    got, want = _group_call(probs, (False, False), zeroed=False, accumulate=False)
+    for gi, wi, p in zip(got, want, probs):
+        assert_close(gi, wi, f"ungrouped {p}", rtol=1e-4, atol=2e-4 * np.sqrt(p[2]))
+
+
+@pytest.mark.parametrize("a_kc,b_kc", [(True, False), (True, True)])
+@pytest.mark.parametrize("M,N,K1", [(6400, 160, 1024), (300, 30, 512), (4096, 30, 512)])
+def test_gemm_dual_k_source(a_kc, b_kc, M, N, K1):
+    """C = [A | A2] [B ; B2] in one pass (dX of both directions, [h | ctx] logits) against fp64."""
+    from las_pytorch_amd import _cabi
+    L = _cabi.lib()
+    g = torch.Generator().manual_seed(M + N + K1)
+    A, A2 = torch.rand(M, K1, generator=g) - 0.5, torch.rand(M, K1, generator=g) - 0.5
+    B, B2 = torch.rand(K1, N, generator=g) - 0.5, torch.rand(K1, N, generator=g) - 0.5
+    want = (A.double() @ B.double() + A2.double() @ B2.double()).numpy()
+    dev = lambda t, kc: (t if kc else t.t()).contiguous().cuda()
+    Ad, A2d = dev(A, a_kc), dev(A2, a_kc)
+    Bd, B2d = dev(B.t(), b_kc) if b_kc else B.contiguous().cuda(), dev(B2.t(), b_kc) if b_kc else B2.contiguous().cuda()
+    if b_kc:
+        Bd, B2d = B.t().contiguous().cuda(), B2.t().contiguous().cuda()
+    C = torch.full((M, N), float("nan"), device="cuda")
+    d = (_cabi.GemmDescC * 1)()
+    d[0].A, d[0].B, d[0].C, d[0].A2, d[0].B2 = Ad.data_ptr(), Bd.data_ptr(), C.data_ptr(), A2d.data_ptr(), B2d.data_ptr()
+    d[0].M, d[0].N, d[0].K, d[0].K1 = M, N, 2 * K1, K1
+    d[0].lda, d[0].ldb, d[0].ldc = (K1 if a_kc else M), (K1 if b_kc else N), N
+    d[0].a_kc, d[0].b_kc, d[0].accumulate, d[0].c_zeroed = int(a_kc), int(b_kc), 0, 0
+    _cabi.check(L.las_gemm_f32_group(d, 1, _cabi.stream_ptr()))
+    torch.cuda.synchronize()
+    assert_close(C.cpu().numpy(), want, f"dual-K gemm {M}x{N}x2*{K1}", rtol=1e-4, atol=2e-4 * np.sqrt(2 * K1))

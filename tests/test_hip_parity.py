@@ -350,15 +350,16 @@ def _persistent_vs_stepwise(cfg_name, B, Tp, U, scale, activate):
     _check_err()
 
 
-def test_direct_gradient_write_matches_autograd_accumulation():
+@pytest.mark.parametrize("cfg_name,B", [("S", 4), ("P", 5), ("P", 40)])
+def test_direct_gradient_write_matches_autograd_accumulation(cfg_name, B):
     """FlatGradAllReducer(direct=True): the backward kernels fill the flat gradient buffer themselves; the result must
     equal what autograd's per-parameter accumulation produces, also on a second step after zero()."""
     from las_pytorch_amd import dp, synth
     from las_pytorch_amd.model import las_model
-    c = synth.CONFIGS["S"]
-    sd_np = synth.make_state_dict(synth.config_shapes("S"), seed=4)
-    x = torch.from_numpy(synth.make_inputs(4, 64, c["F"], seed=4)).cuda()
-    idx, lens = synth.make_labels(4, 6, c["V"], seed=4)
+    c = synth.CONFIGS[cfg_name]
+    sd_np = synth.make_state_dict(synth.config_shapes(cfg_name), seed=4)
+    x = torch.from_numpy(synth.make_inputs(B, 64, c["F"], seed=4)).cuda()
+    idx, lens = synth.make_labels(B, 6, c["V"], seed=4)
     lab = torch.from_numpy(synth.onehot_labels(idx, lens, c["V"])).cuda()
     flats = []
     other = build_las(c, sd_np, max_label_len=6)       # a second model in the process: never tagged, must keep accumulating
