@@ -38,7 +38,8 @@ struct PblstmBwdLayout {
 };
 
 struct SpellerLayout {
-    size_t y_all, ctx_all, h_all, c_all, gates_all, q_all, w0p, ctxcat_all, hx, lgx, total;
+    size_t y_all, ctx_all, h_all, c_all, gates_all, q_all, w0p, ctxcat_all, hx, lgx, wperm, pctx, gx, total;
+    bool pre;                  // room for the persistent decode kernel's pre-multiplied context variant
     int Vp;                    // label width padded to a multiple of 16: every cell operand is aligned and tail-free
     SpellerLayout(const las_speller_desc* d, int U) {
         size_t o = 0;
@@ -54,6 +55,11 @@ struct SpellerLayout {
         w0p = o; o += r4((size_t)4 * d->Hs * (Vp + d->Hs));      // W_ih0 re-laid as [W_y | 0 | W_ctx], ld = Vp + Hs
         hx = o; if (d->L == 2) o += r4((size_t)2 * U * 32 * d->Hs);   // hand-off copy of h for the persistent decode kernel
         lgx = o; if (d->L == 2) o += r4((size_t)U * B * 8 * 32);      // ... and its partial logits (free-running decode)
+        // pre-multiplied context variant: row-permuted W_ctx, feat . W_ctx^T, and the per-step hand-off slabs of its weighted sums
+        pre = speller_persist_pre_shape(d->B, d->Tp, d->Hs, d->D, d->M, d->V, d->L, d->multi_head, d->use_mlp);
+        wperm = o; if (pre) o += r4((size_t)4 * d->Hs * d->Hs);
+        pctx = o; if (pre) o += r4((size_t)B * d->Tp * 4 * d->Hs);
+        gx = o; if (pre) o += r4((size_t)U * B * 4 * d->Hs);
         total = o;
     }
 };
@@ -373,15 +379,28 @@ int las_speller_fwd(const las_speller_desc* d, const float* feat, const float* k
     LAS_TRY(copy2d(feat, (long)Tp * D, ctx_all, D, B, D, 0, stream));     // ctx_{-1} = feat[:,0,:] (las_model.py:198)
     // 16-byte aligned, tail-free shadow of W_ih0: columns [0,V) = label part, [V,Vp) = 0, [Vp,Vp+Hs) = context part (rebuilt
     // every call: in training the parameters change every step, so there is nothing to cache across calls)
-    LAS_TRY(build_w0p(d->w_ih[0], w0p, Hs, V, Vp, stream));
-
     static const bool persist_on = !(getenv("LAS_SPELLER_PERSIST") && atoi(getenv("LAS_SPELLER_PERSIST")) == 0);
     const bool persist = persist_on && err_word && !(flags & LAS_FLAG_FORCE_GENERIC) && (teacher_forced || decode_mode != 2) &&
                          d->relu <= LAS_ACT_RELU &&        // the persistent kernels implement relu / no activation
                          speller_persist_eligible(B, Tp, Hs, D, d->M, V, L, d->multi_head, d->use_mlp, !teacher_forced);
+    // the pre-multiplied context variant of the persistent kernel (teacher forcing): P = feat . W_ctx^T in the cell
+    // workgroups' column order; the kernel then publishes sum_t a_t P_t instead of the context, which one batched GEMM
+    // recovers afterwards (the backward pass and the character distribution need it)
+    const bool pre = persist && teacher_forced && lay.pre &&
+                     speller_persist_pre_eligible(B, Tp, Hs, D, d->M, V, L, d->multi_head, d->use_mlp);
+    LAS_TRY(build_w0p(d->w_ih[0], w0p, Hs, V, Vp, stream, pre ? reserve + lay.wperm : nullptr));
     bool persist_ran = persist;
+    bool pre_ran = false;
     if (persist) {
         PersistFwd p;
+        if (pre) {
+            GemmDesc g;
+            g.A = feat; g.lda = D; g.a_kc = true;
+            g.B = reserve + lay.wperm; g.ldb = Hs; g.b_kc = true;
+            g.C = reserve + lay.pctx; g.ldc = 4 * Hs; g.M = B * Tp; g.N = 4 * Hs; g.K = D; g.splitk = 1;
+            LAS_TRY(gemm_f32(g, stream));
+            p.pctx = reserve + lay.pctx; p.gx = reserve + lay.gx;
+        }
         p.w0p = w0p; p.Vp = Vp;
         p.w_hh0 = d->w_hh[0]; p.w_ih1 = d->w_ih[1]; p.w_hh1 = d->w_hh[1];
         p.b_ih0 = d->b_ih[0]; p.b_hh0 = d->b_hh[0]; p.b_ih1 = d->b_ih[1]; p.b_hh1 = d->b_hh[1];
@@ -398,6 +417,15 @@ int las_speller_fwd(const las_speller_desc* d, const float* feat, const float* k
         const int rc = speller_persist_fwd(p, stream);
         if (rc == LAS_ERR_UNSUPPORTED) persist_ran = false;      // residency check failed: the per-step kernels below run instead
         else LAS_TRY(rc);
+        pre_ran = persist_ran && pre;
+    }
+    if (pre_ran) {   // contexts of every step: ctx_all[1+s][b] = att[s][b] . feat[b], one batched GEMM over the utterances
+        GemmDesc g;
+        g.A = att; g.lda = (long)B * Tp; g.a_kc = true; g.sA = Tp;
+        g.B = feat; g.ldb = D; g.b_kc = false; g.sB = (long)Tp * D;
+        g.C = ctx_all + (size_t)B * D; g.ldc = (long)B * D; g.sC = D;
+        g.M = U; g.N = D; g.K = Tp; g.batch = B; g.splitk = 1;
+        LAS_TRY(gemm_f32(g, stream));
     }
     for (int s = 0; s < (persist_ran ? 0 : U); ++s) {
         for (int l = 0; l < L; ++l) {

@@ -124,10 +124,16 @@ struct PersistFwd {
     const float* w_c = nullptr; const float* b_c = nullptr;
     float* logp = nullptr; int* argmax = nullptr;   // free-running outputs (U,B,V), (U,B)
     float* lgx = nullptr;                           // U*B*8*32 floats: partial logits of the attention workgroups
+    // "pre-multiplied context" variant (teacher forcing only; speller_persist_pre_eligible): pctx = feat . W_ctx^T in the
+    // cell workgroups' column order (B*Tp, 4Hs), gx = U*B*4Hs floats of hand-off slabs.  The kernel then leaves
+    // ctx_all[1..U] to the caller (one batched GEMM att . feat after the launch).
+    const float* pctx = nullptr; float* gx = nullptr;
     int B, Tp, U, Hs, V, relu;
     unsigned* err;
 };
 bool speller_persist_eligible(int B, int Tp, int Hs, int D, int M, int V, int L, int heads, int use_mlp, int free_running);
+bool speller_persist_pre_shape(int B, int Tp, int Hs, int D, int M, int V, int L, int heads, int use_mlp);   // shape only (sizes the reserve)
+bool speller_persist_pre_eligible(int B, int Tp, int Hs, int D, int M, int V, int L, int heads, int use_mlp);   // shape + residency
 int speller_persist_fwd(const PersistFwd& p, hipStream_t stream);
 void speller_persist_set_trace(unsigned long long* dev_buf);   // profiling aid, see tools/ubench_persist_trace.py
 
@@ -191,7 +197,7 @@ int ls_loss(const float* logp, long sU, long sB, const long long* labels, int U,
             float* loss, float* dlogp, long dU, long dB, hipStream_t stream);
 int ler(const float* logp, long sU, long sB, const long long* labels, int U, int U_lab, int B, int V, float* out, int* work,
         hipStream_t stream);
-int build_w0p(const float* w_ih0, float* w0p, int Hs, int V, int Vp, hipStream_t stream);
+int build_w0p(const float* w_ih0, float* w0p, int Hs, int V, int Vp, hipStream_t stream, float* wperm = nullptr);
 int labels_to_y(const long long* labels, float* y_all, int B, int U, int V, int Vp, int u_lab, hipStream_t stream);
 int collate_pad(const float* packed, const long long* foff, const long long* plab, const long long* loff, int B, int T, int F, int U,
                 int V, float* inputs, long long* targets, hipStream_t stream);

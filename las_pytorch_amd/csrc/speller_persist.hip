@@ -45,6 +45,7 @@ struct PersistArgs {
     const float* w_c; const float* b_c;   // (V, 2Hs), (V)
     float* logp; int* argmax_out;          // (U,B,V), (U,B) or null
     float* lgx;                            // [U][B][split][32] partial logits of the attention workgroups, sentinel-prefilled
+    const float* pctx; float* gx;          // PRE variant: feat . W_ctx^T (B*Tp, 4Hs) and its per-step weighted sums [U][B][4Hs] (sentinel-prefilled)
     int B, Tp, U, relu;
     int split;                     // attention workgroups per utterance (each owns D/split context columns)
     unsigned* err;
@@ -54,7 +55,11 @@ struct PersistArgs {
 #define PS_STAMP(role, s, k) do { if (a.trace && first_wg && threadIdx.x == 0) a.trace[((size_t)(role) * a.U + (s)) * 8 + (k)] = wall_clock64(); } while (0)
 
 // ------------------------------------------------------------------------------------------------ cell workgroups
-template <int HS, bool GREEDY>
+// PRE ("pre-multiplied context", teacher forcing only): layer 0's context half W_ctx . ctx_{s-1} arrives already multiplied —
+// the attention workgroups publish sum_t a_t (W_ctx feat_t) from a register-resident slice of feat . W_ctx^T — so layer 0 is
+// off the MFMA chain: its recurrent / label halves are reduced ahead of time and the cell lanes only add 16 bytes per
+// (utterance, unit) that they poll themselves.
+template <int HS, bool GREEDY, bool PRE = false>
 struct CellRole {
     static constexpr int NF = HS / 256;                 // 16-wide k-blocks of an Hs-wide operand per wave
     static constexpr int RLD = 20;                      // row stride of a partial tile: 16 columns + pad, 16-byte aligned
@@ -295,8 +300,8 @@ struct CellRole {
                 y[0][mt] = ok ? v : z;
             }
         };
-        // gates of one layer: reduce the 16 waves' partial tiles, apply the cell, publish h, stash c / gates
-        auto finish = [&](const f32x4 (&acc)[2], float& c, int layer, int s) {
+        // gates of one layer: reduce the 16 waves' partial tiles (-> the cell lanes' registers) ...
+        auto reduce_gates = [&](const f32x4 (&acc)[2], int layer, int s) -> f32x4 {
             // one buffer per layer: the single barrier below then also separates this buffer's readers from its next writers
             float (*red)[2][16][RLD] = reinterpret_cast<float (*)[2][16][RLD]>(smem + layer * RED);
 #pragma unroll
@@ -304,9 +309,9 @@ struct CellRole {
 #pragma unroll
                 for (int i = 0; i < 4; ++i) red[wave][mt][kq * 4 + i][rcol] = acc[mt][i];
             lds_barrier();
-            if (layer == 1) PS_STAMP(1, s, 6); else PS_STAMP(1, s, 7);       // (cell wg 0) all 16 waves' products are in
+            if (layer == 1) PS_STAMP(1, s, 6); else if (!PRE) PS_STAMP(1, s, 7);       // (cell wg 0) all 16 waves' products are in
+            f32x4 g4 = {0.f, 0.f, 0.f, 0.f};
             if (pw) {
-                f32x4 g4 = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
                 for (int w = 0; w < PS_NW; ++w) {
                     const f32x4 v = *reinterpret_cast<const f32x4*>(&red[w][pmt][pm][pu * 4]);
@@ -314,6 +319,12 @@ struct CellRole {
                 }
 #pragma unroll
                 for (int g = 0; g < 4; ++g) g4[g] += bias[(layer * 4 + g) * 128 + tid];
+            }
+            return g4;
+        };
+        // ... apply the cell, publish h, stash c / gates
+        auto cell = [&](f32x4 g4, float& c, int layer, int s) {
+            if (pw) {
                 if (GREEDY && layer == 0) {
                     // free-running: the label half of the gates comes from what the previous step produced
                     if (mode == 1) {
@@ -340,6 +351,7 @@ struct CellRole {
                 go[0] = ig; go[HS] = fg; go[2 * HS] = gg; go[3 * HS] = og;
             }
         };
+        auto finish = [&](const f32x4 (&acc)[2], float& c, int layer, int s) { cell(reduce_gates(acc, layer, s), c, layer, s); };
 
         // ---- prologue: label half of step 0's layer-0 gates
         f32x4 accR0[2], accR1[2];
@@ -357,6 +369,54 @@ struct CellRole {
         if (tid < 4) cflags[tid] = 0u;
         lds_barrier();
         int nslow[3] = {0, 0, 0};       // slow-path rounds per tile kind (reported through the trace buffer)
+        if (PRE) {
+            // layer 0's gates minus the context half, reduced ahead of the chain (cell lanes' registers)
+            f32x4 g0 = reduce_gates(accR0, 0, 0);
+            const unsigned gcol = 4u * (unsigned)(blockIdx.x * 16 + pu * 4);          // byte offset of this lane's four gates in a 4Hs row
+            for (int s = 0; s < U; ++s) {
+                f32x4 ynext[1][2];
+                if (s + 1 < U) load_y(s + 1, ynext);
+                PS_STAMP(0, s, 0);
+                // layer 0: + sum_t a_t (W_ctx feat_t) of step s-1 (step 0: the first frame, las_model.py:198), polled by the cell lanes
+                if (wave < 2) {
+                    f32x4 v;
+                    if (s == 0) {
+                        v = ld4p(at_bytes(a.pctx, opaque(4u * (unsigned)((pw ? pb : 0) * a.Tp) * (4 * HS) + gcol)));
+                    } else {
+                        const float* src = at_bytes(a.gx + (size_t)(s - 1) * B * (4 * HS), opaque(4u * (unsigned)(pw ? pb : 0) * (4 * HS) + gcol));
+                        unsigned spins = 0;
+                        for (;;) {
+                            v = ld4_agent(src);
+                            if (!__any(pw && has_sentinel(v))) break;
+                            if (spin_expired(spins, a.err, 0xDEAD0015u)) break;
+                        }
+                    }
+                    g0[0] += v[0]; g0[1] += v[1]; g0[2] += v[2]; g0[3] += v[3];
+                }
+                PS_STAMP(0, s, 1);
+                cell(g0, c0, 0, s);
+                PS_STAMP(0, s, 2);
+                // layer 1: gates = W_ih1 h0_s + W_hh1 h1_{s-1}
+                nslow[0] += poll_mul<0>(a.hx + (size_t)s * HXS, ta, x, Wi1, accR1, a.err, cflags, cep);
+                PS_STAMP(0, s, 4);
+                finish(accR1, c1, 1, s);
+                PS_STAMP(0, s, 5);
+                if (s + 1 == U) break;
+                // off the chain: next step's layer-0 gates without the context half ...
+                accR0[0] = accR0[1] = zero;
+                mfma_tile(x, Wh0, accR0);                              // the h0_s tile is still in registers
+                if (ywave) CellRole<256, GREEDY>::mfma_tile(ynext, Wy, accR0);
+                g0 = reduce_gates(accR0, 0, s);
+                PS_STAMP(0, s, 6);
+                // ... and layer 1's recurrent half
+                accR1[0] = accR1[1] = zero;
+                nslow[2] += poll_mul<0>(a.hx + ((size_t)U + s) * HXS, ta, x, Wh1, accR1, a.err, cflags, cep);
+                PS_STAMP(0, s, 7);
+            }
+            if (a.trace && first_wg && tid == 0)
+                for (int k = 0; k < 3; ++k) a.trace[((size_t)a.U + k) * 8 + 7] = (unsigned long long)nslow[k];
+            return;
+        }
         for (int s = 0; s < U; ++s) {
             // next step's labels: issued now, consumed after layer 1 (plain load, its latency is off the chain)
             f32x4 ynext[1][2];
@@ -580,6 +640,147 @@ struct AttnRole {
     }
 };
 
+
+// ------------------------------------------------------------------------------------------------ attention workgroups, PRE variant
+// Four workgroups per utterance, each owning 4Hs/4 of the layer-0 gate columns: its slice of P = feat . W_ctx^T (T' x Hs
+// floats, register-resident: lane = (column group, time slice)) is contracted with the step's attention weights and published
+// as whole 128-byte lines.  Query, energies and softmax are computed redundantly by the four (as the two of AttnRole do);
+// the context itself is not needed on the chain any more and is left to one batched GEMM after the launch.
+template <int HS>
+struct AttnPreRole {
+    static constexpr int SPLIT = 4;
+    static constexpr int GC = 4 * HS / SPLIT;            // gate columns of this workgroup
+    static constexpr int CG = GC / 4;                    // column groups (one float4 each)
+    static constexpr int TS = PS_THREADS / CG;           // time slices: 8 (Hs=512) or 16 (Hs=256) adjacent lanes
+    static constexpr int MAX_TP = 112;
+    static constexpr int NIP = MAX_TP / TS;              // frames per lane
+    static constexpr int EP = 128;                       // energies padded to whole waves (pad = -inf)
+    static constexpr int NJ = HS / 64;
+    static_assert(MAX_TP % TS == 0 && TS <= 16, "time-slice layout");
+    static __host__ __device__ constexpr int lds_floats(int Tp) { return HS + PS_M + EP + MAX_TP + Tp * PS_KLD; }
+
+    static __device__ void run(const PersistArgs& a, float* smem, const int widx) {
+        const int b = widx / SPLIT, part_id = widx % SPLIT;
+        const int col0 = part_id * GC;
+        const bool first_wg = widx == 0;
+        const int tid = threadIdx.x, lane = tid & 63;
+        const int B = a.B, U = a.U, Tp = a.Tp;
+        float* hs = smem;
+        float* qs = hs + HS;
+        float* es = qs + PS_M;
+        float* as = es + EP;
+        float* ks = as + MAX_TP;
+
+        // ---- resident operands
+        const int ts = tid % TS, cg = tid / TS;
+        f32x4 pr[NIP];
+        const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int i = 0; i < NIP; ++i) {
+            const int t = ts + TS * i;
+            const f32x4 v = ld4p(a.pctx + ((size_t)b * Tp + (t < Tp ? t : 0)) * (4 * HS) + col0 + cg * 4);
+            pr[i] = t < Tp ? v : zero;
+        }
+        if (tid >= Tp && tid < MAX_TP) as[tid] = 0.f;         // frames past T' carry zero weight
+        if (tid >= Tp && tid < EP) es[tid] = -INFINITY;
+        for (int idx = tid; idx < Tp * (PS_M / 4); idx += PS_THREADS) {
+            const int t = idx / (PS_M / 4), m4 = idx % (PS_M / 4);
+            *reinterpret_cast<f32x4*>(ks + t * PS_KLD + m4 * 4) = ld4p(a.keys + ((size_t)b * Tp + t) * PS_M + m4 * 4);
+        }
+        const int prow = tid >> 4, pk = tid & 15;         // phi: 64 rows x 16 lanes
+        f32x4 wphi[NJ];
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) wphi[j] = ld4p(a.w_phi + (size_t)prow * HS + 4 * (pk + 16 * j));
+        const float bphi = a.b_phi[prow];
+        lds_barrier();
+
+        for (int s = 0; s < U; ++s) {
+            PS_STAMP(1, s, 0);
+            // ---- decoder state of this utterance (published by the cell workgroups)
+            if (tid < HS / 4) {
+                const float* p = a.hx + ((size_t)U + s) * ((size_t)32 * HS) + ((size_t)tid * 32 + b) * 4;
+                unsigned spins = 0;
+                f32x4 v;
+                for (;;) {
+                    v = ld4_agent(p);
+                    if (!__any(has_sentinel(v))) break;
+                    if (spin_expired(spins, a.err, 0xDEAD0013u)) break;
+                }
+                *reinterpret_cast<f32x4*>(hs + tid * 4) = v;
+            }
+            PS_STAMP(1, s, 1);
+            lds_barrier();
+            // ---- query q = act(W_phi h + b_phi)
+            {
+                float acc = 0.f;
+#pragma unroll
+                for (int j = 0; j < NJ; ++j) acc = dot4p(wphi[j], *reinterpret_cast<const f32x4*>(hs + 4 * (pk + 16 * j)), acc);
+                acc = gsum<16>(acc);
+                if (pk == 0) {
+                    acc += bphi;
+                    if (a.relu) acc = fmaxf(acc, 0.f);
+                    qs[prow] = acc;
+                    if (part_id == 0) a.q_all[((size_t)s * B + b) * PS_M + prow] = acc;
+                }
+            }
+            lds_barrier();
+            PS_STAMP(1, s, 2);
+            // ---- energies e[t] = q . keys[t]: 8 lanes per frame (T' <= 112 <= 1024 / 8: one frame per lane group)
+            {
+                const int sub = tid & 7, t = tid >> 3;
+                if (t < Tp) {
+                    const f32x4 q0 = *reinterpret_cast<const f32x4*>(qs + sub * 8), q1 = *reinterpret_cast<const f32x4*>(qs + sub * 8 + 4);
+                    const float* kr = ks + t * PS_KLD + sub * 8;
+                    float acc = dot4p(*reinterpret_cast<const f32x4*>(kr), q0, 0.f);
+                    acc = dot4p(*reinterpret_cast<const f32x4*>(kr + 4), q1, acc);
+                    acc = gsum<8>(acc);
+                    if (sub == 0) es[t] = acc;
+                }
+            }
+            lds_barrier();
+            PS_STAMP(1, s, 3);
+            // ---- softmax over ALL frames (no mask, reference las_model.py:292), statistics redundantly per wave
+            float ev[EP / 64];
+            float mx = -INFINITY;
+#pragma unroll
+            for (int k = 0; k < EP / 64; ++k) { ev[k] = es[lane + 64 * k]; mx = fmaxf(mx, ev[k]); }
+            mx = wmax(mx);
+            float sm = 0.f;
+#pragma unroll
+            for (int k = 0; k < EP / 64; ++k) sm += __builtin_amdgcn_exp2f((ev[k] - mx) * 1.4426950408889634f);
+            const float inv = 1.0f / wsum(sm);
+            if (tid < Tp) {
+                const float w = __builtin_amdgcn_exp2f((es[tid] - mx) * 1.4426950408889634f) * inv;
+                as[tid] = w;
+                if (part_id == 0) a.att[((size_t)s * B + b) * Tp + tid] = w;
+            }
+            lds_barrier();
+            PS_STAMP(1, s, 4);
+            // ---- sum_t a_t P_t over this workgroup's gate columns; the TS time slices of a column group are adjacent lanes
+            {
+                f32x4 acc = zero;
+#pragma unroll
+                for (int i = 0; i < NIP; ++i) {
+                    const float w = as[ts + TS * i];
+                    acc[0] = fmaf(w, pr[i][0], acc[0]); acc[1] = fmaf(w, pr[i][1], acc[1]);
+                    acc[2] = fmaf(w, pr[i][2], acc[2]); acc[3] = fmaf(w, pr[i][3], acc[3]);
+                }
+                acc[0] = gsum<TS>(acc[0]); acc[1] = gsum<TS>(acc[1]); acc[2] = gsum<TS>(acc[2]); acc[3] = gsum<TS>(acc[3]);
+                if (ts == 0) st4_agent(a.gx + ((size_t)s * B + b) * (4 * HS) + col0 + cg * 4, acc);
+            }
+            PS_STAMP(1, s, 5);
+        }
+    }
+};
+
+template <int HS>
+__global__ __launch_bounds__(PS_THREADS) void speller_persist_fwd_pre_kernel(PersistArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    constexpr int NC = HS / 4;
+    if ((int)blockIdx.x < NC) CellRole<HS, false, true>::run(a, smem);
+    else AttnPreRole<HS>::run(a, smem, blockIdx.x - NC);
+}
+
 template <int HS, int SPLIT, bool GREEDY>
 __global__ __launch_bounds__(PS_THREADS) void speller_persist_fwd_kernel(PersistArgs a) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -622,6 +823,34 @@ bool speller_persist_eligible(int B, int Tp, int Hs, int D, int M, int V, int L,
     return persist_split(B, Tp, Hs, V, free_running != 0) != 0;
 }
 
+bool speller_persist_pre_shape(int B, int Tp, int Hs, int D, int M, int V, int L, int heads, int use_mlp) {
+    if (L != 2 || heads != 1 || !use_mlp || M != PS_M || D != Hs) return false;
+    if (Hs != 256 && Hs != 512) return false;
+    if (B < 1 || B > 32 || ((V + 15) & ~15) > 256) return false;
+    return Tp <= 112;
+}
+bool speller_persist_pre_eligible(int B, int Tp, int Hs, int D, int M, int V, int L, int heads, int use_mlp) {
+    static const bool on = !(getenv("LAS_SPELLER_PRE") && atoi(getenv("LAS_SPELLER_PRE")) == 0);
+    if (!on || !speller_persist_pre_shape(B, Tp, Hs, D, M, V, L, heads, use_mlp)) return false;
+    int cus = 0, dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess)
+        return false;
+    return Hs / 4 + 4 * B <= cus;
+}
+
+template <int HS>
+static int launch_persist_fwd_pre(const PersistArgs& a, int grid, hipStream_t stream) {
+    const size_t smem = sizeof(float) * (size_t)std::max(CellRole<HS, false, true>::LDS_FLOATS, AttnPreRole<HS>::lds_floats(a.Tp));
+    LAS_REQUIRE(smem <= 160 * 1024, "persistent speller LDS budget");
+    LAS_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&speller_persist_fwd_pre_kernel<HS>),
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
+    if (!persistent_launch_fits(speller_persist_fwd_pre_kernel<HS>, PS_THREADS, smem, grid))
+        return fail(LAS_ERR_UNSUPPORTED, "persistent decode kernel: %s%ld workgroups cannot all be resident", "", (long)grid);
+    hipLaunchKernelGGL((speller_persist_fwd_pre_kernel<HS>), dim3(grid), dim3(PS_THREADS), smem, stream, a);
+    LAS_LAUNCH_CHECK();
+    return LAS_OK;
+}
+
 template <int HS, int SPLIT, bool GREEDY>
 static int launch_persist_fwd2(const PersistArgs& a, int grid, hipStream_t stream) {
     const size_t smem = sizeof(float) * (size_t)std::max(CellRole<HS, GREEDY>::LDS_FLOATS, AttnRole<HS, SPLIT, GREEDY>::lds_floats(a.Tp, a.V, GREEDY));
@@ -655,7 +884,16 @@ int speller_persist_fwd(const PersistFwd& p, hipStream_t stream) {
     a.B = p.B; a.Tp = p.Tp; a.U = p.U; a.relu = p.relu; a.err = p.err;
     a.split = persist_split(p.B, p.Tp, p.Hs, p.V, p.mode != 0);
     a.trace = g_persist_trace;
+    a.pctx = p.pctx; a.gx = p.gx;
     LAS_REQUIRE(p.err != nullptr, "the persistent speller needs the device error word");
+    if (p.pctx) {      // pre-multiplied context variant (the caller checked speller_persist_pre_eligible)
+        LAS_REQUIRE(p.mode == 0 && p.gx && speller_persist_pre_shape(p.B, p.Tp, p.Hs, p.Hs, PS_M, p.V, 2, 1, 1), "persistent speller (pre) shape");
+        a.split = 4;
+        LAS_HIP_CHECK(hipMemsetAsync(p.hx, 0xFF, sizeof(float) * 2 * p.U * 32 * p.Hs, stream));
+        LAS_HIP_CHECK(hipMemsetAsync(p.gx, 0xFF, sizeof(float) * (size_t)p.U * p.B * 4 * p.Hs, stream));
+        const int grid = p.Hs / 4 + 4 * p.B;
+        return p.Hs == 512 ? launch_persist_fwd_pre<512>(a, grid, stream) : launch_persist_fwd_pre<256>(a, grid, stream);
+    }
     // sentinel-fill what the phases hand over: every h of both layers and the contexts of steps 1..U
     const size_t sH = (size_t)p.B * p.Hs;
     LAS_HIP_CHECK(hipMemsetAsync(p.hx, 0xFF, sizeof(float) * 2 * p.U * 32 * p.Hs, stream));
