@@ -13,6 +13,7 @@ MAX_L = 4
 
 FLAG_STASH = 1
 FLAG_FORCE_GENERIC = 2
+FLAG_TEACHER_FORCED = 4     # las_speller_bwd: the forward that filled `reserve` was teacher-forced (same flags / error word)
 
 _f = C.c_void_p   # every device pointer is passed as an integer address
 

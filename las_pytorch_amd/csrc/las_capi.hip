@@ -73,6 +73,7 @@ struct SpellerBwdLayout {
         const size_t Mq = d->use_mlp ? d->M : d->Hs;
         dG_all = o; o += r4((size_t)d->L * U * B * 4 * d->Hs);
         dz_all = o; o += r4((size_t)U * B * d->V);
+        o += r4(B * d->D);                       // headroom: the row block "step -1" of the deferred dG0 . W_ctx product (PRE variant)
         dctx_all = o; o += r4((size_t)U * B * d->D);
         de_all = o; o += r4((size_t)U * B * d->Tp * d->multi_head);
         dqpre_all = o; o += r4((size_t)U * B * d->M * d->multi_head);
@@ -631,6 +632,8 @@ int las_speller_bwd(const las_speller_desc* d, const float* feat, const float* k
     const bool persist = persist_on && hoist && err_word && !(flags & LAS_FLAG_FORCE_GENERIC) && d->relu <= LAS_ACT_RELU &&
                          speller_persist_bwd_eligible(B, Tp, Hs, D, M, V, L, NH, d->use_mlp);
     bool persist_ran = persist;
+    float* dx0_ctx = dx0 + V;              // gradient of the initial context (step 0's context input) and its row stride
+    long ld_dx0 = V + D;
     if (persist) {
         PersistBwd p;
         p.w_ih0 = d->w_ih[0]; p.w_hh0 = d->w_hh[0]; p.w_ih1 = d->w_ih[1]; p.w_hh1 = d->w_hh[1]; p.w_phi = d->w_phi;
@@ -639,9 +642,25 @@ int las_speller_bwd(const las_speller_desc* d, const float* feat, const float* k
         p.dG_all = dG_all; p.dctx_all = dctx_all; p.de_all = de_all; p.dqpre_all = dqpre_all;
         p.dx0 = dx0; p.xbuf = workspace + wl.pxbuf;
         p.B = B; p.Tp = Tp; p.U = U; p.Hs = Hs; p.V = V; p.relu = d->relu; p.err = err_word;
+        // PRE variant: same decision as las_speller_fwd took (same shape, same switches, same device), so P and the gx slabs exist
+        const bool pre = lay.pre && (flags & LAS_FLAG_TEACHER_FORCED) && speller_persist_bwd_pre_eligible(B, Tp, Hs, D, M, V, L, NH, d->use_mlp);
+        if (pre) { p.pctx = reserve + lay.pctx; p.gxf = reserve + lay.gx; }
         const int rc = speller_persist_bwd(p, stream);
         if (rc == LAS_ERR_UNSUPPORTED) persist_ran = false;      // residency check failed: the per-step kernels below run instead
         else LAS_TRY(rc);
+        if (persist_ran && pre) {
+            // context gradients of every step, off the chain: dctx_s = dcat_ctx_s + dG0_{s+1} W_ctx; the row block of dG0_0 is the
+            // gradient of the initial context feat[:,0,:] (the headroom block in front of dctx_all)
+            float* dctx_m1 = dctx_all - (size_t)B * D;
+            LAS_HIP_CHECK(hipMemsetAsync(dctx_m1, 0, sizeof(float) * (size_t)B * D, stream));
+            LAS_TRY(copy2d(dcat_all + Hs, Hs + D, dctx_all, D, (long)U * B, D, 0, stream));
+            GemmDesc g;
+            g.A = dG_all; g.lda = 4 * Hs; g.a_kc = true;
+            g.B = reserve + lay.w0p + lay.Vp; g.ldb = lay.Vp + Hs; g.b_kc = false;
+            g.C = dctx_m1; g.ldc = D; g.M = U * B; g.N = D; g.K = 4 * Hs; g.accumulate = true; g.splitk = 1;
+            LAS_TRY(gemm_f32(g, stream));
+            dx0_ctx = dctx_m1; ld_dx0 = D;
+        }
     }
     for (int s = persist_ran ? -1 : U - 1; s >= 0; --s) {
         const bool last = (s == U - 1);
@@ -713,7 +732,7 @@ int las_speller_bwd(const las_speller_desc* d, const float* feat, const float* k
         AttnDeferred x;
         x.feat = feat; x.keys = keys; x.att = att; x.q_all = q_all; x.de_all = de_all; x.dqpre_all = dqpre_all; x.dctx_all = dctx_all;
         x.dctxcat_all = dctxcat_all; x.ctxcat_all = ctxcat_all; x.h_top_all = h_top_all; x.dK = dK; x.U = U; x.zg = zg;
-        x.dx0_ctx = dx0 + V; x.ld_dx0 = V + D; x.skip_dw_phi = NH == 1;       // single head: dW_phi rides in the grouped launch below
+        x.dx0_ctx = dx0_ctx; x.ld_dx0 = ld_dx0; x.skip_dw_phi = NH == 1;       // single head: dW_phi rides in the grouped launch below
         LAS_TRY(attention_deferred(d, x, g, stream));
     }
     {   // every remaining weight gradient (K = U*B rows each) in ONE grouped stream-K launch

@@ -145,11 +145,15 @@ struct PersistBwd {
     float* dG_all; float* dctx_all; float* de_all; float* dqpre_all;        // per-step gradients for the deferred GEMMs
     float* dx0;                                                             // (B,V+D): context part written at step 0
     float* xbuf;                                                            // speller_persist_bwd_workspace_floats()
+    // PRE variant (speller_persist_bwd_pre_eligible; the forward ran its PRE variant): feat . W_ctx^T and the forward's gx slabs.
+    // The kernel then leaves dctx_all and the context part of dx0 to the caller (one GEMM over the stashed dG0 afterwards).
+    const float* pctx = nullptr; const float* gxf = nullptr;
     int B, Tp, U, Hs, V, relu;
     unsigned* err;
 };
 bool speller_persist_bwd_eligible(int B, int Tp, int Hs, int D, int M, int V, int L, int heads, int use_mlp);
 size_t speller_persist_bwd_workspace_floats(int B, int Tp, int U, int Hs, int M);
+bool speller_persist_bwd_pre_eligible(int B, int Tp, int Hs, int D, int M, int V, int L, int heads, int use_mlp);
 int speller_persist_bwd(const PersistBwd& p, hipStream_t stream);
 void speller_persist_bwd_set_trace(unsigned long long* dev_buf);
 

@@ -829,22 +829,36 @@ bool speller_persist_pre_shape(int B, int Tp, int Hs, int D, int M, int V, int L
     if (B < 1 || B > 32 || ((V + 15) & ~15) > 256) return false;
     return Tp <= 112;
 }
+template <int HS>
+static size_t persist_fwd_pre_smem(int Tp) {
+    return sizeof(float) * (size_t)std::max(CellRole<HS, false, true>::LDS_FLOATS, AttnPreRole<HS>::lds_floats(Tp));
+}
+template <int HS>
+static bool persist_fwd_pre_fits(int Tp, int grid) {
+    const size_t smem = persist_fwd_pre_smem<HS>(Tp);
+    if (smem > 160 * 1024) return false;
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&speller_persist_fwd_pre_kernel<HS>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                            (int)smem) != hipSuccess)
+        return false;
+    return persistent_launch_fits(speller_persist_fwd_pre_kernel<HS>, PS_THREADS, smem, grid);
+}
+// Shape, switch, CU count AND the occupancy calculator: las_speller_bwd repeats this call to learn what las_speller_fwd did
+// (its PRE variant needs the P matrix and the gx slabs the forward's PRE variant left in the reserve).
 bool speller_persist_pre_eligible(int B, int Tp, int Hs, int D, int M, int V, int L, int heads, int use_mlp) {
     static const bool on = !(getenv("LAS_SPELLER_PRE") && atoi(getenv("LAS_SPELLER_PRE")) == 0);
     if (!on || !speller_persist_pre_shape(B, Tp, Hs, D, M, V, L, heads, use_mlp)) return false;
     int cus = 0, dev = 0;
     if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess)
         return false;
-    return Hs / 4 + 4 * B <= cus;
+    const int grid = Hs / 4 + 4 * B;
+    if (grid > cus) return false;
+    return Hs == 512 ? persist_fwd_pre_fits<512>(Tp, grid) : persist_fwd_pre_fits<256>(Tp, grid);
 }
 
 template <int HS>
 static int launch_persist_fwd_pre(const PersistArgs& a, int grid, hipStream_t stream) {
-    const size_t smem = sizeof(float) * (size_t)std::max(CellRole<HS, false, true>::LDS_FLOATS, AttnPreRole<HS>::lds_floats(a.Tp));
-    LAS_REQUIRE(smem <= 160 * 1024, "persistent speller LDS budget");
-    LAS_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&speller_persist_fwd_pre_kernel<HS>),
-                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
-    if (!persistent_launch_fits(speller_persist_fwd_pre_kernel<HS>, PS_THREADS, smem, grid))
+    const size_t smem = persist_fwd_pre_smem<HS>(a.Tp);
+    if (!persist_fwd_pre_fits<HS>(a.Tp, grid))
         return fail(LAS_ERR_UNSUPPORTED, "persistent decode kernel: %s%ld workgroups cannot all be resident", "", (long)grid);
     hipLaunchKernelGGL((speller_persist_fwd_pre_kernel<HS>), dim3(grid), dim3(PS_THREADS), smem, stream, a);
     LAS_LAUNCH_CHECK();

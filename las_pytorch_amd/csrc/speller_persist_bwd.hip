@@ -41,6 +41,9 @@ struct PersistBwdArgs {
     float* dGx;      // [2][U][Hs/16][32][64]    tiled gate gradients (layer, step, unit tile, row, unit*4+gate)
     float* dcx;      // [U][Hs/16][32][16]       context gradient carried to the previous step
     float* dhc;      // [U][Hs/16][32][16]       top-layer recurrent carry (R -> Y)
+    // PRE variant (the forward ran speller_persist_fwd_pre_kernel): P = feat . W_ctx^T (B*T', 4Hs, columns unit*4+gate), the
+    // forward's published sums gxf[s][b] = sum_t a_t P_t, and e0[s][b][t] = dcat_ctx[s][b] . feat[b][t] (one batched GEMM)
+    const float* pctx; const float* gxf; const float* e0;
     int B, Tp, U, relu;
     int ns;          // attention-backward workgroups per utterance (each owns ceil(T'/ns) frames)
     unsigned* err;
@@ -190,9 +193,11 @@ struct ProdRole {
     // ROLE 0 (X): dh0 = dG1 W_ih1 -> bottom cell backward -> dG0 ; recurrent carry dG0 W_hh0 (own, off the chain, W in LDS)
     // ROLE 1 (Y): top cell backward -> dG1 ; dctx = dG0 W_ctx
     // ROLE 2 (R): recurrent carry of the top layer dG1 W_hh1, handed to the Y workgroup of the same tile (off the chain)
-    template <int ROLE>
+    // ROLE 3 (RY, PRE variant only): top cell backward AND the top layer's recurrent carry in one workgroup (the carry never
+    // leaves it).  In the PRE variant there is no Y product: the attention workgroups take dG0 themselves.
+    template <int ROLE, bool PREV = false>
     static __device__ void run(const PersistBwdArgs& a, float* smem, const int widx) {
-        constexpr bool IS_X = ROLE == 0, IS_Y = ROLE == 1, IS_R = ROLE == 2;
+        constexpr bool IS_X = ROLE == 0, IS_Y = ROLE == 1, IS_R = ROLE == 2, IS_RY = ROLE == 3;
         const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
         const int j = widx >> 1, mt = widx & 1;
         const int B = a.B, U = a.U;
@@ -203,7 +208,7 @@ struct ProdRole {
         float Wc[KB][4];
         if (IS_X) load_w(a.w_ih1, HS, 0, j, wave, lane, Wc);
         else if (IS_Y) load_w(a.w_ih0, a.ldw0, a.V, j, wave, lane, Wc);
-        else load_w(a.w_hh1, HS, 0, j, wave, lane, Wc);
+        else load_w(a.w_hh1, HS, 0, j, wave, lane, Wc);           // R and RY
         float* wlds = smem + RED + (wave * KB * 64 + lane) * 4;              // [wave][block][lane][gate]
         if (IS_X) {
             float Wt[KB][4];
@@ -239,7 +244,7 @@ struct ProdRole {
         const unsigned o4 = 4u * ((unsigned)pb * 4 * HS + 16 * j + pu);       // ... in a (B,4Hs) slab
         const unsigned ox = 4u * ((((unsigned)j * 32 + pb) * 16 + pu) * 4);   // its float4 in a tiled dG slab
         const unsigned oc = 4u * (((unsigned)j * 32 + pb) * 16 + pu);         // its dword in a dcx / dhc slab
-        const int layer = IS_Y ? 1 : 0;
+        const int layer = (IS_Y || IS_RY) ? 1 : 0;
         const float* dG1x = a.dGx + (size_t)U * GXS;
         const float* dG0x = a.dGx;
         float* dGx_out = a.dGx + (size_t)layer * U * GXS;
@@ -268,7 +273,46 @@ struct ProdRole {
             float dcat = 0.f;
             if (pw) {
                 ci = load_cell(a, layer, s, opaque(o4), opaque(o1));
-                if (IS_Y) dcat = *at_bytes(a.dcat_all + (size_t)s * B * 2 * HS, opaque(4u * ((unsigned)pb * 2 * HS + 16 * j + pu)));
+                if (IS_Y || IS_RY) dcat = *at_bytes(a.dcat_all + (size_t)s * B * 2 * HS, opaque(4u * ((unsigned)pb * 2 * HS + 16 * j + pu)));
+            }
+            if (IS_RY) {
+                // ---- decoder-state gradient parts of the attention workgroups + own carry -> top cell backward -> dG1_s
+                PB_STAMP(1, s, 0);
+                if (pw) {
+                    const unsigned* p0 = reinterpret_cast<const unsigned*>(
+                        at_bytes(a.dhA + (size_t)s * B * a.ns * HS, opaque(4u * ((unsigned)pb * a.ns * HS + 16 * j + pu))));
+                    unsigned spins = 0;
+                    float parts = 0.f;
+                    for (;;) {
+                        bool ok = true;
+                        parts = 0.f;
+                        for (int k = 0; k < a.ns; ++k) {
+                            const unsigned v = __hip_atomic_load(p0 + k * HS, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                            ok &= v != PS_SENT;
+                            parts += __uint_as_float(v);
+                        }
+                        if (ok) break;
+                        if (spin_expired(spins, a.err, 0xDEAD0027u)) break;
+                    }
+                    PB_STAMP(1, s, 1);
+                    const f32x4 g = cell_bwd(ci, dcat + parts + dh_carry, dc);
+                    st4_agent(at_bytes(dGx_out + (size_t)s * GXS, opaque(ox)), g);
+                    stash_dG(a, 1, s, opaque(o4), g);
+                }
+                PB_STAMP(1, s, 2);
+                // ---- (off the chain) recurrent carry for step s-1: dG1_s W_hh1, once the X workgroup of the same tile has
+                // consumed dG1_s (published dG0_s): the chain's consumers get the fabric and the L2 to themselves
+                if (s > 0) {
+                    {
+                        const unsigned* cp = reinterpret_cast<const unsigned*>(dG0x + (size_t)s * GXS) + (((unsigned)j * 32 + mt * 16) * 64 + 63);
+                        unsigned spins = 0;
+                        while (__hip_atomic_load(cp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == PS_SENT)
+                            if (spin_expired(spins, a.err, 0xDEAD0028u)) break;
+                    }
+                    dh_carry = reduce_tile<true>(red, poll_mul(dG1x + (size_t)s * GXS, la, x, a.err, cflags, cep, mul_reg), wave, lane, tid);
+                }
+                PB_STAMP(1, s, 3);
+                continue;
             }
             if (IS_Y) {
                 // ---- Y1: decoder-state gradient parts of the two attention halves (+ carry from R) -> top cell backward -> dG1_s
@@ -325,7 +369,7 @@ struct ProdRole {
                 PB_STAMP(0, s, 2);
                 // ---- X2 (off the chain): recurrent carry of the bottom layer for step s-1
                 if (s > 0) {
-                    {   // start once the Y workgroup of the same tile has consumed dG0_s: both would pull the same 8 MB
+                    if (!PREV) {   // start once the Y workgroup of the same tile has consumed dG0_s: both would pull the same 8 MB
                         const unsigned* cp = reinterpret_cast<const unsigned*>(a.dcx + (size_t)s * CXS) + ((unsigned)j * 32 + mt * 16) * 16;
                         unsigned spins = 0;
                         while (__hip_atomic_load(cp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == PS_SENT)
@@ -480,6 +524,175 @@ struct AttnBwdRole {
     }
 };
 
+
+// ------------------------------------------------------------------------------------------------ attention backward, PRE variant
+// The context gradient never materialises on the chain: with P = feat . W_ctx^T resident (its frames x all 4Hs gate columns,
+// 32 lanes per frame), da_t = dcat_ctx . feat_t + dG0_{s+1} . P_t — the first term is a batched GEMM before the launch (e0),
+// the second a register-resident contraction with the 4Hs-long gate gradient row of this utterance that the X workgroups
+// just published.  The softmax-backward statistic ctx_s . dctx_s = sum_t a_t e0_t + dG0_{s+1} . gx_s uses the forward's
+// hand-off slab gx_s = sum_t a_t P_t as one more "frame", so the four frame slices of an utterance still never talk.
+template <int HS>
+struct AttnBwdPreRole {
+    static constexpr int NS = 4;
+    static constexpr int GC = 4 * HS;                      // length of a P row / of a gate-gradient row
+    static constexpr int NC4 = GC / 32 / 4;                // float4 per lane: 32 lanes per frame slot
+    static constexpr int TH = 28;                          // frames per workgroup (T' <= 112); slot 31 is the gx row
+    static constexpr int NJ = HS / 16;                     // producer tiles of a gate-gradient row (256 B each)
+    static constexpr int NMH = PS_THREADS / HS, MPT = PS_M / NMH;
+    static constexpr int WLD = PS_M + 4;                   // LDS row stride of a W_phi column (conflict-free 16-byte reads)
+    static __host__ __device__ constexpr int lds_floats() { return GC + 128 + 128 + PS_M + 32 + PS_M + HS + 32 + TH * PS_KLD + HS * WLD; }
+
+    static __device__ void run(const PersistBwdArgs& a, float* smem, const int widx) {
+        const int b = widx / NS, part = widx % NS;
+        const bool first_wg = widx == 0;
+        const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+        const int B = a.B, U = a.U, Tp = a.Tp;
+        const int th = (Tp + NS - 1) / NS, t0 = part * th, nt = max(0, min(th, Tp - t0));     // this workgroup's frames
+        float* dg = smem;
+        float* attr = dg + GC;
+        float* e0r = attr + 128;
+        float* qs = e0r + 128;
+        float* de = qs + PS_M;
+        float* dqpre = de + 32;
+        float* dhl = dqpre + PS_M;
+        float* slotv = dhl + HS;
+        float* ks = slotv + 32;
+        float* wl = ks + TH * PS_KLD;            // W_phi, column-major: the P rows take the registers
+        const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
+
+        // ---- resident operands: P rows of its frames (registers), keys of its frames and W_phi (LDS)
+        const int slot = tid >> 5, l32 = tid & 31;
+        f32x4 pr[NC4];
+#pragma unroll
+        for (int i = 0; i < NC4; ++i) {
+            const f32x4 v = ld4p(a.pctx + ((size_t)b * Tp + (slot < nt ? t0 + slot : 0)) * GC + 4 * (l32 + 32 * i));
+            pr[i] = slot < nt ? v : zero;
+        }
+        for (int idx = tid; idx < nt * (PS_M / 4); idx += PS_THREADS) {
+            const int t = idx / (PS_M / 4), m4 = idx % (PS_M / 4);
+            *reinterpret_cast<f32x4*>(ks + t * PS_KLD + m4 * 4) = ld4p(a.keys + ((size_t)b * Tp + t0 + t) * PS_M + m4 * 4);
+        }
+        const int pmh = tid % NMH, pc = tid / NMH;        // the NMH lanes of a column are adjacent: DPP sum, no LDS
+        for (int idx = tid; idx < PS_M * HS; idx += PS_THREADS) wl[(idx % HS) * WLD + idx / HS] = a.w_phi[idx];
+        lds_barrier();
+
+        for (int s = U - 1; s >= 0; --s) {
+            // ---- stash operands of this step (plain loads, issued before the wait)
+            // (wave-uniform base + opaque 32-bit lane offset: otherwise one 64-bit address pair per access is hoisted out
+            //  of the step loop and spilled — the P rows leave no registers for that)
+            const size_t sb = (size_t)s * B + b;
+            if (tid < 128) {
+                const unsigned o = opaque(4u * (unsigned)(tid < Tp ? tid : 0));
+                const float av = *at_bytes(a.att + sb * Tp, o), ev = *at_bytes(a.e0 + sb * Tp, o);
+                attr[tid] = tid < Tp ? av : 0.f;
+                e0r[tid] = tid < Tp ? ev : 0.f;
+            }
+            if (tid >= 128 && tid < 128 + PS_M) qs[tid - 128] = *at_bytes(a.q_all + sb * PS_M, opaque(4u * (unsigned)(tid - 128)));
+            if (slot == 31) {
+                const float* gp = at_bytes(a.gxf + sb * GC, opaque(16u * (unsigned)l32));
+#pragma unroll
+                for (int i = 0; i < NC4; ++i) pr[i] = ld4p(gp + 128 * i);
+            }
+            PB_STAMP(2, s, 0);
+            // ---- the gate gradients of step s+1's bottom cell, row b: one 256-byte piece per X workgroup of this M-tile
+            if (s < U - 1) {
+                const float* slab = a.dGx + (size_t)(s + 1) * ((size_t)NJ * 32 * 64);
+                if (wave == 0) {
+                    const unsigned* cp = reinterpret_cast<const unsigned*>(at_bytes(slab, opaque(4u * (((unsigned)(lane < NJ ? lane : 0) * 32 + b) * 64 + 63))));
+                    unsigned spins = 0;
+                    for (;;) {
+                        const unsigned v = __hip_atomic_load(cp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        if (!__any(lane < NJ && v == PS_SENT)) break;
+                        if (spin_expired(spins, a.err, 0xDEAD0029u)) break;
+                    }
+                }
+                lds_barrier();
+                if (tid < GC / 4) {
+                    const float* src = at_bytes(slab, opaque(4u * (((unsigned)(tid >> 4) * 32 + b) * 64 + 4 * (tid & 15))));
+                    unsigned spins = 0;
+                    f32x4 v;
+                    for (;;) {
+                        v = ld4_agent(src);
+                        if (!__any(has_sentinel(v))) break;
+                        if (spin_expired(spins, a.err, 0xDEAD002Au)) break;
+                    }
+                    *reinterpret_cast<f32x4*>(dg + 4 * tid) = v;
+                }
+            } else if (tid < GC / 4) {
+                *reinterpret_cast<f32x4*>(dg + 4 * tid) = zero;
+            }
+            PB_STAMP(2, s, 1);
+            lds_barrier();
+            // ---- dG0 . P_t for its frames (and dG0 . gx_s in slot 31): 32 lanes per slot
+            {
+                float acc = 0.f;
+#pragma unroll
+                for (int i = 0; i < NC4; ++i) acc = dot4p(pr[i], *reinterpret_cast<const f32x4*>(dg + 4 * (l32 + 32 * i)), acc);
+                acc = gsum<16>(acc);
+                const float s0 = lane_f(acc, 0) + lane_f(acc, 16), s1 = lane_f(acc, 32) + lane_f(acc, 48);
+                if (lane == 0) { slotv[2 * wave] = s0; slotv[2 * wave + 1] = s1; }
+            }
+            lds_barrier();
+            // ---- softmax backward de_t = a_t (e0_t + dG0 . P_t - ctx . dctx) for its frames (one wave)
+            if (wave == 0) {
+                const float c0 = wsum(attr[lane] * e0r[lane] + attr[lane + 64] * e0r[lane + 64]);
+                const float sd = c0 + slotv[31];
+                if (lane < 32) {
+                    const bool valid = lane < nt;
+                    const int tt = valid ? t0 + lane : 0;
+                    const float v = valid ? attr[tt] * (e0r[tt] + slotv[lane] - sd) : 0.f;
+                    de[lane] = v;
+                    if (valid) *at_bytes(a.de_all + sb * Tp, opaque(4u * (unsigned)tt)) = v;
+                }
+            }
+            lds_barrier();
+            PB_STAMP(2, s, 2);
+            // ---- dq[m] = sum_t de_t keys[t][m] over this slice's frames: 16 adjacent lanes per m, DPP row sum
+            {
+                const int m = tid >> 4, tg = tid & 15;
+                float acc = 0.f;
+                for (int t = tg; t < nt; t += 16) acc = fmaf(de[t], ks[t * PS_KLD + m], acc);
+                acc = gsum<16>(acc);
+                if (tg == 0) {
+                    if (a.relu && !(qs[m] > 0.f)) acc = 0.f;
+                    dqpre[m] = acc;
+                    *at_bytes(a.dqpre_part + (((size_t)part * U + s) * B + b) * PS_M, opaque(4u * (unsigned)m)) = acc;
+                }
+            }
+            lds_barrier();
+            PB_STAMP(2, s, 3);
+            // ---- decoder-state gradient part W_phi^T dqpre: NMH adjacent lanes per column, published straight from registers
+            {
+                float acc = 0.f;
+                const float* wc = wl + pc * WLD + pmh * MPT;
+#pragma unroll
+                for (int i = 0; i < MPT; i += 4)
+                    acc = dot4p(*reinterpret_cast<const f32x4*>(wc + i), *reinterpret_cast<const f32x4*>(dqpre + pmh * MPT + i), acc);
+                acc = gsum<NMH>(acc);
+                if (NMH == 2) {          // a wave's 32 columns are one whole 128-byte line
+                    if (pmh == 0) st1_agent(at_bytes(a.dhA + (sb * NS + part) * HS, opaque(4u * (unsigned)pc)), acc);
+                } else {                 // gather through LDS so that the publication still moves whole lines
+                    if (pmh == 0) dhl[pc] = acc;
+                    lds_barrier();
+                    if (tid < HS / 4)
+                        st4_agent(at_bytes(a.dhA + (sb * NS + part) * HS, opaque(16u * (unsigned)tid)), *reinterpret_cast<const f32x4*>(dhl + tid * 4));
+                }
+            }
+            PB_STAMP(2, s, 4);
+        }
+    }
+};
+
+template <int HS>
+__global__ __launch_bounds__(PS_THREADS) void speller_persist_bwd_pre_kernel(PersistBwdArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    constexpr int NXY = (HS / 16) * 2;
+    const int bx = blockIdx.x;
+    if (bx < NXY) ProdRole<HS>::template run<0, true>(a, smem, bx);
+    else if (bx < 2 * NXY) ProdRole<HS>::template run<3, true>(a, smem, bx - NXY);
+    else AttnBwdPreRole<HS>::run(a, smem, bx - 2 * NXY);
+}
+
 template <int HS>
 __global__ __launch_bounds__(PS_THREADS) void speller_persist_bwd_kernel(PersistBwdArgs a) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -521,12 +734,36 @@ bool speller_persist_bwd_eligible(int B, int Tp, int Hs, int D, int M, int V, in
     return persist_bwd_ns(B, Tp, Hs, cus) != 0;
 }
 
-// floats of the hand-off slabs + the attention workgroups' dqpre parts; 0 when the shape is not covered
+// floats of the hand-off slabs + the attention workgroups' dqpre parts; 0 when the shape is not covered.  The PRE variant
+// (4 attention workgroups per utterance, no dcx / dhc slabs, plus the e0 rows) fits in the same block.
 size_t speller_persist_bwd_workspace_floats(int B, int Tp, int U, int Hs, int M) {
     if (Hs != 256 && Hs != 512) return 0;
     const int ns = persist_bwd_ns(B, Tp, Hs, -1);
     if (ns == 0) return 0;
-    return (size_t)ns * U * B * M + (size_t)U * B * ns * Hs + (size_t)2 * U * (Hs / 16) * 32 * 64 + (size_t)2 * (U + 1) * (Hs / 16) * 32 * 16;
+    const size_t classic = (size_t)ns * U * B * M + (size_t)U * B * ns * Hs + (size_t)2 * U * (Hs / 16) * 32 * 64 + (size_t)2 * (U + 1) * (Hs / 16) * 32 * 16;
+    const size_t pre = Tp <= 112 ? (size_t)4 * U * B * M + (size_t)U * B * Tp + 4 + (size_t)U * B * 4 * Hs + (size_t)2 * U * (Hs / 16) * 32 * 64 : 0;
+    return std::max(classic, pre);
+}
+bool speller_persist_bwd_pre_eligible(int B, int Tp, int Hs, int D, int M, int V, int L, int heads, int use_mlp) {
+    static const bool on = !(getenv("LAS_SPELLER_PRE_BWD") && atoi(getenv("LAS_SPELLER_PRE_BWD")) == 0);
+    if (!on || !persist_bwd_shape(B, Hs, D, M, L, heads, use_mlp) || Tp > 112) return false;
+    if (!speller_persist_pre_eligible(B, Tp, Hs, D, M, V, L, heads, use_mlp)) return false;      // the forward must have produced P and gx
+    int cus = 0, dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess)
+        return false;
+    return 2 * (Hs / 16) * 2 + 4 * B <= cus;
+}
+
+template <int HS>
+static int launch_persist_bwd_pre(const PersistBwdArgs& a, int grid, hipStream_t stream) {
+    const size_t smem = sizeof(float) * (size_t)std::max(ProdRole<HS>::LDS_FLOATS, AttnBwdPreRole<HS>::lds_floats());
+    LAS_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&speller_persist_bwd_pre_kernel<HS>),
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
+    if (!persistent_launch_fits(speller_persist_bwd_pre_kernel<HS>, PS_THREADS, smem, grid))
+        return fail(LAS_ERR_UNSUPPORTED, "persistent decode backward: %s%ld workgroups cannot all be resident", "", (long)grid);
+    hipLaunchKernelGGL((speller_persist_bwd_pre_kernel<HS>), dim3(grid), dim3(PS_THREADS), smem, stream, a);
+    LAS_LAUNCH_CHECK();
+    return LAS_OK;
 }
 
 template <int HS>
@@ -548,7 +785,8 @@ int speller_persist_bwd(const PersistBwd& p, hipStream_t stream) {
     LAS_HIP_CHECK(hipGetDevice(&dev));
     LAS_HIP_CHECK(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
     PersistBwdArgs a;
-    a.ns = persist_bwd_ns(p.B, p.Tp, p.Hs, cus);
+    a.pctx = p.pctx; a.gxf = p.gxf; a.e0 = nullptr;
+    a.ns = p.pctx ? 4 : persist_bwd_ns(p.B, p.Tp, p.Hs, cus);
     a.w_ih0 = p.w_ih0; a.ldw0 = p.V + p.Hs; a.V = p.V;
     a.w_hh0 = p.w_hh0; a.w_ih1 = p.w_ih1; a.w_hh1 = p.w_hh1; a.w_phi = p.w_phi;
     a.feat = p.feat; a.keys = p.keys; a.att = p.att; a.q_all = p.q_all; a.ctx_all = p.ctx_all;
@@ -558,6 +796,39 @@ int speller_persist_bwd(const PersistBwd& p, hipStream_t stream) {
     // carve the workspace: [dqpre parts | sentinel-prefilled slabs: dhA | tiled dG (2 layers) | dcx | dhc]
     const size_t nq = (size_t)p.U * p.B * PS_M;
     a.dqpre_part = p.xbuf;
+    if (p.pctx) {
+        // PRE variant: [dqpre parts (4) | e0 | sentinel-prefilled slabs: dhA (4 parts) | tiled dG (2 layers)]
+        LAS_REQUIRE(p.gxf && p.Tp <= 112, "persistent speller backward (pre) buffers");
+        float* e0 = p.xbuf + 4 * nq;
+        float* slabs = e0 + (((size_t)p.U * p.B * p.Tp + 3) & ~(size_t)3);
+        a.e0 = e0;
+        a.dhA = slabs;
+        a.dGx = a.dhA + (size_t)p.U * p.B * 4 * p.Hs;
+        a.dcx = nullptr; a.dhc = nullptr;
+        a.w_ih0 = p.w_ih0; a.ldw0 = p.V + p.Hs; a.V = p.V;
+        a.w_hh0 = p.w_hh0; a.w_ih1 = p.w_ih1; a.w_hh1 = p.w_hh1; a.w_phi = p.w_phi;
+        a.feat = p.feat; a.keys = p.keys; a.att = p.att; a.q_all = p.q_all; a.ctx_all = p.ctx_all;
+        a.gates_all = p.gates_all; a.c_all = p.c_all; a.dcat_all = p.dcat_all;
+        a.dG_all = p.dG_all; a.dctx_all = p.dctx_all; a.de_all = p.de_all;
+        a.dx0 = p.dx0; a.ldx0 = p.V + p.Hs;
+        a.B = p.B; a.Tp = p.Tp; a.U = p.U; a.relu = p.relu; a.err = p.err; a.trace = g_persist_bwd_trace;
+        {   // e0[s][b][t] = dcat_ctx[s][b] . feat[b][t]: one batched GEMM over the utterances
+            GemmDesc g;
+            g.A = p.dcat_all + p.Hs; g.lda = (long)p.B * 2 * p.Hs; g.a_kc = true; g.sA = 2 * p.Hs;
+            g.B = p.feat; g.ldb = p.Hs; g.b_kc = true; g.sB = (long)p.Tp * p.Hs;
+            g.C = e0; g.ldc = (long)p.B * p.Tp; g.sC = p.Tp;
+            g.M = p.U; g.N = p.Tp; g.K = p.Hs; g.batch = p.B; g.splitk = 1;
+            LAS_TRY(gemm_f32(g, stream));
+        }
+        const size_t slab_floats = (size_t)p.U * p.B * 4 * p.Hs + (size_t)2 * p.U * (p.Hs / 16) * 32 * 64;
+        LAS_HIP_CHECK(hipMemsetAsync(slabs, 0xFF, sizeof(float) * slab_floats, stream));
+        const int grid = 2 * (p.Hs / 16) * 2 + 4 * p.B;
+        if (p.Hs == 512) LAS_TRY(launch_persist_bwd_pre<512>(a, grid, stream));
+        else LAS_TRY(launch_persist_bwd_pre<256>(a, grid, stream));
+        LAS_HIP_CHECK(hipMemcpyAsync(p.dqpre_all, a.dqpre_part, sizeof(float) * nq, hipMemcpyDeviceToDevice, stream));
+        for (int k = 1; k < 4; ++k) LAS_TRY(add_inplace(p.dqpre_all, a.dqpre_part + (size_t)k * nq, (long)nq, stream));
+        return LAS_OK;
+    }
     float* slabs = p.xbuf + (size_t)a.ns * nq;
     a.dhA = slabs;
     a.dGx = a.dhA + (size_t)p.U * p.B * a.ns * p.Hs;

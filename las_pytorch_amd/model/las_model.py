@@ -23,7 +23,7 @@ import torch
 import torch.nn as nn
 
 from .. import _cabi
-from .._cabi import FLAG_FORCE_GENERIC, FLAG_STASH, SpellerDesc, SpellerGrads, check, lib, ptr, stream_ptr
+from .._cabi import FLAG_FORCE_GENERIC, FLAG_STASH, FLAG_TEACHER_FORCED, SpellerDesc, SpellerGrads, check, lib, ptr, stream_ptr
 
 def set_force_generic(module, flag=True):
     """A/B switch for tests and profiling: every pBLSTM layer / Speller under ``module`` uses the generic kernels
@@ -483,7 +483,8 @@ class _SpellerFn(torch.autograd.Function):
         work = torch.empty(Lh.las_speller_bwd_workspace_floats(d, U), device=dev, dtype=torch.float32)
         mode0 = int((not teacher_forced) and decode_mode == 0)
         check(Lh.las_speller_bwd(d, ptr(feat), ptr(keys), ptr(logp), ptr(att), ptr(dlogp), U, mode0, ptr(reserve),
-                                 ptr(work), g, ptr(_cabi.err_word(dev)), _flags(True, force_generic), stream_ptr()))
+                                 ptr(work), g, ptr(_cabi.err_word(dev)),
+                                 _flags(True, force_generic) | (FLAG_TEACHER_FORCED if teacher_forced else 0), stream_ptr()))
         return (None, dfeat, None, None, *([None] * len(grads) if ctx.direct else grads))
 
 
