@@ -140,8 +140,15 @@ def step_gemm_launches(c, B, T, U):
         BT, D = B * (T >> (l + 1)), (2 * F if l == 0 else 4 * H)
         out.append((f"L{l} X W_ih^T (2 dirs batched)", "single", [(BT, 4 * H, D, 1, 1, 2, 1, 0)]))
     out.append(("keys psi", "single", [(B * Tp, M, 2 * H, 1, 1, 1, max(1, min(2 * H // 64, 256 // max(1, -(-B * Tp // 128)))), 0)]))
+    pre = B <= 32 and Tp <= 112 and Hs in (256, 512)      # pre-multiplied-context decode kernels (speller_persist*.hip) and their GEMMs
+    if pre:
+        out.append(("P = feat W_ctx^T (decode chain pre-product)", "single", [(B * Tp, 4 * Hs, Hs, 1, 1, 1, 1, 0)]))
+        out.append(("ctx = att feat (per utterance)", "single", [(U, Hs, Tp, 1, 0, B, 1, 0)]))
     out.append(("logits [h|ctx] W_c^T (dual K)", "group", [(UB, V, 2 * Hs, 1, 1, 1, 0, Hs)]))
     out.append(("dcat = dz W_c", "single", [(UB, 2 * Hs, V, 1, 0, 1, 1, 0)]))
+    if pre:
+        out.append(("e0 = dcat_ctx feat^T (per utterance)", "single", [(U, Tp, Hs, 1, 1, B, 1, 0)]))
+        out.append(("dctx = dG0 W_ctx", "single", [(UB, Hs, 4 * Hs, 1, 0, 1, 1, 0)]))
     out.append(("dfeat (per utterance)", "single", [(Tp, Hs, U, 0, 0, B, 1, 0)]))
     out.append(("dK (per utterance)", "single", [(Tp, M, U, 0, 0, B, 1, 0)]))
     out.append(("dW_psi", "single", [(M, Hs, B * Tp, 0, 0, 1, 0, 0)]))
