@@ -140,7 +140,9 @@ def step_gemm_launches(c, B, T, U):
         BT, D = B * (T >> (l + 1)), (2 * F if l == 0 else 4 * H)
         out.append((f"L{l} X W_ih^T (2 dirs batched)", "single", [(BT, 4 * H, D, 1, 1, 2, 1, 0)]))
     out.append(("keys psi", "single", [(B * Tp, M, 2 * H, 1, 1, 1, max(1, min(2 * H // 64, 256 // max(1, -(-B * Tp // 128)))), 0)]))
-    pre = B <= 32 and Tp <= 112 and Hs in (256, 512)      # pre-multiplied-context decode kernels (speller_persist*.hip) and their GEMMs
+    # pre-multiplied-context decode kernels (speller_persist*.hip: 4 / 8 / 16 attention workgroups per utterance) and their GEMMs
+    pre = B <= 32 and Hs in (256, 512) and any(1024 * ws // Hs <= 32 and Tp <= 14 * (1024 * ws // Hs) and Hs // 4 + ws * B <= 256
+                                               for ws in (4, 8, 16))
     if pre:
         out.append(("P = feat W_ctx^T (decode chain pre-product)", "single", [(B * Tp, 4 * Hs, Hs, 1, 1, 1, 1, 0)]))
         out.append(("ctx = att feat (per utterance)", "single", [(U, Hs, Tp, 1, 0, B, 1, 0)]))

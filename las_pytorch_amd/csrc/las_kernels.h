@@ -132,6 +132,7 @@ struct PersistFwd {
     unsigned* err;
 };
 bool speller_persist_eligible(int B, int Tp, int Hs, int D, int M, int V, int L, int heads, int use_mlp, int free_running);
+int speller_persist_pre_ws(int B, int Tp, int Hs, int cus);   // attention workgroups per utterance of the PRE variant (0: n/a; cus < 0: shape only)
 bool speller_persist_pre_shape(int B, int Tp, int Hs, int D, int M, int V, int L, int heads, int use_mlp);   // shape only (sizes the reserve)
 bool speller_persist_pre_eligible(int B, int Tp, int Hs, int D, int M, int V, int L, int heads, int use_mlp);   // shape + residency
 int speller_persist_fwd(const PersistFwd& p, hipStream_t stream);

@@ -646,18 +646,18 @@ struct AttnRole {
 // floats, register-resident: lane = (column group, time slice)) is contracted with the step's attention weights and published
 // as whole 128-byte lines.  Query, energies and softmax are computed redundantly by the four (as the two of AttnRole do);
 // the context itself is not needed on the chain any more and is left to one batched GEMM after the launch.
-template <int HS>
+template <int HS, int WS>
 struct AttnPreRole {
-    static constexpr int SPLIT = 4;
+    static constexpr int SPLIT = WS;                     // workgroups per utterance: 4, 8 or 16 (longer T' at smaller batches)
     static constexpr int GC = 4 * HS / SPLIT;            // gate columns of this workgroup
     static constexpr int CG = GC / 4;                    // column groups (one float4 each)
-    static constexpr int TS = PS_THREADS / CG;           // time slices: 8 (Hs=512) or 16 (Hs=256) adjacent lanes
-    static constexpr int MAX_TP = 112;
-    static constexpr int NIP = MAX_TP / TS;              // frames per lane
-    static constexpr int EP = 128;                       // energies padded to whole waves (pad = -inf)
+    static constexpr int TS = PS_THREADS / CG;           // time slices: 8, 16 or 32 adjacent lanes
+    static constexpr int NIP = 14;                       // frames per lane (56 VGPRs of P)
+    static constexpr int MAX_TP = NIP * TS;              // 112, 224 or 448 frames
+    static constexpr int EP = (MAX_TP + 63) & ~63;       // energies padded to whole waves (pad = -inf)
     static constexpr int NJ = HS / 64;
-    static_assert(MAX_TP % TS == 0 && TS <= 16, "time-slice layout");
-    static __host__ __device__ constexpr int lds_floats(int Tp) { return HS + PS_M + EP + MAX_TP + Tp * PS_KLD; }
+    static_assert(TS == 8 || TS == 16 || TS == 32, "time-slice layout");
+    static __host__ __device__ constexpr int lds_floats(int Tp) { return HS + PS_M + EP + MAX_TP + GC + Tp * PS_KLD; }
 
     static __device__ void run(const PersistArgs& a, float* smem, const int widx) {
         const int b = widx / SPLIT, part_id = widx % SPLIT;
@@ -669,7 +669,8 @@ struct AttnPreRole {
         float* qs = hs + HS;
         float* es = qs + PS_M;
         float* as = es + EP;
-        float* ks = as + MAX_TP;
+        float* gxl = as + MAX_TP;
+        float* ks = gxl + GC;
 
         // ---- resident operands
         const int ts = tid % TS, cg = tid / TS;
@@ -681,7 +682,7 @@ struct AttnPreRole {
             const f32x4 v = ld4p(a.pctx + ((size_t)b * Tp + (t < Tp ? t : 0)) * (4 * HS) + col0 + cg * 4);
             pr[i] = t < Tp ? v : zero;
         }
-        if (tid >= Tp && tid < MAX_TP) as[tid] = 0.f;         // frames past T' carry zero weight
+        if (tid >= Tp && tid < MAX_TP) as[tid] = 0.f;         // frames past T' carry zero weight (MAX_TP <= 448 < threads)
         if (tid >= Tp && tid < EP) es[tid] = -INFINITY;
         for (int idx = tid; idx < Tp * (PS_M / 4); idx += PS_THREADS) {
             const int t = idx / (PS_M / 4), m4 = idx % (PS_M / 4);
@@ -698,7 +699,7 @@ struct AttnPreRole {
             PS_STAMP(1, s, 0);
             // ---- decoder state of this utterance (published by the cell workgroups)
             if (tid < HS / 4) {
-                const float* p = a.hx + ((size_t)U + s) * ((size_t)32 * HS) + ((size_t)tid * 32 + b) * 4;
+                const float* p = at_bytes(a.hx + ((size_t)U + s) * ((size_t)32 * HS), opaque(4u * (((unsigned)tid * 32 + b) * 4)));
                 unsigned spins = 0;
                 f32x4 v;
                 for (;;) {
@@ -720,16 +721,18 @@ struct AttnPreRole {
                     acc += bphi;
                     if (a.relu) acc = fmaxf(acc, 0.f);
                     qs[prow] = acc;
-                    if (part_id == 0) a.q_all[((size_t)s * B + b) * PS_M + prow] = acc;
+                    if (part_id == 0) *at_bytes(a.q_all + ((size_t)s * B + b) * PS_M, opaque(4u * (unsigned)prow)) = acc;
                 }
             }
             lds_barrier();
             PS_STAMP(1, s, 2);
-            // ---- energies e[t] = q . keys[t]: 8 lanes per frame (T' <= 112 <= 1024 / 8: one frame per lane group)
+            // ---- energies e[t] = q . keys[t]: 8 lanes per frame
             {
-                const int sub = tid & 7, t = tid >> 3;
-                if (t < Tp) {
-                    const f32x4 q0 = *reinterpret_cast<const f32x4*>(qs + sub * 8), q1 = *reinterpret_cast<const f32x4*>(qs + sub * 8 + 4);
+                const int sub = tid & 7;
+                const f32x4 q0 = *reinterpret_cast<const f32x4*>(qs + sub * 8), q1 = *reinterpret_cast<const f32x4*>(qs + sub * 8 + 4);
+#pragma unroll
+                for (int t = tid >> 3; t < EP; t += PS_THREADS / 8) {
+                    if (t >= Tp) break;
                     const float* kr = ks + t * PS_KLD + sub * 8;
                     float acc = dot4p(*reinterpret_cast<const f32x4*>(kr), q0, 0.f);
                     acc = dot4p(*reinterpret_cast<const f32x4*>(kr + 4), q1, acc);
@@ -740,19 +743,18 @@ struct AttnPreRole {
             lds_barrier();
             PS_STAMP(1, s, 3);
             // ---- softmax over ALL frames (no mask, reference las_model.py:292), statistics redundantly per wave
-            float ev[EP / 64];
             float mx = -INFINITY;
 #pragma unroll
-            for (int k = 0; k < EP / 64; ++k) { ev[k] = es[lane + 64 * k]; mx = fmaxf(mx, ev[k]); }
+            for (int k = 0; k < EP / 64; ++k) mx = fmaxf(mx, es[lane + 64 * k]);
             mx = wmax(mx);
             float sm = 0.f;
 #pragma unroll
-            for (int k = 0; k < EP / 64; ++k) sm += __builtin_amdgcn_exp2f((ev[k] - mx) * 1.4426950408889634f);
+            for (int k = 0; k < EP / 64; ++k) sm += __builtin_amdgcn_exp2f((es[lane + 64 * k] - mx) * 1.4426950408889634f);
             const float inv = 1.0f / wsum(sm);
             if (tid < Tp) {
                 const float w = __builtin_amdgcn_exp2f((es[tid] - mx) * 1.4426950408889634f) * inv;
                 as[tid] = w;
-                if (part_id == 0) a.att[((size_t)s * B + b) * Tp + tid] = w;
+                if (part_id == 0) *at_bytes(a.att + ((size_t)s * B + b) * Tp, opaque(4u * (unsigned)tid)) = w;
             }
             lds_barrier();
             PS_STAMP(1, s, 4);
@@ -765,20 +767,34 @@ struct AttnPreRole {
                     acc[0] = fmaf(w, pr[i][0], acc[0]); acc[1] = fmaf(w, pr[i][1], acc[1]);
                     acc[2] = fmaf(w, pr[i][2], acc[2]); acc[3] = fmaf(w, pr[i][3], acc[3]);
                 }
-                acc[0] = gsum<TS>(acc[0]); acc[1] = gsum<TS>(acc[1]); acc[2] = gsum<TS>(acc[2]); acc[3] = gsum<TS>(acc[3]);
-                if (ts == 0) st4_agent(a.gx + ((size_t)s * B + b) * (4 * HS) + col0 + cg * 4, acc);
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    acc[k] = gsum<(TS < 16 ? TS : 16)>(acc[k]);
+                    if (TS == 32) {          // two 16-lane rows per column group: add the row sums (wave-uniform scalars)
+                        const float lo = lane_f(acc[k], 0) + lane_f(acc[k], 16), hi = lane_f(acc[k], 32) + lane_f(acc[k], 48);
+                        acc[k] = lane < 32 ? lo : hi;
+                    }
+                }
+                float* dst = a.gx + ((size_t)s * B + b) * (4 * HS) + col0;
+                if (TS == 8) {               // the 8 column groups of a wave are one whole 128-byte line
+                    if (ts == 0) st4_agent(at_bytes(dst, opaque(16u * (unsigned)cg)), acc);
+                } else {                     // gather through LDS so that the publication still moves whole lines
+                    if (ts == 0) *reinterpret_cast<f32x4*>(gxl + cg * 4) = acc;
+                    lds_barrier();
+                    if (tid < CG) st4_agent(at_bytes(dst, opaque(16u * (unsigned)tid)), *reinterpret_cast<const f32x4*>(gxl + tid * 4));
+                }
             }
             PS_STAMP(1, s, 5);
         }
     }
 };
 
-template <int HS>
+template <int HS, int WS>
 __global__ __launch_bounds__(PS_THREADS) void speller_persist_fwd_pre_kernel(PersistArgs a) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     constexpr int NC = HS / 4;
     if ((int)blockIdx.x < NC) CellRole<HS, false, true>::run(a, smem);
-    else AttnPreRole<HS>::run(a, smem, blockIdx.x - NC);
+    else AttnPreRole<HS, WS>::run(a, smem, blockIdx.x - NC);
 }
 
 template <int HS, int SPLIT, bool GREEDY>
@@ -823,24 +839,39 @@ bool speller_persist_eligible(int B, int Tp, int Hs, int D, int M, int V, int L,
     return persist_split(B, Tp, Hs, V, free_running != 0) != 0;
 }
 
+// attention workgroups per utterance of the PRE variant: the smallest of 4 / 8 / 16 whose lanes hold T' frames of P
+// (14 per lane, 1024*ws/Hs... time slices of 8 / 16 / 32 lanes) and that leaves every workgroup resident; 0 = not applicable.
+// cus < 0: shape check only (sizes the reserve).
+int speller_persist_pre_ws(int B, int Tp, int Hs, int cus) {
+    for (int ws = 4; ws <= 16; ws *= 2) {
+        const int ts = PS_THREADS / (Hs / ws);           // time slices = threads / column groups
+        if (ts > 32) break;
+        if (Tp <= 14 * ts && (cus < 0 || Hs / 4 + ws * B <= cus)) return ws;
+    }
+    return 0;
+}
 bool speller_persist_pre_shape(int B, int Tp, int Hs, int D, int M, int V, int L, int heads, int use_mlp) {
     if (L != 2 || heads != 1 || !use_mlp || M != PS_M || D != Hs) return false;
     if (Hs != 256 && Hs != 512) return false;
     if (B < 1 || B > 32 || ((V + 15) & ~15) > 256) return false;
-    return Tp <= 112;
+    return speller_persist_pre_ws(B, Tp, Hs, -1) != 0;
 }
-template <int HS>
+template <int HS, int WS>
 static size_t persist_fwd_pre_smem(int Tp) {
-    return sizeof(float) * (size_t)std::max(CellRole<HS, false, true>::LDS_FLOATS, AttnPreRole<HS>::lds_floats(Tp));
+    return sizeof(float) * (size_t)std::max(CellRole<HS, false, true>::LDS_FLOATS, AttnPreRole<HS, WS>::lds_floats(Tp));
 }
-template <int HS>
+template <int HS, int WS>
 static bool persist_fwd_pre_fits(int Tp, int grid) {
-    const size_t smem = persist_fwd_pre_smem<HS>(Tp);
+    const size_t smem = persist_fwd_pre_smem<HS, WS>(Tp);
     if (smem > 160 * 1024) return false;
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&speller_persist_fwd_pre_kernel<HS>), hipFuncAttributeMaxDynamicSharedMemorySize,
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&speller_persist_fwd_pre_kernel<HS, WS>), hipFuncAttributeMaxDynamicSharedMemorySize,
                             (int)smem) != hipSuccess)
         return false;
-    return persistent_launch_fits(speller_persist_fwd_pre_kernel<HS>, PS_THREADS, smem, grid);
+    return persistent_launch_fits(speller_persist_fwd_pre_kernel<HS, WS>, PS_THREADS, smem, grid);
+}
+static bool persist_fwd_pre_fits_rt(int Hs, int ws, int Tp, int grid) {
+    if (Hs == 512) return ws == 4 ? persist_fwd_pre_fits<512, 4>(Tp, grid) : ws == 8 ? persist_fwd_pre_fits<512, 8>(Tp, grid) : persist_fwd_pre_fits<512, 16>(Tp, grid);
+    return ws == 4 ? persist_fwd_pre_fits<256, 4>(Tp, grid) : persist_fwd_pre_fits<256, 8>(Tp, grid);
 }
 // Shape, switch, CU count AND the occupancy calculator: las_speller_bwd repeats this call to learn what las_speller_fwd did
 // (its PRE variant needs the P matrix and the gx slabs the forward's PRE variant left in the reserve).
@@ -850,17 +881,17 @@ bool speller_persist_pre_eligible(int B, int Tp, int Hs, int D, int M, int V, in
     int cus = 0, dev = 0;
     if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess)
         return false;
-    const int grid = Hs / 4 + 4 * B;
-    if (grid > cus) return false;
-    return Hs == 512 ? persist_fwd_pre_fits<512>(Tp, grid) : persist_fwd_pre_fits<256>(Tp, grid);
+    const int ws = speller_persist_pre_ws(B, Tp, Hs, cus);
+    if (ws == 0) return false;
+    return persist_fwd_pre_fits_rt(Hs, ws, Tp, Hs / 4 + ws * B);
 }
 
-template <int HS>
+template <int HS, int WS>
 static int launch_persist_fwd_pre(const PersistArgs& a, int grid, hipStream_t stream) {
-    const size_t smem = persist_fwd_pre_smem<HS>(a.Tp);
-    if (!persist_fwd_pre_fits<HS>(a.Tp, grid))
+    const size_t smem = persist_fwd_pre_smem<HS, WS>(a.Tp);
+    if (!persist_fwd_pre_fits<HS, WS>(a.Tp, grid))
         return fail(LAS_ERR_UNSUPPORTED, "persistent decode kernel: %s%ld workgroups cannot all be resident", "", (long)grid);
-    hipLaunchKernelGGL((speller_persist_fwd_pre_kernel<HS>), dim3(grid), dim3(PS_THREADS), smem, stream, a);
+    hipLaunchKernelGGL((speller_persist_fwd_pre_kernel<HS, WS>), dim3(grid), dim3(PS_THREADS), smem, stream, a);
     LAS_LAUNCH_CHECK();
     return LAS_OK;
 }
@@ -901,12 +932,19 @@ int speller_persist_fwd(const PersistFwd& p, hipStream_t stream) {
     a.pctx = p.pctx; a.gx = p.gx;
     LAS_REQUIRE(p.err != nullptr, "the persistent speller needs the device error word");
     if (p.pctx) {      // pre-multiplied context variant (the caller checked speller_persist_pre_eligible)
-        LAS_REQUIRE(p.mode == 0 && p.gx && speller_persist_pre_shape(p.B, p.Tp, p.Hs, p.Hs, PS_M, p.V, 2, 1, 1), "persistent speller (pre) shape");
-        a.split = 4;
+        int cus = 0, dev = 0;
+        LAS_HIP_CHECK(hipGetDevice(&dev));
+        LAS_HIP_CHECK(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
+        const int ws = speller_persist_pre_ws(p.B, p.Tp, p.Hs, cus);
+        LAS_REQUIRE(p.mode == 0 && p.gx && ws != 0 && speller_persist_pre_shape(p.B, p.Tp, p.Hs, p.Hs, PS_M, p.V, 2, 1, 1), "persistent speller (pre) shape");
+        a.split = ws;
         LAS_HIP_CHECK(hipMemsetAsync(p.hx, 0xFF, sizeof(float) * 2 * p.U * 32 * p.Hs, stream));
         LAS_HIP_CHECK(hipMemsetAsync(p.gx, 0xFF, sizeof(float) * (size_t)p.U * p.B * 4 * p.Hs, stream));
-        const int grid = p.Hs / 4 + 4 * p.B;
-        return p.Hs == 512 ? launch_persist_fwd_pre<512>(a, grid, stream) : launch_persist_fwd_pre<256>(a, grid, stream);
+        const int grid = p.Hs / 4 + ws * p.B;
+        if (p.Hs == 512)
+            return ws == 4 ? launch_persist_fwd_pre<512, 4>(a, grid, stream)
+                           : ws == 8 ? launch_persist_fwd_pre<512, 8>(a, grid, stream) : launch_persist_fwd_pre<512, 16>(a, grid, stream);
+        return ws == 4 ? launch_persist_fwd_pre<256, 4>(a, grid, stream) : launch_persist_fwd_pre<256, 8>(a, grid, stream);
     }
     // sentinel-fill what the phases hand over: every h of both layers and the contexts of steps 1..U
     const size_t sH = (size_t)p.B * p.Hs;

@@ -533,16 +533,20 @@ struct AttnBwdRole {
 // hand-off slab gx_s = sum_t a_t P_t as one more "frame", so the four frame slices of an utterance still never talk.
 template <int HS>
 struct AttnBwdPreRole {
-    static constexpr int NS = 4;
     static constexpr int GC = 4 * HS;                      // length of a P row / of a gate-gradient row
-    static constexpr int NC4 = GC / 32 / 4;                // float4 per lane: 32 lanes per frame slot
-    static constexpr int TH = 28;                          // frames per workgroup (T' <= 112); slot 31 is the gx row
+    static constexpr int LPS = HS / 16;                    // lanes per frame slot: 32 (Hs=512) or 16 (Hs=256)
+    static constexpr int NSLOT = PS_THREADS / LPS;         // 32 or 64 slots; the last one holds the forward's gx row
+    static constexpr int NC4 = GC / LPS / 4;               // float4 per lane: 16 (64 VGPRs of P)
+    static constexpr int TH = NSLOT - 1;                   // frames per workgroup: 31 or 63
+    static constexpr int MAXTP = 512;                      // rows of attention weights / e0 kept in LDS (T' <= 448)
     static constexpr int NJ = HS / 16;                     // producer tiles of a gate-gradient row (256 B each)
     static constexpr int NMH = PS_THREADS / HS, MPT = PS_M / NMH;
     static constexpr int WLD = PS_M + 4;                   // LDS row stride of a W_phi column (conflict-free 16-byte reads)
-    static __host__ __device__ constexpr int lds_floats() { return GC + 128 + 128 + PS_M + 32 + PS_M + HS + 32 + TH * PS_KLD + HS * WLD; }
+    static_assert(LPS == 16 || LPS == 32, "slot layout");
+    static __host__ __device__ constexpr int lds_floats() { return GC + 2 * MAXTP + PS_M + 64 + PS_M + HS + 64 + TH * PS_KLD + HS * WLD; }
 
     static __device__ void run(const PersistBwdArgs& a, float* smem, const int widx) {
+        const int NS = a.ns;                                // frame slices (workgroups) per utterance: 4, 8 or 16
         const int b = widx / NS, part = widx % NS;
         const bool first_wg = widx == 0;
         const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -550,22 +554,22 @@ struct AttnBwdPreRole {
         const int th = (Tp + NS - 1) / NS, t0 = part * th, nt = max(0, min(th, Tp - t0));     // this workgroup's frames
         float* dg = smem;
         float* attr = dg + GC;
-        float* e0r = attr + 128;
-        float* qs = e0r + 128;
+        float* e0r = attr + MAXTP;
+        float* qs = e0r + MAXTP;
         float* de = qs + PS_M;
-        float* dqpre = de + 32;
+        float* dqpre = de + 64;
         float* dhl = dqpre + PS_M;
         float* slotv = dhl + HS;
-        float* ks = slotv + 32;
+        float* ks = slotv + 64;
         float* wl = ks + TH * PS_KLD;            // W_phi, column-major: the P rows take the registers
         const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
 
         // ---- resident operands: P rows of its frames (registers), keys of its frames and W_phi (LDS)
-        const int slot = tid >> 5, l32 = tid & 31;
+        const int slot = tid / LPS, l32 = tid % LPS;
         f32x4 pr[NC4];
 #pragma unroll
         for (int i = 0; i < NC4; ++i) {
-            const f32x4 v = ld4p(a.pctx + ((size_t)b * Tp + (slot < nt ? t0 + slot : 0)) * GC + 4 * (l32 + 32 * i));
+            const f32x4 v = ld4p(a.pctx + ((size_t)b * Tp + (slot < nt ? t0 + slot : 0)) * GC + 4 * (l32 + LPS * i));
             pr[i] = slot < nt ? v : zero;
         }
         for (int idx = tid; idx < nt * (PS_M / 4); idx += PS_THREADS) {
@@ -581,17 +585,17 @@ struct AttnBwdPreRole {
             // (wave-uniform base + opaque 32-bit lane offset: otherwise one 64-bit address pair per access is hoisted out
             //  of the step loop and spilled — the P rows leave no registers for that)
             const size_t sb = (size_t)s * B + b;
-            if (tid < 128) {
+            if (tid < MAXTP) {
                 const unsigned o = opaque(4u * (unsigned)(tid < Tp ? tid : 0));
                 const float av = *at_bytes(a.att + sb * Tp, o), ev = *at_bytes(a.e0 + sb * Tp, o);
                 attr[tid] = tid < Tp ? av : 0.f;
                 e0r[tid] = tid < Tp ? ev : 0.f;
             }
-            if (tid >= 128 && tid < 128 + PS_M) qs[tid - 128] = *at_bytes(a.q_all + sb * PS_M, opaque(4u * (unsigned)(tid - 128)));
-            if (slot == 31) {
+            if (tid >= MAXTP && tid < MAXTP + PS_M) qs[tid - MAXTP] = *at_bytes(a.q_all + sb * PS_M, opaque(4u * (unsigned)(tid - MAXTP)));
+            if (slot == NSLOT - 1) {
                 const float* gp = at_bytes(a.gxf + sb * GC, opaque(16u * (unsigned)l32));
 #pragma unroll
-                for (int i = 0; i < NC4; ++i) pr[i] = ld4p(gp + 128 * i);
+                for (int i = 0; i < NC4; ++i) pr[i] = ld4p(gp + 4 * LPS * i);
             }
             PB_STAMP(2, s, 0);
             // ---- the gate gradients of step s+1's bottom cell, row b: one 256-byte piece per X workgroup of this M-tile
@@ -627,17 +631,24 @@ struct AttnBwdPreRole {
             {
                 float acc = 0.f;
 #pragma unroll
-                for (int i = 0; i < NC4; ++i) acc = dot4p(pr[i], *reinterpret_cast<const f32x4*>(dg + 4 * (l32 + 32 * i)), acc);
+                for (int i = 0; i < NC4; ++i) acc = dot4p(pr[i], *reinterpret_cast<const f32x4*>(dg + 4 * (l32 + LPS * i)), acc);
                 acc = gsum<16>(acc);
-                const float s0 = lane_f(acc, 0) + lane_f(acc, 16), s1 = lane_f(acc, 32) + lane_f(acc, 48);
-                if (lane == 0) { slotv[2 * wave] = s0; slotv[2 * wave + 1] = s1; }
+                if (LPS == 32) {
+                    const float s0 = lane_f(acc, 0) + lane_f(acc, 16), s1 = lane_f(acc, 32) + lane_f(acc, 48);
+                    if (lane == 0) { slotv[2 * wave] = s0; slotv[2 * wave + 1] = s1; }
+                } else if ((lane & 15) == 0) {
+                    slotv[4 * wave + (lane >> 4)] = acc;
+                }
             }
             lds_barrier();
             // ---- softmax backward de_t = a_t (e0_t + dG0 . P_t - ctx . dctx) for its frames (one wave)
             if (wave == 0) {
-                const float c0 = wsum(attr[lane] * e0r[lane] + attr[lane + 64] * e0r[lane + 64]);
-                const float sd = c0 + slotv[31];
-                if (lane < 32) {
+                float cp = 0.f;
+#pragma unroll
+                for (int k = 0; k < MAXTP / 64; ++k) cp = fmaf(attr[lane + 64 * k], e0r[lane + 64 * k], cp);
+                const float c0 = wsum(cp);
+                const float sd = c0 + slotv[NSLOT - 1];
+                {
                     const bool valid = lane < nt;
                     const int tt = valid ? t0 + lane : 0;
                     const float v = valid ? attr[tt] * (e0r[tt] + slotv[lane] - sd) : 0.f;
@@ -734,6 +745,14 @@ bool speller_persist_bwd_eligible(int B, int Tp, int Hs, int D, int M, int V, in
     return persist_bwd_ns(B, Tp, Hs, cus) != 0;
 }
 
+// attention-backward workgroups per utterance of the PRE variant: the smallest of 4 / 8 / 16 whose frame slots (31 at Hs=512,
+// 63 at Hs=256) cover ceil(T'/ns) frames and that leaves every workgroup resident; 0 = n/a.  cus < 0: shape only.
+static int persist_bwd_pre_ns(int B, int Tp, int Hs, int cus) {
+    const int th = 1024 / (Hs / 16) - 1;
+    for (int ns = 4; ns <= 16; ns *= 2)
+        if ((Tp + ns - 1) / ns <= th && (cus < 0 || 2 * (Hs / 16) * 2 + ns * B <= cus)) return ns;
+    return 0;
+}
 // floats of the hand-off slabs + the attention workgroups' dqpre parts; 0 when the shape is not covered.  The PRE variant
 // (4 attention workgroups per utterance, no dcx / dhc slabs, plus the e0 rows) fits in the same block.
 size_t speller_persist_bwd_workspace_floats(int B, int Tp, int U, int Hs, int M) {
@@ -741,17 +760,18 @@ size_t speller_persist_bwd_workspace_floats(int B, int Tp, int U, int Hs, int M)
     const int ns = persist_bwd_ns(B, Tp, Hs, -1);
     if (ns == 0) return 0;
     const size_t classic = (size_t)ns * U * B * M + (size_t)U * B * ns * Hs + (size_t)2 * U * (Hs / 16) * 32 * 64 + (size_t)2 * (U + 1) * (Hs / 16) * 32 * 16;
-    const size_t pre = Tp <= 112 ? (size_t)4 * U * B * M + (size_t)U * B * Tp + 4 + (size_t)U * B * 4 * Hs + (size_t)2 * U * (Hs / 16) * 32 * 64 : 0;
+    const size_t nsp = (size_t)persist_bwd_pre_ns(B, Tp, Hs, -1);
+    const size_t pre = (nsp && Tp <= 448) ? nsp * U * B * M + (size_t)U * B * Tp + 4 + (size_t)U * B * nsp * Hs + (size_t)2 * U * (Hs / 16) * 32 * 64 : 0;
     return std::max(classic, pre);
 }
 bool speller_persist_bwd_pre_eligible(int B, int Tp, int Hs, int D, int M, int V, int L, int heads, int use_mlp) {
     static const bool on = !(getenv("LAS_SPELLER_PRE_BWD") && atoi(getenv("LAS_SPELLER_PRE_BWD")) == 0);
-    if (!on || !persist_bwd_shape(B, Hs, D, M, L, heads, use_mlp) || Tp > 112) return false;
+    if (!on || !persist_bwd_shape(B, Hs, D, M, L, heads, use_mlp) || Tp > 448) return false;
     if (!speller_persist_pre_eligible(B, Tp, Hs, D, M, V, L, heads, use_mlp)) return false;      // the forward must have produced P and gx
     int cus = 0, dev = 0;
     if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess)
         return false;
-    return 2 * (Hs / 16) * 2 + 4 * B <= cus;
+    return persist_bwd_pre_ns(B, Tp, Hs, cus) != 0;
 }
 
 template <int HS>
@@ -786,7 +806,7 @@ int speller_persist_bwd(const PersistBwd& p, hipStream_t stream) {
     LAS_HIP_CHECK(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
     PersistBwdArgs a;
     a.pctx = p.pctx; a.gxf = p.gxf; a.e0 = nullptr;
-    a.ns = p.pctx ? 4 : persist_bwd_ns(p.B, p.Tp, p.Hs, cus);
+    a.ns = p.pctx ? persist_bwd_pre_ns(p.B, p.Tp, p.Hs, cus) : persist_bwd_ns(p.B, p.Tp, p.Hs, cus);
     a.w_ih0 = p.w_ih0; a.ldw0 = p.V + p.Hs; a.V = p.V;
     a.w_hh0 = p.w_hh0; a.w_ih1 = p.w_ih1; a.w_hh1 = p.w_hh1; a.w_phi = p.w_phi;
     a.feat = p.feat; a.keys = p.keys; a.att = p.att; a.q_all = p.q_all; a.ctx_all = p.ctx_all;
@@ -797,13 +817,13 @@ int speller_persist_bwd(const PersistBwd& p, hipStream_t stream) {
     const size_t nq = (size_t)p.U * p.B * PS_M;
     a.dqpre_part = p.xbuf;
     if (p.pctx) {
-        // PRE variant: [dqpre parts (4) | e0 | sentinel-prefilled slabs: dhA (4 parts) | tiled dG (2 layers)]
-        LAS_REQUIRE(p.gxf && p.Tp <= 112, "persistent speller backward (pre) buffers");
-        float* e0 = p.xbuf + 4 * nq;
+        // PRE variant: [dqpre parts (ns) | e0 | sentinel-prefilled slabs: dhA (ns parts) | tiled dG (2 layers)]
+        LAS_REQUIRE(p.gxf && a.ns != 0, "persistent speller backward (pre) buffers");
+        float* e0 = p.xbuf + (size_t)a.ns * nq;
         float* slabs = e0 + (((size_t)p.U * p.B * p.Tp + 3) & ~(size_t)3);
         a.e0 = e0;
         a.dhA = slabs;
-        a.dGx = a.dhA + (size_t)p.U * p.B * 4 * p.Hs;
+        a.dGx = a.dhA + (size_t)p.U * p.B * a.ns * p.Hs;
         a.dcx = nullptr; a.dhc = nullptr;
         a.w_ih0 = p.w_ih0; a.ldw0 = p.V + p.Hs; a.V = p.V;
         a.w_hh0 = p.w_hh0; a.w_ih1 = p.w_ih1; a.w_hh1 = p.w_hh1; a.w_phi = p.w_phi;
@@ -820,13 +840,13 @@ int speller_persist_bwd(const PersistBwd& p, hipStream_t stream) {
             g.M = p.U; g.N = p.Tp; g.K = p.Hs; g.batch = p.B; g.splitk = 1;
             LAS_TRY(gemm_f32(g, stream));
         }
-        const size_t slab_floats = (size_t)p.U * p.B * 4 * p.Hs + (size_t)2 * p.U * (p.Hs / 16) * 32 * 64;
+        const size_t slab_floats = (size_t)p.U * p.B * a.ns * p.Hs + (size_t)2 * p.U * (p.Hs / 16) * 32 * 64;
         LAS_HIP_CHECK(hipMemsetAsync(slabs, 0xFF, sizeof(float) * slab_floats, stream));
-        const int grid = 2 * (p.Hs / 16) * 2 + 4 * p.B;
+        const int grid = 2 * (p.Hs / 16) * 2 + a.ns * p.B;
         if (p.Hs == 512) LAS_TRY(launch_persist_bwd_pre<512>(a, grid, stream));
         else LAS_TRY(launch_persist_bwd_pre<256>(a, grid, stream));
         LAS_HIP_CHECK(hipMemcpyAsync(p.dqpre_all, a.dqpre_part, sizeof(float) * nq, hipMemcpyDeviceToDevice, stream));
-        for (int k = 1; k < 4; ++k) LAS_TRY(add_inplace(p.dqpre_all, a.dqpre_part + (size_t)k * nq, (long)nq, stream));
+        for (int k = 1; k < a.ns; ++k) LAS_TRY(add_inplace(p.dqpre_all, a.dqpre_part + (size_t)k * nq, (long)nq, stream));
         return LAS_OK;
     }
     float* slabs = p.xbuf + (size_t)a.ns * nq;

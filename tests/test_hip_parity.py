@@ -302,6 +302,41 @@ def test_persistent_decode_kernel_without_attention_activation():
     _persistent_vs_stepwise("S", 9, 40, 6, None, "None")
 
 
+@pytest.mark.parametrize("cfg_name,B,Tp,U", [("P", 32, 100, 16), ("P", 7, 57, 5), ("S", 20, 111, 6), ("S", 32, 200, 5), ("P", 16, 200, 4),
+                                             ("P", 8, 375, 4), ("S", 16, 300, 4)])
+def test_pre_multiplied_context_backward_matches_classic_persistent_backward(cfg_name, B, Tp, U):
+    """las_speller_bwd with and without LAS_FLAG_TEACHER_FORCED on the SAME forward stash: with the flag the attention-backward
+    workgroups contract the gate gradients with feat.W_ctx^T (speller_persist_bwd_pre_kernel), without it the classic
+    persistent backward multiplies dG0 W_ctx on the chain.  Same gradients either way (fp32 re-association only)."""
+    from las_pytorch_amd import Speller, synth
+    from las_pytorch_amd.model import las_model as M
+    c = synth.CONFIGS[cfg_name]
+    torch.manual_seed(9)
+    sp = Speller(vocab_size=c["V"], hidden_size=c["Hs"], rnn_unit="LSTM", num_layers=c["Ls"], max_label_len=U,
+                 use_mlp_in_attention=True, mlp_dim_in_attention=c["M"], mlp_activate_in_attention="relu",
+                 listener_hidden_size=c["H"], multi_head=1, decode_mode=1).cuda()
+    feat0 = torch.randn(B, Tp, 2 * c["H"], device="cuda") * 0.5
+    idx, lens = synth.make_labels(B, U, c["V"], seed=3, ragged=True)
+    lab = torch.from_numpy(synth.onehot_labels(idx, lens, c["V"])).cuda()
+    w = torch.randn(U, B, c["V"], device="cuda")
+    res = []
+    saved = M.FLAG_TEACHER_FORCED
+    for flag in (saved, 0):
+        M.FLAG_TEACHER_FORCED = flag
+        try:
+            sp.zero_grad(set_to_none=True)
+            feat = feat0.clone().requires_grad_(True)
+            preds, _ = sp(feat, ground_truth=lab, teacher_force_rate=1.0)
+            (torch.stack(preds) * w).sum().backward()
+            res.append(dict(dfeat=feat.grad.cpu().numpy(), **{"d" + n: p.grad.cpu().numpy() for n, p in sp.named_parameters()}))
+        finally:
+            M.FLAG_TEACHER_FORCED = saved
+    for k in res[0]:
+        scale_k = float(np.abs(res[1][k]).max()) + 1e-30
+        assert_close(res[0][k], res[1][k], f"pre vs classic persistent backward {k}", rtol=1e-3, atol=1e-5 * max(1.0, scale_k))
+    _check_err()
+
+
 def _persistent_vs_stepwise(cfg_name, B, Tp, U, scale, activate):
     """The one-launch teacher-forced decode loop (speller_persist.hip) against the per-step launch chain it replaces:
     outputs and every gradient (the backward pass consumes the stash the forward kernel wrote).  The larger-weight
