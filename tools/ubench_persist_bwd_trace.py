@@ -1,5 +1,6 @@
 """Per-phase timeline of the persistent Speller backward kernel (speller_persist_bwd.hip): workgroup 0 of each role
-(X: bottom-layer products, Y: top-layer cell + context product, A: attention backward) stamps the wall clock."""
+(X: bottom-layer products, Y: top-layer cell + context product, A: attention backward) stamps the wall clock.
+The phase labels describe the CLASSIC kernel (roles X / Y / R / A): run with LAS_SPELLER_PRE_BWD=0 for them.  With the pre-multiplied-context variant (default where eligible) role slot 1 is RY (0: wait for the attention parts, 1: parts in, 2: dG1 published, 3: carry done), role slot 2 is the attention backward (0: stash loaded, 1: gate-gradient row in, 2: de done, 3: dq done, 4: part published); the whole-kernel span is the reliable number."""
 import ctypes, os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch

@@ -1,5 +1,6 @@
 """Per-phase timeline of the persistent Speller decode kernel (speller_persist.hip): workgroup 0 of each role stamps
-the shader clock at its phase boundaries; this prints the mean duration of every phase in microseconds."""
+the shader clock at its phase boundaries; this prints the mean duration of every phase in microseconds.
+With the pre-multiplied-context variant (default where eligible; LAS_SPELLER_PRE=0 selects the classic kernel) "wait ctx" is the cell lanes' wait for the attention workgroups' gx slab and "layer0 mfma+cell" is the cell step alone (the products were reduced ahead of the chain). s_memrealtime stamps cost ~0.3 us each in the stamped workgroup: the whole-kernel span is the reliable number."""
 import ctypes, os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
