@@ -53,13 +53,14 @@ struct SpellerLayout {
         q_all = o; if (d->use_mlp) o += r4((size_t)U * B * d->M * d->multi_head);
         ctxcat_all = o; if (d->multi_head > 1) o += r4((size_t)U * B * d->multi_head * d->D);   // per-head contexts (dim_reduce input)
         w0p = o; o += r4((size_t)4 * d->Hs * (Vp + d->Hs));      // W_ih0 re-laid as [W_y | 0 | W_ctx], ld = Vp + Hs
-        hx = o; if (d->L == 2) o += r4((size_t)2 * U * 32 * d->Hs);   // hand-off copy of h for the persistent decode kernel
-        lgx = o; if (d->L == 2) o += r4((size_t)U * B * 8 * 32);      // ... and its partial logits (free-running decode)
         // pre-multiplied context variant: row-permuted W_ctx, feat . W_ctx^T, and the per-step hand-off slabs of its weighted sums
+        // (gx directly behind hx: one sentinel fill covers both)
         pre = speller_persist_pre_shape(d->B, d->Tp, d->Hs, d->D, d->M, d->V, d->L, d->multi_head, d->use_mlp);
+        hx = o; if (d->L == 2) o += r4((size_t)2 * U * 32 * d->Hs);   // hand-off copy of h for the persistent decode kernel
+        gx = o; if (pre) o += r4((size_t)U * B * 4 * d->Hs);
+        lgx = o; if (d->L == 2) o += r4((size_t)U * B * 8 * 32);      // ... and its partial logits (free-running decode)
         wperm = o; if (pre) o += r4((size_t)4 * d->Hs * d->Hs);
         pctx = o; if (pre) o += r4((size_t)B * d->Tp * 4 * d->Hs);
-        gx = o; if (pre) o += r4((size_t)U * B * 4 * d->Hs);
         total = o;
     }
 };

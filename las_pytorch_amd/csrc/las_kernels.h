@@ -194,6 +194,7 @@ struct ColsumJob { const float* src; long ld; int rows; int cols; float* dst; fl
 int colsum_multi(const ColsumJob* jobs, int n, int zeroed, hipStream_t stream);
 int act_bwd_inplace(float* grad, const float* act, long n, int code, hipStream_t stream);                    // grad *= act'(.) (LAS_ACT_* code)
 int add_inplace(float* dst, const float* src, long n, hipStream_t stream);
+int sum_parts(float* dst, const float* src, long n, long stride, int parts, hipStream_t stream);   // dst[i] = sum_k src[k*stride+i]
 int act_inplace(float* x, long n, int code, hipStream_t stream);
 int copy2d(const float* src, long lds, float* dst, long ldd, int rows, int cols, int accumulate, hipStream_t stream);
 int log_softmax_rows(float* x, long rows, int V, hipStream_t stream);

@@ -128,6 +128,20 @@ int add_inplace(float* dst, const float* src, long n, hipStream_t stream) {
     return LAS_OK;
 }
 
+// dst[i] = sum_k src[k*stride + i]: the parts several workgroups of one utterance produced, summed in a fixed order
+__global__ void sum_parts_kernel(float* __restrict__ dst, const float* __restrict__ src, long n, long stride, int parts) {
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    float acc = src[i];
+    for (int k = 1; k < parts; ++k) acc += src[(long)k * stride + i];
+    dst[i] = acc;
+}
+int sum_parts(float* dst, const float* src, long n, long stride, int parts, hipStream_t stream) {
+    hipLaunchKernelGGL(sum_parts_kernel, dim3(cdiv(n, 256)), dim3(256), 0, stream, dst, src, n, stride, parts);
+    LAS_LAUNCH_CHECK();
+    return LAS_OK;
+}
+
 // dst[r][c] (+)= src[r][c] for a rows x cols window with independent leading dimensions
 __global__ void copy2d_kernel(const float* __restrict__ src, long lds, float* __restrict__ dst, long ldd, int rows, int cols,
                               int accumulate) {

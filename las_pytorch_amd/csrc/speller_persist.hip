@@ -938,8 +938,12 @@ int speller_persist_fwd(const PersistFwd& p, hipStream_t stream) {
         const int ws = speller_persist_pre_ws(p.B, p.Tp, p.Hs, cus);
         LAS_REQUIRE(p.mode == 0 && p.gx && ws != 0 && speller_persist_pre_shape(p.B, p.Tp, p.Hs, p.Hs, PS_M, p.V, 2, 1, 1), "persistent speller (pre) shape");
         a.split = ws;
-        LAS_HIP_CHECK(hipMemsetAsync(p.hx, 0xFF, sizeof(float) * 2 * p.U * 32 * p.Hs, stream));
-        LAS_HIP_CHECK(hipMemsetAsync(p.gx, 0xFF, sizeof(float) * (size_t)p.U * p.B * 4 * p.Hs, stream));
+        if (p.gx == p.hx + (size_t)2 * p.U * 32 * p.Hs) {      // adjacent (the layout las_capi.hip uses): one fill
+            LAS_HIP_CHECK(hipMemsetAsync(p.hx, 0xFF, sizeof(float) * ((size_t)2 * p.U * 32 * p.Hs + (size_t)p.U * p.B * 4 * p.Hs), stream));
+        } else {
+            LAS_HIP_CHECK(hipMemsetAsync(p.hx, 0xFF, sizeof(float) * 2 * p.U * 32 * p.Hs, stream));
+            LAS_HIP_CHECK(hipMemsetAsync(p.gx, 0xFF, sizeof(float) * (size_t)p.U * p.B * 4 * p.Hs, stream));
+        }
         const int grid = p.Hs / 4 + ws * p.B;
         if (p.Hs == 512)
             return ws == 4 ? launch_persist_fwd_pre<512, 4>(a, grid, stream)

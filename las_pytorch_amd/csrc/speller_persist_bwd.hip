@@ -845,8 +845,7 @@ int speller_persist_bwd(const PersistBwd& p, hipStream_t stream) {
         const int grid = 2 * (p.Hs / 16) * 2 + a.ns * p.B;
         if (p.Hs == 512) LAS_TRY(launch_persist_bwd_pre<512>(a, grid, stream));
         else LAS_TRY(launch_persist_bwd_pre<256>(a, grid, stream));
-        LAS_HIP_CHECK(hipMemcpyAsync(p.dqpre_all, a.dqpre_part, sizeof(float) * nq, hipMemcpyDeviceToDevice, stream));
-        for (int k = 1; k < a.ns; ++k) LAS_TRY(add_inplace(p.dqpre_all, a.dqpre_part + (size_t)k * nq, (long)nq, stream));
+        LAS_TRY(sum_parts(p.dqpre_all, a.dqpre_part, (long)nq, (long)nq, a.ns, stream));      // the relu mask is linear in dq
         return LAS_OK;
     }
     float* slabs = p.xbuf + (size_t)a.ns * nq;
@@ -861,8 +860,7 @@ int speller_persist_bwd(const PersistBwd& p, hipStream_t stream) {
     if (p.Hs == 512) LAS_TRY(launch_persist_bwd<512>(a, grid, stream));
     else LAS_TRY(launch_persist_bwd<256>(a, grid, stream));
     // dqpre = sum of the attention workgroups' parts (the relu mask is linear in dq)
-    LAS_HIP_CHECK(hipMemcpyAsync(p.dqpre_all, a.dqpre_part, sizeof(float) * nq, hipMemcpyDeviceToDevice, stream));
-    for (int k = 1; k < a.ns; ++k) LAS_TRY(add_inplace(p.dqpre_all, a.dqpre_part + (size_t)k * nq, (long)nq, stream));
+    LAS_TRY(sum_parts(p.dqpre_all, a.dqpre_part, (long)nq, (long)nq, a.ns, stream));
     return LAS_OK;
 }
 
