@@ -837,7 +837,13 @@ int speller_persist_bwd(const PersistBwd& p, hipStream_t stream) {
             g.A = p.dcat_all + p.Hs; g.lda = (long)p.B * 2 * p.Hs; g.a_kc = true; g.sA = 2 * p.Hs;
             g.B = p.feat; g.ldb = p.Hs; g.b_kc = true; g.sB = (long)p.Tp * p.Hs;
             g.C = e0; g.ldc = (long)p.B * p.Tp; g.sC = p.Tp;
-            g.M = p.U; g.N = p.Tp; g.K = p.Hs; g.batch = p.B; g.splitk = 1;
+            g.M = p.U; g.N = p.Tp; g.K = p.Hs; g.batch = p.B;
+            // one 128x128 tile per utterance and 32 k-tiles: split K so that the launch covers the chip (atomics onto a zeroed e0)
+            g.splitk = p.B * ((p.U + 127) / 128) * ((p.Tp + 127) / 128) < 128 ? std::max(1, std::min(8, p.Hs / 64)) : 1;
+            if (g.splitk > 1) {
+                LAS_HIP_CHECK(hipMemsetAsync(e0, 0, sizeof(float) * (size_t)p.U * p.B * p.Tp, stream));
+                g.c_zeroed = true;
+            }
             LAS_TRY(gemm_f32(g, stream));
         }
         const size_t slab_floats = (size_t)p.U * p.B * a.ns * p.Hs + (size_t)2 * p.U * (p.Hs / 16) * 32 * 64;
