@@ -167,7 +167,9 @@ size_t las_speller_bwd_workspace_floats(const las_speller_desc* d, int U);
 /* dlogp (U,B,V): gradient of the loss wrt the returned log-probs.  feedback_mode0: the forward ran
  * free-running with decode_mode 0 (gradient flows through the fed-back log-probs).
  * err_word / flags: as las_speller_fwd (the persistent backward kernel needs the error word; NULL or
- * LAS_FLAG_FORCE_GENERIC selects the per-step launch chain). */
+ * LAS_FLAG_FORCE_GENERIC selects the per-step launch chain).  Add LAS_FLAG_TEACHER_FORCED when the forward call that filled
+ * `reserve` was teacher-forced (same flags, same err_word): the backward then reuses the feat.W_ctx^T product and the
+ * per-step attention-weighted sums that forward left in `reserve` instead of multiplying dG0.W_ctx on the decode chain. */
 int las_speller_bwd(const las_speller_desc* d, const float* feat, const float* keys,
                     const float* logp, const float* att, const float* dlogp, int U, int feedback_mode0,
                     const float* reserve, float* workspace, const las_speller_grads* g, uint32_t* err_word, int flags,
