@@ -43,3 +43,10 @@ print("chain : A publishes -> Y has parts %.2f | Y published dG1 -> X has it %.2
     us(Y[:, 1] - A[:, 4]), us(X[:, 1] - Y[:, 2]), us(Y[:, 4] - X[:, 2]), us(A[:-1, 1] - Y[1:, 5]), us(A[:-1, 4] - A[1:, 4])))
 print("X1 detail: mfma %.2f | reduce %.2f | cell bwd + stores %.2f" % (us(X[:, 6] - X[:, 1]), us(X[:, 7] - X[:, 6]), us(X[:, 2] - X[:, 7])))
 print("Y3 detail: mfma %.2f | reduce %.2f | publish %.2f" % (us(Y[:, 6] - Y[:, 4]), us(Y[:, 7] - Y[:, 6]), us(Y[:, 5] - Y[:, 7])))
+# pre-multiplied-context variant (roles X / RY / A, see the module docstring): the chain A -> RY -> X -> A(s-1)
+RY = Y
+print("PRE   : A: wait dG0 row %.2f | contraction+de %.2f | dq %.2f | W_phi^T dq + publish %.2f || RY: wait parts %.2f | cell bwd + publish dG1 %.2f | carry (off chain) %.2f" % (
+    us(A[:, 1] - A[:, 0]), us(A[:, 2] - A[:, 1]), us(A[:, 3] - A[:, 2]), us(A[:, 4] - A[:, 3]),
+    us(RY[:, 1] - RY[:, 0]), us(RY[:, 2] - RY[:, 1]), us(RY[:, 3] - RY[:, 2])))
+print("PRE chain: A published -> RY has parts %.2f | RY published dG1 -> X has it %.2f | X published dG0 -> A(s-1) has its row %.2f | A(s-1) row in -> published %.2f | period %.2f" % (
+    us(RY[:, 1] - A[:, 4]), us(X[:, 1] - RY[:, 2]), us(A[:-1, 1] - X[1:, 2]), us(A[:, 4] - A[:, 1]), us(A[:-1, 4] - A[1:, 4])))
