@@ -262,7 +262,10 @@ __global__ __launch_bounds__(UW * (H / 16)) void rec_fwd_fast(float* __restrict_
 // members' h for all NB utterances.  The two barriers and the inter-CU hand-off latency of a step are paid once per NB
 // utterances, and the launch never needs more than 2*ceil(B/NB)*G <= #CU resident workgroups, whatever the batch.
 // ------------------------------------------------------------------------------------------------
-template <int H, int UW, int NB, bool STASH>
+// PIPE (G > 1): the block's utterances are stepped as two halves half a step apart — while every thread multiplies one half's
+// h by the resident W_hh slice, the other half's cell waves apply the cell and publish, and its foreign h components travel
+// between the CUs: the inter-CU hand-off and the cell wave's dependent chain hide behind the other half's mat-vecs.
+template <int H, int UW, int NB, bool STASH, bool PIPE = false>
 __global__ __launch_bounds__(UW * (H / 16)) void rec_fwd_multi(float* __restrict__ gates, const float* __restrict__ w_hh_f,
                                                                const float* __restrict__ w_hh_r, float* __restrict__ out,
                                                                float* __restrict__ cbuf, float* __restrict__ hprev, int B,
@@ -320,6 +323,83 @@ __global__ __launch_bounds__(UW * (H / 16)) void rec_fwd_multi(float* __restrict
     const int nvalid = min(NB, Bc - blk * NB);   // live utterances of this block
 
     int cur = 0;
+    if (PIPE) {
+        constexpr int NBH = NB / 2;
+        static_assert(!PIPE || (NB >= 2 && NB % 2 == 0 && G > 1), "pipelined stepping needs two halves and a hand-off to hide");
+        auto matvec = [&](int u0, int buf) {          // gsum[u] = W_hh slice . h_u for the NBH utterances from u0
+#pragma unroll
+            for (int uu = 0; uu < NBH; ++uu) {
+                const int u = u0 + uu;
+                f32x4 hv[4];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) hv[i] = *reinterpret_cast<const f32x4*>(&hs[buf][u][i * 4 * LPU + kc * 4]);
+                float acc[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+#pragma unroll
+                    for (int e = 0; e < 4; ++e)
+#pragma unroll
+                        for (int g = 0; g < 4; ++g) acc[g] = fmaf(w[g][i][e], hv[i][e], acc[g]);
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    acc[g] = row_sum<(LPU < 16 ? LPU : 16)>(acc[g]);
+                    if (LPU > 16) acc[g] += __shfl_xor(acc[g], 16);
+                }
+                if (kc == 0) *reinterpret_cast<f32x4*>(&gsum[u][ul][0]) = f32x4{acc[0], acc[1], acc[2], acc[3]};
+            }
+        };
+        auto cellstep = [&](int step, int t, unsigned epoch) {
+            const f32x4 s4 = *reinterpret_cast<const f32x4*>(&gsum[cu][tid % UW][0]);
+            const float ig = sigmoidf_acc(s4[0] + pre[0]);
+            const float fg = sigmoidf_acc(s4[1] + pre[1]);
+            const float gg = tanhf_acc(s4[2] + pre[2]);
+            const float og = sigmoidf_acc(s4[3] + pre[3]);
+            c = fg * c + ig * gg;
+            const float h = og * tanhf_acc(c);
+            u64* gp64 = xg + ((long)(step & 1) * NB + cu) * H + jc;
+            if (l2x) publish_granule_l2(gp64, epoch, h); else publish_granule(gp64, epoch, h);
+            const float hp = hs[cur][cu][jc];
+            hs[cur ^ 1][cu][jc] = h;
+            out[((long)b * T + t) * 2 * H + dir * H + jc] = h;
+            if (STASH) {
+                hprev[(seq + t) * H + jc] = hp;
+                cbuf[(seq + t) * H + jc] = c;
+                float* gp = gb + (long)t * 4 * H;
+                gp[0] = ig; gp[H] = fg; gp[2 * H] = gg; gp[3 * H] = og;
+            }
+            if (step + 1 < T) {      // next step's pre-activations: consumed a whole step from now
+                const int tn = dir ? t - 1 : t + 1;
+#pragma unroll
+                for (int g = 0; g < 4; ++g) pre[g] = gb[(long)tn * 4 * H + g * H];
+            }
+        };
+        auto gather = [&](int u0, int step, unsigned epoch) {     // foreign h of the live utterances among [u0, u0 + NBH)
+            const int nv = max(0, min(NBH, nvalid - u0));
+            for (int fidx = tid - PS; fidx < nv * (H - UW); fidx += NT - PS) {
+                const int u = u0 + fidx / (H - UW), f = fidx % (H - UW);
+                const int fu = f < member * UW ? f : f + UW;
+                hs[cur ^ 1][u][fu] = poll_granule(xg + ((long)(step & 1) * NB + u) * H + fu, epoch, err);
+            }
+        };
+        matvec(0, 0);                  // h_{-1} = 0
+        lds_barrier();
+        for (int step = 0; step < T; ++step) {
+            const int t = dir ? T - 1 - step : step;
+            const unsigned epoch = (unsigned)step + 1u;
+            // phase 1: cells of the first half | mat-vecs of the second half | foreign h of the first half
+            if (cell && cu < NBH) cellstep(step, t, epoch);
+            matvec(NBH, cur);
+            if (poller) gather(0, step, epoch);
+            lds_barrier();
+            // phase 2: cells of the second half | next step's mat-vecs of the first half | foreign h of the second half
+            if (cell && cu >= NBH) cellstep(step, t, epoch);
+            if (step + 1 < T) matvec(0, cur ^ 1);
+            if (poller) gather(NBH, step, epoch);
+            lds_barrier();
+            cur ^= 1;
+        }
+        return;
+    }
     for (int step = 0; step < T; ++step) {
         const int t = dir ? T - 1 - step : step;
         const unsigned epoch = (unsigned)step + 1u;
@@ -857,6 +937,7 @@ int pblstm_rec_fwd(float* gates, const float* w_hh_f, const float* w_hh_r, float
     static const int dbg = env_int("LAS_REC_AGENT_HANDOFF", 0);
     static const int uw_env = env_int("LAS_REC_UW", 0);
     static const int nb_env = env_int("LAS_REC_NB", 0);          // force the utterances per group (A/B tests)
+    static const bool pipe_on = env_int("LAS_REC_PIPE", 1) != 0;  // 0: lock-step multi-utterance kernels instead of the pipelined halves
     // UW: hidden units per workgroup (measured best on MI355X: one CU holds 256 KB of W_hh)
     const int uw = uw_env > 0 ? uw_env : (H == 128 ? 128 : (H == 256 ? 64 : 32));
     RecPlan plan = {0, 0};
@@ -889,12 +970,22 @@ int pblstm_rec_fwd(float* gates, const float* w_hh_f, const float* w_hh_r, float
 #define TRY_FWD_M(HH, UWV, NBV)                                                                                           \
     if (!launched && plan.nb == NBV && H == HH && uw == UWV) {                                                           \
         launched = true;                                                                                                  \
-        fits = persistent_launch_fits(rec_fwd_multi<HH, UWV, NBV, true>, block.x, 0, grid.x);                             \
-        if (!fits) break;                                                                                                 \
-        if (stash) hipLaunchKernelGGL((rec_fwd_multi<HH, UWV, NBV, true>), grid, block, 0, stream, gates, w_hh_f, w_hh_r, \
-                                      out, cbuf, hprev, B, T, xbuf, err, dbg, b0, Bc);                                    \
-        else hipLaunchKernelGGL((rec_fwd_multi<HH, UWV, NBV, false>), grid, block, 0, stream, gates, w_hh_f, w_hh_r, out, \
-                                cbuf, hprev, B, T, xbuf, err, dbg, b0, Bc);                                               \
+        constexpr bool PP = (HH / UWV) > 1;      /* pipelined halves where there is an inter-CU hand-off to hide */       \
+        if (PP && pipe_on) {                                                                                              \
+            fits = persistent_launch_fits(rec_fwd_multi<HH, UWV, NBV, true, PP>, block.x, 0, grid.x);                     \
+            if (!fits) break;                                                                                             \
+            if (stash) hipLaunchKernelGGL((rec_fwd_multi<HH, UWV, NBV, true, PP>), grid, block, 0, stream, gates, w_hh_f, \
+                                          w_hh_r, out, cbuf, hprev, B, T, xbuf, err, dbg, b0, Bc);                        \
+            else hipLaunchKernelGGL((rec_fwd_multi<HH, UWV, NBV, false, PP>), grid, block, 0, stream, gates, w_hh_f,      \
+                                    w_hh_r, out, cbuf, hprev, B, T, xbuf, err, dbg, b0, Bc);                              \
+        } else {                                                                                                          \
+            fits = persistent_launch_fits(rec_fwd_multi<HH, UWV, NBV, true>, block.x, 0, grid.x);                         \
+            if (!fits) break;                                                                                             \
+            if (stash) hipLaunchKernelGGL((rec_fwd_multi<HH, UWV, NBV, true>), grid, block, 0, stream, gates, w_hh_f,     \
+                                          w_hh_r, out, cbuf, hprev, B, T, xbuf, err, dbg, b0, Bc);                        \
+            else hipLaunchKernelGGL((rec_fwd_multi<HH, UWV, NBV, false>), grid, block, 0, stream, gates, w_hh_f, w_hh_r,  \
+                                    out, cbuf, hprev, B, T, xbuf, err, dbg, b0, Bc);                                      \
+        }                                                                                                                 \
     }
             TRY_FWD(128, 128) TRY_FWD(128, 64) TRY_FWD(128, 32) TRY_FWD(128, 16)
             TRY_FWD(256, 64) TRY_FWD(256, 32) TRY_FWD(256, 16)
