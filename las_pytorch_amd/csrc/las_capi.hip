@@ -599,7 +599,6 @@ int las_speller_bwd(const las_speller_desc* d, const float* feat, const float* k
     float* de_all = workspace + wl.de_all;
     float* dqpre_all = workspace + wl.dqpre_all;
     float* dh_top = workspace + wl.dh_top;
-    float* dh_below = workspace + wl.dh_below;
     float* dh_carry = workspace + wl.dh_carry;
     float* dc_carry = workspace + wl.dc_carry;
     float* dx0 = workspace + wl.dx0;

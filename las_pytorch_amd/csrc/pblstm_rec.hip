@@ -323,7 +323,7 @@ __global__ __launch_bounds__(UW * (H / 16)) void rec_fwd_multi(float* __restrict
     const int nvalid = min(NB, Bc - blk * NB);   // live utterances of this block
 
     int cur = 0;
-    if (PIPE) {
+    if constexpr (PIPE) {
         constexpr int NBH = NB / 2;
         static_assert(!PIPE || (NB >= 2 && NB % 2 == 0 && G > 1), "pipelined stepping needs two halves and a hand-off to hide");
         auto matvec = [&](int u0, int buf) {          // gsum[u] = W_hh slice . h_u for the NBH utterances from u0
