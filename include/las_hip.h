@@ -237,6 +237,14 @@ typedef struct las_gemm_desc {
     int a_kc, b_kc, accumulate, c_zeroed;
 } las_gemm_desc;
 int las_gemm_f32_group(const las_gemm_desc* descs, int n, void* stream);
+/* Arithmetic of the MFMA GEMMs' interior tiles (process-wide; initial value from LAS_GEMM_ARITH):
+ *   0  v_mfma_f32_32x32x2_f32 (fp32 operands on the fp32 matrix pipe)
+ *   1  every fp32 operand split EXACTLY into three bf16 terms in registers, six of the nine partial products on
+ *      v_mfma_f32_32x32x16_bf16 with fp32 accumulation; the dropped terms are below 2^-26 of |a*b|, i.e. the result is as
+ *      accurate as mode 0 (tests/test_hip_kernels.py measures both against float64) at 2.67x its matrix-pipe roofline.
+ * Replaces nothing in the reference (ATen picks its own GEMM kernels, model/las_model.py:90,279). */
+int las_gemm_get_arith(void);
+void las_gemm_set_arith(int mode);
 /* recurrence only: gates (2,B,T,4H) pre-activations in, see las_pblstm_fwd for the rest */
 size_t las_rec_xbuf_bytes(int B, int H);
 int las_pblstm_rec_fwd(float* gates, const float* w_hh_f, const float* w_hh_r, float* out, float* cbuf, float* hprev,

@@ -15,6 +15,7 @@
 #include "las_kernels.h"
 #include <stdlib.h>
 #include <algorithm>
+#include <type_traits>
 
 namespace las {
 
@@ -27,12 +28,92 @@ namespace las {
 #ifndef LAS_GEMM_PF
 #define LAS_GEMM_PF 1
 #endif
+#ifndef LAS_GEMM_ARITH_DEFAULT
+#define LAS_GEMM_ARITH_DEFAULT 0
+#endif
 constexpr int BM = 128, BN = 128, BK = LAS_GEMM_BK, PAD = 4, GEMM_THREADS = 256, PF = LAS_GEMM_PF;
 constexpr int NLD = BM * BK / 4 / GEMM_THREADS;     // float4 loads per thread per operand tile
 constexpr int KQ = BK / 4;                           // float4 per K-contiguous row segment
 
 typedef __attribute__((address_space(3))) void* lds_ptr_t;
 static __device__ __forceinline__ lds_ptr_t to_lds(float* p) { return (lds_ptr_t)p; }     // generic -> LDS address space
+
+// ---- split-operand arithmetic (LAS_GEMM_ARITH=1) ------------------------------------------------------------------------
+// fp32 MFMA runs at 1/16 of the bf16 MFMA rate on gfx950.  Every fp32 value is the EXACT sum of three bf16 values
+// (x = x1 + x2 + x3 with x1 = rne_bf16(x), x2 = rne_bf16(x - x1), x3 = x - x1 - x2: the residuals are exact in fp32 and the
+// third one has at most 8 significant bits left), so a*b = sum_ij a_i*b_j exactly, every a_i*b_j is exact in the fp32
+// accumulator of the bf16 MFMA (8 x 8 significant bits), and the three terms that are dropped (a2*b3, a3*b2, a3*b3) are below
+// 2^-26 |a*b| — a quarter of the rounding error of ONE fp32 multiply-add.  Six v_mfma_f32_32x32x16_bf16 per 16 k-steps replace
+// eight v_mfma_f32_32x32x2_f32 at 1/16 of the cost each: 2.67x the fp32-MFMA roofline at the accuracy of an fp32 GEMM
+// (tests/test_hip_kernels.py compares both against float64).  The split happens in registers on the way from global memory to
+// LDS; LDS holds three bf16 planes per operand as k-pairs ([plane][k/2][row] dwords), conflict-free for both store patterns and
+// for the fragment reads (4 dwords = 8 consecutive k per lane and plane).
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2;
+typedef __attribute__((ext_vector_type(2))) float f32x2;
+typedef __attribute__((ext_vector_type(4))) unsigned u32x4;
+typedef __attribute__((ext_vector_type(2))) unsigned u32x2;
+// Two LDS images of a bf16 plane (128 rows x 16 k = 1088 dwords with padding), chosen by the operand's memory orientation so
+// that stores AND fragment reads are wide and conflict-free:
+//   K-contiguous operand  : [k-half (2)][row][4 dwords]  (SP_KH dwords per half)  store 8 B per thread and plane, read one b128
+//   row-contiguous operand: [k-pair (8)][row]            (SP_LD dwords per pair)  store 16 B per thread and plane, read 4 dwords
+// either way a lane ends up with k = 8 (lane / 32) .. +7 of its row in increasing order.
+constexpr int SP_LD = BM + 8;                    // +8 dwords: the two k-halves of a fragment read land on disjoint banks
+constexpr int SP_KH = BM * 4 + 32;               // +32 dwords (128 B): the k-halves of an 8-byte store land on disjoint banks
+constexpr int SP_PLANE = (16 / 2) * SP_LD;       // one bf16 plane of one operand tile (128 rows x 16 k)
+static_assert(SP_PLANE == 2 * SP_KH, "both plane images have the same size");
+constexpr int SP_OPER = 3 * SP_PLANE;
+constexpr int SP_BUF = 2 * SP_OPER;              // A and B
+constexpr int SP_NBUF = 3;                       // tile kt is multiplied while kt+1 is read into fragments and kt+2 is stored
+constexpr int SP_SMEM_BYTES = SP_NBUF * SP_BUF * 4;
+
+static __device__ __forceinline__ unsigned pk_bf16(float a, float b) {
+    f32x2 v = {a, b};
+    return __builtin_bit_cast(unsigned, __builtin_convertvector(v, bf16x2));      // v_cvt_pk_bf16_f32 (round to nearest even)
+}
+// (x0, x1) -> three packed bf16 pairs (low half = x0) with x = p1 + p2 + p3 exactly
+static __device__ __forceinline__ void split_pair(float x0, float x1, unsigned& p1, unsigned& p2, unsigned& p3) {
+    p1 = pk_bf16(x0, x1);
+    x0 -= __uint_as_float(p1 << 16); x1 -= __uint_as_float(p1 & 0xffff0000u);
+    p2 = pk_bf16(x0, x1);
+    x0 -= __uint_as_float(p2 << 16); x1 -= __uint_as_float(p2 & 0xffff0000u);
+    p3 = pk_bf16(x0, x1);
+}
+// registers of one operand tile (two 16-byte loads per thread) -> the three LDS planes, in two halves so that the caller can
+// spread the work between its MFMA groups
+//  KC : load i covers row (t + 256 i) / 4, k = 4 ((t + 256 i) % 4) .. +3         -> half i: two k-pair dwords per plane
+//  !KC: loads 0/1 cover k = 2 (t / 32) and 2 (t / 32) + 1, rows 4 (t % 32) .. +3  -> half 0: rows 0,1; half 1: rows 2,3 and one
+//       16-byte store of the four k-pairs per plane
+template <bool KC, int HALF>
+static __device__ __forceinline__ void split_store_half(unsigned* S, const f32x4 (&reg)[NLD], u32x4 (&o)[3]) {
+    static_assert(NLD == 2 && BK == 16, "split path is written for BK = 16");
+    const int t = threadIdx.x;
+    if constexpr (KC) {
+        const int idx = t + HALF * GEMM_THREADS;
+        const int row = idx >> 2, q = idx & 3;
+        unsigned a[3], b[3];
+        split_pair(reg[HALF][0], reg[HALF][1], a[0], a[1], a[2]);
+        split_pair(reg[HALF][2], reg[HALF][3], b[0], b[1], b[2]);
+#pragma unroll
+        for (int pl = 0; pl < 3; ++pl) {
+            u32x2 v = {a[pl], b[pl]};
+            *reinterpret_cast<u32x2*>(&S[pl * SP_PLANE + (q >> 1) * SP_KH + row * 4 + (q & 1) * 2]) = v;
+        }
+    } else {
+#pragma unroll
+        for (int j = 2 * HALF; j < 2 * HALF + 2; ++j) {
+            unsigned q0, q1, q2;
+            split_pair(reg[0][j], reg[1][j], q0, q1, q2);
+            o[0][j] = q0; o[1][j] = q1; o[2][j] = q2;
+        }
+        if constexpr (HALF == 1) {
+            const int kp = t >> 5, rq = (t & 31) * 4;
+#pragma unroll
+            for (int pl = 0; pl < 3; ++pl) *reinterpret_cast<u32x4*>(&S[pl * SP_PLANE + kp * SP_LD + rq]) = o[pl];
+        }
+    }
+}
+struct SplitFrag { u32x4 a[3][2], b[3][2]; };      // [plane][32-row tile]: 8 consecutive k of this lane's row as bf16
 
 struct GemmParams {
     const float* A; const float* B; float* C; const float* bias0; const float* bias1;
@@ -128,9 +209,9 @@ __device__ __forceinline__ void store_tile(float (*S)[BM + PAD], const f32x4 (&r
 // One output tile over the k-iterations [it0, it1) (BK each): main loop + epilogue.  `atomic`: this segment is one of several
 // contributors to the tile (split-K / stream-K): accumulate with atomics onto a C that starts from zero (or from the
 // value to accumulate onto); the contributor that owns k-iteration 0 adds the biases.
-template <bool A_KC, bool B_KC>
-__device__ __forceinline__ void gemm_segment(const GemmParams& p, float (*As)[BK][BM + PAD], float (*Bs)[BK][BN + PAD], int bz, int m0,
-                                             int n0, int kbeg, int kend, bool atomic, bool add_bias) {
+template <bool A_KC, bool B_KC, bool SPLIT>
+__device__ __forceinline__ void gemm_segment(const GemmParams& p, float (*As)[BK][BM + PAD], float (*Bs)[BK][BN + PAD], unsigned* sp, int bz,
+                                             int m0, int n0, int kbeg, int kend, bool atomic, bool add_bias) {
     const float* A = p.A + (long)bz * p.sA;
     const float* B = p.B + (long)bz * p.sB;
     float* C = p.C + (long)bz * p.sC;
@@ -164,7 +245,138 @@ __device__ __forceinline__ void gemm_segment(const GemmParams& p, float (*As)[BK
     // four 16-byte loads, and the only branch is the loop itself.  Everything else (edge tiles, odd K, unaligned operands)
     // goes through the guarded loader below.
     const bool fast = p.a_vec && p.b_vec && (m0 + BM <= p.M) && (n0 + BN <= p.N) && ((kend - kbeg) % BK == 0) && ntiles > 0;
-    if (fast) {
+    if (fast && SPLIT) {
+      if constexpr (SPLIT) {
+        // Split-operand main loop (see the comment at split_pair).  Per k-tile of 16 and wave: 24 MFMAs in six groups of four (one
+        // group = one pair of planes on the 2x2 accumulators).  Three LDS buffers, ONE fragment register set, one barrier per tile:
+        // while tile kt is multiplied, its planes are replaced by those of tile kt+1 as soon as their last group has been issued
+        // (group order x2*y2, x2*y1, x1*y2, x3*y1, x1*y3, x1*y1 frees x2, y2, x3, y3 early; x1 / y1 are reloaded after the barrier,
+        // under the first group of the next tile, which does not need them), tile kt+2 is split in registers and stored to the
+        // third buffer in four slices between the groups, and the global loads of tile kt+3 are issued.
+        const int t = threadIdx.x;
+        long oA[NLD], oB[NLD];
+#pragma unroll
+        for (int i = 0; i < NLD; ++i) {
+            const int idx = t + i * GEMM_THREADS;
+            oA[i] = A_KC ? (long)(m0 + (idx >> 2)) * p.lda + (idx & 3) * 4 : (long)(2 * (t >> 5) + i) * p.lda + m0 + (t & 31) * 4;
+            oB[i] = B_KC ? (long)(n0 + (idx >> 2)) * p.ldb + (idx & 3) * 4 : (long)(2 * (t >> 5) + i) * p.ldb + n0 + (t & 31) * 4;
+        }
+        const long strideA = A_KC ? 1 : p.lda, strideB = B_KC ? 1 : p.ldb;
+        auto gload = [&](int k0, f32x4 (&ra_)[NLD], f32x4 (&rb_)[NLD]) {
+            const bool second = p.A2 != nullptr && k0 >= p.K1;          // wave-uniform
+            const float* Ab = second ? p.A2 : A;
+            const float* Bb = second ? p.B2 : B;
+            const long kk = second ? k0 - p.K1 : k0;
+#pragma unroll
+            for (int i = 0; i < NLD; ++i) ra_[i] = *reinterpret_cast<const f32x4*>(Ab + oA[i] + kk * strideA);
+#pragma unroll
+            for (int i = 0; i < NLD; ++i) rb_[i] = *reinterpret_cast<const f32x4*>(Bb + oB[i] + kk * strideB);
+        };
+        u32x4 oa[3], ob[3];
+        // fragment offsets (dwords) of this lane inside an operand buffer; the second 32-row tile of a row-contiguous operand gets
+        // an offset the compiler cannot relate to the first one, so that it pairs the dword reads inside ONE register tuple
+        // (ds_read2_b32 across the two tiles needs moves, and those moves drag the LDS wait to just behind the reads)
+        int fa[2], fb[2];
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            fa[i] = A_KC ? lk * SP_KH + (wm + i * 32 + lr) * 4 : (4 * lk) * SP_LD + wm + i * 32 + lr;
+            fb[i] = B_KC ? lk * SP_KH + (wn + i * 32 + lr) * 4 : (4 * lk) * SP_LD + wn + i * 32 + lr;
+        }
+        if constexpr (!A_KC) asm volatile("" : "+v"(fa[1]));
+        if constexpr (!B_KC) asm volatile("" : "+v"(fb[1]));
+        SplitFrag f;
+        auto rd_a = [&](int buf, int pl) {
+            const unsigned* pa = sp + buf * SP_BUF + pl * SP_PLANE;
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                if constexpr (A_KC) {
+                    f.a[pl][i] = *reinterpret_cast<const u32x4*>(pa + fa[i]);
+                } else {
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) f.a[pl][i][q] = pa[fa[i] + q * SP_LD];
+                }
+            }
+        };
+        auto rd_b = [&](int buf, int pl) {
+            const unsigned* pb = sp + buf * SP_BUF + SP_OPER + pl * SP_PLANE;
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                if constexpr (B_KC) {
+                    f.b[pl][i] = *reinterpret_cast<const u32x4*>(pb + fb[i]);
+                } else {
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) f.b[pl][i][q] = pb[fb[i] + q * SP_LD];
+                }
+            }
+        };
+        auto grp = [&](int pa, int pb) {
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, f.a[pa][i]),
+                                                                         __builtin_bit_cast(bf16x8, f.b[pb][j]), acc[i][j], 0, 0, 0);
+        };
+        f32x4 ra[2][NLD], rb[2][NLD];
+        gload(kbeg, ra[0], rb[0]);
+        if (ntiles > 1) gload(kbeg + BK, ra[1], rb[1]);
+        split_store_half<A_KC, 0>(sp, ra[0], oa); split_store_half<A_KC, 1>(sp, ra[0], oa);
+        split_store_half<B_KC, 0>(sp + SP_OPER, rb[0], ob); split_store_half<B_KC, 1>(sp + SP_OPER, rb[0], ob);
+        if (ntiles > 2) gload(kbeg + 2 * BK, ra[0], rb[0]);
+        if (ntiles > 1) {
+            split_store_half<A_KC, 0>(sp + SP_BUF, ra[1], oa); split_store_half<A_KC, 1>(sp + SP_BUF, ra[1], oa);
+            split_store_half<B_KC, 0>(sp + SP_BUF + SP_OPER, rb[1], ob); split_store_half<B_KC, 1>(sp + SP_BUF + SP_OPER, rb[1], ob);
+        }
+        __syncthreads();
+#pragma unroll
+        for (int pl = 0; pl < 3; ++pl) { rd_a(0, pl); rd_b(0, pl); }
+        // iteration kt (parity P = kt & 1): register set P holds tile kt+2; FULL: kt + 3 < ntiles, nothing to guard
+        auto step = [&](auto PC, auto FULLC, int kt, int b1, int b2) {
+            constexpr int P = decltype(PC)::value;
+            constexpr bool FULL = decltype(FULLC)::value;
+            const bool nxt = FULL || kt + 1 < ntiles, st = FULL || kt + 2 < ntiles;
+            unsigned* sa = sp + b2 * SP_BUF;
+            unsigned* sb = sa + SP_OPER;
+            if (FULL || kt + 3 < ntiles) gload(kbeg + (kt + 3) * BK, ra[P ^ 1], rb[P ^ 1]);
+            grp(1, 1);
+            if (st) split_store_half<A_KC, 0>(sa, ra[P], oa);
+            __builtin_amdgcn_sched_barrier(0);
+            grp(1, 0);
+            if (nxt) rd_a(b1, 1);
+            if (st) split_store_half<A_KC, 1>(sa, ra[P], oa);
+            __builtin_amdgcn_sched_barrier(0);
+            grp(0, 1);
+            if (nxt) rd_b(b1, 1);
+            if (st) split_store_half<B_KC, 0>(sb, rb[P], ob);
+            __builtin_amdgcn_sched_barrier(0);
+            grp(2, 0);
+            if (nxt) rd_a(b1, 2);
+            if (st) split_store_half<B_KC, 1>(sb, rb[P], ob);
+            __builtin_amdgcn_sched_barrier(0);
+            grp(0, 2);
+            if (nxt) rd_b(b1, 2);
+            __builtin_amdgcn_sched_barrier(0);
+            grp(0, 0);
+            __syncthreads();
+            if (nxt) { rd_a(b1, 0); rd_b(b1, 0); }
+            __builtin_amdgcn_sched_barrier(0);
+        };
+        int b0 = 0, kt = 0;
+        for (; kt + 4 < ntiles; kt += 2) {       // both steps of the pair are unguarded
+            const int b1 = b0 == 2 ? 0 : b0 + 1, b2 = b1 == 2 ? 0 : b1 + 1;
+            step(std::integral_constant<int, 0>{}, std::true_type{}, kt, b1, b2);
+            step(std::integral_constant<int, 1>{}, std::true_type{}, kt + 1, b2, b0);
+            b0 = b2;
+        }
+        for (; kt < ntiles; kt += 2) {
+            const int b1 = b0 == 2 ? 0 : b0 + 1, b2 = b1 == 2 ? 0 : b1 + 1;
+            step(std::integral_constant<int, 0>{}, std::false_type{}, kt, b1, b2);
+            if (kt + 1 < ntiles) step(std::integral_constant<int, 1>{}, std::false_type{}, kt + 1, b2, b0);
+            b0 = b2;
+        }
+      }
+    } else if (fast) {
+      if constexpr (!SPLIT) {
         long offA[NLD], offB[NLD];
 #pragma unroll
         for (int i = 0; i < NLD; ++i) {
@@ -260,6 +472,7 @@ __device__ __forceinline__ void gemm_segment(const GemmParams& p, float (*As)[BK
             a[0] = an[0]; a[1] = an[1]; b[0] = bn[0]; b[1] = bn[1];
         }
         __syncthreads();                             // the segment's last reads precede the next segment's first LDS writes
+      }
     } else {
     // Register-staged prefetch PF k-tiles ahead (the loads of tile kt+PF are issued before tile kt is multiplied): one tile
     // of MFMA work (2048 cycles per wave) does not cover an L2-miss round trip under load, and with two resident workgroups
@@ -351,10 +564,32 @@ __device__ __forceinline__ void gemm_segment(const GemmParams& p, float (*As)[BK
 //    tiles are combined with atomics on a C window zeroed beforehand.
 // (The parameter block is passed by value: ~100 of its SGPRs spill into VGPR lanes, which measured FASTER than fetching
 // the fields from the kernel-argument segment inside the loop.)
-template <bool A_KC, bool B_KC>
+// LDS of one workgroup: the fp32 kernels hold two K-major fp32 tiles per operand (static); the split-operand kernels take
+// SP_SMEM_BYTES of dynamic LDS (three buffers of bf16 planes) and carve the fp32 tiles of their guarded path out of it.
+template <bool SPLIT> struct GemmSmem;
+template <> struct GemmSmem<false> {
+    float (*As)[BK][BM + PAD]; float (*Bs)[BK][BN + PAD]; unsigned* sp;
+    __device__ __forceinline__ GemmSmem() {
+        __shared__ __attribute__((aligned(16))) float as_[2][BK][BM + PAD];
+        __shared__ __attribute__((aligned(16))) float bs_[2][BK][BN + PAD];
+        As = as_; Bs = bs_; sp = nullptr;
+    }
+};
+template <> struct GemmSmem<true> {
+    float (*As)[BK][BM + PAD]; float (*Bs)[BK][BN + PAD]; unsigned* sp;
+    __device__ __forceinline__ GemmSmem() {
+        extern __shared__ __attribute__((aligned(16))) unsigned dyn_[];
+        static_assert(SP_SMEM_BYTES >= (int)sizeof(float) * 2 * 2 * BK * (BM + PAD), "guarded path fits the dynamic LDS");
+        sp = dyn_;
+        As = reinterpret_cast<float (*)[BK][BM + PAD]>(dyn_);
+        Bs = reinterpret_cast<float (*)[BK][BN + PAD]>(dyn_ + 2 * BK * (BM + PAD));
+    }
+};
+
+template <bool A_KC, bool B_KC, bool SPLIT>
 __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_f32_kernel(GemmParams p) {
-    __shared__ __attribute__((aligned(16))) float As[2][BK][BM + PAD];
-    __shared__ __attribute__((aligned(16))) float Bs[2][BK][BN + PAD];
+    GemmSmem<SPLIT> sm;
+    float (*As)[BK][BM + PAD] = sm.As; float (*Bs)[BK][BN + PAD] = sm.Bs; unsigned* sp = sm.sp;
     if (!p.persistent) {
         const int bz = blockIdx.z / p.splitk, kz = blockIdx.z % p.splitk;
         // XCD-aware tile order: workgroups are dispatched round-robin over the 8 XCDs (private L2 each); remap so that
@@ -362,7 +597,7 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_f32_kernel(GemmParams p)
         int tile = blockIdx.x;
         if (p.swz) tile = (tile & 7) * (gridDim.x >> 3) + (tile >> 3);
         const int kbeg = kz * p.kper;
-        gemm_segment<A_KC, B_KC>(p, As, Bs, bz, (tile / p.gx) * BM, (tile % p.gx) * BN, kbeg, min(p.K, kbeg + p.kper), p.atomic, kz == 0);
+        gemm_segment<A_KC, B_KC, SPLIT>(p, As, Bs, sp, bz, (tile / p.gx) * BM, (tile % p.gx) * BN, kbeg, min(p.K, kbeg + p.kper), p.atomic, kz == 0);
         return;
     }
     // workgroup -> slot: blocks are dispatched round-robin over the 8 XCDs (block b on XCD b % 8, observed; speed only), so
@@ -373,7 +608,7 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_f32_kernel(GemmParams p)
     const int per_batch = p.gx * p.gy;
     for (int tile = w; tile < p.dp_tiles; tile += W) {
         const int bz = tile / per_batch, t = tile % per_batch;
-        gemm_segment<A_KC, B_KC>(p, As, Bs, bz, (t / p.gx) * BM, (t % p.gx) * BN, 0, p.K, false, true);
+        gemm_segment<A_KC, B_KC, SPLIT>(p, As, Bs, sp, bz, (t / p.gx) * BM, (t % p.gx) * BN, 0, p.K, false, true);
     }
     long i0 = (long)w * p.sk_per, i1 = min(i0 + p.sk_per, p.sk_iters);
     while (i0 < i1) {
@@ -381,7 +616,7 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_f32_kernel(GemmParams p)
         const int it0 = (int)(i0 % p.kt), it1 = (int)min((long)p.kt, it0 + (i1 - i0));
         const int bz = tile / per_batch, t = tile % per_batch;
         const bool whole = it0 == 0 && it1 == p.kt;
-        gemm_segment<A_KC, B_KC>(p, As, Bs, bz, (t / p.gx) * BM, (t % p.gx) * BN, it0 * BK, min(p.K, it1 * BK), !whole || p.sk_atomic_whole,
+        gemm_segment<A_KC, B_KC, SPLIT>(p, As, Bs, sp, bz, (t / p.gx) * BM, (t % p.gx) * BN, it0 * BK, min(p.K, it1 * BK), !whole || p.sk_atomic_whole,
                                  it0 == 0);
         i0 += it1 - it0;
     }
@@ -397,10 +632,10 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_f32_kernel(GemmParams p)
 constexpr int GROUP_MAX = 8;
 struct GemmGroupParams { GemmParams prob[GROUP_MAX]; long first[GROUP_MAX + 1]; int n; int xcd_swz; };
 
-template <bool A_KC, bool B_KC>
+template <bool A_KC, bool B_KC, bool SPLIT>
 __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_group_kernel(GemmGroupParams g) {
-    __shared__ __attribute__((aligned(16))) float As[2][BK][BM + PAD];
-    __shared__ __attribute__((aligned(16))) float Bs[2][BK][BN + PAD];
+    GemmSmem<SPLIT> sm;
+    float (*As)[BK][BM + PAD] = sm.As; float (*Bs)[BK][BN + PAD] = sm.Bs; unsigned* sp = sm.sp;
     const int W = gridDim.x;
     const int w = (W % 8 == 0 && g.xcd_swz) ? (int)(blockIdx.x & 7) * (W >> 3) + (int)(blockIdx.x >> 3) : (int)blockIdx.x;
     const long total = g.first[g.n];
@@ -418,7 +653,7 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_group_kernel(GemmGroupPa
             const int t = (int)(l0 / p.kt);
             const int it0 = (int)(l0 % p.kt), it1 = (int)min((long)p.kt, it0 + (l1 - l0));
             const bool whole = it0 == 0 && it1 == p.kt;
-            gemm_segment<A_KC, B_KC>(p, As, Bs, 0, (t / p.gx) * BM, (t % p.gx) * BN, it0 * BK, min(p.K, it1 * BK), !whole, false);
+            gemm_segment<A_KC, B_KC, SPLIT>(p, As, Bs, sp, 0, (t / p.gx) * BM, (t % p.gx) * BN, it0 * BK, min(p.K, it1 * BK), !whole, false);
             l0 += it1 - it0;
         }
         i0 = pend;
@@ -437,6 +672,57 @@ __global__ __launch_bounds__(256) void gemm_zero_tiles_kernel(GemmParams p) {
         const int m = m0 + i / BN, n = n0 + i % BN;
         if (m < p.M && n < p.N) C[(long)m * p.ldc + n] = 0.f;
     }
+}
+
+// ---- arithmetic mode and launch helpers ---------------------------------------------------------------------------------
+static int g_gemm_arith = -1;      // 0: v_mfma_f32_32x32x2_f32 ; 1: split-operand bf16 MFMA (fp32-faithful, see split_pair)
+int gemm_get_arith() {
+    if (g_gemm_arith < 0) g_gemm_arith = getenv("LAS_GEMM_ARITH") ? atoi(getenv("LAS_GEMM_ARITH")) : LAS_GEMM_ARITH_DEFAULT;
+    return g_gemm_arith;
+}
+void gemm_set_arith(int mode) { g_gemm_arith = mode ? 1 : 0; }
+
+template <class Kern>
+static int split_kernel_ready(Kern kernel) {       // dynamic LDS beyond 64 KB has to be allowed once per kernel
+    return hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, SP_SMEM_BYTES) == hipSuccess;
+}
+template <bool A_KC, bool B_KC>
+static int launch_gemm_ab(const GemmParams& p, bool split, dim3 grid, hipStream_t stream) {
+    if (split) {
+        static const int ready = split_kernel_ready(gemm_f32_kernel<A_KC, B_KC, true>);
+        LAS_REQUIRE(ready, "dynamic LDS of the split-operand GEMM");
+        hipLaunchKernelGGL((gemm_f32_kernel<A_KC, B_KC, true>), grid, dim3(GEMM_THREADS), SP_SMEM_BYTES, stream, p);
+    } else {
+        hipLaunchKernelGGL((gemm_f32_kernel<A_KC, B_KC, false>), grid, dim3(GEMM_THREADS), 0, stream, p);
+    }
+    LAS_LAUNCH_CHECK();
+    return LAS_OK;
+}
+static int launch_gemm(const GemmParams& p, bool a_kc, bool b_kc, dim3 grid, hipStream_t stream) {
+    const bool split = gemm_get_arith() == 1;
+    if (a_kc && b_kc) return launch_gemm_ab<true, true>(p, split, grid, stream);
+    if (a_kc && !b_kc) return launch_gemm_ab<true, false>(p, split, grid, stream);
+    if (!a_kc && b_kc) return launch_gemm_ab<false, true>(p, split, grid, stream);
+    return launch_gemm_ab<false, false>(p, split, grid, stream);
+}
+template <bool A_KC, bool B_KC>
+static int launch_group_ab(const GemmGroupParams& g, bool split, dim3 grid, hipStream_t stream) {
+    if (split) {
+        static const int ready = split_kernel_ready(gemm_group_kernel<A_KC, B_KC, true>);
+        LAS_REQUIRE(ready, "dynamic LDS of the split-operand GEMM");
+        hipLaunchKernelGGL((gemm_group_kernel<A_KC, B_KC, true>), grid, dim3(GEMM_THREADS), SP_SMEM_BYTES, stream, g);
+    } else {
+        hipLaunchKernelGGL((gemm_group_kernel<A_KC, B_KC, false>), grid, dim3(GEMM_THREADS), 0, stream, g);
+    }
+    LAS_LAUNCH_CHECK();
+    return LAS_OK;
+}
+static int launch_group(const GemmGroupParams& g, bool a_kc, bool b_kc, dim3 grid, hipStream_t stream) {
+    const bool split = gemm_get_arith() == 1;
+    if (a_kc && b_kc) return launch_group_ab<true, true>(g, split, grid, stream);
+    if (a_kc && !b_kc) return launch_group_ab<true, false>(g, split, grid, stream);
+    if (!a_kc && b_kc) return launch_group_ab<false, true>(g, split, grid, stream);
+    return launch_group_ab<false, false>(g, split, grid, stream);
 }
 
 static int gemm_resident_slots() {      // persistent grid: two 256-thread workgroups per CU (34 KB LDS, <= 128 VGPRs each)
@@ -481,14 +767,7 @@ int gemm_f32_group(const GemmDesc* ds, int n, hipStream_t stream) {
         p.accumulate = d.accumulate;           // whole tiles: plain add onto the caller's values instead of a plain store
         g.first[i + 1] = g.first[i] + (long)p.gx * p.gy * p.kt;
     }
-    dim3 grid(W), block(GEMM_THREADS);
-    const bool a_kc = ds[0].a_kc, b_kc = ds[0].b_kc;
-    if (a_kc && b_kc) hipLaunchKernelGGL((gemm_group_kernel<true, true>), grid, block, 0, stream, g);
-    else if (a_kc && !b_kc) hipLaunchKernelGGL((gemm_group_kernel<true, false>), grid, block, 0, stream, g);
-    else if (!a_kc && b_kc) hipLaunchKernelGGL((gemm_group_kernel<false, true>), grid, block, 0, stream, g);
-    else hipLaunchKernelGGL((gemm_group_kernel<false, false>), grid, block, 0, stream, g);
-    LAS_LAUNCH_CHECK();
-    return LAS_OK;
+    return launch_group(g, ds[0].a_kc, ds[0].b_kc, dim3(W), stream);
 }
 
 int gemm_f32(const GemmDesc& d, hipStream_t stream) {
@@ -536,13 +815,8 @@ int gemm_f32(const GemmDesc& d, hipStream_t stream) {
                 hipLaunchKernelGGL(gemm_zero_tiles_kernel, dim3(sk_tiles), dim3(256), 0, stream, p);
             }
         }
-        dim3 grid((unsigned)std::min<long>(W, std::max<long>(dp > 0 ? W : 1, cdiv(p.sk_iters, std::max<long>(1, p.sk_per))))), block(GEMM_THREADS);
-        if (d.a_kc && d.b_kc) hipLaunchKernelGGL((gemm_f32_kernel<true, true>), grid, block, 0, stream, p);
-        else if (d.a_kc && !d.b_kc) hipLaunchKernelGGL((gemm_f32_kernel<true, false>), grid, block, 0, stream, p);
-        else if (!d.a_kc && d.b_kc) hipLaunchKernelGGL((gemm_f32_kernel<false, true>), grid, block, 0, stream, p);
-        else hipLaunchKernelGGL((gemm_f32_kernel<false, false>), grid, block, 0, stream, p);
-        LAS_LAUNCH_CHECK();
-        return LAS_OK;
+        dim3 grid((unsigned)std::min<long>(W, std::max<long>(dp > 0 ? W : 1, cdiv(p.sk_iters, std::max<long>(1, p.sk_per)))));
+        return launch_gemm(p, d.a_kc, d.b_kc, grid, stream);
     }
 
     int splitk = d.splitk > 0 ? d.splitk : 1;
@@ -570,13 +844,7 @@ int gemm_f32(const GemmDesc& d, hipStream_t stream) {
         }
     }
     p.swz = ((gx * gy) % 8 == 0) && (gx * gy >= 64);
-    dim3 grid(gx * gy, 1, batch * splitk), block(GEMM_THREADS);
-    if (d.a_kc && d.b_kc) hipLaunchKernelGGL((gemm_f32_kernel<true, true>), grid, block, 0, stream, p);
-    else if (d.a_kc && !d.b_kc) hipLaunchKernelGGL((gemm_f32_kernel<true, false>), grid, block, 0, stream, p);
-    else if (!d.a_kc && d.b_kc) hipLaunchKernelGGL((gemm_f32_kernel<false, true>), grid, block, 0, stream, p);
-    else hipLaunchKernelGGL((gemm_f32_kernel<false, false>), grid, block, 0, stream, p);
-    LAS_LAUNCH_CHECK();
-    return LAS_OK;
+    return launch_gemm(p, d.a_kc, d.b_kc, dim3(gx * gy, 1, batch * splitk), stream);
 }
 
 }  // namespace las

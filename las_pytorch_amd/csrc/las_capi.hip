@@ -1037,6 +1037,9 @@ int las_gemm_f32(const float* A, const float* B, float* C, const float* bias0, c
     return gemm_f32(g, (hipStream_t)stream);
 }
 
+int las_gemm_get_arith(void) { return gemm_get_arith(); }
+void las_gemm_set_arith(int mode) { gemm_set_arith(mode); }
+
 int las_gemm_f32_group(const las_gemm_desc* descs, int n, void* stream) {
     LAS_REQUIRE(descs != nullptr && n >= 1 && n <= 8, "gemm group");
     GemmDesc g[8];

@@ -28,6 +28,10 @@ int gemm_f32(const GemmDesc& d, hipStream_t stream);
 // n independent GEMMs of one operand layout, no bias / activation, outputs pre-zeroed (or accumulated onto): ONE launch, the
 // k-iterations of all problems spread evenly over the resident workgroups.  Falls back to n launches when not groupable.
 int gemm_f32_group(const GemmDesc* ds, int n, hipStream_t stream);
+// arithmetic of the interior tiles: 0 = v_mfma_f32_32x32x2_f32, 1 = exact three-way bf16 operand split on the bf16 MFMA pipe
+// (six partial products, fp32 accumulate; as accurate as the fp32 MFMA, see gemm_f32.hip).  Process-wide; LAS_GEMM_ARITH.
+int gemm_get_arith();
+void gemm_set_arith(int mode);
 
 // ---- pblstm_rec.hip --------------------------------------------------------------------
 // Forward time recurrence of one bidirectional LSTM layer, both directions in one launch.
