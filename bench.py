@@ -42,6 +42,39 @@ WORKLOADS = {
 }
 HBM_PEAK_GBS = 8000.0    # MI355X HBM3E spec peak (guides/MI355X_MICROARCH.md)
 MFMA_F32_PEAK_TF = 157.3  # dense fp32-input MFMA peak (same guide)
+MFMA_BF16_PEAK_TF = 2500.0  # dense bf16 MFMA peak (same guide); the split-operand GEMM spends six bf16 MFMA products per fp32 product
+
+
+def gemm_arith():
+    """(mode, description, MFMA peak in fp32-equivalent TFLOP/s) of the GEMM arithmetic the library is running in."""
+    from las_pytorch_amd import _cabi
+    mode = _cabi.lib().las_gemm_get_arith()
+    if mode == 1:
+        return mode, ("fp32 operands split exactly into three bf16 terms in registers, six partial products on "
+                      "v_mfma_f32_32x32x16_bf16, fp32 accumulation (dropped terms < 2^-26 |a*b|: error vs float64 not above the fp32 MFMA's, "
+                      "see gemm_accuracy)"), MFMA_BF16_PEAK_TF / 6.0
+    return mode, "fp32 operands on v_mfma_f32_32x32x2_f32", MFMA_F32_PEAK_TF
+
+
+def gemm_accuracy():
+    """One GEMM of the step (L2 input projection, 3200x1024x1024) in both arithmetic modes against float64, measured in this run:
+    max |C - AB| / (|A||B|) in units of 2^-24 (the scale of an fp32 dot-product error bound)."""
+    from las_pytorch_amd import _cabi
+    L = _cabi.lib()
+    M, N, K = 3200, 1024, 1024
+    g = torch.Generator(device="cuda").manual_seed(17)
+    A = torch.randn(M, K, device="cuda", generator=g); Bm = torch.randn(N, K, device="cuda", generator=g)
+    ref = A.double() @ Bm.double().t(); mag = A.double().abs() @ Bm.double().abs().t()
+    old, out = L.las_gemm_get_arith(), {}
+    for mode, key in ((0, "mfma_f32_err_ulp"), (1, "split_bf16_err_ulp")):
+        L.las_gemm_set_arith(mode)
+        C = torch.empty(M, N, device="cuda")
+        _cabi.check(L.las_gemm_f32(A.data_ptr(), Bm.data_ptr(), C.data_ptr(), None, None, M, N, K, K, K, N, 1, 1, 1, 0, 0, 0, 1, 0, 0,
+                                   _cabi.stream_ptr()))
+        out[key] = round(float(((C.double() - ref).abs() / mag).max()) / 2.0 ** -24, 3)
+    L.las_gemm_set_arith(old)
+    out["shape"] = f"{M}x{N}x{K}, N(0,1) operands; torch CPU/GPU float64 reference"
+    return out
 
 
 def _sha16(path):
@@ -212,8 +245,11 @@ def roofline_mfma(c, B, T, U, reps=10):
         rows.append({"launch": name, "gemms": len(probs), "us": round(us, 1), "tflops": round(fl / us / 1e6, 1)})
         del bufs
     tf = tot_fl / tot_us / 1e6
-    return dict(bound="mfma", kernel="gemm_f32_kernel / gemm_group_kernel: every MFMA GEMM launch of one training step (v_mfma_f32_32x32x2_f32, exact fp32)",
-                achieved=round(tf, 1), peak=MFMA_F32_PEAK_TF, unit="TFLOP/s", frac=round(tf / MFMA_F32_PEAK_TF, 4),
+    mode, desc, peak = gemm_arith()
+    return dict(bound="mfma", kernel="gemm_f32_kernel / gemm_group_kernel: every MFMA GEMM launch of one training step; " + desc,
+                achieved=round(tf, 1), peak=round(peak, 1), unit="TFLOP/s (fp32 flops of the GEMMs: 2MNK)", frac=round(tf / peak, 4),
+                peak_note=("dense bf16 MFMA peak 2500 TF / 6 partial products per fp32 product" if mode == 1 else "dense fp32-input MFMA peak"),
+                frac_of_fp32_mfma_peak=round(tf / MFMA_F32_PEAK_TF, 4),
                 flops_per_step=int(tot_fl), gemm_ms_per_step=round(tot_us / 1e3, 3), launches=rows)
 
 
@@ -390,6 +426,26 @@ def main():
                        "per_gpu_batch": B, "global_batch": B * world, "frames": T, "decode_steps": U,
                        "parallelism": f"dp{world}", "final_loss_or_logp": round(final, 6)},
         }
+        res["config"]["gemm_arith"] = gemm_arith()[1]
+        if world == 1 and train and not args.no_mfma:
+            # the same step with the GEMMs on the fp32 matrix pipe (LAS_GEMM_ARITH=0), timed right after the headline loop, and the
+            # measured accuracy of both GEMM arithmetics against float64
+            from las_pytorch_amd import _cabi
+            mode0 = _cabi.lib().las_gemm_get_arith()
+            _cabi.lib().las_gemm_set_arith(1 - mode0)
+            for _ in range(3):
+                step()
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            nalt = max(5, args.steps // 2)
+            for _ in range(nalt):
+                step()
+            torch.cuda.synchronize()
+            dta = (time.perf_counter() - t1) / nalt
+            _cabi.lib().las_gemm_set_arith(mode0)
+            res["gemm_arith_variant"] = {"arith": "fp32 operands on v_mfma_f32_32x32x2_f32 (LAS_GEMM_ARITH=0)" if mode0 == 1 else "split-operand bf16 MFMA (LAS_GEMM_ARITH=1)",
+                                         "value": round(B / dta, 2), "unit": "utt/s", "ms_per_step": round(dta * 1e3, 3), "steps": nalt}
+            res["gemm_accuracy"] = gemm_accuracy()
         if not args.no_roofline:
             res["roofline"] = roofline_rec_fwd(c, B, T)
         if world == 1 and train and not args.no_mfma:

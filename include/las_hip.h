@@ -245,6 +245,9 @@ int las_gemm_f32_group(const las_gemm_desc* descs, int n, void* stream);
  * Replaces nothing in the reference (ATen picks its own GEMM kernels, model/las_model.py:90,279). */
 int las_gemm_get_arith(void);
 void las_gemm_set_arith(int mode);
+/* profiling aid: schedule thresholds of las_gemm_f32 (key 0 stream-K on/off, 1 fewest tiles for the persistent schedule,
+ * 2 split K below this many tiles, 3 workgroup target of the split); value -1 restores the default */
+void las_gemm_set_tuning(int key, int64_t value);
 /* recurrence only: gates (2,B,T,4H) pre-activations in, see las_pblstm_fwd for the rest */
 size_t las_rec_xbuf_bytes(int B, int H);
 int las_pblstm_rec_fwd(float* gates, const float* w_hh_f, const float* w_hh_r, float* out, float* cbuf, float* hprev,

@@ -76,6 +76,7 @@ PROTOTYPES = {
     "las_gemm_f32_group": (C.c_int, [C.POINTER(GemmDescC), C.c_int, _f]),
     "las_gemm_get_arith": (C.c_int, []),
     "las_gemm_set_arith": (None, [C.c_int]),
+    "las_gemm_set_tuning": (None, [C.c_int, C.c_int64]),
     "las_rec_xbuf_bytes": (C.c_size_t, [C.c_int, C.c_int]),
     "las_pblstm_rec_fwd": (C.c_int, [_f] * 6 + [C.c_int] * 3 + [_f, _f, C.c_int, _f]),
 }

@@ -6,10 +6,11 @@
 //   * every dX / dW contraction of the backward pass (autograd of the above, solver/solver.py:95)
 //
 // Design (CDNA4): 128x128 block tile, BK=16, 256 threads = 4 wave64 in a 2x2 grid, each wave owns a
-// 64x64 sub-tile = 2x2 v_mfma_f32_32x32x2_f32 accumulators (64 acc VGPRs).  f32-in MFMA is exact fp32
-// (bitwise an fmaf chain) at the fp32 vector rate (157 TF peak) — there is no TF32 on gfx950.
-// Operands go global -> registers -> LDS (K-major tiles so a fragment read is 32 consecutive dwords per
-// half-wave: conflict-free ds_read_b32), double-buffered with one barrier per k-tile.
+// 64x64 sub-tile = 2x2 32x32 MFMA accumulators (64 acc VGPRs).  Two arithmetic modes, both fp32 in / fp32 out / fp32 accumulate:
+//   arith 1 (default): every operand is split exactly into three bf16 terms on its way to LDS and six partial products run on
+//            v_mfma_f32_32x32x16_bf16 (16x the fp32 MFMA rate): fp32-faithful at 2.67x the fp32 matrix roofline, see split_pair
+//   arith 0: v_mfma_f32_32x32x2_f32, fp32 operands on the fp32 matrix pipe (157 TF peak; there is no TF32 on gfx950);
+//            operands go global -> registers -> LDS (K-major tiles, conflict-free ds_read_b32 fragments), double-buffered.
 // Either operand may be K-contiguous or M/N-contiguous (all four transposition cases of the backward pass).
 #include "las_common.h"
 #include "las_kernels.h"
@@ -28,8 +29,11 @@ namespace las {
 #ifndef LAS_GEMM_PF
 #define LAS_GEMM_PF 1
 #endif
+#ifndef LAS_SPLIT_ABL
+#define LAS_SPLIT_ABL 0     // timing ablations of the split-operand loop (wrong results): 1 no global loads, 2 no split/store, 4 no fragment reloads
+#endif
 #ifndef LAS_GEMM_ARITH_DEFAULT
-#define LAS_GEMM_ARITH_DEFAULT 0
+#define LAS_GEMM_ARITH_DEFAULT 1
 #endif
 constexpr int BM = 128, BN = 128, BK = LAS_GEMM_BK, PAD = 4, GEMM_THREADS = 256, PF = LAS_GEMM_PF;
 constexpr int NLD = BM * BK / 4 / GEMM_THREADS;     // float4 loads per thread per operand tile
@@ -59,9 +63,9 @@ typedef __attribute__((ext_vector_type(2))) unsigned u32x2;
 //   row-contiguous operand: [k-pair (8)][row]            (SP_LD dwords per pair)  store 16 B per thread and plane, read 4 dwords
 // either way a lane ends up with k = 8 (lane / 32) .. +7 of its row in increasing order.
 constexpr int SP_LD = BM + 8;                    // +8 dwords: the two k-halves of a fragment read land on disjoint banks
-constexpr int SP_KH = BM * 4 + 32;               // +32 dwords (128 B): the k-halves of an 8-byte store land on disjoint banks
+constexpr int SP_KH = BM * 4 + 16;               // +16 dwords: the two k-halves of an 8-byte store (16 lanes, 32 banks) stay disjoint
 constexpr int SP_PLANE = (16 / 2) * SP_LD;       // one bf16 plane of one operand tile (128 rows x 16 k)
-static_assert(SP_PLANE == 2 * SP_KH, "both plane images have the same size");
+static_assert(SP_PLANE >= 2 * SP_KH && SP_KH % 4 == 0, "both plane images fit; 16-byte aligned k-halves");
 constexpr int SP_OPER = 3 * SP_PLANE;
 constexpr int SP_BUF = 2 * SP_OPER;              // A and B
 constexpr int SP_NBUF = 3;                       // tile kt is multiplied while kt+1 is read into fragments and kt+2 is stored
@@ -82,16 +86,15 @@ static __device__ __forceinline__ void split_pair(float x0, float x1, unsigned& 
 // registers of one operand tile (two 16-byte loads per thread) -> the three LDS planes, in two halves so that the caller can
 // spread the work between its MFMA groups
 //  KC : load i covers row (t + 256 i) / 4, k = 4 ((t + 256 i) % 4) .. +3         -> half i: two k-pair dwords per plane
-//  !KC: loads 0/1 cover k = 2 (t / 32) and 2 (t / 32) + 1, rows 4 (t % 32) .. +3  -> half 0: rows 0,1; half 1: rows 2,3 and one
-//       16-byte store of the four k-pairs per plane
+//  !KC: loads 0/1 cover k = 2 (t / 32) and 2 (t / 32) + 1, rows 4 (t % 32) .. +3  -> half h: rows 2h, 2h+1, one k-pair dword each
 template <bool KC, int HALF>
-static __device__ __forceinline__ void split_store_half(unsigned* S, const f32x4 (&reg)[NLD], u32x4 (&o)[3]) {
+static __device__ __forceinline__ void split_store_half(unsigned* S, const f32x4 (&reg)[NLD]) {
     static_assert(NLD == 2 && BK == 16, "split path is written for BK = 16");
     const int t = threadIdx.x;
+    unsigned a[3], b[3];
     if constexpr (KC) {
         const int idx = t + HALF * GEMM_THREADS;
         const int row = idx >> 2, q = idx & 3;
-        unsigned a[3], b[3];
         split_pair(reg[HALF][0], reg[HALF][1], a[0], a[1], a[2]);
         split_pair(reg[HALF][2], reg[HALF][3], b[0], b[1], b[2]);
 #pragma unroll
@@ -100,17 +103,50 @@ static __device__ __forceinline__ void split_store_half(unsigned* S, const f32x4
             *reinterpret_cast<u32x2*>(&S[pl * SP_PLANE + (q >> 1) * SP_KH + row * 4 + (q & 1) * 2]) = v;
         }
     } else {
+        const int kp = t >> 5, rq = (t & 31) * 4 + 2 * HALF;
+        split_pair(reg[0][2 * HALF], reg[1][2 * HALF], a[0], a[1], a[2]);
+        split_pair(reg[0][2 * HALF + 1], reg[1][2 * HALF + 1], b[0], b[1], b[2]);
 #pragma unroll
-        for (int j = 2 * HALF; j < 2 * HALF + 2; ++j) {
-            unsigned q0, q1, q2;
-            split_pair(reg[0][j], reg[1][j], q0, q1, q2);
-            o[0][j] = q0; o[1][j] = q1; o[2][j] = q2;
+        for (int pl = 0; pl < 3; ++pl) {
+            u32x2 v = {a[pl], b[pl]};
+            *reinterpret_cast<u32x2*>(&S[pl * SP_PLANE + kp * SP_LD + rq]) = v;
         }
-        if constexpr (HALF == 1) {
-            const int kp = t >> 5, rq = (t & 31) * 4;
+    }
+}
+// Guarded form of the split path's register image (edge tiles, a K range that is not a multiple of 16, operands that are not
+// 16-byte aligned): same thread -> element map as the vector loads above, zero outside [0,R) x [k0,kend).
+template <bool KC>
+static __device__ __forceinline__ void split_load_guarded(const float* __restrict__ P, long ld, int R, int r0, int k0, int kend,
+                                                          bool vec_ok, f32x4 (&reg)[NLD]) {
+    const int t = threadIdx.x;
 #pragma unroll
-            for (int pl = 0; pl < 3; ++pl) *reinterpret_cast<u32x4*>(&S[pl * SP_PLANE + kp * SP_LD + rq]) = o[pl];
+    for (int i = 0; i < NLD; ++i) {
+        f32x4 v = {0.f, 0.f, 0.f, 0.f};
+        if constexpr (KC) {
+            const int idx = t + i * GEMM_THREADS;
+            const int r = r0 + (idx >> 2), k = k0 + (idx & 3) * 4;
+            if (r < R) {
+                const float* q = P + (long)r * ld + k;
+                if (vec_ok && k + 3 < kend) {
+                    v = *reinterpret_cast<const f32x4*>(q);
+                } else {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) if (k + j < kend) v[j] = q[j];
+                }
+            }
+        } else {
+            const int k = k0 + 2 * (t >> 5) + i, r = r0 + (t & 31) * 4;
+            if (k < kend) {
+                const float* q = P + (long)k * ld + r;
+                if (vec_ok && r + 3 < R) {
+                    v = *reinterpret_cast<const f32x4*>(q);
+                } else {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) if (r + j < R) v[j] = q[j];
+                }
+            }
         }
+        reg[i] = v;
     }
 }
 struct SplitFrag { u32x4 a[3][2], b[3][2]; };      // [plane][32-row tile]: 8 consecutive k of this lane's row as bf16
@@ -245,8 +281,8 @@ __device__ __forceinline__ void gemm_segment(const GemmParams& p, float (*As)[BK
     // four 16-byte loads, and the only branch is the loop itself.  Everything else (edge tiles, odd K, unaligned operands)
     // goes through the guarded loader below.
     const bool fast = p.a_vec && p.b_vec && (m0 + BM <= p.M) && (n0 + BN <= p.N) && ((kend - kbeg) % BK == 0) && ntiles > 0;
-    if (fast && SPLIT) {
-      if constexpr (SPLIT) {
+    if constexpr (SPLIT) {
+      if (ntiles > 0) {
         // Split-operand main loop (see the comment at split_pair).  Per k-tile of 16 and wave: 24 MFMAs in six groups of four (one
         // group = one pair of planes on the 2x2 accumulators).  Three LDS buffers, ONE fragment register set, one barrier per tile:
         // while tile kt is multiplied, its planes are replaced by those of tile kt+1 as soon as their last group has been issued
@@ -262,17 +298,22 @@ __device__ __forceinline__ void gemm_segment(const GemmParams& p, float (*As)[BK
             oB[i] = B_KC ? (long)(n0 + (idx >> 2)) * p.ldb + (idx & 3) * 4 : (long)(2 * (t >> 5) + i) * p.ldb + n0 + (t & 31) * 4;
         }
         const long strideA = A_KC ? 1 : p.lda, strideB = B_KC ? 1 : p.ldb;
-        auto gload = [&](int k0, f32x4 (&ra_)[NLD], f32x4 (&rb_)[NLD]) {
+        auto gload_any = [&](auto FASTC, int k0, f32x4 (&ra_)[NLD], f32x4 (&rb_)[NLD]) {
             const bool second = p.A2 != nullptr && k0 >= p.K1;          // wave-uniform
             const float* Ab = second ? p.A2 : A;
             const float* Bb = second ? p.B2 : B;
             const long kk = second ? k0 - p.K1 : k0;
+            if constexpr (decltype(FASTC)::value) {
 #pragma unroll
-            for (int i = 0; i < NLD; ++i) ra_[i] = *reinterpret_cast<const f32x4*>(Ab + oA[i] + kk * strideA);
+                for (int i = 0; i < NLD; ++i) ra_[i] = *reinterpret_cast<const f32x4*>(Ab + oA[i] + kk * strideA);
 #pragma unroll
-            for (int i = 0; i < NLD; ++i) rb_[i] = *reinterpret_cast<const f32x4*>(Bb + oB[i] + kk * strideB);
+                for (int i = 0; i < NLD; ++i) rb_[i] = *reinterpret_cast<const f32x4*>(Bb + oB[i] + kk * strideB);
+            } else {
+                const int ke = second ? kend - p.K1 : (p.A2 != nullptr ? min(kend, p.K1) : kend);
+                split_load_guarded<A_KC>(Ab, p.lda, p.M, m0, (int)kk, ke, p.a_vec, ra_);
+                split_load_guarded<B_KC>(Bb, p.ldb, p.N, n0, (int)kk, ke, p.b_vec, rb_);
+            }
         };
-        u32x4 oa[3], ob[3];
         // fragment offsets (dwords) of this lane inside an operand buffer; the second 32-row tile of a row-contiguous operand gets
         // an offset the compiler cannot relate to the first one, so that it pairs the dword reads inside ONE register tuple
         // (ds_read2_b32 across the two tiles needs moves, and those moves drag the LDS wait to just behind the reads)
@@ -317,66 +358,73 @@ __device__ __forceinline__ void gemm_segment(const GemmParams& p, float (*As)[BK
                     acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, f.a[pa][i]),
                                                                          __builtin_bit_cast(bf16x8, f.b[pb][j]), acc[i][j], 0, 0, 0);
         };
-        f32x4 ra[2][NLD], rb[2][NLD];
+        // interior segments and guarded ones (edge tiles, odd K, unaligned operands) run the same loop with their own loader
+        auto mainloop = [&](auto FASTC) {
+        auto gload = [&](int k0, f32x4 (&ra_)[NLD], f32x4 (&rb_)[NLD]) { gload_any(FASTC, k0, ra_, rb_); };
+        // register sets: tile j travels in set j % 3; its loads are issued two iterations before its split/store
+        f32x4 ra[3][NLD], rb[3][NLD];
+        auto sstore_all = [&](int buf, const f32x4 (&ra_)[NLD], const f32x4 (&rb_)[NLD]) {
+            unsigned* sa = sp + buf * SP_BUF;
+            split_store_half<A_KC, 0>(sa, ra_); split_store_half<A_KC, 1>(sa, ra_);
+            split_store_half<B_KC, 0>(sa + SP_OPER, rb_); split_store_half<B_KC, 1>(sa + SP_OPER, rb_);
+        };
         gload(kbeg, ra[0], rb[0]);
         if (ntiles > 1) gload(kbeg + BK, ra[1], rb[1]);
-        split_store_half<A_KC, 0>(sp, ra[0], oa); split_store_half<A_KC, 1>(sp, ra[0], oa);
-        split_store_half<B_KC, 0>(sp + SP_OPER, rb[0], ob); split_store_half<B_KC, 1>(sp + SP_OPER, rb[0], ob);
-        if (ntiles > 2) gload(kbeg + 2 * BK, ra[0], rb[0]);
-        if (ntiles > 1) {
-            split_store_half<A_KC, 0>(sp + SP_BUF, ra[1], oa); split_store_half<A_KC, 1>(sp + SP_BUF, ra[1], oa);
-            split_store_half<B_KC, 0>(sp + SP_BUF + SP_OPER, rb[1], ob); split_store_half<B_KC, 1>(sp + SP_BUF + SP_OPER, rb[1], ob);
-        }
+        if (ntiles > 2) gload(kbeg + 2 * BK, ra[2], rb[2]);
+        sstore_all(0, ra[0], rb[0]);
+        if (ntiles > 3) gload(kbeg + 3 * BK, ra[0], rb[0]);
+        if (ntiles > 1) sstore_all(1, ra[1], rb[1]);
         __syncthreads();
 #pragma unroll
         for (int pl = 0; pl < 3; ++pl) { rd_a(0, pl); rd_b(0, pl); }
-        // iteration kt (parity P = kt & 1): register set P holds tile kt+2; FULL: kt + 3 < ntiles, nothing to guard
-        auto step = [&](auto PC, auto FULLC, int kt, int b1, int b2) {
-            constexpr int P = decltype(PC)::value;
+        // iteration kt with R = kt % 3: tile kt is in the fragment registers and LDS buffer R, tile kt+1 in buffer R+1, tile kt+2 in
+        // register set R+2 (on its way to buffer R+2), tile kt+3 in flight into set R, tile kt+4 is requested into set R+1.
+        // FULL: kt + 4 < ntiles, nothing to guard.
+        auto step = [&](auto RC, auto FULLC, int kt) {
+            constexpr int R = decltype(RC)::value, R1 = (R + 1) % 3, R2 = (R + 2) % 3;
             constexpr bool FULL = decltype(FULLC)::value;
-            const bool nxt = FULL || kt + 1 < ntiles, st = FULL || kt + 2 < ntiles;
-            unsigned* sa = sp + b2 * SP_BUF;
+            const bool nxt = !(LAS_SPLIT_ABL & 4) && (FULL || kt + 1 < ntiles), st = !(LAS_SPLIT_ABL & 2) && (FULL || kt + 2 < ntiles);
+            unsigned* sa = sp + R2 * SP_BUF;
             unsigned* sb = sa + SP_OPER;
-            if (FULL || kt + 3 < ntiles) gload(kbeg + (kt + 3) * BK, ra[P ^ 1], rb[P ^ 1]);
+            if (!(LAS_SPLIT_ABL & 1) && (FULL || kt + 4 < ntiles)) gload(kbeg + (kt + 4) * BK, ra[R1], rb[R1]);
             grp(1, 1);
-            if (st) split_store_half<A_KC, 0>(sa, ra[P], oa);
+            if (st) split_store_half<A_KC, 0>(sa, ra[R2]);
             __builtin_amdgcn_sched_barrier(0);
             grp(1, 0);
-            if (nxt) rd_a(b1, 1);
-            if (st) split_store_half<A_KC, 1>(sa, ra[P], oa);
+            if (nxt) rd_a(R1, 1);
+            if (st) split_store_half<A_KC, 1>(sa, ra[R2]);
             __builtin_amdgcn_sched_barrier(0);
             grp(0, 1);
-            if (nxt) rd_b(b1, 1);
-            if (st) split_store_half<B_KC, 0>(sb, rb[P], ob);
+            if (nxt) rd_b(R1, 1);
+            if (st) split_store_half<B_KC, 0>(sb, rb[R2]);
             __builtin_amdgcn_sched_barrier(0);
             grp(2, 0);
-            if (nxt) rd_a(b1, 2);
-            if (st) split_store_half<B_KC, 1>(sb, rb[P], ob);
+            if (nxt) rd_a(R1, 2);
+            if (st) split_store_half<B_KC, 1>(sb, rb[R2]);
             __builtin_amdgcn_sched_barrier(0);
             grp(0, 2);
-            if (nxt) rd_b(b1, 2);
+            if (nxt) rd_b(R1, 2);
             __builtin_amdgcn_sched_barrier(0);
             grp(0, 0);
             __syncthreads();
-            if (nxt) { rd_a(b1, 0); rd_b(b1, 0); }
+            if (nxt) { rd_a(R1, 0); rd_b(R1, 0); }
             __builtin_amdgcn_sched_barrier(0);
         };
-        int b0 = 0, kt = 0;
-        for (; kt + 4 < ntiles; kt += 2) {       // both steps of the pair are unguarded
-            const int b1 = b0 == 2 ? 0 : b0 + 1, b2 = b1 == 2 ? 0 : b1 + 1;
-            step(std::integral_constant<int, 0>{}, std::true_type{}, kt, b1, b2);
-            step(std::integral_constant<int, 1>{}, std::true_type{}, kt + 1, b2, b0);
-            b0 = b2;
+        int kt = 0;
+        for (; kt + 6 < ntiles; kt += 3) {       // all three steps unguarded
+            step(std::integral_constant<int, 0>{}, std::true_type{}, kt);
+            step(std::integral_constant<int, 1>{}, std::true_type{}, kt + 1);
+            step(std::integral_constant<int, 2>{}, std::true_type{}, kt + 2);
         }
-        for (; kt < ntiles; kt += 2) {
-            const int b1 = b0 == 2 ? 0 : b0 + 1, b2 = b1 == 2 ? 0 : b1 + 1;
-            step(std::integral_constant<int, 0>{}, std::false_type{}, kt, b1, b2);
-            if (kt + 1 < ntiles) step(std::integral_constant<int, 1>{}, std::false_type{}, kt + 1, b2, b0);
-            b0 = b2;
+        for (; kt < ntiles; kt += 3) {
+            step(std::integral_constant<int, 0>{}, std::false_type{}, kt);
+            if (kt + 1 < ntiles) step(std::integral_constant<int, 1>{}, std::false_type{}, kt + 1);
+            if (kt + 2 < ntiles) step(std::integral_constant<int, 2>{}, std::false_type{}, kt + 2);
         }
+              };
+        if (fast) mainloop(std::true_type{}); else mainloop(std::false_type{});
       }
     } else if (fast) {
-      if constexpr (!SPLIT) {
         long offA[NLD], offB[NLD];
 #pragma unroll
         for (int i = 0; i < NLD; ++i) {
@@ -472,7 +520,6 @@ __device__ __forceinline__ void gemm_segment(const GemmParams& p, float (*As)[BK
             a[0] = an[0]; a[1] = an[1]; b[0] = bn[0]; b[1] = bn[1];
         }
         __syncthreads();                             // the segment's last reads precede the next segment's first LDS writes
-      }
     } else {
     // Register-staged prefetch PF k-tiles ahead (the loads of tile kt+PF are issued before tile kt is multiplied): one tile
     // of MFMA work (2048 cycles per wave) does not cover an L2-miss round trip under load, and with two resident workgroups
@@ -681,6 +728,15 @@ int gemm_get_arith() {
     return g_gemm_arith;
 }
 void gemm_set_arith(int mode) { g_gemm_arith = mode ? 1 : 0; }
+// schedule knobs (tools/ubench_gemm_sched.py sweeps them inside one process; -1 = built-in default, environment otherwise)
+enum { TUNE_STREAMK = 0, TUNE_SK_MIN_TILES = 1, TUNE_SPLIT_BELOW = 2, TUNE_SPLIT_TARGET = 3, TUNE_N = 4 };
+static long g_tune[TUNE_N] = {-1, -1, -1, -1};
+void gemm_set_tuning(int key, long value) { if (key >= 0 && key < TUNE_N) g_tune[key] = value; }
+static long tune(int key, const char* env, long dflt) {
+    if (g_tune[key] >= 0) return g_tune[key];
+    const char* e = getenv(env);
+    return e ? atol(e) : dflt;
+}
 
 template <class Kern>
 static int split_kernel_ready(Kern kernel) {       // dynamic LDS beyond 64 KB has to be allowed once per kernel
@@ -792,10 +848,14 @@ int gemm_f32(const GemmDesc& d, hipStream_t stream) {
     p.persistent = 0; p.dp_tiles = 0; p.sk_iters = 0; p.sk_per = 0; p.sk_atomic_whole = 0; p.atomic = 0; p.swz = 0; p.splitk = 1; p.kper = d.K;
 
     // ---- schedule --------------------------------------------------------------------------------------------------
-    static const int sk_on = getenv("LAS_GEMM_STREAMK") ? atoi(getenv("LAS_GEMM_STREAMK")) : 1;
+    const int sk_on = (int)tune(TUNE_STREAMK, "LAS_GEMM_STREAMK", 1);
     const int W = gemm_resident_slots();
     const bool may_split = !d.relu && d.K >= 4 * BK;         // a relu epilogue needs the whole sum in one place
-    if (sk_on && d.splitk <= 1 && W > 0 && may_split && kt >= 32 && tiles % W != 0 && tiles * kt >= 4L * W) {
+    // split-operand arithmetic runs a k-iteration 2-3x faster, so the fixed costs of the stream-K epilogue (zeroing pass, one atomic
+    // per output of every partial tile) weigh more: there the persistent schedule is used only when whole tiles fill every slot at
+    // least once (plain stores for those, stream-K for the ragged tail), fewer tiles take the classic grid / split-K
+    const long min_tiles = tune(TUNE_SK_MIN_TILES, "LAS_GEMM_SK_MIN_TILES", gemm_get_arith() == 1 ? W : 0);
+    if (sk_on && d.splitk <= 1 && W > 0 && may_split && kt >= 32 && tiles % W != 0 && tiles * kt >= 4L * W && tiles >= min_tiles) {
         // persistent: whole tiles while they fill every slot, the ragged tail (or everything, when there are fewer tiles than
         // slots) as equal runs of k-iterations
         const long full = (tiles / W) * W;
@@ -820,11 +880,15 @@ int gemm_f32(const GemmDesc& d, hipStream_t stream) {
     }
 
     int splitk = d.splitk > 0 ? d.splitk : 1;
-    if (d.splitk == 0) {
+    // (callers pass splitk = 1 where the persistent schedule was the measured best in fp32-MFMA arithmetic; in split-operand
+    // arithmetic that schedule is not taken below one tile per slot, so the request falls back to the automatic split)
+    const bool can_zero = d.accumulate || d.c_zeroed || d.ldc == d.N || batch == 1;      // split-K partials need a zeroed (or accumulated) C
+    if (d.splitk == 0 || (d.splitk == 1 && gemm_get_arith() == 1 && may_split && can_zero)) {
         // auto: few output tiles and a long K -> split K so the launch covers the chip (256 CUs)
-        if (!d.relu && tiles < 128 && d.K >= 256) {
+        const long below = tune(TUNE_SPLIT_BELOW, "LAS_GEMM_SPLIT_BELOW", gemm_get_arith() == 1 ? W / 2 : 128);
+        if (!d.relu && tiles < below && d.K >= 256) {
             // few output tiles, long K: about two workgroups per CU (they hide each other's barrier stalls) with at least 4 k-tiles each
-            static const long target = getenv("LAS_GEMM_SPLIT_TARGET") ? atol(getenv("LAS_GEMM_SPLIT_TARGET")) : 512;   // ~2 workgroups per CU: measured best
+            const long target = tune(TUNE_SPLIT_TARGET, "LAS_GEMM_SPLIT_TARGET", 512);   // ~2 workgroups per CU: measured best
             splitk = (int)min((long)cdiv(d.K, 4 * BK), max(1L, target / tiles));
         }
     }

@@ -1039,6 +1039,7 @@ int las_gemm_f32(const float* A, const float* B, float* C, const float* bias0, c
 
 int las_gemm_get_arith(void) { return gemm_get_arith(); }
 void las_gemm_set_arith(int mode) { gemm_set_arith(mode); }
+void las_gemm_set_tuning(int key, int64_t value) { gemm_set_tuning(key, (long)value); }
 
 int las_gemm_f32_group(const las_gemm_desc* descs, int n, void* stream) {
     LAS_REQUIRE(descs != nullptr && n >= 1 && n <= 8, "gemm group");

@@ -32,6 +32,7 @@ int gemm_f32_group(const GemmDesc* ds, int n, hipStream_t stream);
 // (six partial products, fp32 accumulate; as accurate as the fp32 MFMA, see gemm_f32.hip).  Process-wide; LAS_GEMM_ARITH.
 int gemm_get_arith();
 void gemm_set_arith(int mode);
+void gemm_set_tuning(int key, long value);     // schedule knobs for tools/ubench_gemm_sched.py (see gemm_f32.hip)
 
 // ---- pblstm_rec.hip --------------------------------------------------------------------
 // Forward time recurrence of one bidirectional LSTM layer, both directions in one launch.

@@ -3,7 +3,7 @@ import numpy as np
 import pytest
 import torch
 
-from hip_util import assert_close
+from hip_util import assert_close, record
 
 pytestmark = pytest.mark.gpu
 
@@ -14,6 +14,94 @@ def _gemm(A, B, C, bias0=None, bias1=None, *, M, N, K, lda, ldb, ldc, a_kc, b_kc
     L = _cabi.lib()
     _cabi.check(L.las_gemm_f32(_cabi.ptr(A), _cabi.ptr(B), _cabi.ptr(C), _cabi.ptr(bias0), _cabi.ptr(bias1), M, N, K, lda, ldb, ldc,
                                int(a_kc), int(b_kc), batch, sA, sB, sC, splitk, accumulate, relu, _cabi.stream_ptr()))
+
+
+@pytest.fixture(autouse=True)
+def gemm_arith(request):
+    """Every test with "gemm" in its name runs in both arithmetic modes of the MFMA GEMM (las_gemm_set_arith): fp32 operands on
+    v_mfma_f32_32x32x2_f32, and the exact three-way bf16 operand split on v_mfma_f32_32x32x16_bf16 (the default)."""
+    mode = getattr(request, "param", None)
+    if mode is None:
+        yield None
+        return
+    from las_pytorch_amd import _cabi
+    L = _cabi.lib()
+    old = L.las_gemm_get_arith()
+    L.las_gemm_set_arith(mode)
+    yield mode
+    L.las_gemm_set_arith(old)
+
+
+def pytest_generate_tests(metafunc):
+    if "gemm" in metafunc.function.__name__ and "gemm_arith" in metafunc.fixturenames:
+        metafunc.parametrize("gemm_arith", [0, 1], indirect=True, ids=["mfma_f32", "split_bf16"])
+
+
+def _err_ulp(C, A64, B64):
+    """max |C - A B| / (|A| |B|) in units of 2^-24: the scale a forward error bound of an fp32 dot product is stated against."""
+    ref = A64 @ B64
+    mag = A64.abs() @ B64.abs() + 1e-300
+    return float(((C.double() - ref).abs() / mag).max()) / 2.0 ** -24
+
+
+@pytest.mark.parametrize("a_kc,b_kc", [(True, True), (True, False), (False, False), (False, True)])
+@pytest.mark.parametrize("M,N,K,spread", [(512, 384, 1024, 0), (1024, 1024, 4096, 0), (300, 200, 1000, 0), (256, 256, 2048, 20),
+                                          (3200, 1024, 1024, 0), (1024, 160, 12800, 0)])
+def test_split_operand_arithmetic_is_fp32_faithful(a_kc, b_kc, M, N, K, spread):
+    """The split-operand GEMM against float64, beside the fp32-MFMA GEMM on the same operands: its error must not exceed the
+    fp32 MFMA's (1.25x + half an ulp of slack for the different summation order), with N(0,1) operands and with operands whose
+    exponents are spread over 2^+-20 (the small terms of the split must not be lost next to large ones)."""
+    from las_pytorch_amd import _cabi
+    L = _cabi.lib()
+    g = torch.Generator(device="cuda").manual_seed(M + 3 * N + 7 * K + spread)
+    A = torch.randn(M, K, device="cuda", generator=g)
+    B = torch.randn(K, N, device="cuda", generator=g)
+    if spread:
+        A = A * torch.exp2(torch.randint(-spread, spread, (M, K), device="cuda", generator=g).float())
+        B = B * torch.exp2(torch.randint(-spread, spread, (K, N), device="cuda", generator=g).float())
+    Ad = (A if a_kc else A.t()).contiguous()
+    Bd = (B.t() if b_kc else B).contiguous()
+    err = {}
+    old = L.las_gemm_get_arith()
+    try:
+        for mode in (0, 1):
+            L.las_gemm_set_arith(mode)
+            C = torch.full((M, N), float("nan"), device="cuda")
+            _gemm(Ad, Bd, C, M=M, N=N, K=K, lda=K if a_kc else M, ldb=K if b_kc else N, ldc=N, a_kc=a_kc, b_kc=b_kc)
+            err[mode] = _err_ulp(C, A.double(), B.double())
+    finally:
+        L.las_gemm_set_arith(old)
+    record(f"gemm_split_vs_f64/{int(a_kc)}{int(b_kc)}_{M}x{N}x{K}_s{spread}", err_ulp_mfma_f32=err[0], err_ulp_split_bf16=err[1])
+    assert np.isfinite(err[1]) and err[1] <= 1.25 * err[0] + 0.5, err
+
+
+def test_split_operand_arithmetic_keeps_all_three_terms():
+    """Operands with full 24-bit significands and products that are exactly representable (one power-of-two entry per column
+    of B): the result must be within one fp32 ulp of the exact product in both arithmetic modes.  A split that lost its third
+    bf16 term would be off by up to 2^-18, its second by 2^-9.  (Bit-exactness is not demanded of the split mode: the bf16 MFMA
+    adds its 16 products and the accumulator in one aligned sum, not as an fmaf chain, so the last bit may differ.)"""
+    from las_pytorch_amd import _cabi
+    L = _cabi.lib()
+    M, N, K = 256, 128, 64
+    g = torch.Generator().manual_seed(5)
+    A = ((torch.randint(2 ** 22, 2 ** 23, (M, K), generator=g) * 2 + 1).double() * 2.0 ** -23)      # odd 24-bit significands in [1, 2)
+    B = torch.zeros(K, N, dtype=torch.float64)
+    for n in range(N):
+        k = int(torch.randint(0, K, (1,), generator=g))
+        B[k, n] = (1.0 if n % 2 else -1.0) * 2.0 ** int(torch.randint(-6, 6, (1,), generator=g))
+    want = A @ B
+    assert (want.float().double() == want).all()        # representable in fp32
+    old = L.las_gemm_get_arith()
+    try:
+        for mode in (0, 1):
+            L.las_gemm_set_arith(mode)
+            C = torch.full((M, N), float("nan"), device="cuda")
+            _gemm(A.float().cuda(), B.float().t().contiguous().cuda(), C, M=M, N=N, K=K, lda=K, ldb=K, ldc=N, a_kc=True, b_kc=True)
+            rel = ((C.cpu().double() - want).abs() / want.abs()).max().item()
+            record(f"gemm_exact_products/arith{mode}", max_rel_err=rel)
+            assert rel <= 2.0 ** -23, f"arith {mode}: relative error {rel:.3g}"
+    finally:
+        L.las_gemm_set_arith(old)
 
 
 @pytest.mark.parametrize("a_kc", [True, False])
