@@ -57,15 +57,21 @@ typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2;
 typedef __attribute__((ext_vector_type(2))) float f32x2;
 typedef __attribute__((ext_vector_type(4))) unsigned u32x4;
 typedef __attribute__((ext_vector_type(2))) unsigned u32x2;
-// Two LDS images of a bf16 plane (128 rows x 16 k = 1088 dwords with padding), chosen by the operand's memory orientation so
-// that stores AND fragment reads are wide and conflict-free:
+// Two LDS images of a bf16 plane (128 rows x 16 k, at most 1088 dwords), chosen by the operand's memory orientation so that
+// stores AND fragment reads are wide and conflict-free:
 //   K-contiguous operand  : [k-half (2)][row][4 dwords]  (SP_KH dwords per half)  store 8 B per thread and plane, read one b128
-//   row-contiguous operand: [k-pair (8)][row]            (SP_LD dwords per pair)  store 16 B per thread and plane, read 4 dwords
+//   row-contiguous operand: [k-quad (4)][slot(row)][2 dwords]  (256 dwords per quad; a dword = one k-pair).  A thread holds ONE
+//       k-pair of four rows, its partner 32 lanes up the other k-pair of the quad for the same rows: one v_permlane32_swap per
+//       plane and row pair gives the lower lane both k-pairs of rows r, r+1 and the upper lane those of rows r+2, r+3, stored as
+//       8 bytes each; slot(row) = (row % 4) * 32 + (row / 4 + 8 (row % 4)) % 32 makes those stores (16 lanes x 8 B of one
+//       row class) and the fragment reads (32 consecutive rows = 4 classes x 8 slots, 64 distinct banks) conflict-free.
 // either way a lane ends up with k = 8 (lane / 32) .. +7 of its row in increasing order.
-constexpr int SP_LD = BM + 8;                    // +8 dwords: the two k-halves of a fragment read land on disjoint banks
+constexpr int SP_LD = BM + 8;                    // (plane size; the k-pair-major image of the first version needed the padding)
 constexpr int SP_KH = BM * 4 + 16;               // +16 dwords: the two k-halves of an 8-byte store (16 lanes, 32 banks) stay disjoint
+constexpr int SP_KQ = BM * 2;                    // dwords per k-quad of a row-contiguous operand
 constexpr int SP_PLANE = (16 / 2) * SP_LD;       // one bf16 plane of one operand tile (128 rows x 16 k)
-static_assert(SP_PLANE >= 2 * SP_KH && SP_KH % 4 == 0, "both plane images fit; 16-byte aligned k-halves");
+static __device__ __forceinline__ int sp_slot(int row) { return (row & 3) * 32 + (((row >> 2) + 8 * (row & 3)) & 31); }
+static_assert(SP_PLANE >= 2 * SP_KH && SP_PLANE >= 4 * SP_KQ && SP_KH % 4 == 0, "both plane images fit; 16-byte aligned k-halves");
 constexpr int SP_OPER = 3 * SP_PLANE;
 constexpr int SP_BUF = 2 * SP_OPER;              // A and B
 constexpr int SP_NBUF = 3;                       // tile kt is multiplied while kt+1 is read into fragments and kt+2 is stored
@@ -86,7 +92,8 @@ static __device__ __forceinline__ void split_pair(float x0, float x1, unsigned& 
 // registers of one operand tile (two 16-byte loads per thread) -> the three LDS planes, in two halves so that the caller can
 // spread the work between its MFMA groups
 //  KC : load i covers row (t + 256 i) / 4, k = 4 ((t + 256 i) % 4) .. +3         -> half i: two k-pair dwords per plane
-//  !KC: loads 0/1 cover k = 2 (t / 32) and 2 (t / 32) + 1, rows 4 (t % 32) .. +3  -> half h: rows 2h, 2h+1, one k-pair dword each
+//  !KC: loads 0/1 cover k = 2 (t / 32) and 2 (t / 32) + 1, rows 4 (t % 32) .. +3  -> half h: rows h and h+2, exchanged with the
+//       partner lane so that each lane stores both k-pairs of one row
 template <bool KC, int HALF>
 static __device__ __forceinline__ void split_store_half(unsigned* S, const f32x4 (&reg)[NLD]) {
     static_assert(NLD == 2 && BK == 16, "split path is written for BK = 16");
@@ -103,13 +110,16 @@ static __device__ __forceinline__ void split_store_half(unsigned* S, const f32x4
             *reinterpret_cast<u32x2*>(&S[pl * SP_PLANE + (q >> 1) * SP_KH + row * 4 + (q & 1) * 2]) = v;
         }
     } else {
-        const int kp = t >> 5, rq = (t & 31) * 4 + 2 * HALF;
-        split_pair(reg[0][2 * HALF], reg[1][2 * HALF], a[0], a[1], a[2]);
-        split_pair(reg[0][2 * HALF + 1], reg[1][2 * HALF + 1], b[0], b[1], b[2]);
+        // rows rq + HALF (held as k-pair 2w by lanes < 32, as k-pair 2w+1 by their partners) and rq + HALF + 2
+        const int rq = (t & 31) * 4 + HALF + ((t & 32) ? 2 : 0), kq = t >> 6;
+        split_pair(reg[0][HALF], reg[1][HALF], a[0], a[1], a[2]);
+        split_pair(reg[0][HALF + 2], reg[1][HALF + 2], b[0], b[1], b[2]);
+        unsigned* dst = S + kq * SP_KQ + sp_slot(rq) * 2;
 #pragma unroll
         for (int pl = 0; pl < 3; ++pl) {
-            u32x2 v = {a[pl], b[pl]};
-            *reinterpret_cast<u32x2*>(&S[pl * SP_PLANE + kp * SP_LD + rq]) = v;
+            auto r = __builtin_amdgcn_permlane32_swap(a[pl], b[pl], false, false);      // {[a.lo | b.lo], [a.hi | b.hi]}
+            u32x2 v = {r[0], r[1]};                                                      // (even k-pair, odd k-pair) of this lane's row
+            *reinterpret_cast<u32x2*>(dst + pl * SP_PLANE) = v;
         }
     }
 }
@@ -314,17 +324,18 @@ __device__ __forceinline__ void gemm_segment(const GemmParams& p, float (*As)[BK
                 split_load_guarded<B_KC>(Bb, p.ldb, p.N, n0, (int)kk, ke, p.b_vec, rb_);
             }
         };
-        // fragment offsets (dwords) of this lane inside an operand buffer; the second 32-row tile of a row-contiguous operand gets
-        // an offset the compiler cannot relate to the first one, so that it pairs the dword reads inside ONE register tuple
-        // (ds_read2_b32 across the two tiles needs moves, and those moves drag the LDS wait to just behind the reads)
-        int fa[2], fb[2];
+        // fragment offsets (dwords) of this lane inside an operand plane.  The second k-quad of a row-contiguous operand gets an
+        // offset the compiler cannot relate to the first, or it would merge the two 8-byte reads into one ds_read2_b64 (8 LDS
+        // cycles instead of 2 + 2)
+        int fa[2], fb[2], fa2[2], fb2[2];
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
-            fa[i] = A_KC ? lk * SP_KH + (wm + i * 32 + lr) * 4 : (4 * lk) * SP_LD + wm + i * 32 + lr;
-            fb[i] = B_KC ? lk * SP_KH + (wn + i * 32 + lr) * 4 : (4 * lk) * SP_LD + wn + i * 32 + lr;
+            fa[i] = A_KC ? lk * SP_KH + (wm + i * 32 + lr) * 4 : (2 * lk) * SP_KQ + sp_slot(wm + i * 32 + lr) * 2;
+            fb[i] = B_KC ? lk * SP_KH + (wn + i * 32 + lr) * 4 : (2 * lk) * SP_KQ + sp_slot(wn + i * 32 + lr) * 2;
+            fa2[i] = fa[i] + SP_KQ; fb2[i] = fb[i] + SP_KQ;
+            if constexpr (!A_KC) asm volatile("" : "+v"(fa2[i]));
+            if constexpr (!B_KC) asm volatile("" : "+v"(fb2[i]));
         }
-        if constexpr (!A_KC) asm volatile("" : "+v"(fa[1]));
-        if constexpr (!B_KC) asm volatile("" : "+v"(fb[1]));
         SplitFrag f;
         auto rd_a = [&](int buf, int pl) {
             const unsigned* pa = sp + buf * SP_BUF + pl * SP_PLANE;
@@ -333,8 +344,8 @@ __device__ __forceinline__ void gemm_segment(const GemmParams& p, float (*As)[BK
                 if constexpr (A_KC) {
                     f.a[pl][i] = *reinterpret_cast<const u32x4*>(pa + fa[i]);
                 } else {
-#pragma unroll
-                    for (int q = 0; q < 4; ++q) f.a[pl][i][q] = pa[fa[i] + q * SP_LD];
+                    const u32x2 lo = *reinterpret_cast<const u32x2*>(pa + fa[i]), hi = *reinterpret_cast<const u32x2*>(pa + fa2[i]);
+                    f.a[pl][i] = u32x4{lo[0], lo[1], hi[0], hi[1]};
                 }
             }
         };
@@ -345,8 +356,8 @@ __device__ __forceinline__ void gemm_segment(const GemmParams& p, float (*As)[BK
                 if constexpr (B_KC) {
                     f.b[pl][i] = *reinterpret_cast<const u32x4*>(pb + fb[i]);
                 } else {
-#pragma unroll
-                    for (int q = 0; q < 4; ++q) f.b[pl][i][q] = pb[fb[i] + q * SP_LD];
+                    const u32x2 lo = *reinterpret_cast<const u32x2*>(pb + fb[i]), hi = *reinterpret_cast<const u32x2*>(pb + fb2[i]);
+                    f.b[pl][i] = u32x4{lo[0], lo[1], hi[0], hi[1]};
                 }
             }
         };
