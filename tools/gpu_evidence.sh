@@ -14,10 +14,17 @@ cd /tmp && export TMPDIR=/tmp
 rocprofv3 --kernel-trace --stats -d $O/stats -o x -- python3 $R/bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-sweep --no-mfma --no-roofline --no-secondary > $O/stats.log 2>&1
 rocprofv3 --pmc FETCH_SIZE -d $O/pmc_fetch -o x -- python3 $R/tools/ubench_rec.py > $O/pmc_fetch.log 2>&1
 rocprofv3 --pmc WRITE_SIZE -d $O/pmc_write -o x -- python3 $R/tools/ubench_rec.py > $O/pmc_write.log 2>&1
-rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU_MFMA_MOPS_F32 GRBM_GUI_ACTIVE -d $O/pmc_gemm_a -o x -- python3 $R/tools/ubench_gemm_pmc.py > $O/pmc_gemm_a.log 2>&1
-rocprofv3 --pmc SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_VMEM SQ_INSTS_LDS SQ_WAIT_INST_LDS SQ_ACTIVE_INST_VALU SQ_INSTS_VALU -d $O/pmc_gemm_b -o x -- python3 $R/tools/ubench_gemm_pmc.py > $O/pmc_gemm_b.log 2>&1
+# MFMA-busy / stall / LDS counters of the GEMM in both arithmetic modes (1 = split-operand bf16 MFMA, the default; 0 = fp32 MFMA)
+for a in 1 0; do
+  export LAS_GEMM_ARITH=$a
+  if [ $a = 1 ]; then MOPS=SQ_INSTS_VALU_MFMA_MOPS_BF16; else MOPS=SQ_INSTS_VALU_MFMA_MOPS_F32; fi
+  rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY $MOPS GRBM_GUI_ACTIVE -d $O/pmc_gemm_a$a -o x -- python3 $R/tools/ubench_gemm_pmc.py > $O/pmc_gemm_a$a.log 2>&1
+  rocprofv3 --pmc SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_VMEM SQ_INSTS_LDS SQ_WAIT_INST_LDS SQ_ACTIVE_INST_VALU SQ_INSTS_VALU -d $O/pmc_gemm_b$a -o x -- python3 $R/tools/ubench_gemm_pmc.py > $O/pmc_gemm_b$a.log 2>&1
+done
+unset LAS_GEMM_ARITH
 cd $R
 python tools/ubench_rec_sweep.py > $O/rec_sweep.log 2>&1
+python tools/ubench_gemm_split.py > $O/gemm_split.log 2>&1
 # soak: 1500 consecutive training steps (~1e7 inter-workgroup hand-offs) must end without a device error word
 python bench.py --steps 1500 --warmup 5 --no-cpu-baseline --no-sweep --no-mfma --no-roofline --no-secondary > $O/soak.json 2> $O/soak.err
 for w in "P_long 8" "S_train 32" "Y_train 16" "P_fwd 32" "S_fwd 32" "P_train 128"; do set -- $w; python bench.py --workload $1 --batch $2 --steps 10 --warmup 3 --no-cpu-baseline --no-sweep --no-mfma --no-secondary --no-roofline 2>/dev/null | tail -1; done > $O/variants.jsonl

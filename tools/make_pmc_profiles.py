@@ -2,7 +2,7 @@
 """Turn the rocprofv3 --pmc result databases of a GPU run into the JSON summaries kept under profiles/.
 
     python tools/make_pmc_profiles.py rec  <fetch.db> <write.db>  B T_l H  -> profiles/r02_pmc_rec_fwd.json
-    python tools/make_pmc_profiles.py gemm <sq_a.db> <sq_b.db>             -> profiles/r02_pmc_gemm.json
+    python tools/make_pmc_profiles.py gemm <arith> <sq_a.db> <sq_b.db> ...  -> profiles/r02_pmc_gemm.json
 
 The recurrence file carries the sha256 prefix of the kernel source it was measured on; bench.py refuses to quote a file
 whose hash no longer matches (the traffic figure would be stale)."""
@@ -65,32 +65,37 @@ def rec(fetch_db, write_db, B, T_l, H):
     print(path, json.dumps(out)[:400])
 
 
-def gemm(db_a, db_b):
-    a = rows(db_a, "gemm_f32_kernel"); b = rows(db_b, "gemm_f32_kernel")
-    names = {131072: "6400x1024x1024 / 1024x1024x6400 (512 resident workgroups)", 262144: "4096^3 (1024 workgroups)"}
-    out = {"counters": "rocprofv3 --pmc, two passes (SQ set a / SQ set b) over tools/ubench_gemm_pmc.py", "kernels": []}
-    for key, d in a.items():
-        e = dict(d)
-        if key in b:
-            e.update(b[key])
-        n = e["SQ_VALU_MFMA_BUSY_CYCLES"][1]
-        m = {c: v[0] / v[1] for c, v in e.items()}
-        dur_us = e["SQ_VALU_MFMA_BUSY_CYCLES"][2] / n / 1e3
-        gui_per_xcd = m["GRBM_GUI_ACTIVE"] / 8.0
-        flops = m["SQ_INSTS_VALU_MFMA_MOPS_F32"] * 512.0
-        out["kernels"].append({
-            "kernel": key[0], "grid_threads": key[1], "launches": n, "duration_us_under_pmc": round(dur_us, 1),
-            "mfma_flops_counted": flops, "tflops_under_pmc": round(flops / dur_us / 1e6, 1),
-            "MfmaUtil_pct": round(100.0 * m["SQ_VALU_MFMA_BUSY_CYCLES"] / (gui_per_xcd * 1024.0), 1),
-            "SQ_VALU_MFMA_BUSY_CYCLES": m["SQ_VALU_MFMA_BUSY_CYCLES"], "GRBM_GUI_ACTIVE_sum_over_8_xcd": m["GRBM_GUI_ACTIVE"],
-            "SQ_WAVE_CYCLES": m["SQ_WAVE_CYCLES"], "SQ_WAIT_ANY": m["SQ_WAIT_ANY"], "SQ_WAIT_INST_ANY": m["SQ_WAIT_INST_ANY"],
-            "SQ_ACTIVE_INST_ANY": m["SQ_ACTIVE_INST_ANY"], "wait_any_frac_of_wave_cycles": round(m["SQ_WAIT_ANY"] / m["SQ_WAVE_CYCLES"], 3),
-            "SQ_LDS_BANK_CONFLICT": m.get("SQ_LDS_BANK_CONFLICT"), "SQ_LDS_IDX_ACTIVE": m.get("SQ_LDS_IDX_ACTIVE"),
-            "SQ_INSTS_LDS": m.get("SQ_INSTS_LDS"), "SQ_INSTS_VALU": m.get("SQ_INSTS_VALU"),
-        })
-    out["reading"] = ("MfmaUtil = SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE per XCD x 1024 SIMDs): the fp32 matrix pipe is busy 58-75 % of "
-                      "the kernel; SQ_WAIT_ANY (s_waitcnt / barrier) is 22-28 % of the wave cycles: the register-staged double buffer with one "
-                      "barrier per 16-wide k-tile is what is left on the table, not LDS conflicts (0-25 % of a lightly used LDS) or VALU work.")
+def gemm(dbs):
+    """dbs = [(arith, sq_a.db, sq_b.db), ...]"""
+    out = {"counters": "rocprofv3 --pmc, two passes (SQ set a / SQ set b) per arithmetic mode over tools/ubench_gemm_pmc.py "
+                       "(6400x1024x1024 NT / NN, 1024x1024x6400 TN, 2048x512x4096 TN, 4096^3 NT; three launches each)", "kernels": []}
+    for arith, db_a, db_b in dbs:
+        a = rows(db_a, "gemm_f32_kernel"); b = rows(db_b, "gemm_f32_kernel")
+        for key, d in a.items():
+            e = dict(d)
+            if key in b:
+                e.update(b[key])
+            n = e["SQ_VALU_MFMA_BUSY_CYCLES"][1]
+            m = {c: v[0] / v[1] for c, v in e.items()}
+            dur_us = e["SQ_VALU_MFMA_BUSY_CYCLES"][2] / n / 1e3
+            gui_per_xcd = m["GRBM_GUI_ACTIVE"] / 8.0
+            mops = m.get("SQ_INSTS_VALU_MFMA_MOPS_BF16", m.get("SQ_INSTS_VALU_MFMA_MOPS_F32"))
+            out["kernels"].append({
+                "arith": "split-operand bf16 MFMA (6 products)" if arith == 1 else "fp32 MFMA",
+                "kernel": key[0], "grid_threads": key[1], "launches": n, "duration_us_under_pmc": round(dur_us, 1),
+                "mfma_mops_counted": mops, "sclk_MHz_under_pmc": round(gui_per_xcd / dur_us, 0),
+                "MfmaUtil_pct": round(100.0 * m["SQ_VALU_MFMA_BUSY_CYCLES"] / (gui_per_xcd * 1024.0), 1),
+                "SQ_VALU_MFMA_BUSY_CYCLES": m["SQ_VALU_MFMA_BUSY_CYCLES"], "GRBM_GUI_ACTIVE_sum_over_8_xcd": m["GRBM_GUI_ACTIVE"],
+                "SQ_WAVE_CYCLES": m["SQ_WAVE_CYCLES"], "SQ_WAIT_ANY": m["SQ_WAIT_ANY"], "SQ_WAIT_INST_ANY": m["SQ_WAIT_INST_ANY"],
+                "SQ_ACTIVE_INST_ANY": m["SQ_ACTIVE_INST_ANY"], "wait_any_frac_of_wave_cycles": round(m["SQ_WAIT_ANY"] / m["SQ_WAVE_CYCLES"], 3),
+                "SQ_LDS_BANK_CONFLICT": m.get("SQ_LDS_BANK_CONFLICT"), "SQ_LDS_IDX_ACTIVE": m.get("SQ_LDS_IDX_ACTIVE"),
+                "lds_busy_frac_of_kernel": round(m.get("SQ_LDS_IDX_ACTIVE", 0.0) / (gui_per_xcd * 256.0), 3),
+                "SQ_INSTS_LDS": m.get("SQ_INSTS_LDS"), "SQ_INSTS_VALU": m.get("SQ_INSTS_VALU"),
+            })
+    out["reading"] = ("MfmaUtil = SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE per XCD x 1024 SIMDs) at the clock the profiler runs the chip at "
+                      "(sclk column; lower than an unprofiled run's).  fp32 MFMA: the fp32 matrix pipe is busy 58-75 % of the kernel.  Split-operand "
+                      "mode: the bf16 pipe is busy for the same number of cycles per output as 3/8 of the fp32 case (six 32-cycle MFMAs instead "
+                      "of eight 64-cycle ones per 16 k), the kernel is LDS- and issue-paced: lds_busy_frac = SQ_LDS_IDX_ACTIVE / (cycles x 256 CUs).")
     path = os.path.join(ROOT, "profiles", "r02_pmc_gemm.json")
     json.dump(out, open(path, "w"), indent=1)
     print(path)
@@ -100,4 +105,5 @@ if __name__ == "__main__":
     if sys.argv[1] == "rec":
         rec(sys.argv[2], sys.argv[3], int(sys.argv[4]), int(sys.argv[5]), int(sys.argv[6]))
     else:
-        gemm(sys.argv[2], sys.argv[3])
+        args = sys.argv[2:]       # arith db_a db_b [arith db_a db_b ...]
+        gemm([(int(args[i]), args[i + 1], args[i + 2]) for i in range(0, len(args), 3)])
