@@ -304,8 +304,8 @@ def launch_ranks(n):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--steps", type=int, default=100)
+    ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--workload", default="P_train", choices=sorted(WORKLOADS))
     ap.add_argument("--batch", type=int, default=32, help="utterances per GPU (weak scaling: fixed per-GPU batch)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
