@@ -50,7 +50,8 @@ def main():
                                               "rows": gemm_rows}},
               open(os.path.join(P, "r02_parity_observed.json"), "w"), indent=1)
     open(os.path.join(P, "r02_rec_sweep.txt"), "w").write(open(os.path.join(E, "rec_sweep.log")).read())
-    open(os.path.join(P, "r02_pytest_gpu.txt"), "w").write("".join(open(os.path.join(E, "pytest_gpu.log")).readlines()[-6:]))
+    lines = open(os.path.join(E, "pytest_gpu.log")).readlines()
+    open(os.path.join(P, "r02_pytest_gpu.txt"), "w").write("".join([l for l in lines if " passed" in l or " failed" in l or l.startswith("FAILED")] + lines[-6:]))
     runs = []
     for l in open(os.path.join(E, "variants.jsonl")):
         if l.startswith("{"):

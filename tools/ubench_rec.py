@@ -3,6 +3,7 @@ import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
 from las_pytorch_amd import _cabi
+if os.environ.get("LAS_ABL_LIB"): _cabi.LIB_PATH = os.path.abspath(os.environ["LAS_ABL_LIB"])      # an experiment build instead of the product library
 L = _cabi.lib()
 B, T, H = int(os.environ.get("B", 32)), int(os.environ.get("T", 400)), int(os.environ.get("H", 256))
 g = torch.Generator().manual_seed(0)
