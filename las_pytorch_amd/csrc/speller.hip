@@ -357,7 +357,7 @@ int smallm_gemm_nn2(const float* a, long lda, int B, int K, const float* w0, lon
 // Every phase is shaped so that ALL of its global loads are independent and issued together (one L2 round trip
 // per phase): the decode step is a chain of ~6 dependent phases and each costs a memory latency, not bandwidth.
 // ------------------------------------------------------------------------------------------------
-constexpr int ATT_THREADS = 1024, ATT_NW = 16, ATT_MAX_TP = 4096, ATT_MAX_V = 128;
+constexpr int ATT_THREADS = 1024, ATT_MAX_TP = 4096, ATT_MAX_V = 128;
 
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll

@@ -192,3 +192,31 @@ def test_training_trajectory_matches_reference():
         record(f"S_trajectory/reducer={use_reducer}", max_abs_err=worst, worst_ratio=worst / 1e-3)
     torch.cuda.synchronize()
     las_pytorch_amd.check_device_errors()
+
+
+def test_bench_line_contract():
+    """`python bench.py` (short run, one GPU) prints ONE JSON line with the fields the driver's contract names, the hot-path
+    `roofline` block, the GEMM `roofline_mfma` block, the measured GEMM accuracy of both arithmetic modes and the same step timed
+    with the GEMMs on the fp32 matrix pipe; the CPU baseline leg is exercised by the full default run only (it takes ~30 s)."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    p = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--steps", "3", "--warmup", "2", "--no-cpu-baseline", "--no-sweep"],
+                       capture_output=True, text=True, timeout=600, cwd=root)
+    assert p.returncode == 0, p.stderr[-2000:]
+    lines = [l for l in p.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, p.stdout[-2000:]
+    j = json.loads(lines[0])
+    base = json.load(open(os.path.join(root, "BASELINE.json")))
+    assert j["metric"] == base["metric"] and j["unit"] == "utt/s" and j["n_gpus"] == 1 and j["steps"] == 3 and j["warmup"] == 2
+    assert j["higher_is_better"] is True and j["scaling"] == "weak" and j["vs_baseline"] is None and j["dtype"] == "f32"
+    assert j["value"] > 0 and abs(j["value"] - 32 / (j["ms_per_step"] * 1e-3)) < 0.01 * j["value"]
+    assert "workload" in j["config"] and "gemm_arith" in j["config"]
+    r = j["roofline"]
+    assert r["bound"] == "hbm" and r["peak"] == 8000.0 and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-4
+    m = j["roofline_mfma"]
+    assert m["bound"] == "mfma" and abs(m["frac"] - m["achieved"] / m["peak"]) < 2e-3 and len(m["launches"]) >= 15
+    acc = j["gemm_accuracy"]
+    assert acc["split_bf16_err_ulp"] <= 1.25 * acc["mfma_f32_err_ulp"] + 0.5, acc
+    assert j["gemm_arith_variant"]["ms_per_step"] > 0

@@ -66,6 +66,23 @@ def _loss_ls(preds, lab, U):
     return label_smoothing_loss(pred_y, lab[:, :U, :].float(), label_smoothing=0.1)
 
 
+@pytest.fixture
+def fp32_mfma_gemm():
+    """The GEMMs on the fp32 matrix pipe (LAS_GEMM_ARITH=0) for one test; the default is the split-operand bf16-MFMA arithmetic."""
+    from las_pytorch_amd import _cabi
+    L = _cabi.lib()
+    old = L.las_gemm_get_arith()
+    L.las_gemm_set_arith(0)
+    yield
+    L.las_gemm_set_arith(old)
+
+
+@pytest.mark.parametrize("name", ["P_B32_T800_U32", "S_B32_T800_U32", "tiny_mh4"])
+def test_grads_golden_fp32_mfma_gemm(name, fp32_mfma_gemm):
+    """The reference goldens at the benchmark's size with the GEMMs in their other arithmetic mode (both modes are shipped)."""
+    test_grads_golden(name)
+
+
 @pytest.mark.parametrize("name", [n for n in HIP_CASES if n not in ("S_T800", "P_T800")])
 def test_grads_golden(name):
     g, info, sd_np, x, idx, lens, onehot = load_case(name)
