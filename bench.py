@@ -82,6 +82,36 @@ def _sha16(path):
     return hashlib.sha256(open(path, "rb").read()).hexdigest()[:16]
 
 
+def csrc_sha16():
+    """One hash over everything the kernels are built from: every file of las_pytorch_amd/csrc (sources, headers, the Makefile
+    with its CXXFLAGS) and include/las_hip.h.  The committed PMC measurements carry it; a stale one is refused, not quoted."""
+    import hashlib
+    h = hashlib.sha256()
+    d = os.path.join(ROOT, "las_pytorch_amd", "csrc")
+    for name in sorted(os.listdir(d)):
+        if name.endswith((".hip", ".h")) or name == "Makefile":
+            h.update(name.encode()); h.update(open(os.path.join(d, name), "rb").read())
+    h.update(open(os.path.join(ROOT, "include", "las_hip.h"), "rb").read())
+    return h.hexdigest()[:16]
+
+
+def pmc_traffic(tag, shape):
+    """HBM bytes per launch from a committed counter run (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes, corrected as
+    guides/MI355X_MICROARCH.md prescribes; tools/make_pmc_profiles.py writes the JSON): the newest profiles/*<tag>*.json whose shape and
+    source hash match this build.  Returns (bytes | None, source string | None)."""
+    want = csrc_sha16()
+    for name in sorted(os.listdir(os.path.join(ROOT, "profiles")), reverse=True):
+        if not (name.endswith(".json") and tag in name):
+            continue
+        j = json.load(open(os.path.join(ROOT, "profiles", name)))
+        if j.get("shape") != shape:
+            continue
+        if j.get("csrc_sha16") == want:
+            return int(j["traffic_bytes"]), "profiles/" + name
+        return None, f"profiles/{name} is stale (kernel sources / flags changed since it was measured): not quoted"
+    return None, None
+
+
 def build_model(cfg_name, U, device):
     from las_pytorch_amd import LAS, Listener, Speller, synth
     c = synth.CONFIGS[cfg_name]
@@ -144,19 +174,7 @@ def roofline_rec_fwd(c, B, T, iters=20, with_traffic=True):
     # HBM bytes per launch from the PMC counters (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes): measured
     # offline on this kernel and shape and committed under profiles/ (a counter run cannot nest inside this process)
     # The JSON names the kernel source it was measured on (sha256 of pblstm_rec.hip): a stale file is refused, not quoted.
-    traffic, traffic_src = None, None
-    if with_traffic:
-        src_hash = _sha16(os.path.join(ROOT, "las_pytorch_amd", "csrc", "pblstm_rec.hip"))
-        for name in sorted(os.listdir(os.path.join(ROOT, "profiles")), reverse=True):
-            if not (name.endswith(".json") and "pmc_rec_fwd" in name):
-                continue
-            j = json.load(open(os.path.join(ROOT, "profiles", name)))
-            if j.get("shape") == dict(B=B, T_l=T_l, H=H):
-                if j.get("kernel_source_sha16") == src_hash:
-                    traffic, traffic_src = int(j["traffic_bytes"]), "profiles/" + name
-                else:
-                    traffic_src = f"profiles/{name} is stale (kernel source changed since it was measured): not quoted"
-                break
+    traffic, traffic_src = pmc_traffic("pmc_rec_fwd", dict(B=B, T_l=T_l, H=H)) if with_traffic else (None, None)
     return dict(bound="hbm", kernel=f"rec_fwd_fast<{H}> layer0 (B={B},T_l={T_l})", achieved=round(achieved, 2), peak=HBM_PEAK_GBS,
                 unit="GB/s", frac=round(achieved / HBM_PEAK_GBS, 5), traffic=traffic, traffic_source=traffic_src,
                 kernel_ms=round(ms, 4), us_per_step=round(ms * 1e3 / T_l, 3), algorithmic_bytes=alg_bytes)
@@ -265,6 +283,116 @@ def sweep_rec(c, T, batches=(32, 128, 512)):
     return out
 
 
+def speller_param_bytes(c):
+    Hs, V, M = c["Hs"], c["V"], c["M"]
+    n = 4 * Hs * (V + Hs) + 4 * Hs * Hs + 2 * 4 * Hs * Hs + 4 * 4 * Hs + 2 * (M * Hs + M) + V * 2 * Hs + V
+    return 4 * n
+
+
+def roofline_speller(step, c, B, T, U, iters=10):
+    """The two kernels that dominate the step by time — the one-launch decode loop forward and backward — each timed ALONE with
+    HIP events on its launch stream (library option TIME_KERNELS: events recorded around that one launch inside liblas_hip.so,
+    read back with las_debug_kernel_ms) while the real training step runs.  Algorithmic bytes per SURVEY.md section 8d: per utterance
+    feat 4*T'*2H + log-probs 4*U*V + attention 4*U*T', plus the Speller's weights once per launch; backward = 3x (every operand read
+    again, gradients written).  Both are chains of U dependent steps: the fraction is the honest distance from the HBM roofline,
+    us_per_decode_step is what the design actually works on."""
+    import ctypes
+    from las_pytorch_amd import _cabi
+    Tp = T >> c["L"]
+    per_utt = 4 * Tp * c["Hs"] + 4 * U * c["V"] + 4 * U * Tp
+    alg_fwd = B * per_utt + speller_param_bytes(c)
+    _cabi.set_option("TIME_KERNELS", 1)
+    ms = {0: [], 1: []}
+    try:
+        for _ in range(iters):
+            step()
+            for which in (0, 1):
+                v = ctypes.c_float(0.0)
+                if _cabi.lib().las_debug_kernel_ms(which, ctypes.byref(v)) == 0:
+                    ms[which].append(float(v.value))
+    finally:
+        _cabi.set_option("TIME_KERNELS", 0)
+    out = {}
+    for which, key, alg, tag in ((0, "roofline_speller_fwd", alg_fwd, "pmc_speller_fwd"), (1, "roofline_speller_bwd", 3 * alg_fwd, "pmc_speller_bwd")):
+        if not ms[which]:
+            continue           # the per-step kernels ran (shape outside the one-launch kernels)
+        t = float(np.mean(ms[which]))
+        ach = alg / (t * 1e-3) / 1e9
+        traffic, src = pmc_traffic(tag, dict(B=B, Tp=Tp, U=U, Hs=c["Hs"]))
+        out[key] = dict(bound="hbm", kernel=("speller_persist_fwd_pre_kernel" if which == 0 else "speller_persist_bwd_pre_kernel") + f"<{c['Hs']}> (B={B},T'={Tp},U={U})",
+                        achieved=round(ach, 2), peak=HBM_PEAK_GBS, unit="GB/s", frac=round(ach / HBM_PEAK_GBS, 5), traffic=traffic,
+                        traffic_source=src, kernel_ms=round(t, 4), us_per_decode_step=round(t * 1e3 / U, 3), algorithmic_bytes=int(alg))
+    return out
+
+
+def allreduce_alone_ms(reducer, iters=10):
+    """The step's ONE collective (flat fp32 gradient + the error flag) timed alone on the step's stream; meaningful for N > 1
+    ranks, and with LAS_FORCE_DIST=1 it shows the 1-rank RCCL launch floor."""
+    if not reducer._collective():
+        return None
+    for _ in range(2):
+        reducer.allreduce_mean()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(iters):
+        reducer.allreduce_mean()
+    e1.record(); torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / iters
+
+
+def make_train_step(las, x, lab, reducer, opt, graph=False):
+    """One training step of the benchmark as a callable returning the loss tensor: zero the flat gradient, forward (teacher
+    forced), fused label-smoothing loss + gradient, backward through every HIP kernel, ONE gradient all-reduce (N > 1), global-norm
+    clip at 1.0 + Adam as the fused launch pair.  graph=True captures zero + forward + loss + backward into one HIP graph
+    (all-reduce / clip / Adam stay eager behind the replay)."""
+    from las_pytorch_amd.solver.solver import label_smoothing_loss_device, stack_steps
+
+    def fwd_bwd():
+        reducer.zero()
+        preds, _ = las(batch_data=x, batch_label=lab, teacher_force_rate=1.0, is_training=True)
+        loss = label_smoothing_loss_device(stack_steps(preds), lab, 0.1)      # fused loss + gradient kernel, no copies
+        loss.backward()
+        return loss
+
+    def tail():
+        reducer.allreduce_mean()
+        opt.step_clipped(1.0)
+
+    if not graph:
+        def step():
+            loss = fwd_bwd()
+            tail()
+            return loss
+        return step
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        for _ in range(3):
+            fwd_bwd()
+    torch.cuda.current_stream().wait_stream(side)
+    torch.cuda.synchronize()
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g):
+        static_loss = fwd_bwd()
+
+    def step():  # noqa: F811
+        g.replay()
+        tail()
+        return static_loss
+    step.graph = g
+    return step
+
+
+def cpu_model_name():
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.lower().startswith("model name"):
+                return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
+
+
 def cpu_baseline(cfg_name, B, T, U, train):
     from las_pytorch_amd import synth
     from oracle import cpu_baseline as CB
@@ -276,12 +404,17 @@ def cpu_baseline(cfg_name, B, T, U, train):
     host_threads = torch.get_num_threads()
     threads = CB.best_threads(c, sd_np, x, onehot, train=train)
     r = CB.time_cpu(c, sd_np, x, onehot, train=train, iters=3, warmup=1, threads=threads)
+    # single thread (SURVEY.md section 8d asks for it: the decode loop is dispatch-bound), on a quarter of the batch to stay bounded
+    Bs = max(1, B // 4)
+    r1 = CB.time_cpu(c, sd_np, x[:Bs], onehot[:Bs], train=train, iters=1, warmup=1, threads=1)
     torch.set_num_threads(host_threads)
     return dict(value=round(r["utt_per_s"], 3), unit="utt/s", cores=r["threads"], kind="port",
                 sample=f"{r['iters']} steps after 1 warm-up of the same workload (B={B},T={T},U={U}, {'fwd+loss+bwd+clip+Adam' if train else 'fwd'}) "
                        f"on the host CPU with the fastest of 8/16/32 torch threads (host offers {host_threads}; the dispatch-bound decode "
                        f"loop slows down beyond that), torch {torch.__version__} oneDNN LSTM path, {r['ms_per_step']:.0f} ms/step",
-                ms_per_step=round(r["ms_per_step"], 1))
+                ms_per_step=round(r["ms_per_step"], 1), cpu_model=cpu_model_name(), host_threads=host_threads,
+                single_thread={"value": round(r1["utt_per_s"], 3), "unit": "utt/s", "cores": 1, "ms_per_step": round(r1["ms_per_step"], 1),
+                               "sample": f"1 step after 1 warm-up of the same workload at B={Bs} (a quarter of the batch), one torch thread"})
 
 
 def launch_ranks(n):
@@ -314,6 +447,9 @@ def main():
     ap.add_argument("--no-sweep", action="store_true")
     ap.add_argument("--no-mfma", action="store_true")
     ap.add_argument("--graph", type=int, default=0, help="1: replay fwd+loss+bwd as one captured HIP graph per step")
+    ap.add_argument("--scaling", default="weak", choices=["weak", "strong"],
+                    help="weak: --batch utterances per GPU (default); strong: --global-batch utterances split over the GPUs")
+    ap.add_argument("--global-batch", type=int, default=256, help="total utterances per step with --scaling strong (SURVEY 8d config 3: 256)")
     args = ap.parse_args()
 
     if "WORLD_SIZE" not in os.environ and args.gpus > 1:
@@ -329,62 +465,41 @@ def main():
     if use_dist:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        os.environ.setdefault("MASTER_PORT", "29511")
+        if "MASTER_PORT" not in os.environ:          # single process (LAS_FORCE_DIST=1): any free port; launchers set their own
+            import socket
+            sk = socket.socket(); sk.bind(("127.0.0.1", 0)); os.environ["MASTER_PORT"] = str(sk.getsockname()[1]); sk.close()
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
+        if dist.get_world_size() != args.gpus:
+            raise SystemExit(f"bench.py: --gpus {args.gpus} but the RCCL group has {dist.get_world_size()} ranks")
 
     import las_pytorch_amd
     from las_pytorch_amd import dp, synth
-    from las_pytorch_amd.solver.solver import label_smoothing_loss_device, stack_steps
+    from las_pytorch_amd.optim import FusedClipAdam
 
     cfg_name, T, U, train = WORKLOADS[args.workload]
     B = args.batch
+    if args.scaling == "strong":
+        if args.global_batch % world != 0:
+            raise SystemExit(f"bench.py: --global-batch {args.global_batch} does not divide over {world} ranks")
+        B = args.global_batch // world
     las, c, _ = build_model(cfg_name, U, device)
     x = torch.from_numpy(synth.make_inputs(B, T, c["F"], seed=17, rank=rank)).to(device)
     idx, lens = synth.make_labels(B, U, c["V"], seed=17, rank=rank)
     lab = torch.from_numpy(synth.onehot_labels(idx, lens, c["V"])).to(device)
     labf = lab.float()
 
+    first_loss = None
     if train:
         reducer = dp.FlatGradAllReducer(las, force=os.environ.get("LAS_FORCE_DIST") == "1", direct=True)
-        opt = torch.optim.Adam(las.parameters(), lr=2e-4, fused=True)
-
-        def step():
-            reducer.zero()
-            preds, _ = las(batch_data=x, batch_label=lab, teacher_force_rate=1.0, is_training=True)
-            loss = label_smoothing_loss_device(stack_steps(preds), lab, 0.1)      # fused loss + gradient kernel, no copies
-            loss.backward()
-            reducer.allreduce_mean()
-            reducer.clip_(1.0)
-            opt.step()
-            return loss
+        opt = FusedClipAdam(reducer, lr=2e-4)          # clip_grad_norm_(params, 1) + Adam(lr 2e-4) as two HIP launches
+        eager_step = make_train_step(las, x, lab, reducer, opt)
+        first_loss = float(eager_step().item())         # the loss at the initial weights: checked against the reference below
+        step = make_train_step(las, x, lab, reducer, opt, graph=True) if args.graph else eager_step
     else:
         def step():
             with torch.no_grad():
                 preds, _ = las(batch_data=x, batch_label=lab, teacher_force_rate=1.0, is_training=True)
             return preds[-1]
-
-    if args.graph and train:
-        # capture fwd + loss + bwd (+ gradient zeroing) once; all-reduce / clip / Adam stay eager after the replay
-        side = torch.cuda.Stream()
-        side.wait_stream(torch.cuda.current_stream())
-        with torch.cuda.stream(side):
-            for _ in range(3):
-                step()
-        torch.cuda.current_stream().wait_stream(side)
-        torch.cuda.synchronize()
-        graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(graph):
-            reducer.zero()
-            preds, _ = las(batch_data=x, batch_label=lab, teacher_force_rate=1.0, is_training=True)
-            static_loss = label_smoothing_loss_device(stack_steps(preds), lab, 0.1)
-            static_loss.backward()
-
-        def step():  # noqa: F811
-            graph.replay()
-            reducer.allreduce_mean()
-            reducer.clip_(1.0)
-            opt.step()
-            return static_loss
 
     for _ in range(args.warmup):
         step()
@@ -408,7 +523,18 @@ def main():
     las_pytorch_amd.check_device_errors()
     final = float(last.float().mean().item())
     assert np.isfinite(final), "non-finite result in the timed region"
+    # parity hook inside the benchmark itself: rank 0's loss at the initial weights on the default workload equals the loss the
+    # UNMODIFIED reference computes on the same inputs (tests/golden/P_B32_T800_U128.npz: same seeds, same shapes)
+    ref_loss = None
+    gpath = os.path.join(ROOT, "tests", "golden", "P_B32_T800_U128.npz")
+    if train and rank == 0 and args.workload == "P_train" and B == 32 and os.path.exists(gpath):
+        ref_loss = float(np.load(gpath)["loss_ls"][0])
+        assert abs(first_loss - ref_loss) <= 1e-4 * abs(ref_loss), f"first-step loss {first_loss} != reference {ref_loss}"
 
+    # every rank takes part in what contains a collective: the step's all-reduce timed alone, and the training steps under which the
+    # two decode kernels are event-timed
+    ar_ms = allreduce_alone_ms(reducer) if train else None
+    speller_roof = roofline_speller(step, c, B, T, U) if (train and not args.no_roofline) else {}
     if rank == 0:
         ms = dt / args.steps * 1e3
         try:
@@ -418,13 +544,15 @@ def main():
         res = {
             "metric": metric_name, "value": round(world * B * args.steps / dt, 2), "unit": "utt/s", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms, 3), "higher_is_better": True,
-            "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "scaling": args.scaling, "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "rccl_ranks": dist.get_world_size() if use_dist else 0,
             "config": {"workload": f"{args.workload}: Listener {c['H']}x{c['L']} / Speller {c['Hs']}x{c['Ls']}, "
                                    f"(B={B},T={T},F={c['F']}) log-mel per GPU, teacher-forced U={U}, "
                                    + ("fwd + label-smoothing loss + bwd + grad all-reduce + clip(1.0) + Adam" if train else "fwd only"),
                        "per_gpu_batch": B, "global_batch": B * world, "frames": T, "decode_steps": U,
-                       "parallelism": f"dp{world}", "final_loss_or_logp": round(final, 6)},
+                       "parallelism": f"dp{world}", "final_loss_or_logp": round(final, 6),
+                       "first_step_loss": first_loss, "first_step_loss_reference": ref_loss,
+                       "optimizer": "clip(1.0) + Adam(2e-4) as las_clip_adam (two HIP launches on the flat gradient)" if train else None},
         }
         res["config"]["gemm_arith"] = gemm_arith()[1]
         if world == 1 and train and not args.no_mfma:
@@ -448,6 +576,10 @@ def main():
             res["gemm_accuracy"] = gemm_accuracy()
         if not args.no_roofline:
             res["roofline"] = roofline_rec_fwd(c, B, T)
+            res.update(speller_roof)
+        if train:
+            res["allreduce_ms"] = None if ar_ms is None else round(ar_ms, 4)
+            res["allreduce_bytes"] = 4 * reducer.flat_ext.numel()
         if world == 1 and train and not args.no_mfma:
             res["roofline_mfma"] = roofline_mfma(c, B, T, U)
         if world == 1 and not args.no_sweep and not args.no_roofline:

@@ -15,7 +15,10 @@
  *     message.  Never throws, never exits.
  *   - `err_word` is a caller-owned, zero-initialised device uint32: kernels that hand data between
  *     workgroups write a nonzero code there if a bounded spin expires (results are then invalid).
- *   - Re-entrant per device; no global mutable state (the undeclared las_debug_* profiling hooks aside).
+ *   - Re-entrant per device.  Process-wide state is limited to (a) the mutex-guarded per-device RCCL handles, (b) the option
+ *     registry below (atomics, initialised once from LAS_<NAME> environment variables: A/B and profiling switches whose
+ *     defaults are the measured best) and (c) the las_debug_* profiling hooks declared at the end of this header.  Nothing a
+ *     call computes depends on another thread's call; the GEMM arithmetic can be chosen per call (LAS_FLAG_GEMM_F32).
  *   - The persistent kernels (Listener recurrences; the one-launch Speller decode loop, chosen automatically for
  *     2-layer single-head MLP-attention spellers with Hs in {256,512}, B <= 32) need every workgroup resident at
  *     once, up to all compute units of the device: do not run other kernels concurrently on other streams while a
@@ -33,7 +36,7 @@
 extern "C" {
 #endif
 
-#define LAS_ABI_VERSION 4
+#define LAS_ABI_VERSION 5
 #define LAS_MAX_SPELLER_LAYERS 4
 
 /* flags */
@@ -44,8 +47,29 @@ extern "C" {
                                        (feat.W_ctx^T and its per-step attention-weighted sums); without it the backward
                                        recomputes nothing and runs its classic path — always correct, about 0.4 ms slower. */
 
+#define LAS_FLAG_GEMM_F32       8   /* this call's MFMA GEMMs run on the fp32 matrix pipe (v_mfma_f32_32x32x2_f32) whatever the
+                                       process-wide GEMM_ARITH option says: per-call, per-thread, re-entrant */
+
 int las_abi_version(void);
 const char* las_last_error(void);
+
+/* ------------------------------------------------------------------------------------------------
+ * Run-time options (process-wide atomics; initial value = environment variable LAS_<NAME>, read once).  Keys are
+ * case-insensitive, with or without the LAS_ prefix.  Returns 0, or 1 for an unknown key.
+ *   GEMM_ARITH            1* split-operand bf16 MFMA (fp32-faithful, see las_gemm_f32), 0 fp32 MFMA
+ *   GEMM_STREAMK, GEMM_SK_MIN_TILES, GEMM_SPLIT_BELOW, GEMM_SPLIT_TARGET   schedule thresholds of the GEMM (-1* = automatic)
+ *   GEMM_SLOTS_PER_CU     resident GEMM workgroups per CU (2*; read at the first GEMM)
+ *   GEMM_GROUP 1*, GEMM_XCD_SWZ 1*, GEMM_BATCH_DIRS 1*          grouped weight-gradient launches / XCD order / batched directions
+ *   SPELLER_PERSIST 1*, SPELLER_PERSIST_BWD 1*                   one-launch decode loop forward / backward (0: per-step launches)
+ *   SPELLER_PRE 1*, SPELLER_PRE_BWD 1*                           pre-multiplied-context variants of those kernels
+ *   REC_UW 0*, REC_NB 0*, REC_PIPE 1*, REC_AGENT_HANDOFF 0*, REC_MFMA 1*   Listener recurrence: units per workgroup, utterances per
+ *                                                                group, pipelined halves, agent-scope hand-off, matrix-pipe form
+ *   CELL_MT 0*            M-tiles per workgroup of the per-step cell kernel
+ *   TIME_KERNELS 0*       record HIP events around the one-launch decode kernels on their launch stream (las_debug_kernel_ms)
+ * Replaces nothing in the reference (pure Python, no switches).
+ * ---------------------------------------------------------------------------------------------- */
+int las_set_option(const char* key, int64_t value);
+int las_get_option(const char* key, int64_t* value_out);
 
 /* ------------------------------------------------------------------------------------------------
  * Listener: one pyramidal BiLSTM layer.
@@ -190,6 +214,22 @@ int las_ls_loss(const float* logp, int64_t stride_u, int64_t stride_b, const int
 int las_letter_error_rate(const float* logp, int64_t stride_u, int64_t stride_b, const int64_t* labels_onehot, int U,
                           int U_lab, int B, int V, float* ler_out, int32_t* work, void* stream);
 
+/* Global-norm clip + Adam step on the flat gradient buffer in two launches: torch.nn.utils.clip_grad_norm_(params, max_norm)
+ * followed by torch.optim.Adam.step() (amsgrad off, weight_decay 0) — reference solver/solver.py:96-97, train.py:82.
+ *   params[t]            device pointer of parameter tensor t (fp32, contiguous), t < n_tensors   (HOST array)
+ *   offsets[t]           element offset of tensor t inside grad_flat / exp_avg / exp_avg_sq; offsets[n_tensors] = total (HOST array)
+ *   grad_flat            all gradients back to back (scaled in place when the clip is active, as clip_grad_norm_ does)
+ *   exp_avg, exp_avg_sq  Adam moments in the same flat layout (caller-owned, zero before step 1)
+ *   step                 1-based step count of THIS update (bias corrections 1 - beta^step)
+ *   max_norm <= 0        no clipping;  norm_out (1 float, may be NULL) receives the total gradient norm before clipping
+ *   workspace            las_clip_adam_workspace_floats() floats
+ *   err_word             optional device error word of the step's persistent kernels: if nonzero when the update kernel runs,
+ *                        parameters and moments are left UNCHANGED (the step's gradients are invalid; the host re-runs it) */
+size_t las_clip_adam_workspace_floats(void);
+int las_clip_adam(float* const* params, const int64_t* offsets, int n_tensors, float* grad_flat, float* exp_avg,
+                  float* exp_avg_sq, float max_norm, float lr, float beta1, float beta2, float eps, int step,
+                  float* norm_out, float* workspace, const uint32_t* err_word, void* stream);
+
 /* ------------------------------------------------------------------------------------------------
  * Input side: the collate contract on device (reference utils/data.py:116-149, collate_fn).
  *   packed_feat (sum_b len_b, F) fp32: the utterances' frames back to back; feat_offsets int64 (B+1) frame offsets.
@@ -237,11 +277,13 @@ typedef struct las_gemm_desc {
     int a_kc, b_kc, accumulate, c_zeroed;
 } las_gemm_desc;
 int las_gemm_f32_group(const las_gemm_desc* descs, int n, void* stream);
-/* Arithmetic of the MFMA GEMMs' interior tiles (process-wide; initial value from LAS_GEMM_ARITH):
+/* Arithmetic of the MFMA GEMMs' interior tiles (= option GEMM_ARITH; LAS_FLAG_GEMM_F32 overrides it for one call):
  *   0  v_mfma_f32_32x32x2_f32 (fp32 operands on the fp32 matrix pipe)
  *   1  every fp32 operand split EXACTLY into three bf16 terms in registers, six of the nine partial products on
  *      v_mfma_f32_32x32x16_bf16 with fp32 accumulation; the dropped terms are below 2^-26 of |a*b|, i.e. the result is as
  *      accurate as mode 0 (tests/test_hip_kernels.py measures both against float64) at 2.67x its matrix-pipe roofline.
+ *      Range edge: an operand that is +-Inf, or rounds to Inf in bf16 (|x| > ~3.39e38), yields NaN where mode 0 yields +-Inf
+ *      (its residual is Inf - Inf); operands below ~2^-108 lose their second / third term to the matrix pipe's denormal flush.
  * Replaces nothing in the reference (ATen picks its own GEMM kernels, model/las_model.py:90,279). */
 int las_gemm_get_arith(void);
 void las_gemm_set_arith(int mode);
@@ -252,6 +294,19 @@ void las_gemm_set_tuning(int key, int64_t value);
 size_t las_rec_xbuf_bytes(int B, int H);
 int las_pblstm_rec_fwd(float* gates, const float* w_hh_f, const float* w_hh_r, float* out, float* cbuf, float* hprev,
                        int B, int T, int H, void* xbuf, uint32_t* err_word, int flags, void* stream);
+
+
+/* ------------------------------------------------------------------------------------------------
+ * Profiling hooks (tools/ubench_persist*_trace.py): per-phase shader-clock stamps of workgroup 0 of each role of the
+ * persistent decode kernels.  dev_buf: device buffer of 3*U*8 uint64 (NULL switches the stamps off again).  Process-wide,
+ * not for production use.  las_debug_rec_trace exists only in builds with -DLAS_REC_TRACE.
+ * ---------------------------------------------------------------------------------------------- */
+void las_debug_persist_trace(unsigned long long* dev_buf);
+void las_debug_persist_bwd_trace(unsigned long long* dev_buf);
+/* With option TIME_KERNELS = 1: duration (HIP events on the launch stream) of the most recent launch of the one-launch decode
+ * kernel, which = 0 forward (speller_persist_fwd*_kernel), 1 backward (speller_persist_bwd*_kernel).  Synchronises on that launch.
+ * bench.py prices these two kernels against the roofline with it. */
+int las_debug_kernel_ms(int which, float* ms_out);
 
 #ifdef __cplusplus
 }

@@ -14,6 +14,7 @@ MAX_L = 4
 FLAG_STASH = 1
 FLAG_FORCE_GENERIC = 2
 FLAG_TEACHER_FORCED = 4     # las_speller_bwd: the forward that filled `reserve` was teacher-forced (same flags / error word)
+FLAG_GEMM_F32 = 8           # this call's GEMMs on the fp32 matrix pipe (per call; the process-wide default is option GEMM_ARITH)
 
 _f = C.c_void_p   # every device pointer is passed as an integer address
 
@@ -42,6 +43,14 @@ class SpellerGrads(C.Structure):
 PROTOTYPES = {
     "las_abi_version": (C.c_int, []),
     "las_last_error": (C.c_char_p, []),
+    "las_set_option": (C.c_int, [C.c_char_p, C.c_int64]),
+    "las_get_option": (C.c_int, [C.c_char_p, C.POINTER(C.c_int64)]),
+    "las_clip_adam_workspace_floats": (C.c_size_t, []),
+    "las_clip_adam": (C.c_int, [C.POINTER(_f), C.POINTER(C.c_int64), C.c_int, _f, _f, _f, C.c_float, C.c_float, C.c_float, C.c_float,
+                                C.c_float, C.c_int, _f, _f, _f, _f]),
+    "las_debug_persist_trace": (None, [_f]),
+    "las_debug_persist_bwd_trace": (None, [_f]),
+    "las_debug_kernel_ms": (C.c_int, [C.c_int, C.POINTER(C.c_float)]),
     "las_pblstm_reserve_floats": (C.c_size_t, [C.c_int] * 4),
     "las_pblstm_fwd": (C.c_int, [_f, C.c_int, C.c_int, C.c_int, C.c_int] + [_f] * 8 + [_f, _f, _f, C.c_int, _f]),
     "las_pblstm_bwd_workspace_floats": (C.c_size_t, [C.c_int] * 3),
@@ -101,6 +110,17 @@ def lib():
     return _lib
 
 
+def set_option(key, value):
+    """las_set_option: process-wide run-time switch of the library (see include/las_hip.h for the keys)."""
+    check(lib().las_set_option(str(key).encode(), int(value)))
+
+
+def get_option(key):
+    out = C.c_int64(0)
+    check(lib().las_get_option(str(key).encode(), C.byref(out)))
+    return int(out.value)
+
+
 def check(rc):
     if rc != 0:
         msg = lib().las_last_error().decode(errors="replace")
@@ -150,8 +170,30 @@ def err_word(device):
     return w
 
 
+class DeviceHandoffError(RuntimeError):
+    """A persistent kernel reported a hand-off timeout through the device error word (the call's results are invalid)."""
+
+
+_defer_polls = 0
+
+
+class polls_deferred:
+    """``with polls_deferred():`` — the non-blocking polls at the top of every Listener / Speller forward do not raise inside
+    the block.  ``solver.batch_iterator`` uses it: it checks the error word itself at the step's synchronisation point, where
+    all ranks of a data-parallel group reach the same verdict and the step can be re-run as a whole."""
+
+    def __enter__(self):
+        global _defer_polls
+        _defer_polls += 1
+
+    def __exit__(self, *exc):
+        global _defer_polls
+        _defer_polls -= 1
+        return False
+
+
 def _raise_device_error(key, v):
-    raise RuntimeError(f"liblas_hip device-side failure 0x{v & 0xffffffff:08x} on cuda:{key} "
+    raise DeviceHandoffError(f"liblas_hip device-side failure 0x{v & 0xffffffff:08x} on cuda:{key} "
                        "(an inter-workgroup hand-off of a persistent kernel timed out: another kernel was resident on the "
                        "GPU, or fewer compute units were available than the launch assumed; the results of that call are "
                        "invalid).  The error word has been cleared; LAS_FLAG_FORCE_GENERIC / force_generic selects the "
@@ -176,7 +218,7 @@ def poll_device_errors(device):
     enqueues the next snapshot.  Detection is one call late but costs no host synchronisation."""
     key = _dev_index(device)
     w = _err_words.get(key)
-    if w is None or torch.cuda.is_current_stream_capturing():
+    if w is None or _defer_polls or torch.cuda.is_current_stream_capturing():
         return
     snap = _err_snap.get(key)
     if snap is not None:

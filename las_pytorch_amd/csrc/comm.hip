@@ -2,8 +2,9 @@
 // fp32 gradient per step (include/las_hip.h, las_comm_* / las_allreduce_f32).  Replaces nn.DataParallel's per-step
 // parameter broadcast + output gather + gradient reduce, reference train.py:76-78.
 //
-// librccl is opened with dlopen on first use: liblas_hip.so has no link-time dependency on it, single-GPU users never load
-// it, and inside a PyTorch process the already-loaded RCCL is reused (same SONAME).  xGMI is point-to-point, so the ring
+// librccl is opened with dlopen on first use: liblas_hip.so has no LINK-time dependency on it (<rccl/rccl.h> is needed at build
+// time for the types only), single-GPU users never load it, and inside a PyTorch process the already-loaded RCCL is reused
+// (same SONAME).  xGMI is point-to-point, so the ring
 // all-reduce of the 39.9 MB (P) gradient is per-link bound; one large message per step is the shape that suits it.
 #include "../../include/las_hip.h"
 #include "las_common.h"
@@ -77,14 +78,23 @@ int las_comm_init(int rank, int world, const void* uid128) {
     LAS_REQUIRE(dev < MAX_DEVICES, "device index");
     ncclUniqueId id;
     memcpy(&id, uid128, sizeof(id));
-    std::lock_guard<std::mutex> lk(g_mu);
-    LAS_TRY(load_rccl());
-    if (g_comm[dev]) { g_rccl.CommDestroy(g_comm[dev]); g_comm[dev] = nullptr; }
+    // the lock only guards the handle table: ncclCommInitRank blocks until every rank has arrived, and in a one-thread-per-device
+    // process the peer thread must be able to enter this function meanwhile — never hold g_mu across a collective call
+    ncclComm_t old = nullptr;
+    {
+        std::lock_guard<std::mutex> lk(g_mu);
+        LAS_TRY(load_rccl());
+        old = g_comm[dev]; g_comm[dev] = nullptr;
+    }
+    if (old) g_rccl.CommDestroy(old);
     ncclComm_t c = nullptr;
     const ncclResult_t rc = g_rccl.CommInitRank(&c, world, id, rank);
     if (rc != ncclSuccess) return nccl_fail("ncclCommInitRank", rc);
-    g_comm[dev] = c;
-    g_world[dev] = world;
+    {
+        std::lock_guard<std::mutex> lk(g_mu);
+        g_comm[dev] = c;
+        g_world[dev] = world;
+    }
     return LAS_OK;
 }
 
@@ -108,10 +118,13 @@ int las_comm_destroy(void) {
     int dev = 0;
     LAS_HIP_CHECK(hipGetDevice(&dev));
     LAS_REQUIRE(dev < MAX_DEVICES, "device index");
-    std::lock_guard<std::mutex> lk(g_mu);
-    if (g_comm[dev]) {
-        const ncclResult_t rc = g_rccl.CommDestroy(g_comm[dev]);
-        g_comm[dev] = nullptr;
+    ncclComm_t c = nullptr;
+    {
+        std::lock_guard<std::mutex> lk(g_mu);
+        c = g_comm[dev]; g_comm[dev] = nullptr;
+    }
+    if (c) {
+        const ncclResult_t rc = g_rccl.CommDestroy(c);
         if (rc != ncclSuccess) return nccl_fail("ncclCommDestroy", rc);
     }
     return LAS_OK;

@@ -14,6 +14,7 @@
 // Either operand may be K-contiguous or M/N-contiguous (all four transposition cases of the backward pass).
 #include "las_common.h"
 #include "las_kernels.h"
+#include "options.h"
 #include <stdlib.h>
 #include <algorithm>
 #include <type_traits>
@@ -733,20 +734,17 @@ __global__ __launch_bounds__(256) void gemm_zero_tiles_kernel(GemmParams p) {
 }
 
 // ---- arithmetic mode and launch helpers ---------------------------------------------------------------------------------
-static int g_gemm_arith = -1;      // 0: v_mfma_f32_32x32x2_f32 ; 1: split-operand bf16 MFMA (fp32-faithful, see split_pair)
-int gemm_get_arith() {
-    if (g_gemm_arith < 0) g_gemm_arith = getenv("LAS_GEMM_ARITH") ? atoi(getenv("LAS_GEMM_ARITH")) : LAS_GEMM_ARITH_DEFAULT;
-    return g_gemm_arith;
-}
-void gemm_set_arith(int mode) { g_gemm_arith = mode ? 1 : 0; }
-// schedule knobs (tools/ubench_gemm_sched.py sweeps them inside one process; -1 = built-in default, environment otherwise)
+// 0: v_mfma_f32_32x32x2_f32 ; 1: split-operand bf16 MFMA (fp32-faithful, see split_pair).  OPT_GEMM_ARITH, or the calling
+// thread's per-call override (LAS_FLAG_GEMM_F32 -> GemmArithScope)
+int gemm_get_arith() { return gemm_arith_effective(); }
+void gemm_set_arith(int mode) { opt_set(OPT_GEMM_ARITH, mode ? 1 : 0); }
+// schedule knobs (tools/ubench_gemm_sched.py sweeps them inside one process; -1 = built-in default)
 enum { TUNE_STREAMK = 0, TUNE_SK_MIN_TILES = 1, TUNE_SPLIT_BELOW = 2, TUNE_SPLIT_TARGET = 3, TUNE_N = 4 };
-static long g_tune[TUNE_N] = {-1, -1, -1, -1};
-void gemm_set_tuning(int key, long value) { if (key >= 0 && key < TUNE_N) g_tune[key] = value; }
-static long tune(int key, const char* env, long dflt) {
-    if (g_tune[key] >= 0) return g_tune[key];
-    const char* e = getenv(env);
-    return e ? atol(e) : dflt;
+static const int kTuneOpt[TUNE_N] = {OPT_GEMM_STREAMK, OPT_GEMM_SK_MIN_TILES, OPT_GEMM_SPLIT_BELOW, OPT_GEMM_SPLIT_TARGET};
+void gemm_set_tuning(int key, long value) { if (key >= 0 && key < TUNE_N) opt_set(kTuneOpt[key], value); }
+static long tune(int key, long dflt) {
+    const long v = opt_get(kTuneOpt[key]);
+    return v >= 0 ? v : dflt;
 }
 
 template <class Kern>
@@ -797,7 +795,7 @@ static int gemm_resident_slots() {      // persistent grid: two 256-thread workg
     if (slots < 0) {
         int dev = 0, cus = 0;
         if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) cus = 0;
-        const int per_cu = getenv("LAS_GEMM_SLOTS_PER_CU") ? atoi(getenv("LAS_GEMM_SLOTS_PER_CU")) : 2;
+        const int per_cu = (int)opt_get(OPT_GEMM_SLOTS_PER_CU);
         slots = per_cu * cus;
     }
     return slots;
@@ -806,7 +804,7 @@ static int gemm_resident_slots() {      // persistent grid: two 256-thread workg
 static bool gemm_aligned(const float* ptr, long ld, long bs) { return ((uintptr_t)ptr % 16 == 0) && (ld % 4 == 0) && (bs % 4 == 0); }
 
 int gemm_f32_group(const GemmDesc* ds, int n, hipStream_t stream) {
-    static const int group_on = getenv("LAS_GEMM_GROUP") ? atoi(getenv("LAS_GEMM_GROUP")) : 1;
+    const int group_on = (int)opt_get(OPT_GEMM_GROUP);
     const int W = gemm_resident_slots();
     bool ok = group_on && W > 0 && n >= 1 && n <= GROUP_MAX;
     for (int i = 0; ok && i < n; ++i) {
@@ -821,7 +819,7 @@ int gemm_f32_group(const GemmDesc* ds, int n, hipStream_t stream) {
     GemmGroupParams g;
     g.n = n;
     g.first[0] = 0;
-    static const int xcd_swz = getenv("LAS_GEMM_XCD_SWZ") ? atoi(getenv("LAS_GEMM_XCD_SWZ")) : 1;
+    const int xcd_swz = (int)opt_get(OPT_GEMM_XCD_SWZ);
     g.xcd_swz = xcd_swz;
     for (int i = 0; i < n; ++i) {
         const GemmDesc& d = ds[i];
@@ -854,18 +852,18 @@ int gemm_f32(const GemmDesc& d, hipStream_t stream) {
     p.b_vec = gemm_aligned(d.B, d.ldb, d.sB) && (d.B2 == nullptr || gemm_aligned(d.B2, d.ldb, 0));
     p.gx = gx; p.gy = gy; p.kt = kt;
     p.accumulate = d.accumulate; p.relu = d.relu;
-    static const int xcd_swz = getenv("LAS_GEMM_XCD_SWZ") ? atoi(getenv("LAS_GEMM_XCD_SWZ")) : 1;
+    const int xcd_swz = (int)opt_get(OPT_GEMM_XCD_SWZ);
     p.xcd_swz = xcd_swz;
     p.persistent = 0; p.dp_tiles = 0; p.sk_iters = 0; p.sk_per = 0; p.sk_atomic_whole = 0; p.atomic = 0; p.swz = 0; p.splitk = 1; p.kper = d.K;
 
     // ---- schedule --------------------------------------------------------------------------------------------------
-    const int sk_on = (int)tune(TUNE_STREAMK, "LAS_GEMM_STREAMK", 1);
+    const int sk_on = (int)tune(TUNE_STREAMK, 1);
     const int W = gemm_resident_slots();
     const bool may_split = !d.relu && d.K >= 4 * BK;         // a relu epilogue needs the whole sum in one place
     // split-operand arithmetic runs a k-iteration 2-3x faster, so the fixed costs of the stream-K epilogue (zeroing pass, one atomic
     // per output of every partial tile) weigh more: there the persistent schedule is used only when whole tiles fill every slot at
     // least once (plain stores for those, stream-K for the ragged tail), fewer tiles take the classic grid / split-K
-    const long min_tiles = tune(TUNE_SK_MIN_TILES, "LAS_GEMM_SK_MIN_TILES", gemm_get_arith() == 1 ? W : 0);
+    const long min_tiles = tune(TUNE_SK_MIN_TILES, gemm_get_arith() == 1 ? W : 0);
     if (sk_on && d.splitk <= 1 && W > 0 && may_split && kt >= 32 && tiles % W != 0 && tiles * kt >= 4L * W && tiles >= min_tiles) {
         // persistent: whole tiles while they fill every slot, the ragged tail (or everything, when there are fewer tiles than
         // slots) as equal runs of k-iterations
@@ -896,10 +894,10 @@ int gemm_f32(const GemmDesc& d, hipStream_t stream) {
     const bool can_zero = d.accumulate || d.c_zeroed || d.ldc == d.N || batch == 1;      // split-K partials need a zeroed (or accumulated) C
     if (d.splitk == 0 || (d.splitk == 1 && gemm_get_arith() == 1 && may_split && can_zero)) {
         // auto: few output tiles and a long K -> split K so the launch covers the chip (256 CUs)
-        const long below = tune(TUNE_SPLIT_BELOW, "LAS_GEMM_SPLIT_BELOW", gemm_get_arith() == 1 ? W / 2 : 128);
+        const long below = tune(TUNE_SPLIT_BELOW, gemm_get_arith() == 1 ? W / 2 : 128);
         if (!d.relu && tiles < below && d.K >= 256) {
             // few output tiles, long K: about two workgroups per CU (they hide each other's barrier stalls) with at least 4 k-tiles each
-            const long target = tune(TUNE_SPLIT_TARGET, "LAS_GEMM_SPLIT_TARGET", 512);   // ~2 workgroups per CU: measured best
+            const long target = tune(TUNE_SPLIT_TARGET, 512);   // ~2 workgroups per CU: measured best
             splitk = (int)min((long)cdiv(d.K, 4 * BK), max(1L, target / tiles));
         }
     }

@@ -3,6 +3,7 @@
 #include "../../include/las_hip.h"
 #include "las_common.h"
 #include "las_kernels.h"
+#include "options.h"
 #include <algorithm>
 #include <utility>
 #include <vector>
@@ -226,6 +227,7 @@ int las_pblstm_fwd(const float* x, int B, int T_in, int D_in, int H, const float
                    const float* b_ih_f, const float* b_hh_f, const float* w_ih_r, const float* w_hh_r, const float* b_ih_r,
                    const float* b_hh_r, float* out, float* reserve, uint32_t* err_word, int flags, void* stream_) {
     hipStream_t stream = (hipStream_t)stream_;
+    GemmArithScope arith_scope(flags);
     LAS_REQUIRE(B > 0 && T_in > 0 && D_in > 0 && H > 0, "pblstm dims");
     LAS_REQUIRE(T_in % 2 == 0, "pBLSTM needs an even number of frames (reference las_model.py:86-87)");
     LAS_REQUIRE(x && out && reserve && err_word, "pblstm pointers");
@@ -239,7 +241,7 @@ int las_pblstm_fwd(const float* x, int B, int T_in, int D_in, int H, const float
     // One launch of two "batches": A is shared, the per-direction operands are addressed through element strides that
     // are simply the distance between the two parameter tensors.  2 x 400 tiles in flight fill the 256 CUs more evenly
     // than two launches of 400 (1.56 tiles per CU each).
-    static const bool batch_dirs = !(getenv("LAS_GEMM_BATCH_DIRS") && atoi(getenv("LAS_GEMM_BATCH_DIRS")) == 0);
+    const bool batch_dirs = opt_get(OPT_GEMM_BATCH_DIRS) != 0;
     for (int dir = 0; dir < (batch_dirs ? 1 : 2); ++dir) {
         GemmDesc g;
         g.A = x; g.lda = D; g.a_kc = true;
@@ -266,6 +268,7 @@ int las_pblstm_bwd(const float* x, const float* dout, int B, int T_in, int D_in,
                    float* dx, float* dw_ih_f, float* dw_hh_f, float* db_ih_f, float* db_hh_f, float* dw_ih_r, float* dw_hh_r,
                    float* db_ih_r, float* db_hh_r, uint32_t* err_word, int flags, void* stream_) {
     hipStream_t stream = (hipStream_t)stream_;
+    GemmArithScope arith_scope(flags);
     LAS_REQUIRE(B > 0 && T_in > 0 && D_in > 0 && H > 0 && T_in % 2 == 0, "pblstm dims");
     LAS_REQUIRE(x && dout && reserve && workspace && err_word, "pblstm bwd pointers");
     LAS_REQUIRE(dw_ih_f && dw_hh_f && db_ih_f && db_hh_f && dw_ih_r && dw_hh_r && db_ih_r && db_hh_r, "pblstm grad outputs");
@@ -344,7 +347,7 @@ int las_attn_keys_fwd(const las_speller_desc* d, const float* feat, float* keys,
 
 size_t las_speller_reserve_floats(const las_speller_desc* d, int U) { return SpellerLayout(d, U).total; }
 
-// Profiling aid, deliberately not part of include/las_hip.h: per-phase shader-clock stamps of the persistent decode kernel.
+// Profiling aid (declared at the end of include/las_hip.h): per-phase shader-clock stamps of the persistent decode kernel.
 extern "C" void las_debug_persist_trace(unsigned long long* dev_buf) { speller_persist_set_trace(dev_buf); }
 extern "C" void las_debug_persist_bwd_trace(unsigned long long* dev_buf) { speller_persist_bwd_set_trace(dev_buf); }
 #ifdef LAS_REC_TRACE
@@ -355,6 +358,7 @@ int las_speller_fwd(const las_speller_desc* d, const float* feat, const float* k
                     int U, int teacher_forced, int decode_mode, const float* sample_noise, float* logp, float* att,
                     int32_t* argmax, float* reserve, uint32_t* err_word, int flags, void* stream_) {
     hipStream_t stream = (hipStream_t)stream_;
+    GemmArithScope arith_scope(flags);
     LAS_TRY(check_desc(d));
     LAS_REQUIRE(U > 0, "decode steps");
     LAS_REQUIRE(feat && logp && att && reserve, "speller pointers");
@@ -381,7 +385,7 @@ int las_speller_fwd(const las_speller_desc* d, const float* feat, const float* k
     LAS_TRY(copy2d(feat, (long)Tp * D, ctx_all, D, B, D, 0, stream));     // ctx_{-1} = feat[:,0,:] (las_model.py:198)
     // 16-byte aligned, tail-free shadow of W_ih0: columns [0,V) = label part, [V,Vp) = 0, [Vp,Vp+Hs) = context part (rebuilt
     // every call: in training the parameters change every step, so there is nothing to cache across calls)
-    static const bool persist_on = !(getenv("LAS_SPELLER_PERSIST") && atoi(getenv("LAS_SPELLER_PERSIST")) == 0);
+    const bool persist_on = opt_get(OPT_SPELLER_PERSIST) != 0;
     const bool persist = persist_on && err_word && !(flags & LAS_FLAG_FORCE_GENERIC) && (teacher_forced || decode_mode != 2) &&
                          d->relu <= LAS_ACT_RELU &&        // the persistent kernels implement relu / no activation
                          speller_persist_eligible(B, Tp, Hs, D, d->M, V, L, d->multi_head, d->use_mlp, !teacher_forced);
@@ -390,19 +394,23 @@ int las_speller_fwd(const las_speller_desc* d, const float* feat, const float* k
     // recovers afterwards (the backward pass and the character distribution need it)
     const bool pre = persist && teacher_forced && lay.pre &&
                      speller_persist_pre_eligible(B, Tp, Hs, D, d->M, V, L, d->multi_head, d->use_mlp);
-    LAS_TRY(build_w0p(d->w_ih[0], w0p, Hs, V, Vp, stream, pre ? reserve + lay.wperm : nullptr));
+    // What a teacher-forced forward leaves in `reserve` depends on the SHAPE only (lay.pre), never on switches, the error word
+    // or the occupancy calculator: P = feat . W_ctx^T and the per-step sums gx_s = sum_t a_t P_t are always there, so that
+    // las_speller_bwd (LAS_FLAG_TEACHER_FORCED) can rely on them whichever forward variant actually ran.
+    const bool pre_stash = teacher_forced && lay.pre;
+    LAS_TRY(build_w0p(d->w_ih[0], w0p, Hs, V, Vp, stream, pre_stash ? reserve + lay.wperm : nullptr));
+    if (pre_stash) {
+        GemmDesc g;
+        g.A = feat; g.lda = D; g.a_kc = true;
+        g.B = reserve + lay.wperm; g.ldb = Hs; g.b_kc = true;
+        g.C = reserve + lay.pctx; g.ldc = 4 * Hs; g.M = B * Tp; g.N = 4 * Hs; g.K = D; g.splitk = 1;
+        LAS_TRY(gemm_f32(g, stream));
+    }
     bool persist_ran = persist;
     bool pre_ran = false;
     if (persist) {
         PersistFwd p;
-        if (pre) {
-            GemmDesc g;
-            g.A = feat; g.lda = D; g.a_kc = true;
-            g.B = reserve + lay.wperm; g.ldb = Hs; g.b_kc = true;
-            g.C = reserve + lay.pctx; g.ldc = 4 * Hs; g.M = B * Tp; g.N = 4 * Hs; g.K = D; g.splitk = 1;
-            LAS_TRY(gemm_f32(g, stream));
-            p.pctx = reserve + lay.pctx; p.gx = reserve + lay.gx;
-        }
+        if (pre) { p.pctx = reserve + lay.pctx; p.gx = reserve + lay.gx; }
         p.w0p = w0p; p.Vp = Vp;
         p.w_hh0 = d->w_hh[0]; p.w_ih1 = d->w_ih[1]; p.w_hh1 = d->w_hh[1];
         p.b_ih0 = d->b_ih[0]; p.b_hh0 = d->b_hh[0]; p.b_ih1 = d->b_ih[1]; p.b_hh1 = d->b_hh[1];
@@ -478,6 +486,14 @@ int las_speller_fwd(const las_speller_desc* d, const float* feat, const float* k
                 LAS_TRY(attn_step_fwd(a, stream));
             }
         }
+    }
+    if (pre_stash && !pre_ran) {   // the per-step / classic persistent kernels ran: gx_s[b] = att_s[b] . P[b], one batched GEMM
+        GemmDesc g;
+        g.A = att; g.lda = (long)B * Tp; g.a_kc = true; g.sA = Tp;
+        g.B = reserve + lay.pctx; g.ldb = 4 * Hs; g.b_kc = false; g.sB = (long)Tp * 4 * Hs;
+        g.C = reserve + lay.gx; g.ldc = (long)B * 4 * Hs; g.sC = 4 * Hs;
+        g.M = U; g.N = 4 * Hs; g.K = Tp; g.batch = B; g.splitk = 1;
+        LAS_TRY(gemm_f32(g, stream));
     }
     if (teacher_forced) {
         // character distribution of all U steps at once (reference las_model.py:181-182, per step there):
@@ -577,6 +593,7 @@ int las_speller_bwd(const las_speller_desc* d, const float* feat, const float* k
                     const float* dlogp, int U, int feedback_mode0, const float* reserve, float* workspace,
                     const las_speller_grads* g, uint32_t* err_word, int flags, void* stream_) {
     hipStream_t stream = (hipStream_t)stream_;
+    GemmArithScope arith_scope(flags);
     LAS_TRY(check_desc(d));
     LAS_REQUIRE(U > 0 && feat && logp && att && dlogp && reserve && workspace && g, "speller bwd pointers");
     LAS_REQUIRE(!d->use_mlp || keys, "attention keys");
@@ -628,7 +645,7 @@ int las_speller_bwd(const las_speller_desc* d, const float* feat, const float* k
     const int NH = d->multi_head;
     float* dctxcat_all = NH > 1 ? workspace + wl.dctxcat_all : nullptr;
     const float* ctxcat_all = NH > 1 ? reserve + lay.ctxcat_all : nullptr;
-    static const bool persist_on = !(getenv("LAS_SPELLER_PERSIST_BWD") && atoi(getenv("LAS_SPELLER_PERSIST_BWD")) == 0);
+    const bool persist_on = opt_get(OPT_SPELLER_PERSIST_BWD) != 0;
     const bool persist = persist_on && hoist && err_word && !(flags & LAS_FLAG_FORCE_GENERIC) && d->relu <= LAS_ACT_RELU &&
                          speller_persist_bwd_eligible(B, Tp, Hs, D, M, V, L, NH, d->use_mlp);
     bool persist_ran = persist;

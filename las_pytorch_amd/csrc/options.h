@@ -1,0 +1,56 @@
+// Run-time options of liblas_hip.so: ONE registry behind las_set_option / las_get_option (include/las_hip.h).
+// Every option is a process-wide atomic whose initial value comes from the environment variable LAS_<NAME> (read once, at first
+// use) and otherwise from the built-in default; there is no other getenv in the library.  They are A/B and profiling aids — the
+// defaults are the measured best — except GEMM_ARITH, which a single call can also override with LAS_FLAG_GEMM_F32.
+#pragma once
+#include <hip/hip_runtime.h>
+
+namespace las {
+
+enum Opt : int {
+    OPT_GEMM_ARITH = 0,         // 1 split-operand bf16 MFMA (default), 0 fp32 MFMA
+    OPT_GEMM_STREAMK,           // persistent data-parallel + stream-K schedule on/off            (-1 = automatic)
+    OPT_GEMM_SK_MIN_TILES,      // fewest output tiles for the persistent schedule                (-1 = automatic)
+    OPT_GEMM_SPLIT_BELOW,       // split K below this many output tiles                           (-1 = automatic)
+    OPT_GEMM_SPLIT_TARGET,      // workgroup count the automatic split-K aims for                 (-1 = automatic)
+    OPT_GEMM_SLOTS_PER_CU,      // resident GEMM workgroups per CU (default 2; read once)
+    OPT_GEMM_GROUP,             // grouped weight-gradient launches on/off
+    OPT_GEMM_XCD_SWZ,           // XCD-aware workgroup order in the grouped launch
+    OPT_GEMM_BATCH_DIRS,        // both directions' input projections in one batched launch
+    OPT_SPELLER_PERSIST,        // one-launch decode forward
+    OPT_SPELLER_PERSIST_BWD,    // one-launch decode backward
+    OPT_SPELLER_PRE,            // pre-multiplied-context variant of the decode kernels (forward + backward)
+    OPT_SPELLER_PRE_BWD,        // ... of the backward only
+    OPT_REC_UW,                 // hidden units per workgroup of the forward recurrence (0 = automatic)
+    OPT_REC_AGENT_HANDOFF,      // agent-scope hand-off even when a recurrence group shares an XCD
+    OPT_REC_NB,                 // minimum utterances per recurrence group (0 = automatic)
+    OPT_REC_PIPE,               // pipelined halves in the multi-utterance forward recurrence
+    OPT_REC_MFMA,               // multi-utterance recurrences on the matrix pipe where eligible
+    OPT_CELL_MT,                // M-tiles per workgroup of the per-step cell kernel (0 = automatic)
+    OPT_TIME_KERNELS,           // record HIP events around the persistent decode kernels (las_debug_kernel_ms reads them)
+    OPT_COUNT
+};
+
+long opt_get(int opt);
+void opt_set(int opt, long value);
+int opt_find(const char* name);          // "GEMM_ARITH" / "gemm_arith" / "LAS_GEMM_ARITH" -> index, -1 if unknown
+const char* opt_name(int opt);
+
+// Per-call override of OPT_GEMM_ARITH for the calling thread (LAS_FLAG_GEMM_F32): RAII, nests.
+struct GemmArithScope {
+    int saved;
+    explicit GemmArithScope(int flags);
+    ~GemmArithScope();
+};
+int gemm_arith_effective();              // thread override if any, else the option
+
+// HIP-event timing of single kernels on their launch stream (OPT_TIME_KERNELS; bench.py's roofline blocks): RAII around the launch
+enum : int { TIMED_DECODE_FWD = 0, TIMED_DECODE_BWD = 1, TIMED_COUNT = 2 };
+struct KernelTimer {
+    int which; hipStream_t stream; bool on;
+    KernelTimer(int which, hipStream_t stream);
+    ~KernelTimer();
+};
+int kernel_timer_read(int which, float* ms_out);    // synchronises on the closing event
+
+}  // namespace las

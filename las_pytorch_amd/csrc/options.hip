@@ -1,0 +1,105 @@
+// Option registry (options.h) and the C-ABI entry points las_set_option / las_get_option.
+#include "../../include/las_hip.h"
+#include "las_common.h"
+#include "options.h"
+#include <atomic>
+#include <ctype.h>
+#include <stdlib.h>
+
+namespace las {
+
+namespace {
+struct OptDef { const char* name; long dflt; };
+// order = enum Opt
+const OptDef kDefs[OPT_COUNT] = {
+    {"GEMM_ARITH", 1}, {"GEMM_STREAMK", -1}, {"GEMM_SK_MIN_TILES", -1}, {"GEMM_SPLIT_BELOW", -1}, {"GEMM_SPLIT_TARGET", -1},
+    {"GEMM_SLOTS_PER_CU", 2}, {"GEMM_GROUP", 1}, {"GEMM_XCD_SWZ", 1}, {"GEMM_BATCH_DIRS", 1},
+    {"SPELLER_PERSIST", 1}, {"SPELLER_PERSIST_BWD", 1}, {"SPELLER_PRE", 1}, {"SPELLER_PRE_BWD", 1},
+    {"REC_UW", 0}, {"REC_AGENT_HANDOFF", 0}, {"REC_NB", 0}, {"REC_PIPE", 1}, {"REC_MFMA", 1}, {"CELL_MT", 0},
+    {"TIME_KERNELS", 0},
+};
+std::atomic<long> g_val[OPT_COUNT];
+std::atomic<int> g_init{0};
+
+void init_once() {
+    int st = g_init.load(std::memory_order_acquire);
+    if (st == 2) return;
+    int expect = 0;
+    if (g_init.compare_exchange_strong(expect, 1, std::memory_order_acq_rel)) {
+        for (int i = 0; i < OPT_COUNT; ++i) {
+            char env[64];
+            snprintf(env, sizeof(env), "LAS_%s", kDefs[i].name);
+            const char* e = getenv(env);
+            g_val[i].store(e ? atol(e) : kDefs[i].dflt, std::memory_order_relaxed);
+        }
+        g_init.store(2, std::memory_order_release);
+    } else {
+        while (g_init.load(std::memory_order_acquire) != 2) {}
+    }
+}
+
+thread_local int tl_arith = -1;     // per-call override (GemmArithScope)
+}  // namespace
+
+long opt_get(int opt) { init_once(); return g_val[opt].load(std::memory_order_relaxed); }
+void opt_set(int opt, long value) { init_once(); g_val[opt].store(value, std::memory_order_relaxed); }
+const char* opt_name(int opt) { return kDefs[opt].name; }
+int opt_find(const char* name) {
+    if (!name) return -1;
+    if ((name[0] == 'L' || name[0] == 'l') && (name[1] == 'A' || name[1] == 'a') && (name[2] == 'S' || name[2] == 's') && name[3] == '_') name += 4;
+    for (int i = 0; i < OPT_COUNT; ++i) {
+        const char* a = kDefs[i].name; const char* b = name;
+        while (*a && *b && toupper((unsigned char)*b) == *a) { ++a; ++b; }
+        if (!*a && !*b) return i;
+    }
+    return -1;
+}
+
+GemmArithScope::GemmArithScope(int flags) : saved(tl_arith) { if (flags & LAS_FLAG_GEMM_F32) tl_arith = 0; }
+GemmArithScope::~GemmArithScope() { tl_arith = saved; }
+int gemm_arith_effective() { return tl_arith >= 0 ? tl_arith : (opt_get(OPT_GEMM_ARITH) ? 1 : 0); }
+
+namespace {
+hipEvent_t g_ev[TIMED_COUNT][2] = {};
+bool g_ev_valid[TIMED_COUNT] = {};
+}  // namespace
+KernelTimer::KernelTimer(int w, hipStream_t s) : which(w), stream(s), on(opt_get(OPT_TIME_KERNELS) != 0) {
+    if (!on) return;
+    for (int k = 0; k < 2; ++k)
+        if (!g_ev[which][k] && hipEventCreate(&g_ev[which][k]) != hipSuccess) { on = false; return; }
+    g_ev_valid[which] = false;
+    if (hipEventRecord(g_ev[which][0], stream) != hipSuccess) on = false;
+}
+KernelTimer::~KernelTimer() {
+    if (on && hipEventRecord(g_ev[which][1], stream) == hipSuccess) g_ev_valid[which] = true;
+}
+int kernel_timer_read(int which, float* ms_out) {
+    if (which < 0 || which >= TIMED_COUNT || !ms_out || !g_ev_valid[which]) return fail(LAS_ERR_ARG, "no timed launch of kernel %s%ld", "", (long)which);
+    LAS_HIP_CHECK(hipEventSynchronize(g_ev[which][1]));
+    LAS_HIP_CHECK(hipEventElapsedTime(ms_out, g_ev[which][0], g_ev[which][1]));
+    return LAS_OK;
+}
+
+}  // namespace las
+
+using namespace las;
+
+extern "C" {
+
+int las_set_option(const char* key, int64_t value) {
+    const int i = opt_find(key);
+    if (i < 0) return fail(LAS_ERR_ARG, "unknown option %s", key ? key : "(null)");
+    opt_set(i, (long)value);
+    return LAS_OK;
+}
+
+int las_debug_kernel_ms(int which, float* ms_out) { return kernel_timer_read(which, ms_out); }
+
+int las_get_option(const char* key, int64_t* value_out) {
+    const int i = opt_find(key);
+    if (i < 0 || !value_out) return fail(LAS_ERR_ARG, "unknown option %s", key ? key : "(null)");
+    *value_out = (int64_t)opt_get(i);
+    return LAS_OK;
+}
+
+}  // extern "C"

@@ -19,6 +19,7 @@
 // A generic fallback (any H, weights streamed from L2) keeps every shape correct.
 #include "las_common.h"
 #include "las_kernels.h"
+#include "options.h"
 #include <stdlib.h>
 #include <algorithm>
 
@@ -926,7 +927,6 @@ static RecPlan rec_plan(int B, int G, int nb_min, int nb_max, int cus) {
         if ((B + nb - 1) / nb <= blocks) return {nb, B};
     return {nb_max, blocks * nb_max};
 }
-static int env_int(const char* name, int dflt) { const char* v = getenv(name); return v ? atoi(v) : dflt; }
 
 int pblstm_rec_fwd(float* gates, const float* w_hh_f, const float* w_hh_r, float* out, float* cbuf, float* hprev, int B,
                    int T, int H, int stash, u64* xbuf, unsigned* err, int force_generic, hipStream_t stream) {
@@ -934,10 +934,10 @@ int pblstm_rec_fwd(float* gates, const float* w_hh_f, const float* w_hh_r, float
     LAS_REQUIRE(!stash || (cbuf && hprev), "stash buffers");
     const int ngroups = 2 * B;
     // LAS_REC_AGENT_HANDOFF=1 forces the placement-independent agent-scope hand-off even when a group shares an XCD (A/B tests)
-    static const int dbg = env_int("LAS_REC_AGENT_HANDOFF", 0);
-    static const int uw_env = env_int("LAS_REC_UW", 0);
-    static const int nb_env = env_int("LAS_REC_NB", 0);          // force the utterances per group (A/B tests)
-    static const bool pipe_on = env_int("LAS_REC_PIPE", 1) != 0;  // 0: lock-step multi-utterance kernels instead of the pipelined halves
+    const int dbg = (int)opt_get(OPT_REC_AGENT_HANDOFF);
+    const int uw_env = (int)opt_get(OPT_REC_UW);
+    const int nb_env = (int)opt_get(OPT_REC_NB);          // force the utterances per group (A/B tests)
+    const bool pipe_on = opt_get(OPT_REC_PIPE) != 0;  // 0: lock-step multi-utterance kernels instead of the pipelined halves
     // UW: hidden units per workgroup (measured best on MI355X: one CU holds 256 KB of W_hh)
     const int uw = uw_env > 0 ? uw_env : (H == 128 ? 128 : (H == 256 ? 64 : 32));
     RecPlan plan = {0, 0};
@@ -1028,7 +1028,7 @@ int pblstm_rec_bwd(const float* dout, const float* gates, const float* cbuf, con
     LAS_REQUIRE(B > 0 && T > 0 && H > 0, "rec dims");
     if (db_done) *db_done = 0;
     const int ngroups = 2 * B;
-    static const int nb_env = env_int("LAS_REC_NB", 0);
+    const int nb_env = (int)opt_get(OPT_REC_NB);
     RecPlan plan = {0, 0};
     const int G = H * H / 16384 > 0 ? H * H / 16384 : 1;
     if (fast_h(H) && !force_generic) {

@@ -16,6 +16,7 @@
 //     temporary per step, las_model.py:293-297).
 #include "las_common.h"
 #include "las_kernels.h"
+#include "options.h"
 
 namespace las {
 
@@ -186,7 +187,7 @@ int lstm_cell_fwd(const CellSeg* segs, int nseg, const float* b_ih, const float*
     p.nseg = nseg; p.b_ih = b_ih; p.b_hh = b_hh; p.c_prev = c_prev; p.h_out = h_out; p.c_out = c_out; p.gates_out = gates_out;
     p.B = B; p.Hs = Hs; p.linear_out = nullptr; p.ldo = 0; p.linear_bias = nullptr;
     // one 16-utterance M-tile per workgroup while that keeps the grid within ~two waves of the 256 CUs
-    static int mt_env = getenv("LAS_CELL_MT") ? atoi(getenv("LAS_CELL_MT")) : 0;
+    const int mt_env = (int)opt_get(OPT_CELL_MT);
     const int mt = mt_env ? mt_env : ((long)(Hs / 4) * cdiv(B, 16) <= 1024 ? 1 : 2);
     dim3 grid(Hs / 4, cdiv(B, 16 * mt)), block(CELL_THREADS);
     if (mt == 1) hipLaunchKernelGGL((lstm_cell_fwd_kernel<1>), grid, block, 0, stream, p);

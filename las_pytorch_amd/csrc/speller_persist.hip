@@ -23,6 +23,7 @@
 #include "las_common.h"
 #include "las_kernels.h"
 #include "persist_common.h"
+#include "options.h"
 #include <algorithm>
 
 namespace las {
@@ -876,7 +877,7 @@ static bool persist_fwd_pre_fits_rt(int Hs, int ws, int Tp, int grid) {
 // Shape, switch, CU count AND the occupancy calculator: las_speller_bwd repeats this call to learn what las_speller_fwd did
 // (its PRE variant needs the P matrix and the gx slabs the forward's PRE variant left in the reserve).
 bool speller_persist_pre_eligible(int B, int Tp, int Hs, int D, int M, int V, int L, int heads, int use_mlp) {
-    static const bool on = !(getenv("LAS_SPELLER_PRE") && atoi(getenv("LAS_SPELLER_PRE")) == 0);
+    const bool on = opt_get(OPT_SPELLER_PRE) != 0;
     if (!on || !speller_persist_pre_shape(B, Tp, Hs, D, M, V, L, heads, use_mlp)) return false;
     int cus = 0, dev = 0;
     if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess)
@@ -891,7 +892,10 @@ static int launch_persist_fwd_pre(const PersistArgs& a, int grid, hipStream_t st
     const size_t smem = persist_fwd_pre_smem<HS, WS>(a.Tp);
     if (!persist_fwd_pre_fits<HS, WS>(a.Tp, grid))
         return fail(LAS_ERR_UNSUPPORTED, "persistent decode kernel: %s%ld workgroups cannot all be resident", "", (long)grid);
-    hipLaunchKernelGGL((speller_persist_fwd_pre_kernel<HS, WS>), dim3(grid), dim3(PS_THREADS), smem, stream, a);
+    {
+        KernelTimer timer(TIMED_DECODE_FWD, stream);
+        hipLaunchKernelGGL((speller_persist_fwd_pre_kernel<HS, WS>), dim3(grid), dim3(PS_THREADS), smem, stream, a);
+    }
     LAS_LAUNCH_CHECK();
     return LAS_OK;
 }
@@ -904,7 +908,10 @@ static int launch_persist_fwd2(const PersistArgs& a, int grid, hipStream_t strea
                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
     if (!persistent_launch_fits(speller_persist_fwd_kernel<HS, SPLIT, GREEDY>, PS_THREADS, smem, grid))
         return fail(LAS_ERR_UNSUPPORTED, "persistent decode kernel: %s%ld workgroups cannot all be resident", "", (long)grid);
-    hipLaunchKernelGGL((speller_persist_fwd_kernel<HS, SPLIT, GREEDY>), dim3(grid), dim3(PS_THREADS), smem, stream, a);
+    {
+        KernelTimer timer(TIMED_DECODE_FWD, stream);
+        hipLaunchKernelGGL((speller_persist_fwd_kernel<HS, SPLIT, GREEDY>), dim3(grid), dim3(PS_THREADS), smem, stream, a);
+    }
     LAS_LAUNCH_CHECK();
     return LAS_OK;
 }

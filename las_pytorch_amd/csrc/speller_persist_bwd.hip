@@ -25,6 +25,7 @@
 #include "las_common.h"
 #include "las_kernels.h"
 #include "persist_common.h"
+#include "options.h"
 #include <algorithm>
 
 namespace las {
@@ -768,7 +769,7 @@ size_t speller_persist_bwd_workspace_floats(int B, int Tp, int U, int Hs, int M)
     return std::max(classic, pre);
 }
 bool speller_persist_bwd_pre_eligible(int B, int Tp, int Hs, int D, int M, int V, int L, int heads, int use_mlp) {
-    static const bool on = !(getenv("LAS_SPELLER_PRE_BWD") && atoi(getenv("LAS_SPELLER_PRE_BWD")) == 0);
+    const bool on = opt_get(OPT_SPELLER_PRE_BWD) != 0;
     if (!on || !persist_bwd_shape(B, Hs, D, M, L, heads, use_mlp) || Tp > 448) return false;
     if (!speller_persist_pre_eligible(B, Tp, Hs, D, M, V, L, heads, use_mlp)) return false;      // the forward must have produced P and gx
     int cus = 0, dev = 0;
@@ -784,7 +785,10 @@ static int launch_persist_bwd_pre(const PersistBwdArgs& a, int grid, hipStream_t
                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
     if (!persistent_launch_fits(speller_persist_bwd_pre_kernel<HS>, PS_THREADS, smem, grid))
         return fail(LAS_ERR_UNSUPPORTED, "persistent decode backward: %s%ld workgroups cannot all be resident", "", (long)grid);
-    hipLaunchKernelGGL((speller_persist_bwd_pre_kernel<HS>), dim3(grid), dim3(PS_THREADS), smem, stream, a);
+    {
+        KernelTimer timer(TIMED_DECODE_BWD, stream);
+        hipLaunchKernelGGL((speller_persist_bwd_pre_kernel<HS>), dim3(grid), dim3(PS_THREADS), smem, stream, a);
+    }
     LAS_LAUNCH_CHECK();
     return LAS_OK;
 }
@@ -796,7 +800,10 @@ static int launch_persist_bwd(const PersistBwdArgs& a, int grid, hipStream_t str
                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
     if (!persistent_launch_fits(speller_persist_bwd_kernel<HS>, PS_THREADS, smem, grid))
         return fail(LAS_ERR_UNSUPPORTED, "persistent decode backward: %s%ld workgroups cannot all be resident", "", (long)grid);
-    hipLaunchKernelGGL((speller_persist_bwd_kernel<HS>), dim3(grid), dim3(PS_THREADS), smem, stream, a);
+    {
+        KernelTimer timer(TIMED_DECODE_BWD, stream);
+        hipLaunchKernelGGL((speller_persist_bwd_kernel<HS>), dim3(grid), dim3(PS_THREADS), smem, stream, a);
+    }
     LAS_LAUNCH_CHECK();
     return LAS_OK;
 }

@@ -6,7 +6,7 @@ utterances of the minibatch sharded by rank, and ONE all-reduce of a flat fp32 g
 The batch-coupled quantities of the reference step are (solver/solver.py:43,96; las_model.py:189):
   * the batch-mean loss  -> average of equal-shard rank gradients == full-batch gradient,
   * the global grad-norm clip -> applied AFTER the all-reduce, identically on every rank,
-  * the single teacher-forcing coin flip -> ``sync_coin`` broadcasts rank 0's NumPy RNG state draw.
+  * the single teacher-forcing coin flip -> ``sync_coin`` / ``restore_coin``: every rank draws it from rank 0's stream.
 """
 from __future__ import annotations
 
@@ -26,7 +26,11 @@ class FlatGradAllReducer:
         self.params = [p for p in module.parameters() if p.requires_grad]
         n = sum(p.numel() for p in self.params)
         dev = self.params[0].device
-        self.flat = torch.zeros(n, dtype=torch.float32, device=dev)
+        # 4 extra floats behind the gradients: [n] is the step's device-error flag, which rides in the same collective so that
+        # every rank learns whether ANY rank's persistent kernels timed out (solver.batch_iterator then re-runs the step on all)
+        self.flat_ext = torch.zeros(n + 4, dtype=torch.float32, device=dev)
+        self.flat = self.flat_ext[:n]
+        self.flag = self.flat_ext[n:n + 1]
         off = 0
         for p in self.params:
             p.grad = self.flat[off:off + p.numel()].view_as(p)
@@ -46,7 +50,23 @@ class FlatGradAllReducer:
 
     def zero(self):
         """Use instead of ``optimizer.zero_grad()`` (which would drop the views with set_to_none=True)."""
-        self.flat.zero_()
+        self.flat_ext.zero_()
+
+    def _collective(self):
+        """True when allreduce_mean() really exchanges data (more than one rank, or ``force``)."""
+        if self.comm is not None:
+            return self.comm.world > 1 or self.force
+        return dist.is_available() and dist.is_initialized() and (dist.get_world_size() > 1 or self.force)
+
+    def error_flag_ptr(self):
+        """What the fused optimizer's device-side guard looks at: the all-reduced flag when the gradients were exchanged (any
+        rank's timeout invalidates every rank's averaged gradient), this device's error word otherwise.  None on CPU."""
+        if not self.flat.is_cuda:
+            return None
+        if self._collective():
+            return self.flag.data_ptr()
+        from . import _cabi
+        return _cabi.err_word(self.flat.device).data_ptr()
 
     def check_views(self):
         """Every ``p.grad`` must still be its view of the flat buffer: ``optimizer.zero_grad()`` with torch's default
@@ -61,18 +81,18 @@ class FlatGradAllReducer:
     def allreduce_mean(self):
         """Average the flat gradient over the ranks with ONE collective (RCCL ``ncclAvg`` when the backend is nccl)."""
         self.check_views()
-        if self.comm is not None:
-            if self.comm.world > 1 or self.force:
-                self.comm.allreduce_(self.flat, average=True)
+        if not self._collective():
             return
-        if dist.is_available() and dist.is_initialized():
-            world = dist.get_world_size()
-            if world > 1 or self.force:
-                if dist.get_backend() == "nccl":
-                    dist.all_reduce(self.flat, op=dist.ReduceOp.AVG)
-                else:                                   # gloo has no AVG
-                    dist.all_reduce(self.flat, op=dist.ReduceOp.SUM)
-                    self.flat.div_(world)
+        if self.flat.is_cuda:       # this rank's device error word -> the flag element (codes are negative int32: averages cannot cancel)
+            from . import _cabi
+            self.flag.copy_(_cabi.err_word(self.flat.device)[:1])
+        if self.comm is not None:
+            self.comm.allreduce_(self.flat_ext, average=True)
+        elif dist.get_backend() == "nccl":
+            dist.all_reduce(self.flat_ext, op=dist.ReduceOp.AVG)
+        else:                                   # gloo has no AVG
+            dist.all_reduce(self.flat_ext, op=dist.ReduceOp.SUM)
+            self.flat_ext.div_(dist.get_world_size())
 
     def clip_(self, max_norm=1.0):
         """clip_grad_norm_(params, max_norm) on the flat buffer (solver/solver.py:96), same formula as torch's."""
@@ -125,16 +145,38 @@ class CabiComm:
 
 
 def sync_coin(seed_if_rank0=None):
-    """Keep the per-forward teacher-forcing coin (one ``np.random.random_sample()``, las_model.py:189) identical on
-    every rank: rank 0 draws a 32-bit seed and everyone reseeds NumPy's global RNG with it."""
+    """Make the next draw of NumPy's GLOBAL stream — the per-forward teacher-forcing coin, one
+    ``np.random.random_sample()`` in ``Speller.forward`` (las_model.py:189) — identical on every rank: rank 0 broadcasts
+    its generator state and the other ranks install it.  Returns a token for ``restore_coin`` (the rank's own state, None
+    on rank 0 / outside a multi-rank group), so that a rank's own use of ``np.random`` (shuffling, augmentation) keeps
+    its private stream.  ``solver.batch_iterator`` calls the pair around the model call, and only when the coin matters
+    (training with 0 < tf_rate < 1).  ``seed_if_rank0`` (tests): reseed rank 0's stream first."""
     if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
-        return
-    dev = "cuda" if dist.get_backend() == "nccl" else "cpu"
-    t = torch.zeros(1, dtype=torch.int64, device=dev)
-    if dist.get_rank() == 0:
-        t[0] = int(np.random.randint(0, 2 ** 31 - 1)) if seed_if_rank0 is None else int(seed_if_rank0)
+        return None
+    rank = dist.get_rank()
+    if rank == 0 and seed_if_rank0 is not None:
+        np.random.seed(int(seed_if_rank0))
+    own = np.random.get_state()
+    t = torch.zeros(625, dtype=torch.int64)
+    if rank == 0:
+        t[:624] = torch.from_numpy(own[1].astype(np.int64))
+        t[624] = int(own[2])
+    if dist.get_backend() == "nccl":
+        t = t.cuda()
     dist.broadcast(t, src=0)
-    np.random.seed(int(t.item()))
+    if rank == 0:
+        return None
+    host = t.cpu().numpy()
+    np.random.set_state((own[0], host[:624].astype(np.uint32), int(host[624]), 0, 0.0))
+    return own
+
+
+def restore_coin(token):
+    """Give a rank its own NumPy stream back after the synchronised coin has been drawn (advanced by the one draw the
+    forward consumed, as it would have been without the synchronisation)."""
+    if token is not None:
+        np.random.set_state(token)
+        np.random.random_sample()
 
 
 def shard_batch(n_items, rank, world):

@@ -284,7 +284,10 @@ class _AttentionFn(torch.autograd.Function):
         B, Tp, D = feat.shape
         if state.shape != (B, D):
             raise RuntimeError(f"decoder_state must be (B,1,{D}) / (B,{D}), got {tuple(state.shape)}")
-        direct = _direct_targets(params)
+        # never direct gradient writes here: a stand-alone attention call may share phi / psi with other uses in the same
+        # backward (Speller.forward, further Attention.forward calls), and every las_attention_bwd OVERWRITES its outputs —
+        # fresh tensors + autograd's AccumulateGrad sum them correctly
+        direct = None
         params = [_f32c(p) for p in params]
         dev = feat.device
         Lh, stream = lib(), stream_ptr()
@@ -334,7 +337,9 @@ class _SpellerStepFn(torch.autograd.Function):
         (L, use_mlp, relu, M, V, heads) = cfg
         feat, x = _f32c(feat), _f32c(x)
         B, Tp, D = feat.shape
-        direct = _direct_targets(params)
+        # forward_step is by nature called once per decode step, so every parameter is used U times per backward and each
+        # las_speller_step_bwd call overwrites its gradient outputs: no direct writes into p.grad here, autograd sums the steps
+        direct = None
         params = [_f32c(p) for p in params]
         lstm, rest = params[:4 * L], params[4 * L:]
         Hs = lstm[1].shape[1]

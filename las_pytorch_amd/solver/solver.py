@@ -184,7 +184,7 @@ def _loss_and_ler(logp, labels, steps, smoothed, label_smoothing):
 
 
 def batch_iterator(batch_data, batch_label, las_model, optimizer, tf_rate, is_training, max_label_len, label_smoothing,
-                   use_gpu=True, vocab_dict=None, grad_hook=None):
+                   use_gpu=True, vocab_dict=None, grad_hook=None, _retry=False):
     """One batch through the model: forward, loss, and when ``is_training`` backward, clip at 1.0 and the optimizer
     step (reference solver/solver.py:48-101; same arguments, returns ``(loss as a NumPy scalar, list of per-utterance
     letter error rates)``).  ``use_gpu`` / ``vocab_dict`` are accepted for signature parity; tensors stay on the device
@@ -192,18 +192,30 @@ def batch_iterator(batch_data, batch_label, las_model, optimizer, tf_rate, is_tr
 
     Data parallel: attach a ``las_pytorch_amd.dp.FlatGradAllReducer`` to the model (its constructor does) and this
     function zeroes, all-reduces and clips the flat gradient buffer; the teacher-forcing coin is synchronised across
-    ranks first.  ``grad_hook(model)`` (optional) runs between backward and the clip for callers that exchange
-    gradients themselves."""
+    ranks first.  With a ``las_pytorch_amd.optim.FusedClipAdam`` optimizer the clip and the Adam step are two HIP launches.
+    ``grad_hook(model)`` (optional) runs between backward and the clip for callers that exchange gradients themselves.
+
+    A hand-off timeout of a persistent kernel (another kernel was resident on the GPU) invalidates the step.  When nothing
+    irreversible happened — validation, or training with ``FusedClipAdam``, whose update kernel skips itself when the error
+    word (on any rank) is set — the step is re-run ONCE on the generic kernels with a warning; otherwise it raises."""
     from .. import _cabi, dp
+    from ..optim import FusedClipAdam
     steps = min(int(batch_label.shape[1]), int(max_label_len))
     reducer = _attached_reducer(las_model)
+    fused = isinstance(optimizer, FusedClipAdam)
+    if fused and reducer is not optimizer.reducer:
+        raise RuntimeError("FusedClipAdam was built on a different FlatGradAllReducer than the one attached to the model")
     if reducer is not None:
         reducer.zero()                        # keeps every p.grad a view of the flat buffer
     else:
         optimizer.zero_grad()
-    dp.sync_coin()                            # no-op outside a multi-rank process group
+    # data parallel: all ranks must take the same forced / free-running branch.  Only then does the coin matter; no-op otherwise
+    coin_state = np.random.get_state() if (is_training and not _retry) else None
+    coin_token = dp.sync_coin() if (is_training and 0.0 < float(tf_rate) < 1.0) else None
 
-    step_logp, _ = las_model(batch_data=batch_data, batch_label=batch_label, teacher_force_rate=tf_rate, is_training=is_training)
+    with _cabi.polls_deferred():              # a hand-off timeout is dealt with below, for the step as a whole
+        step_logp, _ = las_model(batch_data=batch_data, batch_label=batch_label, teacher_force_rate=tf_rate, is_training=is_training)
+    dp.restore_coin(coin_token)
     if len(step_logp) < steps:
         raise RuntimeError(f"the model decoded {len(step_logp)} steps but {steps} are scored")
     logp = stack_steps(step_logp, steps)                     # (B,steps,V); a strided view when the steps share one buffer
@@ -216,14 +228,43 @@ def batch_iterator(batch_data, batch_label, las_model, optimizer, tf_rate, is_tr
             grad_hook(las_model)
         if reducer is not None:
             reducer.allreduce_mean()
-            reducer.clip_(CLIP_NORM)
+            if fused:
+                optimizer.step_clipped(CLIP_NORM)
+            else:
+                reducer.clip_(CLIP_NORM)
+                optimizer.step()
         else:
             torch.nn.utils.clip_grad_norm_(las_model.parameters(), CLIP_NORM)
-        optimizer.step()
+            optimizer.step()
 
     batch_loss = loss.detach().cpu().numpy()                 # the step's host synchronisation point
     if torch.is_tensor(ler):
         ler = ler.cpu().tolist()
     if logp.is_cuda:
-        _cabi.check_device_errors()           # a hand-off timeout in a persistent kernel invalidates this step: raise
+        failed = None
+        try:
+            _cabi.check_device_errors()       # a hand-off timeout in a persistent kernel invalidates this step
+        except _cabi.DeviceHandoffError as e:
+            failed = e
+        peer_failed = bool(is_training and reducer is not None and reducer._collective() and float(reducer.flag.item()) != 0.0)
+        if failed is not None or peer_failed:
+            recoverable = (not is_training) or fused          # the fused update skipped itself on every rank (all-reduced flag)
+            if _retry or not recoverable:
+                raise failed if failed is not None else RuntimeError("a peer rank reported a device-side hand-off timeout")
+            import warnings
+            from ..model.las_model import set_force_generic
+            warnings.warn(f"liblas_hip: persistent-kernel hand-off timeout ({failed or 'reported by a peer rank'}); re-running this "
+                          "step once on the generic kernels (another kernel was resident on the GPU?)")
+            if fused and is_training:
+                optimizer.rollback_step()
+            if coin_state is not None:
+                np.random.set_state(coin_state)               # the re-run must draw the same teacher-forcing coin
+            before = {m: m.force_generic for m in las_model.modules() if hasattr(m, "force_generic")}
+            set_force_generic(las_model, True)
+            try:
+                return batch_iterator(batch_data, batch_label, las_model, optimizer, tf_rate, is_training, max_label_len,
+                                      label_smoothing, use_gpu, vocab_dict, grad_hook, _retry=True)
+            finally:
+                for m, v in before.items():
+                    m.force_generic = v
     return batch_loss, ler

@@ -220,3 +220,35 @@ def test_bench_line_contract():
     acc = j["gemm_accuracy"]
     assert acc["split_bf16_err_ulp"] <= 1.25 * acc["mfma_f32_err_ulp"] + 0.5, acc
     assert j["gemm_arith_variant"]["ms_per_step"] > 0
+    # round 3: the two decode kernels that dominate the step are priced too (HIP events around the single launch), and the line
+    # checks its own first-step loss against the reference's
+    for key in ("roofline_speller_fwd", "roofline_speller_bwd"):
+        q = j[key]
+        assert q["bound"] == "hbm" and q["kernel_ms"] > 0 and abs(q["frac"] - q["achieved"] / q["peak"]) < 1e-4
+        assert abs(q["us_per_decode_step"] - q["kernel_ms"] * 1e3 / 128) < 1e-2
+    assert 3 * j["roofline_speller_fwd"]["algorithmic_bytes"] == j["roofline_speller_bwd"]["algorithmic_bytes"]
+    cfgj = j["config"]
+    assert abs(cfgj["first_step_loss"] - cfgj["first_step_loss_reference"]) <= 1e-4 * abs(cfgj["first_step_loss_reference"])
+    assert j["allreduce_ms"] is None and j["rccl_ranks"] == 0
+
+
+def test_bench_rccl_path_on_one_gpu_and_strong_scaling_flag():
+    """The N > 1 code path end to end on one GPU: LAS_FORCE_DIST=1 initialises RCCL, every step all-reduces the flat gradient +
+    error flag, the collective is timed alone (allreduce_ms), and --scaling strong splits --global-batch over the ranks."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, LAS_FORCE_DIST="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    env.pop("MASTER_PORT", None)
+    p = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "1", "--steps", "3", "--warmup", "2", "--no-cpu-baseline", "--no-sweep",
+                        "--no-mfma", "--no-secondary", "--no-roofline", "--scaling", "strong", "--global-batch", "16"],
+                       capture_output=True, text=True, timeout=600, cwd=root, env=env)
+    assert p.returncode == 0, p.stderr[-2000:]
+    j = json.loads([l for l in p.stdout.splitlines() if l.startswith("{")][-1])
+    assert j["rccl_ranks"] == 1 and j["scaling"] == "strong" and j["config"]["per_gpu_batch"] == 16 and j["config"]["global_batch"] == 16
+    assert j["allreduce_ms"] > 0 and j["allreduce_bytes"] > 39e6
+    # a launcher / --gpus mismatch fails loudly instead of reporting a 1-GPU number as N-GPU
+    p = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0"],
+                       capture_output=True, text=True, timeout=120, cwd=root, env=dict(os.environ, WORLD_SIZE="1", RANK="0", LOCAL_RANK="0"))
+    assert p.returncode != 0 and "WORLD_SIZE=1" in (p.stderr + p.stdout)

@@ -5,7 +5,7 @@ import numpy as np
 import pytest
 import torch
 
-from golden_util import ALL_CASES, BIG_CASES, load_case, oracle_cfg
+from golden_util import ALL_CASES, BIG_CASES, load_case, oracle_cfg, tf_argmax_mask
 from hip_util import assert_close, build_las, grad_close, record
 
 pytestmark = pytest.mark.gpu
@@ -35,14 +35,15 @@ def test_forward_golden(name):
         preds, atts = las(batch_data=xt, batch_label=lab, teacher_force_rate=1.0, is_training=True)
         logp = torch.stack(preds).cpu().numpy()
         assert_close(logp, g["tf_logp"], f"{name}/tf_logp")
-        assert (logp.argmax(-1) == g["tf_argmax"]).all(), f"{name}: teacher-forced argmax differs"
+        mask = tf_argmax_mask(g["tf_logp"])
+        assert (logp.argmax(-1) == g["tf_argmax"])[mask].all() and mask.mean() > 0.99, f"{name}: teacher-forced argmax differs"
         att = np.stack([torch.stack([a[hd] for a in atts]).cpu().numpy() for hd in range(info["multi_head"])], 0)
         want = g["tf_att"]
         assert_close(att if info["full"] else att[:, :, :, ::info["sub_t"]], want, f"{name}/tf_att", atol=1e-6)
         preds, _ = las(batch_data=xt, batch_label=lab, teacher_force_rate=0.0, is_training=False)
         logp = torch.stack(preds).cpu().numpy()
         assert (logp.argmax(-1) == g["greedy_argmax"]).all(), f"{name}: greedy argmax sequence differs"
-        assert_close(logp, g["greedy_logp"], f"{name}/greedy_logp")
+        assert_close(logp[::info["sub_u"]], g["greedy_logp"], f"{name}/greedy_logp")
         if "mode0_logp" in g:
             # decode_mode 0 feeds the log-probs back as the next input (las_model.py:220-221): rounding differences are
             # re-amplified every step, so the deviation grows with the step index; observed worst is recorded
@@ -116,9 +117,12 @@ def test_grads_golden(name):
 
 @pytest.mark.parametrize("cfg_name,B,T,U,scale", [("S", 5, 96, 7, None), ("P", 6, 64, 6, 0.12), ("tiny", 3, 24, 4, 0.4),
                                                   ("Y", 3, 64, 5, 0.08),
-                                                  ("S", 32, 800, 16, None), ("P", 32, 800, 16, None)])
+                                                  ("S", 32, 800, 16, None), ("P", 32, 800, 16, None),
+                                                  ("P", 32, 800, 128, None)])
 def test_forward_backward_vs_oracle(cfg_name, B, T, U, scale):
-    """Fresh seeded inputs, sizes the goldens do not cover (odd batch, full LibriSpeech shape)."""
+    """Fresh seeded inputs, sizes the goldens do not cover (odd batch, full LibriSpeech shape); the last row is the benchmark's
+    EXACT shape (P, B=32, T=800, U=128): log-probs, loss and every gradient of all 128 steps of the one-launch decode kernels
+    against the CPU oracle (ragged label lengths here; tests/golden/P_B32_T800_U128.npz pins the same shape to the reference)."""
     from las_pytorch_amd import synth
     from oracle import las_oracle as O
     c = synth.CONFIGS[cfg_name]

@@ -12,6 +12,9 @@ python -c "import __graft_entry__ as g; g.smoke()" > $O/smoke.log 2>&1
 python bench.py --steps 20 --warmup 5 > $O/bench.json 2> $O/bench.err
 cd /tmp && export TMPDIR=/tmp
 rocprofv3 --kernel-trace --stats -d $O/stats -o x -- python3 $R/bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-sweep --no-mfma --no-roofline --no-secondary > $O/stats.log 2>&1
+F="--steps 4 --warmup 2 --no-cpu-baseline --no-sweep --no-mfma --no-roofline --no-secondary"
+rocprofv3 --pmc FETCH_SIZE -d $O/pmc_step/fetch -o x -- python3 $R/bench.py $F > $O/pmc_step_fetch.log 2>&1
+rocprofv3 --pmc WRITE_SIZE -d $O/pmc_step/write -o x -- python3 $R/bench.py $F > $O/pmc_step_write.log 2>&1
 rocprofv3 --pmc FETCH_SIZE -d $O/pmc_fetch -o x -- python3 $R/tools/ubench_rec.py > $O/pmc_fetch.log 2>&1
 rocprofv3 --pmc WRITE_SIZE -d $O/pmc_write -o x -- python3 $R/tools/ubench_rec.py > $O/pmc_write.log 2>&1
 # MFMA-busy / stall / LDS counters of the GEMM in both arithmetic modes (1 = split-operand bf16 MFMA, the default; 0 = fp32 MFMA)

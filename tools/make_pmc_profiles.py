@@ -13,6 +13,13 @@ import sqlite3
 import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+ROUND = os.environ.get("LAS_ROUND", "r03")
+
+
+def csrc_sha16():
+    import bench
+    return bench.csrc_sha16()
 
 
 def rows(db, match):
@@ -49,7 +56,7 @@ def rec(fetch_db, write_db, B, T_l, H):
     src = os.path.join(ROOT, "las_pytorch_amd", "csrc", "pblstm_rec.hip")
     out = {
         "kernel": kname, "grid_threads": grid, "shape": {"B": B, "T_l": T_l, "H": H},
-        "kernel_source_sha16": hashlib.sha256(open(src, "rb").read()).hexdigest()[:16],
+        "kernel_source_sha16": hashlib.sha256(open(src, "rb").read()).hexdigest()[:16], "csrc_sha16": csrc_sha16(),
         "dispatches": fd["FETCH_SIZE"][1], "kernel_us_under_pmc": fd["FETCH_SIZE"][2] / fd["FETCH_SIZE"][1] / 1e3,
         "fetch_size_bytes_raw": fetch, "write_size_bytes": write, "traffic_bytes": fetch + write,
         "expected_read_bytes": pre + wts, "expected_write_bytes": stash, "handoff_granule_bytes": 2 * B * T_l * H * 8, "calibration": cal,
@@ -60,9 +67,30 @@ def rec(fetch_db, write_db, B, T_l, H):
                 "WRITE_SIZE is exact on the copy; on the kernel it exceeds the expected stash bytes by the hand-off granules "
                 "(2*B*G workgroups x T_l steps x 64 units x 8 B = 52.4 MB at this shape), which reach memory once.",
     }
-    path = os.path.join(ROOT, "profiles", "r02_pmc_rec_fwd.json")
+    path = os.path.join(ROOT, "profiles", f"{ROUND}_pmc_rec_fwd.json")
     json.dump(out, open(path, "w"), indent=1)
     print(path, json.dumps(out)[:400])
+
+
+def speller(fetch_db, write_db, B, Tp, U, Hs):
+    """The two one-launch decode kernels under `bench.py` (a few training steps): FETCH_SIZE / WRITE_SIZE per launch."""
+    for tag, match in (("fwd", "speller_persist_fwd"), ("bwd", "speller_persist_bwd")):
+        f = rows(fetch_db, match); w = rows(write_db, match)
+        if not f or not w:
+            print("no dispatches of", match); continue
+        (kname, grid), fd = next(iter(f.items()))
+        wd = next(iter(w.values()))
+        fetch = mean(fd, "FETCH_SIZE") * 1024.0; write = mean(wd, "WRITE_SIZE") * 1024.0
+        out = {"kernel": kname, "grid_threads": grid, "shape": {"B": B, "Tp": Tp, "U": U, "Hs": Hs}, "csrc_sha16": csrc_sha16(),
+               "dispatches": fd["FETCH_SIZE"][1], "kernel_us_under_pmc": fd["FETCH_SIZE"][2] / fd["FETCH_SIZE"][1] / 1e3,
+               "fetch_size_bytes_raw": fetch, "write_size_bytes": write, "traffic_bytes": fetch + write,
+               "note": "rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate passes over bench.py (training steps of the headline "
+                       "workload); per launch of this kernel. FETCH_SIZE raw: the guide's x2 gfx950 correction applies to wide 16-B/lane "
+                       "streams, most of this kernel's reads are agent-scope polls and 16-B tile loads that hit the XCD's L2 after the "
+                       "first workgroup, so the raw counter is quoted. Hand-off slabs and the backward stash are written through (sc1)."}
+        path = os.path.join(ROOT, "profiles", f"{ROUND}_pmc_speller_{tag}.json")
+        json.dump(out, open(path, "w"), indent=1)
+        print(path, json.dumps(out)[:300])
 
 
 def gemm(dbs):
@@ -96,7 +124,7 @@ def gemm(dbs):
                       "(sclk column; lower than an unprofiled run's).  fp32 MFMA: the fp32 matrix pipe is busy 58-75 % of the kernel.  Split-operand "
                       "mode: the bf16 pipe is busy for the same number of cycles per output as 3/8 of the fp32 case (six 32-cycle MFMAs instead "
                       "of eight 64-cycle ones per 16 k), the kernel is LDS- and issue-paced: lds_busy_frac = SQ_LDS_IDX_ACTIVE / (cycles x 256 CUs).")
-    path = os.path.join(ROOT, "profiles", "r02_pmc_gemm.json")
+    path = os.path.join(ROOT, "profiles", f"{ROUND}_pmc_gemm.json")
     json.dump(out, open(path, "w"), indent=1)
     print(path)
 
@@ -104,6 +132,8 @@ def gemm(dbs):
 if __name__ == "__main__":
     if sys.argv[1] == "rec":
         rec(sys.argv[2], sys.argv[3], int(sys.argv[4]), int(sys.argv[5]), int(sys.argv[6]))
+    elif sys.argv[1] == "speller":
+        speller(sys.argv[2], sys.argv[3], *[int(v) for v in sys.argv[4:8]])
     else:
         args = sys.argv[2:]       # arith db_a db_b [arith db_a db_b ...]
         gemm([(int(args[i]), args[i + 1], args[i + 2]) for i in range(0, len(args), 3)])
