@@ -227,7 +227,7 @@ int las_letter_error_rate(const float* logp, int64_t stride_u, int64_t stride_b,
  *                        parameters and moments are left UNCHANGED (the step's gradients are invalid; the host re-runs it) */
 size_t las_clip_adam_workspace_floats(void);
 int las_clip_adam(float* const* params, const int64_t* offsets, int n_tensors, float* grad_flat, float* exp_avg,
-                  float* exp_avg_sq, float max_norm, float lr, float beta1, float beta2, float eps, int step,
+                  float* exp_avg_sq, float max_norm, double lr, double beta1, double beta2, double eps, int step,
                   float* norm_out, float* workspace, const uint32_t* err_word, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
@@ -298,7 +298,7 @@ int las_pblstm_rec_fwd(float* gates, const float* w_hh_f, const float* w_hh_r, f
 
 /* ------------------------------------------------------------------------------------------------
  * Profiling hooks (tools/ubench_persist*_trace.py): per-phase shader-clock stamps of workgroup 0 of each role of the
- * persistent decode kernels.  dev_buf: device buffer of 3*U*8 uint64 (NULL switches the stamps off again).  Process-wide,
+ * persistent decode kernels.  dev_buf: device buffer of 3*U*8 (forward) / 4*U*8 (backward) uint64; NULL switches the stamps off again.  Process-wide,
  * not for production use.  las_debug_rec_trace exists only in builds with -DLAS_REC_TRACE.
  * ---------------------------------------------------------------------------------------------- */
 void las_debug_persist_trace(unsigned long long* dev_buf);

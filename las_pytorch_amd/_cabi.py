@@ -46,8 +46,8 @@ PROTOTYPES = {
     "las_set_option": (C.c_int, [C.c_char_p, C.c_int64]),
     "las_get_option": (C.c_int, [C.c_char_p, C.POINTER(C.c_int64)]),
     "las_clip_adam_workspace_floats": (C.c_size_t, []),
-    "las_clip_adam": (C.c_int, [C.POINTER(_f), C.POINTER(C.c_int64), C.c_int, _f, _f, _f, C.c_float, C.c_float, C.c_float, C.c_float,
-                                C.c_float, C.c_int, _f, _f, _f, _f]),
+    "las_clip_adam": (C.c_int, [C.POINTER(_f), C.POINTER(C.c_int64), C.c_int, _f, _f, _f, C.c_float, C.c_double, C.c_double, C.c_double,
+                                C.c_double, C.c_int, _f, _f, _f, _f]),
     "las_debug_persist_trace": (None, [_f]),
     "las_debug_persist_bwd_trace": (None, [_f]),
     "las_debug_kernel_ms": (C.c_int, [C.c_int, C.POINTER(C.c_float)]),

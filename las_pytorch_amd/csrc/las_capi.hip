@@ -39,7 +39,7 @@ struct PblstmBwdLayout {
 };
 
 struct SpellerLayout {
-    size_t y_all, ctx_all, h_all, c_all, gates_all, q_all, w0p, ctxcat_all, hx, lgx, wperm, pctx, gx, total;
+    size_t y_all, ctx_all, h_all, c_all, gates_all, q_all, w0p, ctxcat_all, hx, r0x, lgx, wperm, wyperm, bperm, yw, pctx, gx, total;
     bool pre;                  // room for the persistent decode kernel's pre-multiplied context variant
     int Vp;                    // label width padded to a multiple of 16: every cell operand is aligned and tail-free
     SpellerLayout(const las_speller_desc* d, int U) {
@@ -55,12 +55,16 @@ struct SpellerLayout {
         ctxcat_all = o; if (d->multi_head > 1) o += r4((size_t)U * B * d->multi_head * d->D);   // per-head contexts (dim_reduce input)
         w0p = o; o += r4((size_t)4 * d->Hs * (Vp + d->Hs));      // W_ih0 re-laid as [W_y | 0 | W_ctx], ld = Vp + Hs
         // pre-multiplied context variant: row-permuted W_ctx, feat . W_ctx^T, and the per-step hand-off slabs of its weighted sums
-        // (gx directly behind hx: one sentinel fill covers both)
+        // (r0x directly behind hx: one sentinel fill covers both)
         pre = speller_persist_pre_shape(d->B, d->Tp, d->Hs, d->D, d->M, d->V, d->L, d->multi_head, d->use_mlp);
         hx = o; if (d->L == 2) o += r4((size_t)2 * U * 32 * d->Hs);   // hand-off copy of h for the persistent decode kernel
+        r0x = o; if (pre) o += r4((size_t)U * 32 * 4 * d->Hs);        // ... and the cell workgroups' part of the bottom-layer gates
         gx = o; if (pre) o += r4((size_t)U * B * 4 * d->Hs);
         lgx = o; if (d->L == 2) o += r4((size_t)U * B * 8 * 32);      // ... and its partial logits (free-running decode)
         wperm = o; if (pre) o += r4((size_t)4 * d->Hs * d->Hs);
+        wyperm = o; if (pre) o += r4((size_t)4 * d->Hs * Vp);      // W_y rows and b_ih0 + b_hh0 in the same row order ...
+        bperm = o; if (pre) o += r4((size_t)4 * d->Hs);
+        yw = o; if (pre) o += r4((size_t)U * B * 4 * d->Hs);       // ... and y_s W_y^T + b for every step (label half of the bottom-layer gates)
         pctx = o; if (pre) o += r4((size_t)B * d->Tp * 4 * d->Hs);
         total = o;
     }
@@ -398,7 +402,8 @@ int las_speller_fwd(const las_speller_desc* d, const float* feat, const float* k
     // or the occupancy calculator: P = feat . W_ctx^T and the per-step sums gx_s = sum_t a_t P_t are always there, so that
     // las_speller_bwd (LAS_FLAG_TEACHER_FORCED) can rely on them whichever forward variant actually ran.
     const bool pre_stash = teacher_forced && lay.pre;
-    LAS_TRY(build_w0p(d->w_ih[0], w0p, Hs, V, Vp, stream, pre_stash ? reserve + lay.wperm : nullptr));
+    LAS_TRY(build_w0p(d->w_ih[0], w0p, Hs, V, Vp, stream, pre_stash ? reserve + lay.wperm : nullptr, pre ? reserve + lay.wyperm : nullptr,
+                      pre ? reserve + lay.bperm : nullptr, d->b_ih[0], d->b_hh[0]));
     if (pre_stash) {
         GemmDesc g;
         g.A = feat; g.lda = D; g.a_kc = true;
@@ -410,7 +415,15 @@ int las_speller_fwd(const las_speller_desc* d, const float* feat, const float* k
     bool pre_ran = false;
     if (persist) {
         PersistFwd p;
-        if (pre) { p.pctx = reserve + lay.pctx; p.gx = reserve + lay.gx; }
+        if (pre) {
+            // label half of the bottom-layer gates for every step, off the decode chain: yw[s][b] = y_s[b] W_y^T + b_ih0 + b_hh0
+            GemmDesc g;
+            g.A = y_all; g.lda = Vp; g.a_kc = true;
+            g.B = reserve + lay.wyperm; g.ldb = Vp; g.b_kc = true; g.bias0 = reserve + lay.bperm;
+            g.C = reserve + lay.yw; g.ldc = 4 * Hs; g.M = U * B; g.N = 4 * Hs; g.K = Vp; g.splitk = 1;
+            LAS_TRY(gemm_f32(g, stream));
+            p.pctx = reserve + lay.pctx; p.gx = reserve + lay.gx; p.r0x = reserve + lay.r0x; p.yw = reserve + lay.yw;
+        }
         p.w0p = w0p; p.Vp = Vp;
         p.w_hh0 = d->w_hh[0]; p.w_ih1 = d->w_ih[1]; p.w_hh1 = d->w_hh[1];
         p.b_ih0 = d->b_ih[0]; p.b_hh0 = d->b_hh[0]; p.b_ih1 = d->b_ih[1]; p.b_hh1 = d->b_hh[1];

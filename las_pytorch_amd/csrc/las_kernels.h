@@ -133,6 +133,8 @@ struct PersistFwd {
     // cell workgroups' column order (B*Tp, 4Hs), gx = U*B*4Hs floats of hand-off slabs.  The kernel then leaves
     // ctx_all[1..U] to the caller (one batched GEMM att . feat after the launch).
     const float* pctx = nullptr; float* gx = nullptr;
+    float* r0x = nullptr;                           // PRE variant: U*32*4Hs floats, the cell workgroups' part of the bottom-layer gates
+    const float* yw = nullptr;                      // PRE variant: (U*B, 4Hs) label half + biases of the bottom-layer gates, permuted columns
     int B, Tp, U, Hs, V, relu;
     unsigned* err;
 };
@@ -208,7 +210,10 @@ int ls_loss(const float* logp, long sU, long sB, const long long* labels, int U,
             float* loss, float* dlogp, long dU, long dB, hipStream_t stream);
 int ler(const float* logp, long sU, long sB, const long long* labels, int U, int U_lab, int B, int V, float* out, int* work,
         hipStream_t stream);
-int build_w0p(const float* w_ih0, float* w0p, int Hs, int V, int Vp, hipStream_t stream, float* wperm = nullptr);
+// wperm / wyperm / bperm (optional, together): W_ctx rows, W_y rows (4Hs, Vp) and b_ih0 + b_hh0 in the persistent decode kernel's
+// unit*4 + gate row order
+int build_w0p(const float* w_ih0, float* w0p, int Hs, int V, int Vp, hipStream_t stream, float* wperm = nullptr,
+              float* wyperm = nullptr, float* bperm = nullptr, const float* b_ih0 = nullptr, const float* b_hh0 = nullptr);
 int labels_to_y(const long long* labels, float* y_all, int B, int U, int V, int Vp, int u_lab, hipStream_t stream);
 int collate_pad(const float* packed, const long long* foff, const long long* plab, const long long* loff, int B, int T, int F, int U,
                 int V, float* inputs, long long* targets, hipStream_t stream);

@@ -163,26 +163,30 @@ int copy2d(const float* src, long lds, float* dst, long ldd, int rows, int cols,
 // wperm (optional): the context part again as (4Hs, Hs) with the rows in the order the persistent decode kernel's cell
 // workgroups consume them: row (j*16 + unit*4 + gate) = W_ih0 row (gate*Hs + 4j + unit) — the B operand of the
 // `feat . W_ctx^T` product whose attention-weighted sum replaces `W_ctx . context` on the decode chain.
-__global__ void build_w0p_kernel(const float* __restrict__ w, float* __restrict__ w0p, float* __restrict__ wperm, int rows, int V,
-                                 int Vp, int Hs) {
+__global__ void build_w0p_kernel(const float* __restrict__ w, float* __restrict__ w0p, float* __restrict__ wperm,
+                                 float* __restrict__ wyperm, float* __restrict__ bperm, const float* __restrict__ b_ih0,
+                                 const float* __restrict__ b_hh0, int rows, int V, int Vp, int Hs) {
     const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
     const int ld = Vp + Hs;
     if (i >= (long)rows * ld) return;
     const int r = i / ld, c = i % ld;
+    const int gate = r / Hs, u = r % Hs;
+    const long pr = (u >> 2) * 16 + (u & 3) * 4 + gate;       // row in the cell workgroups' order
     float v = 0.f;
     if (c < V) v = w[(long)r * (V + Hs) + c];
     else if (c >= Vp) {
         v = w[(long)r * (V + Hs) + V + (c - Vp)];
-        if (wperm) {
-            const int gate = r / Hs, u = r % Hs;
-            wperm[(long)((u >> 2) * 16 + (u & 3) * 4 + gate) * Hs + (c - Vp)] = v;
-        }
+        if (wperm) wperm[pr * Hs + (c - Vp)] = v;
     }
+    if (wyperm && c < Vp) wyperm[pr * Vp + c] = v;
+    if (bperm && c == 0) bperm[pr] = b_ih0[r] + b_hh0[r];
     w0p[i] = v;
 }
-int build_w0p(const float* w_ih0, float* w0p, int Hs, int V, int Vp, hipStream_t stream, float* wperm) {
+int build_w0p(const float* w_ih0, float* w0p, int Hs, int V, int Vp, hipStream_t stream, float* wperm, float* wyperm, float* bperm,
+              const float* b_ih0, const float* b_hh0) {
     const long n = (long)4 * Hs * (Vp + Hs);
-    hipLaunchKernelGGL(build_w0p_kernel, dim3(cdiv(n, 256)), dim3(256), 0, stream, w_ih0, w0p, wperm, 4 * Hs, V, Vp, Hs);
+    hipLaunchKernelGGL(build_w0p_kernel, dim3(cdiv(n, 256)), dim3(256), 0, stream, w_ih0, w0p, wperm, wyperm, bperm, b_ih0, b_hh0, 4 * Hs, V,
+                       Vp, Hs);
     LAS_LAUNCH_CHECK();
     return LAS_OK;
 }

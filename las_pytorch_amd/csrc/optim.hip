@@ -68,12 +68,14 @@ struct AdamTable {
     int n;
 };
 
-struct AdamScalars { float max_norm, lr_c1, inv_sqrt_c2, b1, b2, eps; };
+struct AdamScalars { float max_norm, lr_c1, sqrt_c2, w1, b2, w2, eps; };
 
 __device__ __forceinline__ void adam_one(float& p, float& m, float& v, float g, const AdamScalars& h) {
-    m = h.b1 * m + (1.f - h.b1) * g;
-    v = h.b2 * v + (1.f - h.b2) * g * g;
-    const float denom = sqrtf(v) * h.inv_sqrt_c2 + h.eps;
+    // the operation order of torch's Adam: exp_avg.lerp_(grad, 1 - beta1); exp_avg_sq.mul_(beta2).addcmul_(grad, grad, value=1 - beta2);
+    // denom = sqrt(exp_avg_sq) / sqrt(bias_correction2) + eps; param.addcdiv_(exp_avg, denom, value=-lr / bias_correction1)
+    m = m + (g - m) * h.w1;
+    v = h.b2 * v + h.w2 * (g * g);
+    const float denom = sqrtf(v) / h.sqrt_c2 + h.eps;
     p -= h.lr_c1 * (m / denom);
 }
 
@@ -142,11 +144,11 @@ extern "C" {
 size_t las_clip_adam_workspace_floats(void) { return NORM_BLOCKS; }
 
 int las_clip_adam(float* const* params, const int64_t* offsets, int n_tensors, float* grad_flat, float* exp_avg, float* exp_avg_sq,
-                  float max_norm, float lr, float beta1, float beta2, float eps, int step, float* norm_out, float* workspace,
+                  float max_norm, double lr, double beta1, double beta2, double eps, int step, float* norm_out, float* workspace,
                   const uint32_t* err_word, void* stream_) {
     hipStream_t stream = (hipStream_t)stream_;
     LAS_REQUIRE(params && offsets && n_tensors > 0 && grad_flat && exp_avg && exp_avg_sq && workspace, "clip_adam pointers");
-    LAS_REQUIRE(step >= 1 && lr >= 0.f && beta1 >= 0.f && beta1 < 1.f && beta2 >= 0.f && beta2 < 1.f && eps >= 0.f, "Adam hyper-parameters");
+    LAS_REQUIRE(step >= 1 && lr >= 0. && beta1 >= 0. && beta1 < 1. && beta2 >= 0. && beta2 < 1. && eps >= 0., "Adam hyper-parameters");
     LAS_REQUIRE(offsets[0] == 0, "offsets start at 0");
     for (int t = 0; t < n_tensors; ++t) LAS_REQUIRE(params[t] && offsets[t + 1] > offsets[t], "parameter table");
     const long total = (long)offsets[n_tensors];
@@ -154,9 +156,9 @@ int las_clip_adam(float* const* params, const int64_t* offsets, int n_tensors, f
     LAS_LAUNCH_CHECK();
     AdamScalars h;
     // torch.optim.Adam (single-tensor / fused): step_size = lr / bias_correction1 ; denom = sqrt(v) / sqrt(bias_correction2) + eps
-    const double c1 = 1.0 - pow((double)beta1, (double)step), c2 = 1.0 - pow((double)beta2, (double)step);
-    h.max_norm = max_norm; h.lr_c1 = (float)((double)lr / c1); h.inv_sqrt_c2 = (float)(1.0 / sqrt(c2));
-    h.b1 = beta1; h.b2 = beta2; h.eps = eps;
+    const double c1 = 1.0 - pow(beta1, (double)step), c2 = 1.0 - pow(beta2, (double)step);
+    h.max_norm = max_norm; h.lr_c1 = (float)(lr / c1); h.sqrt_c2 = (float)sqrt(c2);
+    h.w1 = (float)(1.0 - beta1); h.b2 = (float)beta2; h.w2 = (float)(1.0 - beta2); h.eps = (float)eps;
     for (int t0 = 0; t0 < n_tensors; t0 += MAX_T) {
         AdamTable tb;
         tb.n = std::min(MAX_T, n_tensors - t0);

@@ -56,7 +56,9 @@ __device__ __forceinline__ void lds_barrier() {     // orders LDS traffic only (
 // bounded-spin bookkeeping shared by every poller; returns true when the caller must give up
 __device__ __forceinline__ bool spin_expired(unsigned& spins, unsigned* err, unsigned code) {
     ++spins;
-    if ((spins & 127u) == 0) {
+    // the error word is looked at rarely: that agent-scope load takes ~1 us, and a poller that is inside it when its data arrives
+    // delays its whole workgroup (with a check every 128 spins one of a workgroup's 16 waves was caught in almost every wait)
+    if ((spins & 8191u) == 0) {
         if (spins > PS_SPIN_LIMIT) { atomicExch(err, code); return true; }
         if (__hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) return true;
     }
@@ -84,6 +86,59 @@ __device__ __forceinline__ void wg_canary_wait(volatile unsigned* flags, unsigne
         while ((int)(flags[k] - ep) < 0)
             if (spin_expired(spins, err, code)) return;
     }
+}
+
+// ---- fp32 products on the bf16 matrix pipe (same arithmetic as gemm_f32.hip's split-operand mode) -----------------------------
+// Every fp32 value is the EXACT sum of three bf16 values (x1 = rne(x), x2 = rne(x - x1), x3 = x - x1 - x2); six of the nine partial
+// products per operand pair are issued (the dropped ones are below 2^-26 |a b|), each exact in the MFMA's fp32 accumulator.  On gfx950
+// v_mfma_f32_16x16x4_f32 occupies a SIMD's matrix pipe for 32 cycles per 4 k, v_mfma_f32_16x16x32_bf16 for 16 cycles per 32 k: six
+// of the latter replace eight of the former for a lane's 8 k-slots — 2.67x less matrix-pipe time on the decode chain.
+typedef __attribute__((ext_vector_type(8))) __bf16 ps_bf16x8;
+typedef __attribute__((ext_vector_type(4))) __bf16 ps_bf16x4;
+typedef __attribute__((ext_vector_type(2))) __bf16 ps_bf16x2;
+typedef __attribute__((ext_vector_type(2))) float ps_f32x2;
+typedef __attribute__((ext_vector_type(4))) unsigned ps_u32x4;
+typedef __attribute__((ext_vector_type(2))) unsigned ps_u32x2;
+__device__ __forceinline__ unsigned ps_pk_bf16(float a, float b) {
+    ps_f32x2 v = {a, b};
+    return __builtin_bit_cast(unsigned, __builtin_convertvector(v, ps_bf16x2));      // v_cvt_pk_bf16_f32 (round to nearest even)
+}
+// (x0, x1) -> three packed bf16 pairs (low half = x0) with x = p1 + p2 + p3 exactly
+__device__ __forceinline__ void ps_split_pair(float x0, float x1, unsigned& p1, unsigned& p2, unsigned& p3) {
+    p1 = ps_pk_bf16(x0, x1);
+    x0 -= __uint_as_float(p1 << 16); x1 -= __uint_as_float(p1 & 0xffff0000u);
+    p2 = ps_pk_bf16(x0, x1);
+    x0 -= __uint_as_float(p2 << 16); x1 -= __uint_as_float(p2 & 0xffff0000u);
+    p3 = ps_pk_bf16(x0, x1);
+}
+// N8 consecutive k-slots of one lane (N8 = 1: 8 slots -> one 16x16x32 operand; the 4-slot form serves Hs = 256) as three bf16 planes
+template <int NK> struct PsPlanes { unsigned p[3][NK / 2]; };      // NK = 8 or 4 k-slots
+template <int NK>
+__device__ __forceinline__ PsPlanes<NK> ps_split(const float (&v)[NK]) {
+    PsPlanes<NK> o;
+#pragma unroll
+    for (int i = 0; i < NK / 2; ++i) ps_split_pair(v[2 * i], v[2 * i + 1], o.p[0][i], o.p[1][i], o.p[2][i]);
+    return o;
+}
+__device__ __forceinline__ f32x4 ps_mfma(const unsigned (&a)[4], const unsigned (&b)[4], f32x4 c) {
+    ps_u32x4 av = {a[0], a[1], a[2], a[3]}, bv = {b[0], b[1], b[2], b[3]};
+    return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(ps_bf16x8, av), __builtin_bit_cast(ps_bf16x8, bv), c, 0, 0, 0);
+}
+__device__ __forceinline__ f32x4 ps_mfma(const unsigned (&a)[2], const unsigned (&b)[2], f32x4 c) {
+    ps_u32x2 av = {a[0], a[1]}, bv = {b[0], b[1]};
+    return __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(__builtin_bit_cast(__attribute__((ext_vector_type(4))) short, av),
+                                                     __builtin_bit_cast(__attribute__((ext_vector_type(4))) short, bv), c, 0, 0, 0);
+}
+// c += A . B for one lane-set of k-slots: six partial products, smallest terms first
+template <int NK>
+__device__ __forceinline__ f32x4 ps_mfma6(const PsPlanes<NK>& a, const PsPlanes<NK>& b, f32x4 c) {
+    c = ps_mfma(a.p[1], b.p[1], c);
+    c = ps_mfma(a.p[1], b.p[0], c);
+    c = ps_mfma(a.p[0], b.p[1], c);
+    c = ps_mfma(a.p[2], b.p[0], c);
+    c = ps_mfma(a.p[0], b.p[2], c);
+    c = ps_mfma(a.p[0], b.p[0], c);
+    return c;
 }
 
 // Reductions with DPP row operations (1 VALU instruction per level) instead of __shfl_xor (a ds_bpermute, i.e. an LDS

@@ -46,7 +46,9 @@ struct PersistArgs {
     const float* w_c; const float* b_c;   // (V, 2Hs), (V)
     float* logp; int* argmax_out;          // (U,B,V), (U,B) or null
     float* lgx;                            // [U][B][split][32] partial logits of the attention workgroups, sentinel-prefilled
-    const float* pctx; float* gx;          // PRE variant: feat . W_ctx^T (B*Tp, 4Hs) and its per-step weighted sums [U][B][4Hs] (sentinel-prefilled)
+    const float* pctx; float* gx;          // PRE variant: feat . W_ctx^T (B*Tp, 4Hs) and its per-step weighted sums [U][B][4Hs] (stash for the backward)
+    float* r0x;                            // PRE variant: layer-0 gates minus the context half, [U][Hs/4][32][16] (cell -> attention, sentinel-prefilled)
+    const float* yw;                       // PRE variant: y_s W_y^T + b_ih0 + b_hh0 for every step, (U*B, 4Hs), columns in unit*4 + gate order
     int B, Tp, U, relu;
     int split;                     // attention workgroups per utterance (each owns D/split context columns)
     unsigned* err;
@@ -60,7 +62,7 @@ struct PersistArgs {
 // the attention workgroups publish sum_t a_t (W_ctx feat_t) from a register-resident slice of feat . W_ctx^T — so layer 0 is
 // off the MFMA chain: its recurrent / label halves are reduced ahead of time and the cell lanes only add 16 bytes per
 // (utterance, unit) that they poll themselves.
-template <int HS, bool GREEDY, bool PRE = false>
+template <int HS, bool GREEDY>
 struct CellRole {
     static constexpr int NF = HS / 256;                 // 16-wide k-blocks of an Hs-wide operand per wave
     static constexpr int RLD = 20;                      // row stride of a partial tile: 16 columns + pad, 16-byte aligned
@@ -89,13 +91,14 @@ struct CellRole {
     static __device__ __forceinline__ TileAddr tile_addr(int B, int split, int wave, int lane) {
         TileAddr t;
         const int r = lane & 15, kq = lane >> 4;
+        const int kwave = wave;
 #pragma unroll
         for (int mt = 0; mt < 2; ++mt) {
             t.ok[mt] = mt * 16 + r < B;
 #pragma unroll
             for (int f = 0; f < NF; ++f) {
-                t.x[f][mt] = 4u * ((t.ok[mt] ? mt * 16 + r : 0) * HS + (wave * NF + f) * 16 + kq * 4);
-                t.hx[f][mt] = 4u * ((((wave * NF + f) * 4 + kq) * 32 + (t.ok[mt] ? mt * 16 + r : 0)) * 4);
+                t.x[f][mt] = 4u * ((t.ok[mt] ? mt * 16 + r : 0) * HS + (kwave * NF + f) * 16 + kq * 4);
+                t.hx[f][mt] = 4u * ((((kwave * NF + f) * 4 + kq) * 32 + (t.ok[mt] ? mt * 16 + r : 0)) * 4);
             }
         }
         {
@@ -113,9 +116,9 @@ struct CellRole {
     }
     // acc += tile * W.  The product is started speculatively as the tile's loads land (load and MFMA time overlap); the
     // sentinel check comes afterwards and a tile that was not complete is repaired and multiplied again.
-    template <int KIND>
+    template <int KIND, class WT>
     static __device__ __forceinline__ int poll_mul(const float* base, const TileAddr& t, f32x4 (&x)[NF][2],
-                                                   const float (&W)[NF][4], f32x4 (&acc)[2],
+                                                   const WT& W, f32x4 (&acc)[2],
                                                    unsigned* err, volatile unsigned* flags, unsigned& ep) {
         unsigned spins = 0;
         int slow = 0;
@@ -178,6 +181,29 @@ struct CellRole {
 #pragma unroll
                 for (int mt = 0; mt < 2; ++mt)
                     acc[mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(x[f][mt][e], w[f][e], acc[mt], 0, 0, 0);
+    }
+    // the same product on the bf16 matrix pipe (persist_common.h: exact three-way operand split, six partial products): the
+    // lane's 4 NF k-slots of every k-block it owns form ONE 16x16x(16 NF) operand; the weights are split once per launch
+    static constexpr int NK = 4 * NF;
+    using WSplit = PsPlanes<NK>;
+    static __device__ __forceinline__ WSplit split_w(const float (&w)[NF][4]) {
+        float v[NK];
+#pragma unroll
+        for (int f = 0; f < NF; ++f)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[f * 4 + e] = w[f][e];
+        return ps_split<NK>(v);
+    }
+    static __device__ __forceinline__ void mfma_tile(const f32x4 (&x)[NF][2], const WSplit& w, f32x4 (&acc)[2]) {
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt) {
+            float v[NK];
+#pragma unroll
+            for (int f = 0; f < NF; ++f)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[f * 4 + e] = x[f][mt][e];
+            acc[mt] = ps_mfma6<NK>(ps_split<NK>(v), w, acc[mt]);
+        }
     }
 
     static __device__ void run(const PersistArgs& a, float* smem) {
@@ -310,7 +336,7 @@ struct CellRole {
 #pragma unroll
                 for (int i = 0; i < 4; ++i) red[wave][mt][kq * 4 + i][rcol] = acc[mt][i];
             lds_barrier();
-            if (layer == 1) PS_STAMP(1, s, 6); else if (!PRE) PS_STAMP(1, s, 7);       // (cell wg 0) all 16 waves' products are in
+            if (layer == 1) PS_STAMP(1, s, 6); else PS_STAMP(1, s, 7);       // (cell wg 0) all 16 waves' products are in
             f32x4 g4 = {0.f, 0.f, 0.f, 0.f};
             if (pw) {
 #pragma unroll
@@ -344,11 +370,13 @@ struct CellRole {
                 c = fg * c + ig * gg;
                 const float h = og * tanhf_acc(c);
                 const size_t slab = ((size_t)layer * U + s) * sH;           // wave-uniform
-                const unsigned o = opaque(4u * ((unsigned)pb * HS + j0 + pu));
-                st1_agent(at_bytes(a.hx + ((size_t)layer * U + s) * HXS, opaque(4u * (((unsigned)blockIdx.x * 32 + pb) * 4 + pu))), h);
+                // lane offsets re-derived from the thread id in every step: as loop invariants they would be kept live (and spilled)
+                const unsigned tq = opaque((unsigned)tid), pbq = tq >> 2, puq = tq & 3;
+                const unsigned o = 4u * (pbq * HS + j0 + puq);
+                st1_agent(at_bytes(a.hx + ((size_t)layer * U + s) * HXS, 4u * (((unsigned)blockIdx.x * 32 + pbq) * 4 + puq)), h);
                 *at_bytes(a.h_all + slab, o) = h;
                 *at_bytes(a.c_all + slab, o) = c;
-                float* go = at_bytes(a.gates_all + 4 * slab, opaque(4u * ((unsigned)pb * 4 * HS + j0 + pu)));
+                float* go = at_bytes(a.gates_all + 4 * slab, 4u * (pbq * 4 * HS + j0 + puq));
                 go[0] = ig; go[HS] = fg; go[2 * HS] = gg; go[3 * HS] = og;
             }
         };
@@ -370,54 +398,6 @@ struct CellRole {
         if (tid < 4) cflags[tid] = 0u;
         lds_barrier();
         int nslow[3] = {0, 0, 0};       // slow-path rounds per tile kind (reported through the trace buffer)
-        if (PRE) {
-            // layer 0's gates minus the context half, reduced ahead of the chain (cell lanes' registers)
-            f32x4 g0 = reduce_gates(accR0, 0, 0);
-            const unsigned gcol = 4u * (unsigned)(blockIdx.x * 16 + pu * 4);          // byte offset of this lane's four gates in a 4Hs row
-            for (int s = 0; s < U; ++s) {
-                f32x4 ynext[1][2];
-                if (s + 1 < U) load_y(s + 1, ynext);
-                PS_STAMP(0, s, 0);
-                // layer 0: + sum_t a_t (W_ctx feat_t) of step s-1 (step 0: the first frame, las_model.py:198), polled by the cell lanes
-                if (wave < 2) {
-                    f32x4 v;
-                    if (s == 0) {
-                        v = ld4p(at_bytes(a.pctx, opaque(4u * (unsigned)((pw ? pb : 0) * a.Tp) * (4 * HS) + gcol)));
-                    } else {
-                        const float* src = at_bytes(a.gx + (size_t)(s - 1) * B * (4 * HS), opaque(4u * (unsigned)(pw ? pb : 0) * (4 * HS) + gcol));
-                        unsigned spins = 0;
-                        for (;;) {
-                            v = ld4_agent(src);
-                            if (!__any(pw && has_sentinel(v))) break;
-                            if (spin_expired(spins, a.err, 0xDEAD0015u)) break;
-                        }
-                    }
-                    g0[0] += v[0]; g0[1] += v[1]; g0[2] += v[2]; g0[3] += v[3];
-                }
-                PS_STAMP(0, s, 1);
-                cell(g0, c0, 0, s);
-                PS_STAMP(0, s, 2);
-                // layer 1: gates = W_ih1 h0_s + W_hh1 h1_{s-1}
-                nslow[0] += poll_mul<0>(a.hx + (size_t)s * HXS, ta, x, Wi1, accR1, a.err, cflags, cep);
-                PS_STAMP(0, s, 4);
-                finish(accR1, c1, 1, s);
-                PS_STAMP(0, s, 5);
-                if (s + 1 == U) break;
-                // off the chain: next step's layer-0 gates without the context half ...
-                accR0[0] = accR0[1] = zero;
-                mfma_tile(x, Wh0, accR0);                              // the h0_s tile is still in registers
-                if (ywave) CellRole<256, GREEDY>::mfma_tile(ynext, Wy, accR0);
-                g0 = reduce_gates(accR0, 0, s);
-                PS_STAMP(0, s, 6);
-                // ... and layer 1's recurrent half
-                accR1[0] = accR1[1] = zero;
-                nslow[2] += poll_mul<0>(a.hx + ((size_t)U + s) * HXS, ta, x, Wh1, accR1, a.err, cflags, cep);
-                PS_STAMP(0, s, 7);
-            }
-            if (a.trace && first_wg && tid == 0)
-                for (int k = 0; k < 3; ++k) a.trace[((size_t)a.U + k) * 8 + 7] = (unsigned long long)nslow[k];
-            return;
-        }
         for (int s = 0; s < U; ++s) {
             // next step's labels: issued now, consumed after layer 1 (plain load, its latency is off the chain)
             f32x4 ynext[1][2];
@@ -454,6 +434,208 @@ struct CellRole {
             collect_logits(U - 1);
             lds_barrier();
             choose_next(U - 1);
+        }
+        if (a.trace && first_wg && tid == 0)
+            for (int k = 0; k < 3; ++k) a.trace[((size_t)a.U + k) * 8 + 7] = (unsigned long long)nslow[k];
+    }
+};
+
+// ------------------------------------------------------------------------------------------------ cell workgroups, PRE variant
+// Teacher forcing with the pre-multiplied context (AttnPreRole below): the attention workgroups own the BOTTOM cell, this role runs
+// the TOP cell and prepares what the bottom cell needs besides the context term,
+//     R0_s = W_hh0 h0_{s-1} + W_y y_s + b_ih0 + b_hh0            (the "recurrent / label / bias part" of the bottom-layer gates),
+// published per workgroup as a tile [32 utterances][4 units x 4 gates] (whole 128-byte lines) a whole attention phase ahead of its
+// use.  Chain per decode step:  attention + bottom cell -> h0_s slab -> W_ih1 product, reduce, top cell -> h1_s : TWO cross-CU hops
+// (three when the bottom cell lived here and waited for the published context term).
+//   * the three resident matrices (W_ih1, W_hh1, W_hh0 rows of this workgroup's 4 units) are split ONCE into bf16 planes and every
+//     product runs on the bf16 matrix pipe (persist_common.h: exact three-way split, six partial products, fp32 accumulation): a
+//     SIMD's four waves spend 0.3 us instead of 0.85 us of matrix-pipe time per product;
+//   * the label half W_y y_s is a 32-wide dot product per (utterance, gate row) from LDS (W_y rows and the step's label rows),
+//     computed by the R0 lanes — no MFMA, no resident operand;
+//   * one LDS exchange per step serves both layers: every wave drops its partial tiles of the top layer's gates and of the next
+//     step's R0 (same h0_s tile, still in registers), ONE barrier, then waves 0-1 reduce / apply / publish the top cell while
+//     waves 2-3 reduce and publish R0.
+template <int HS>
+struct CellPreRole {
+    using Base = CellRole<HS, false>;
+    static constexpr int NF = Base::NF, RLD = Base::RLD, RED = Base::RED;
+    static constexpr int NK = Base::NK;
+    // ONE reduction buffer (both layers take turns), biases, canary flags, W_y rows, label rows (2 steps), label halves (2 steps), and
+    // the bf16 planes of W_hh0 and W_hh1: their products are off the chain, and three resident split matrices do not fit the
+    // 128 registers a lane has at 1024 threads — only W_ih1, whose product IS the chain, stays in registers
+    static constexpr int WPL = 3 * (NK / 2) * PS_THREADS;      // dwords of one matrix' bf16 planes
+    static constexpr int LDS_FLOATS = RED + 4 * 128 + 4 + 2 * 128 * 4 + 2 * WPL + 32;      // (+32: per-wave stamps of a PS_WAVE_TRACE build)
+    using TileAddr = typename Base::TileAddr;
+    using WSplit = typename Base::WSplit;
+
+    static __device__ void run(const PersistArgs& a, float* smem) {
+        const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+        const int r = lane & 15, kq = lane >> 4;
+        const int j0 = blockIdx.x * 4;
+        const bool first_wg = blockIdx.x == 0;
+        const int B = a.B, U = a.U;
+        const long wrow = (long)(r >> 2) * HS + j0 + (r & 3);       // tile column n = gate*4 + unit
+        const int kwave = wave;
+        const size_t sH = (size_t)B * HS;
+        constexpr size_t HXS = (size_t)32 * HS;
+        float* bias = smem + RED;                     // [gate][cell lane]: b_ih1 + b_hh1 (the bottom layer's biases ride in a.yw)
+        volatile unsigned* cflags = reinterpret_cast<volatile unsigned*>(smem + RED + 4 * 128);
+        float* ywl = smem + RED + 4 * 128 + 4;        // [step parity][R0 lane][4 gates]: label half + bias of the bottom-layer gates
+        unsigned* wl = reinterpret_cast<unsigned*>(ywl + 2 * 128 * 4);     // [matrix: W_hh0, W_hh1][plane][thread][NK / 2]
+
+        // ---- weights, split once: W[wrow][16*blk + 4*kq + e]
+        WSplit Si1;
+        {
+            float wi1[NF][4], wh0[NF][4], wh1[NF][4];
+#pragma unroll
+            for (int f = 0; f < NF; ++f) {
+                const int k = (kwave * NF + f) * 16 + kq * 4;
+                const f32x4 h0 = ld4p(a.w_hh0 + wrow * HS + k), i1 = ld4p(a.w_ih1 + wrow * HS + k), h1 = ld4p(a.w_hh1 + wrow * HS + k);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) { wh0[f][e] = h0[e]; wi1[f][e] = i1[e]; wh1[f][e] = h1[e]; }
+            }
+            Si1 = Base::split_w(wi1);
+            const WSplit S0 = Base::split_w(wh0), S1 = Base::split_w(wh1);
+#pragma unroll
+            for (int pl = 0; pl < 3; ++pl)
+#pragma unroll
+                for (int i = 0; i < NK / 2; ++i) {
+                    wl[(pl * PS_THREADS + tid) * (NK / 2) + i] = S0.p[pl][i];
+                    wl[WPL + (pl * PS_THREADS + tid) * (NK / 2) + i] = S1.p[pl][i];
+                }
+        }
+        auto load_w = [&](int m) {           // m = 0: W_hh0, 1: W_hh1
+            WSplit w;
+            const unsigned* src = at_bytes(wl + m * WPL, opaque(4u * (unsigned)tid * (NK / 2)));      // opaque: re-read per step, not kept in registers
+#pragma unroll
+            for (int pl = 0; pl < 3; ++pl)
+#pragma unroll
+                for (int i = 0; i < NK / 2; ++i) w.p[pl][i] = src[pl * PS_THREADS * (NK / 2) + i];
+            return w;
+        };
+        if (tid < 128) {
+            const int pu = tid & 3;
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const int row = g * HS + j0 + pu;
+                bias[g * 128 + tid] = a.b_ih1[row] + a.b_hh1[row];
+            }
+        }
+        const int rcol = (r & 3) * 4 + (r >> 2);        // tile column (gate*4 + unit) stored as unit*4 + gate
+        auto write_red = [&](const f32x4 (&acc)[2]) {
+            float (*red)[2][16][RLD] = reinterpret_cast<float (*)[2][16][RLD]>(smem);
+#pragma unroll
+            for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+                for (int i = 0; i < 4; ++i) red[wave][mt][kq * 4 + i][rcol] = acc[mt][i];
+        };
+        // reduced gates of cell lane lt = (utterance lt / 4, unit lt % 4)
+        auto read_red = [&](unsigned lt) -> f32x4 {
+            float (*red)[2][16][RLD] = reinterpret_cast<float (*)[2][16][RLD]>(smem);
+            const unsigned lb = lt >> 2, lu = lt & 3;
+            f32x4 g4 = {0.f, 0.f, 0.f, 0.f};
+            // four partial tiles in flight at a time: all sixteen at once (what the scheduler prefers) cost 64 registers and spill
+#pragma unroll
+            for (int w0 = 0; w0 < PS_NW; w0 += 4) {
+#pragma unroll
+                for (int w = w0; w < w0 + 4; ++w) {
+                    const f32x4 v = *reinterpret_cast<const f32x4*>(&red[w][(lb >> 4) & 1][lb & 15][lu * 4]);
+                    g4[0] += v[0]; g4[1] += v[1]; g4[2] += v[2]; g4[3] += v[3];
+                }
+            }
+            return g4;
+        };
+        // waves 2-3 (R0 lane t = (utterance, unit)): label half + bias of step s (a.yw = y_s W_y^T + b_ih0 + b_hh0 for every step, one
+        // GEMM before the launch, columns in this role's unit*4 + gate order) -> LDS, a step ahead of its use (off the chain)
+        auto label_half = [&](int s) {
+            const unsigned t = opaque((unsigned)tid) - 128u;
+            if (t < 128u && (int)(t >> 2) < B)
+                *reinterpret_cast<f32x4*>(ywl + ((s & 1) * 128 + t) * 4) =
+                    ld4p(at_bytes(a.yw + (size_t)s * B * (4 * HS), 4u * ((t >> 2) * (4 * HS) + (unsigned)blockIdx.x * 16 + (t & 3) * 4)));
+        };
+        // R0 of step s from waves 2-3: reduced recurrent half (not at step 0: h0_{-1} = 0) + the label half prepared in LDS
+        auto publish_r0 = [&](int s, bool with_red) {
+            const unsigned t = opaque((unsigned)tid) - 128u;
+            if (t < 128u && (int)(t >> 2) < B) {
+                f32x4 g4 = *reinterpret_cast<const f32x4*>(ywl + ((s & 1) * 128 + t) * 4);
+                if (with_red) {
+                    const f32x4 v = read_red(t);
+                    g4[0] += v[0]; g4[1] += v[1]; g4[2] += v[2]; g4[3] += v[3];
+                }
+                st4_agent(at_bytes(a.r0x + (size_t)s * ((size_t)(HS / 4) * 32 * 16), 4u * (((unsigned)blockIdx.x * 128 + t) * 4)), g4);
+            }
+        };
+        // top cell of lane tid < 128: apply, publish h1_s (tiled hand-off copy), stash
+        float c1 = 0.f;
+        auto top_cell = [&](f32x4 g4, int s) {
+            const unsigned tq = opaque((unsigned)tid), pbq = tq >> 2, puq = tq & 3;
+            if ((int)pbq < B) {
+#pragma unroll
+                for (int g = 0; g < 4; ++g) g4[g] += bias[g * 128 + tq];
+                const float ig = sigmoidf_acc(g4[0]), fg = sigmoidf_acc(g4[1]), gg = tanhf_acc(g4[2]), og = sigmoidf_acc(g4[3]);
+                c1 = fg * c1 + ig * gg;
+                const float h = og * tanhf_acc(c1);
+                const size_t slab = ((size_t)U + s) * sH;
+                const unsigned o = 4u * (pbq * HS + j0 + puq);
+                st1_agent(at_bytes(a.hx + ((size_t)U + s) * HXS, 4u * (((unsigned)blockIdx.x * 32 + pbq) * 4 + puq)), h);
+                *at_bytes(a.h_all + slab, o) = h;
+                *at_bytes(a.c_all + slab, o) = c1;
+                float* go = at_bytes(a.gates_all + 4 * slab, 4u * (pbq * 4 * HS + j0 + puq));
+                go[0] = ig; go[HS] = fg; go[2 * HS] = gg; go[3 * HS] = og;
+            }
+        };
+
+        const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
+        f32x4 accR0[2], accR1[2];
+        accR1[0] = accR1[1] = zero;
+        f32x4 x[NF][2];
+        const TileAddr ta = Base::tile_addr(B, a.split, wave, lane);
+        unsigned cep = 0;
+        if (tid < 4) cflags[tid] = 0u;
+        label_half(0);
+        if (U > 1) label_half(1);
+        lds_barrier();
+        publish_r0(0, false);
+        int nslow[3] = {0, 0, 0};
+        for (int s = 0; s < U; ++s) {
+            const bool more = s + 1 < U;
+            PS_STAMP(0, s, 0);
+            // top layer: gates = W_ih1 h0_s + W_hh1 h1_{s-1}; h0_s arrives from the attention workgroups as a row-major (B, Hs) slab
+            nslow[0] += Base::template poll_mul<1>(a.hx + (size_t)s * HXS, ta, x, Si1, accR1, a.err, cflags, cep);
+            PS_STAMP(0, s, 4);
+#ifdef PS_WAVE_TRACE
+            if (a.trace && first_wg && lane == 0) reinterpret_cast<unsigned long long*>(smem + LDS_FLOATS - 32)[wave] = wall_clock64();
+#endif
+            write_red(accR1);
+            lds_barrier();
+            PS_STAMP(1, s, 6);
+#ifdef PS_WAVE_TRACE
+            if (a.trace && first_wg && tid == 0) {
+                const unsigned long long* wt = reinterpret_cast<const unsigned long long*>(smem + LDS_FLOATS - 32);
+                unsigned long long mx = 0; int mi = 0;
+                for (int w = 0; w < PS_NW; ++w) if (wt[w] > mx) { mx = wt[w]; mi = w; }
+                a.trace[((size_t)0 * a.U + s) * 8 + 1] = mx;
+                a.trace[((size_t)0 * a.U + s) * 8 + 2] = (unsigned long long)mi;
+                a.trace[((size_t)0 * a.U + s) * 8 + 3] = wt[1];
+            }
+#endif
+            if (tid < 128) top_cell(read_red(opaque((unsigned)tid)), s);
+            PS_STAMP(0, s, 5);
+            if (!more) break;
+            // ---- off the chain (the attention workgroups are working now)
+            // next step's bottom-layer gates without the context half, from the h0_s tile still in registers
+            accR0[0] = accR0[1] = zero;
+            Base::mfma_tile(x, load_w(0), accR0);
+            lds_barrier();                       // the top-cell lanes have left the reduction buffer
+            write_red(accR0);
+            lds_barrier();
+            publish_r0(s + 1, true);
+            if (s + 2 < U) label_half(s + 2);
+            PS_STAMP(0, s, 6);
+            // the top layer's recurrent half
+            accR1[0] = accR1[1] = zero;
+            nslow[2] += Base::template poll_mul<0>(a.hx + ((size_t)U + s) * HXS, ta, x, load_w(1), accR1, a.err, cflags, cep);
+            PS_STAMP(0, s, 7);
         }
         if (a.trace && first_wg && tid == 0)
             for (int k = 0; k < 3; ++k) a.trace[((size_t)a.U + k) * 8 + 7] = (unsigned long long)nslow[k];
@@ -658,7 +840,8 @@ struct AttnPreRole {
     static constexpr int EP = (MAX_TP + 63) & ~63;       // energies padded to whole waves (pad = -inf)
     static constexpr int NJ = HS / 64;
     static_assert(TS == 8 || TS == 16 || TS == 32, "time-slice layout");
-    static __host__ __device__ constexpr int lds_floats(int Tp) { return HS + PS_M + EP + MAX_TP + GC + Tp * PS_KLD; }
+    static constexpr int NJR = NJ / 2;                   // float4 of a W_phi row slice kept in registers; the other half lives in LDS
+    static __host__ __device__ constexpr int lds_floats(int Tp) { return HS + PS_M + EP + MAX_TP + 2 * GC + Tp * PS_KLD + PS_M * (HS / 2); }
 
     static __device__ void run(const PersistArgs& a, float* smem, const int widx) {
         const int b = widx / SPLIT, part_id = widx % SPLIT;
@@ -671,7 +854,8 @@ struct AttnPreRole {
         float* es = qs + PS_M;
         float* as = es + EP;
         float* gxl = as + MAX_TP;
-        float* ks = gxl + GC;
+        float* r0l = gxl + GC;                   // R0 of the step in flight: 4 gates x this workgroup's CG units
+        float* ks = r0l + GC;
 
         // ---- resident operands
         const int ts = tid % TS, cg = tid / TS;
@@ -690,11 +874,79 @@ struct AttnPreRole {
             *reinterpret_cast<f32x4*>(ks + t * PS_KLD + m4 * 4) = ld4p(a.keys + ((size_t)b * Tp + t) * PS_M + m4 * 4);
         }
         const int prow = tid >> 4, pk = tid & 15;         // phi: 64 rows x 16 lanes
-        f32x4 wphi[NJ];
+        // W_phi row prow, columns 4 (pk + 16 j): j < NJR in registers, the rest in LDS ([row][HS / 2], a wave's 16-lane row groups read
+        // 256 contiguous bytes each: conflict-free b128 reads) — the P rows and the query weights together do not fit 128 registers
+        f32x4 wphi[NJR];
+        float* wpl = ks + Tp * PS_KLD;
 #pragma unroll
-        for (int j = 0; j < NJ; ++j) wphi[j] = ld4p(a.w_phi + (size_t)prow * HS + 4 * (pk + 16 * j));
+        for (int j = 0; j < NJR; ++j) wphi[j] = ld4p(a.w_phi + (size_t)prow * HS + 4 * (pk + 16 * j));
+#pragma unroll
+        for (int j = NJR; j < NJ; ++j)
+            *reinterpret_cast<f32x4*>(wpl + prow * (HS / 2) + 4 * (pk + 16 * (j - NJR))) = ld4p(a.w_phi + (size_t)prow * HS + 4 * (pk + 16 * j));
         const float bphi = a.b_phi[prow];
         lds_barrier();
+
+        // ---- the bottom LSTM cell of this workgroup's CG hidden units, one per lane of the first CG/64 waves, state in a register:
+        //      gates_s = sum_t a_{s-1,t} P_t (reduced by the ts == 0 lanes, handed over through LDS) + R0_s (the cell workgroups'
+        //      recurrent / label / bias part, fetched while the attention of step s-1 is computed)
+        const bool clane = ts == 0;
+        const size_t sH = (size_t)B * HS;
+        constexpr size_t HXS = (size_t)32 * HS, R0S = (size_t)(HS / 4) * 32 * 16;
+        float c0 = 0.f;
+        // R0_s is published ~0.7 us after h1_{s-1}: waves 2.. issue its loads once the query is done (four agent-scope dword loads
+        // the compiler schedules itself: their latency hides under the energies / softmax / weighted sum) and hand it to the bottom
+        // cell's lanes through LDS; a slot that was not complete yet is re-polled when it is consumed
+        const bool rlane = tid >= HS / 4 && tid < HS / 4 + CG;
+        auto r0_src = [&](int s) {
+            const int u = part_id * CG + (rlane ? tid - HS / 4 : 0);
+            return at_bytes(a.r0x + (size_t)s * R0S, opaque(4u * ((((unsigned)(u >> 2) * 32 + b) * 4 + (u & 3)) * 4)));
+        };
+        auto r0_issue = [&](int s, unsigned (&rv)[4]) {
+            const unsigned* src = reinterpret_cast<const unsigned*>(r0_src(s));
+#pragma unroll
+            for (int k = 0; k < 4; ++k) rv[k] = rlane ? __hip_atomic_load(src + k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0u;
+        };
+        auto r0_land = [&](int s, const unsigned (&rv)[4]) {
+            if (tid >= HS / 4 && tid < HS / 4 + CG) {       // whole waves
+                f32x4 v;
+#pragma unroll
+                for (int k = 0; k < 4; ++k) v[k] = __uint_as_float(rv[k]);
+                if (__any(has_sentinel(v))) {
+                    const float* src = r0_src(s);
+                    unsigned spins = 0;
+                    for (;;) {
+                        v = ld4_agent(src);
+                        if (!__any(has_sentinel(v))) break;
+                        if (spin_expired(spins, a.err, 0xDEAD0015u)) break;
+                    }
+                }
+                *reinterpret_cast<f32x4*>(r0l + (tid - HS / 4) * 4) = v;
+            }
+        };
+        // after the barrier that follows the ts == 0 lanes' LDS hand-over of the reduced sums (gxl): apply the cell, publish h0_s
+        auto bottom_cell = [&](int s) {
+            if (tid >= CG) return;                               // whole waves (CG is a multiple of 64)
+            const int unit = part_id * CG + tid;                 // hidden unit; its four gates are columns col0 + 4 tid .. + 3
+            const f32x4 g4 = *reinterpret_cast<const f32x4*>(gxl + tid * 4);
+            const f32x4 r = *reinterpret_cast<const f32x4*>(r0l + tid * 4);
+            const float ig = sigmoidf_acc(g4[0] + r[0]), fg = sigmoidf_acc(g4[1] + r[1]), gg = tanhf_acc(g4[2] + r[2]), og = sigmoidf_acc(g4[3] + r[3]);
+            c0 = fg * c0 + ig * gg;
+            const float h = og * tanhf_acc(c0);
+            const unsigned o = opaque(4u * ((unsigned)b * HS + unit));
+            st1_agent(at_bytes(a.hx + (size_t)s * HXS, o), h);       // hand-off to the cell workgroups: a wave writes 256 contiguous bytes
+            *at_bytes(a.h_all + (size_t)s * sH, o) = h;              // stash for the backward pass
+            *at_bytes(a.c_all + (size_t)s * sH, o) = c0;
+            float* go = at_bytes(a.gates_all + 4 * (size_t)s * sH, opaque(4u * ((unsigned)b * 4 * HS + unit)));
+            go[0] = ig; go[HS] = fg; go[2 * HS] = gg; go[3 * HS] = og;
+        };
+        {   // step 0: the context is the first listener frame (las_model.py:198): W_ctx feat_0 = P row 0 = pr[0] of the ts == 0 lanes
+            unsigned rv0[4];
+            r0_issue(0, rv0);
+            r0_land(0, rv0);
+            if (clane) *reinterpret_cast<f32x4*>(gxl + cg * 4) = pr[0];
+            lds_barrier();
+            bottom_cell(0);
+        }
 
         for (int s = 0; s < U; ++s) {
             PS_STAMP(1, s, 0);
@@ -716,7 +968,13 @@ struct AttnPreRole {
             {
                 float acc = 0.f;
 #pragma unroll
-                for (int j = 0; j < NJ; ++j) acc = dot4p(wphi[j], *reinterpret_cast<const f32x4*>(hs + 4 * (pk + 16 * j)), acc);
+                for (int j = 0; j < NJR; ++j) acc = dot4p(wphi[j], *reinterpret_cast<const f32x4*>(hs + 4 * (pk + 16 * j)), acc);
+                {
+                    const float* wr = at_bytes(wpl, opaque(4u * (unsigned)(prow * (HS / 2) + 4 * pk)));
+#pragma unroll
+                    for (int j = NJR; j < NJ; ++j)
+                        acc = dot4p(*reinterpret_cast<const f32x4*>(wr + 64 * (j - NJR)), *reinterpret_cast<const f32x4*>(hs + 4 * (pk + 16 * j)), acc);
+                }
                 acc = gsum<16>(acc);
                 if (pk == 0) {
                     acc += bphi;
@@ -727,6 +985,8 @@ struct AttnPreRole {
             }
             lds_barrier();
             PS_STAMP(1, s, 2);
+            unsigned rv[4];
+            if (s + 1 < U) r0_issue(s + 1, rv);
             // ---- energies e[t] = q . keys[t]: 8 lanes per frame
             {
                 const int sub = tid & 7;
@@ -776,14 +1036,19 @@ struct AttnPreRole {
                         acc[k] = lane < 32 ? lo : hi;
                     }
                 }
+                // stash for the backward pass (its softmax-backward statistic reuses this sum): off the chain, plain stores
                 float* dst = a.gx + ((size_t)s * B + b) * (4 * HS) + col0;
-                if (TS == 8) {               // the 8 column groups of a wave are one whole 128-byte line
-                    if (ts == 0) st4_agent(at_bytes(dst, opaque(16u * (unsigned)cg)), acc);
-                } else {                     // gather through LDS so that the publication still moves whole lines
-                    if (ts == 0) *reinterpret_cast<f32x4*>(gxl + cg * 4) = acc;
-                    lds_barrier();
-                    if (tid < CG) st4_agent(at_bytes(dst, opaque(16u * (unsigned)tid)), *reinterpret_cast<const f32x4*>(gxl + tid * 4));
+                if (clane) {
+                    *reinterpret_cast<f32x4*>(at_bytes(dst, opaque(16u * (unsigned)cg))) = acc;
+                    *reinterpret_cast<f32x4*>(gxl + cg * 4) = acc;
                 }
+            }
+            // ---- bottom cell of step s+1 and its hand-off to the top layer
+            if (s + 1 < U) {
+                r0_land(s + 1, rv);
+                lds_barrier();
+                PS_STAMP(2, s + 1, 0);
+                bottom_cell(s + 1);
             }
             PS_STAMP(1, s, 5);
         }
@@ -794,7 +1059,7 @@ template <int HS, int WS>
 __global__ __launch_bounds__(PS_THREADS) void speller_persist_fwd_pre_kernel(PersistArgs a) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     constexpr int NC = HS / 4;
-    if ((int)blockIdx.x < NC) CellRole<HS, false, true>::run(a, smem);
+    if ((int)blockIdx.x < NC) CellPreRole<HS>::run(a, smem);
     else AttnPreRole<HS, WS>::run(a, smem, blockIdx.x - NC);
 }
 
@@ -854,12 +1119,12 @@ int speller_persist_pre_ws(int B, int Tp, int Hs, int cus) {
 bool speller_persist_pre_shape(int B, int Tp, int Hs, int D, int M, int V, int L, int heads, int use_mlp) {
     if (L != 2 || heads != 1 || !use_mlp || M != PS_M || D != Hs) return false;
     if (Hs != 256 && Hs != 512) return false;
-    if (B < 1 || B > 32 || ((V + 15) & ~15) > 256) return false;
+    if (B < 1 || B > 32 || ((V + 15) & ~15) > 32) return false;      // the label half is a 32-wide dot product from LDS
     return speller_persist_pre_ws(B, Tp, Hs, -1) != 0;
 }
 template <int HS, int WS>
 static size_t persist_fwd_pre_smem(int Tp) {
-    return sizeof(float) * (size_t)std::max(CellRole<HS, false, true>::LDS_FLOATS, AttnPreRole<HS, WS>::lds_floats(Tp));
+    return sizeof(float) * (size_t)std::max(CellPreRole<HS>::LDS_FLOATS, AttnPreRole<HS, WS>::lds_floats(Tp));
 }
 template <int HS, int WS>
 static bool persist_fwd_pre_fits(int Tp, int grid) {
@@ -936,20 +1201,22 @@ int speller_persist_fwd(const PersistFwd& p, hipStream_t stream) {
     a.B = p.B; a.Tp = p.Tp; a.U = p.U; a.relu = p.relu; a.err = p.err;
     a.split = persist_split(p.B, p.Tp, p.Hs, p.V, p.mode != 0);
     a.trace = g_persist_trace;
-    a.pctx = p.pctx; a.gx = p.gx;
+    a.pctx = p.pctx; a.gx = p.gx; a.r0x = p.r0x; a.yw = p.yw;
     LAS_REQUIRE(p.err != nullptr, "the persistent speller needs the device error word");
     if (p.pctx) {      // pre-multiplied context variant (the caller checked speller_persist_pre_eligible)
         int cus = 0, dev = 0;
         LAS_HIP_CHECK(hipGetDevice(&dev));
         LAS_HIP_CHECK(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
         const int ws = speller_persist_pre_ws(p.B, p.Tp, p.Hs, cus);
-        LAS_REQUIRE(p.mode == 0 && p.gx && ws != 0 && speller_persist_pre_shape(p.B, p.Tp, p.Hs, p.Hs, PS_M, p.V, 2, 1, 1), "persistent speller (pre) shape");
+        LAS_REQUIRE(p.mode == 0 && p.gx && p.r0x && p.yw && ws != 0 && speller_persist_pre_shape(p.B, p.Tp, p.Hs, p.Hs, PS_M, p.V, 2, 1, 1), "persistent speller (pre) shape");
         a.split = ws;
-        if (p.gx == p.hx + (size_t)2 * p.U * 32 * p.Hs) {      // adjacent (the layout las_capi.hip uses): one fill
-            LAS_HIP_CHECK(hipMemsetAsync(p.hx, 0xFF, sizeof(float) * ((size_t)2 * p.U * 32 * p.Hs + (size_t)p.U * p.B * 4 * p.Hs), stream));
+        // sentinel-fill what the phases hand over: h0 (row-major slabs, first half of hx), h1 (tiled, second half), R0 tiles
+        const size_t r0_floats = (size_t)p.U * 32 * 4 * p.Hs;
+        if (p.r0x == p.hx + (size_t)2 * p.U * 32 * p.Hs) {      // adjacent (the layout las_capi.hip uses): one fill
+            LAS_HIP_CHECK(hipMemsetAsync(p.hx, 0xFF, sizeof(float) * ((size_t)2 * p.U * 32 * p.Hs + r0_floats), stream));
         } else {
             LAS_HIP_CHECK(hipMemsetAsync(p.hx, 0xFF, sizeof(float) * 2 * p.U * 32 * p.Hs, stream));
-            LAS_HIP_CHECK(hipMemsetAsync(p.gx, 0xFF, sizeof(float) * (size_t)p.U * p.B * 4 * p.Hs, stream));
+            LAS_HIP_CHECK(hipMemsetAsync(p.r0x, 0xFF, sizeof(float) * r0_floats, stream));
         }
         const int grid = p.Hs / 4 + ws * p.B;
         if (p.Hs == 512)

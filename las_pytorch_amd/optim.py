@@ -61,6 +61,8 @@ class FusedClipAdam(torch.optim.Optimizer):
 
     def load_state_dict(self, state_dict):
         super().load_state_dict(state_dict)       # replaces the state tensors by copies: pour them back into the flat buffers
+        for g in self.param_groups:               # a torch.optim.Adam checkpoint has no clip threshold
+            g.setdefault("max_norm", self.defaults["max_norm"])
         off, steps = 0, 0
         for p in self.reducer.params:
             st, n = self.state[p], p.numel()

@@ -382,7 +382,7 @@ def _persistent_vs_stepwise(cfg_name, B, Tp, U, scale, activate):
     L = _cabi.lib()
     L.las_debug_persist_trace.argtypes = [ctypes.c_void_p]
     L.las_debug_persist_trace.restype = None
-    trace = torch.zeros(2 * U * 8, dtype=torch.int64, device="cuda")
+    trace = torch.zeros(3 * U * 8, dtype=torch.int64, device="cuda")      # las_debug_persist_trace: 3 roles x U steps x 8 stamps
     res = []
     for force in (False, True):
         sp.force_generic = force
@@ -466,7 +466,7 @@ def test_persistent_free_running_decode_matches_stepwise(cfg_name, B, Tp, U, dec
     L = _cabi.lib()
     L.las_debug_persist_trace.argtypes = [ctypes.c_void_p]
     L.las_debug_persist_trace.restype = None
-    trace = torch.zeros(2 * U * 8, dtype=torch.int64, device="cuda")
+    trace = torch.zeros(3 * U * 8, dtype=torch.int64, device="cuda")      # las_debug_persist_trace: 3 roles x U steps x 8 stamps
     res = []
     for force in (False, True):
         sp.force_generic = force

@@ -13,7 +13,7 @@ sp = Speller(vocab_size=c["V"], hidden_size=c["Hs"], rnn_unit="LSTM", num_layers
 feat = torch.randn(B, Tp, 2 * c["H"], device="cuda") * 0.3
 idx, lens = synth.make_labels(B, U, c["V"])
 lab = torch.from_numpy(synth.onehot_labels(idx, lens, c["V"])).cuda()
-trace = torch.zeros(2 * U * 8, dtype=torch.int64, device="cuda")
+trace = torch.zeros(3 * U * 8, dtype=torch.int64, device="cuda")
 L = _cabi.lib()
 L.las_debug_persist_trace.argtypes = [ctypes.c_void_p]; L.las_debug_persist_trace.restype = None
 with torch.no_grad():
@@ -22,7 +22,7 @@ with torch.no_grad():
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record(); sp(feat, ground_truth=lab, teacher_force_rate=1.0); e1.record(); torch.cuda.synchronize()
     L.las_debug_persist_trace(None)
-t = trace.cpu().numpy().reshape(2, U, 8).astype(np.float64)
+t = trace.cpu().numpy().reshape(3, U, 8).astype(np.float64)
 span = t[1, U - 1, 5] - t[0, 0, 0]
 mhz = float(os.environ.get("CLK_MHZ", 100.0))
 print(f"forward call {e0.elapsed_time(e1):.3f} ms; decode kernel span {span:.0f} ticks = {span / mhz:.1f} us at {mhz} MHz -> {span / mhz / U:.2f} us/step")
@@ -37,3 +37,14 @@ print("chain:     h1 published(cell stamp5) -> ctx published(attn stamp5): %.2f 
     us(at[:, 5] - cl[:, 5]), us(cl[1:, 1] - at[:-1, 5]), us(cl[1:, 1] - cl[:-1, 1])))
 print("slow-path (agent-scope re-read) rounds of cell wg0 wave0 over %d steps: h0 tiles %d, ctx tiles %d, h1 tiles %d" % (U, t[1, 0, 7], t[1, 1, 7], t[1, 2, 7]))
 print("finish detail (cell wg0): layer1 wait-for-slowest-wave %.2f + cell %.2f" % (us(at[:, 6] - cl[:, 4]), us(cl[:, 5] - at[:, 6])))
+
+if t[2, 1:, 0].any():     # attention workgroups own the bottom cell (round 3): stamps around bottom_cell of step s (fed by step s-1's attention)
+    bx = t[2]
+    print("attn wg0 bottom cell (step s>=1): softmax-end -> weighted sum + LDS + barrier %.2f | cell + publish h0 + stash stores %.2f" % (
+        us(bx[1:, 0] - at[:-1, 4]), us(at[:-1, 5] - bx[1:, 0])))
+    print("chain (2 hops): h1 published -> attn has it %.2f | attention+bottom cell %.2f | h0 published -> top-layer product done %.2f | barrier + reduce + top cell + publish %.2f" % (
+        us(at[1:, 1] - cl[1:, 5]), us(at[:, 5] - at[:, 1]), us(cl[1:, 4] - at[:-1, 5]), us(cl[:, 5] - cl[:, 4])))
+if cl[:, 1].any() and cl[0, 1] > cl[0, 0]:      # -DPS_WAVE_TRACE build: per-wave exit times of the top-layer product (cell wg0)
+    import collections
+    print("wave trace: wave0 done -> slowest wave done %.2f | wave1 done - wave0 done %.2f | slowest wave histogram %s" % (
+        us(cl[:, 1] - cl[:, 4]), us(cl[:, 3] - cl[:, 4]), dict(collections.Counter(cl[:, 2].astype(int).tolist()))))
