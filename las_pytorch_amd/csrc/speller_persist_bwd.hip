@@ -45,6 +45,9 @@ struct PersistBwdArgs {
     // PRE variant (the forward ran speller_persist_fwd_pre_kernel): P = feat . W_ctx^T (B*T', 4Hs, columns unit*4+gate), the
     // forward's published sums gxf[s][b] = sum_t a_t P_t, and e0[s][b][t] = dcat_ctx[s][b] . feat[b][t] (one batched GEMM)
     const float* pctx; const float* gxf; const float* e0;
+    float* dqx;      // [U][B][ns][M]            PRE variant: the frame slices' query-gradient parts, exchanged between the ns attention
+                     //                          workgroups of an utterance (sentinel-prefilled)
+    float* dqpre_all;   // (U*B, M)              PRE variant: the summed parts (what dW_phi needs), written by slice 0
     int B, Tp, U, relu;
     int ns;          // attention-backward workgroups per utterance (each owns ceil(T'/ns) frames)
     unsigned* err;
@@ -70,8 +73,11 @@ struct ProdRole {
         unsigned canary;       // byte offset of the producer dword this lane watches when its wave is the canary wave
         bool cact;             // ... and whether that producer exists
         bool ok;               // its utterance row exists
+        // PRE variant: a dG1 tile is produced by the attention workgroups — (utterance row, unit slice) — not by one workgroup per
+        // unit tile: producer p = row * ns + slice, watched by lane p % 64 of canary wave p / 64
+        unsigned canaryA; bool cactA; int npwA;
     };
-    static __device__ __forceinline__ Lane lane_addr(int B, int mt, int wave, int lane) {
+    static __device__ __forceinline__ Lane lane_addr(int B, int mt, int wave, int lane, int ns = 0) {
         Lane t;
         const int r = lane & 15, kq = lane >> 4;
         t.ok = mt * 16 + r < B;
@@ -81,6 +87,13 @@ struct ProdRole {
         // one dword per producer workgroup (unit tile `lane`, same M-tile): the last gate of its last row
         t.cact = lane < NJ;
         t.canary = 4u * (((t.cact ? lane : 0) * 32 + mt * 16 + min(15, B - 1 - mt * 16)) * 64 + 63);
+        t.canaryA = 0u; t.cactA = false; t.npwA = 1;
+        if (ns > 0) {
+            const int p = wave * 64 + lane, prow = p / ns, pq = p % ns;     // the last gate of the last unit tile of slice pq, row prow
+            t.npwA = (16 * ns + 63) / 64;
+            t.cactA = p < 16 * ns && mt * 16 + prow < B;
+            t.canaryA = 4u * ((((t.cactA ? pq + 1 : 1) * (NJ / ns) - 1) * 32 + mt * 16 + (t.cactA ? prow : 0)) * 64 + 63);
+        }
         return t;
     }
     // resident MFMA B operand: W[(gate e)*HS + unit(k)][cb + 16 j + n] for this wave's k-blocks, k = unit*4 + gate
@@ -97,13 +110,13 @@ struct ProdRole {
     // Returns mul(tile).  The product is started speculatively as the tile's loads land (load and MFMA time overlap);
     // the sentinel check comes afterwards and, if a word had not been published yet, the tile is repaired with
     // L2-bypassing loads and the product redone.
-    template <class Mul>
+    template <bool FROM_A = false, class Mul>
     static __device__ __forceinline__ f32x4 poll_mul(const float* base, const Lane& t, f32x4 (&x)[KB], unsigned* err,
                                                      volatile unsigned* flags, unsigned& ep, Mul mul) {
         unsigned spins = 0;
         {
-            const unsigned* cp = reinterpret_cast<const unsigned*>(at_bytes(base, opaque(t.canary)));
-            wg_canary_wait(flags, ++ep, 1, threadIdx.x >> 6, threadIdx.x & 63, cp, t.cact, err, 0xDEAD0021u);
+            const unsigned* cp = reinterpret_cast<const unsigned*>(at_bytes(base, opaque(FROM_A ? t.canaryA : t.canary)));
+            wg_canary_wait(flags, ++ep, FROM_A ? t.npwA : 1, threadIdx.x >> 6, threadIdx.x & 63, cp, FROM_A ? t.cactA : t.cact, err, 0xDEAD0021u);
         }
         asm volatile("" ::: "memory");
         bool need[KB];
@@ -233,7 +246,7 @@ struct ProdRole {
             return acc;
         };
         auto mul_reg = [&](const f32x4 (&xt)[KB]) { return mfma_tile(xt, Wc); };
-        const Lane la = lane_addr(B, mt, wave, lane);
+        const Lane la = lane_addr(B, mt, wave, lane, PREV ? a.ns : 0);
         volatile unsigned* cflags = reinterpret_cast<volatile unsigned*>(smem + RED + PS_NW * KB * 64 * 4);
         unsigned cep = 0;
         if (tid < 4) cflags[tid] = 0u;
@@ -256,14 +269,15 @@ struct ProdRole {
                 // ---- recurrent carry of the top layer for step s-1: dG1_s W_hh1 -> Y workgroup (j, mt)
                 if (s == 0) break;
                 PB_STAMP(3, s, 0);
-                {   // start once the X workgroup of the same tile has published dG0_s, i.e. consumed dG1_s: the chain's
-                    // consumers get the fabric and the L2 to themselves (this carry is only needed a whole step later)
+                if (!PREV) {   // start once the X workgroup of the same tile has published dG0_s, i.e. consumed dG1_s: the chain's
+                    // consumers get the fabric and the L2 to themselves (this carry is only needed a whole step later).  PRE variant:
+                    // the chain is short enough that the carry has to start right away to be back in time.
                     const unsigned* cp = reinterpret_cast<const unsigned*>(dG0x + (size_t)s * GXS) + (((unsigned)j * 32 + mt * 16) * 64 + 63);
                     unsigned spins = 0;
                     while (__hip_atomic_load(cp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == PS_SENT)
                         if (spin_expired(spins, a.err, 0xDEAD0026u)) break;
                 }
-                const f32x4 accr = poll_mul(dG1x + (size_t)s * GXS, la, x, a.err, cflags, cep, mul_reg);
+                const f32x4 accr = poll_mul<PREV>(dG1x + (size_t)s * GXS, la, x, a.err, cflags, cep, mul_reg);
                 PB_STAMP(3, s, 1);
                 const float v = reduce_tile<false>(red + (s & 1) * RED, accr, wave, lane, tid);
                 if (pw) st1_agent(at_bytes(a.dhc + (size_t)s * CXS, opaque(oc)), v);
@@ -356,7 +370,7 @@ struct ProdRole {
             } else {
                 // ---- X1: dh0 = dG1_s W_ih1 -> bottom-layer cell backward -> dG0_s
                 PB_STAMP(0, s, 0);
-                const f32x4 accx = poll_mul(dG1x + (size_t)s * GXS, la, x, a.err, cflags, cep, mul_reg);
+                const f32x4 accx = poll_mul<PREV>(dG1x + (size_t)s * GXS, la, x, a.err, cflags, cep, mul_reg);
                 if (a.trace && first_wg && tid == 0) { asm volatile("s_nop 0" :: "v"(accx[0])); }
                 PB_STAMP(0, s, 1);
                 PB_STAMP(0, s, 6);
@@ -698,14 +712,246 @@ struct AttnBwdPreRole {
     }
 };
 
+// ------------------------------------------------------------------------------------------------ attention backward, PRE variant, round 3
+// The attention workgroups also own the TOP cell's pointwise backward, which removes a role (RY), a 64-producer fan-in and a hop
+// from the chain:  A -> X -> A  instead of  A -> RY -> X -> A.
+//   stage 1 (frame slice, as AttnBwdPreRole): gate-gradient row of step s+1 -> dG0 . P_t, softmax backward, de_t, this slice's part
+//           of dq (masked: the relu mask is linear) -> exchanged between the ns workgroups of the utterance (256 bytes each);
+//   stage 2 (UNIT slice: Hs / ns hidden units of the top layer, one per lane): dq = sum of the parts, decoder-state gradient
+//           W_phi^T dq for its units (its W_phi columns live in LDS), + dz W_c part + recurrent carry (R workgroups) -> top cell
+//           backward (cell-state gradient in a register) -> its piece of the tiled dG1 slab, whole 256-byte rows, straight to X.
+template <int HS>
+struct AttnBwdPre2Role {
+    static constexpr int GC = 4 * HS;                      // length of a P row / of a gate-gradient row
+    static constexpr int LPS = HS / 16;                    // lanes per frame slot: 32 (Hs=512) or 16 (Hs=256)
+    static constexpr int NSLOT = PS_THREADS / LPS;         // 32 or 64 slots; the last one holds the forward's gx row
+    static constexpr int NC4 = GC / LPS / 4;               // float4 per lane: 16 (64 VGPRs of P)
+    static constexpr int TH = NSLOT - 1;                   // frames per workgroup: 31 or 63
+    static constexpr int MAXTP = 512;                      // rows of attention weights / e0 kept in LDS (T' <= 448)
+    static constexpr int NJ = HS / 16;                     // producer tiles of a gate-gradient row (256 B each)
+    static constexpr int MAXUN = HS / 4;                   // units per workgroup at ns = 4 (fewer with more slices)
+    static_assert(LPS == 16 || LPS == 32, "slot layout");
+    static __host__ __device__ constexpr int lds_floats() {
+        return GC + 2 * MAXTP + PS_M + 64 + PS_M + 64 + TH * PS_KLD + PS_M * MAXUN + 16 * PS_M + PS_M + 8 * MAXUN;
+    }
+
+    static __device__ void run(const PersistBwdArgs& a, float* smem, const int widx) {
+        const int NS = a.ns;                                // workgroups per utterance: 4, 8 or 16
+        const int b = widx / NS, part = widx % NS;
+        const bool first_wg = widx == 0;
+        const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+        const int B = a.B, U = a.U, Tp = a.Tp;
+        const int th = (Tp + NS - 1) / NS, t0 = part * th, nt = max(0, min(th, Tp - t0));     // this workgroup's frames
+        const int UN = HS / NS, u0 = part * UN;             // ... and its hidden units of the top layer
+        float* dg = smem;
+        float* attr = dg + GC;
+        float* e0r = attr + MAXTP;
+        float* qs = e0r + MAXTP;
+        float* de = qs + PS_M;
+        float* dqpre = de + 64;
+        float* slotv = dqpre + PS_M;
+        float* ks = slotv + 64;
+        float* wps = ks + TH * PS_KLD;           // W_phi columns of its units: [m][MAXUN] (compile-time row stride: immediate LDS offsets)
+        float* dqp = wps + PS_M * MAXUN;         // the ns parts of dq as they arrive: [part][m]
+        float* dqf = dqp + 16 * PS_M;            // their sum
+        float* stl = dqf + PS_M;                 // stash of its units for this step: [i, f, g, o, c, c_prev, dz W_c part, dc][MAXUN]
+        const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
+
+        // ---- resident operands: P rows of its frames (registers), keys of its frames and the W_phi columns of its units (LDS)
+        const int slot = tid / LPS, l32 = tid % LPS;
+        f32x4 pr[NC4];
+#pragma unroll
+        for (int i = 0; i < NC4; ++i) {
+            const f32x4 v = ld4p(a.pctx + ((size_t)b * Tp + (slot < nt ? t0 + slot : 0)) * GC + 4 * (l32 + LPS * i));
+            pr[i] = slot < nt ? v : zero;
+        }
+        for (int idx = tid; idx < nt * (PS_M / 4); idx += PS_THREADS) {
+            const int t = idx / (PS_M / 4), m4 = idx % (PS_M / 4);
+            *reinterpret_cast<f32x4*>(ks + t * PS_KLD + m4 * 4) = ld4p(a.keys + ((size_t)b * Tp + t0 + t) * PS_M + m4 * 4);
+        }
+        for (int idx = tid; idx < PS_M * UN; idx += PS_THREADS) wps[(idx / UN) * MAXUN + idx % UN] = a.w_phi[(size_t)(idx / UN) * HS + u0 + idx % UN];
+        lds_barrier();
+        constexpr size_t GXS = (size_t)NJ * 32 * 64, CXS = (size_t)NJ * 32 * 16;
+        const bool ulane = tid < UN;                         // stage-2 lane: hidden unit u0 + tid of utterance b
+        if (ulane) stl[7 * MAXUN + tid] = 0.f;                  // cell-state gradient of that (utterance, unit): lives in LDS between the steps
+
+        for (int s = U - 1; s >= 0; --s) {
+            // ---- stash operands of this step (plain loads, issued before the wait)
+            const size_t sb = (size_t)s * B + b;
+            if (tid < MAXTP) {
+                const unsigned o = opaque(4u * (unsigned)(tid < Tp ? tid : 0));
+                const float av = *at_bytes(a.att + sb * Tp, o), ev = *at_bytes(a.e0 + sb * Tp, o);
+                attr[tid] = tid < Tp ? av : 0.f;
+                e0r[tid] = tid < Tp ? ev : 0.f;
+            }
+            if (tid >= MAXTP && tid < MAXTP + PS_M) qs[tid - MAXTP] = *at_bytes(a.q_all + sb * PS_M, opaque(4u * (unsigned)(tid - MAXTP)));
+            if (slot == NSLOT - 1) {
+                const float* gp = at_bytes(a.gxf + sb * GC, opaque(16u * (unsigned)l32));
+#pragma unroll
+                for (int i = 0; i < NC4; ++i) pr[i] = ld4p(gp + 4 * LPS * i);
+            }
+            if (ulane) {      // top-layer stash of its units -> LDS (the workgroup is about to wait for the gate-gradient row anyway)
+                const unsigned u = opaque((unsigned)tid);
+                const size_t slab = ((size_t)U + s) * (size_t)B * HS;
+                const float* gp = at_bytes(a.gates_all + 4 * slab, 4u * ((unsigned)b * 4 * HS + u0 + u));
+                stl[0 * MAXUN + u] = gp[0]; stl[1 * MAXUN + u] = gp[HS]; stl[2 * MAXUN + u] = gp[2 * HS]; stl[3 * MAXUN + u] = gp[3 * HS];
+                stl[4 * MAXUN + u] = *at_bytes(a.c_all + slab, 4u * ((unsigned)b * HS + u0 + u));
+                stl[5 * MAXUN + u] = s > 0 ? *at_bytes(a.c_all + slab - (size_t)B * HS, 4u * ((unsigned)b * HS + u0 + u)) : 0.f;
+                stl[6 * MAXUN + u] = *at_bytes(a.dcat_all + sb * 2 * HS, 4u * (unsigned)(u0 + u));
+            }
+            PB_STAMP(2, s, 0);
+            // ---- the gate gradients of step s+1's bottom cell, row b: one 256-byte piece per X workgroup of this M-tile
+            if (s < U - 1) {
+                const float* slab = a.dGx + (size_t)(s + 1) * GXS;
+                if (wave == 0) {
+                    const unsigned* cp = reinterpret_cast<const unsigned*>(at_bytes(slab, opaque(4u * (((unsigned)(lane < NJ ? lane : 0) * 32 + b) * 64 + 63))));
+                    unsigned spins = 0;
+                    for (;;) {
+                        const unsigned v = __hip_atomic_load(cp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        if (!__any(lane < NJ && v == PS_SENT)) break;
+                        if (spin_expired(spins, a.err, 0xDEAD0029u)) break;
+                    }
+                }
+                lds_barrier();
+                if (tid < GC / 4) {
+                    const float* src = at_bytes(slab, opaque(4u * (((unsigned)(tid >> 4) * 32 + b) * 64 + 4 * (tid & 15))));
+                    unsigned spins = 0;
+                    f32x4 v;
+                    for (;;) {
+                        v = ld4_agent(src);
+                        if (!__any(has_sentinel(v))) break;
+                        if (spin_expired(spins, a.err, 0xDEAD002Au)) break;
+                    }
+                    *reinterpret_cast<f32x4*>(dg + 4 * tid) = v;
+                }
+            } else if (tid < GC / 4) {
+                *reinterpret_cast<f32x4*>(dg + 4 * tid) = zero;
+            }
+            PB_STAMP(2, s, 1);
+            lds_barrier();
+            // ---- dG0 . P_t for its frames (and dG0 . gx_s in the last slot)
+            {
+                float acc = 0.f;
+#pragma unroll
+                for (int i = 0; i < NC4; ++i) acc = dot4p(pr[i], *reinterpret_cast<const f32x4*>(dg + 4 * (l32 + LPS * i)), acc);
+                acc = gsum<16>(acc);
+                if (LPS == 32) {
+                    const float s0 = lane_f(acc, 0) + lane_f(acc, 16), s1 = lane_f(acc, 32) + lane_f(acc, 48);
+                    if (lane == 0) { slotv[2 * wave] = s0; slotv[2 * wave + 1] = s1; }
+                } else if ((lane & 15) == 0) {
+                    slotv[4 * wave + (lane >> 4)] = acc;
+                }
+            }
+            // the recurrent carry of its units (R workgroups, published ~2 us ago): one agent-scope dword per stage-2 lane, in flight
+            // under the softmax backward / dq phases
+            unsigned carry_bits = 0u;
+            auto carry_src = [&]() {       // re-derived where it is used: as a loop-invariant pointer it would hold two registers for the whole step
+                const unsigned un = (unsigned)u0 + (ulane ? opaque((unsigned)tid) : 0u);
+                return reinterpret_cast<const unsigned*>(at_bytes(a.dhc + (size_t)(s + 1 < U ? s + 1 : s) * CXS, 4u * (((un >> 4) * 32 + b) * 16 + (un & 15))));
+            };
+            if (ulane && s < U - 1) carry_bits = __hip_atomic_load(carry_src(), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            lds_barrier();
+            // ---- softmax backward de_t = a_t (e0_t + dG0 . P_t - ctx . dctx) for its frames (one wave)
+            if (wave == 0) {
+                float cp = 0.f;
+#pragma unroll
+                for (int k = 0; k < MAXTP / 64; ++k) cp = fmaf(attr[lane + 64 * k], e0r[lane + 64 * k], cp);
+                const float c0 = wsum(cp);
+                const float sd = c0 + slotv[NSLOT - 1];
+                {
+                    const bool valid = lane < nt;
+                    const int tt = valid ? t0 + lane : 0;
+                    const float v = valid ? attr[tt] * (e0r[tt] + slotv[lane] - sd) : 0.f;
+                    de[lane] = v;
+                    if (valid) *at_bytes(a.de_all + sb * Tp, opaque(4u * (unsigned)tt)) = v;
+                }
+            }
+            lds_barrier();
+            PB_STAMP(2, s, 2);
+            // ---- this slice's part of dq[m] = sum_t de_t keys[t][m] (masked): 16 adjacent lanes per m, DPP row sum
+            {
+                const int m = tid >> 4, tg = tid & 15;
+                float acc = 0.f;
+                for (int t = tg; t < nt; t += 16) acc = fmaf(de[t], ks[t * PS_KLD + m], acc);
+                acc = gsum<16>(acc);
+                if (tg == 0) {
+                    if (a.relu && !(qs[m] > 0.f)) acc = 0.f;
+                    dqpre[m] = acc;
+                }
+            }
+            lds_barrier();
+            // ---- exchange: publish its part (256 bytes, two whole lines), collect all ns parts of this utterance
+            float* xs = a.dqx + sb * NS * PS_M;
+            if (tid < PS_M / 4) st4_agent(at_bytes(xs + part * PS_M, opaque(16u * (unsigned)tid)), *reinterpret_cast<const f32x4*>(dqpre + tid * 4));
+            PB_STAMP(2, s, 3);
+            if (tid < NS * (PS_M / 4)) {      // lane = (part p, float4 i): ns * 16 lanes <= 256
+                const float* src = at_bytes(xs, opaque(16u * (unsigned)tid));
+                unsigned spins = 0;
+                f32x4 v;
+                for (;;) {
+                    v = ld4_agent(src);
+                    if (!__any(has_sentinel(v))) break;
+                    if (spin_expired(spins, a.err, 0xDEAD002Bu)) break;
+                }
+                *reinterpret_cast<f32x4*>(dqp + tid * 4) = v;
+            }
+            lds_barrier();
+            if (tid < PS_M) {
+                float acc = 0.f;
+                for (int p = 0; p < NS; ++p) acc += dqp[p * PS_M + tid];
+                dqf[tid] = acc;
+                if (part == 0) *at_bytes(a.dqpre_all + sb * PS_M, opaque(4u * (unsigned)tid)) = acc;
+            }
+            lds_barrier();
+            PB_STAMP(2, s, 4);
+            // ---- stage 2: decoder-state gradient of its units, top cell backward, its piece of dG1_s
+            if (ulane) {
+                const unsigned u = opaque((unsigned)tid);
+                // 64-term dot product per lane, four independent partial sums.  Deliberately NOT fully unrolled (two rounds of 32 reads):
+                // fully unrolled, the scheduler hoists all 64 LDS reads and register allocation spills the P rows (380 bytes per lane)
+                float acc4[4] = {stl[6 * MAXUN + u], 0.f, 0.f, 0.f};
+                const float* wp = wps + u;
+#pragma unroll 8
+                for (int m = 0; m < PS_M; m += 4) {
+                    const f32x4 q4 = *reinterpret_cast<const f32x4*>(dqf + m);
+                    acc4[0] = fmaf(wp[(m + 0) * MAXUN], q4[0], acc4[0]); acc4[1] = fmaf(wp[(m + 1) * MAXUN], q4[1], acc4[1]);
+                    acc4[2] = fmaf(wp[(m + 2) * MAXUN], q4[2], acc4[2]); acc4[3] = fmaf(wp[(m + 3) * MAXUN], q4[3], acc4[3]);
+                }
+                float dh = (acc4[0] + acc4[1]) + (acc4[2] + acc4[3]);
+                PB_STAMP(2, s, 6);
+                if (s < U - 1) {
+                    unsigned spins = 0;
+                    while (__any(carry_bits == PS_SENT)) {
+                        if (spin_expired(spins, a.err, 0xDEAD002Cu)) break;
+                        carry_bits = __hip_atomic_load(carry_src(), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    }
+                    dh += __uint_as_float(carry_bits);
+                }
+                PB_STAMP(2, s, 7);
+                typename ProdRole<HS>::CellIn ci;
+                ci.ig = stl[0 * MAXUN + u]; ci.fg = stl[1 * MAXUN + u]; ci.gg = stl[2 * MAXUN + u]; ci.og = stl[3 * MAXUN + u];
+                ci.c = stl[4 * MAXUN + u]; ci.cp = stl[5 * MAXUN + u];
+                float dc1 = stl[7 * MAXUN + u];
+                const f32x4 g = ProdRole<HS>::cell_bwd(ci, dh, dc1);
+                stl[7 * MAXUN + u] = dc1;
+                const unsigned un = (unsigned)u0 + u;
+                st4_agent(at_bytes(a.dGx + ((size_t)U + s) * GXS, 4u * ((((un >> 4) * 32 + b) * 16 + (un & 15)) * 4)), g);
+                float* dp = at_bytes(a.dG_all + 4 * (((size_t)U + s) * (size_t)B * HS), 4u * ((unsigned)b * 4 * HS + un));
+                dp[0] = g[0]; dp[HS] = g[1]; dp[2 * HS] = g[2]; dp[3 * HS] = g[3];
+            }
+            PB_STAMP(2, s, 5);
+        }
+    }
+};
+
 template <int HS>
 __global__ __launch_bounds__(PS_THREADS) void speller_persist_bwd_pre_kernel(PersistBwdArgs a) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     constexpr int NXY = (HS / 16) * 2;
     const int bx = blockIdx.x;
     if (bx < NXY) ProdRole<HS>::template run<0, true>(a, smem, bx);
-    else if (bx < 2 * NXY) ProdRole<HS>::template run<3, true>(a, smem, bx - NXY);
-    else AttnBwdPreRole<HS>::run(a, smem, bx - 2 * NXY);
+    else if (bx < 2 * NXY) ProdRole<HS>::template run<2, true>(a, smem, bx - NXY);
+    else AttnBwdPre2Role<HS>::run(a, smem, bx - 2 * NXY);
 }
 
 template <int HS>
@@ -765,7 +1011,8 @@ size_t speller_persist_bwd_workspace_floats(int B, int Tp, int U, int Hs, int M)
     if (ns == 0) return 0;
     const size_t classic = (size_t)ns * U * B * M + (size_t)U * B * ns * Hs + (size_t)2 * U * (Hs / 16) * 32 * 64 + (size_t)2 * (U + 1) * (Hs / 16) * 32 * 16;
     const size_t nsp = (size_t)persist_bwd_pre_ns(B, Tp, Hs, -1);
-    const size_t pre = (nsp && Tp <= 448) ? nsp * U * B * M + (size_t)U * B * Tp + 4 + (size_t)U * B * nsp * Hs + (size_t)2 * U * (Hs / 16) * 32 * 64 : 0;
+    // PRE variant: [e0 | sentinel-prefilled slabs: dq exchange (ns parts) | tiled dG (2 layers) | recurrent carry of the top layer]
+    const size_t pre = (nsp && Tp <= 448) ? (size_t)U * B * Tp + 4 + nsp * U * B * M + (size_t)2 * U * (Hs / 16) * 32 * 64 + (size_t)(U + 1) * (Hs / 16) * 32 * 16 : 0;
     return std::max(classic, pre);
 }
 bool speller_persist_bwd_pre_eligible(int B, int Tp, int Hs, int D, int M, int V, int L, int heads, int use_mlp) {
@@ -780,7 +1027,7 @@ bool speller_persist_bwd_pre_eligible(int B, int Tp, int Hs, int D, int M, int V
 
 template <int HS>
 static int launch_persist_bwd_pre(const PersistBwdArgs& a, int grid, hipStream_t stream) {
-    const size_t smem = sizeof(float) * (size_t)std::max(ProdRole<HS>::LDS_FLOATS, AttnBwdPreRole<HS>::lds_floats());
+    const size_t smem = sizeof(float) * (size_t)std::max(ProdRole<HS>::LDS_FLOATS, AttnBwdPre2Role<HS>::lds_floats());
     LAS_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&speller_persist_bwd_pre_kernel<HS>),
                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
     if (!persistent_launch_fits(speller_persist_bwd_pre_kernel<HS>, PS_THREADS, smem, grid))
@@ -827,14 +1074,16 @@ int speller_persist_bwd(const PersistBwd& p, hipStream_t stream) {
     const size_t nq = (size_t)p.U * p.B * PS_M;
     a.dqpre_part = p.xbuf;
     if (p.pctx) {
-        // PRE variant: [dqpre parts (ns) | e0 | sentinel-prefilled slabs: dhA (ns parts) | tiled dG (2 layers)]
+        // PRE variant: [e0 | sentinel-prefilled slabs: dq exchange (ns parts) | tiled dG (2 layers) | top-layer recurrent carry]
         LAS_REQUIRE(p.gxf && a.ns != 0, "persistent speller backward (pre) buffers");
-        float* e0 = p.xbuf + (size_t)a.ns * nq;
+        float* e0 = p.xbuf;
         float* slabs = e0 + (((size_t)p.U * p.B * p.Tp + 3) & ~(size_t)3);
         a.e0 = e0;
-        a.dhA = slabs;
-        a.dGx = a.dhA + (size_t)p.U * p.B * a.ns * p.Hs;
-        a.dcx = nullptr; a.dhc = nullptr;
+        a.dqx = slabs;
+        a.dGx = a.dqx + (size_t)a.ns * nq;
+        a.dhc = a.dGx + (size_t)2 * p.U * (p.Hs / 16) * 32 * 64;
+        a.dcx = nullptr; a.dhA = nullptr; a.dqpre_part = nullptr;
+        a.dqpre_all = p.dqpre_all;
         a.w_ih0 = p.w_ih0; a.ldw0 = p.V + p.Hs; a.V = p.V;
         a.w_hh0 = p.w_hh0; a.w_ih1 = p.w_ih1; a.w_hh1 = p.w_hh1; a.w_phi = p.w_phi;
         a.feat = p.feat; a.keys = p.keys; a.att = p.att; a.q_all = p.q_all; a.ctx_all = p.ctx_all;
@@ -856,13 +1105,12 @@ int speller_persist_bwd(const PersistBwd& p, hipStream_t stream) {
             }
             LAS_TRY(gemm_f32(g, stream));
         }
-        const size_t slab_floats = (size_t)p.U * p.B * a.ns * p.Hs + (size_t)2 * p.U * (p.Hs / 16) * 32 * 64;
+        const size_t slab_floats = (size_t)a.ns * nq + (size_t)2 * p.U * (p.Hs / 16) * 32 * 64 + (size_t)(p.U + 1) * (p.Hs / 16) * 32 * 16;
         LAS_HIP_CHECK(hipMemsetAsync(slabs, 0xFF, sizeof(float) * slab_floats, stream));
         const int grid = 2 * (p.Hs / 16) * 2 + a.ns * p.B;
         if (p.Hs == 512) LAS_TRY(launch_persist_bwd_pre<512>(a, grid, stream));
         else LAS_TRY(launch_persist_bwd_pre<256>(a, grid, stream));
-        LAS_TRY(sum_parts(p.dqpre_all, a.dqpre_part, (long)nq, (long)nq, a.ns, stream));      // the relu mask is linear in dq
-        return LAS_OK;
+        return LAS_OK;       // dqpre_all was written by the kernel (slice 0 of every utterance: the sum of the masked parts)
     }
     float* slabs = p.xbuf + (size_t)a.ns * nq;
     a.dhA = slabs;

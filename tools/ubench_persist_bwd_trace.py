@@ -50,3 +50,11 @@ print("PRE   : A: wait dG0 row %.2f | contraction+de %.2f | dq %.2f | W_phi^T dq
     us(RY[:, 1] - RY[:, 0]), us(RY[:, 2] - RY[:, 1]), us(RY[:, 3] - RY[:, 2])))
 print("PRE chain: A published -> RY has parts %.2f | RY published dG1 -> X has it %.2f | X published dG0 -> A(s-1) has its row %.2f | A(s-1) row in -> published %.2f | period %.2f" % (
     us(RY[:, 1] - A[:, 4]), us(X[:, 1] - RY[:, 2]), us(A[:-1, 1] - X[1:, 2]), us(A[:, 4] - A[:, 1]), us(A[:-1, 4] - A[1:, 4])))
+# round 3 (PRE variant): roles X / R / A, chain A -> X -> A(s-1); A stamps: 0 stash loaded, 1 gate-gradient row in, 2 de done, 3 part published,
+# 4 parts of the utterance summed, 5 dG1 piece published
+print("R3 A  : wait dG0 row %.2f | contraction+softmax bwd %.2f | dq part + publish %.2f | exchange (4 parts in, summed) %.2f | W_phi^T dq + carry + top cell bwd + publish dG1 %.2f" % (
+    us(A[:, 1] - A[:, 0]), us(A[:, 2] - A[:, 1]), us(A[:, 3] - A[:, 2]), us(A[:, 4] - A[:, 3]), us(A[:, 5] - A[:, 4])))
+print("R3 chain: A published dG1 -> X has the tile's canaries+product done %.2f | X reduce+cell+publish dG0 %.2f | X published dG0 -> A(s-1) has its row %.2f | A(s-1) row in -> dG1 published %.2f | period %.2f" % (
+    us(X[:, 6] - A[:, 5]), us(X[:, 2] - X[:, 6]), us(A[:-1, 1] - X[1:, 2]), us(A[:, 5] - A[:, 1]), us(A[:-1, 5] - A[1:, 5])))
+print("R3 R  : wait dG1 %.2f | W_hh1 product + reduce + publish carry %.2f" % (us(R[1:, 1] - R[1:, 0]), us(R[1:, 2] - R[1:, 1])))
+print("R3 A stage 2: W_phi^T dq %.2f | carry in %.2f | top cell bwd + publish dG1 %.2f" % (us(A[:, 6] - A[:, 4]), us(A[:, 7] - A[:, 6]), us(A[:, 5] - A[:, 7])))
