@@ -71,8 +71,12 @@ __device__ __forceinline__ bool spin_expired(unsigned& spins, unsigned* err, uns
 // of waves and rows (~10^5 32-byte transactions per microsecond over the chip — the memory system's whole transaction
 // rate), which is what the hops were actually waiting for.  `ep` is a per-workgroup call counter (monotonic, so a wave
 // that runs ahead cannot make a slower one miss its epoch).
-__device__ __forceinline__ void wg_canary_wait(volatile unsigned* flags, unsigned ep, int npw, int wave, int lane,
+typedef __attribute__((address_space(3))) unsigned ps_lds_u32;
+__device__ __forceinline__ void wg_canary_wait(volatile unsigned* flags_generic, unsigned ep, int npw, int wave, int lane,
                                                const unsigned* cp, bool active, unsigned* err, unsigned code) {
+    // the flags live in LDS: as an LDS-address-space pointer they cost one 32-bit register and ds_ instructions; as a generic pointer
+    // they are a 64-bit VGPR pair behind flat_ loads / stores (which register allocation spilled to scratch — on the chain)
+    volatile ps_lds_u32* flags = (volatile ps_lds_u32*)flags_generic;
     unsigned spins = 0;
     if (wave < npw) {
         for (;;) {

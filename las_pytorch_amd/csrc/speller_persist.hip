@@ -126,7 +126,7 @@ struct CellRole {
             constexpr int K = KIND == 0 ? 0 : 1;
             const int npw = KIND == 0 ? (HS / 4 + 63) / 64 : t.npw1;      // canary waves: one lane per producer workgroup
             const unsigned* cp = reinterpret_cast<const unsigned*>(at_bytes(base, opaque(t.canary[K])));
-            wg_canary_wait(flags, ++ep, npw, threadIdx.x >> 6, threadIdx.x & 63, cp, t.cact[K], err, 0xDEAD0011u);
+            wg_canary_wait(flags, ++ep, npw, __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), threadIdx.x & 63, cp, t.cact[K], err, 0xDEAD0011u);
         }
         asm volatile("" ::: "memory");
         bool need[NF][2];
@@ -207,7 +207,7 @@ struct CellRole {
     }
 
     static __device__ void run(const PersistArgs& a, float* smem) {
-        const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+        const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);      // wave: scalar register
         const int r = lane & 15, kq = lane >> 4;
         const int j0 = blockIdx.x * 4;
         const bool first_wg = blockIdx.x == 0;
@@ -469,7 +469,7 @@ struct CellPreRole {
     using WSplit = typename Base::WSplit;
 
     static __device__ void run(const PersistArgs& a, float* smem) {
-        const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+        const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);      // wave: scalar register
         const int r = lane & 15, kq = lane >> 4;
         const int j0 = blockIdx.x * 4;
         const bool first_wg = blockIdx.x == 0;

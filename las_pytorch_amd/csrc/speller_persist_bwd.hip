@@ -116,7 +116,7 @@ struct ProdRole {
         unsigned spins = 0;
         {
             const unsigned* cp = reinterpret_cast<const unsigned*>(at_bytes(base, opaque(FROM_A ? t.canaryA : t.canary)));
-            wg_canary_wait(flags, ++ep, FROM_A ? t.npwA : 1, threadIdx.x >> 6, threadIdx.x & 63, cp, FROM_A ? t.cactA : t.cact, err, 0xDEAD0021u);
+            wg_canary_wait(flags, ++ep, FROM_A ? t.npwA : 1, __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), threadIdx.x & 63, cp, FROM_A ? t.cactA : t.cact, err, 0xDEAD0021u);
         }
         asm volatile("" ::: "memory");
         bool need[KB];
@@ -212,7 +212,7 @@ struct ProdRole {
     template <int ROLE, bool PREV = false>
     static __device__ void run(const PersistBwdArgs& a, float* smem, const int widx) {
         constexpr bool IS_X = ROLE == 0, IS_Y = ROLE == 1, IS_R = ROLE == 2, IS_RY = ROLE == 3;
-        const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+        const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);      // wave: scalar register
         const int j = widx >> 1, mt = widx & 1;
         const int B = a.B, U = a.U;
         if (mt * 16 >= B) return;                         // no utterance in this M-tile: nobody waits for its rows
@@ -564,7 +564,7 @@ struct AttnBwdPreRole {
         const int NS = a.ns;                                // frame slices (workgroups) per utterance: 4, 8 or 16
         const int b = widx / NS, part = widx % NS;
         const bool first_wg = widx == 0;
-        const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+        const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);      // wave: scalar register
         const int B = a.B, U = a.U, Tp = a.Tp;
         const int th = (Tp + NS - 1) / NS, t0 = part * th, nt = max(0, min(th, Tp - t0));     // this workgroup's frames
         float* dg = smem;
@@ -730,16 +730,17 @@ struct AttnBwdPre2Role {
     static constexpr int MAXTP = 512;                      // rows of attention weights / e0 kept in LDS (T' <= 448)
     static constexpr int NJ = HS / 16;                     // producer tiles of a gate-gradient row (256 B each)
     static constexpr int MAXUN = HS / 4;                   // units per workgroup at ns = 4 (fewer with more slices)
+    static constexpr int WLD = PS_M + 4;                   // LDS row stride of a unit's W_phi column (16-byte aligned, bank spread)
     static_assert(LPS == 16 || LPS == 32, "slot layout");
     static __host__ __device__ constexpr int lds_floats() {
-        return GC + 2 * MAXTP + PS_M + 64 + PS_M + 64 + TH * PS_KLD + PS_M * MAXUN + 16 * PS_M + PS_M + 8 * MAXUN;
+        return GC + 2 * MAXTP + PS_M + 64 + PS_M + 64 + TH * PS_KLD + WLD * MAXUN + 16 * PS_M + PS_M + 9 * MAXUN;
     }
 
     static __device__ void run(const PersistBwdArgs& a, float* smem, const int widx) {
         const int NS = a.ns;                                // workgroups per utterance: 4, 8 or 16
         const int b = widx / NS, part = widx % NS;
         const bool first_wg = widx == 0;
-        const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+        const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);      // wave: scalar register
         const int B = a.B, U = a.U, Tp = a.Tp;
         const int th = (Tp + NS - 1) / NS, t0 = part * th, nt = max(0, min(th, Tp - t0));     // this workgroup's frames
         const int UN = HS / NS, u0 = part * UN;             // ... and its hidden units of the top layer
@@ -751,10 +752,11 @@ struct AttnBwdPre2Role {
         float* dqpre = de + 64;
         float* slotv = dqpre + PS_M;
         float* ks = slotv + 64;
-        float* wps = ks + TH * PS_KLD;           // W_phi columns of its units: [m][MAXUN] (compile-time row stride: immediate LDS offsets)
-        float* dqp = wps + PS_M * MAXUN;         // the ns parts of dq as they arrive: [part][m]
+        float* wps = ks + TH * PS_KLD;           // W_phi columns of its units: [unit][WLD]
+        float* dqp = wps + WLD * MAXUN;          // the ns parts of dq as they arrive: [part][m]
         float* dqf = dqp + 16 * PS_M;            // their sum
         float* stl = dqf + PS_M;                 // stash of its units for this step: [i, f, g, o, c, c_prev, dz W_c part, dc][MAXUN]
+        float* dhl = stl + 8 * MAXUN;            // W_phi^T dq of its units
         const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
 
         // ---- resident operands: P rows of its frames (registers), keys of its frames and the W_phi columns of its units (LDS)
@@ -769,7 +771,7 @@ struct AttnBwdPre2Role {
             const int t = idx / (PS_M / 4), m4 = idx % (PS_M / 4);
             *reinterpret_cast<f32x4*>(ks + t * PS_KLD + m4 * 4) = ld4p(a.keys + ((size_t)b * Tp + t0 + t) * PS_M + m4 * 4);
         }
-        for (int idx = tid; idx < PS_M * UN; idx += PS_THREADS) wps[(idx / UN) * MAXUN + idx % UN] = a.w_phi[(size_t)(idx / UN) * HS + u0 + idx % UN];
+        for (int idx = tid; idx < PS_M * UN; idx += PS_THREADS) wps[(idx % UN) * WLD + idx / UN] = a.w_phi[(size_t)(idx / UN) * HS + u0 + idx % UN];
         lds_barrier();
         constexpr size_t GXS = (size_t)NJ * 32 * 64, CXS = (size_t)NJ * 32 * 16;
         const bool ulane = tid < UN;                         // stage-2 lane: hidden unit u0 + tid of utterance b
@@ -904,20 +906,21 @@ struct AttnBwdPre2Role {
             }
             lds_barrier();
             PB_STAMP(2, s, 4);
-            // ---- stage 2: decoder-state gradient of its units, top cell backward, its piece of dG1_s
+            // ---- stage 2: decoder-state gradient of its units (W_phi^T dq: 8 adjacent lanes per unit, 8 terms each, DPP row sum) ...
+            if (tid < 8 * UN) {
+                const unsigned t8 = opaque((unsigned)tid), un = t8 >> 3, ms = t8 & 7;
+                const float* wr = wps + un * WLD + ms * 8;
+                const float* qr = dqf + ms * 8;
+                float acc = dot4p(*reinterpret_cast<const f32x4*>(wr), *reinterpret_cast<const f32x4*>(qr), 0.f);
+                acc = dot4p(*reinterpret_cast<const f32x4*>(wr + 4), *reinterpret_cast<const f32x4*>(qr + 4), acc);
+                acc = gsum<8>(acc);
+                if (ms == 0) dhl[un] = acc;
+            }
+            lds_barrier();
+            // ... top cell backward, its piece of dG1_s
             if (ulane) {
                 const unsigned u = opaque((unsigned)tid);
-                // 64-term dot product per lane, four independent partial sums.  Deliberately NOT fully unrolled (two rounds of 32 reads):
-                // fully unrolled, the scheduler hoists all 64 LDS reads and register allocation spills the P rows (380 bytes per lane)
-                float acc4[4] = {stl[6 * MAXUN + u], 0.f, 0.f, 0.f};
-                const float* wp = wps + u;
-#pragma unroll 8
-                for (int m = 0; m < PS_M; m += 4) {
-                    const f32x4 q4 = *reinterpret_cast<const f32x4*>(dqf + m);
-                    acc4[0] = fmaf(wp[(m + 0) * MAXUN], q4[0], acc4[0]); acc4[1] = fmaf(wp[(m + 1) * MAXUN], q4[1], acc4[1]);
-                    acc4[2] = fmaf(wp[(m + 2) * MAXUN], q4[2], acc4[2]); acc4[3] = fmaf(wp[(m + 3) * MAXUN], q4[3], acc4[3]);
-                }
-                float dh = (acc4[0] + acc4[1]) + (acc4[2] + acc4[3]);
+                float dh = stl[6 * MAXUN + u] + dhl[u];
                 PB_STAMP(2, s, 6);
                 if (s < U - 1) {
                     unsigned spins = 0;
