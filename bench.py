@@ -271,7 +271,7 @@ def roofline_mfma(c, B, T, U, reps=10):
                 flops_per_step=int(tot_fl), gemm_ms_per_step=round(tot_us / 1e3, 3), launches=rows)
 
 
-def sweep_rec(c, T, batches=(32, 128, 512)):
+def sweep_rec(c, T, batches=(32, 128, 512, 2048)):
     """The layer-0 forward recurrence alone at growing per-GPU batch (SURVEY.md section 8d asks for the batch sweep next to
     the B=32 headline: at B=32 the kernel is a latency-bound 400-step chain, larger batches amortise the hand-off)."""
     out = []

@@ -4,21 +4,20 @@
 // reference's Speller.forward (model/las_model.py:186-238, teacher-forced branch :207-209) when the shapes allow it.
 // The stepwise kernels stay the general path (free-running decode, multi-head, very long T', batches above 32).
 //
-// Why: a decode step is a chain of three dependent phases.  As three kernels each phase pays ~4 us of launch/drain
-// floor plus ~4 us of L2->CU operand traffic (every workgroup re-reads the weights it used one step ago).  Here
-//   * Hs/4 "cell" workgroups each own 4 hidden units of BOTH LSTM layers for the whole utterance batch and keep their
-//     rows of W_ih/W_hh in VGPRs (36 floats per lane at Hs=512) for all U steps; the cell state c never leaves the
-//     workgroup.  The batch is the M dimension of v_mfma_f32_16x16x4_f32 (exact fp32), the 16 waves split K.
-//   * split*B "attention" workgroups (split = 2, 4 or 8 per utterance, each owning D/split context columns) keep their
-//     slice of the listener features in VGPRs (7 float4 per lane), the keys in LDS and W_phi in VGPRs.
-//   * phases hand data over through per-step slabs (ctx_all, which the backward pass needs anyway, and a tiled copy of
-//     h) that the host pre-fills with a sentinel bit pattern (0xFFFFFFFF, never produced by the kernels): producers
-//     write whole cache lines with agent-scope (write-through) stores; one wave of a consumer workgroup watches one
-//     dword per producer workgroup, then every wave reads its tile with ordinary (L2-shared) loads, multiplies, and
+// Why: a decode step is a chain of dependent phases.  As three kernels each phase pays ~4 us of launch/drain floor plus ~4 us of
+// L2->CU operand traffic (every workgroup re-reads the weights it used one step ago).  Three role sets live in this file:
+//   * classic (CellRole / AttnRole; free-running decode modes 0 / 1, vocabularies above 32, T' beyond the PRE table): Hs/4 "cell"
+//     workgroups own 4 hidden units of BOTH LSTM layers for the whole batch (weight rows in VGPRs, batch = M of v_mfma_f32_16x16x4_f32,
+//     the 16 waves split K); split*B "attention" workgroups keep their slice of the listener features in VGPRs, the keys in LDS;
+//   * PRE, round 3 (CellPreRole / AttnPreRole; teacher forcing — the training case): the context enters the bottom cell as
+//     sum_t a_t (W_ctx feat_t) from a register-resident slice of P = feat . W_ctx^T, and the ATTENTION workgroups apply the bottom cell
+//     themselves (their lanes hold the four gates of 128 units after the reduction); the cell workgroups run the top cell and prepare
+//     R0 = W_hh0 h0 + W_y y + b a whole attention phase ahead.  TWO cross-CU hops per decode step; resident products on the bf16
+//     matrix pipe (exact three-way operand split, persist_common.h).
+//   * phases hand data over through per-step slabs that the host pre-fills with a sentinel bit pattern (0xFFFFFFFF, never produced by
+//     the kernels): producers write whole cache lines with agent-scope (write-through) stores; one wave of a consumer workgroup
+//     watches one dword per producer workgroup, then every wave reads its tile with ordinary (L2-shared) loads, multiplies, and
 //     checks every consumed word against the sentinel — the data is its own flag, no counters, no fences, no epochs.
-//   * only the operand the chain just produced is multiplied on the critical path: the recurrent halves
-//     (W_hh h_{s}) and the label half (W_y y_{s+1}) of the NEXT step's gates are accumulated while the attention
-//     workgroups are busy (the h_0 tile loaded for layer 1 is reused in registers for layer 0's recurrent half).
 // All spins are bounded and report through the device error word (results are then invalid, never a hang).
 #include "las_common.h"
 #include "las_kernels.h"

@@ -19,6 +19,9 @@
 // X, Y and R workgroups own 16 hidden units x 16 utterances (one 16x16 MFMA tile, K = 4Hs split over the 16 waves) and
 // keep the columns of ONE weight matrix in VGPRs (32 floats per lane at Hs=512) for the whole launch — two resident
 // matrices spilled; cell-state gradients never leave them.
+// PRE variant, round 3 (speller_persist_bwd_pre_kernel: roles X, R, AttnBwdPre2Role — the training case): the attention workgroups
+// contract the gate-gradient row with their P rows (no dG0 W_ctx product on the chain), exchange their parts of dq inside the utterance
+// and apply the TOP cell's backward for a unit slice themselves: chain A -> X -> A(s-1); Y / RY do not exist there, R only carries.
 // Hand-off uses the protocol of speller_persist.hip (persist_common.h): sentinel-prefilled per-step slabs, agent-scope
 // producers writing whole cache lines, one canary wave per consumer workgroup watching one dword per producer
 // workgroup, L2-shared plain loads for the big tiles with the MFMA product started while they land.
@@ -833,10 +836,19 @@ struct AttnBwdPre2Role {
             lds_barrier();
             // ---- dG0 . P_t for its frames (and dG0 . gx_s in the last slot)
             {
-                float acc = 0.f;
+                // two partial sums, the row read four float4 at a time (the allocator otherwise funnels all sixteen reads through ONE
+                // register quad: read, wait, four FMAs, sixteen times in a row)
+                float acc = 0.f, acc1 = 0.f;
 #pragma unroll
-                for (int i = 0; i < NC4; ++i) acc = dot4p(pr[i], *reinterpret_cast<const f32x4*>(dg + 4 * (l32 + LPS * i)), acc);
-                acc = gsum<16>(acc);
+                for (int i = 0; i < NC4; i += 4) {
+                    const f32x4 d0 = *reinterpret_cast<const f32x4*>(dg + 4 * (l32 + LPS * i));
+                    const f32x4 d1 = *reinterpret_cast<const f32x4*>(dg + 4 * (l32 + LPS * (i + 1)));
+                    const f32x4 d2 = *reinterpret_cast<const f32x4*>(dg + 4 * (l32 + LPS * (i + 2)));
+                    const f32x4 d3 = *reinterpret_cast<const f32x4*>(dg + 4 * (l32 + LPS * (i + 3)));
+                    acc = dot4p(pr[i], d0, acc); acc1 = dot4p(pr[i + 1], d1, acc1);
+                    acc = dot4p(pr[i + 2], d2, acc); acc1 = dot4p(pr[i + 3], d3, acc1);
+                }
+                acc = gsum<16>(acc + acc1);
                 if (LPS == 32) {
                     const float s0 = lane_f(acc, 0) + lane_f(acc, 16), s1 = lane_f(acc, 32) + lane_f(acc, 48);
                     if (lane == 0) { slotv[2 * wave] = s0; slotv[2 * wave + 1] = s1; }
