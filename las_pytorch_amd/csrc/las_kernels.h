@@ -54,6 +54,11 @@ int pblstm_rec_bwd(const float* dout, const float* gates, const float* cbuf, con
                    int B, int T, int H, unsigned long long* xbuf, unsigned* err, int force_generic,
                    hipStream_t stream, float* db_f = nullptr, float* db_r = nullptr, int* db_done = nullptr);
 size_t rec_xbuf_bytes(int B, int H);
+// pblstm_rec_mfma.hip: the forward recurrence for batches that fill MFMA tiles (16 utterances per group of H/32 workgroups, bf16
+// matrix pipe with the exact three-way operand split).  pblstm_rec_fwd dispatches to it by itself when eligible.
+bool rec_fwd_mfma_eligible(int B, int H);
+int rec_fwd_mfma(float* gates, const float* w_hh_f, const float* w_hh_r, float* out, float* cbuf, float* hprev, int B, int T, int H,
+                 int stash, unsigned long long* xbuf, unsigned* err, hipStream_t stream);
 #ifdef LAS_REC_TRACE
 void rec_set_trace(unsigned long long* dev_buf);    // profiling build only, see tools/ubench_rec_trace.py
 #endif

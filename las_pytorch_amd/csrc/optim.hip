@@ -22,8 +22,6 @@
 
 namespace las {
 
-namespace {
-
 constexpr int OPT_THREADS = 256;
 constexpr int NORM_BLOCKS = 1024;                 // partial sums (workspace floats)
 constexpr int CHUNK = OPT_THREADS * 4 * 4;        // elements per workgroup of the update: 4 float4 per thread
@@ -132,8 +130,6 @@ __global__ __launch_bounds__(OPT_THREADS) void clip_adam_kernel(AdamTable tb, fl
         p[j] = pv; m[j] = mv; v[j] = vv;
     }
 }
-
-}  // namespace
 
 }  // namespace las
 

@@ -932,6 +932,10 @@ int pblstm_rec_fwd(float* gates, const float* w_hh_f, const float* w_hh_r, float
                    int T, int H, int stash, u64* xbuf, unsigned* err, int force_generic, hipStream_t stream) {
     LAS_REQUIRE(B > 0 && T > 0 && H > 0, "rec dims");
     LAS_REQUIRE(!stash || (cbuf && hprev), "stash buffers");
+    if (!force_generic && err && xbuf && rec_fwd_mfma_eligible(B, H)) {      // large batches: 16 utterances per group on the matrix pipe
+        const int rc = rec_fwd_mfma(gates, w_hh_f, w_hh_r, out, cbuf, hprev, B, T, H, stash, xbuf, err, stream);
+        if (rc != LAS_ERR_UNSUPPORTED) return rc;                    // residency check failed: the kernels below run instead
+    }
     const int ngroups = 2 * B;
     // LAS_REC_AGENT_HANDOFF=1 forces the placement-independent agent-scope hand-off even when a group shares an XCD (A/B tests)
     const int dbg = (int)opt_get(OPT_REC_AGENT_HANDOFF);

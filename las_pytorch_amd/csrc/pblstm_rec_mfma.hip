@@ -1,0 +1,341 @@
+// Multi-utterance forward recurrence of a BiLSTM layer on the MATRIX pipe (gfx950): the large-batch form of pblstm_rec.hip.
+//
+// Replaces the recurrent half of nn.LSTM(bidirectional=True) behind the reference's pBLSTMLayer (model/las_model.py:72-79,90)
+// when a launch carries enough utterances to fill MFMA tiles (B >= 128 at H = 256); cell equations, gate order, stash layout and
+// the reverse direction are those of pblstm_rec.hip (rec_fwd_generic is the executable specification).
+//
+// Why: with one utterance per group the recurrent product is a mat-vec and lives on the VALU (64 FMAs per lane and step).  The
+// multi-utterance kernels of pblstm_rec.hip amortise the hand-off over NB utterances but still do NB separate VALU mat-vecs
+// (21 ns per utterance-step at B = 512 against a 3.3 ns FMA floor).  Sixteen utterances of one direction ARE a 16-row MFMA tile:
+//   * a GROUP of G = H / 32 workgroups (one per CU, 1024 threads) owns 16 sequences for all T steps; workgroup m owns hidden units
+//     [32 m, 32 m + 32): its 128 gate rows of W_hh (row order unit*4 + gate) are split ONCE into three bf16 planes and stay in
+//     registers (48 per lane at H = 256: wave = (pair of N-tiles of 16 gate rows, K quarter), two 32-deep k-steps each);
+//   * per step: h_{t-1} of the 16 sequences (16 x H floats, 16 KB at H = 256) is pulled once per workgroup (one float4 per lane),
+//     split ONCE into its three bf16 planes on the way into LDS (the exact three-way split of persist_common.h: fp32-faithful;
+//     splitting in the multiplying waves repeated the same VALU work in every N-tile's wave: 1.8 us per step), every wave reads its
+//     16 x 32 operand blocks as planes and issues six v_mfma_f32_16x16x32_bf16 per block and N-tile, the four K quarters meet in
+//     LDS, 512 lanes apply the cell (c in a register) and publish h_t;
+//   * hand-off = the layer's OUTPUT buffer itself: `out` is pre-filled with the sentinel, producers store h_t with agent-scope
+//     stores (a half wave writes one whole 128-byte line: 32 units of one sequence), one wave of every consumer watches one dword
+//     per producer, the tile is then read with ordinary loads and every word checked against the sentinel (persist_common.h).
+// All spins are bounded and report through the device error word.
+#include "las_common.h"
+#include "las_kernels.h"
+#include "options.h"
+#include "persist_common.h"
+#include <algorithm>
+
+namespace las {
+
+namespace {
+
+constexpr int RM_THREADS = 1024, RM_NB = 16, RM_UW = 32;
+
+template <int H>
+struct RecMfma {
+    static constexpr int G = H / RM_UW;                 // workgroups (CUs) per group
+    static constexpr int KQ = H / 4;                    // K range of a wave (four K quarters)
+    static constexpr int KS = KQ / 32;                  // 32-deep k-steps per wave
+    static constexpr int PLD = H / 2 + 4;               // LDS row stride (dwords = bf16 pairs) of one plane of the h tile
+    static constexpr int PLANE = RM_NB * PLD;           // dwords of one plane
+    static constexpr int RLD = 20;                      // row stride of a partial 16x16 tile
+    static constexpr int RED = 4 * 8 * 16 * RLD;        // [K quarter][N-tile][16 rows][RLD]
+    static constexpr int LDS_FLOATS = 3 * PLANE + RED + 16;
+    static_assert(H == 256, "register budget (2 N-tiles x KS x 12 plane registers per lane) and one tile float4 per lane");
+};
+
+struct RecMfmaArgs {
+    float* gates; const float* w_hh_f; const float* w_hh_r; float* out; float* cbuf; float* hprev;
+    int B, T, b0, Bc;                                   // this launch covers utterances [b0, b0 + Bc)
+    unsigned* err;
+    int nbat;                                           // batches of 16 sequences per group: 1, or 2 stepped alternately
+    unsigned long long* idbuf;                          // zeroed: 32 id slots per group (run-time placement check)
+    int force_agent;                                    // A/B: agent-scope hand-off even when a group shares an XCD
+};
+
+// Run-time placement check (as pblstm_rec.hip::same_xcd_group): every member publishes its XCC id with agent-scope stores and reads
+// all the others'.  True iff all G workgroups of the group run on one XCD — then h may travel through that XCD's L2 (plain stores,
+// L1-bypassing loads: ~0.5 us per hop) instead of through memory (write-through stores, ~1.3 us + a fabric round trip per tile).
+template <int G>
+__device__ __forceinline__ bool rm_same_xcd(unsigned long long* idbuf, int member, unsigned* err, volatile unsigned* lds_flag) {
+    unsigned xcc;
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID, 0, 4)" : "=s"(xcc));
+    const int tid = threadIdx.x;
+    if (tid == 0) {
+        *lds_flag = 1u;
+        __hip_atomic_store(idbuf + member, (0xC0DE0002ull << 32) | (unsigned long long)xcc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    __syncthreads();
+    if (tid < G) {
+        unsigned spins = 0;
+        unsigned long long x;
+        for (;;) {
+            x = __hip_atomic_load(idbuf + tid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if ((unsigned)(x >> 32) == 0xC0DE0002u) break;
+            if (spin_expired(spins, err, 0xDEAD0033u)) break;
+        }
+        if ((unsigned)x != xcc || (unsigned)(x >> 32) != 0xC0DE0002u) *lds_flag = 0u;
+    }
+    __syncthreads();
+    return *lds_flag != 0u;
+}
+
+#ifdef RM_TRACE      // debug build: phase stamps of workgroup 0 into the id buffer behind the id slots (tools/ubench_rec_mfma.py TRACE=1)
+#define RM_STAMP(k) do { if (blockIdx.x == 0 && threadIdx.x == 0 && step < 256) a.idbuf[4096 + step * 8 + (k)] = wall_clock64(); } while (0)
+#else
+#define RM_STAMP(k) do { } while (0)
+#endif
+
+template <int H, bool STASH>
+__global__ __launch_bounds__(RM_THREADS) void rec_fwd_mfma_kernel(RecMfmaArgs a) {
+    using C = RecMfma<H>;
+    constexpr int G = C::G, KS = C::KS, PLD = C::PLD, PLANE = C::PLANE, RLD = C::RLD;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    unsigned* hp3 = reinterpret_cast<unsigned*>(smem);  // [plane][16 sequences][PLD] bf16 pairs
+    float* red = smem + 3 * PLANE;                      // [K quarter][N-tile][16 rows][RLD]
+    volatile unsigned* cflags = reinterpret_cast<volatile unsigned*>(red + C::RED);
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int T = a.T, B = a.B;
+    // a group steps NBAT batches of 16 sequences alternately (a.nbat = 2 when the launch carries more sequences than one batch per
+    // group covers): while one batch's h travels between the CUs, the other batch is multiplied — the hand-off leaves the chain
+    const int nbat = a.nbat;
+    const int per_group = nbat * RM_NB;
+    const int ngb = (a.Bc + per_group - 1) / per_group; // groups per direction
+    const int ngroups = 2 * ngb;
+    // group / member: XCD-local groups under round-robin dispatch (block b -> XCD b % 8) when the group count allows it
+    int group, member;
+    {
+        const int bid = blockIdx.x;
+        if ((ngroups & 7) == 0) { const int q = bid >> 3; member = q % G; group = (q / G) * 8 + (bid & 7); }
+        else { member = bid % G; group = bid / G; }
+    }
+    const int dir = group >= ngb ? 1 : 0;
+    const float* __restrict__ w_hh = dir ? a.w_hh_r : a.w_hh_f;
+    const int u0 = member * RM_UW;
+
+    // ---- resident weights: wave = (N-tile pair np, K quarter kq4); tile column c -> unit 4 nt + c / 4, gate c % 4
+    const int np = wave & 3, kq4 = wave >> 2;
+    const int r16 = lane & 15, kq = lane >> 4;
+    PsPlanes<8> Wp[2][KS];
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int nt = 2 * np + j;
+        const long wrow = (long)(r16 & 3) * H + u0 + 4 * nt + (r16 >> 2);
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+            const float* src = w_hh + wrow * H + kq4 * C::KQ + ks * 32 + kq * 8;
+            const f32x4 w0 = ld4p(src), w1 = ld4p(src + 4);
+            const float v[8] = {w0[0], w0[1], w0[2], w0[3], w1[0], w1[1], w1[2], w1[3]};
+            Wp[j][ks] = ps_split<8>(v);
+        }
+    }
+    // ---- per batch: cell lanes (sequence cs, unit cu) for tid < 512; a half wave = the 32 units of one sequence = one 128-byte
+    //      line of `out`
+    const int cs = tid >> 5, cu = tid & 31;
+    int bbase[2], nvalid[2];
+    bool cell[2];
+    long seq[2];
+    float c[2] = {0.f, 0.f}, hlast[2] = {0.f, 0.f};
+    float pre[2][4];
+#pragma unroll
+    for (int bi = 0; bi < 2; ++bi) {
+        bbase[bi] = a.b0 + ((group - dir * ngb) * nbat + bi) * RM_NB;
+        nvalid[bi] = bi < nbat ? max(0, min(RM_NB, a.b0 + a.Bc - bbase[bi])) : 0;
+        cell[bi] = tid < RM_NB * RM_UW && cs < nvalid[bi];
+        const int cb = bbase[bi] + (cell[bi] ? cs : 0);
+        seq[bi] = ((long)dir * B + (cell[bi] ? cb : a.b0)) * T;          // row base in the (2, B, T, *) stash arrays
+#pragma unroll
+        for (int g = 0; g < 4; ++g) pre[bi][g] = 0.f;
+        if (cell[bi]) {
+            const float* gb = a.gates + seq[bi] * 4 * H + u0 + cu;
+            const int t0 = dir ? T - 1 : 0;
+#pragma unroll
+            for (int g = 0; g < 4; ++g) pre[bi][g] = gb[(long)t0 * 4 * H + g * H];
+        }
+    }
+    // ---- tile loader: lane -> (row lr, float4 column lc) of the 16 x H tile: exactly one float4 per lane at H = 256
+    constexpr int F4_PER_ROW = H / 4, TILE_F4 = RM_NB * F4_PER_ROW;
+    unsigned cep = 0;
+    if (tid < 4) cflags[tid] = 0u;
+    lds_barrier();
+    const bool l2x = !a.force_agent && rm_same_xcd<G>(a.idbuf + (size_t)group * 32, member, a.err, cflags + 4);
+
+    static_assert(TILE_F4 == RM_THREADS, "one float4 of the tile per lane");
+    const int tlr = tid / F4_PER_ROW, tlc = tid % F4_PER_ROW;
+    auto tile_src = [&](int bi, int tprev) {
+        return a.out + ((long)(bbase[bi] + (tlr < nvalid[bi] ? tlr : 0)) * T + tprev) * 2 * H + dir * H + tlc * 4;
+    };
+    unsigned pf[4] = {0u, 0u, 0u, 0u};
+    bool have_pf = false;
+
+    for (int step = 0; step < T; ++step) {
+        const int t = dir ? T - 1 - step : step;
+        const int tp = dir ? t + 1 : t - 1;
+#pragma unroll
+        for (int bi = 0; bi < 2; ++bi) {
+            if (nvalid[bi] == 0) continue;          // (uniform) no second batch, or an empty one
+            f32x4 acc[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+            if (bi == 0) RM_STAMP(0);
+            if (step > 0) {
+                // ---- h_{t-1} of the 16 sequences -> three bf16 planes in LDS
+                // Same XCD: every lane polls its own float4 straight away (the polls hit this XCD's L2: no fabric traffic, and one round
+                // trip less than canary-then-load).  Otherwise: canary first — wave 0, lane m watches producer m's last unit of the last
+                // valid row — so that the memory system does not carry 16 KB of polls per workgroup and round.
+                if (!l2x) {
+                    const int lrow = nvalid[bi] - 1;
+                    const unsigned* cp = reinterpret_cast<const unsigned*>(a.out + ((long)(bbase[bi] + lrow) * T + tp) * 2 * H + dir * H) + (lane < G ? lane * RM_UW + RM_UW - 1 : 0);
+                    wg_canary_wait(cflags, ++cep, 1, wave, lane, cp, lane < G, a.err, 0xDEAD0031u);
+                }
+                if (bi == 0) RM_STAMP(1);
+                {
+                    // this lane's float4 of the tile: prefetched during the other batch's half-round when two batches alternate
+                    f32x4 v;
+                    const float* src = tile_src(bi, tp);
+                    if (have_pf) {
+#pragma unroll
+                        for (int k = 0; k < 4; ++k) v[k] = __uint_as_float(pf[k]);
+                    } else {
+                        // same XCD: the producers' plain stores sit in this XCD's L2 — read past the L1 only; otherwise ordinary loads first
+                        v = l2x ? ld4_agent(src) : *reinterpret_cast<const f32x4*>(src);
+                    }
+                    if (has_sentinel(v)) {          // raced ahead of a producer's lines: re-read past the L1 / L2
+                        unsigned spins = 0;
+                        for (;;) {
+                            v = ld4_agent(src);
+                            if (!has_sentinel(v)) break;
+                            if (spin_expired(spins, a.err, 0xDEAD0032u)) break;
+                        }
+                    }
+                    unsigned p0[3], p1[3];
+                    ps_split_pair(v[0], v[1], p0[0], p0[1], p0[2]);
+                    ps_split_pair(v[2], v[3], p1[0], p1[1], p1[2]);
+#pragma unroll
+                    for (int pl = 0; pl < 3; ++pl) {
+                        ps_u32x2 w2 = {p0[pl], p1[pl]};
+                        *reinterpret_cast<ps_u32x2*>(hp3 + pl * PLANE + tlr * PLD + tlc * 2) = w2;
+                    }
+                }
+                lds_barrier();
+                if (bi == 0) RM_STAMP(2);
+                have_pf = false;
+                // ---- this wave's part of G_t = h_{t-1} W_hh^T: 16 sequences x 2 x 16 gate rows over its K quarter
+#pragma unroll
+                for (int ks = 0; ks < KS; ++ks) {
+                    PsPlanes<8> A;
+                    const unsigned* ar = hp3 + r16 * PLD + (kq4 * C::KQ + ks * 32 + kq * 8) / 2;
+#pragma unroll
+                    for (int pl = 0; pl < 3; ++pl) {
+                        const ps_u32x4 q = *reinterpret_cast<const ps_u32x4*>(ar + pl * PLANE);
+                        A.p[pl][0] = q[0]; A.p[pl][1] = q[1]; A.p[pl][2] = q[2]; A.p[pl][3] = q[3];
+                    }
+                    acc[0] = ps_mfma6<8>(A, Wp[0][ks], acc[0]);
+                    acc[1] = ps_mfma6<8>(A, Wp[1][ks], acc[1]);
+                }
+            }
+            if (nbat == 2) {
+                // the NEXT half-round's tile (the other batch: this step's for batch 1, the next step's for batch 0) was published a
+                // whole half-round ago: fetch it now, under the reduction / cell phases (four agent-scope dword loads, no wait here)
+                const int nb_i = bi ^ 1;
+                const int nstep = bi == 0 ? step : step + 1;
+                if (nvalid[nb_i] != 0 && nstep > 0 && nstep < T) {
+                    const int nt_ = dir ? T - 1 - nstep : nstep;
+                    const unsigned* src = reinterpret_cast<const unsigned*>(tile_src(nb_i, dir ? nt_ + 1 : nt_ - 1));
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) pf[k] = __hip_atomic_load(src + k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    have_pf = true;
+                }
+            }
+            if (bi == 0) RM_STAMP(3);
+            // ---- the four K quarters meet in LDS: D[row 4 kq + i][column r16]
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                float* rt = red + ((kq4 * 8 + 2 * np + j) * 16) * RLD;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) rt[(kq * 4 + i) * RLD + r16] = acc[j][i];
+            }
+            lds_barrier();
+            if (bi == 0) RM_STAMP(4);
+            if (cell[bi]) {
+                const float* r0 = red + (((cu >> 2) * 16) + cs) * RLD + (cu & 3) * 4;
+                f32x4 sg = *reinterpret_cast<const f32x4*>(r0);
+#pragma unroll
+                for (int q = 1; q < 4; ++q) {
+                    const f32x4 sq = *reinterpret_cast<const f32x4*>(r0 + q * 8 * 16 * RLD);
+                    sg[0] += sq[0]; sg[1] += sq[1]; sg[2] += sq[2]; sg[3] += sq[3];
+                }
+                const float ig = sigmoidf_acc(sg[0] + pre[bi][0]);
+                const float fg = sigmoidf_acc(sg[1] + pre[bi][1]);
+                const float gg = tanhf_acc(sg[2] + pre[bi][2]);
+                const float og = sigmoidf_acc(sg[3] + pre[bi][3]);
+                c[bi] = fg * c[bi] + ig * gg;
+                const float h = og * tanhf_acc(c[bi]);
+                const int cb = bbase[bi] + cs;
+                float* hp = a.out + ((long)cb * T + t) * 2 * H + dir * H + u0 + cu;          // the layer output IS the hand-off slab
+                if (l2x) __hip_atomic_store(reinterpret_cast<unsigned*>(hp), pub_bits(h), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                else st1_agent(hp, h);
+                float* gb = a.gates + seq[bi] * 4 * H + u0 + cu;
+                if (STASH) {
+                    a.hprev[(seq[bi] + t) * H + u0 + cu] = hlast[bi];
+                    a.cbuf[(seq[bi] + t) * H + u0 + cu] = c[bi];
+                    float* gp = gb + (long)t * 4 * H;
+                    gp[0] = ig; gp[H] = fg; gp[2 * H] = gg; gp[3 * H] = og;
+                }
+                hlast[bi] = h;
+                if (step + 1 < T) {      // next step's pre-activations: consumed a whole step from now
+                    const int tn = dir ? t - 1 : t + 1;
+#pragma unroll
+                    for (int g = 0; g < 4; ++g) pre[bi][g] = gb[(long)tn * 4 * H + g * H];
+                }
+            }
+            if (bi == 0) RM_STAMP(5);
+            // (the next tile's barrier separates these reads of `red` from its next writes)
+        }
+    }
+}
+
+}  // namespace
+
+// Eligibility: the shapes this form pays for.  Measured on MI355X, layer-0 forward at H = 256, T = 400 (tools/ubench_rec_mfma.py):
+// B = 128 1.26 ms (the VALU multi-utterance kernels: 1.27), 256 1.43 (2.33), 512 2.57 (4.38), 2048 9.8 (17.1).
+bool rec_fwd_mfma_eligible(int B, int H) {
+    if (opt_get(OPT_REC_MFMA) == 0) return false;
+    return H == 256 && B > 128;
+}
+
+int rec_fwd_mfma(float* gates, const float* w_hh_f, const float* w_hh_r, float* out, float* cbuf, float* hprev, int B, int T, int H,
+                 int stash, unsigned long long* xbuf, unsigned* err, hipStream_t stream) {
+    LAS_REQUIRE(H == 256, "rec_fwd_mfma shape");
+    LAS_REQUIRE(err != nullptr && xbuf != nullptr && (!stash || (cbuf && hprev)), "rec_fwd_mfma buffers");
+    using C = RecMfma<256>;
+    int dev = 0, cus = 0;
+    LAS_HIP_CHECK(hipGetDevice(&dev));
+    LAS_HIP_CHECK(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
+    const int groups_max = cus / (2 * C::G);            // groups per direction that are resident at once
+    if (groups_max < 1) return fail(LAS_ERR_UNSUPPORTED, "rec_fwd_mfma: %s%ld compute units are too few", "", (long)cus);
+    const size_t smem = sizeof(float) * C::LDS_FLOATS;
+    // one batch of 16 sequences per group while that covers the launch; beyond it two batches per group, stepped alternately
+    const int nbat = B > groups_max * RM_NB ? 2 : 1;
+    const int chunk = groups_max * RM_NB * nbat;
+    // the output buffer is the hand-off slab: sentinel-fill it (every element is overwritten by exactly one cell lane)
+    LAS_HIP_CHECK(hipMemsetAsync(out, 0xFF, sizeof(float) * (size_t)B * T * 2 * H, stream));
+    for (int b0 = 0; b0 < B; b0 += chunk) {
+        const int Bc = std::min(chunk, B - b0);
+        const int grid = 2 * ((Bc + nbat * RM_NB - 1) / (nbat * RM_NB)) * C::G;
+        // id slots of the placement check: 32 per group, zeroed per launch (rec_xbuf_bytes covers 2 (B + 15) groups)
+        LAS_HIP_CHECK(hipMemsetAsync(xbuf, 0, sizeof(unsigned long long) * 32 * (size_t)(grid / C::G), stream));
+        RecMfmaArgs a{gates, w_hh_f, w_hh_r, out, cbuf, hprev, B, T, b0, Bc, err, nbat, xbuf, (int)opt_get(OPT_REC_AGENT_HANDOFF)};
+        if (stash) {
+            if (!persistent_launch_fits(rec_fwd_mfma_kernel<256, true>, RM_THREADS, smem, grid))
+                return fail(LAS_ERR_UNSUPPORTED, "rec_fwd_mfma: %s%ld workgroups cannot all be resident", "", (long)grid);
+            hipLaunchKernelGGL((rec_fwd_mfma_kernel<256, true>), dim3(grid), dim3(RM_THREADS), smem, stream, a);
+        } else {
+            if (!persistent_launch_fits(rec_fwd_mfma_kernel<256, false>, RM_THREADS, smem, grid))
+                return fail(LAS_ERR_UNSUPPORTED, "rec_fwd_mfma: %s%ld workgroups cannot all be resident", "", (long)grid);
+            hipLaunchKernelGGL((rec_fwd_mfma_kernel<256, false>), dim3(grid), dim3(RM_THREADS), smem, stream, a);
+        }
+        LAS_LAUNCH_CHECK();
+    }
+    return LAS_OK;
+}
+
+}  // namespace las

@@ -239,6 +239,42 @@ def test_multi_utterance_recurrence_matches_generic(H, B, T):
         assert_close(res[0][k], res[1][k], f"multi-utterance recurrence H={H} B={B}: {k}", rtol=1e-3, atol=2e-5 * scale)
 
 
+@pytest.mark.parametrize("B,T", [(144, 12), (300, 10), (130, 6)])
+def test_matrix_pipe_recurrence_matches_generic(B, T):
+    """Batches above 128 utterances at H = 256: the forward recurrence runs 16 utterances per group as MFMA tiles on the bf16 matrix
+    pipe (pblstm_rec_mfma.hip; partial last batch at B = 144 / 130, two alternating batches per group and a partial one at B = 300).
+    Forward output and — through the stash it leaves — dx and all eight parameter gradients against the generic kernels; with the
+    option switched off the VALU multi-utterance kernels must give the same."""
+    import las_pytorch_amd
+    from las_pytorch_amd import _cabi, pBLSTMLayer
+    from las_pytorch_amd.model.las_model import set_force_generic
+    torch.manual_seed(B)
+    H, D = 256, 24
+    layer = pBLSTMLayer(D, H).cuda()
+    x0 = torch.randn(B, 2 * T, D, device="cuda")
+    w = torch.randn(B, T, 2 * H, device="cuda")
+    res = []
+    for force, mfma in ((False, 1), (True, 1), (False, 0)):
+        set_force_generic(layer, force)
+        _cabi.set_option("REC_MFMA", mfma)
+        try:
+            layer.zero_grad(set_to_none=True)
+            x = x0.clone().requires_grad_(True)
+            out, _ = layer(x)
+            (out * w).sum().backward()
+        finally:
+            _cabi.set_option("REC_MFMA", 1)
+        res.append(dict(out=out.detach().cpu().numpy(), dx=x.grad.cpu().numpy(),
+                        **{n: p.grad.cpu().numpy() for n, p in layer.named_parameters()}))
+    torch.cuda.synchronize()
+    las_pytorch_amd.check_device_errors()
+    for k in res[0]:
+        scale = float(np.abs(res[1][k]).max()) + 1e-30
+        assert_close(res[0][k], res[1][k], f"matrix-pipe recurrence B={B}: {k}", rtol=1e-3, atol=2e-5 * scale)
+        assert_close(res[2][k], res[1][k], f"VALU multi-utterance recurrence B={B}: {k}", rtol=1e-3, atol=2e-5 * scale)
+    assert float(np.abs(res[0]["out"] - res[1]["out"]).max()) < 5e-6      # fp32-faithful: the split-operand product is no bf16 product
+
+
 def test_multi_utterance_recurrence_vs_oracle():
     """P listener at B=40 (two utterances per group at H=256) against the CPU oracle, forward and gradients."""
     import las_pytorch_amd
