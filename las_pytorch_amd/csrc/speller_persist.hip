@@ -839,8 +839,11 @@ struct AttnPreRole {
     static constexpr int EP = (MAX_TP + 63) & ~63;       // energies padded to whole waves (pad = -inf)
     static constexpr int NJ = HS / 64;
     static_assert(TS == 8 || TS == 16 || TS == 32, "time-slice layout");
-    static constexpr int NJR = NJ / 2;                   // float4 of a W_phi row slice kept in registers; the other half lives in LDS
-    static __host__ __device__ constexpr int lds_floats(int Tp) { return HS + PS_M + EP + MAX_TP + 2 * GC + Tp * PS_KLD + PS_M * (HS / 2); }
+    // float4 of a W_phi row slice kept in registers; the rest lives in LDS.  With 16 workgroups per utterance (T' up to 448: the keys
+    // alone take up to 122 KB of LDS) all of it stays in registers and R0 is fetched with a blocking load instead
+    static constexpr int NJR = WS == 16 ? NJ : NJ / 2;
+    static constexpr bool R0_BLOCKING = WS == 16;
+    static __host__ __device__ constexpr int lds_floats(int Tp) { return HS + PS_M + EP + MAX_TP + 2 * GC + Tp * PS_KLD + PS_M * 4 * (NJ - NJR) * 16; }
 
     static __device__ void run(const PersistArgs& a, float* smem, const int widx) {
         const int b = widx / SPLIT, part_id = widx % SPLIT;
@@ -881,7 +884,7 @@ struct AttnPreRole {
         for (int j = 0; j < NJR; ++j) wphi[j] = ld4p(a.w_phi + (size_t)prow * HS + 4 * (pk + 16 * j));
 #pragma unroll
         for (int j = NJR; j < NJ; ++j)
-            *reinterpret_cast<f32x4*>(wpl + prow * (HS / 2) + 4 * (pk + 16 * (j - NJR))) = ld4p(a.w_phi + (size_t)prow * HS + 4 * (pk + 16 * j));
+            *reinterpret_cast<f32x4*>(wpl + prow * (64 * (NJ - NJR)) + 4 * (pk + 16 * (j - NJR))) = ld4p(a.w_phi + (size_t)prow * HS + 4 * (pk + 16 * j));
         const float bphi = a.b_phi[prow];
         lds_barrier();
 
@@ -968,8 +971,8 @@ struct AttnPreRole {
                 float acc = 0.f;
 #pragma unroll
                 for (int j = 0; j < NJR; ++j) acc = dot4p(wphi[j], *reinterpret_cast<const f32x4*>(hs + 4 * (pk + 16 * j)), acc);
-                {
-                    const float* wr = at_bytes(wpl, opaque(4u * (unsigned)(prow * (HS / 2) + 4 * pk)));
+                if (NJR < NJ) {
+                    const float* wr = at_bytes(wpl, opaque(4u * (unsigned)(prow * (64 * (NJ - NJR)) + 4 * pk)));
 #pragma unroll
                     for (int j = NJR; j < NJ; ++j)
                         acc = dot4p(*reinterpret_cast<const f32x4*>(wr + 64 * (j - NJR)), *reinterpret_cast<const f32x4*>(hs + 4 * (pk + 16 * j)), acc);
@@ -985,7 +988,7 @@ struct AttnPreRole {
             lds_barrier();
             PS_STAMP(1, s, 2);
             unsigned rv[4];
-            if (s + 1 < U) r0_issue(s + 1, rv);
+            if (!R0_BLOCKING && s + 1 < U) r0_issue(s + 1, rv);
             // ---- energies e[t] = q . keys[t]: 8 lanes per frame
             {
                 const int sub = tid & 7;
@@ -1044,6 +1047,7 @@ struct AttnPreRole {
             }
             // ---- bottom cell of step s+1 and its hand-off to the top layer
             if (s + 1 < U) {
+                if (R0_BLOCKING) r0_issue(s + 1, rv);
                 r0_land(s + 1, rv);
                 lds_barrier();
                 PS_STAMP(2, s + 1, 0);
