@@ -443,152 +443,240 @@ struct CellRole {
 // Teacher forcing with the pre-multiplied context (AttnPreRole below): the attention workgroups own the BOTTOM cell, this role runs
 // the TOP cell and prepares what the bottom cell needs besides the context term,
 //     R0_s = W_hh0 h0_{s-1} + W_y y_s + b_ih0 + b_hh0            (the "recurrent / label / bias part" of the bottom-layer gates),
-// published per workgroup as a tile [32 utterances][4 units x 4 gates] (whole 128-byte lines) a whole attention phase ahead of its
-// use.  Chain per decode step:  attention + bottom cell -> h0_s slab -> W_ih1 product, reduce, top cell -> h1_s : TWO cross-CU hops
-// (three when the bottom cell lived here and waited for the published context term).
-//   * the three resident matrices (W_ih1, W_hh1, W_hh0 rows of this workgroup's 4 units) are split ONCE into bf16 planes and every
-//     product runs on the bf16 matrix pipe (persist_common.h: exact three-way split, six partial products, fp32 accumulation): a
-//     SIMD's four waves spend 0.3 us instead of 0.85 us of matrix-pipe time per product;
-//   * the label half W_y y_s is a 32-wide dot product per (utterance, gate row) from LDS (W_y rows and the step's label rows),
-//     computed by the R0 lanes — no MFMA, no resident operand;
-//   * one LDS exchange per step serves both layers: every wave drops its partial tiles of the top layer's gates and of the next
-//     step's R0 (same h0_s tile, still in registers), ONE barrier, then waves 0-1 reduce / apply / publish the top cell while
-//     waves 2-3 reduce and publish R0.
+// published per workgroup as a tile [16 utterances][8 units x 4 gates] (whole 128-byte lines) a whole attention phase ahead of its
+// use.  Chain per decode step:  attention + bottom cell -> h0_s slab -> W_ih1 product, reduce, top cell -> h1_s : TWO cross-CU hops.
+//   * partition: a workgroup owns EIGHT hidden units (two 16-column gate tiles) for SIXTEEN utterances (one 16-row M-tile), i.e. it
+//     pulls a (16, Hs) tile of h0_s per step — 32 KB.  The first version of this role (4 units x 32 utterances, 64 KB per step) spent
+//     0.6 us longer in the product: a CU takes in freshly written lines at ~32 B/clk, so bytes-in per workgroup, not matrix-pipe
+//     work (identical: two 16x16 output tiles either way), is what the last of the 16 waves waits for;
+//   * every product runs on the bf16 matrix pipe (persist_common.h: exact three-way split, six partial products, fp32 accumulation).
+//     W_ih1 (on the chain) lives in registers as bf16 planes; W_hh0 (R0: needed by the attention workgroups before their weighted sum
+//     ends) as bf16 planes in LDS; W_hh1 (needed last) as fp32 in registers, split again in every step — three resident split
+//     matrices do not fit the 128 registers a lane has at 1024 threads;
+//   * the label half W_y y_s + biases comes from ONE GEMM before the launch (a.yw) and is staged in LDS a step ahead;
+//   * one LDS exchange buffer serves both layers in turn: top-layer gates -> barrier -> waves 0-1 reduce / apply / publish the top
+//     cell; then R0's product (same h0_s tile, still in registers) -> barrier -> waves 2-3 reduce and publish R0.
 template <int HS>
 struct CellPreRole {
-    using Base = CellRole<HS, false>;
-    static constexpr int NF = Base::NF, RLD = Base::RLD, RED = Base::RED;
-    static constexpr int NK = Base::NK;
-    // ONE reduction buffer (both layers take turns), biases, canary flags, W_y rows, label rows (2 steps), label halves (2 steps), and
-    // the bf16 planes of W_hh0 and W_hh1: their products are off the chain, and three resident split matrices do not fit the
-    // 128 registers a lane has at 1024 threads — only W_ih1, whose product IS the chain, stays in registers
-    static constexpr int WPL = 3 * (NK / 2) * PS_THREADS;      // dwords of one matrix' bf16 planes
-    static constexpr int LDS_FLOATS = RED + 4 * 128 + 4 + 2 * 128 * 4 + 2 * WPL + 32;      // (+32: per-wave stamps of a PS_WAVE_TRACE build)
-    using TileAddr = typename Base::TileAddr;
-    using WSplit = typename Base::WSplit;
+    static constexpr int NF = HS / 256;                 // 16-wide k-blocks of an Hs-wide operand per wave
+    static constexpr int NK = 4 * NF;
+    static constexpr int RLD = 36;                      // row stride of a partial tile: 32 columns + pad, 16-byte aligned
+    static constexpr int RED = PS_NW * 16 * RLD;
+    static constexpr int WPL = 2 * 3 * (NK / 2) * PS_THREADS;      // dwords of one matrix' bf16 planes (two column tiles)
+    static constexpr int LDS_FLOATS = RED + 4 * 128 + 4 + 2 * 128 * 4 + WPL + 32;
+    static constexpr int NWG = 2 * (HS / 8);
+    using WSplit = PsPlanes<NK>;
+
+    struct TileAddr {
+        unsigned x[NF], hx[NF];      // (bytes) this lane's float4 of k-block f in the row-major h0 slab / the tiled h1 slab
+        bool ok;                     // its row is an utterance
+        unsigned canary[2];
+        bool cact[2];
+        int npw1;
+    };
+    // acc[nt] += tile . W[nt]   (see CellRole::poll_mul: canary, plain loads, speculative product, sentinel check, repair)
+    template <int KIND, class WF>
+    static __device__ __forceinline__ int poll_mul(const float* base, const TileAddr& t, f32x4 (&x)[NF], const WF& wf, f32x4 (&acc)[2],
+                                                   unsigned* err, volatile unsigned* flags, unsigned& ep) {
+        unsigned spins = 0;
+        int slow = 0;
+        {
+            constexpr int K = KIND == 0 ? 0 : 1;
+            const int npw = KIND == 0 ? 1 : t.npw1;
+            const unsigned* cp = reinterpret_cast<const unsigned*>(at_bytes(base, opaque(t.canary[K])));
+            wg_canary_wait(flags, ++ep, npw, __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), threadIdx.x & 63, cp, t.cact[K], err, 0xDEAD0011u);
+        }
+        asm volatile("" ::: "memory");
+#pragma unroll
+        for (int f = 0; f < NF; ++f) x[f] = *reinterpret_cast<const f32x4*>(at_bytes(base, opaque(KIND == 0 ? t.hx[f] : t.x[f])));
+        const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
+        f32x4 p[2] = {zero, zero};
+        mul(x, wf, p);
+        bool need[NF];
+        bool bad = false;
+#pragma unroll
+        for (int f = 0; f < NF; ++f) { need[f] = __any(t.ok && has_sentinel(x[f])); bad |= need[f]; }
+        asm volatile("" ::: "memory");
+        const bool redo = bad;
+        while (bad) {
+            if (spin_expired(spins, err, 0xDEAD0012u)) break;
+            bad = false;
+            ++slow;
+#pragma unroll
+            for (int f = 0; f < NF; ++f)
+                if (need[f]) {
+                    x[f] = ld4_agent(at_bytes(base, opaque(KIND == 0 ? t.hx[f] : t.x[f])));
+                    need[f] = __any(t.ok && has_sentinel(x[f]));
+                    bad |= need[f];
+                }
+        }
+        if (redo) { p[0] = p[1] = zero; mul(x, wf, p); }
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) acc[nt][i] += p[nt][i];
+        return slow;
+    }
+    template <class WF>
+    static __device__ __forceinline__ void mul(const f32x4 (&x)[NF], const WF& wf, f32x4 (&acc)[2]) {
+        float v[NK];
+#pragma unroll
+        for (int f = 0; f < NF; ++f)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[f * 4 + e] = x[f][e];
+        const WSplit xs = ps_split<NK>(v);
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt) acc[nt] = ps_mfma6<NK>(xs, wf(nt), acc[nt]);
+    }
 
     static __device__ void run(const PersistArgs& a, float* smem) {
-        const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);      // wave: scalar register
+        const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
         const int r = lane & 15, kq = lane >> 4;
-        const int j0 = blockIdx.x * 4;
+        const int j8 = blockIdx.x >> 1, mh = blockIdx.x & 1;           // its 8 units start at 8 j8; its utterances at 16 mh
         const bool first_wg = blockIdx.x == 0;
         const int B = a.B, U = a.U;
-        const long wrow = (long)(r >> 2) * HS + j0 + (r & 3);       // tile column n = gate*4 + unit
-        const int kwave = wave;
+        const int nrows = min(16, B - 16 * mh);
+        if (nrows <= 0) return;                                         // B <= 16: the second half of the workgroups has no utterances
         const size_t sH = (size_t)B * HS;
         constexpr size_t HXS = (size_t)32 * HS;
-        float* bias = smem + RED;                     // [gate][cell lane]: b_ih1 + b_hh1 (the bottom layer's biases ride in a.yw)
+        float* bias = smem + RED;                     // [gate][cell lane]: b_ih1 + b_hh1
         volatile unsigned* cflags = reinterpret_cast<volatile unsigned*>(smem + RED + 4 * 128);
-        float* ywl = smem + RED + 4 * 128 + 4;        // [step parity][R0 lane][4 gates]: label half + bias of the bottom-layer gates
-        unsigned* wl = reinterpret_cast<unsigned*>(ywl + 2 * 128 * 4);     // [matrix: W_hh0, W_hh1][plane][thread][NK / 2]
+        float* ywl = smem + RED + 4 * 128 + 4;        // [step parity][R0 lane][4 gates]
+        unsigned* wl = reinterpret_cast<unsigned*>(ywl + 2 * 128 * 4);     // W_hh0: [column tile][plane][thread][NK / 2]
 
-        // ---- weights, split once: W[wrow][16*blk + 4*kq + e]
-        WSplit Si1;
-        {
-            float wi1[NF][4], wh0[NF][4], wh1[NF][4];
+        // ---- weights: column n of tile nt = gate n / 4 of unit 8 j8 + 4 nt + n % 4;  W[row][16*blk + 4*kq + e]
+        WSplit Si1[2];
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt) {
+            const long wrow = (long)(r >> 2) * HS + j8 * 8 + nt * 4 + (r & 3);
+            float wi1[NK], wh0[NK];
 #pragma unroll
             for (int f = 0; f < NF; ++f) {
-                const int k = (kwave * NF + f) * 16 + kq * 4;
-                const f32x4 h0 = ld4p(a.w_hh0 + wrow * HS + k), i1 = ld4p(a.w_ih1 + wrow * HS + k), h1 = ld4p(a.w_hh1 + wrow * HS + k);
+                const int k = (wave * NF + f) * 16 + kq * 4;
+                const f32x4 h0 = ld4p(a.w_hh0 + wrow * HS + k), i1 = ld4p(a.w_ih1 + wrow * HS + k);
 #pragma unroll
-                for (int e = 0; e < 4; ++e) { wh0[f][e] = h0[e]; wi1[f][e] = i1[e]; wh1[f][e] = h1[e]; }
+                for (int e = 0; e < 4; ++e) { wh0[f * 4 + e] = h0[e]; wi1[f * 4 + e] = i1[e]; }
             }
-            Si1 = Base::split_w(wi1);
-            const WSplit S0 = Base::split_w(wh0), S1 = Base::split_w(wh1);
+            Si1[nt] = ps_split<NK>(wi1);
+            const WSplit S0 = ps_split<NK>(wh0);
 #pragma unroll
             for (int pl = 0; pl < 3; ++pl)
 #pragma unroll
-                for (int i = 0; i < NK / 2; ++i) {
-                    wl[(pl * PS_THREADS + tid) * (NK / 2) + i] = S0.p[pl][i];
-                    wl[WPL + (pl * PS_THREADS + tid) * (NK / 2) + i] = S1.p[pl][i];
-                }
+                for (int i = 0; i < NK / 2; ++i) wl[((nt * 3 + pl) * PS_THREADS + tid) * (NK / 2) + i] = S0.p[pl][i];
         }
-        auto load_w = [&](int m) {           // m = 0: W_hh0, 1: W_hh1
+        auto w_i1 = [&](int nt) -> const WSplit& { return Si1[nt]; };
+        auto w_h0 = [&](int nt) {            // re-read per step, not kept in registers
             WSplit w;
-            const unsigned* src = at_bytes(wl + m * WPL, opaque(4u * (unsigned)tid * (NK / 2)));      // opaque: re-read per step, not kept in registers
+            const unsigned* src = at_bytes(wl + nt * 3 * PS_THREADS * (NK / 2), opaque(4u * (unsigned)tid * (NK / 2)));
 #pragma unroll
             for (int pl = 0; pl < 3; ++pl)
 #pragma unroll
                 for (int i = 0; i < NK / 2; ++i) w.p[pl][i] = src[pl * PS_THREADS * (NK / 2) + i];
             return w;
         };
+        // W_hh1: 64 KB of fp32 per workgroup that neither the registers nor the LDS have room for — re-read from the L2 in every step
+        // (its product waits for h1_s anyway; the offsets are opaque so that the loads are not hoisted back into registers)
+        auto w_h1 = [&](int nt) {
+            const unsigned ln = opaque((unsigned)tid) & 63u, rr = ln & 15u, kk = ln >> 4;
+            const float* src = a.w_hh1 + ((size_t)(j8 * 8 + nt * 4) * HS + (size_t)wave * NF * 16);
+            float v[NK];
+#pragma unroll
+            for (int f = 0; f < NF; ++f) {
+                const f32x4 h1 = ld4p(at_bytes(src, 4u * (((rr >> 2) * HS + (rr & 3)) * HS + f * 16 + kk * 4)));
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[f * 4 + e] = h1[e];
+            }
+            return ps_split<NK>(v);
+        };
         if (tid < 128) {
-            const int pu = tid & 3;
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
-                const int row = g * HS + j0 + pu;
+                const int row = g * HS + j8 * 8 + (tid & 7);
                 bias[g * 128 + tid] = a.b_ih1[row] + a.b_hh1[row];
             }
         }
         const int rcol = (r & 3) * 4 + (r >> 2);        // tile column (gate*4 + unit) stored as unit*4 + gate
         auto write_red = [&](const f32x4 (&acc)[2]) {
-            float (*red)[2][16][RLD] = reinterpret_cast<float (*)[2][16][RLD]>(smem);
+            float (*red)[16][RLD] = reinterpret_cast<float (*)[16][RLD]>(smem);
 #pragma unroll
-            for (int mt = 0; mt < 2; ++mt)
+            for (int nt = 0; nt < 2; ++nt)
 #pragma unroll
-                for (int i = 0; i < 4; ++i) red[wave][mt][kq * 4 + i][rcol] = acc[mt][i];
+                for (int i = 0; i < 4; ++i) red[wave][kq * 4 + i][nt * 16 + rcol] = acc[nt][i];
         };
-        // reduced gates of cell lane lt = (utterance lt / 4, unit lt % 4)
+        // reduced gates of cell lane lt = (utterance lt / 8, unit lt % 8)
         auto read_red = [&](unsigned lt) -> f32x4 {
-            float (*red)[2][16][RLD] = reinterpret_cast<float (*)[2][16][RLD]>(smem);
-            const unsigned lb = lt >> 2, lu = lt & 3;
+            float (*red)[16][RLD] = reinterpret_cast<float (*)[16][RLD]>(smem);
+            const unsigned lb = lt >> 3, lu = lt & 7;
             f32x4 g4 = {0.f, 0.f, 0.f, 0.f};
-            // four partial tiles in flight at a time: all sixteen at once (what the scheduler prefers) cost 64 registers and spill
 #pragma unroll
             for (int w0 = 0; w0 < PS_NW; w0 += 4) {
 #pragma unroll
                 for (int w = w0; w < w0 + 4; ++w) {
-                    const f32x4 v = *reinterpret_cast<const f32x4*>(&red[w][(lb >> 4) & 1][lb & 15][lu * 4]);
+                    const f32x4 v = *reinterpret_cast<const f32x4*>(&red[w][lb][lu * 4]);
                     g4[0] += v[0]; g4[1] += v[1]; g4[2] += v[2]; g4[3] += v[3];
                 }
             }
             return g4;
         };
-        // waves 2-3 (R0 lane t = (utterance, unit)): label half + bias of step s (a.yw = y_s W_y^T + b_ih0 + b_hh0 for every step, one
-        // GEMM before the launch, columns in this role's unit*4 + gate order) -> LDS, a step ahead of its use (off the chain)
         auto label_half = [&](int s) {
             const unsigned t = opaque((unsigned)tid) - 128u;
-            if (t < 128u && (int)(t >> 2) < B)
+            if (t < 128u && (int)(t >> 3) < nrows)
                 *reinterpret_cast<f32x4*>(ywl + ((s & 1) * 128 + t) * 4) =
-                    ld4p(at_bytes(a.yw + (size_t)s * B * (4 * HS), 4u * ((t >> 2) * (4 * HS) + (unsigned)blockIdx.x * 16 + (t & 3) * 4)));
+                    ld4p(at_bytes(a.yw + (size_t)s * B * (4 * HS), 4u * ((16u * mh + (t >> 3)) * (4 * HS) + ((unsigned)j8 * 8 + (t & 7)) * 4)));
         };
-        // R0 of step s from waves 2-3: reduced recurrent half (not at step 0: h0_{-1} = 0) + the label half prepared in LDS
         auto publish_r0 = [&](int s, bool with_red) {
             const unsigned t = opaque((unsigned)tid) - 128u;
-            if (t < 128u && (int)(t >> 2) < B) {
+            if (t < 128u && (int)(t >> 3) < nrows) {
                 f32x4 g4 = *reinterpret_cast<const f32x4*>(ywl + ((s & 1) * 128 + t) * 4);
                 if (with_red) {
                     const f32x4 v = read_red(t);
                     g4[0] += v[0]; g4[1] += v[1]; g4[2] += v[2]; g4[3] += v[3];
                 }
-                st4_agent(at_bytes(a.r0x + (size_t)s * ((size_t)(HS / 4) * 32 * 16), 4u * (((unsigned)blockIdx.x * 128 + t) * 4)), g4);
+                st4_agent(at_bytes(a.r0x + (size_t)s * ((size_t)NWG * 128 * 4), 4u * (((unsigned)blockIdx.x * 128 + t) * 4)), g4);
             }
         };
-        // top cell of lane tid < 128: apply, publish h1_s (tiled hand-off copy), stash
         float c1 = 0.f;
         auto top_cell = [&](f32x4 g4, int s) {
-            const unsigned tq = opaque((unsigned)tid), pbq = tq >> 2, puq = tq & 3;
-            if ((int)pbq < B) {
+            const unsigned tq = opaque((unsigned)tid), pbq = 16u * mh + (tq >> 3), unit = (unsigned)j8 * 8 + (tq & 7);
+            if ((int)(tq >> 3) < nrows) {
 #pragma unroll
                 for (int g = 0; g < 4; ++g) g4[g] += bias[g * 128 + tq];
                 const float ig = sigmoidf_acc(g4[0]), fg = sigmoidf_acc(g4[1]), gg = tanhf_acc(g4[2]), og = sigmoidf_acc(g4[3]);
                 c1 = fg * c1 + ig * gg;
                 const float h = og * tanhf_acc(c1);
                 const size_t slab = ((size_t)U + s) * sH;
-                const unsigned o = 4u * (pbq * HS + j0 + puq);
-                st1_agent(at_bytes(a.hx + ((size_t)U + s) * HXS, 4u * (((unsigned)blockIdx.x * 32 + pbq) * 4 + puq)), h);
+                const unsigned o = 4u * (pbq * HS + unit);
+                st1_agent(at_bytes(a.hx + ((size_t)U + s) * HXS, 4u * (((unit >> 2) * 32 + pbq) * 4 + (unit & 3))), h);
                 *at_bytes(a.h_all + slab, o) = h;
                 *at_bytes(a.c_all + slab, o) = c1;
-                float* go = at_bytes(a.gates_all + 4 * slab, 4u * (pbq * 4 * HS + j0 + puq));
+                float* go = at_bytes(a.gates_all + 4 * slab, 4u * (pbq * 4 * HS + unit));
                 go[0] = ig; go[HS] = fg; go[2 * HS] = gg; go[3 * HS] = og;
             }
         };
 
+        TileAddr ta;
+        {
+            ta.ok = r < nrows;
+            const int row = 16 * mh + (ta.ok ? r : 0);
+#pragma unroll
+            for (int f = 0; f < NF; ++f) {
+                ta.x[f] = 4u * (row * HS + (wave * NF + f) * 16 + kq * 4);
+                ta.hx[f] = 4u * ((((wave * NF + f) * 4 + kq) * 32 + row) * 4);
+            }
+            // KIND 0: producer p = the cell workgroup of units 8p.. for these utterances; watch its last unit of the last row
+            const int p0 = wave * 64 + lane;
+            ta.cact[0] = p0 < HS / 8;
+            ta.canary[0] = 4u * ((((ta.cact[0] ? p0 : 0) * 2 + 1) * 32 + 16 * mh + nrows - 1) * 4 + 3);
+            // KIND 1: producer p = attention workgroup (utterance 16 mh + p / split, column part p % split)
+            ta.npw1 = (a.split * nrows + 63) / 64;
+            ta.cact[1] = p0 < a.split * nrows;
+            const int pb = 16 * mh + (ta.cact[1] ? p0 / a.split : 0), pp = p0 % a.split;
+            ta.canary[1] = 4u * (pb * HS + (pp + 1) * (HS / a.split) - 1);
+        }
         const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
         f32x4 accR0[2], accR1[2];
         accR1[0] = accR1[1] = zero;
-        f32x4 x[NF][2];
-        const TileAddr ta = Base::tile_addr(B, a.split, wave, lane);
+        f32x4 x[NF];
         unsigned cep = 0;
         if (tid < 4) cflags[tid] = 0u;
         label_half(0);
@@ -600,31 +688,17 @@ struct CellPreRole {
             const bool more = s + 1 < U;
             PS_STAMP(0, s, 0);
             // top layer: gates = W_ih1 h0_s + W_hh1 h1_{s-1}; h0_s arrives from the attention workgroups as a row-major (B, Hs) slab
-            nslow[0] += Base::template poll_mul<1>(a.hx + (size_t)s * HXS, ta, x, Si1, accR1, a.err, cflags, cep);
+            nslow[0] += poll_mul<1>(a.hx + (size_t)s * HXS, ta, x, w_i1, accR1, a.err, cflags, cep);
             PS_STAMP(0, s, 4);
-#ifdef PS_WAVE_TRACE
-            if (a.trace && first_wg && lane == 0) reinterpret_cast<unsigned long long*>(smem + LDS_FLOATS - 32)[wave] = wall_clock64();
-#endif
             write_red(accR1);
             lds_barrier();
             PS_STAMP(1, s, 6);
-#ifdef PS_WAVE_TRACE
-            if (a.trace && first_wg && tid == 0) {
-                const unsigned long long* wt = reinterpret_cast<const unsigned long long*>(smem + LDS_FLOATS - 32);
-                unsigned long long mx = 0; int mi = 0;
-                for (int w = 0; w < PS_NW; ++w) if (wt[w] > mx) { mx = wt[w]; mi = w; }
-                a.trace[((size_t)0 * a.U + s) * 8 + 1] = mx;
-                a.trace[((size_t)0 * a.U + s) * 8 + 2] = (unsigned long long)mi;
-                a.trace[((size_t)0 * a.U + s) * 8 + 3] = wt[1];
-            }
-#endif
             if (tid < 128) top_cell(read_red(opaque((unsigned)tid)), s);
             PS_STAMP(0, s, 5);
             if (!more) break;
-            // ---- off the chain (the attention workgroups are working now)
-            // next step's bottom-layer gates without the context half, from the h0_s tile still in registers
+            // ---- off the chain (the attention workgroups are working now): next step's R0 from the h0_s tile still in registers
             accR0[0] = accR0[1] = zero;
-            Base::mfma_tile(x, load_w(0), accR0);
+            mul(x, w_h0, accR0);
             lds_barrier();                       // the top-cell lanes have left the reduction buffer
             write_red(accR0);
             lds_barrier();
@@ -633,7 +707,7 @@ struct CellPreRole {
             PS_STAMP(0, s, 6);
             // the top layer's recurrent half
             accR1[0] = accR1[1] = zero;
-            nslow[2] += Base::template poll_mul<0>(a.hx + ((size_t)U + s) * HXS, ta, x, load_w(1), accR1, a.err, cflags, cep);
+            nslow[2] += poll_mul<0>(a.hx + ((size_t)U + s) * HXS, ta, x, w_h1, accR1, a.err, cflags, cep);
             PS_STAMP(0, s, 7);
         }
         if (a.trace && first_wg && tid == 0)
@@ -900,8 +974,9 @@ struct AttnPreRole {
         // cell's lanes through LDS; a slot that was not complete yet is re-polled when it is consumed
         const bool rlane = tid >= HS / 4 && tid < HS / 4 + CG;
         auto r0_src = [&](int s) {
-            const int u = part_id * CG + (rlane ? tid - HS / 4 : 0);
-            return at_bytes(a.r0x + (size_t)s * R0S, opaque(4u * ((((unsigned)(u >> 2) * 32 + b) * 4 + (u & 3)) * 4)));
+            // cell workgroup (u / 8, b / 16) publishes a tile [16 utterances][8 units x 4 gates]; offsets re-derived per use (opaque)
+            const unsigned u = part_id * CG + (rlane ? opaque((unsigned)tid) - HS / 4 : 0u);
+            return at_bytes(a.r0x + (size_t)s * R0S + ((size_t)(b >> 4) * 16 + (b & 15)) * 32, ((u & ~7u) << 9) + ((u & 7u) << 4));
         };
         auto r0_issue = [&](int s, unsigned (&rv)[4]) {
             const unsigned* src = reinterpret_cast<const unsigned*>(r0_src(s));
@@ -1062,8 +1137,8 @@ template <int HS, int WS>
 __global__ __launch_bounds__(PS_THREADS) void speller_persist_fwd_pre_kernel(PersistArgs a) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     constexpr int NC = HS / 4;
-    if ((int)blockIdx.x < NC) CellPreRole<HS>::run(a, smem);
-    else AttnPreRole<HS, WS>::run(a, smem, blockIdx.x - NC);
+    if ((int)blockIdx.x >= NC) AttnPreRole<HS, WS>::run(a, smem, blockIdx.x - NC);
+    else CellPreRole<HS>::run(a, smem);
 }
 
 template <int HS, int SPLIT, bool GREEDY>
