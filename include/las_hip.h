@@ -36,7 +36,7 @@
 extern "C" {
 #endif
 
-#define LAS_ABI_VERSION 5
+#define LAS_ABI_VERSION 6
 #define LAS_MAX_SPELLER_LAYERS 4
 
 /* flags */
@@ -139,6 +139,13 @@ typedef struct las_speller_grads {           /* all OVERWRITTEN by las_speller_b
 int las_attn_keys_fwd(const las_speller_desc* d, const float* feat, float* keys, void* stream);
 
 size_t las_speller_reserve_floats(const las_speller_desc* d, int U);
+
+/* Utterances per launch of the one-launch decode kernels for this description (d->B is ignored): the largest batch for which
+ * las_speller_fwd / las_speller_bwd take the persistent path (today 32, or 0 when the shape, the decode mode or a switch rules it
+ * out).  A caller with a larger batch gains by running the Speller in slices of that many utterances — every slice then decodes
+ * in one launch instead of U per-step launch chains (las_pytorch_amd/model/las_model.py::Speller._run does; the reference's loop
+ * model/las_model.py:205-236 has no such notion).  Pure function of its arguments, the option registry and the device's CU count. */
+int las_speller_decode_batch(const las_speller_desc* d, int teacher_forced, int decode_mode);
 /* Decode U steps.
  *   labels_onehot : int64 (B, U_lab, V) one-hot ground truth as utils/data.py:141-143 delivers it, or NULL
  *   teacher_forced: 1 -> step s+1 is fed labels[:, s] (las_model.py:216-217); 0 -> free running with

@@ -58,6 +58,7 @@ PROTOTYPES = {
                        + [_f, C.c_int, _f]),
     "las_attn_keys_fwd": (C.c_int, [C.POINTER(SpellerDesc), _f, _f, _f]),
     "las_speller_reserve_floats": (C.c_size_t, [C.POINTER(SpellerDesc), C.c_int]),
+    "las_speller_decode_batch": (C.c_int, [C.POINTER(SpellerDesc), C.c_int, C.c_int]),
     "las_speller_fwd": (C.c_int, [C.POINTER(SpellerDesc), _f, _f, _f, C.c_int, C.c_int, C.c_int, C.c_int, _f, _f, _f, _f, _f,
                                   _f, C.c_int, _f]),
     "las_speller_step_workspace_floats": (C.c_size_t, [C.POINTER(SpellerDesc)]),

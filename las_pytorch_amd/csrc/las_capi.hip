@@ -351,6 +351,13 @@ int las_attn_keys_fwd(const las_speller_desc* d, const float* feat, float* keys,
 
 size_t las_speller_reserve_floats(const las_speller_desc* d, int U) { return SpellerLayout(d, U).total; }
 
+int las_speller_decode_batch(const las_speller_desc* d, int teacher_forced, int decode_mode) {
+    if (!d || check_desc(d) != LAS_OK) return 0;
+    if (opt_get(OPT_SPELLER_PERSIST) == 0 || (!teacher_forced && decode_mode == 2) || d->relu > LAS_ACT_RELU) return 0;
+    constexpr int NB = 32;      // the persistent kernels' utterance limit (two 16-row M tiles)
+    return speller_persist_eligible(NB, d->Tp, d->Hs, d->D, d->M, d->V, d->L, d->multi_head, d->use_mlp, !teacher_forced) ? NB : 0;
+}
+
 // Profiling aid (declared at the end of include/las_hip.h): per-phase shader-clock stamps of the persistent decode kernel.
 extern "C" void las_debug_persist_trace(unsigned long long* dev_buf) { speller_persist_set_trace(dev_buf); }
 extern "C" void las_debug_persist_bwd_trace(unsigned long long* dev_buf) { speller_persist_bwd_set_trace(dev_buf); }

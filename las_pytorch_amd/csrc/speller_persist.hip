@@ -2,7 +2,8 @@
 //
 // Replaces the per-step launch chain (lstm_cell_fwd x2 + attn_step_fwd, speller.hip) for the training forward of the
 // reference's Speller.forward (model/las_model.py:186-238, teacher-forced branch :207-209) when the shapes allow it.
-// The stepwise kernels stay the general path (free-running decode, multi-head, very long T', batches above 32).
+// The stepwise kernels stay the general path (decode mode 2, multi-head, very long T'); batches above 32 utterances are decoded in
+// slices of 32 by the caller (las_speller_decode_batch, include/las_hip.h).
 //
 // Why: a decode step is a chain of dependent phases.  As three kernels each phase pays ~4 us of launch/drain floor plus ~4 us of
 // L2->CU operand traffic (every workgroup re-reads the weights it used one step ago).  Three role sets live in this file:

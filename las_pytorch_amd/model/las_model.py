@@ -420,10 +420,10 @@ def _speller_grads(grads, L, use_mlp, heads):
 class _SpellerFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, cfg, feat, labels, noise, *params):
-        (U, teacher_forced, decode_mode, L, use_mlp, relu, M, V, heads, force_generic) = cfg
+        (U, teacher_forced, decode_mode, L, use_mlp, relu, M, V, heads, force_generic, allow_direct) = cfg
         feat = _f32c(feat)
         B, Tp, D = feat.shape
-        direct = _direct_targets(params)
+        direct = _direct_targets(params) if allow_direct else None      # a sliced batch uses every parameter once per slice
         params = [_f32c(p) for p in params]
         lstm, rest = params[:4 * L], params[4 * L:]
         Hs = lstm[1].shape[1]
@@ -464,7 +464,7 @@ class _SpellerFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, dlogp, _datt):
         feat, keys, logp, att, reserve, *params = ctx.saved_tensors
-        (U, teacher_forced, decode_mode, L, use_mlp, relu, M, V, heads, force_generic) = ctx.cfg
+        (U, teacher_forced, decode_mode, L, use_mlp, relu, M, V, heads, force_generic, _allow_direct) = ctx.cfg
         B, Tp, D, Hs = ctx.dims
         dev = feat.device
         dlogp = _f32c(dlogp)
@@ -549,7 +549,30 @@ class Speller(nn.Module):
                 B = listener_feature.shape[0]
                 noise = torch.stack([torch.empty(B, self.label_dim, device=listener_feature.device).exponential_(1)
                                      for _ in range(int(steps))])
-        return _SpellerFn.apply(cfg, listener_feature, ground_truth if teacher_force else None, noise, *self._params())
+        params = self._params()
+        labels = ground_truth if teacher_force else None
+        B = listener_feature.shape[0]
+        nb = self._decode_slice(listener_feature, params, cfg) if listener_feature.is_cuda else 0
+        if nb <= 0 or B <= nb:
+            return _SpellerFn.apply(cfg + (True,), listener_feature, labels, noise, *params)
+        # Batches beyond what one launch of the decode kernels takes: slices of nb utterances, each decoded in ONE launch (the per-step
+        # kernels would need U launch chains for the whole batch: P at B=128 26 ms -> see DESIGN.md 4.3).  The utterances of a batch
+        # are independent in the Speller (reference las_model.py:205-236), so this is the same arithmetic per utterance; parameter
+        # gradients of the slices are summed by autograd (no direct writes: every parameter is used once per slice).
+        feats = listener_feature.split(nb, 0)
+        labs = labels.split(nb, 0) if labels is not None else [None] * len(feats)
+        noises = noise.split(nb, 1) if noise is not None else [None] * len(feats)
+        outs = [_SpellerFn.apply(cfg + (False,), f, l, n, *params) for f, l, n in zip(feats, labs, noises)]
+        return torch.cat([o[0] for o in outs], 1), torch.cat([o[1] for o in outs], 2)
+
+    def _decode_slice(self, feat, params, cfg):
+        (_U, teacher_forced, decode_mode, L, use_mlp, relu, M, V, heads, force_generic) = cfg
+        if force_generic or feat.dim() != 3:
+            return 0
+        B, Tp, D = feat.shape
+        lstm, rest = params[:4 * L], params[4 * L:]
+        d = _speller_desc(B, Tp, D, lstm[1].shape[1], V, M, L, use_mlp, relu, [_f32c(p) for p in lstm], [_f32c(p) for p in rest], heads)
+        return int(lib().las_speller_decode_batch(d, int(teacher_forced), int(decode_mode)))
 
     def forward(self, listener_feature, ground_truth=None, teacher_force_rate=0.9):
         if ground_truth is None:

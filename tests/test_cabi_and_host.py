@@ -28,7 +28,7 @@ def test_library_exports_every_declared_symbol():
     for n in names:
         assert hasattr(lib, n), f"{n} declared in include/las_hip.h but not exported by liblas_hip.so"
         assert n in _cabi.PROTOTYPES, f"{n} has no ctypes prototype in las_pytorch_amd/_cabi.py"
-    assert lib.las_abi_version() == 5
+    assert lib.las_abi_version() == 6
     assert isinstance(lib.las_last_error(), bytes)
     # size queries are pure host code
     assert lib.las_pblstm_reserve_floats(32, 800, 256, 1) > lib.las_pblstm_reserve_floats(32, 800, 256, 0) > 0

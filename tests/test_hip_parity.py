@@ -312,7 +312,9 @@ def test_edge_shapes_vs_oracle(cfg_name, B, T, U):
 @pytest.mark.parametrize("cfg_name,B,Tp,U,scale", [("P", 32, 100, 24, None), ("P", 5, 37, 7, 0.1), ("S", 17, 200, 9, None),
                                                     ("S", 32, 100, 12, 0.1), ("P", 1, 1, 3, None),
                                                     ("P", 8, 375, 5, None), ("P", 32, 200, 4, None), ("S", 8, 500, 4, None),
-                                                    ("S", 16, 300, 4, None)])
+                                                    ("S", 16, 300, 4, None),
+                                                    # batches beyond one launch: Speller._run slices them (32 + 32 + 6, 32 + 1)
+                                                    ("P", 70, 50, 6, None), ("S", 33, 40, 5, None)])
 def test_persistent_decode_kernel_matches_stepwise(cfg_name, B, Tp, U, scale):
     _persistent_vs_stepwise(cfg_name, B, Tp, U, scale, "relu")
 
@@ -450,7 +452,7 @@ def test_direct_gradient_write_matches_autograd_accumulation(cfg_name, B):
 
 
 @pytest.mark.parametrize("cfg_name,B,Tp,U,decode_mode", [("P", 32, 100, 20, 1), ("P", 32, 100, 20, 0), ("S", 7, 150, 9, 1),
-                                                          ("S", 32, 60, 6, 0), ("P", 3, 30, 5, 1)])
+                                                          ("S", 32, 60, 6, 0), ("P", 3, 30, 5, 1), ("P", 40, 30, 5, 1)])
 def test_persistent_free_running_decode_matches_stepwise(cfg_name, B, Tp, U, decode_mode):
     """Greedy (decode_mode 1) and log-prob-feedback (decode_mode 0) decoding inside the one-launch kernel against the
     per-step launch chain: log-probabilities, attention, arg-max sequences, and (mode 1) the gradients."""
