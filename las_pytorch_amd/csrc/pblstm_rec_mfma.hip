@@ -40,7 +40,8 @@ struct RecMfma {
     static constexpr int PLANE = RM_NB * PLD;           // dwords of one plane
     static constexpr int RLD = 20;                      // row stride of a partial 16x16 tile
     static constexpr int RED = 4 * 8 * 16 * RLD;        // [K quarter][N-tile][16 rows][RLD]
-    static constexpr int LDS_FLOATS = 3 * PLANE + RED + 16;
+    static constexpr int PREL = 2 * 512 * 4;            // pre-activations of the coming cell phase: [batch][cell lane][gate]
+    static constexpr int LDS_FLOATS = 3 * PLANE + RED + 16 + PREL;
     static_assert(H == 256, "register budget (2 N-tiles x KS x 12 plane registers per lane) and one tile float4 per lane");
 };
 
@@ -94,6 +95,7 @@ __global__ __launch_bounds__(RM_THREADS) void rec_fwd_mfma_kernel(RecMfmaArgs a)
     unsigned* hp3 = reinterpret_cast<unsigned*>(smem);  // [plane][16 sequences][PLD] bf16 pairs
     float* red = smem + 3 * PLANE;                      // [K quarter][N-tile][16 rows][RLD]
     volatile unsigned* cflags = reinterpret_cast<volatile unsigned*>(red + C::RED);
+    float* prel = red + C::RED + 16;
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int T = a.T, B = a.B;
     // a group steps NBAT batches of 16 sequences alternately (a.nbat = 2 when the launch carries more sequences than one batch per
@@ -131,10 +133,16 @@ __global__ __launch_bounds__(RM_THREADS) void rec_fwd_mfma_kernel(RecMfmaArgs a)
     }
     // ---- per batch: cell lanes (sequence cs, unit cu) for tid < 512; a half wave = the 32 units of one sequence = one 128-byte
     //      line of `out`
-    const int cs = tid >> 5, cu = tid & 31;
+    //      The input half of the gates (x W_ih^T + b, written by the projection GEMM: a long-latency load per step) reaches the cell lanes
+    //      through LDS: lane 512 + i of waves 8-15 loads what cell lane i needs a whole step ahead.  A wave's loads and stores retire
+    //      through ONE in-order counter, so in the cell lanes those loads stood between the tile poll and its completion (the poll
+    //      waited for them and for the stash stores' acknowledgements: 0.65 us per step on the chain).
+    const int cs = (tid & 511) >> 5, cu = tid & 31;
     int bbase[2], nvalid[2];
-    bool cell[2];
-    long seq[2];
+    bool cell[2], feeder[2];
+    int seqr[2];                                        // row base in the (2, B, T, *) stash arrays: 32-bit, the addresses are re-derived per
+                                                        // use behind opaque() — as hoisted 64-bit loop invariants they pushed a pre-activation
+                                                        // into scratch, whose spill WAITED for its load inside the cell phase (0.5 us per step)
     float c[2] = {0.f, 0.f}, hlast[2] = {0.f, 0.f};
     float pre[2][4];
 #pragma unroll
@@ -142,15 +150,20 @@ __global__ __launch_bounds__(RM_THREADS) void rec_fwd_mfma_kernel(RecMfmaArgs a)
         bbase[bi] = a.b0 + ((group - dir * ngb) * nbat + bi) * RM_NB;
         nvalid[bi] = bi < nbat ? max(0, min(RM_NB, a.b0 + a.Bc - bbase[bi])) : 0;
         cell[bi] = tid < RM_NB * RM_UW && cs < nvalid[bi];
-        const int cb = bbase[bi] + (cell[bi] ? cs : 0);
-        seq[bi] = ((long)dir * B + (cell[bi] ? cb : a.b0)) * T;          // row base in the (2, B, T, *) stash arrays
+        feeder[bi] = tid >= RM_NB * RM_UW && cs < nvalid[bi];
+        const int cb = bbase[bi] + (cs < nvalid[bi] ? cs : 0);
+        seqr[bi] = (dir * B + (cs < nvalid[bi] ? cb : a.b0)) * T;
 #pragma unroll
         for (int g = 0; g < 4; ++g) pre[bi][g] = 0.f;
-        if (cell[bi]) {
-            const float* gb = a.gates + seq[bi] * 4 * H + u0 + cu;
-            const int t0 = dir ? T - 1 : 0;
+        if (feeder[bi]) {       // step 0's values straight into LDS, step 1's into registers (in flight)
+            const float* gb = a.gates + (long)seqr[bi] * 4 * H + u0 + cu;
+            const int t0 = dir ? T - 1 : 0, t1 = T > 1 ? (dir ? T - 2 : 1) : t0;
+            f32x4 p0;
 #pragma unroll
-            for (int g = 0; g < 4; ++g) pre[bi][g] = gb[(long)t0 * 4 * H + g * H];
+            for (int g = 0; g < 4; ++g) p0[g] = gb[(long)t0 * 4 * H + g * H];
+            *reinterpret_cast<f32x4*>(prel + (bi * 512 + (tid - 512)) * 4) = p0;
+#pragma unroll
+            for (int g = 0; g < 4; ++g) pre[bi][g] = gb[(long)t1 * 4 * H + g * H];
         }
     }
     // ---- tile loader: lane -> (row lr, float4 column lc) of the 16 x H tile: exactly one float4 per lane at H = 256
@@ -163,7 +176,8 @@ __global__ __launch_bounds__(RM_THREADS) void rec_fwd_mfma_kernel(RecMfmaArgs a)
     static_assert(TILE_F4 == RM_THREADS, "one float4 of the tile per lane");
     const int tlr = tid / F4_PER_ROW, tlc = tid % F4_PER_ROW;
     auto tile_src = [&](int bi, int tprev) {
-        return a.out + ((long)(bbase[bi] + (tlr < nvalid[bi] ? tlr : 0)) * T + tprev) * 2 * H + dir * H + tlc * 4;
+        const unsigned row = opaque((unsigned)(bbase[bi] + (tlr < nvalid[bi] ? tlr : 0)));
+        return a.out + ((long)row * T + tprev) * 2 * H + dir * H + tlc * 4;
     };
     unsigned pf[4] = {0u, 0u, 0u, 0u};
     bool have_pf = false;
@@ -218,6 +232,14 @@ __global__ __launch_bounds__(RM_THREADS) void rec_fwd_mfma_kernel(RecMfmaArgs a)
                 lds_barrier();
                 if (bi == 0) RM_STAMP(2);
                 have_pf = false;
+                if (feeder[bi]) {       // this step's pre-activations (loaded a step ago) -> LDS; the next step's -> registers
+                    const f32x4 pv = {pre[bi][0], pre[bi][1], pre[bi][2], pre[bi][3]};
+                    *reinterpret_cast<f32x4*>(prel + (bi * 512 + (tid - 512)) * 4) = pv;
+                    const float* gb = a.gates + (long)opaque((unsigned)seqr[bi]) * 4 * H + u0 + cu;
+                    const int tn = step + 1 < T ? (dir ? t - 1 : t + 1) : t;
+#pragma unroll
+                    for (int g = 0; g < 4; ++g) pre[bi][g] = gb[(long)tn * 4 * H + g * H];
+                }
                 // ---- this wave's part of G_t = h_{t-1} W_hh^T: 16 sequences x 2 x 16 gate rows over its K quarter
 #pragma unroll
                 for (int ks = 0; ks < KS; ++ks) {
@@ -256,6 +278,8 @@ __global__ __launch_bounds__(RM_THREADS) void rec_fwd_mfma_kernel(RecMfmaArgs a)
             lds_barrier();
             if (bi == 0) RM_STAMP(4);
             if (cell[bi]) {
+                const long srow = (long)opaque((unsigned)seqr[bi]);
+                float* gb = a.gates + srow * 4 * H + u0 + cu;
                 const float* r0 = red + (((cu >> 2) * 16) + cs) * RLD + (cu & 3) * 4;
                 f32x4 sg = *reinterpret_cast<const f32x4*>(r0);
 #pragma unroll
@@ -263,29 +287,28 @@ __global__ __launch_bounds__(RM_THREADS) void rec_fwd_mfma_kernel(RecMfmaArgs a)
                     const f32x4 sq = *reinterpret_cast<const f32x4*>(r0 + q * 8 * 16 * RLD);
                     sg[0] += sq[0]; sg[1] += sq[1]; sg[2] += sq[2]; sg[3] += sq[3];
                 }
-                const float ig = sigmoidf_acc(sg[0] + pre[bi][0]);
-                const float fg = sigmoidf_acc(sg[1] + pre[bi][1]);
-                const float gg = tanhf_acc(sg[2] + pre[bi][2]);
-                const float og = sigmoidf_acc(sg[3] + pre[bi][3]);
+                {
+                    const f32x4 pv = *reinterpret_cast<const f32x4*>(prel + (bi * 512 + tid) * 4);
+#pragma unroll
+                    for (int g = 0; g < 4; ++g) sg[g] += pv[g];
+                }
+                const float ig = sigmoidf_acc(sg[0]);
+                const float fg = sigmoidf_acc(sg[1]);
+                const float gg = tanhf_acc(sg[2]);
+                const float og = sigmoidf_acc(sg[3]);
                 c[bi] = fg * c[bi] + ig * gg;
                 const float h = og * tanhf_acc(c[bi]);
-                const int cb = bbase[bi] + cs;
+                const unsigned cb = opaque((unsigned)(bbase[bi] + cs));
                 float* hp = a.out + ((long)cb * T + t) * 2 * H + dir * H + u0 + cu;          // the layer output IS the hand-off slab
                 if (l2x) __hip_atomic_store(reinterpret_cast<unsigned*>(hp), pub_bits(h), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
                 else st1_agent(hp, h);
-                float* gb = a.gates + seq[bi] * 4 * H + u0 + cu;
                 if (STASH) {
-                    a.hprev[(seq[bi] + t) * H + u0 + cu] = hlast[bi];
-                    a.cbuf[(seq[bi] + t) * H + u0 + cu] = c[bi];
+                    a.hprev[(srow + t) * H + u0 + cu] = hlast[bi];
+                    a.cbuf[(srow + t) * H + u0 + cu] = c[bi];
                     float* gp = gb + (long)t * 4 * H;
                     gp[0] = ig; gp[H] = fg; gp[2 * H] = gg; gp[3 * H] = og;
                 }
                 hlast[bi] = h;
-                if (step + 1 < T) {      // next step's pre-activations: consumed a whole step from now
-                    const int tn = dir ? t - 1 : t + 1;
-#pragma unroll
-                    for (int g = 0; g < 4; ++g) pre[bi][g] = gb[(long)tn * 4 * H + g * H];
-                }
             }
             if (bi == 0) RM_STAMP(5);
             // (the next tile's barrier separates these reads of `red` from its next writes)
@@ -296,10 +319,10 @@ __global__ __launch_bounds__(RM_THREADS) void rec_fwd_mfma_kernel(RecMfmaArgs a)
 }  // namespace
 
 // Eligibility: the shapes this form pays for.  Measured on MI355X, layer-0 forward at H = 256, T = 400 (tools/ubench_rec_mfma.py):
-// B = 128 1.26 ms (the VALU multi-utterance kernels: 1.27), 256 1.43 (2.33), 512 2.57 (4.38), 2048 9.8 (17.1).
+// B = 64 0.93 ms (the VALU multi-utterance kernels: 0.85-0.88), 128 1.08 (1.26), 256 1.33 (2.33), 512 2.29 (4.38), 2048 8.6 (17.1).
 bool rec_fwd_mfma_eligible(int B, int H) {
     if (opt_get(OPT_REC_MFMA) == 0) return false;
-    return H == 256 && B > 128;
+    return H == 256 && B >= 128;
 }
 
 int rec_fwd_mfma(float* gates, const float* w_hh_f, const float* w_hh_r, float* out, float* cbuf, float* hprev, int B, int T, int H,
