@@ -272,3 +272,31 @@ def test_graph_replay_step_equals_eager_step():
     diff = np.abs(outs[1][1] - outs[0][1])
     assert diff.max() <= 2 * 2e-3 * 3 and (diff > 1e-6).mean() < 5e-3, (diff.max(), (diff > 1e-6).mean())
     assert outs[0][0][2] < outs[0][0][0]            # and it trains
+
+
+def test_decode_batch_query_and_slicing_decision():
+    """las_speller_decode_batch (include/las_hip.h): 32 utterances per launch where the one-launch decode kernels apply, 0 where they
+    do not (Hs = 1024, multi-head, decode mode 2, the PERSIST switch off) — Speller._run slices larger batches only in the first case."""
+    from las_pytorch_amd import Speller, _cabi, synth
+
+    def query(cfg_name, heads=1, teacher=True, mode=1, Tp=100):
+        c = synth.CONFIGS[cfg_name]
+        sp = Speller(vocab_size=c["V"], hidden_size=c["Hs"], rnn_unit="LSTM", num_layers=c["Ls"], max_label_len=8,
+                     use_mlp_in_attention=True, mlp_dim_in_attention=c["M"], mlp_activate_in_attention="relu",
+                     listener_hidden_size=c["H"], multi_head=heads, decode_mode=mode).cuda()
+        feat = torch.zeros(48, Tp, 2 * c["H"], device="cuda")
+        a = sp.attention
+        cfg = (8, teacher, mode, c["Ls"], True, 1, c["M"], c["V"], heads, False)
+        return sp._decode_slice(feat, sp._params(), cfg)
+
+    assert query("P") == 32 and query("S") == 32
+    assert query("P", teacher=False, mode=1) == 32          # greedy free-running decode runs in the persistent kernel too
+    assert query("P", teacher=False, mode=2) == 0           # sampled decoding: per-step path
+    assert query("P", heads=2) == 0
+    assert query("Y") == 0                                  # Hs = 1024: per-step path, never sliced
+    assert query("P", Tp=2000) == 0                         # T' beyond the residency table
+    _cabi.set_option("SPELLER_PERSIST", 0)
+    try:
+        assert query("P") == 0
+    finally:
+        _cabi.set_option("SPELLER_PERSIST", 1)
