@@ -33,7 +33,7 @@ struct PblstmBwdLayout {
         size_t o = 0;
         dgates = o; o += r4((size_t)2 * B * T * 4 * H);
         wt = o; o += r4((size_t)2 * H * 4 * H);
-        xbuf = o; o += r4(rec_xbuf_bytes(B, H) / sizeof(float));
+        xbuf = o; o += r4(rec_xbuf_bytes(B, H) / sizeof(float) + rec_bwd_mfma_ring_floats(B, H));     // (+ the matrix-pipe backward's ring)
         total = o;
     }
 };

@@ -57,6 +57,10 @@ size_t rec_xbuf_bytes(int B, int H);
 // pblstm_rec_mfma.hip: the forward recurrence for batches that fill MFMA tiles (16 utterances per group of H/32 workgroups, bf16
 // matrix pipe with the exact three-way operand split).  pblstm_rec_fwd dispatches to it by itself when eligible.
 bool rec_fwd_mfma_eligible(int B, int H);
+bool rec_bwd_mfma_eligible(int B, int H);
+size_t rec_bwd_mfma_ring_floats(int B, int H);
+int rec_bwd_mfma(const float* dout, const float* gates, const float* cbuf, const float* w_hh_t, float* dgates, int B, int T, int H,
+                 unsigned long long* xbuf, unsigned* err, float* db_f, float* db_r, hipStream_t stream);
 int rec_fwd_mfma(float* gates, const float* w_hh_f, const float* w_hh_r, float* out, float* cbuf, float* hprev, int B, int T, int H,
                  int stash, unsigned long long* xbuf, unsigned* err, hipStream_t stream);
 #ifdef LAS_REC_TRACE

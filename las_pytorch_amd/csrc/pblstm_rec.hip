@@ -1031,6 +1031,13 @@ int pblstm_rec_bwd(const float* dout, const float* gates, const float* cbuf, con
                    int* db_done) {
     LAS_REQUIRE(B > 0 && T > 0 && H > 0, "rec dims");
     if (db_done) *db_done = 0;
+    if (!force_generic && err && xbuf && rec_bwd_mfma_eligible(B, H)) {      // large batches: 16 utterances per group on the matrix pipe
+        const int rc = rec_bwd_mfma(dout, gates, cbuf, w_hh_t, dgates, B, T, H, xbuf, err, db_f, db_r, stream);
+        if (rc != LAS_ERR_UNSUPPORTED) {
+            if (rc == LAS_OK && db_done && db_f && db_r) *db_done = 1;
+            return rc;
+        }
+    }
     const int ngroups = 2 * B;
     const int nb_env = (int)opt_get(OPT_REC_NB);
     RecPlan plan = {0, 0};

@@ -316,6 +316,225 @@ __global__ __launch_bounds__(RM_THREADS) void rec_fwd_mfma_kernel(RecMfmaArgs a)
     }
 }
 
+
+// ------------------------------------------------------------------------------------------------ backward (BPTT)
+// dh_{t-1} = dG_t W_hh has K = 4H: cutting it over the OUTPUT units (as the forward does) would make every workgroup pull the whole
+// 16 x 4H dG tile — 64 KB per step (first version: 4.5 us per step, 1.1 us of it the tile, 0.45 its split).  It is cut over K instead:
+// workgroup m of a group owns hidden units [32 m, 32 m + 32), applies their cell backward, and multiplies ITS OWN 128 gate-gradient
+// columns (16 sequences x 128, never leaving the CU: LDS planes) by its 128 rows of W_hh (split once into bf16 planes, 48 registers
+// per lane: wave = one N-tile of 16 output units, the four gates are its four 32-deep k-steps) — a PARTIAL dh for all H output units.
+// The partial sums travel: workgroup m publishes, per consumer c, a block [32 units of c][16 sequences] (one float4 per lane, a wave
+// writes 1 KB) into a four-slot ring; every lane of consumer c polls ONE float4 (producer, unit, sequence quad) — 16 KB in per
+// workgroup and step, like the forward — drops it into LDS, and 512 cell lanes sum the eight producers' parts.  A slot is
+// re-filled with the sentinel by its producer two steps before it is written again (its consumer has provably read it: the
+// producer has seen that consumer's NEXT publication), so only the ring (512 KB per group) is sentinel-filled by the host, not the
+// gradient buffer.  The stash of the coming step (gates, c_t, c_{t-1}, dout: seven HBM reads per unit) is fetched a step ahead by
+// the lanes 512 above the cell lanes, turned into the cell backward's factors there and handed over through LDS.
+#ifdef RM_TRACE
+__device__ unsigned long long rm_bwd_trace[256 * 8];
+#define RB_STAMP(k) do { if (blockIdx.x == 0 && threadIdx.x == 0 && step < 256) rm_bwd_trace[step * 8 + (k)] = wall_clock64(); } while (0)
+#else
+#define RB_STAMP(k) do { } while (0)
+#endif
+
+template <int H>
+struct RecMfmaBwd {
+    static constexpr int G = H / RM_UW;
+    static constexpr int KL = 4 * RM_UW;                // local contraction length: this workgroup's gate rows
+    static constexpr int KS = KL / 32;                  // = 4: one 32-deep k-step per gate
+    static constexpr int PLD = KL / 2 + 4;              // LDS row stride (dwords = bf16 pairs) of one plane of the local dG tile
+    static constexpr int PLANE = RM_NB * PLD;
+    static constexpr int XLD = RM_NB + 4;               // row stride of the partial-sum exchange: [producer][unit][16 sequences + pad]
+    static constexpr int XS = G * RM_UW * XLD;
+    static constexpr int FACL = 2 * 512 * 8;            // cell-backward factors: [step parity][cell lane][8] (written a step ahead)
+    static constexpr int LDS_FLOATS = 3 * PLANE + XS + 16 + FACL;
+    static constexpr int SLOT = G * G * RM_UW * RM_NB;  // floats of one ring slot: [consumer][producer][32 units][16 sequences]
+    static constexpr int RING = 4 * SLOT;               // floats per group
+    static_assert(H == 256 && G * 128 == RM_THREADS, "one float4 of the incoming partial sums per lane; 48 plane registers per lane");
+};
+
+struct RecMfmaBwdArgs {
+    const float* dout; const float* gates; const float* cbuf; const float* w_hh_t; float* dgates;
+    float* db_f; float* db_r;
+    float* ring;                                        // [group][4 slots][SLOT], sentinel-prefilled
+    int B, T, b0, Bc;
+    unsigned* err;
+    unsigned long long* idbuf;
+    int force_agent;
+};
+
+template <int H>
+__global__ __launch_bounds__(RM_THREADS) void rec_bwd_mfma_kernel(RecMfmaBwdArgs a) {
+    using C = RecMfmaBwd<H>;
+    constexpr int G = C::G, KS = C::KS, PLD = C::PLD, PLANE = C::PLANE, XLD = C::XLD, K4 = 4 * H;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    unsigned* gp3 = reinterpret_cast<unsigned*>(smem);  // [plane][16 sequences][PLD] bf16 pairs of this workgroup's dG columns
+    float* xs = smem + 3 * PLANE;                       // [producer][unit][XLD] partial sums of dh
+    volatile unsigned* cflags = reinterpret_cast<volatile unsigned*>(xs + C::XS);
+    float* facl = xs + C::XS + 16;
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int T = a.T, B = a.B;
+    const int ngb = (a.Bc + RM_NB - 1) / RM_NB;         // groups per direction
+    const int ngroups = 2 * ngb;
+    int group, member;
+    {
+        const int bid = blockIdx.x;
+        if ((ngroups & 7) == 0) { const int q = bid >> 3; member = q % G; group = (q / G) * 8 + (bid & 7); }
+        else { member = bid % G; group = bid / G; }
+    }
+    const int dir = group >= ngb ? 1 : 0;
+    const int u0 = member * RM_UW;
+    const int bbase = a.b0 + (group - dir * ngb) * RM_NB;
+    const int nvalid = max(0, min(RM_NB, a.b0 + a.Bc - bbase));
+    float* ring = a.ring + (size_t)group * C::RING;
+
+    // ---- resident weights: wave w = N-tile of output units 16 w .. 16 w + 15; B operand column c -> unit n = 16 w + c; k-step ks = gate,
+    //      its 8 k-slots = own units u0 + 8 kq .. + 7: W_hh[ks H + u0 + 8 kq + e][n] = w_hh_t[n][ks H + u0 + 8 kq + e]
+    const int r16 = lane & 15, kq = lane >> 4;
+    PsPlanes<8> Wp[KS];
+    {
+        const float* wrow = a.w_hh_t + ((long)dir * H + 16 * wave + r16) * K4 + u0 + kq * 8;
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+            const f32x4 w0 = ld4p(wrow + ks * H), w1 = ld4p(wrow + ks * H + 4);
+            const float v[8] = {w0[0], w0[1], w0[2], w0[3], w1[0], w1[1], w1[2], w1[3]};
+            Wp[ks] = ps_split<8>(v);
+        }
+    }
+    // ---- cell lanes (sequence cs, unit cu) for tid < 512; lane 512 + i feeds cell lane i
+    const int cs = (tid & 511) >> 5, cu = tid & 31;
+    const bool valid = cs < nvalid;
+    const bool cell = tid < 512 && valid, feeder = tid >= 512 && valid;
+    const int seqr = (dir * B + bbase + (valid ? cs : 0)) * T;             // row base in the (2, B, T, *) arrays
+    const int dor = (bbase + (valid ? cs : 0)) * T;                         // row base in dout (B, T, 2H)
+    float dc = 0.f, bs[4] = {0.f, 0.f, 0.f, 0.f};
+    float p[7] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    auto load_step = [&](int st) {                      // raw stash of processing step st (clamped: the last steps re-read their own row)
+        const int sc = st < T ? st : T - 1;
+        const int t = dir ? sc : T - 1 - sc;
+        const long row = (long)opaque((unsigned)seqr) + t;
+        const float* gp = a.gates + row * 4 * H + u0 + cu;
+        p[0] = gp[0]; p[1] = gp[H]; p[2] = gp[2 * H]; p[3] = gp[3 * H];
+        p[4] = a.cbuf[row * H + u0 + cu];
+        const int tp = dir ? t + 1 : t - 1;             // the time processed before t in the FORWARD pass
+        const int tpc = (tp >= 0 && tp < T) ? tp : t;
+        const float cp = a.cbuf[((long)opaque((unsigned)seqr) + tpc) * H + u0 + cu];
+        p[5] = (tp >= 0 && tp < T) ? cp : 0.f;
+        p[6] = a.dout[((long)opaque((unsigned)dor) + t) * 2 * H + dir * H + u0 + cu];
+    };
+    auto prepare_to_lds = [&](int par) {                // p -> factors: beta, a_i, a_f, a_g | a_o, f, dout, -
+        const float tc = tanhf_acc(p[4]);
+        const f32x4 lo = {p[3] * (1.f - tc * tc), p[2] * p[0] * (1.f - p[0]), p[5] * p[1] * (1.f - p[1]), p[0] * (1.f - p[2] * p[2])};
+        const f32x4 hi = {tc * p[3] * (1.f - p[3]), p[1], p[6], 0.f};
+        *reinterpret_cast<f32x4*>(facl + (par * 512 + (tid - 512)) * 8) = lo;
+        *reinterpret_cast<f32x4*>(facl + (par * 512 + (tid - 512)) * 8 + 4) = hi;
+    };
+    if (feeder) { load_step(0); prepare_to_lds(0); load_step(1); }
+    if (tid < 4) cflags[tid] = 0u;
+    lds_barrier();
+    const bool l2x = !a.force_agent && rm_same_xcd<G>(a.idbuf + (size_t)group * 32, member, a.err, cflags + 4);
+
+    // incoming partial sums: lane -> (producer pm, unit pu, sequence quad pq) of the block [this consumer][pm]
+    const int pm = tid >> 7, pu = (tid >> 2) & 31, pq = tid & 3;
+    const unsigned in_off = ((unsigned)(member * G + pm) * RM_UW + pu) * RM_NB + pq * 4;
+    // outgoing: wave w holds output units 16 w .. + 15 = consumer w / 2, its units 16 (w & 1) + r16; a lane's acc = sequences 4 kq .. + 3
+    const unsigned out_off = ((unsigned)((wave >> 1) * G + member) * RM_UW + (wave & 1) * 16 + r16) * RM_NB + kq * 4;
+    unsigned short* gp16 = reinterpret_cast<unsigned short*>(gp3);
+
+    for (int step = 0; step < T; ++step) {
+        const int t = dir ? step : T - 1 - step;        // reverse of the forward processing order
+        if (nvalid == 0) break;                         // (uniform) an empty group
+        RB_STAMP(0);
+        if (step > 0) {
+            // ---- the eight producers' partial sums of dh for this workgroup's units: one float4 per lane, polled in place
+            const float* src = at_bytes(ring + (size_t)((step - 1) & 3) * C::SLOT, 4u * opaque(in_off));
+            f32x4 v = ld4_agent(src);
+            if (has_sentinel(v)) {
+                unsigned spins = 0;
+                for (;;) {
+                    v = ld4_agent(src);
+                    if (!has_sentinel(v)) break;
+                    if (spin_expired(spins, a.err, 0xDEAD0035u)) break;
+                }
+            }
+            RB_STAMP(1);
+            *reinterpret_cast<f32x4*>(xs + (pm * RM_UW + pu) * XLD + pq * 4) = v;
+            lds_barrier();
+            RB_STAMP(2);
+        }
+        if (feeder) {           // the NEXT step's factors (its stash was loaded a step ago) -> the other half of `facl` (this step's half is
+            prepare_to_lds((step + 1) & 1);     // being read by the cell lanes right now); the stash of the step after it -> registers
+            load_step(step + 2);
+        }
+        if (cell) {
+            float carry = 0.f;
+            if (step > 0) {
+#pragma unroll
+                for (int m = 0; m < G; ++m) carry += xs[(m * RM_UW + cu) * XLD + cs];
+            }
+            const f32x4 lo = *reinterpret_cast<const f32x4*>(facl + ((step & 1) * 512 + tid) * 8);
+            const f32x4 hi = *reinterpret_cast<const f32x4*>(facl + ((step & 1) * 512 + tid) * 8 + 4);
+            const float dh = hi[2] + carry;
+            const float dct = dc + dh * lo[0];
+            dc = dct * hi[1];
+            const float g4[4] = {dct * lo[1], dct * lo[2], dct * lo[3], dh * hi[0]};
+            // own dG columns -> bf16 planes in LDS (column gate * 32 + unit: a 16-bit store per plane and gate)
+            unsigned pa[3], pb[3];
+            ps_split_pair(g4[0], g4[1], pa[0], pa[1], pa[2]);
+            ps_split_pair(g4[2], g4[3], pb[0], pb[1], pb[2]);
+#pragma unroll
+            for (int pl = 0; pl < 3; ++pl) {
+                unsigned short* row = gp16 + ((size_t)pl * PLANE + cs * PLD) * 2 + cu;
+                row[0] = (unsigned short)(pa[pl] & 0xffffu); row[32] = (unsigned short)(pa[pl] >> 16);
+                row[64] = (unsigned short)(pb[pl] & 0xffffu); row[96] = (unsigned short)(pb[pl] >> 16);
+            }
+            float* dp = a.dgates + ((long)opaque((unsigned)seqr) + t) * K4 + u0 + cu;
+#pragma unroll
+            for (int g = 0; g < 4; ++g) { dp[g * H] = g4[g]; bs[g] += g4[g]; }
+        }
+        RB_STAMP(3);
+        lds_barrier();
+        RB_STAMP(4);
+        if (step + 1 < T) {
+            // ---- partial dh_{t-1} of ALL output units from this workgroup's gate gradients: 16 sequences x 16 units per wave
+            f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks) {
+                PsPlanes<8> A;
+                const unsigned* ar = gp3 + r16 * PLD + (ks * 32 + kq * 8) / 2;
+#pragma unroll
+                for (int pl = 0; pl < 3; ++pl) {
+                    const ps_u32x4 q = *reinterpret_cast<const ps_u32x4*>(ar + pl * PLANE);
+                    A.p[pl][0] = q[0]; A.p[pl][1] = q[1]; A.p[pl][2] = q[2]; A.p[pl][3] = q[3];
+                }
+                acc = ps_mfma6<8>(A, Wp[ks], acc);
+            }
+            RB_STAMP(5);
+            f32x4 pubv;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) pubv[i] = __uint_as_float(pub_bits(acc[i]));
+            float* dst = at_bytes(ring + (size_t)(step & 3) * C::SLOT, 4u * opaque(out_off));
+            if (l2x) *reinterpret_cast<f32x4*>(dst) = pubv; else st4_agent(dst, pubv);
+            if (step + 2 < T) {     // the slot of step + 2 (last used at step - 2, read at step - 1 by a consumer whose step - 1 publication
+                                    // this workgroup has consumed): back to the sentinel
+                const f32x4 sent = {__uint_as_float(PS_SENT), __uint_as_float(PS_SENT), __uint_as_float(PS_SENT), __uint_as_float(PS_SENT)};
+                float* sd = at_bytes(ring + (size_t)((step + 2) & 3) * C::SLOT, 4u * opaque(out_off));
+                if (l2x) *reinterpret_cast<f32x4*>(sd) = sent; else st4_agent_raw(sd, sent);
+            }
+        }
+        RB_STAMP(6);
+        // (the barrier after the next poll separates these reads of the planes / `xs` / `facl` from their next writes)
+    }
+    float* db = dir ? a.db_r : a.db_f;
+    if (db != nullptr && cell) {
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            atomicAdd(db + g * H + u0 + cu, bs[g]);                  // b_ih
+            atomicAdd(db + 4 * H + g * H + u0 + cu, bs[g]);          // b_hh receives the same gradient
+        }
+    }
+}
+
 }  // namespace
 
 // Eligibility: the shapes this form pays for.  Measured on MI355X, layer-0 forward at H = 256, T = 400 (tools/ubench_rec_mfma.py):
@@ -360,5 +579,57 @@ int rec_fwd_mfma(float* gates, const float* w_hh_f, const float* w_hh_r, float* 
     }
     return LAS_OK;
 }
+
+
+bool rec_bwd_mfma_eligible(int B, int H) {
+    if (opt_get(OPT_REC_MFMA) == 0) return false;
+    return H == 256 && B >= 128;
+}
+
+// floats of the partial-sum ring behind the xbuf region of a backward workspace (shape only: the caller sizes its workspace with it)
+size_t rec_bwd_mfma_ring_floats(int B, int H) {
+    if (!(H == 256 && B >= 128)) return 0;
+    return (size_t)32 * RecMfmaBwd<256>::RING;          // 32 groups (256 CUs / 8) is the most one launch carries
+}
+
+int rec_bwd_mfma(const float* dout, const float* gates, const float* cbuf, const float* w_hh_t, float* dgates, int B, int T, int H,
+                 unsigned long long* xbuf, unsigned* err, float* db_f, float* db_r, hipStream_t stream) {
+    LAS_REQUIRE(H == 256, "rec_bwd_mfma shape");
+    LAS_REQUIRE(err != nullptr && xbuf != nullptr, "rec_bwd_mfma buffers");
+    using C = RecMfmaBwd<256>;
+    int dev = 0, cus = 0;
+    LAS_HIP_CHECK(hipGetDevice(&dev));
+    LAS_HIP_CHECK(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
+    const int groups_max = std::min(16, cus / (2 * C::G));            // groups per direction that are resident at once (ring: 32 groups)
+    if (groups_max < 1) return fail(LAS_ERR_UNSUPPORTED, "rec_bwd_mfma: %s%ld compute units are too few", "", (long)cus);
+    const size_t smem = sizeof(float) * C::LDS_FLOATS;
+    LAS_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&rec_bwd_mfma_kernel<256>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
+    const int chunk = groups_max * RM_NB;
+    {   // residency of the largest launch before anything is written
+        const int Bc = std::min(chunk, B);
+        const int grid = 2 * ((Bc + RM_NB - 1) / RM_NB) * C::G;
+        if (!persistent_launch_fits(rec_bwd_mfma_kernel<256>, RM_THREADS, smem, grid))
+            return fail(LAS_ERR_UNSUPPORTED, "rec_bwd_mfma: %s%ld workgroups cannot all be resident", "", (long)grid);
+    }
+    float* ring = reinterpret_cast<float*>(reinterpret_cast<char*>(xbuf) + rec_xbuf_bytes(B, H));      // (PblstmBwdLayout carves it there)
+    for (int b0 = 0; b0 < B; b0 += chunk) {
+        const int Bc = std::min(chunk, B - b0);
+        const int ngroups = 2 * ((Bc + RM_NB - 1) / RM_NB);
+        const int grid = ngroups * C::G;
+        LAS_HIP_CHECK(hipMemsetAsync(xbuf, 0, sizeof(unsigned long long) * 32 * (size_t)ngroups, stream));
+        LAS_HIP_CHECK(hipMemsetAsync(ring, 0xFF, sizeof(float) * (size_t)ngroups * C::RING, stream));
+        RecMfmaBwdArgs a{dout, gates, cbuf, w_hh_t, dgates, db_f, db_r, ring, B, T, b0, Bc, err, xbuf, (int)opt_get(OPT_REC_AGENT_HANDOFF)};
+        hipLaunchKernelGGL((rec_bwd_mfma_kernel<256>), dim3(grid), dim3(RM_THREADS), smem, stream, a);
+        LAS_LAUNCH_CHECK();
+    }
+    return LAS_OK;
+}
+
+#ifdef RM_TRACE
+extern "C" void las_debug_rm_bwd_trace(unsigned long long* host_out) {
+    (void)hipDeviceSynchronize();
+    (void)hipMemcpyFromSymbol(host_out, HIP_SYMBOL(rm_bwd_trace), sizeof(unsigned long long) * 256 * 8);
+}
+#endif
 
 }  // namespace las

@@ -48,6 +48,10 @@ __device__ __forceinline__ void st4_agent(float* p, const f32x4 v) {
     // wait states corrupts the stored value): the compiler protects its own stores but cannot see into inline asm.
     asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 2" : : "v"(p), "v"(b) : "memory");
 }
+// the same store without the NaN canonicalisation: for writing the SENTINEL itself back into a slot that is about to be reused
+__device__ __forceinline__ void st4_agent_raw(float* p, const f32x4 v) {
+    asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 2" : : "v"(p), "v"(v) : "memory");
+}
 __device__ __forceinline__ void lds_barrier() {     // orders LDS traffic only (does not wait for global stores)
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
