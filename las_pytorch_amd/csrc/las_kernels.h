@@ -59,6 +59,7 @@ size_t rec_xbuf_bytes(int B, int H);
 bool rec_fwd_mfma_eligible(int B, int H);
 bool rec_bwd_mfma_eligible(int B, int H);
 size_t rec_bwd_mfma_ring_floats(int B, int H);
+size_t rec_mfma_xbuf_extra_bytes(int B, int H);
 int rec_bwd_mfma(const float* dout, const float* gates, const float* cbuf, const float* w_hh_t, float* dgates, int B, int T, int H,
                  unsigned long long* xbuf, unsigned* err, float* db_f, float* db_r, hipStream_t stream);
 int rec_fwd_mfma(float* gates, const float* w_hh_f, const float* w_hh_r, float* out, float* cbuf, float* hprev, int B, int T, int H,

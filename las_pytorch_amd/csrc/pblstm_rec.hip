@@ -905,7 +905,11 @@ int transpose2d(const float* src, float* dst, int rows, int cols, hipStream_t st
 }
 
 // granules [group][parity][utterance][unit] + XCC-id slots per group; groups*NB <= 2*(B + 15) for every NB <= 16
-size_t rec_xbuf_bytes(int B, int H) { return ((size_t)2 * (B + 15) * 2 * H + (size_t)2 * (B + 15) * XID_SLOTS) * sizeof(u64); }
+// (+ the matrix-pipe forward kernel's hand-off ring at the shapes it serves: the two paths never use the buffer at the same time)
+size_t rec_xbuf_bytes(int B, int H) {
+    const size_t base = ((size_t)2 * (B + 15) * 2 * H + (size_t)2 * (B + 15) * XID_SLOTS) * sizeof(u64);
+    return std::max(base, rec_mfma_xbuf_extra_bytes(B, H));
+}
 
 static bool fast_h(int H) { return H == 128 || H == 256 || H == 512; }
 

@@ -15,9 +15,10 @@
 //     splitting in the multiplying waves repeated the same VALU work in every N-tile's wave: 1.8 us per step), every wave reads its
 //     16 x 32 operand blocks as planes and issues six v_mfma_f32_16x16x32_bf16 per block and N-tile, the four K quarters meet in
 //     LDS, 512 lanes apply the cell (c in a register) and publish h_t;
-//   * hand-off = the layer's OUTPUT buffer itself: `out` is pre-filled with the sentinel, producers store h_t with agent-scope
-//     stores (a half wave writes one whole 128-byte line: 32 units of one sequence), one wave of every consumer watches one dword
-//     per producer, the tile is then read with ordinary loads and every word checked against the sentinel (persist_common.h).
+//   * hand-off = a four-slot ring per (group, batch), slot = step % 4, [16 sequences][H]: sentinel-prefilled once, producers store h_t
+//     (a half wave writes one whole 128-byte line: 32 units of one sequence) and reset their words of slot step + 2 themselves;
+//     consumers poll their own float4 of the tile (same XCD) or watch one dword per producer first (otherwise), always with
+//     agent-scope loads, and check every word against the sentinel (persist_common.h).  `out` receives h_t as an ordinary store.
 // All spins are bounded and report through the device error word.
 #include "las_common.h"
 #include "las_kernels.h"
@@ -30,6 +31,7 @@ namespace las {
 namespace {
 
 constexpr int RM_THREADS = 1024, RM_NB = 16, RM_UW = 32;
+constexpr size_t REC_MFMA_RING_OFFSET = 64 * 1024;      // bytes from the start of xbuf: behind the id slots (and a trace build's stamps)
 
 template <int H>
 struct RecMfma {
@@ -52,6 +54,7 @@ struct RecMfmaArgs {
     int nbat;                                           // batches of 16 sequences per group: 1, or 2 stepped alternately
     unsigned long long* idbuf;                          // zeroed: 32 id slots per group (run-time placement check)
     int force_agent;                                    // A/B: agent-scope hand-off even when a group shares an XCD
+    float* ring;                                        // [group][batch 2][slot 4][16 sequences][H], sentinel-prefilled: the hand-off slab
 };
 
 // Run-time placement check (as pblstm_rec.hip::same_xcd_group): every member publishes its XCC id with agent-scope stores and reads
@@ -175,16 +178,20 @@ __global__ __launch_bounds__(RM_THREADS) void rec_fwd_mfma_kernel(RecMfmaArgs a)
 
     static_assert(TILE_F4 == RM_THREADS, "one float4 of the tile per lane");
     const int tlr = tid / F4_PER_ROW, tlc = tid % F4_PER_ROW;
-    auto tile_src = [&](int bi, int tprev) {
-        const unsigned row = opaque((unsigned)(bbase[bi] + (tlr < nvalid[bi] ? tlr : 0)));
-        return a.out + ((long)row * T + tprev) * 2 * H + dir * H + tlc * 4;
+    // h travels through a four-slot ring per (group, batch) — slot = step % 4, [16 sequences][H] — not through `out`: a slot is reset to
+    // the sentinel by its producer lanes two steps before its next use (the producer has then consumed every consumer's NEXT
+    // publication, so they have finished reading it), and the host fills 128 KB per group instead of the whole output buffer
+    // (105 MB at B = 128, 420 MB at B = 512: 2-4 % of the launch)
+    constexpr int RSLOT = RM_NB * H;
+    float* ring = a.ring + (size_t)group * 2 * 4 * RSLOT;
+    auto tile_src = [&](int bi, int sprev) {
+        return ring + (size_t)(bi * 4 + (sprev & 3)) * RSLOT + opaque((unsigned)((tlr < nvalid[bi] ? tlr : 0) * H + tlc * 4));      // (rows without a sequence are never written)
     };
     unsigned pf[4] = {0u, 0u, 0u, 0u};
     bool have_pf = false;
 
     for (int step = 0; step < T; ++step) {
         const int t = dir ? T - 1 - step : step;
-        const int tp = dir ? t + 1 : t - 1;
 #pragma unroll
         for (int bi = 0; bi < 2; ++bi) {
             if (nvalid[bi] == 0) continue;          // (uniform) no second batch, or an empty one
@@ -197,20 +204,22 @@ __global__ __launch_bounds__(RM_THREADS) void rec_fwd_mfma_kernel(RecMfmaArgs a)
                 // valid row — so that the memory system does not carry 16 KB of polls per workgroup and round.
                 if (!l2x) {
                     const int lrow = nvalid[bi] - 1;
-                    const unsigned* cp = reinterpret_cast<const unsigned*>(a.out + ((long)(bbase[bi] + lrow) * T + tp) * 2 * H + dir * H) + (lane < G ? lane * RM_UW + RM_UW - 1 : 0);
+                    const unsigned* cp = reinterpret_cast<const unsigned*>(ring + (size_t)(bi * 4 + ((step - 1) & 3)) * RSLOT + lrow * H) + (lane < G ? lane * RM_UW + RM_UW - 1 : 0);
                     wg_canary_wait(cflags, ++cep, 1, wave, lane, cp, lane < G, a.err, 0xDEAD0031u);
                 }
                 if (bi == 0) RM_STAMP(1);
                 {
                     // this lane's float4 of the tile: prefetched during the other batch's half-round when two batches alternate
                     f32x4 v;
-                    const float* src = tile_src(bi, tp);
+                    const float* src = tile_src(bi, step - 1);
                     if (have_pf) {
 #pragma unroll
                         for (int k = 0; k < 4; ++k) v[k] = __uint_as_float(pf[k]);
                     } else {
-                        // same XCD: the producers' plain stores sit in this XCD's L2 — read past the L1 only; otherwise ordinary loads first
-                        v = l2x ? ld4_agent(src) : *reinterpret_cast<const f32x4*>(src);
+                        // agent-scope loads in both modes: ring slots are REUSED every four steps, so an ordinary load could hit a stale copy
+                        // of the line in this CU's L1 or this XCD's L2 (same XCD: the producers' plain stores sit in the shared L2, read past
+                        // the L1 only; otherwise the canary above has seen the write-through stores land)
+                        v = ld4_agent(src);
                     }
                     if (has_sentinel(v)) {          // raced ahead of a producer's lines: re-read past the L1 / L2
                         unsigned spins = 0;
@@ -260,8 +269,7 @@ __global__ __launch_bounds__(RM_THREADS) void rec_fwd_mfma_kernel(RecMfmaArgs a)
                 const int nb_i = bi ^ 1;
                 const int nstep = bi == 0 ? step : step + 1;
                 if (nvalid[nb_i] != 0 && nstep > 0 && nstep < T) {
-                    const int nt_ = dir ? T - 1 - nstep : nstep;
-                    const unsigned* src = reinterpret_cast<const unsigned*>(tile_src(nb_i, dir ? nt_ + 1 : nt_ - 1));
+                    const unsigned* src = reinterpret_cast<const unsigned*>(tile_src(nb_i, nstep - 1));
 #pragma unroll
                     for (int k = 0; k < 4; ++k) pf[k] = __hip_atomic_load(src + k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                     have_pf = true;
@@ -299,9 +307,15 @@ __global__ __launch_bounds__(RM_THREADS) void rec_fwd_mfma_kernel(RecMfmaArgs a)
                 c[bi] = fg * c[bi] + ig * gg;
                 const float h = og * tanhf_acc(c[bi]);
                 const unsigned cb = opaque((unsigned)(bbase[bi] + cs));
-                float* hp = a.out + ((long)cb * T + t) * 2 * H + dir * H + u0 + cu;          // the layer output IS the hand-off slab
+                float* hp = ring + (size_t)(bi * 4 + (step & 3)) * RSLOT + opaque((unsigned)(cs * H + u0 + cu));
                 if (l2x) __hip_atomic_store(reinterpret_cast<unsigned*>(hp), pub_bits(h), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
                 else st1_agent(hp, h);
+                a.out[((long)cb * T + t) * 2 * H + dir * H + u0 + cu] = h;
+                if (step + 2 < T) {         // its slot of step + 2 back to the sentinel
+                    unsigned* sp = reinterpret_cast<unsigned*>(ring + (size_t)(bi * 4 + ((step + 2) & 3)) * RSLOT + opaque((unsigned)(cs * H + u0 + cu)));
+                    if (l2x) __hip_atomic_store(sp, PS_SENT, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                    else __hip_atomic_store(sp, PS_SENT, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
                 if (STASH) {
                     a.hprev[(srow + t) * H + u0 + cu] = hlast[bi];
                     a.cbuf[(srow + t) * H + u0 + cu] = c[bi];
@@ -538,7 +552,7 @@ __global__ __launch_bounds__(RM_THREADS) void rec_bwd_mfma_kernel(RecMfmaBwdArgs
 }  // namespace
 
 // Eligibility: the shapes this form pays for.  Measured on MI355X, layer-0 forward at H = 256, T = 400 (tools/ubench_rec_mfma.py):
-// B = 64 0.93 ms (the VALU multi-utterance kernels: 0.85-0.88), 128 1.08 (1.26), 256 1.33 (2.33), 512 2.29 (4.38), 2048 8.6 (17.1).
+// B = 64 0.93 ms before the ring (the VALU multi-utterance kernels: 0.85-0.88), 128 0.85 (1.26), 256 1.07 (2.33), 512 2.10 (4.38), 2048 8.0 (17.1).
 bool rec_fwd_mfma_eligible(int B, int H) {
     if (opt_get(OPT_REC_MFMA) == 0) return false;
     return H == 256 && B >= 128;
@@ -558,14 +572,15 @@ int rec_fwd_mfma(float* gates, const float* w_hh_f, const float* w_hh_r, float* 
     // one batch of 16 sequences per group while that covers the launch; beyond it two batches per group, stepped alternately
     const int nbat = B > groups_max * RM_NB ? 2 : 1;
     const int chunk = groups_max * RM_NB * nbat;
-    // the output buffer is the hand-off slab: sentinel-fill it (every element is overwritten by exactly one cell lane)
-    LAS_HIP_CHECK(hipMemsetAsync(out, 0xFF, sizeof(float) * (size_t)B * T * 2 * H, stream));
+    float* ring = reinterpret_cast<float*>(reinterpret_cast<char*>(xbuf) + REC_MFMA_RING_OFFSET);       // (rec_xbuf_bytes makes room for it)
     for (int b0 = 0; b0 < B; b0 += chunk) {
         const int Bc = std::min(chunk, B - b0);
         const int grid = 2 * ((Bc + nbat * RM_NB - 1) / (nbat * RM_NB)) * C::G;
         // id slots of the placement check: 32 per group, zeroed per launch (rec_xbuf_bytes covers 2 (B + 15) groups)
         LAS_HIP_CHECK(hipMemsetAsync(xbuf, 0, sizeof(unsigned long long) * 32 * (size_t)(grid / C::G), stream));
-        RecMfmaArgs a{gates, w_hh_f, w_hh_r, out, cbuf, hprev, B, T, b0, Bc, err, nbat, xbuf, (int)opt_get(OPT_REC_AGENT_HANDOFF)};
+        // the hand-off ring: four sentinel-filled slots of 16 x H floats per (group, batch)
+        LAS_HIP_CHECK(hipMemsetAsync(ring, 0xFF, sizeof(float) * (size_t)(grid / C::G) * 2 * 4 * RM_NB * H, stream));
+        RecMfmaArgs a{gates, w_hh_f, w_hh_r, out, cbuf, hprev, B, T, b0, Bc, err, nbat, xbuf, (int)opt_get(OPT_REC_AGENT_HANDOFF), ring};
         if (stash) {
             if (!persistent_launch_fits(rec_fwd_mfma_kernel<256, true>, RM_THREADS, smem, grid))
                 return fail(LAS_ERR_UNSUPPORTED, "rec_fwd_mfma: %s%ld workgroups cannot all be resident", "", (long)grid);
@@ -631,5 +646,11 @@ extern "C" void las_debug_rm_bwd_trace(unsigned long long* host_out) {
     (void)hipMemcpyFromSymbol(host_out, HIP_SYMBOL(rm_bwd_trace), sizeof(unsigned long long) * 256 * 8);
 }
 #endif
+
+// extra bytes of a recurrence workspace for the matrix-pipe kernels (shape only): the forward's hand-off ring behind the id slots
+size_t rec_mfma_xbuf_extra_bytes(int B, int H) {
+    if (!(H == 256 && B >= 128)) return 0;
+    return REC_MFMA_RING_OFFSET + sizeof(float) * (size_t)32 * 2 * 4 * RM_NB * 256;        // 32 groups x 2 batches x 4 slots x 16 KB
+}
 
 }  // namespace las
