@@ -1,7 +1,7 @@
 // Multi-utterance forward recurrence of a BiLSTM layer on the MATRIX pipe (gfx950): the large-batch form of pblstm_rec.hip.
 //
 // Replaces the recurrent half of nn.LSTM(bidirectional=True) behind the reference's pBLSTMLayer (model/las_model.py:72-79,90)
-// when a launch carries enough utterances to fill MFMA tiles (B >= 128 at H = 256); cell equations, gate order, stash layout and
+// when a launch carries enough utterances to fill MFMA tiles (B >= 64 at H = 256); cell equations, gate order, stash layout and
 // the reverse direction are those of pblstm_rec.hip (rec_fwd_generic is the executable specification).
 //
 // Why: with one utterance per group the recurrent product is a mat-vec and lives on the VALU (64 FMAs per lane and step).  The
@@ -111,8 +111,11 @@ __global__ __launch_bounds__(RM_THREADS) void rec_fwd_mfma_kernel(RecMfmaArgs a)
     int group, member;
     {
         const int bid = blockIdx.x;
-        if ((ngroups & 7) == 0) { const int q = bid >> 3; member = q % G; group = (q / G) * 8 + (bid & 7); }
-        else { member = bid % G; group = bid / G; }
+        // XCD-local groups under round-robin dispatch (block b -> XCD b % 8, verified at run time below): the grid is padded to whole
+        // rounds of eight groups and the workgroups of the missing groups leave at once
+        const int q = bid >> 3;
+        member = q % G; group = (q / G) * 8 + (bid & 7);
+        if (group >= ngroups) return;
     }
     const int dir = group >= ngb ? 1 : 0;
     const float* __restrict__ w_hh = dir ? a.w_hh_r : a.w_hh_f;
@@ -393,8 +396,11 @@ __global__ __launch_bounds__(RM_THREADS) void rec_bwd_mfma_kernel(RecMfmaBwdArgs
     int group, member;
     {
         const int bid = blockIdx.x;
-        if ((ngroups & 7) == 0) { const int q = bid >> 3; member = q % G; group = (q / G) * 8 + (bid & 7); }
-        else { member = bid % G; group = bid / G; }
+        // XCD-local groups under round-robin dispatch (block b -> XCD b % 8, verified at run time below): the grid is padded to whole
+        // rounds of eight groups and the workgroups of the missing groups leave at once
+        const int q = bid >> 3;
+        member = q % G; group = (q / G) * 8 + (bid & 7);
+        if (group >= ngroups) return;
     }
     const int dir = group >= ngb ? 1 : 0;
     const int u0 = member * RM_UW;
@@ -552,10 +558,11 @@ __global__ __launch_bounds__(RM_THREADS) void rec_bwd_mfma_kernel(RecMfmaBwdArgs
 }  // namespace
 
 // Eligibility: the shapes this form pays for.  Measured on MI355X, layer-0 forward at H = 256, T = 400 (tools/ubench_rec_mfma.py):
-// B = 64 0.93 ms before the ring (the VALU multi-utterance kernels: 0.85-0.88), 128 0.85 (1.26), 256 1.07 (2.33), 512 2.10 (4.38), 2048 8.0 (17.1).
+// B = 48 0.80 ms (the VALU multi-utterance kernels: 0.77), 64 0.80 (0.86), 96 0.82 (1.16), 128 0.84 (1.28), 200 1.04 (2.22), 256 1.07 (2.33), 512 2.10 (4.38),
+// 2048 8.0 (17.1); one layer's backward incl. its GEMMs at B = 48 1.69 (1.80), 96 2.04 (2.73), 128 2.33 (3.07), 512 7.3 (15.2).
 bool rec_fwd_mfma_eligible(int B, int H) {
     if (opt_get(OPT_REC_MFMA) == 0) return false;
-    return H == 256 && B >= 128;
+    return H == 256 && B >= 64;
 }
 
 int rec_fwd_mfma(float* gates, const float* w_hh_f, const float* w_hh_r, float* out, float* cbuf, float* hprev, int B, int T, int H,
@@ -575,11 +582,12 @@ int rec_fwd_mfma(float* gates, const float* w_hh_f, const float* w_hh_r, float* 
     float* ring = reinterpret_cast<float*>(reinterpret_cast<char*>(xbuf) + REC_MFMA_RING_OFFSET);       // (rec_xbuf_bytes makes room for it)
     for (int b0 = 0; b0 < B; b0 += chunk) {
         const int Bc = std::min(chunk, B - b0);
-        const int grid = 2 * ((Bc + nbat * RM_NB - 1) / (nbat * RM_NB)) * C::G;
+        const int ngroups = 2 * ((Bc + nbat * RM_NB - 1) / (nbat * RM_NB));
+        const int grid = (ngroups + 7) / 8 * 8 * C::G;        // padded to whole rounds of eight groups (XCD-local placement)
         // id slots of the placement check: 32 per group, zeroed per launch (rec_xbuf_bytes covers 2 (B + 15) groups)
-        LAS_HIP_CHECK(hipMemsetAsync(xbuf, 0, sizeof(unsigned long long) * 32 * (size_t)(grid / C::G), stream));
+        LAS_HIP_CHECK(hipMemsetAsync(xbuf, 0, sizeof(unsigned long long) * 32 * (size_t)ngroups, stream));
         // the hand-off ring: four sentinel-filled slots of 16 x H floats per (group, batch)
-        LAS_HIP_CHECK(hipMemsetAsync(ring, 0xFF, sizeof(float) * (size_t)(grid / C::G) * 2 * 4 * RM_NB * H, stream));
+        LAS_HIP_CHECK(hipMemsetAsync(ring, 0xFF, sizeof(float) * (size_t)ngroups * 2 * 4 * RM_NB * H, stream));
         RecMfmaArgs a{gates, w_hh_f, w_hh_r, out, cbuf, hprev, B, T, b0, Bc, err, nbat, xbuf, (int)opt_get(OPT_REC_AGENT_HANDOFF), ring};
         if (stash) {
             if (!persistent_launch_fits(rec_fwd_mfma_kernel<256, true>, RM_THREADS, smem, grid))
@@ -598,12 +606,12 @@ int rec_fwd_mfma(float* gates, const float* w_hh_f, const float* w_hh_r, float* 
 
 bool rec_bwd_mfma_eligible(int B, int H) {
     if (opt_get(OPT_REC_MFMA) == 0) return false;
-    return H == 256 && B >= 128;
+    return H == 256 && B >= 64;
 }
 
 // floats of the partial-sum ring behind the xbuf region of a backward workspace (shape only: the caller sizes its workspace with it)
 size_t rec_bwd_mfma_ring_floats(int B, int H) {
-    if (!(H == 256 && B >= 128)) return 0;
+    if (!(H == 256 && B >= 64)) return 0;
     return (size_t)32 * RecMfmaBwd<256>::RING;          // 32 groups (256 CUs / 8) is the most one launch carries
 }
 
@@ -622,7 +630,7 @@ int rec_bwd_mfma(const float* dout, const float* gates, const float* cbuf, const
     const int chunk = groups_max * RM_NB;
     {   // residency of the largest launch before anything is written
         const int Bc = std::min(chunk, B);
-        const int grid = 2 * ((Bc + RM_NB - 1) / RM_NB) * C::G;
+        const int grid = (2 * ((Bc + RM_NB - 1) / RM_NB) + 7) / 8 * 8 * C::G;
         if (!persistent_launch_fits(rec_bwd_mfma_kernel<256>, RM_THREADS, smem, grid))
             return fail(LAS_ERR_UNSUPPORTED, "rec_bwd_mfma: %s%ld workgroups cannot all be resident", "", (long)grid);
     }
@@ -630,7 +638,7 @@ int rec_bwd_mfma(const float* dout, const float* gates, const float* cbuf, const
     for (int b0 = 0; b0 < B; b0 += chunk) {
         const int Bc = std::min(chunk, B - b0);
         const int ngroups = 2 * ((Bc + RM_NB - 1) / RM_NB);
-        const int grid = ngroups * C::G;
+        const int grid = (ngroups + 7) / 8 * 8 * C::G;          // padded to whole rounds of eight groups (XCD-local placement)
         LAS_HIP_CHECK(hipMemsetAsync(xbuf, 0, sizeof(unsigned long long) * 32 * (size_t)ngroups, stream));
         LAS_HIP_CHECK(hipMemsetAsync(ring, 0xFF, sizeof(float) * (size_t)ngroups * C::RING, stream));
         RecMfmaBwdArgs a{dout, gates, cbuf, w_hh_t, dgates, db_f, db_r, ring, B, T, b0, Bc, err, xbuf, (int)opt_get(OPT_REC_AGENT_HANDOFF)};
@@ -649,7 +657,7 @@ extern "C" void las_debug_rm_bwd_trace(unsigned long long* host_out) {
 
 // extra bytes of a recurrence workspace for the matrix-pipe kernels (shape only): the forward's hand-off ring behind the id slots
 size_t rec_mfma_xbuf_extra_bytes(int B, int H) {
-    if (!(H == 256 && B >= 128)) return 0;
+    if (!(H == 256 && B >= 64)) return 0;
     return REC_MFMA_RING_OFFSET + sizeof(float) * (size_t)32 * 2 * 4 * RM_NB * 256;        // 32 groups x 2 batches x 4 slots x 16 KB
 }
 
