@@ -239,12 +239,13 @@ def test_multi_utterance_recurrence_matches_generic(H, B, T):
         assert_close(res[0][k], res[1][k], f"multi-utterance recurrence H={H} B={B}: {k}", rtol=1e-3, atol=2e-5 * scale)
 
 
-@pytest.mark.parametrize("B,T", [(144, 12), (300, 10), (130, 6)])
-def test_matrix_pipe_recurrence_matches_generic(B, T):
-    """Batches above 128 utterances at H = 256: the forward recurrence runs 16 utterances per group as MFMA tiles on the bf16 matrix
-    pipe (pblstm_rec_mfma.hip; partial last batch at B = 144 / 130, two alternating batches per group and a partial one at B = 300).
-    Forward output and — through the stash it leaves — dx and all eight parameter gradients against the generic kernels; with the
-    option switched off the VALU multi-utterance kernels must give the same."""
+@pytest.mark.parametrize("B,T,agent", [(144, 12, 0), (300, 10, 0), (130, 6, 0), (70, 9, 0), (200, 7, 1), (520, 5, 1)])
+def test_matrix_pipe_recurrence_matches_generic(B, T, agent):
+    """Batches from 64 utterances at H = 256: both recurrences run 16 utterances per group as MFMA tiles on the bf16 matrix pipe
+    (pblstm_rec_mfma.hip; partial last batch at B = 144 / 130 / 70, two alternating batches per group in the forward and two launches
+    in the backward at B = 300 / 520).  Forward output, dx and all eight parameter gradients against the generic kernels; with the
+    option switched off the VALU multi-utterance kernels must give the same.  agent = 1 forces the placement-independent hand-off
+    (agent-scope stores and loads through memory) that a group uses when its workgroups do not share an XCD."""
     import las_pytorch_amd
     from las_pytorch_amd import _cabi, pBLSTMLayer
     from las_pytorch_amd.model.las_model import set_force_generic
@@ -257,6 +258,7 @@ def test_matrix_pipe_recurrence_matches_generic(B, T):
     for force, mfma in ((False, 1), (True, 1), (False, 0)):
         set_force_generic(layer, force)
         _cabi.set_option("REC_MFMA", mfma)
+        _cabi.set_option("REC_AGENT_HANDOFF", agent)
         try:
             layer.zero_grad(set_to_none=True)
             x = x0.clone().requires_grad_(True)
@@ -264,6 +266,7 @@ def test_matrix_pipe_recurrence_matches_generic(B, T):
             (out * w).sum().backward()
         finally:
             _cabi.set_option("REC_MFMA", 1)
+            _cabi.set_option("REC_AGENT_HANDOFF", 0)
         res.append(dict(out=out.detach().cpu().numpy(), dx=x.grad.cpu().numpy(),
                         **{n: p.grad.cpu().numpy() for n, p in layer.named_parameters()}))
     torch.cuda.synchronize()
