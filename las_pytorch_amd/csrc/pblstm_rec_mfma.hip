@@ -576,6 +576,8 @@ int rec_fwd_mfma(float* gates, const float* w_hh_f, const float* w_hh_r, float* 
     const int groups_max = cus / (2 * C::G);            // groups per direction that are resident at once
     if (groups_max < 1) return fail(LAS_ERR_UNSUPPORTED, "rec_fwd_mfma: %s%ld compute units are too few", "", (long)cus);
     const size_t smem = sizeof(float) * C::LDS_FLOATS;
+    if (stash) LAS_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&rec_fwd_mfma_kernel<256, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
+    else LAS_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&rec_fwd_mfma_kernel<256, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
     // one batch of 16 sequences per group while that covers the launch; beyond it two batches per group, stepped alternately
     const int nbat = B > groups_max * RM_NB ? 2 : 1;
     const int chunk = groups_max * RM_NB * nbat;
