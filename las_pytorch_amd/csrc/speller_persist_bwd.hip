@@ -21,7 +21,8 @@
 // matrices spilled; cell-state gradients never leave them.
 // PRE variant, round 3 (speller_persist_bwd_pre_kernel: roles X, R, AttnBwdPre2Role — the training case): the attention workgroups
 // contract the gate-gradient row with their P rows (no dG0 W_ctx product on the chain), exchange their parts of dq inside the utterance
-// and apply the TOP cell's backward for a unit slice themselves: chain A -> X -> A(s-1); Y / RY do not exist there, R only carries.
+// and apply the TOP cell's backward for a unit slice themselves: chain A -> X -> A(s-1); Y / RY do not exist there; X and R of a tile
+// share the chain product (ProdPre2Role: half of K each, R's partial sum reaches X through the L2 of the XCD they share).
 // Hand-off uses the protocol of speller_persist.hip (persist_common.h): sentinel-prefilled per-step slabs, agent-scope
 // producers writing whole cache lines, one canary wave per consumer workgroup watching one dword per producer
 // workgroup, L2-shared plain loads for the big tiles with the MFMA product started while they land.
@@ -45,6 +46,8 @@ struct PersistBwdArgs {
     float* dGx;      // [2][U][Hs/16][32][64]    tiled gate gradients (layer, step, unit tile, row, unit*4+gate)
     float* dcx;      // [U][Hs/16][32][16]       context gradient carried to the previous step
     float* dhc;      // [U][Hs/16][32][16]       top-layer recurrent carry (R -> Y)
+    float* dhp;      // [U+1][2 Hs/16][256]      PRE variant: R's half of the chain product dG1 W_ih1 (R -> X, same XCD), sentinel-prefilled;
+                     //                          the extra step holds the XCC ids of the placement check
     // PRE variant (the forward ran speller_persist_fwd_pre_kernel): P = feat . W_ctx^T (B*T', 4Hs, columns unit*4+gate), the
     // forward's published sums gxf[s][b] = sum_t a_t P_t, and e0[s][b][t] = dcat_ctx[s][b] . feat[b][t] (one batched GEMM)
     const float* pctx; const float* gxf; const float* e0;
@@ -396,6 +399,233 @@ struct ProdRole {
                     dh_carry = reduce_tile<true>(red, poll_mul(dG0x + (size_t)s * GXS, la, x, a.err, cflags, cep, mfma_lds), wave, lane, tid);
                 }
                 PB_STAMP(0, s, 3);
+            }
+        }
+    }
+};
+
+
+// ------------------------------------------------------------------------------------------------ X / R workgroups, PRE variant (round 3, last change)
+// What the X product waits for is bytes into ONE CU: its 16 x 4Hs tile of dG1 is 128 KB (1.7 us at the ~32 B/clk a CU takes in
+// freshly written lines), and halving it needs twice the X workgroups — the launch has none to spare, but the R workgroups (the top
+// layer's recurrent carry, off the chain) idle ~8 of every 11 us.  X (j, mt) and R (j, mt) therefore SHARE the chain product
+// dh0 = dG1_s W_ih1: X takes the first half of K (64 KB in, half the weights: 16 registers), R the second half, and R hands its
+// 16 x 16 partial sum to X.  The two sit on the same XCD (block indices NXY apart, NXY a multiple of 8; verified at run time), so that
+// hand-over is an ordinary store into the shared L2 and an L1-bypassing load (~0.5 us) instead of a trip through memory.  R then
+// pulls the other half of the tile for its own product (dG1_s W_hh1 over the whole K), as before off the chain.
+template <int HS>
+struct ProdPre2Role {
+    using P = ProdRole<HS>;
+    static constexpr int NJ = P::NJ, KB = P::KB, KBH = KB / 2, RED = P::RED;
+    static constexpr size_t GXS = P::GXS, CXS = P::CXS;
+    static constexpr int NWG = 2 * NJ;                       // X (or R) workgroups
+    static constexpr size_t HPS = (size_t)NWG * 256;         // floats of one step of the partial-sum slab
+    static_assert(KBH >= 1 && (NJ / 2 * 4) == PS_NW * KBH, "a half of K is KBH blocks per wave");
+
+    struct Half {              // this lane's float4 offsets (bytes) of its KBH blocks of one K half inside a tiled dG slab
+        unsigned x[KBH];
+    };
+    static __device__ __forceinline__ Half half_addr(int half, int row, int wave, int lane) {
+        Half h;
+        const int kq = lane >> 4;
+#pragma unroll
+        for (int i = 0; i < KBH; ++i) {
+            const int gb = wave * KBH + i, tile = half * (NJ / 2) + (gb >> 2), blk = gb & 3;
+            h.x[i] = 4u * ((tile * 32 + row) * 64 + 16 * blk + 4 * kq);
+        }
+        return h;
+    }
+    // the matching columns of a weight matrix: W[(gate e) HS + unit(k)][16 j + n]
+    static __device__ __forceinline__ void load_wh(const float* w, int half, int j, int wave, int lane, float (&W)[KBH][4]) {
+        const int r = lane & 15, kq = lane >> 4;
+#pragma unroll
+        for (int i = 0; i < KBH; ++i) {
+            const int gb = wave * KBH + i, tile = half * (NJ / 2) + (gb >> 2), blk = gb & 3;
+            const int unit = tile * 16 + blk * 4 + kq;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) W[i][e] = w[((long)e * HS + unit) * HS + 16 * j + r];
+        }
+    }
+    // a half tile: ordinary (L2-shared) loads after the canary, every word checked, incomplete slots re-read past the caches
+    static __device__ __forceinline__ void issue_half(const float* base, const Half& h, f32x4 (&x)[KBH]) {
+#pragma unroll
+        for (int i = 0; i < KBH; ++i) x[i] = *reinterpret_cast<const f32x4*>(at_bytes(base, opaque(h.x[i])));
+    }
+    static __device__ __forceinline__ void load_half(const float* base, const Half& h, bool ok, f32x4 (&x)[KBH], unsigned* err) {
+        issue_half(base, h, x);
+        fix_half(base, h, ok, x, err);
+    }
+    static __device__ __forceinline__ void fix_half(const float* base, const Half& h, bool ok, f32x4 (&x)[KBH], unsigned* err) {
+        bool bad = false;
+#pragma unroll
+        for (int i = 0; i < KBH; ++i) bad |= __any(ok && has_sentinel(x[i]));
+        unsigned spins = 0;
+        while (bad) {
+            if (spin_expired(spins, err, 0xDEAD002Du)) break;
+            bad = false;
+#pragma unroll
+            for (int i = 0; i < KBH; ++i) {
+                if (__any(ok && has_sentinel(x[i]))) {
+                    x[i] = ld4_agent(at_bytes(base, opaque(h.x[i])));
+                    bad |= __any(ok && has_sentinel(x[i]));
+                }
+            }
+        }
+    }
+    static __device__ __forceinline__ f32x4 mfma_half(const f32x4 (&x)[KBH], const float (&W)[KBH][4], f32x4 acc) {
+#pragma unroll
+        for (int i = 0; i < KBH; ++i)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(x[i][e], W[i][e], acc, 0, 0, 0);
+        return acc;
+    }
+
+    template <bool IS_X>
+    static __device__ void run(const PersistBwdArgs& a, float* smem, const int widx) {
+        const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+        const int j = widx >> 1, mt = widx & 1;
+        const int B = a.B, U = a.U;
+        if (mt * 16 >= B) return;                         // no utterance in this M-tile (X and R of the tile leave together)
+        const bool first_wg = widx == 0;
+        float* red = smem;
+        const int r = lane & 15;
+        const bool ok = mt * 16 + r < B;
+        const int row = ok ? mt * 16 + r : mt * 16;
+        const Half h0 = half_addr(0, row, wave, lane), h1 = half_addr(1, row, wave, lane);
+        const typename P::Lane la = P::lane_addr(B, mt, wave, lane, a.ns);
+        volatile unsigned* cflags = reinterpret_cast<volatile unsigned*>(smem + RED + PS_NW * KB * 64 * 4);
+        unsigned cep = 0;
+        if (tid < 4) cflags[tid] = 0u;
+        // ---- placement check: X and R of a tile publish their XCC ids in the extra step of the partial-sum slab
+        bool l2x;
+        {
+            unsigned xcc;
+            asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID, 0, 4)" : "=s"(xcc));
+            unsigned* ids = reinterpret_cast<unsigned*>(a.dhp + (size_t)U * HPS + (size_t)widx * 256);
+            volatile int* flag = reinterpret_cast<volatile int*>(smem + RED);
+            if (tid == 0) { *flag = 1; __hip_atomic_store(ids + (IS_X ? 0 : 1), 0xC0DE0000u | xcc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+            lds_barrier();
+            if (tid == 0) {
+                unsigned spins = 0, v;
+                for (;;) {
+                    v = __hip_atomic_load(ids + (IS_X ? 1 : 0), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    if (v != PS_SENT) break;
+                    if (spin_expired(spins, a.err, 0xDEAD002Eu)) break;
+                }
+                if (v != (0xC0DE0000u | xcc)) *flag = 0;
+            }
+            lds_barrier();
+            l2x = *flag != 0;
+            lds_barrier();
+        }
+        const int pb = mt * 16 + (tid >> 4), pu = tid & 15;
+        const bool pw = tid < 256 && pb < B;
+        const unsigned o1 = 4u * ((unsigned)pb * HS + 16 * j + pu);
+        const unsigned o4 = 4u * ((unsigned)pb * 4 * HS + 16 * j + pu);
+        const unsigned ox = 4u * ((((unsigned)j * 32 + pb) * 16 + pu) * 4);
+        const unsigned oc = 4u * (((unsigned)j * 32 + pb) * 16 + pu);
+        const unsigned op = 4u * ((unsigned)widx * 256 + (unsigned)(tid & 255));       // its word of the tile's partial sum
+        const float* dG1x = a.dGx + (size_t)U * GXS;
+        const float* dG0x = a.dGx;
+        auto canary = [&](int s) {
+            const unsigned* cp = reinterpret_cast<const unsigned*>(at_bytes(dG1x + (size_t)s * GXS, opaque(la.canaryA)));
+            wg_canary_wait(cflags, ++cep, la.npwA, wave, lane, cp, la.cactA, a.err, 0xDEAD0021u);
+            asm volatile("" ::: "memory");
+        };
+
+        if (IS_X) {
+            // ---- X: first half of dh0 = dG1 W_ih1, + R's half -> bottom cell backward -> dG0; recurrent carry dG0 W_hh0 (own, off the chain)
+            float Wx[KBH][4];
+            load_wh(a.w_ih1, 0, j, wave, lane, Wx);
+            float* wlds = smem + RED + (wave * KB * 64 + lane) * 4;              // W_hh0 columns: [wave][block][lane][gate]
+            {
+                float Wt[KB][4];
+                P::load_w(a.w_hh0, HS, 0, j, wave, lane, Wt);
+#pragma unroll
+                for (int blk = 0; blk < KB; ++blk) {
+                    f32x4 v;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[e] = Wt[blk][e];
+                    *reinterpret_cast<f32x4*>(wlds + blk * 256) = v;
+                }
+            }
+            auto mfma_lds = [&](const f32x4 (&xt)[KB]) {
+                f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int blk = 0; blk < KB; ++blk) {
+                    const f32x4 w = *reinterpret_cast<const f32x4*>(wlds + blk * 256);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(xt[blk][e], w[e], acc, 0, 0, 0);
+                }
+                return acc;
+            };
+            lds_barrier();
+            float dc = 0.f, dh_carry = 0.f;
+            f32x4 x[KB];
+            for (int s = U - 1; s >= 0; --s) {
+                typename P::CellIn ci;
+                if (pw) ci = P::load_cell(a, 0, s, opaque(o4), opaque(o1));
+                PB_STAMP(0, s, 0);
+                canary(s);
+                f32x4 xh[KBH];
+                load_half(dG1x + (size_t)s * GXS, h0, ok, xh, a.err);
+                const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
+                const f32x4 accx = mfma_half(xh, Wx, zero);
+                PB_STAMP(0, s, 1);
+                // R's half of the sum: one word per cell lane, from the shared L2 (or, if the pair does not share an XCD, from memory); a first
+                // look goes out before the reduction so that its latency hides under it
+                unsigned pv = PS_SENT;
+                if (pw) pv = __hip_atomic_load(reinterpret_cast<const unsigned*>(at_bytes(a.dhp + (size_t)s * HPS, opaque(op))), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                PB_STAMP(0, s, 6);
+                float dh0 = P::template reduce_tile<true>(red, accx, wave, lane, tid);
+                PB_STAMP(0, s, 7);
+                if (pw) {
+                    const unsigned* pp = reinterpret_cast<const unsigned*>(at_bytes(a.dhp + (size_t)s * HPS, opaque(op)));
+                    unsigned spins = 0, v = pv;
+                    while (v == PS_SENT) {
+                        v = __hip_atomic_load(pp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        if (v != PS_SENT) break;
+                        if (spin_expired(spins, a.err, 0xDEAD002Fu)) break;
+                    }
+                    dh0 += __uint_as_float(v);
+                    const f32x4 g = P::cell_bwd(ci, dh0 + dh_carry, dc);
+                    st4_agent(at_bytes(a.dGx + (size_t)s * GXS, opaque(ox)), g);
+                    P::stash_dG(a, 0, s, opaque(o4), g);
+                }
+                PB_STAMP(0, s, 2);
+                // ---- (off the chain) recurrent carry of the bottom layer for step s-1
+                if (s > 0) dh_carry = P::template reduce_tile<true>(red, P::poll_mul(dG0x + (size_t)s * GXS, la, x, a.err, cflags, cep, mfma_lds), wave, lane, tid);
+                PB_STAMP(0, s, 3);
+            }
+        } else {
+            // ---- R: second half of the chain product for X (first), then the top layer's recurrent carry dG1 W_hh1 over the whole K
+            float Wi[KBH][4], Wr0[KBH][4], Wr1[KBH][4];
+            load_wh(a.w_ih1, 1, j, wave, lane, Wi);
+            load_wh(a.w_hh1, 0, j, wave, lane, Wr0);
+            load_wh(a.w_hh1, 1, j, wave, lane, Wr1);
+            lds_barrier();
+            for (int s = U - 1; s >= 0; --s) {
+                PB_STAMP(3, s, 0);
+                canary(s);
+                // (the other half is pulled AFTER the partial sum is out: issued together, the two halves share the CU's intake and the
+                // half the chain waits for arrives later — 10.8 instead of 9.7 us per step)
+                f32x4 x1[KBH];
+                load_half(dG1x + (size_t)s * GXS, h1, ok, x1, a.err);
+                const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
+                const float part = P::template reduce_tile<true>(red, mfma_half(x1, Wi, zero), wave, lane, tid);
+                if (tid < 256) {
+                    float* dst = at_bytes(a.dhp + (size_t)s * HPS, opaque(op));
+                    if (l2x) __hip_atomic_store(reinterpret_cast<unsigned*>(dst), pub_bits(part), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                    else st1_agent(dst, part);
+                }
+                PB_STAMP(3, s, 1);
+                if (s == 0) break;
+                f32x4 x0[KBH];
+                load_half(dG1x + (size_t)s * GXS, h0, ok, x0, a.err);
+                const f32x4 accr = mfma_half(x1, Wr1, mfma_half(x0, Wr0, zero));
+                const float v = P::template reduce_tile<true>(red, accr, wave, lane, tid);
+                if (pw) st1_agent(at_bytes(a.dhc + (size_t)s * CXS, opaque(oc)), v);
+                PB_STAMP(3, s, 2);
             }
         }
     }
@@ -1002,8 +1232,8 @@ __global__ __launch_bounds__(PS_THREADS) void speller_persist_bwd_pre_kernel(Per
     extern __shared__ __attribute__((aligned(16))) float smem[];
     constexpr int NXY = (HS / 16) * 2;
     const int bx = blockIdx.x;
-    if (bx < NXY) ProdRole<HS>::template run<0, true>(a, smem, bx);
-    else if (bx < 2 * NXY) ProdRole<HS>::template run<2, true>(a, smem, bx - NXY);
+    if (bx < NXY) ProdPre2Role<HS>::template run<true>(a, smem, bx);
+    else if (bx < 2 * NXY) ProdPre2Role<HS>::template run<false>(a, smem, bx - NXY);
     else AttnBwdPre2Role<HS>::run(a, smem, bx - 2 * NXY);
 }
 
@@ -1065,7 +1295,8 @@ size_t speller_persist_bwd_workspace_floats(int B, int Tp, int U, int Hs, int M)
     const size_t classic = (size_t)ns * U * B * M + (size_t)U * B * ns * Hs + (size_t)2 * U * (Hs / 16) * 32 * 64 + (size_t)2 * (U + 1) * (Hs / 16) * 32 * 16;
     const size_t nsp = (size_t)persist_bwd_pre_ns(B, Tp, Hs, -1);
     // PRE variant: [e0 | sentinel-prefilled slabs: dq exchange (ns parts) | tiled dG (2 layers) | recurrent carry of the top layer]
-    const size_t pre = (nsp && Tp <= 448) ? (size_t)U * B * Tp + 4 + nsp * U * B * M + (size_t)2 * U * (Hs / 16) * 32 * 64 + (size_t)(U + 1) * (Hs / 16) * 32 * 16 : 0;
+    const size_t pre = (nsp && Tp <= 448) ? (size_t)U * B * Tp + 4 + nsp * U * B * M + (size_t)2 * U * (Hs / 16) * 32 * 64 + (size_t)(U + 1) * (Hs / 16) * 32 * 16 +
+                                            (size_t)(U + 1) * 2 * (Hs / 16) * 256 : 0;
     return std::max(classic, pre);
 }
 bool speller_persist_bwd_pre_eligible(int B, int Tp, int Hs, int D, int M, int V, int L, int heads, int use_mlp) {
@@ -1135,6 +1366,7 @@ int speller_persist_bwd(const PersistBwd& p, hipStream_t stream) {
         a.dqx = slabs;
         a.dGx = a.dqx + (size_t)a.ns * nq;
         a.dhc = a.dGx + (size_t)2 * p.U * (p.Hs / 16) * 32 * 64;
+        a.dhp = a.dhc + (size_t)(p.U + 1) * (p.Hs / 16) * 32 * 16;
         a.dcx = nullptr; a.dhA = nullptr; a.dqpre_part = nullptr;
         a.dqpre_all = p.dqpre_all;
         a.w_ih0 = p.w_ih0; a.ldw0 = p.V + p.Hs; a.V = p.V;
@@ -1158,7 +1390,8 @@ int speller_persist_bwd(const PersistBwd& p, hipStream_t stream) {
             }
             LAS_TRY(gemm_f32(g, stream));
         }
-        const size_t slab_floats = (size_t)a.ns * nq + (size_t)2 * p.U * (p.Hs / 16) * 32 * 64 + (size_t)(p.U + 1) * (p.Hs / 16) * 32 * 16;
+        const size_t slab_floats = (size_t)a.ns * nq + (size_t)2 * p.U * (p.Hs / 16) * 32 * 64 + (size_t)(p.U + 1) * (p.Hs / 16) * 32 * 16 +
+                                   (size_t)(p.U + 1) * 2 * (p.Hs / 16) * 256;
         LAS_HIP_CHECK(hipMemsetAsync(slabs, 0xFF, sizeof(float) * slab_floats, stream));
         const int grid = 2 * (p.Hs / 16) * 2 + a.ns * p.B;
         if (p.Hs == 512) LAS_TRY(launch_persist_bwd_pre<512>(a, grid, stream));
