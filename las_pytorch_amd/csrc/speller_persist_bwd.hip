@@ -416,55 +416,56 @@ struct ProdRole {
 template <int HS>
 struct ProdPre2Role {
     using P = ProdRole<HS>;
-    static constexpr int NJ = P::NJ, KB = P::KB, KBH = KB / 2, RED = P::RED;
+    static constexpr int NJ = P::NJ, KB = P::KB, RED = P::RED;
+    // the split of K: X takes KX of a wave's KB blocks, R the other KR.  Even halves are the measured best (5 : 3 in X's favour, meant to
+    // cover the ~0.6 us R's partial sum needs to reach X: 10.3 instead of 9.75 us per step)
+    static constexpr int KX = KB / 2, KR = KB - KX;
     static constexpr size_t GXS = P::GXS, CXS = P::CXS;
     static constexpr int NWG = 2 * NJ;                       // X (or R) workgroups
     static constexpr size_t HPS = (size_t)NWG * 256;         // floats of one step of the partial-sum slab
-    static_assert(KBH >= 1 && (NJ / 2 * 4) == PS_NW * KBH, "a half of K is KBH blocks per wave");
+    static_assert(KX >= 1 && KR >= 1 && NJ * 4 == PS_NW * KB, "K = NJ unit tiles of four 16-wide blocks, KB blocks per wave");
 
-    struct Half {              // this lane's float4 offsets (bytes) of its KBH blocks of one K half inside a tiled dG slab
-        unsigned x[KBH];
-    };
-    static __device__ __forceinline__ Half half_addr(int half, int row, int wave, int lane) {
-        Half h;
+    // part 0 = the first 16 KX blocks of K (X's share), part 1 = the rest; N = blocks per wave of that part
+    template <int N> struct Part { unsigned x[N]; };         // this lane's float4 offsets (bytes) inside a tiled dG slab
+    template <int PART, int N>
+    static __device__ __forceinline__ int block_of(int wave, int i) { return PART == 0 ? wave * N + i : PS_NW * KX + wave * N + i; }
+    template <int PART, int N>
+    static __device__ __forceinline__ Part<N> part_addr(int row, int wave, int lane) {
+        Part<N> h;
         const int kq = lane >> 4;
 #pragma unroll
-        for (int i = 0; i < KBH; ++i) {
-            const int gb = wave * KBH + i, tile = half * (NJ / 2) + (gb >> 2), blk = gb & 3;
+        for (int i = 0; i < N; ++i) {
+            const int gb = block_of<PART, N>(wave, i), tile = gb >> 2, blk = gb & 3;
             h.x[i] = 4u * ((tile * 32 + row) * 64 + 16 * blk + 4 * kq);
         }
         return h;
     }
     // the matching columns of a weight matrix: W[(gate e) HS + unit(k)][16 j + n]
-    static __device__ __forceinline__ void load_wh(const float* w, int half, int j, int wave, int lane, float (&W)[KBH][4]) {
+    template <int PART, int N>
+    static __device__ __forceinline__ void load_wh(const float* w, int j, int wave, int lane, float (&W)[N][4]) {
         const int r = lane & 15, kq = lane >> 4;
 #pragma unroll
-        for (int i = 0; i < KBH; ++i) {
-            const int gb = wave * KBH + i, tile = half * (NJ / 2) + (gb >> 2), blk = gb & 3;
+        for (int i = 0; i < N; ++i) {
+            const int gb = block_of<PART, N>(wave, i), tile = gb >> 2, blk = gb & 3;
             const int unit = tile * 16 + blk * 4 + kq;
 #pragma unroll
             for (int e = 0; e < 4; ++e) W[i][e] = w[((long)e * HS + unit) * HS + 16 * j + r];
         }
     }
-    // a half tile: ordinary (L2-shared) loads after the canary, every word checked, incomplete slots re-read past the caches
-    static __device__ __forceinline__ void issue_half(const float* base, const Half& h, f32x4 (&x)[KBH]) {
+    // a part of the tile: ordinary (L2-shared) loads after the canary, every word checked, incomplete slots re-read past the caches
+    template <int N>
+    static __device__ __forceinline__ void load_half(const float* base, const Part<N>& h, bool ok, f32x4 (&x)[N], unsigned* err) {
 #pragma unroll
-        for (int i = 0; i < KBH; ++i) x[i] = *reinterpret_cast<const f32x4*>(at_bytes(base, opaque(h.x[i])));
-    }
-    static __device__ __forceinline__ void load_half(const float* base, const Half& h, bool ok, f32x4 (&x)[KBH], unsigned* err) {
-        issue_half(base, h, x);
-        fix_half(base, h, ok, x, err);
-    }
-    static __device__ __forceinline__ void fix_half(const float* base, const Half& h, bool ok, f32x4 (&x)[KBH], unsigned* err) {
+        for (int i = 0; i < N; ++i) x[i] = *reinterpret_cast<const f32x4*>(at_bytes(base, opaque(h.x[i])));
         bool bad = false;
 #pragma unroll
-        for (int i = 0; i < KBH; ++i) bad |= __any(ok && has_sentinel(x[i]));
+        for (int i = 0; i < N; ++i) bad |= __any(ok && has_sentinel(x[i]));
         unsigned spins = 0;
         while (bad) {
             if (spin_expired(spins, err, 0xDEAD002Du)) break;
             bad = false;
 #pragma unroll
-            for (int i = 0; i < KBH; ++i) {
+            for (int i = 0; i < N; ++i) {
                 if (__any(ok && has_sentinel(x[i]))) {
                     x[i] = ld4_agent(at_bytes(base, opaque(h.x[i])));
                     bad |= __any(ok && has_sentinel(x[i]));
@@ -472,9 +473,10 @@ struct ProdPre2Role {
             }
         }
     }
-    static __device__ __forceinline__ f32x4 mfma_half(const f32x4 (&x)[KBH], const float (&W)[KBH][4], f32x4 acc) {
+    template <int N>
+    static __device__ __forceinline__ f32x4 mfma_half(const f32x4 (&x)[N], const float (&W)[N][4], f32x4 acc) {
 #pragma unroll
-        for (int i = 0; i < KBH; ++i)
+        for (int i = 0; i < N; ++i)
 #pragma unroll
             for (int e = 0; e < 4; ++e) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(x[i][e], W[i][e], acc, 0, 0, 0);
         return acc;
@@ -491,7 +493,8 @@ struct ProdPre2Role {
         const int r = lane & 15;
         const bool ok = mt * 16 + r < B;
         const int row = ok ? mt * 16 + r : mt * 16;
-        const Half h0 = half_addr(0, row, wave, lane), h1 = half_addr(1, row, wave, lane);
+        const Part<KX> h0 = part_addr<0, KX>(row, wave, lane);
+        const Part<KR> h1 = part_addr<1, KR>(row, wave, lane);
         const typename P::Lane la = P::lane_addr(B, mt, wave, lane, a.ns);
         volatile unsigned* cflags = reinterpret_cast<volatile unsigned*>(smem + RED + PS_NW * KB * 64 * 4);
         unsigned cep = 0;
@@ -535,8 +538,8 @@ struct ProdPre2Role {
 
         if (IS_X) {
             // ---- X: first half of dh0 = dG1 W_ih1, + R's half -> bottom cell backward -> dG0; recurrent carry dG0 W_hh0 (own, off the chain)
-            float Wx[KBH][4];
-            load_wh(a.w_ih1, 0, j, wave, lane, Wx);
+            float Wx[KX][4];
+            load_wh<0, KX>(a.w_ih1, j, wave, lane, Wx);
             float* wlds = smem + RED + (wave * KB * 64 + lane) * 4;              // W_hh0 columns: [wave][block][lane][gate]
             {
                 float Wt[KB][4];
@@ -567,7 +570,7 @@ struct ProdPre2Role {
                 if (pw) ci = P::load_cell(a, 0, s, opaque(o4), opaque(o1));
                 PB_STAMP(0, s, 0);
                 canary(s);
-                f32x4 xh[KBH];
+                f32x4 xh[KX];
                 load_half(dG1x + (size_t)s * GXS, h0, ok, xh, a.err);
                 const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
                 const f32x4 accx = mfma_half(xh, Wx, zero);
@@ -599,17 +602,17 @@ struct ProdPre2Role {
             }
         } else {
             // ---- R: second half of the chain product for X (first), then the top layer's recurrent carry dG1 W_hh1 over the whole K
-            float Wi[KBH][4], Wr0[KBH][4], Wr1[KBH][4];
-            load_wh(a.w_ih1, 1, j, wave, lane, Wi);
-            load_wh(a.w_hh1, 0, j, wave, lane, Wr0);
-            load_wh(a.w_hh1, 1, j, wave, lane, Wr1);
+            float Wi[KR][4], Wr0[KX][4], Wr1[KR][4];
+            load_wh<1, KR>(a.w_ih1, j, wave, lane, Wi);
+            load_wh<0, KX>(a.w_hh1, j, wave, lane, Wr0);
+            load_wh<1, KR>(a.w_hh1, j, wave, lane, Wr1);
             lds_barrier();
             for (int s = U - 1; s >= 0; --s) {
                 PB_STAMP(3, s, 0);
                 canary(s);
                 // (the other half is pulled AFTER the partial sum is out: issued together, the two halves share the CU's intake and the
                 // half the chain waits for arrives later — 10.8 instead of 9.7 us per step)
-                f32x4 x1[KBH];
+                f32x4 x1[KR];
                 load_half(dG1x + (size_t)s * GXS, h1, ok, x1, a.err);
                 const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
                 const float part = P::template reduce_tile<true>(red, mfma_half(x1, Wi, zero), wave, lane, tid);
@@ -620,7 +623,7 @@ struct ProdPre2Role {
                 }
                 PB_STAMP(3, s, 1);
                 if (s == 0) break;
-                f32x4 x0[KBH];
+                f32x4 x0[KX];
                 load_half(dG1x + (size_t)s * GXS, h0, ok, x0, a.err);
                 const f32x4 accr = mfma_half(x1, Wr1, mfma_half(x0, Wr0, zero));
                 const float v = P::template reduce_tile<true>(red, accr, wave, lane, tid);
