@@ -36,7 +36,7 @@
 extern "C" {
 #endif
 
-#define LAS_ABI_VERSION 6
+#define LAS_ABI_VERSION 7
 #define LAS_MAX_SPELLER_LAYERS 4
 
 /* flags */
@@ -58,6 +58,9 @@ const char* las_last_error(void);
  * case-insensitive, with or without the LAS_ prefix.  Returns 0, or 1 for an unknown key.
  *   GEMM_ARITH            1* split-operand bf16 MFMA (fp32-faithful, see las_gemm_f32), 0 fp32 MFMA
  *   GEMM_STREAMK, GEMM_SK_MIN_TILES, GEMM_SPLIT_BELOW, GEMM_SPLIT_TARGET   schedule thresholds of the GEMM (-1* = automatic)
+ *   GEMM_SK_FIXUP 1*      stream-K with in-kernel fix-up: tiles that straddle workgroup runs are summed from parked partial tiles by the
+ *                         workgroup owning the tile's first k-iteration (no atomics, no zeroing pass, any epilogue); 0: the atomic forms
+ *   GEMM_SKF_MIN_KT, GEMM_SKF_MIN_RUN  fewest k-iterations per tile / per workgroup run for that schedule (-1* = automatic: 8 / 8)
  *   GEMM_SLOTS_PER_CU     resident GEMM workgroups per CU (2*; read at the first GEMM)
  *   GEMM_GROUP 1*, GEMM_XCD_SWZ 1*, GEMM_BATCH_DIRS 1*          grouped weight-gradient launches / XCD order / batched directions
  *   SPELLER_PERSIST 1*, SPELLER_PERSIST_BWD 1*                   one-launch decode loop forward / backward (0: per-step launches)
@@ -273,8 +276,14 @@ int las_comm_destroy(void);
 int las_gemm_f32(const float* A, const float* B, float* C, const float* bias0, const float* bias1,
                  int M, int N, int K, int64_t lda, int64_t ldb, int64_t ldc, int a_kc, int b_kc,
                  int batch, int64_t sA, int64_t sB, int64_t sC, int splitk, int accumulate, int relu, void* stream);
+/* Stream-K fix-up bookkeeping: 0, or LAS_ERR_DEVICE (4) once after a fix-up wait of an earlier GEMM launch ran into its spin limit (its
+ * workgroups were not all resident, e.g. a foreign kernel held the CUs: the tile it was waiting for is wrong).  Reading clears the
+ * report.  Every las_gemm_* call and every entry point that issues GEMMs checks it too (one launch late); call it after a
+ * synchronisation for a definite answer. */
+int las_gemm_check(void);
 /* n independent GEMMs C_i (+)= A_i B_i in ONE launch (stream-K across the concatenated k-iterations of all problems) when they
- * share the operand orientation and every output is pre-zeroed (c_zeroed) or accumulated onto; otherwise one launch each.
+ * share the operand orientation (with GEMM_SK_FIXUP=0 every output must also be pre-zeroed (c_zeroed) or accumulated onto); otherwise
+ * one launch each.
  * A2/B2/K1: optional second source along K (k >= K1 reads A2/B2 at k-K1), single problems only.  This is how the backward
  * passes issue their weight-gradient contractions; exported so that bench.py times exactly the launches a step makes. */
 typedef struct las_gemm_desc {

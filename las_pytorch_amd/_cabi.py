@@ -44,6 +44,7 @@ PROTOTYPES = {
     "las_abi_version": (C.c_int, []),
     "las_last_error": (C.c_char_p, []),
     "las_set_option": (C.c_int, [C.c_char_p, C.c_int64]),
+    "las_gemm_check": (C.c_int, []),
     "las_get_option": (C.c_int, [C.c_char_p, C.POINTER(C.c_int64)]),
     "las_clip_adam_workspace_floats": (C.c_size_t, []),
     "las_clip_adam": (C.c_int, [C.POINTER(_f), C.POINTER(C.c_int64), C.c_int, _f, _f, _f, C.c_float, C.c_double, C.c_double, C.c_double,
@@ -205,6 +206,9 @@ def check_device_errors():
     """Synchronising check of the device error words: raises if any persistent kernel reported a hand-off timeout and
     clears the word so later launches run normally.  ``solver.batch_iterator`` calls this right after the loss reaches
     the host (the step's existing synchronisation point); tests, smoke and bench call it after their timed regions."""
+    if torch.cuda.is_available() and torch.cuda.is_initialized():
+        torch.cuda.synchronize()
+        check(lib().las_gemm_check())     # a stream-K fix-up wait that timed out (host-visible word, needs no device copy)
     for key, w in _err_words.items():
         v = int(w[0].item())
         if v != 0:

@@ -17,6 +17,8 @@
 #include "options.h"
 #include <stdlib.h>
 #include <algorithm>
+#include <atomic>
+#include <mutex>
 #include <type_traits>
 
 namespace las {
@@ -177,7 +179,37 @@ struct GemmParams {
     // persistent (data-parallel + stream-K) schedule
     int persistent, gy, kt, dp_tiles, sk_atomic_whole, xcd_swz;
     long sk_iters, sk_per;
+    // stream-K with in-kernel fix-up (no atomics, no zeroing pass): a workgroup that covers a tile's k-range only from k-iteration
+    // it0 > 0 parks its 128x128 partial sum in sk_part[slot] and raises sk_flag[slot] = sk_id; the workgroup that owns k-iteration 0
+    // of the tile (its LAST segment) adds the parked sums of the slots behind it and runs the epilogue (bias / accumulate / relu)
+    float* sk_part; unsigned* sk_flag; unsigned* sk_err; unsigned sk_id;
 };
+
+// what a segment does with its accumulators
+enum : int { SEG_STORE = 0, SEG_ATOMIC = 1, SEG_PART = 2 };
+struct SegRole {
+    int kind;           // SEG_STORE: epilogue + plain store (after adding the partial sums of slots [c0, c1));  SEG_ATOMIC: atomicAdd onto C;
+    int slot;           // SEG_PART: park the partial sum in sk_part[slot]
+    int c0, c1;
+    bool add_bias;
+};
+static __device__ __forceinline__ SegRole seg_store(bool add_bias = true) { return SegRole{SEG_STORE, 0, 0, 0, add_bias}; }
+static __device__ __forceinline__ SegRole seg_atomic(bool add_bias) { return SegRole{SEG_ATOMIC, 0, 0, 0, add_bias}; }
+
+// 16-byte agent-scope accesses (sc1: L2 write-through / L2-bypassing), the hand-off idiom of the persistent kernels (persist_common.h)
+static __device__ __forceinline__ void sk_st4(float* p, const f32x4 v) {
+    asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 2" : : "v"(p), "v"(v) : "memory");
+}
+static __device__ __forceinline__ void sk_ld4x4(const float* p, f32x4& a, f32x4& b, f32x4& c, f32x4& d) {      // p + 0, 4 KB, 8 KB, 12 KB
+    asm volatile("global_load_dwordx4 %0, %4, off sc1\n\t"
+                 "global_load_dwordx4 %1, %5, off sc1\n\t"
+                 "global_load_dwordx4 %2, %6, off sc1\n\t"
+                 "global_load_dwordx4 %3, %7, off sc1\n\t"
+                 "s_waitcnt vmcnt(0)"
+                 : "=&v"(a), "=&v"(b), "=&v"(c), "=&v"(d) : "v"(p), "v"(p + 1024), "v"(p + 2048), "v"(p + 3072) : "memory");
+}
+constexpr unsigned SK_SPIN_LIMIT = 1u << 24;
+
 
 // Load one BK x BM(BN) operand tile into registers (NLD float4 per thread).
 // KC = true : element(r, k) at P[r*ld + k]   (row index r is the M or N index)
@@ -258,7 +290,8 @@ __device__ __forceinline__ void store_tile(float (*S)[BM + PAD], const f32x4 (&r
 // value to accumulate onto); the contributor that owns k-iteration 0 adds the biases.
 template <bool A_KC, bool B_KC, bool SPLIT>
 __device__ __forceinline__ void gemm_segment(const GemmParams& p, float (*As)[BK][BM + PAD], float (*Bs)[BK][BN + PAD], unsigned* sp, int bz,
-                                             int m0, int n0, int kbeg, int kend, bool atomic, bool add_bias) {
+                                             int m0, int n0, int kbeg, int kend, const SegRole role) {
+    const bool atomic = role.kind == SEG_ATOMIC, add_bias = role.add_bias;
     const float* A = p.A + (long)bz * p.sA;
     const float* B = p.B + (long)bz * p.sB;
     float* C = p.C + (long)bz * p.sC;
@@ -585,6 +618,48 @@ __device__ __forceinline__ void gemm_segment(const GemmParams& p, float (*As)[BK
     }
 
     }
+    // Stream-K fix-up (workgroup-uniform role).  Parked image: [i][j][quad q of the 16 accumulator registers][thread][4 floats] — every
+    // thread of every workgroup holds the same tile positions, so the image needs no index arithmetic and a wave moves whole lines.
+    if (role.kind == SEG_PART) {
+        float* dst = p.sk_part + (size_t)role.slot * (BM * BN) + threadIdx.x * 4;
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const f32x4 v = {acc[i][j][4 * q], acc[i][j][4 * q + 1], acc[i][j][4 * q + 2], acc[i][j][4 * q + 3]};
+                    sk_st4(dst + ((i * 2 + j) * 4 + q) * (GEMM_THREADS * 4), v);
+                }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // this wave's part has reached the memory side
+        __syncthreads();
+        if (threadIdx.x == 0) __hip_atomic_store(p.sk_flag + role.slot, p.sk_id, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        return;
+    }
+    for (int c = role.c0; c < role.c1; ++c) {
+        if (threadIdx.x == 0) {
+            unsigned spins = 0;
+            while (__hip_atomic_load(p.sk_flag + c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != p.sk_id) {
+                if (++spins > SK_SPIN_LIMIT) { atomicExch(p.sk_err, 1u); break; }      // a contributor that is not resident: reported by the host
+                __builtin_amdgcn_s_sleep(2);
+            }
+        }
+        __syncthreads();
+        const float* src = p.sk_part + (size_t)c * (BM * BN) + threadIdx.x * 4;
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                f32x4 v0, v1, v2, v3;
+                sk_ld4x4(src + ((i * 2 + j) * 4) * (GEMM_THREADS * 4), v0, v1, v2, v3);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    acc[i][j][e] += v0[e]; acc[i][j][4 + e] += v1[e]; acc[i][j][8 + e] += v2[e]; acc[i][j][12 + e] += v3[e];
+                }
+            }
+        __syncthreads();                                           // every wave has its part: the slot may be reused by a later launch
+        if (threadIdx.x == 0) __hip_atomic_store(p.sk_flag + c, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
     // Epilogue.  C/D map of 32x32 MFMA: col(n) = lane&31, row(m) = (r&3) + 8*(r>>2) + 4*(lane>>5).
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
@@ -656,7 +731,8 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_f32_kernel(GemmParams p)
         int tile = blockIdx.x;
         if (p.swz) tile = (tile & 7) * (gridDim.x >> 3) + (tile >> 3);
         const int kbeg = kz * p.kper;
-        gemm_segment<A_KC, B_KC, SPLIT>(p, As, Bs, sp, bz, (tile / p.gx) * BM, (tile % p.gx) * BN, kbeg, min(p.K, kbeg + p.kper), p.atomic, kz == 0);
+        gemm_segment<A_KC, B_KC, SPLIT>(p, As, Bs, sp, bz, (tile / p.gx) * BM, (tile % p.gx) * BN, kbeg, min(p.K, kbeg + p.kper),
+                                        p.atomic ? seg_atomic(kz == 0) : seg_store(kz == 0));
         return;
     }
     // workgroup -> slot: blocks are dispatched round-robin over the 8 XCDs (block b on XCD b % 8, observed; speed only), so
@@ -667,7 +743,7 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_f32_kernel(GemmParams p)
     const int per_batch = p.gx * p.gy;
     for (int tile = w; tile < p.dp_tiles; tile += W) {
         const int bz = tile / per_batch, t = tile % per_batch;
-        gemm_segment<A_KC, B_KC, SPLIT>(p, As, Bs, sp, bz, (t / p.gx) * BM, (t % p.gx) * BN, 0, p.K, false, true);
+        gemm_segment<A_KC, B_KC, SPLIT>(p, As, Bs, sp, bz, (t / p.gx) * BM, (t % p.gx) * BN, 0, p.K, seg_store());
     }
     long i0 = (long)w * p.sk_per, i1 = min(i0 + p.sk_per, p.sk_iters);
     while (i0 < i1) {
@@ -675,8 +751,18 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_f32_kernel(GemmParams p)
         const int it0 = (int)(i0 % p.kt), it1 = (int)min((long)p.kt, it0 + (i1 - i0));
         const int bz = tile / per_batch, t = tile % per_batch;
         const bool whole = it0 == 0 && it1 == p.kt;
-        gemm_segment<A_KC, B_KC, SPLIT>(p, As, Bs, sp, bz, (t / p.gx) * BM, (t % p.gx) * BN, it0 * BK, min(p.K, it1 * BK), !whole || p.sk_atomic_whole,
-                                 it0 == 0);
+        SegRole role;
+        if (p.sk_part == nullptr) {
+            role = (!whole || p.sk_atomic_whole) ? seg_atomic(it0 == 0) : seg_store();
+        } else if (it0 > 0) {
+            role = SegRole{SEG_PART, w, 0, 0, false};
+        } else {
+            // owner of the tile: the slots behind this one whose runs start inside the tile's k-range hold the rest of the sum
+            const long tile_end = i0 + p.kt;
+            const int c1 = (int)min((long)W, (min(tile_end, p.sk_iters) + p.sk_per - 1) / p.sk_per);
+            role = SegRole{SEG_STORE, 0, w + 1, whole ? w + 1 : c1, true};
+        }
+        gemm_segment<A_KC, B_KC, SPLIT>(p, As, Bs, sp, bz, (t / p.gx) * BM, (t % p.gx) * BN, it0 * BK, min(p.K, it1 * BK), role);
         i0 += it1 - it0;
     }
 }
@@ -689,7 +775,10 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_f32_kernel(GemmParams p)
 // as the balance allows (the atomic traffic is W + #tiles partial tiles, not W per problem).  Partial tiles accumulate with
 // atomics onto buffers the caller has zeroed (the flat gradient buffer); whole tiles are stored (or added) plainly.
 constexpr int GROUP_MAX = 8;
-struct GemmGroupParams { GemmParams prob[GROUP_MAX]; long first[GROUP_MAX + 1]; int n; int xcd_swz; };
+struct GemmGroupParams {
+    GemmParams prob[GROUP_MAX]; long first[GROUP_MAX + 1]; int n; int xcd_swz;
+    float* sk_part; unsigned* sk_flag; unsigned* sk_err; unsigned sk_id;      // stream-K fix-up (see GemmParams); null: atomics onto zeroed outputs
+};
 
 template <bool A_KC, bool B_KC, bool SPLIT>
 __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_group_kernel(GemmGroupParams g) {
@@ -703,8 +792,9 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_group_kernel(GemmGroupPa
     int pi = 0;
     while (pi + 1 < g.n && g.first[pi + 1] <= i0) ++pi;
     while (i0 < i1) {
-        const GemmParams p = g.prob[pi];       // by value: the fields live in SGPRs across the k-loop (fetching them from the
+        GemmParams p = g.prob[pi];             // by value: the fields live in SGPRs across the k-loop (fetching them from the
                                                // kernel-argument segment inside the loop measured slower)
+        p.sk_part = g.sk_part; p.sk_flag = g.sk_flag; p.sk_err = g.sk_err; p.sk_id = g.sk_id;
         const long pend = min(i1, g.first[pi + 1]);
         long l0 = i0 - g.first[pi];
         const long l1 = pend - g.first[pi];
@@ -712,7 +802,18 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_group_kernel(GemmGroupPa
             const int t = (int)(l0 / p.kt);
             const int it0 = (int)(l0 % p.kt), it1 = (int)min((long)p.kt, it0 + (l1 - l0));
             const bool whole = it0 == 0 && it1 == p.kt;
-            gemm_segment<A_KC, B_KC, SPLIT>(p, As, Bs, sp, 0, (t / p.gx) * BM, (t % p.gx) * BN, it0 * BK, min(p.K, it1 * BK), !whole, false);
+            SegRole role;
+            if (g.sk_part == nullptr) {
+                role = whole ? SegRole{SEG_STORE, 0, 0, 0, false} : seg_atomic(false);
+            } else if (it0 > 0) {
+                role = SegRole{SEG_PART, w, 0, 0, false};
+            } else {
+                // owner: the slots behind this one whose runs start before the tile's last k-iteration (global iteration space)
+                const long tile_end = g.first[pi] + (l0 - it0) + p.kt;
+                const int c1 = (int)min((long)W, (tile_end + per - 1) / per);
+                role = SegRole{SEG_STORE, 0, w + 1, whole ? w + 1 : c1, false};
+            }
+            gemm_segment<A_KC, B_KC, SPLIT>(p, As, Bs, sp, 0, (t / p.gx) * BM, (t % p.gx) * BN, it0 * BK, min(p.K, it1 * BK), role);
             l0 += it1 - it0;
         }
         i0 = pend;
@@ -746,6 +847,7 @@ static long tune(int key, long dflt) {
     const long v = opt_get(kTuneOpt[key]);
     return v >= 0 ? v : dflt;
 }
+static long tune_skf_min_run() { return opt_get(OPT_GEMM_SKF_MIN_RUN) >= 0 ? opt_get(OPT_GEMM_SKF_MIN_RUN) : 8; }
 
 template <class Kern>
 static int split_kernel_ready(Kern kernel) {       // dynamic LDS beyond 64 KB has to be allowed once per kernel
@@ -801,21 +903,77 @@ static int gemm_resident_slots() {      // persistent grid: two 256-thread workg
     return slots;
 }
 
+// ---- scratch of the stream-K fix-up: one per (device, stream), created on first use -------------------------------------------------
+// W parked partial tiles (64 KB each) + W flags + a host-visible error word.  This is the GEMM's own workspace handle (what a BLAS
+// handle carries); every other buffer of the library is the caller's.  Kernels of one stream run in order, so one scratch per stream
+// is race-free; a stream beyond SK_MAX_SCRATCH (or a first use during stream capture, where hipMalloc is illegal) gets none and
+// the GEMM takes the schedules that do not need it.
+struct SkScratch { int dev; hipStream_t stream; float* part; unsigned* flag; unsigned* err_host; unsigned* err_dev; int slots; };
+constexpr int SK_MAX_SCRATCH = 16;
+static std::mutex g_sk_mu;
+static SkScratch g_sk[SK_MAX_SCRATCH];
+static int g_sk_n = 0;
+static std::atomic<unsigned> g_sk_id{1};
+
+static const SkScratch* sk_scratch(hipStream_t stream, int slots) {
+    if (opt_get(OPT_GEMM_SK_FIXUP) == 0 || slots <= 0) return nullptr;
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return nullptr;
+    std::lock_guard<std::mutex> lk(g_sk_mu);
+    for (int i = 0; i < g_sk_n; ++i)
+        if (g_sk[i].dev == dev && g_sk[i].stream == stream && g_sk[i].slots >= slots) return &g_sk[i];
+    if (g_sk_n >= SK_MAX_SCRATCH) return nullptr;
+    hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+    if (hipStreamIsCapturing(stream, &cap) != hipSuccess || cap != hipStreamCaptureStatusNone) return nullptr;
+    SkScratch s{dev, stream, nullptr, nullptr, nullptr, nullptr, slots};
+    if (hipMalloc(&s.part, sizeof(float) * (size_t)slots * BM * BN) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
+    if (hipMalloc(&s.flag, sizeof(unsigned) * (size_t)slots) != hipSuccess || hipMemset(s.flag, 0, sizeof(unsigned) * (size_t)slots) != hipSuccess ||
+        hipHostMalloc(&s.err_host, sizeof(unsigned), hipHostMallocMapped) != hipSuccess ||
+        hipHostGetDevicePointer(reinterpret_cast<void**>(&s.err_dev), s.err_host, 0) != hipSuccess) {
+        (void)hipGetLastError();
+        if (s.part) (void)hipFree(s.part);
+        if (s.flag) (void)hipFree(s.flag);
+        if (s.err_host) (void)hipHostFree(s.err_host);
+        return nullptr;
+    }
+    *s.err_host = 0;
+    g_sk[g_sk_n] = s;
+    return &g_sk[g_sk_n++];
+}
+static unsigned sk_next_id() {
+    unsigned id = g_sk_id.fetch_add(1, std::memory_order_relaxed);
+    if (id == 0) id = g_sk_id.fetch_add(1, std::memory_order_relaxed);
+    return id;
+}
+// A fix-up wait that ran into its spin limit (a contributing workgroup was not resident: another kernel held the CUs) leaves a wrong
+// tile behind; the device raises the host-visible word and the next GEMM call (or las_gemm_check) fails loudly.
+int gemm_sk_check() {
+    std::lock_guard<std::mutex> lk(g_sk_mu);
+    bool bad = false;
+    for (int i = 0; i < g_sk_n; ++i)
+        if (*reinterpret_cast<volatile unsigned*>(g_sk[i].err_host) != 0) { *g_sk[i].err_host = 0; bad = true; }
+    return bad ? fail(LAS_ERR_DEVICE, "stream-K fix-up: a contributing workgroup never arrived (GEMM workgroups were not all resident)%s", "") : LAS_OK;
+}
+
+bool gemm_sk_fixup_ready(hipStream_t stream) { return opt_get(OPT_GEMM_STREAMK) != 0 && sk_scratch(stream, gemm_resident_slots()) != nullptr; }
+
 static bool gemm_aligned(const float* ptr, long ld, long bs) { return ((uintptr_t)ptr % 16 == 0) && (ld % 4 == 0) && (bs % 4 == 0); }
 
 int gemm_f32_group(const GemmDesc* ds, int n, hipStream_t stream) {
     const int group_on = (int)opt_get(OPT_GEMM_GROUP);
     const int W = gemm_resident_slots();
     bool ok = group_on && W > 0 && n >= 1 && n <= GROUP_MAX;
+    const SkScratch* sc = ok ? sk_scratch(stream, W) : nullptr;      // with the fix-up schedule an output need not start from zero
     for (int i = 0; ok && i < n; ++i) {
         const GemmDesc& d = ds[i];
-        ok = d.batch <= 1 && !d.relu && !d.bias0 && !d.bias1 && (d.c_zeroed || d.accumulate) && d.a_kc == ds[0].a_kc && d.b_kc == ds[0].b_kc &&
+        ok = d.batch <= 1 && !d.relu && !d.bias0 && !d.bias1 && (d.c_zeroed || d.accumulate || sc != nullptr) && d.a_kc == ds[0].a_kc && d.b_kc == ds[0].b_kc &&
              d.A2 == nullptr && d.M > 0 && d.N > 0 && d.K > 0;
     }
     if (!ok) {      // not groupable (or switched off): one launch per problem
         for (int i = 0; i < n; ++i) LAS_TRY(gemm_f32(ds[i], stream));
         return LAS_OK;
     }
+    LAS_TRY(gemm_sk_check());
     GemmGroupParams g;
     g.n = n;
     g.first[0] = 0;
@@ -832,7 +990,15 @@ int gemm_f32_group(const GemmDesc* ds, int n, hipStream_t stream) {
         p.accumulate = d.accumulate;           // whole tiles: plain add onto the caller's values instead of a plain store
         g.first[i + 1] = g.first[i] + (long)p.gx * p.gy * p.kt;
     }
-    return launch_group(g, ds[0].a_kc, ds[0].b_kc, dim3(W), stream);
+    // fix-up schedule: parked partial sums instead of atomics; runs of at least SKF_MIN_RUN k-iterations (small groups use fewer slots)
+    g.sk_part = nullptr; g.sk_flag = nullptr; g.sk_err = nullptr; g.sk_id = 0;
+    int Wg = W;
+    if (sc != nullptr) {
+        const long min_run = std::max<long>(1, tune_skf_min_run());
+        Wg = (int)std::min<long>(W, std::max<long>(8, g.first[n] / min_run / 8 * 8));
+        g.sk_part = sc->part; g.sk_flag = sc->flag; g.sk_err = sc->err_dev; g.sk_id = sk_next_id();
+    }
+    return launch_group(g, ds[0].a_kc, ds[0].b_kc, dim3(Wg), stream);
 }
 
 int gemm_f32(const GemmDesc& d, hipStream_t stream) {
@@ -864,6 +1030,26 @@ int gemm_f32(const GemmDesc& d, hipStream_t stream) {
     // per output of every partial tile) weigh more: there the persistent schedule is used only when whole tiles fill every slot at
     // least once (plain stores for those, stream-K for the ragged tail), fewer tiles take the classic grid / split-K
     const long min_tiles = tune(TUNE_SK_MIN_TILES, gemm_get_arith() == 1 ? W : 0);
+    p.sk_part = nullptr; p.sk_flag = nullptr; p.sk_err = nullptr; p.sk_id = 0;
+    LAS_TRY(gemm_sk_check());
+    // Stream-K with in-kernel fix-up: the k-iterations of ALL tiles laid end to end and cut into equal runs, one per resident
+    // workgroup; a tile that straddles runs is finished by the workgroup holding its first k-iteration, which adds the partial sums the
+    // others parked (plain coalesced 64 KB per partial instead of 16 K atomics, no zeroing pass, any epilogue).  Taken whenever the tile
+    // count does not fill whole rounds of the resident slots; a run is at least SKF_MIN_RUN k-iterations and a quarter tile.
+    {
+        const long total = tiles * kt;
+        const long skf_min_kt = opt_get(OPT_GEMM_SKF_MIN_KT) >= 0 ? opt_get(OPT_GEMM_SKF_MIN_KT) : 8;
+        const long min_run = std::max<long>(tune_skf_min_run(), (kt + 3) / 4);
+        const int Wuse = (int)std::min<long>(W, total / std::max<long>(1, min_run) / 8 * 8);
+        const bool uneven = (double)tiles / ((double)cdiv(tiles, W) * W) < 0.92;      // share of the resident slots a classic grid keeps busy
+        if (sk_on && d.splitk <= 1 && Wuse >= 16 && kt >= skf_min_kt && uneven) {
+            if (const SkScratch* sc = sk_scratch(stream, W)) {
+                p.persistent = 1; p.dp_tiles = 0; p.sk_iters = total; p.sk_per = (total + Wuse - 1) / Wuse;
+                p.sk_part = sc->part; p.sk_flag = sc->flag; p.sk_err = sc->err_dev; p.sk_id = sk_next_id();
+                return launch_gemm(p, d.a_kc, d.b_kc, dim3((unsigned)cdiv(total, p.sk_per)), stream);
+            }
+        }
+    }
     if (sk_on && d.splitk <= 1 && W > 0 && may_split && kt >= 32 && tiles % W != 0 && tiles * kt >= 4L * W && tiles >= min_tiles) {
         // persistent: whole tiles while they fill every slot, the ragged tail (or everything, when there are fewer tiles than
         // slots) as equal runs of k-iterations

@@ -336,8 +336,9 @@ int las_attn_keys_fwd(const las_speller_desc* d, const float* feat, float* keys,
     g.C = keys; g.ldc = d->M; g.bias0 = d->b_psi;
     g.M = d->B * d->Tp; g.N = d->M; g.K = d->D;
     // a 64-column output gives only B*T'/128 tiles: split K over the chip and apply the activation in a second tiny pass
+    // (with the stream-K fix-up schedule the K split and the relu share ONE launch: no zeroing pass, no activation pass)
     const long tiles = (long)cdiv(g.M, 128) * cdiv(g.N, 128);
-    if (tiles < 64 && g.K >= 256) {
+    if (tiles < 64 && g.K >= 256 && !gemm_sk_fixup_ready(stream)) {
         g.splitk = (int)std::min<long>(g.K / 64, std::max<long>(1, 256 / tiles));
         LAS_TRY(gemm_f32(g, stream));
         if (d->relu) LAS_TRY(act_inplace(keys, (long)g.M * g.N, d->relu, stream));
@@ -408,7 +409,8 @@ int las_speller_fwd(const las_speller_desc* d, const float* feat, const float* k
     // What a teacher-forced forward leaves in `reserve` depends on the SHAPE only (lay.pre), never on switches, the error word
     // or the occupancy calculator: P = feat . W_ctx^T and the per-step sums gx_s = sum_t a_t P_t are always there, so that
     // las_speller_bwd (LAS_FLAG_TEACHER_FORCED) can rely on them whichever forward variant actually ran.
-    const bool pre_stash = teacher_forced && lay.pre;
+    // (Only a stashing forward has a backward: without LAS_FLAG_STASH the two GEMMs are skipped unless the PRE kernel itself needs P.)
+    const bool pre_stash = teacher_forced && lay.pre && ((flags & LAS_FLAG_STASH) || pre);
     LAS_TRY(build_w0p(d->w_ih[0], w0p, Hs, V, Vp, stream, pre_stash ? reserve + lay.wperm : nullptr, pre ? reserve + lay.wyperm : nullptr,
                       pre ? reserve + lay.bperm : nullptr, d->b_ih[0], d->b_hh[0]));
     if (pre_stash) {
@@ -1077,6 +1079,7 @@ int las_gemm_f32(const float* A, const float* B, float* C, const float* bias0, c
 int las_gemm_get_arith(void) { return gemm_get_arith(); }
 void las_gemm_set_arith(int mode) { gemm_set_arith(mode); }
 void las_gemm_set_tuning(int key, int64_t value) { gemm_set_tuning(key, (long)value); }
+int las_gemm_check(void) { return gemm_sk_check(); }
 
 int las_gemm_f32_group(const las_gemm_desc* descs, int n, void* stream) {
     LAS_REQUIRE(descs != nullptr && n >= 1 && n <= 8, "gemm group");

@@ -27,6 +27,9 @@ enum Opt : int {
     OPT_REC_PIPE,               // pipelined halves in the multi-utterance forward recurrence
     OPT_REC_MFMA,               // multi-utterance recurrences on the matrix pipe where eligible
     OPT_CELL_MT,                // M-tiles per workgroup of the per-step cell kernel (0 = automatic)
+    OPT_GEMM_SK_FIXUP,          // stream-K with in-kernel fix-up (parked partial sums, no atomics / zeroing) on/off
+    OPT_GEMM_SKF_MIN_KT,        // fewest k-iterations per output tile for that schedule             (-1 = automatic)
+    OPT_GEMM_SKF_MIN_RUN,       // fewest k-iterations per workgroup run                              (-1 = automatic)
     OPT_TIME_KERNELS,           // record HIP events around the persistent decode kernels (las_debug_kernel_ms reads them)
     OPT_COUNT
 };
@@ -47,7 +50,7 @@ int gemm_arith_effective();              // thread override if any, else the opt
 // HIP-event timing of single kernels on their launch stream (OPT_TIME_KERNELS; bench.py's roofline blocks): RAII around the launch
 enum : int { TIMED_DECODE_FWD = 0, TIMED_DECODE_BWD = 1, TIMED_COUNT = 2 };
 struct KernelTimer {
-    int which; hipStream_t stream; bool on;
+    int which; hipStream_t stream; bool on; int dev = -1;
     KernelTimer(int which, hipStream_t stream);
     ~KernelTimer();
 };

@@ -4,6 +4,7 @@
 #include "options.h"
 #include <atomic>
 #include <ctype.h>
+#include <mutex>
 #include <stdlib.h>
 
 namespace las {
@@ -16,6 +17,7 @@ const OptDef kDefs[OPT_COUNT] = {
     {"GEMM_SLOTS_PER_CU", 2}, {"GEMM_GROUP", 1}, {"GEMM_XCD_SWZ", 1}, {"GEMM_BATCH_DIRS", 1},
     {"SPELLER_PERSIST", 1}, {"SPELLER_PERSIST_BWD", 1}, {"SPELLER_PRE", 1}, {"SPELLER_PRE_BWD", 1},
     {"REC_UW", 0}, {"REC_AGENT_HANDOFF", 0}, {"REC_NB", 0}, {"REC_PIPE", 1}, {"REC_MFMA", 1}, {"CELL_MT", 0},
+    {"GEMM_SK_FIXUP", 1}, {"GEMM_SKF_MIN_KT", -1}, {"GEMM_SKF_MIN_RUN", -1},
     {"TIME_KERNELS", 0},
 };
 std::atomic<long> g_val[OPT_COUNT];
@@ -60,23 +62,45 @@ GemmArithScope::~GemmArithScope() { tl_arith = saved; }
 int gemm_arith_effective() { return tl_arith >= 0 ? tl_arith : (opt_get(OPT_GEMM_ARITH) ? 1 : 0); }
 
 namespace {
-hipEvent_t g_ev[TIMED_COUNT][2] = {};
-bool g_ev_valid[TIMED_COUNT] = {};
+// events per (device, kernel), guarded: two device threads with TIME_KERNELS=1 must not share or race on them
+constexpr int TIMER_MAX_DEV = 16;
+std::mutex g_ev_mu;
+hipEvent_t g_ev[TIMER_MAX_DEV][TIMED_COUNT][2] = {};
+bool g_ev_valid[TIMER_MAX_DEV][TIMED_COUNT] = {};
+int timer_device() {
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= TIMER_MAX_DEV) return -1;
+    return dev;
+}
 }  // namespace
 KernelTimer::KernelTimer(int w, hipStream_t s) : which(w), stream(s), on(opt_get(OPT_TIME_KERNELS) != 0) {
     if (!on) return;
+    dev = timer_device();
+    if (dev < 0) { on = false; return; }
+    hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+    if (hipStreamIsCapturing(stream, &cap) != hipSuccess || cap != hipStreamCaptureStatusNone) { on = false; return; }   // a graph replay records nothing
+    std::lock_guard<std::mutex> lk(g_ev_mu);
     for (int k = 0; k < 2; ++k)
-        if (!g_ev[which][k] && hipEventCreate(&g_ev[which][k]) != hipSuccess) { on = false; return; }
-    g_ev_valid[which] = false;
-    if (hipEventRecord(g_ev[which][0], stream) != hipSuccess) on = false;
+        if (!g_ev[dev][which][k] && hipEventCreate(&g_ev[dev][which][k]) != hipSuccess) { on = false; return; }
+    g_ev_valid[dev][which] = false;
+    if (hipEventRecord(g_ev[dev][which][0], stream) != hipSuccess) on = false;
 }
 KernelTimer::~KernelTimer() {
-    if (on && hipEventRecord(g_ev[which][1], stream) == hipSuccess) g_ev_valid[which] = true;
+    if (!on) return;
+    std::lock_guard<std::mutex> lk(g_ev_mu);
+    if (hipEventRecord(g_ev[dev][which][1], stream) == hipSuccess) g_ev_valid[dev][which] = true;
 }
 int kernel_timer_read(int which, float* ms_out) {
-    if (which < 0 || which >= TIMED_COUNT || !ms_out || !g_ev_valid[which]) return fail(LAS_ERR_ARG, "no timed launch of kernel %s%ld", "", (long)which);
-    LAS_HIP_CHECK(hipEventSynchronize(g_ev[which][1]));
-    LAS_HIP_CHECK(hipEventElapsedTime(ms_out, g_ev[which][0], g_ev[which][1]));
+    const int dev = timer_device();
+    if (which < 0 || which >= TIMED_COUNT || !ms_out || dev < 0) return fail(LAS_ERR_ARG, "no timed launch of kernel %s%ld", "", (long)which);
+    hipEvent_t e0, e1;
+    {
+        std::lock_guard<std::mutex> lk(g_ev_mu);
+        if (!g_ev_valid[dev][which]) return fail(LAS_ERR_ARG, "no timed launch of kernel %s%ld", "", (long)which);
+        e0 = g_ev[dev][which][0]; e1 = g_ev[dev][which][1];
+    }
+    LAS_HIP_CHECK(hipEventSynchronize(e1));
+    LAS_HIP_CHECK(hipEventElapsedTime(ms_out, e0, e1));
     return LAS_OK;
 }
 

@@ -573,7 +573,7 @@ int rec_fwd_mfma(float* gates, const float* w_hh_f, const float* w_hh_r, float* 
     int dev = 0, cus = 0;
     LAS_HIP_CHECK(hipGetDevice(&dev));
     LAS_HIP_CHECK(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
-    const int groups_max = cus / (2 * C::G);            // groups per direction that are resident at once
+    const int groups_max = std::min(16, cus / (2 * C::G));            // groups per direction that are resident at once (ring and id slots: 32 groups)
     if (groups_max < 1) return fail(LAS_ERR_UNSUPPORTED, "rec_fwd_mfma: %s%ld compute units are too few", "", (long)cus);
     const size_t smem = sizeof(float) * C::LDS_FLOATS;
     if (stash) LAS_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&rec_fwd_mfma_kernel<256, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));

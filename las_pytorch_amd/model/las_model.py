@@ -446,15 +446,16 @@ class _SpellerFn(torch.autograd.Function):
         logp = torch.empty(U, B, V, device=dev, dtype=torch.float32)
         att = torch.empty(U, heads, B, Tp, device=dev, dtype=torch.float32)
         reserve = torch.empty(Lh.las_speller_reserve_floats(d, U), device=dev, dtype=torch.float32)
+        stash = any(ctx.needs_input_grad)      # no backward will follow otherwise (validation / inference): skip the backward-only products
         if noise is not None:
             noise = _f32c(noise)
             if tuple(noise.shape) != (U, B, V):
                 raise RuntimeError(f"decode_mode 2 needs Exp(1) draws of shape {(U, B, V)}, got {tuple(noise.shape)}")
         check(Lh.las_speller_fwd(d, ptr(feat), ptr(keys), ptr(labels) if teacher_forced else None, u_lab, U,
                                  int(teacher_forced), decode_mode, ptr(noise), ptr(logp), ptr(att), None, ptr(reserve),
-                                 ptr(_cabi.err_word(dev)), _flags(True, force_generic), stream))
+                                 ptr(_cabi.err_word(dev)), _flags(stash, force_generic), stream))
         ctx.mark_non_differentiable(att)
-        if any(ctx.needs_input_grad):
+        if stash:
             ctx.save_for_backward(feat, keys, logp, att, reserve, *params)
             ctx.direct = direct
             ctx.cfg = cfg

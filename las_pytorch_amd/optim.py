@@ -39,7 +39,7 @@ class FusedClipAdam(torch.optim.Optimizer):
         self.total_norm = torch.zeros(1, device=dev)
         self._work = torch.empty(_cabi.lib().las_clip_adam_workspace_floats(), device=dev)
         self._steps = 0
-        self._step_t = torch.tensor(0.0)          # shared by every parameter's state (torch keeps one per parameter)
+        self._step_ts = []                        # one step tensor per parameter, as torch.optim.Adam keeps them
         offs, off = [0], 0
         for p in params:
             off += p.numel()
@@ -52,17 +52,28 @@ class FusedClipAdam(torch.optim.Optimizer):
     def _link_state(self):
         """``self.state[p]`` in torch.optim.Adam's layout, the moments being views of the flat buffers."""
         off = 0
-        self._step_t.fill_(float(self._steps))
-        for p in self.reducer.params:
+        # every parameter gets its OWN step tensor: torch.optim.Adam increments ``state[p]["step"]`` once per parameter, so a
+        # checkpoint whose parameters share one tensor would advance by N per step after being loaded there
+        self._step_ts = [torch.tensor(float(self._steps)) for _ in self.reducer.params]
+        for p, st in zip(self.reducer.params, self._step_ts):
             n = p.numel()
-            self.state[p] = dict(step=self._step_t, exp_avg=self.exp_avg[off:off + n].view_as(p),
+            self.state[p] = dict(step=st, exp_avg=self.exp_avg[off:off + n].view_as(p),
                                  exp_avg_sq=self.exp_avg_sq[off:off + n].view_as(p))
             off += n
+
+    def _set_steps(self, steps):
+        self._steps = steps
+        for st in self._step_ts:
+            st.fill_(float(steps))
 
     def load_state_dict(self, state_dict):
         super().load_state_dict(state_dict)       # replaces the state tensors by copies: pour them back into the flat buffers
         for g in self.param_groups:               # a torch.optim.Adam checkpoint has no clip threshold
             g.setdefault("max_norm", self.defaults["max_norm"])
+            # las_clip_adam implements plain Adam only: refuse to continue silently under a different update rule
+            bad = [k for k in ("weight_decay", "amsgrad", "maximize") if g.get(k)]
+            if bad:
+                raise RuntimeError(f"FusedClipAdam: the checkpoint's param group sets {bad}, which las_clip_adam does not implement")
         off, steps = 0, 0
         for p in self.reducer.params:
             st, n = self.state[p], p.numel()
@@ -89,7 +100,7 @@ class FusedClipAdam(torch.optim.Optimizer):
                 float(g["max_norm"] if max_norm is None else max_norm), float(g["lr"]), float(g["betas"][0]), float(g["betas"][1]),
                 float(g["eps"]), self._steps, self.total_norm.data_ptr(), self._work.data_ptr(), self.reducer.error_flag_ptr(),
                 _cabi.stream_ptr()))
-        self._step_t.fill_(float(self._steps))
+        self._set_steps(self._steps)
         return self.total_norm
 
     def step(self, closure=None):
@@ -100,8 +111,7 @@ class FusedClipAdam(torch.optim.Optimizer):
 
     def rollback_step(self):
         """The last ``step_clipped`` was skipped on the device (error word set): take back the host's step count."""
-        self._steps = max(0, self._steps - 1)
-        self._step_t.fill_(float(self._steps))
+        self._set_steps(max(0, self._steps - 1))
 
     def zero_grad(self, set_to_none=False):
         self.reducer.zero()      # keeps every p.grad a view of the flat buffer

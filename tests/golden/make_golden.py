@@ -216,6 +216,27 @@ def main_big3(refmods):
         run_case(refmods, "P_B32_T800_U128", "P", B=32, T=800, U=128, sub_u=4, **big)
     run_case(refmods, "P_B32_T800_U32_s", "P", B=32, T=800, U=32, scale=0.2, seed=43, **big)      # greedy margin 7.5e-4, ~6 symbol changes per utterance; at scale >= 0.25 the saturated attention turns chaotic (oracle vs reference 2e-3)
     run_case(refmods, "P_B8_T3000_U16_s", "P", B=8, T=3000, U=16, scale=0.2, seed=43, **big)
+    main_big4(refmods)
+
+
+def main_big4(refmods):
+    """Round 4: (a) 128 utterances per GPU at the benchmark's T (the matrix-pipe recurrences run 400 / 200 / 100 steps forward and
+    backward, the decode loop takes more than 32 utterances); (b) the reference's shipped YAML sizes at T = 800, B = 16;
+    (c) multi-head attention at paper size (heads = 4 and 2)."""
+    big = dict(full=False, light=True, sub_t=10, sub_d=32)
+    which = os.environ.get("BIG4", "abc")
+    if "a" in which:
+        # default-scale weights: seed 17 has a top-1 / top-2 margin of 2.6e-3 over the 2048 greedy positions (most seeds: ~1e-6, a coin flip
+        # for any fp32 path), its greedy sequence is one repeated symbol; the "_s" case (U(-0.2, 0.2) weights, seed 51: margin 1.4e-3)
+        # decodes 24 distinct symbols
+        big128 = dict(full=False, light=True, sub_t=20, sub_d=32)
+        run_case(refmods, "P_B128_T800_U16", "P", B=128, T=800, U=16, ragged=True, seed=17, **big128)
+        run_case(refmods, "P_B128_T800_U16_s", "P", B=128, T=800, U=16, ragged=True, seed=51, scale=0.2, **big128)
+    if "b" in which:
+        run_case(refmods, "Y_B16_T800_U16", "Y", B=16, T=800, U=16, scale=0.05, seed=37, **big)
+    if "c" in which:
+        run_case(refmods, "P_short_mh4", "P", B=4, T=64, U=8, multi_head=4, scale=0.1, full=False, light=True, seed=23)
+        run_case(refmods, "P_B32_T800_U16_mh2", "P", B=32, T=800, U=16, multi_head=2, scale=0.1, seed=23, **big)
 
 
 
@@ -343,6 +364,11 @@ if __name__ == "__main__" and len(sys.argv) > 1 and sys.argv[1] == "big3":
     torch.manual_seed(0)
     torch.set_num_threads(8)
     main_big3(import_reference())
+
+if __name__ == "__main__" and len(sys.argv) > 1 and sys.argv[1] == "big4":
+    torch.manual_seed(0)
+    torch.set_num_threads(8)
+    main_big4(import_reference())
 
 if __name__ == "__main__" and len(sys.argv) > 1 and sys.argv[1] == "extra":
     torch.set_num_threads(8)

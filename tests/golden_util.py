@@ -12,7 +12,10 @@ ALL_CASES = ["tiny_default", "tiny_sat", "tiny_mh4", "tiny_nomlp", "tiny_noact",
 BIG_CASES = ["Y_short", "P_B40_T64_U6", "P_B32_T800_U32", "P_B16_T1600_U8", "P_B8_T3000_U16", "S_B32_T800_U32", "S_B8_T3000_U8",
              # round 3: the benchmark's exact shape (U=128; greedy log-probs stored every 4th step) and headline sizes with scaled
              # weights (greedy arg-max sequences with ~6 symbol changes per utterance, top-1/top-2 margin >= 5e-4)
-             "P_B32_T800_U128", "P_B32_T800_U32_s", "P_B8_T3000_U16_s"]
+             "P_B32_T800_U128", "P_B32_T800_U32_s", "P_B8_T3000_U16_s",
+             # round 4: 128 utterances per GPU at T = 800 (matrix-pipe recurrences for 400 / 200 / 100 steps, decode beyond 32 utterances;
+             # default-scale and U(-0.2, 0.2) weights), the reference's shipped YAML sizes at T = 800, multi-head attention at paper size
+             "P_B128_T800_U16", "P_B128_T800_U16_s", "Y_B16_T800_U16", "P_short_mh4", "P_B32_T800_U16_mh2"]
 
 
 def load_case(name):

@@ -144,6 +144,74 @@ def test_gemm_bias_relu_accumulate_strided():
     assert torch.equal(C.cpu()[:, N:], C0[:, N:])
 
 
+@pytest.mark.parametrize("a_kc,b_kc", [(True, True), (False, False), (True, False)])
+@pytest.mark.parametrize("M,N,K,batch", [(6400, 1024, 1024, 1), (3200, 2048, 512, 1), (3200, 64, 512, 1), (4096, 512, 2048, 1), (1000, 1000, 1000, 1),
+                                         (640, 384, 4096, 3), (128, 128, 8192, 1), (12800, 2048, 160, 1)])
+def test_gemm_stream_k_fixup(a_kc, b_kc, M, N, K, batch):
+    """Stream-K with in-kernel fix-up (GEMM_SK_FIXUP, the default): tiles that straddle workgroup runs are finished by the workgroup
+    owning their first k-iteration from the partial tiles the others parked.  The training step's ragged shapes, with bias + relu (an
+    epilogue the atomic forms cannot carry), onto a NaN-filled C (nothing may rely on zeroing), three launches back to back (flags and
+    parked tiles are reused), against float64 and against the atomic schedule on the same operands."""
+    from las_pytorch_amd import _cabi
+    g = torch.Generator(device="cuda").manual_seed(M + N + K)
+    A = torch.rand(batch, M, K, device="cuda", generator=g) - 0.4
+    Bm = torch.rand(batch, K, N, device="cuda", generator=g) - 0.6
+    bias = torch.randn(N, device="cuda", generator=g)
+    Ad = (A if a_kc else A.transpose(1, 2)).contiguous()
+    Bd = (Bm.transpose(1, 2) if b_kc else Bm).contiguous()
+    want = torch.relu(A.double() @ Bm.double() + bias.double()).cpu().numpy()
+    want_lin = (A.double() @ Bm.double()).cpu().numpy()
+    kw = dict(M=M, N=N, K=K, lda=K if a_kc else M, ldb=K if b_kc else N, ldc=N, a_kc=a_kc, b_kc=b_kc, batch=batch, sA=M * K, sB=K * N, sC=M * N)
+    outs = []
+    for rep in range(3):
+        C = torch.full((batch, M, N), float("nan"), device="cuda")
+        _gemm(Ad, Bd, C, bias, **kw, relu=1)
+        outs.append(C)
+    torch.cuda.synchronize()
+    _cabi.check(_cabi.lib().las_gemm_check())
+    for C in outs:
+        assert_close(C.cpu().numpy(), want, f"fix-up gemm {M}x{N}x{K} bias relu", rtol=1e-4, atol=2e-4 * np.sqrt(K))
+    assert torch.equal(outs[0], outs[1]) and torch.equal(outs[0], outs[2]), "the fix-up sums in a fixed order: launches must agree bit for bit"
+    # accumulate onto existing values, and the atomic schedule on the same operands
+    C0 = torch.randn(batch, M, N, device="cuda", generator=g)
+    C1 = C0.clone()
+    _gemm(Ad, Bd, C1, **kw, accumulate=1)
+    assert_close(C1.cpu().numpy(), C0.cpu().numpy().astype(np.float64) + want_lin, "fix-up gemm accumulate", rtol=1e-4, atol=2e-4 * np.sqrt(K))
+    _cabi.set_option("GEMM_SK_FIXUP", 0)
+    try:
+        C2 = torch.full((batch, M, N), float("nan"), device="cuda")
+        _gemm(Ad, Bd, C2, **kw)
+    finally:
+        _cabi.set_option("GEMM_SK_FIXUP", 1)
+    C3 = torch.full((batch, M, N), float("nan"), device="cuda")
+    _gemm(Ad, Bd, C3, **kw)
+    assert_close(C3.cpu().numpy(), C2.cpu().numpy(), "fix-up vs atomic schedule", rtol=1e-5, atol=1e-5 * np.sqrt(K))
+    _cabi.check(_cabi.lib().las_gemm_check())
+
+
+def test_gemm_stream_k_fixup_under_graph_replay():
+    """A captured GEMM replays with the same launch id: the owner resets every flag it consumed, so replays stay correct."""
+    M, N, K = 3200, 1024, 1024
+    g = torch.Generator(device="cuda").manual_seed(9)
+    A = torch.randn(M, K, device="cuda", generator=g); Bm = torch.randn(N, K, device="cuda", generator=g)
+    C = torch.empty(M, N, device="cuda")
+    kw = dict(M=M, N=N, K=K, lda=K, ldb=K, ldc=N, a_kc=True, b_kc=True)
+    _gemm(A, Bm, C, **kw)                      # creates the scratch outside the capture
+    want = C.clone()
+    s = torch.cuda.Stream()
+    s.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(s):
+        _gemm(A, Bm, C, **kw)                  # this stream's scratch
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph, stream=s):
+            _gemm(A, Bm, C, **kw)
+    for _ in range(3):
+        C.fill_(float("nan"))
+        graph.replay()
+        torch.cuda.synchronize()
+        assert torch.equal(C, want)
+
+
 def test_gemm_batched_transposed():
     """The per-utterance contractions of the speller backward: C[b] = X[:,b,:]^T Y[:,b,:]."""
     g = torch.Generator().manual_seed(2)
@@ -342,19 +410,33 @@ def _group_call(probs, layout, zeroed=True, accumulate=False):
 ])
 def test_gemm_group_stream_k(layout, probs):
     """las_gemm_f32_group: several GEMMs of one layout in one launch, k-iterations of all problems laid end to end and cut into
-    equal runs (partial tiles combined with atomics, whole tiles stored) against fp64, pre-zeroed and accumulating outputs."""
-    for accumulate in (False, True):
-        got, want = _group_call(probs, layout, zeroed=True, accumulate=accumulate)
-        for i, (gi, wi) in enumerate(zip(got, want)):
-            K = probs[i][2]
-            assert_close(gi, wi, f"group gemm problem {i} {probs[i]} layout {layout} acc {accumulate}", rtol=1e-4, atol=2e-4 * np.sqrt(K))
+    equal runs against fp64: with the fix-up schedule (default: parked partial tiles, outputs may hold anything — NaN here) and with the
+    atomic one (GEMM_SK_FIXUP=0: pre-zeroed outputs), plain and accumulating."""
+    from las_pytorch_amd import _cabi
+    for fixup in (1, 0):
+        _cabi.set_option("GEMM_SK_FIXUP", fixup)
+        try:
+            for accumulate in (False, True):
+                got, want = _group_call(probs, layout, zeroed=not fixup, accumulate=accumulate)
+                for i, (gi, wi) in enumerate(zip(got, want)):
+                    K = probs[i][2]
+                    assert_close(gi, wi, f"group gemm problem {i} {probs[i]} layout {layout} acc {accumulate} fixup {fixup}", rtol=1e-4,
+                                 atol=2e-4 * np.sqrt(K))
+        finally:
+            _cabi.set_option("GEMM_SK_FIXUP", 1)
+    _cabi.check(_cabi.lib().las_gemm_check())
 
 
 def test_gemm_group_falls_back_when_not_groupable():
     """Outputs that are neither pre-zeroed nor accumulated onto cannot share the atomic-combining launch: one launch per problem
     (which zeroes what it needs itself); the results are the same."""
+    from las_pytorch_amd import _cabi
     probs = [(300, 200, 1000), (128, 128, 2048)]
-    got, want = _group_call(probs, (False, False), zeroed=False, accumulate=False)
+    _cabi.set_option("GEMM_SK_FIXUP", 0)
+    try:
+        got, want = _group_call(probs, (False, False), zeroed=False, accumulate=False)
+    finally:
+        _cabi.set_option("GEMM_SK_FIXUP", 1)
     for gi, wi, p in zip(got, want, probs):
         assert_close(gi, wi, f"ungrouped {p}", rtol=1e-4, atol=2e-4 * np.sqrt(p[2]))
 

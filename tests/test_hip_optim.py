@@ -61,6 +61,47 @@ def test_clip_adam_matches_torch(gscale, max_norm):
         assert_close(p.detach().cpu().numpy(), q.detach().cpu().numpy(), f"after load_state_dict param {i}", rtol=2e-6, atol=1e-7)
 
 
+def test_fused_checkpoint_continues_in_torch_adam():
+    """fused -> torch.optim.Adam (the reference's optimizer, train.py:82): every parameter owns its step tensor in the fused state, so
+    the loaded optimizer advances by ONE per step (a shared tensor made it advance by the parameter count: wrong bias corrections
+    after a resume), and the continued run matches a torch-only run."""
+    from las_pytorch_amd import dp
+    from las_pytorch_amd.optim import FusedClipAdam
+    shapes = [(64, 30), (30,), (16, 8), (5,), (12,)]
+    a, b = _Holder(shapes, 5).cuda(), _Holder(shapes, 5).cuda()
+    red = dp.FlatGradAllReducer(a)
+    opt_a = FusedClipAdam(red, lr=1e-2, max_norm=1.0)
+    opt_b = torch.optim.Adam(b.parameters(), lr=1e-2)
+    g = torch.Generator(device="cuda").manual_seed(3)
+    for _ in range(3):
+        grads = [torch.randn(p.shape, device="cuda", generator=g) for p in a.ps]
+        red.zero()
+        for p, q, gr in zip(a.ps, b.ps, grads):
+            p.grad.copy_(gr); q.grad = gr.clone()
+        torch.nn.utils.clip_grad_norm_(b.parameters(), 1.0)
+        opt_b.step(); opt_a.step_clipped()
+    sd = opt_a.state_dict()
+    steps = [sd["state"][i]["step"] for i in range(len(shapes))]
+    assert len({id(t) for t in steps}) == len(shapes) and all(float(t) == 3.0 for t in steps)
+    c = _Holder(shapes, 5).cuda()
+    with torch.no_grad():
+        for p, q in zip(c.ps, a.ps):
+            p.copy_(q)
+    opt_c = torch.optim.Adam(c.parameters(), lr=1e-2)
+    opt_c.load_state_dict(sd)
+    grads = [torch.randn(p.shape, device="cuda", generator=g) for p in a.ps]
+    for p, q, gr in zip(c.ps, b.ps, grads):
+        p.grad = gr.clone(); q.grad = gr.clone()
+    opt_c.step(); opt_b.step()
+    assert all(float(st["step"]) == 4.0 for st in opt_c.state_dict()["state"].values())
+    for i, (p, q) in enumerate(zip(c.ps, b.ps)):
+        assert_close(p.detach().cpu().numpy(), q.detach().cpu().numpy(), f"resumed in torch.optim.Adam, param {i}", rtol=4e-6, atol=2e-7)
+    # a checkpoint whose update rule las_clip_adam does not implement is refused, not silently reinterpreted
+    opt_d = torch.optim.Adam(b.parameters(), lr=1e-2, amsgrad=True)
+    with pytest.raises(RuntimeError, match="amsgrad"):
+        opt_a.load_state_dict(opt_d.state_dict())
+
+
 def test_clip_adam_skips_the_update_when_the_error_word_is_set():
     from las_pytorch_amd import _cabi, dp
     from las_pytorch_amd.optim import FusedClipAdam

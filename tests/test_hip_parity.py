@@ -118,9 +118,12 @@ def test_grads_golden(name):
 @pytest.mark.parametrize("cfg_name,B,T,U,scale", [("S", 5, 96, 7, None), ("P", 6, 64, 6, 0.12), ("tiny", 3, 24, 4, 0.4),
                                                   ("Y", 3, 64, 5, 0.08),
                                                   ("S", 32, 800, 16, None), ("P", 32, 800, 16, None),
-                                                  ("P", 32, 800, 128, None)])
+                                                  ("P", 32, 800, 128, None),
+                                                  ("P", 72, 800, 8, None)])
 def test_forward_backward_vs_oracle(cfg_name, B, T, U, scale):
-    """Fresh seeded inputs, sizes the goldens do not cover (odd batch, full LibriSpeech shape); the last row is the benchmark's
+    """Fresh seeded inputs, sizes the goldens do not cover (odd batch, full LibriSpeech shape); ("P", 72, 800, 8) runs the matrix-pipe
+    recurrences (B >= 64) with a partial last group of 8 utterances for 400 / 200 / 100 steps and the decode in slices of 32 + 32 + 8;
+    the row before it is the benchmark's
     EXACT shape (P, B=32, T=800, U=128): log-probs, loss and every gradient of all 128 steps of the one-launch decode kernels
     against the CPU oracle (ragged label lengths here; tests/golden/P_B32_T800_U128.npz pins the same shape to the reference)."""
     from las_pytorch_amd import synth
