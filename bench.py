@@ -434,6 +434,37 @@ def launch_ranks(n):
     return subprocess.call(cmd, env=env)
 
 
+def dist_preflight(device, rank, world):
+    """First-run diagnostics of a multi-GPU launch, before any timing: every rank reports (host, GPU identity, CU count); the ranks
+    of one host must sit on DISTINCT devices (two ranks on one GPU make every persistent kernel wait for the other's CUs — the
+    symptom would be hand-off timeouts, not an error message) and every device must offer the 256 CUs the one-launch kernels are
+    sized for.  Raises on every rank with the full table; returns the table for the JSON line."""
+    import socket
+    props = torch.cuda.get_device_properties(device)
+    ident = getattr(props, "uuid", None)
+    ident = str(ident) if ident is not None else f"{getattr(props, 'pci_bus_id', '?')}:{getattr(props, 'pci_device_id', '?')}"
+    mine = dict(rank=rank, host=socket.gethostname(), device=int(device.index), id=ident, name=props.name,
+                cus=int(props.multi_processor_count), visible=torch.cuda.device_count())
+    table = [None] * world
+    dist.all_gather_object(table, mine)
+    problems = []
+    seen = {}
+    for row in table:
+        key = (row["host"], row["id"] if row["id"] not in ("None", "?:?") else row["device"])
+        if key in seen:
+            problems.append(f"ranks {seen[key]} and {row['rank']} share one GPU ({key})")
+        seen[key] = row["rank"]
+        if row["cus"] != 256:
+            problems.append(f"rank {row['rank']}: {row['name']} reports {row['cus']} CUs (the one-launch kernels are sized for 256; they fall back to "
+                            "the per-step kernels)")
+    fatal = [p for p in problems if "share one GPU" in p]
+    if rank == 0 and problems:
+        print("bench.py preflight: " + "; ".join(problems), file=sys.stderr, flush=True)
+    if fatal:
+        raise SystemExit("bench.py preflight failed: " + "; ".join(fatal))
+    return dict(ranks=table, warnings=problems)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -471,6 +502,7 @@ def main():
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
         if dist.get_world_size() != args.gpus:
             raise SystemExit(f"bench.py: --gpus {args.gpus} but the RCCL group has {dist.get_world_size()} ranks")
+        preflight = dist_preflight(device, rank, world)
 
     import las_pytorch_amd
     from las_pytorch_amd import dp, synth
@@ -513,13 +545,19 @@ def main():
     for _ in range(args.steps):
         last = step()
     torch.cuda.synchronize()
+    dt_own = time.perf_counter() - t0
     if use_dist:
         dist.barrier()
     dt = time.perf_counter() - t0
+    rank_ms = None
     if use_dist:
-        t = torch.tensor([dt], device=device, dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
+        # the line reports the MAX over ranks (the contract); the per-rank values (time from the common barrier to each rank's own
+        # synchronize, and to the closing barrier) say which rank, if any, the others wait for
+        own = torch.tensor([dt_own, dt], device=device, dtype=torch.float64)
+        allt = [torch.zeros_like(own) for _ in range(world)]
+        dist.all_gather(allt, own)
+        rank_ms = [round(float(v[0]) / args.steps * 1e3, 4) for v in allt]
+        dt = max(float(v[1]) for v in allt)
     las_pytorch_amd.check_device_errors()
     final = float(last.float().mean().item())
     assert np.isfinite(final), "non-finite result in the timed region"
@@ -546,6 +584,8 @@ def main():
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms, 3), "higher_is_better": True,
             "scaling": args.scaling, "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "rccl_ranks": dist.get_world_size() if use_dist else 0,
+            **({"ms_per_step_by_rank": rank_ms, "ms_per_step_min": min(rank_ms), "ms_per_step_max": max(rank_ms),
+                "preflight": preflight} if use_dist else {}),
             "config": {"workload": f"{args.workload}: Listener {c['H']}x{c['L']} / Speller {c['Hs']}x{c['Ls']}, "
                                    f"(B={B},T={T},F={c['F']}) log-mel per GPU, teacher-forced U={U}, "
                                    + ("fwd + label-smoothing loss + bwd + grad all-reduce + clip(1.0) + Adam" if train else "fwd only"),

@@ -200,13 +200,19 @@ static __device__ __forceinline__ SegRole seg_atomic(bool add_bias) { return Seg
 static __device__ __forceinline__ void sk_st4(float* p, const f32x4 v) {
     asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 2" : : "v"(p), "v"(v) : "memory");
 }
-static __device__ __forceinline__ void sk_ld4x4(const float* p, f32x4& a, f32x4& b, f32x4& c, f32x4& d) {      // p + 0, 4 KB, 8 KB, 12 KB
-    asm volatile("global_load_dwordx4 %0, %4, off sc1\n\t"
-                 "global_load_dwordx4 %1, %5, off sc1\n\t"
-                 "global_load_dwordx4 %2, %6, off sc1\n\t"
-                 "global_load_dwordx4 %3, %7, off sc1\n\t"
+// eight 16-byte agent-scope loads in flight, one wait: p + q * 4 KB, q = 0..7 (two accumulator blocks of a parked tile)
+static __device__ __forceinline__ void sk_ld4x8(const float* p, f32x4 (&v)[8]) {
+    asm volatile("global_load_dwordx4 %0, %8, off sc1\n\t"
+                 "global_load_dwordx4 %1, %9, off sc1\n\t"
+                 "global_load_dwordx4 %2, %10, off sc1\n\t"
+                 "global_load_dwordx4 %3, %11, off sc1\n\t"
+                 "global_load_dwordx4 %4, %12, off sc1\n\t"
+                 "global_load_dwordx4 %5, %13, off sc1\n\t"
+                 "global_load_dwordx4 %6, %14, off sc1\n\t"
+                 "global_load_dwordx4 %7, %15, off sc1\n\t"
                  "s_waitcnt vmcnt(0)"
-                 : "=&v"(a), "=&v"(b), "=&v"(c), "=&v"(d) : "v"(p), "v"(p + 1024), "v"(p + 2048), "v"(p + 3072) : "memory");
+                 : "=&v"(v[0]), "=&v"(v[1]), "=&v"(v[2]), "=&v"(v[3]), "=&v"(v[4]), "=&v"(v[5]), "=&v"(v[6]), "=&v"(v[7])
+                 : "v"(p), "v"(p + 1024), "v"(p + 2048), "v"(p + 3072), "v"(p + 4096), "v"(p + 5120), "v"(p + 6144), "v"(p + 7168) : "memory");
 }
 constexpr unsigned SK_SPIN_LIMIT = 1u << 24;
 
@@ -620,17 +626,22 @@ __device__ __forceinline__ void gemm_segment(const GemmParams& p, float (*As)[BK
     }
     // Stream-K fix-up (workgroup-uniform role).  Parked image: [i][j][quad q of the 16 accumulator registers][thread][4 floats] — every
     // thread of every workgroup holds the same tile positions, so the image needs no index arithmetic and a wave moves whole lines.
+    // A 32x32 block of the wave's 64x64 sub-tile that lies wholly outside M x N is neither parked nor fetched (wave-uniform; the same
+    // predicate on both sides): the vocabulary-sized problems (N = 30) move a quarter of the tile.
+    auto blk_live = [&](int i, int j) { return m0 + wm + i * 32 < p.M && n0 + wn + j * 32 < p.N; };
     if (role.kind == SEG_PART) {
         float* dst = p.sk_part + (size_t)role.slot * (BM * BN) + threadIdx.x * 4;
 #pragma unroll
         for (int i = 0; i < 2; ++i)
 #pragma unroll
-            for (int j = 0; j < 2; ++j)
+            for (int j = 0; j < 2; ++j) {
+                if (!blk_live(i, j)) continue;
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
                     const f32x4 v = {acc[i][j][4 * q], acc[i][j][4 * q + 1], acc[i][j][4 * q + 2], acc[i][j][4 * q + 3]};
                     sk_st4(dst + ((i * 2 + j) * 4 + q) * (GEMM_THREADS * 4), v);
                 }
+            }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // this wave's part has reached the memory side
         __syncthreads();
         if (threadIdx.x == 0) __hip_atomic_store(p.sk_flag + role.slot, p.sk_id, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -647,16 +658,20 @@ __device__ __forceinline__ void gemm_segment(const GemmParams& p, float (*As)[BK
         __syncthreads();
         const float* src = p.sk_part + (size_t)c * (BM * BN) + threadIdx.x * 4;
 #pragma unroll
-        for (int i = 0; i < 2; ++i)
+        for (int i = 0; i < 2; ++i) {
+            const bool l0 = blk_live(i, 0), l1 = blk_live(i, 1);
+            if (!l0 && !l1) continue;
+            f32x4 v[8];
+            sk_ld4x8(src + (i * 2 * 4) * (GEMM_THREADS * 4), v);         // (a dead block's words are stale data: fetched, not used)
 #pragma unroll
             for (int j = 0; j < 2; ++j) {
-                f32x4 v0, v1, v2, v3;
-                sk_ld4x4(src + ((i * 2 + j) * 4) * (GEMM_THREADS * 4), v0, v1, v2, v3);
+                if (!(j ? l1 : l0)) continue;
 #pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    acc[i][j][e] += v0[e]; acc[i][j][4 + e] += v1[e]; acc[i][j][8 + e] += v2[e]; acc[i][j][12 + e] += v3[e];
-                }
+                for (int q = 0; q < 4; ++q)
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) acc[i][j][4 * q + e] += v[j * 4 + q][e];
             }
+        }
         __syncthreads();                                           // every wave has its part: the slot may be reused by a later launch
         if (threadIdx.x == 0) __hip_atomic_store(p.sk_flag + c, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
@@ -963,7 +978,11 @@ int gemm_f32_group(const GemmDesc* ds, int n, hipStream_t stream) {
     const int group_on = (int)opt_get(OPT_GEMM_GROUP);
     const int W = gemm_resident_slots();
     bool ok = group_on && W > 0 && n >= 1 && n <= GROUP_MAX;
-    const SkScratch* sc = ok ? sk_scratch(stream, W) : nullptr;      // with the fix-up schedule an output need not start from zero
+    // The grouped weight-gradient launches keep the atomic combination by default: their tiles have K = 3 200 .. 12 800 and span 4 - 9
+    // workgroup runs, so an owner would fetch up to 512 KB of parked tiles serially at the end of its run, where atomics are fire-and-
+    // forget and overlap the next segment (measured: L0 dW group 185 against 164 us, the others +3 .. +7 us).  GEMM_SK_FIXUP=2 selects
+    // the fix-up form here too (outputs then need not start from zero; results are run-to-run deterministic).
+    const SkScratch* sc = (ok && opt_get(OPT_GEMM_SK_FIXUP) >= 2) ? sk_scratch(stream, W) : nullptr;
     for (int i = 0; ok && i < n; ++i) {
         const GemmDesc& d = ds[i];
         ok = d.batch <= 1 && !d.relu && !d.bias0 && !d.bias1 && (d.c_zeroed || d.accumulate || sc != nullptr) && d.a_kc == ds[0].a_kc && d.b_kc == ds[0].b_kc &&
@@ -1039,10 +1058,13 @@ int gemm_f32(const GemmDesc& d, hipStream_t stream) {
     {
         const long total = tiles * kt;
         const long skf_min_kt = opt_get(OPT_GEMM_SKF_MIN_KT) >= 0 ? opt_get(OPT_GEMM_SKF_MIN_KT) : 8;
-        const long min_run = std::max<long>(tune_skf_min_run(), (kt + 3) / 4);
+        // a run is at least 8 k-iterations; at most 8 runs share a tile (the owner fetches 64 KB per sharer)
+        const long min_run = std::max<long>(tune_skf_min_run(), (kt + 7) / 8);
         const int Wuse = (int)std::min<long>(W, total / std::max<long>(1, min_run) / 8 * 8);
         const bool uneven = (double)tiles / ((double)cdiv(tiles, W) * W) < 0.92;      // share of the resident slots a classic grid keeps busy
-        if (sk_on && d.splitk <= 1 && Wuse >= 16 && kt >= skf_min_kt && uneven) {
+        // (fewer than 16 tiles would need more than 8 sharers per tile to cover the chip: the owner's serial fetch of their parked tiles
+        // then costs more than fire-and-forget atomics — dW_psi, 4 tiles x 200 k-iterations: 47 against 15 us — so those keep the split-K path)
+        if (sk_on && d.splitk <= 1 && Wuse >= 16 && kt >= skf_min_kt && uneven && tiles >= 16) {
             if (const SkScratch* sc = sk_scratch(stream, W)) {
                 p.persistent = 1; p.dp_tiles = 0; p.sk_iters = total; p.sk_per = (total + Wuse - 1) / Wuse;
                 p.sk_part = sc->part; p.sk_flag = sc->flag; p.sk_err = sc->err_dev; p.sk_id = sk_next_id();

@@ -67,6 +67,9 @@ size_t rec_bwd_mfma_ring_floats(int B, int H);
 size_t rec_mfma_xbuf_extra_bytes(int B, int H);
 int rec_bwd_mfma(const float* dout, const float* gates, const float* cbuf, const float* w_hh_t, float* dgates, int B, int T, int H,
                  unsigned long long* xbuf, unsigned* err, float* db_f, float* db_r, hipStream_t stream);
+// second form of the forward (pblstm_rec_mfma2.hip: wave-specialised pipeline, 512-thread workgroups); same buffers and semantics
+int rec_fwd_mfma2(float* gates, const float* w_hh_f, const float* w_hh_r, float* out, float* cbuf, float* hprev, int B, int T, int H,
+                  int stash, unsigned long long* xbuf, unsigned* err, hipStream_t stream);
 int rec_fwd_mfma(float* gates, const float* w_hh_f, const float* w_hh_r, float* out, float* cbuf, float* hprev, int B, int T, int H,
                  int stash, unsigned long long* xbuf, unsigned* err, hipStream_t stream);
 #ifdef LAS_REC_TRACE

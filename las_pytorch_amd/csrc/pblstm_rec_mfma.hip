@@ -24,14 +24,12 @@
 #include "las_kernels.h"
 #include "options.h"
 #include "persist_common.h"
+#include "rec_mfma_common.h"
 #include <algorithm>
 
 namespace las {
 
 namespace {
-
-constexpr int RM_THREADS = 1024, RM_NB = 16, RM_UW = 32;
-constexpr size_t REC_MFMA_RING_OFFSET = 64 * 1024;      // bytes from the start of xbuf: behind the id slots (and a trace build's stamps)
 
 template <int H>
 struct RecMfma {
@@ -46,43 +44,6 @@ struct RecMfma {
     static constexpr int LDS_FLOATS = 3 * PLANE + RED + 16 + PREL;
     static_assert(H == 256, "register budget (2 N-tiles x KS x 12 plane registers per lane) and one tile float4 per lane");
 };
-
-struct RecMfmaArgs {
-    float* gates; const float* w_hh_f; const float* w_hh_r; float* out; float* cbuf; float* hprev;
-    int B, T, b0, Bc;                                   // this launch covers utterances [b0, b0 + Bc)
-    unsigned* err;
-    int nbat;                                           // batches of 16 sequences per group: 1, or 2 stepped alternately
-    unsigned long long* idbuf;                          // zeroed: 32 id slots per group (run-time placement check)
-    int force_agent;                                    // A/B: agent-scope hand-off even when a group shares an XCD
-    float* ring;                                        // [group][batch 2][slot 4][16 sequences][H], sentinel-prefilled: the hand-off slab
-};
-
-// Run-time placement check (as pblstm_rec.hip::same_xcd_group): every member publishes its XCC id with agent-scope stores and reads
-// all the others'.  True iff all G workgroups of the group run on one XCD — then h may travel through that XCD's L2 (plain stores,
-// L1-bypassing loads: ~0.5 us per hop) instead of through memory (write-through stores, ~1.3 us + a fabric round trip per tile).
-template <int G>
-__device__ __forceinline__ bool rm_same_xcd(unsigned long long* idbuf, int member, unsigned* err, volatile unsigned* lds_flag) {
-    unsigned xcc;
-    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID, 0, 4)" : "=s"(xcc));
-    const int tid = threadIdx.x;
-    if (tid == 0) {
-        *lds_flag = 1u;
-        __hip_atomic_store(idbuf + member, (0xC0DE0002ull << 32) | (unsigned long long)xcc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    }
-    __syncthreads();
-    if (tid < G) {
-        unsigned spins = 0;
-        unsigned long long x;
-        for (;;) {
-            x = __hip_atomic_load(idbuf + tid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            if ((unsigned)(x >> 32) == 0xC0DE0002u) break;
-            if (spin_expired(spins, err, 0xDEAD0033u)) break;
-        }
-        if ((unsigned)x != xcc || (unsigned)(x >> 32) != 0xC0DE0002u) *lds_flag = 0u;
-    }
-    __syncthreads();
-    return *lds_flag != 0u;
-}
 
 #ifdef RM_TRACE      // debug build: phase stamps of workgroup 0 into the id buffer behind the id slots (tools/ubench_rec_mfma.py TRACE=1)
 #define RM_STAMP(k) do { if (blockIdx.x == 0 && threadIdx.x == 0 && step < 256) a.idbuf[4096 + step * 8 + (k)] = wall_clock64(); } while (0)
@@ -569,6 +530,7 @@ int rec_fwd_mfma(float* gates, const float* w_hh_f, const float* w_hh_r, float* 
                  int stash, unsigned long long* xbuf, unsigned* err, hipStream_t stream) {
     LAS_REQUIRE(H == 256, "rec_fwd_mfma shape");
     LAS_REQUIRE(err != nullptr && xbuf != nullptr && (!stash || (cbuf && hprev)), "rec_fwd_mfma buffers");
+    if (opt_get(OPT_REC_MFMA) >= 2) return rec_fwd_mfma2(gates, w_hh_f, w_hh_r, out, cbuf, hprev, B, T, H, stash, xbuf, err, stream);
     using C = RecMfma<256>;
     int dev = 0, cus = 0;
     LAS_HIP_CHECK(hipGetDevice(&dev));
@@ -590,7 +552,7 @@ int rec_fwd_mfma(float* gates, const float* w_hh_f, const float* w_hh_r, float* 
         LAS_HIP_CHECK(hipMemsetAsync(xbuf, 0, sizeof(unsigned long long) * 32 * (size_t)ngroups, stream));
         // the hand-off ring: four sentinel-filled slots of 16 x H floats per (group, batch)
         LAS_HIP_CHECK(hipMemsetAsync(ring, 0xFF, sizeof(float) * (size_t)ngroups * 2 * 4 * RM_NB * H, stream));
-        RecMfmaArgs a{gates, w_hh_f, w_hh_r, out, cbuf, hprev, B, T, b0, Bc, err, nbat, xbuf, (int)opt_get(OPT_REC_AGENT_HANDOFF), ring};
+        RecMfmaArgs a{gates, w_hh_f, w_hh_r, out, cbuf, hprev, B, T, b0, Bc, err, nbat, xbuf, (int)opt_get(OPT_REC_AGENT_HANDOFF), ring, 0};
         if (stash) {
             if (!persistent_launch_fits(rec_fwd_mfma_kernel<256, true>, RM_THREADS, smem, grid))
                 return fail(LAS_ERR_UNSUPPORTED, "rec_fwd_mfma: %s%ld workgroups cannot all be resident", "", (long)grid);

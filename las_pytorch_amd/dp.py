@@ -68,6 +68,11 @@ class FlatGradAllReducer:
         from . import _cabi
         return _cabi.err_word(self.flat.device).data_ptr()
 
+    def inject_error(self, code=-1.0):
+        """Tests / hosts without the device error word: put ``code`` into this rank's flag element; the next ``allreduce_mean``
+        carries it to every rank (on a GPU the flag is overwritten with the device error word right before the collective)."""
+        self.flag.fill_(float(code))
+
     def check_views(self):
         """Every ``p.grad`` must still be its view of the flat buffer: ``optimizer.zero_grad()`` with torch's default
         ``set_to_none=True`` silently replaces them, after which the collective would reduce a buffer of zeros while

@@ -31,7 +31,10 @@ class FusedClipAdam(torch.optim.Optimizer):
         for p in params:
             if p.dtype != torch.float32 or not p.is_contiguous():
                 raise RuntimeError("FusedClipAdam needs contiguous fp32 parameters")
-        super().__init__(params, dict(lr=lr, betas=betas, eps=eps, max_norm=max_norm))
+        # the param-group keys of torch.optim.Adam ride along at their (only supported) defaults, so that this optimizer's
+        # state_dict loads into a torch.optim.Adam — which adopts the checkpoint's groups as they are
+        super().__init__(params, dict(lr=lr, betas=betas, eps=eps, max_norm=max_norm, weight_decay=0, amsgrad=False, maximize=False,
+                                      foreach=None, capturable=False, differentiable=False, fused=None, decoupled_weight_decay=False))
         self.reducer = reducer
         dev = reducer.flat.device
         self.exp_avg = torch.zeros_like(reducer.flat)

@@ -237,16 +237,31 @@ def batch_iterator(batch_data, batch_label, las_model, optimizer, tf_rate, is_tr
             torch.nn.utils.clip_grad_norm_(las_model.parameters(), CLIP_NORM)
             optimizer.step()
 
-    batch_loss = loss.detach().cpu().numpy()                 # the step's host synchronisation point
+    # the step's ONE host synchronisation point: the loss and, in a multi-rank run, the all-reduced device-error flag travel together
+    peer_flag = 0.0
+    if is_training and reducer is not None and reducer._collective() and not loss.is_cuda:
+        batch_loss = loss.detach().numpy()
+        peer_flag = float(reducer.flag[0])
+    elif is_training and reducer is not None and reducer._collective():
+        both = torch.stack([loss.detach().reshape(()).float(), reducer.flag[0]]).cpu()
+        batch_loss = both[0].numpy().astype(np.float32, copy=False)
+        if str(loss.dtype) != "torch.float32":
+            batch_loss = loss.detach().cpu().numpy()
+        peer_flag = float(both[1])
+    else:
+        batch_loss = loss.detach().cpu().numpy()
     if torch.is_tensor(ler):
         ler = ler.cpu().tolist()
+    if not logp.is_cuda and peer_flag != 0.0:
+        raise RuntimeError("a peer rank reported a device-side hand-off timeout (all-reduced error flag "
+                           f"{peer_flag:g}); this step's averaged gradient is invalid on every rank")
     if logp.is_cuda:
         failed = None
         try:
             _cabi.check_device_errors()       # a hand-off timeout in a persistent kernel invalidates this step
         except _cabi.DeviceHandoffError as e:
             failed = e
-        peer_failed = bool(is_training and reducer is not None and reducer._collective() and float(reducer.flag.item()) != 0.0)
+        peer_failed = peer_flag != 0.0
         if failed is not None or peer_failed:
             recoverable = (not is_training) or fused          # the fused update skipped itself on every rank (all-reduced flag)
             if _retry or not recoverable:

@@ -146,6 +146,49 @@ def test_batch_iterator_two_ranks_keeps_replicas_identical(tmp_path):
     assert np.abs(r0["params"] - start).max() > 1e-5          # the optimizer really stepped
 
 
+def _flag_worker(rank, world, port, out_dir):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    torch.set_num_threads(1)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from las_pytorch_amd.solver import solver as S
+        sd_np, x, onehot, U = _data()
+        model = OracleLASModel(sd_np, max_label_len=U)
+        red = dp.FlatGradAllReducer(model)
+        opt = torch.optim.Adam(model.parameters(), lr=2e-4)
+        sl = dp.shard_batch(x.shape[0], rank, world)
+        outcome = []
+        for step in range(3):
+            if step == 1 and rank == 1:
+                # rank 1's "device" reports a hand-off timeout in step 1: zero() clears the flag at the top of batch_iterator, so the
+                # injection goes in through the gradient hook, i.e. after the backward and before the collective — where the GPU
+                # path copies its error word into the flag element
+                hook = lambda m: red.inject_error(-3.0)
+            else:
+                hook = None
+            try:
+                S.batch_iterator(x[sl], onehot[sl], model, opt, tf_rate=1.0, is_training=True, max_label_len=U, label_smoothing=0.1,
+                                 use_gpu=False, grad_hook=hook)
+                outcome.append(0)
+            except RuntimeError as e:
+                assert "peer rank" in str(e)
+                outcome.append(1)
+        np.savez(os.path.join(out_dir, f"f{rank}.npz"), outcome=np.array(outcome), flag=float(red.flag[0]))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_error_flag_reaches_every_rank_through_the_gradient_allreduce(tmp_path):
+    """The device-error flag rides in the gradient all-reduce (dp.FlatGradAllReducer.flag): a timeout on ONE rank must stop (or, with
+    the fused optimizer on a GPU, re-run) the step on EVERY rank, or the replicas diverge.  Two gloo ranks, rank 1 injects a flag in
+    step 1: both ranks see a nonzero flag in exactly that step and raise; steps 0 and 2 run normally on both."""
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    mp.start_processes(_flag_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True, start_method="spawn")
+    r0, r1 = np.load(tmp_path / "f0.npz"), np.load(tmp_path / "f1.npz")
+    assert r0["outcome"].tolist() == [0, 1, 0] and r1["outcome"].tolist() == [0, 1, 0]
+    assert float(r0["flag"]) == 0.0 and float(r1["flag"]) == 0.0          # the next step's zero() cleared it
+
+
 def test_oracle_training_trajectory_matches_reference():
     """Eight consecutive solver steps (this build's batch_iterator: loss, clip, Adam) on the CPU oracle walk the trajectory the
     unmodified reference walked (tests/golden/S_trajectory.npz): per-step loss, per-utterance LER, validation call."""

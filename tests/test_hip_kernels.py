@@ -323,7 +323,8 @@ def test_matrix_pipe_recurrence_matches_generic(B, T, agent):
     x0 = torch.randn(B, 2 * T, D, device="cuda")
     w = torch.randn(B, T, 2 * H, device="cuda")
     res = []
-    for force, mfma in ((False, 1), (True, 1), (False, 0)):
+    default_mfma = _cabi.get_option("REC_MFMA")
+    for force, mfma in ((False, 1), (True, 1), (False, 0), (False, 2)):
         set_force_generic(layer, force)
         _cabi.set_option("REC_MFMA", mfma)
         _cabi.set_option("REC_AGENT_HANDOFF", agent)
@@ -333,7 +334,7 @@ def test_matrix_pipe_recurrence_matches_generic(B, T, agent):
             out, _ = layer(x)
             (out * w).sum().backward()
         finally:
-            _cabi.set_option("REC_MFMA", 1)
+            _cabi.set_option("REC_MFMA", default_mfma)
             _cabi.set_option("REC_AGENT_HANDOFF", 0)
         res.append(dict(out=out.detach().cpu().numpy(), dx=x.grad.cpu().numpy(),
                         **{n: p.grad.cpu().numpy() for n, p in layer.named_parameters()}))
@@ -343,7 +344,9 @@ def test_matrix_pipe_recurrence_matches_generic(B, T, agent):
         scale = float(np.abs(res[1][k]).max()) + 1e-30
         assert_close(res[0][k], res[1][k], f"matrix-pipe recurrence B={B}: {k}", rtol=1e-3, atol=2e-5 * scale)
         assert_close(res[2][k], res[1][k], f"VALU multi-utterance recurrence B={B}: {k}", rtol=1e-3, atol=2e-5 * scale)
+        assert_close(res[3][k], res[1][k], f"matrix-pipe recurrence, wave-specialised forward (REC_MFMA=2) B={B}: {k}", rtol=1e-3, atol=2e-5 * scale)
     assert float(np.abs(res[0]["out"] - res[1]["out"]).max()) < 5e-6      # fp32-faithful: the split-operand product is no bf16 product
+    assert float(np.abs(res[3]["out"] - res[1]["out"]).max()) < 5e-6
 
 
 def test_multi_utterance_recurrence_vs_oracle():
@@ -413,7 +416,7 @@ def test_gemm_group_stream_k(layout, probs):
     equal runs against fp64: with the fix-up schedule (default: parked partial tiles, outputs may hold anything — NaN here) and with the
     atomic one (GEMM_SK_FIXUP=0: pre-zeroed outputs), plain and accumulating."""
     from las_pytorch_amd import _cabi
-    for fixup in (1, 0):
+    for fixup in (2, 0):
         _cabi.set_option("GEMM_SK_FIXUP", fixup)
         try:
             for accumulate in (False, True):

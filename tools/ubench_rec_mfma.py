@@ -11,6 +11,7 @@ w = [((torch.rand(4 * H, H, generator=g) * 2 - 1) / np.sqrt(H)).cuda() for _ in 
 err = _cabi.err_word("cuda")
 def run(B, flags, mfma, iters=5, check=None):
     _cabi.set_option("REC_MFMA", mfma)
+    _cabi.set_option("REC_TRACE", 1 if os.environ.get("TRACE") else 0)
     pre = torch.randn(2 * B * T * 4 * H, generator=torch.Generator().manual_seed(1)).cuda()
     gates = torch.empty_like(pre); out = torch.empty(B, T, 2 * H, device="cuda")
     cbuf = torch.empty(2 * B * T * H, device="cuda"); hprev = torch.empty_like(cbuf)
@@ -25,7 +26,14 @@ def run(B, flags, mfma, iters=5, check=None):
         e1.record(); torch.cuda.synchronize()
         if it >= 2: ts.append(e0.elapsed_time(e1))
     _cabi.check_device_errors()
-    if os.environ.get("TRACE") and mfma:
+    if os.environ.get("TRACE") and mfma == 2:
+        tr = xbuf.view(torch.int64)[4096:4096 + 256 * 8].cpu().numpy().reshape(256, 8).astype(np.float64)[3:min(T, 256) - 1]
+        d = lambda a, b: (tr[:, b] - tr[:, a]).mean() / 100.0
+        dn = lambda a, b: (tr[1:, b] - tr[:-1, a]).mean() / 100.0      # stamp a of step s -> stamp b of step s + 1
+        print("  pipeline trace wg0/batch0 (us): L poll %.2f | L split+store %.2f | L->M flag %.2f | M mfma %.2f | M gates+post %.2f | M->C flag %.2f | "
+              "C cell+publish %.2f | C publish -> next L tile in %.2f | period %.2f" % (
+                  d(0, 1), d(1, 2), d(2, 3), d(3, 4), d(4, 5), d(5, 6), d(6, 7), dn(7, 1), (tr[1:, 0] - tr[:-1, 0]).mean() / 100.0))
+    if os.environ.get("TRACE") and mfma == 1:
         tr = xbuf.view(torch.int64)[4096:4096 + 256 * 8].cpu().numpy().reshape(256, 8).astype(np.float64)[2:min(T, 256) - 1]
         d = lambda a, b: (tr[:, b] - tr[:, a]).mean() / 100.0
         print("  trace wg0: canary wait %.2f | tile load + LDS + barrier %.2f | split + MFMA %.2f | red write + barrier %.2f | cell + publish %.2f | period %.2f us" % (
@@ -34,6 +42,9 @@ def run(B, flags, mfma, iters=5, check=None):
 for B in [int(v) for v in os.environ.get("BS", "128,512").split(",")]:
     t1, o1, g1, c1, h1 = run(B, _cabi.FLAG_STASH, 1)
     t0, o0, g0, c0, h0 = run(B, _cabi.FLAG_STASH, 0)
+    t2, o2, g2, c2, h2 = run(B, _cabi.FLAG_STASH, 2)
     d = [float(np.abs(a - b).max()) for a, b in ((o1, o0), (g1, g0), (c1, c0), (h1, h0))]
+    d2 = [float(np.abs(a - b).max()) for a, b in ((o2, o0), (g2, g0), (c2, c0), (h2, h0))]
     print(f"B={B} T={T} H={H}: mfma {t1:.3f} ms ({t1 * 1e3 / T:.2f} us/step)  valu {t0:.3f} ms   max|diff| out {d[0]:.2e} gates {d[1]:.2e} c {d[2]:.2e} hprev {d[3]:.2e}")
+    print(f"            pipeline (REC_MFMA=2) {t2:.3f} ms ({t2 * 1e3 / T:.2f} us/step)   max|diff| out {d2[0]:.2e} gates {d2[1]:.2e} c {d2[2]:.2e} hprev {d2[3]:.2e}", flush=True)
 _cabi.set_option("REC_MFMA", 1)
