@@ -622,7 +622,7 @@ extern "C" void las_debug_rm_bwd_trace(unsigned long long* host_out) {
 // extra bytes of a recurrence workspace for the matrix-pipe kernels (shape only): the forward's hand-off ring behind the id slots
 size_t rec_mfma_xbuf_extra_bytes(int B, int H) {
     if (!(H == 256 && B >= 64)) return 0;
-    return REC_MFMA_RING_OFFSET + sizeof(float) * (size_t)32 * 2 * 4 * RM_NB * 256;        // 32 groups x 2 batches x 4 slots x 16 KB
+    return REC_MFMA_RING_OFFSET + sizeof(float) * (size_t)32 * (3 * 4 * 3 * RM_NB * 128 + 1024);     // 32 groups x (up to 3 batches (pipeline form) x 4 slots x 24 KB (three bf16 planes) + dump words)
 }
 
 }  // namespace las

@@ -30,9 +30,9 @@ def run(B, flags, mfma, iters=5, check=None):
         tr = xbuf.view(torch.int64)[4096:4096 + 256 * 8].cpu().numpy().reshape(256, 8).astype(np.float64)[3:min(T, 256) - 1]
         d = lambda a, b: (tr[:, b] - tr[:, a]).mean() / 100.0
         dn = lambda a, b: (tr[1:, b] - tr[:-1, a]).mean() / 100.0      # stamp a of step s -> stamp b of step s + 1
-        print("  pipeline trace wg0/batch0 (us): L poll %.2f | L split+store %.2f | L->M flag %.2f | M mfma %.2f | M gates+post %.2f | M->C flag %.2f | "
-              "C cell+publish %.2f | C publish -> next L tile in %.2f | period %.2f" % (
-                  d(0, 1), d(1, 2), d(2, 3), d(3, 4), d(4, 5), d(5, 6), d(6, 7), dn(7, 1), (tr[1:, 0] - tr[:-1, 0]).mean() / 100.0))
+        print("  pipeline trace wg0/batch0 (us): L wait+poll %.2f | L copy %.2f | L post -> M has planes %.2f | M mfma %.2f | M exchange+cell+publish %.2f | "
+              "M publish -> next L tile in %.2f | M: start -> PF/SF seen + acc init %.2f -> planes seen %.2f | period %.2f" % (
+                  d(0, 1), d(1, 2), d(2, 3), d(3, 4), d(4, 5), dn(5, 1), d(6, 7), d(7, 3), (tr[1:, 0] - tr[:-1, 0]).mean() / 100.0))
     if os.environ.get("TRACE") and mfma == 1:
         tr = xbuf.view(torch.int64)[4096:4096 + 256 * 8].cpu().numpy().reshape(256, 8).astype(np.float64)[2:min(T, 256) - 1]
         d = lambda a, b: (tr[:, b] - tr[:, a]).mean() / 100.0
