@@ -7,14 +7,13 @@
 // matrix pipe / LDS / VALU) while the others idle, and two alternating batches only hide the hand-off latency, not the phases (2.6 us of
 // local time per batch-step against 0.73 us of matrix-pipe time).  Here a workgroup has 12 waves with fixed roles that meet only
 // through LDS flags (monotonic counters; no workgroup barrier in the step loop), and up to three batches of 16 sequences in flight:
-//   * waves 0-7  M : wave (w = mw % 4, kh = mw / 4) multiplies N-tiles 2w, 2w+1 (32 gate rows = 8 hidden units x 4 gates) over K-half kh:
-//                   its W_hh block as three bf16 planes in 96 registers, 48 v_mfma_f32_16x16x32_bf16 per batch-step.  The two K-halves of
-//                   a tile pair exchange one accumulator through LDS: wave kh ends up with the complete N-tile 2w + kh, transposes it
-//                   inside quads (a lane then holds the four gates of ONE cell), applies the cell (c in a register), publishes h and
-//                   stages the stash.  Two M waves share a SIMD: while one applies cells (VALU), the other's MFMAs keep the pipe busy.
-//   * waves 8-9  L : poll the h tile of the ring (twelve 16-byte agent-scope loads per lane in flight) and copy it to this batch's planes.
-//   * wave 10    F : feeds the cells: the input half of the gates (x W_ih^T + b, HBM) into LDS two steps ahead — loads only.
-//   * wave 11    S : stores what the cells made (`out`, and gates / c / h_prev for the backward pass) from the LDS staging — stores only.
+//   * waves 0-3  M (one per SIMD): wave w multiplies N-tiles 2w, 2w+1 (32 gate rows = 8 hidden units x 4 gates) over the WHOLE K = H: its
+//                   W_hh rows as three bf16 planes in 192 registers, 96 v_mfma_f32_16x16x32_bf16 per batch-step, no K split and hence no
+//                   reduction; it then transposes the accumulators inside quads (a lane holds the four gates of its two cells — the
+//                   ADJACENT units 2p, 2p+1), applies the cells (c in registers), publishes h and stages the stash.
+//   * waves 4-5  L : poll the h tile of the ring (twelve 16-byte agent-scope loads per lane in flight) and copy it to this batch's planes.
+//   * wave 6     F : feeds the cells: the input half of the gates (x W_ih^T + b, HBM) into LDS two steps ahead — loads only.
+//   * wave 7     S : stores what the cells made (`out`, and gates / c / h_prev for the backward pass) from the LDS staging — stores only.
 // What the first version of this file (three roles, fp32 ring) taught, kept here because each cost a measured microsecond:
 //   * the ring carries h as its three bf16 PLANES, split once by the producing lane (11 VALU per pair) instead of by each of the group's
 //     eight consumers (176 VALU per L lane and batch-step); a dword = one k-pair, written by one lane in one store, so it is either the
@@ -25,6 +24,11 @@
 //     mixes loads with conditional stores becomes a vmcnt(0) — hence separate F (wide loads) and S (wide stores) waves, gate-major
 //     staging rows, and pollers (L) that issue nothing else;
 //   * pointer selects compile to exec-masked branches; 32-bit offset selects do not (lanes without a sequence publish to a dump word).
+// Also measured and NOT kept (git history): (a) software-pipelining the M wave (product of the next batch-step in one basic block with the
+// cell work of the pending one): at 247-256 registers the scheduler keeps the 96 MFMAs together and the cell's VALU work behind them,
+// sched_group_barrier or not, and any forced interleave spills; (b) 12 waves with the K-halves on separate M waves (96 weight registers,
+// two M waves per SIMD so that one wave's cells overlap the other's MFMAs): the accumulator exchange through LDS and three waves per
+// SIMD cost more than the overlap gained (2.9 against 2.2 us per batch-step).
 // All spins are bounded and report through the device error word.
 #include "las_common.h"
 #include "las_kernels.h"
@@ -38,12 +42,12 @@ namespace las {
 
 namespace {
 
-constexpr int RM2_THREADS = 768, RM2_NBMAX = 3, RM2_MW = 8;
+constexpr int RM2_THREADS = 512, RM2_NBMAX = 3, RM2_MW = 4;
 
 template <int H>
 struct RecMfma2 {
     static constexpr int G = H / RM_UW;                 // workgroups (CUs) per group
-    static constexpr int KS = H / 64;                   // 32-deep k-steps of one K-half
+    static constexpr int KS = H / 32;                   // 32-deep k-steps (whole K per M wave)
     static constexpr int PLD = H / 2 + 4;               // LDS row stride (dwords = bf16 pairs) of one plane of the h tile
     static constexpr int PLANE = RM_NB * PLD;           // dwords of one plane
     // gate-major per-sequence rows [gate][32 units]: the F / S waves move 16 bytes (four units of one gate) per lane, the M waves single
@@ -55,9 +59,8 @@ struct RecMfma2 {
     static constexpr int S2 = RM_NB * SLD;
     // per batch: three planes of the h tile | input half of the gates of the coming step (prel) | stash staging: gates (4) and (c, h) per cell
     static constexpr int PER_BATCH = 3 * PLANE + G4 + G4 + S2;
-    static constexpr int XCH = 4 * 2 * 64 * 4;          // accumulator exchange of the K-half partners: [tile pair w][destination kh][lane][4]
     static constexpr int NFLAGS = 128;
-    static constexpr int LDS_FLOATS = RM2_NBMAX * PER_BATCH + XCH + NFLAGS;
+    static constexpr int LDS_FLOATS = RM2_NBMAX * PER_BATCH + NFLAGS;
     static_assert(H == 256, "register budget of the M waves (2 N-tiles x KS x 12 plane registers) and twelve tile float4 per L lane");
     static_assert(LDS_FLOATS * 4 <= 160 * 1024, "LDS of one workgroup");
 };
@@ -66,10 +69,8 @@ struct RecMfma2 {
 __device__ __forceinline__ int FL_PR(int b, int w) { return b * 24 + w; }           // L wave w stored the planes for step s: s            (2)
 __device__ __forceinline__ int FL_PF(int b) { return b * 24 + 2; }                  // the F wave wrote prel for step s: s
 __device__ __forceinline__ int FL_SF(int b) { return b * 24 + 3; }                  // the S wave took the staging of step s: s + 1
-__device__ __forceinline__ int FL_MF(int b, int w) { return b * 24 + 8 + w; }       // M wave w finished reading the planes of step s: s    (8)
+__device__ __forceinline__ int FL_MF(int b, int w) { return b * 24 + 8 + w; }       // M wave w finished reading the planes of step s: s    (4)
 __device__ __forceinline__ int FL_CD(int b, int w) { return b * 24 + 16 + w; }      // M wave w applied its cells of step s, staging written: s + 1 (8)
-__device__ __forceinline__ int FL_XW(int w) { return 80 + w; }                      // M wave w wrote its partner's accumulator of batch-step n: n + 1
-__device__ __forceinline__ int FL_XR(int w) { return 88 + w; }                      // M wave w read the accumulator sent to it for batch-step n: n + 1
 constexpr int FL_INIT = 96, FL_XCD = 100;
 
 typedef __attribute__((address_space(3))) unsigned rm2_lds_u32;
@@ -145,8 +146,7 @@ __global__ __launch_bounds__(RM2_THREADS) void rec_fwd_mfma2_kernel(RecMfmaArgs 
     auto prel_of = [&](int b) { return smem + b * C::PER_BATCH + 3 * PLANE; };                        // [16][GLD]: x W_ih^T + b of the coming step
     auto stg4_of = [&](int b) { return smem + b * C::PER_BATCH + 3 * PLANE + C::G4; };               // [16][GLD]: i, f, g, o after activation
     auto stg2_of = [&](int b) { return smem + b * C::PER_BATCH + 3 * PLANE + 2 * C::G4; };           // [16][SLD]: c_t, h_t
-    float* xch = smem + NBM * C::PER_BATCH;
-    volatile unsigned* flags = reinterpret_cast<volatile unsigned*>(xch + C::XCH);
+    volatile unsigned* flags = reinterpret_cast<volatile unsigned*>(smem + NBM * C::PER_BATCH);
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int T = a.T, B = a.B;
     const int nbat = a.nbat;
@@ -180,29 +180,27 @@ __global__ __launch_bounds__(RM2_THREADS) void rec_fwd_mfma2_kernel(RecMfmaArgs 
 
     if (wave < RM2_MW) {
         // ================================================================================================ M: the recurrent product and the cells
-        // N-tile j of tile pair w, tile column c <-> unit 8 w + 4 j + c / 4, gate c % 4.  Wave (w, kh) multiplies both N-tiles over K-half kh
-        // and ends up with the complete N-tile j = kh: after the quad transpose lane (kq, uq, g4) holds the cell (sequence 4 kq + g4, unit
-        // 8 w + 4 kh + uq); units 2p, 2p + 1 sit four lanes apart (one ds_bpermute pairs them for the k-pair dword to publish).
-        const int w = wave & 3, kh = wave >> 2, pw = wave ^ 4;
+        // N-tile j of wave w, tile column c <-> unit 8 w + 2 (c / 4) + j, gate c % 4: after the quad transpose a lane holds the cells of the
+        // ADJACENT units 2 p, 2 p + 1 (p = 4 w + uq) of sequence 4 kq + g4 — one k-pair dword per plane to publish
+        const int w = wave;
         PsPlanes<8> Wp[2][KS];
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
             const int r16 = lane & 15, kq = lane >> 4;
-            const long wrow = (long)(r16 & 3) * H + u0 + 8 * w + 4 * j + (r16 >> 2);
+            const long wrow = (long)(r16 & 3) * H + u0 + 8 * w + 2 * (r16 >> 2) + j;
 #pragma unroll
             for (int ks = 0; ks < KS; ++ks) {
-                const float* src = w_hh + wrow * H + (kh * KS + ks) * 32 + kq * 8;
+                const float* src = w_hh + wrow * H + ks * 32 + kq * 8;
                 const f32x4 w0 = ld4p(src), w1 = ld4p(src + 4);
                 const float v[8] = {w0[0], w0[1], w0[2], w0[3], w1[0], w1[1], w1[2], w1[3]};
                 Wp[j][ks] = ps_split<8>(v);
             }
         }
-        float c[NBM];
+        float c[NBM][2];
 #pragma unroll
-        for (int bi = 0; bi < NBM; ++bi) c[bi] = 0.f;
+        for (int bi = 0; bi < NBM; ++bi) c[bi][0] = c[bi][1] = 0.f;
         if (!rm2_wait<1>(flags, FL_INIT, 1u, a.err, 0xDEAD0047u)) return;   // the F wave has put step 0's input half into LDS
         const unsigned dump_off = (unsigned)(NBM * 4 * RSLOT) + tid;         // (32-bit offsets from the group's ring: selects, not branches)
-        unsigned nseq = 0;                                                   // batch-step sequence number (the same in every M wave)
         auto m_role = [&](auto L2XC) {
             constexpr bool L2X = decltype(L2XC)::value;                      // (compile time: a run-time branch would split the cell block)
             for (int step = 0; step < T; ++step) {
@@ -213,21 +211,21 @@ __global__ __launch_bounds__(RM2_THREADS) void rec_fwd_mfma2_kernel(RecMfmaArgs 
                     // hoisted out of the step loop and spill (scratch reloads inside the cell phase, on the chain)
                     const int ln = (int)opaque((unsigned)lane);
                     const int r16 = ln & 15, kq = ln >> 4, g4 = ln & 3, uq = (ln >> 2) & 3;
+                    const int cs = 4 * kq + g4, ul0 = 8 * w + 2 * uq;       // this lane's sequence and units ul0, ul0 + 1
                     if (wave == 0) RM2_STAMP(6);
-                    // accumulators: K-half 0 starts from the input half of this step's gates (x W_ih^T + b; the F wave put it into LDS a step
-                    // ago) in the MFMA's own C layout — D[row 4 kq + i][column 4 uq + g] —, K-half 1 from zero
+                    // the accumulators START from the input half of this step's gates (x W_ih^T + b; the F wave put it into LDS a step ago) in
+                    // the MFMA's own C layout — D[row 4 kq + i][column 4 uq + g]; the staging rows of the previous step have long been taken
                     if (!rm2_wait<2>(flags, FL_PF(bi), (unsigned)step, a.err, 0xDEAD0042u)) return;         // PF and SF are adjacent words
-                    f32x4 acc[2];
+                    f32x4 acc[2];                                             // (two interleaved chains; four accumulators spilled)
 #pragma unroll
                     for (int j = 0; j < 2; ++j)
 #pragma unroll
-                        for (int i = 0; i < 4; ++i)
-                            acc[j][i] = kh == 0 ? prel_of(bi)[(4 * kq + i) * GLD + g4 * GS + 8 * w + 4 * j + uq] : 0.f;
+                        for (int i = 0; i < 4; ++i) acc[j][i] = prel_of(bi)[(4 * kq + i) * GLD + g4 * GS + ul0 + j];
                     if (wave == 0) RM2_STAMP(7);
                     if (step > 0) {
                         if (!rm2_wait<2>(flags, FL_PR(bi, 0), (unsigned)step, a.err, 0xDEAD0041u)) return;
                         if (wave == 0) RM2_STAMP(3);
-                        const unsigned* ar = planes_of(bi) + r16 * PLD + kh * (KS * 16) + kq * 4;
+                        const unsigned* ar = planes_of(bi) + r16 * PLD + kq * 4;
                         auto load_a = [&](int ks) {
                             PsPlanes<8> A;
 #pragma unroll
@@ -250,35 +248,31 @@ __global__ __launch_bounds__(RM2_THREADS) void rec_fwd_mfma2_kernel(RecMfmaArgs 
                         rm2_post(flags, FL_MF(bi, wave), (unsigned)step, lane);
                     }
                     if (wave == 0) RM2_STAMP(4);
-                    // ---- the K-halves meet: this wave keeps N-tile kh, its partner gets the other one (one 16-byte word per lane through LDS)
-                    if (!rm2_wait<1>(flags, FL_XR(pw), nseq, a.err, 0xDEAD0048u)) return;      // the partner has read what was sent for the previous batch-step
-                    *reinterpret_cast<f32x4*>(xch + ((w * 2 + (kh ^ 1)) * 64 + ln) * 4) = acc[kh ^ 1];
-                    rm2_post(flags, FL_XW(wave), nseq + 1, lane);
-                    if (!rm2_wait<1>(flags, FL_XW(pw), nseq + 1, a.err, 0xDEAD0049u)) return;
-                    f32x4 sg = *reinterpret_cast<const f32x4*>(xch + ((w * 2 + kh) * 64 + ln) * 4);
-                    rm2_post(flags, FL_XR(wave), nseq + 1, lane);
-                    ++nseq;
+                    // ---- the two cells: (i, f, g, o) of (sequence cs, unit ul0 + j) after the quad transpose; stage the stash for the S wave
+                    float hh[2];
 #pragma unroll
-                    for (int i = 0; i < 4; ++i) sg[i] += acc[kh][i];
-                    // ---- the cell (sequence cs, unit ul): (i, f, g, o) after the quad transpose
-                    quad_transpose(sg, g4);
-                    const int cs = 4 * kq + g4, ul = 8 * w + 4 * kh + uq;
-                    const float ig = sigmoidf_acc(sg[0]);
-                    const float fg = sigmoidf_acc(sg[1]);
-                    const float gg = tanhf_acc(sg[2]);
-                    const float og = sigmoidf_acc(sg[3]);
-                    c[bi] = fg * c[bi] + ig * gg;
-                    const float hh = og * tanhf_acc(c[bi]);
-                    // publish: the k-pair (unit 2p, unit 2p + 1) as three bf16 plane dwords, by the lane of the even unit (a NaN is canonicalised
-                    // first: its terms must not look like the sentinel); the slot of step + 2 goes back to the sentinel (its consumers have read
-                    // it: they have published h of step - 1 since, which this workgroup consumed before this cell ran)
-                    const float hpub = __uint_as_float(pub_bits(hh));
-                    const float hoth = __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute((ln ^ 4) << 2, __builtin_bit_cast(int, hpub)));
+                    for (int j = 0; j < 2; ++j) {
+                        f32x4 sg = acc[j];
+                        quad_transpose(sg, g4);
+                        const float ig = sigmoidf_acc(sg[0]);
+                        const float fg = sigmoidf_acc(sg[1]);
+                        const float gg = tanhf_acc(sg[2]);
+                        const float og = sigmoidf_acc(sg[3]);
+                        c[bi][j] = fg * c[bi][j] + ig * gg;
+                        hh[j] = og * tanhf_acc(c[bi][j]);
+                        float* s4 = stg4_of(bi) + cs * GLD + ul0 + j;
+                        s4[0] = ig; s4[GS] = fg; s4[2 * GS] = gg; s4[3 * GS] = og;
+                        float* s2 = stg2_of(bi) + cs * SLD + ul0 + j;
+                        s2[0] = c[bi][j]; s2[GS] = hh[j];
+                    }
+                    // publish: the pair's three bf16 plane dwords (a NaN is canonicalised first: its terms must not look like the sentinel); the
+                    // words of slot step + 2 go back to the sentinel (their consumers have read them: they have published h of step - 1 since,
+                    // which this workgroup consumed before this cell ran)
                     unsigned p3[3];
-                    ps_split_pair(hpub, hoth, p3[0], p3[1], p3[2]);
-                    const bool pub = cs < nvalid[bi] && (uq & 1) == 0;
+                    ps_split_pair(__uint_as_float(pub_bits(hh[0])), __uint_as_float(pub_bits(hh[1])), p3[0], p3[1], p3[2]);
+                    const bool pub = cs < nvalid[bi];
                     const bool reset = pub && step + 2 < T;
-                    const unsigned off = (unsigned)(cs * RROW + ((u0 + ul) >> 1));
+                    const unsigned off = (unsigned)(cs * RROW + ((u0 + ul0) >> 1));
 #pragma unroll
                     for (int pl = 0; pl < 3; ++pl) {
                         const unsigned oh = pub ? (unsigned)((bi * 4 + (step & 3)) * RSLOT + pl * RPLANE) + off : dump_off;
@@ -291,11 +285,6 @@ __global__ __launch_bounds__(RM2_THREADS) void rec_fwd_mfma2_kernel(RecMfmaArgs 
                             __hip_atomic_store(ring + os, PS_SENT, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                         }
                     }
-                    // stage the stash for the S wave (the staging rows of the previous step were taken long ago: SF checked above)
-                    float* s4 = stg4_of(bi) + cs * GLD + ul;
-                    s4[0] = ig; s4[GS] = fg; s4[2 * GS] = gg; s4[3 * GS] = og;
-                    float* s2 = stg2_of(bi) + cs * SLD + ul;
-                    s2[0] = c[bi]; s2[GS] = hh;
                     rm2_post(flags, FL_CD(bi, wave), (unsigned)(step + 1), lane);
                     if (wave == 0) RM2_STAMP(5);
                 }
@@ -310,7 +299,7 @@ __global__ __launch_bounds__(RM2_THREADS) void rec_fwd_mfma2_kernel(RecMfmaArgs 
             for (int bi = 0; bi < NBM; ++bi) {
                 if (nvalid[bi] == 0) continue;
                 // the plane buffer of this batch is free once every M wave has read the previous step's planes
-                if (!rm2_wait<8>(flags, FL_MF(bi, 0), (unsigned)(step - 1), a.err, 0xDEAD0043u)) return;
+                if (!rm2_wait<RM2_MW>(flags, FL_MF(bi, 0), (unsigned)(step - 1), a.err, 0xDEAD0043u)) return;
                 if (lw == 0) RM2_STAMP(0);
                 const unsigned* slot = ring + (size_t)(bi * 4 + ((step - 1) & 3)) * RSLOT;
                 // 3 planes x 16 rows x 32 float4 = 1536 float4: twelve per lane; rows without a sequence are never written (row 0 stands in)
@@ -375,7 +364,7 @@ __global__ __launch_bounds__(RM2_THREADS) void rec_fwd_mfma2_kernel(RecMfmaArgs 
             for (int bi = 0; bi < NBM; ++bi) {
                 if (nvalid[bi] == 0) continue;
                 // the M waves have read this step's input half (their cells of this step are applied)
-                if (!rm2_wait<8>(flags, FL_CD(bi, 0), (unsigned)(step + 1), a.err, 0xDEAD0045u)) return;
+                if (!rm2_wait<RM2_MW>(flags, FL_CD(bi, 0), (unsigned)(step + 1), a.err, 0xDEAD0045u)) return;
 #pragma unroll
                 for (int k = 0; k < 8; ++k) *reinterpret_cast<f32x4*>(prel_of(bi) + 2 * k * GLD + lds_o) = pn[bi][k];
                 rm2_post(flags, FL_PF(bi), (unsigned)(step + 1), lane);
@@ -404,7 +393,7 @@ __global__ __launch_bounds__(RM2_THREADS) void rec_fwd_mfma2_kernel(RecMfmaArgs 
 #pragma unroll
             for (int bi = 0; bi < NBM; ++bi) {
                 if (nvalid[bi] == 0) continue;
-                if (!rm2_wait<8>(flags, FL_CD(bi, 0), (unsigned)(step + 1), a.err, 0xDEAD0046u)) return;
+                if (!rm2_wait<RM2_MW>(flags, FL_CD(bi, 0), (unsigned)(step + 1), a.err, 0xDEAD0046u)) return;
                 f32x4 gq[8], cq[2], hq[2];
 #pragma unroll
                 for (int k = 0; k < 8; ++k) gq[k] = *reinterpret_cast<const f32x4*>(stg4_of(bi) + 2 * k * GLD + lds_g);
