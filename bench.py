@@ -624,7 +624,8 @@ def main():
             res["roofline_mfma"] = roofline_mfma(c, B, T, U)
         if world == 1 and not args.no_sweep and not args.no_roofline:
             res["sweep"] = {"kernel": f"layer-0 forward recurrence, H={c['H']}, T_l={T // 2}: rec_fwd_fast (B=32), "
-                                      "rec_fwd_mfma (B>=64: 16 utterances per group on the bf16 matrix pipe)", "points": sweep_rec(c, T)}
+                                      "rec_fwd_mfma (64 <= B <= 256: 16 utterances per group on the bf16 matrix pipe), rec_fwd_mfma2 (B > 256: the same as a wave-specialised "
+                                      "pipeline, two or three batches of 16 per group in flight)", "points": sweep_rec(c, T)}
         if world == 1 and not args.no_cpu_baseline:
             res["cpu_baseline"] = cpu_baseline(cfg_name, B, T, U, train)
         if world == 1 and args.workload == "P_train" and not args.no_secondary:

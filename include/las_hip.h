@@ -68,6 +68,9 @@ const char* las_last_error(void);
  *   SPELLER_PRE 1*, SPELLER_PRE_BWD 1*                           pre-multiplied-context variants of those kernels
  *   REC_UW 0*, REC_NB 0*, REC_PIPE 1*, REC_AGENT_HANDOFF 0*, REC_MFMA 1*   Listener recurrence: units per workgroup, utterances per
  *                                                                group, pipelined halves, agent-scope hand-off, matrix-pipe form
+ *                                                                (0 off, 1 automatic, 2 / 3: forward always as wave-specialised
+ *                                                                pipeline / as the barrier-phased first form)
+ *   REC_TRACE 0*          phase stamps of the pipeline form's first workgroup into its id buffer (tools/ubench_rec_mfma.py)
  *   CELL_MT 0*            M-tiles per workgroup of the per-step cell kernel
  *   TIME_KERNELS 0*       record HIP events around the one-launch decode kernels on their launch stream (las_debug_kernel_ms)
  * Replaces nothing in the reference (pure Python, no switches).

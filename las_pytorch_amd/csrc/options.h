@@ -25,7 +25,7 @@ enum Opt : int {
     OPT_REC_AGENT_HANDOFF,      // agent-scope hand-off even when a recurrence group shares an XCD
     OPT_REC_NB,                 // minimum utterances per recurrence group (0 = automatic)
     OPT_REC_PIPE,               // pipelined halves in the multi-utterance forward recurrence
-    OPT_REC_MFMA,               // multi-utterance recurrences on the matrix pipe where eligible (2: wave-specialised forward pipeline)
+    OPT_REC_MFMA,               // multi-utterance recurrences on the matrix pipe where eligible (1: automatic; forward: 2 pipeline form always, 3 first form always)
     OPT_REC_TRACE,              // phase stamps of the pipeline form's workgroup 0 into its id buffer (profiling aid)
     OPT_CELL_MT,                // M-tiles per workgroup of the per-step cell kernel (0 = automatic)
     OPT_GEMM_SK_FIXUP,          // stream-K with in-kernel fix-up (parked partial sums, no atomics / zeroing) on/off

@@ -530,7 +530,18 @@ int rec_fwd_mfma(float* gates, const float* w_hh_f, const float* w_hh_r, float* 
                  int stash, unsigned long long* xbuf, unsigned* err, hipStream_t stream) {
     LAS_REQUIRE(H == 256, "rec_fwd_mfma shape");
     LAS_REQUIRE(err != nullptr && xbuf != nullptr && (!stash || (cbuf && hprev)), "rec_fwd_mfma buffers");
-    if (opt_get(OPT_REC_MFMA) >= 2) return rec_fwd_mfma2(gates, w_hh_f, w_hh_r, out, cbuf, hprev, B, T, H, stash, xbuf, err, stream);
+    // From two batches of 16 sequences per group (B > 256 on 256 CUs) the wave-specialised pipeline (pblstm_rec_mfma2.hip) is the faster form:
+    // measured layer-0 forward, T = 400: B = 512 1.93 against 2.11 ms, B = 768 2.79 against 3.82; with ONE batch per group its longer
+    // per-step chain loses (B = 128: 1.24 against 0.82 ms).  REC_MFMA = 2 forces the pipeline, 3 forces this file's form (A/B).
+    {
+        int dev0 = 0, cus0 = 0;
+        LAS_HIP_CHECK(hipGetDevice(&dev0));
+        LAS_HIP_CHECK(hipDeviceGetAttribute(&cus0, hipDeviceAttributeMultiprocessorCount, dev0));
+        const long mode = opt_get(OPT_REC_MFMA);
+        const int one_batch = std::min(16, cus0 / 16) * RM_NB;          // sequences of one direction that one batch per group covers
+        if (mode == 2 || (mode == 1 && B > one_batch))
+            return rec_fwd_mfma2(gates, w_hh_f, w_hh_r, out, cbuf, hprev, B, T, H, stash, xbuf, err, stream);
+    }
     using C = RecMfma<256>;
     int dev = 0, cus = 0;
     LAS_HIP_CHECK(hipGetDevice(&dev));

@@ -33,14 +33,14 @@ def run(B, flags, mfma, iters=5, check=None):
         print("  pipeline trace wg0/batch0 (us): L wait+poll %.2f | L copy %.2f | L post -> M has planes %.2f | M mfma %.2f | M exchange+cell+publish %.2f | "
               "M publish -> next L tile in %.2f | M: start -> PF/SF seen + acc init %.2f -> planes seen %.2f | period %.2f" % (
                   d(0, 1), d(1, 2), d(2, 3), d(3, 4), d(4, 5), dn(5, 1), d(6, 7), d(7, 3), (tr[1:, 0] - tr[:-1, 0]).mean() / 100.0))
-    if os.environ.get("TRACE") and mfma == 1:
+    if os.environ.get("TRACE") and mfma == 3:
         tr = xbuf.view(torch.int64)[4096:4096 + 256 * 8].cpu().numpy().reshape(256, 8).astype(np.float64)[2:min(T, 256) - 1]
         d = lambda a, b: (tr[:, b] - tr[:, a]).mean() / 100.0
         print("  trace wg0: canary wait %.2f | tile load + LDS + barrier %.2f | split + MFMA %.2f | red write + barrier %.2f | cell + publish %.2f | period %.2f us" % (
             d(0, 1), d(1, 2), d(2, 3), d(3, 4), d(4, 5), (tr[1:, 0] - tr[:-1, 0]).mean() / 100.0))
     return float(np.median(ts)), out.cpu().numpy(), gates.cpu().numpy(), cbuf.cpu().numpy(), hprev.cpu().numpy()
 for B in [int(v) for v in os.environ.get("BS", "128,512").split(",")]:
-    t1, o1, g1, c1, h1 = run(B, _cabi.FLAG_STASH, 1)
+    t1, o1, g1, c1, h1 = run(B, _cabi.FLAG_STASH, 3)
     t0, o0, g0, c0, h0 = run(B, _cabi.FLAG_STASH, 0)
     t2, o2, g2, c2, h2 = run(B, _cabi.FLAG_STASH, 2)
     d = [float(np.abs(a - b).max()) for a, b in ((o1, o0), (g1, g0), (c1, c0), (h1, h0))]
