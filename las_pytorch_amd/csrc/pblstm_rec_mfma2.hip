@@ -443,7 +443,10 @@ int rec_fwd_mfma2(float* gates, const float* w_hh_f, const float* w_hh_r, float*
     else LAS_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&rec_fwd_mfma2_kernel<256, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
     // one batch of 16 sequences per group while that covers the launch; beyond it two or three batches per group, pipelined through the roles
     const int nbat = std::min(RM2_NBMAX, std::max(1, (B + groups_max * RM_NB - 1) / (groups_max * RM_NB)));
-    const int chunk = groups_max * RM_NB * nbat;
+    // equal launches rather than full ones and a remainder (B = 2048: 3 x 688 utterances instead of 768 + 768 + 512)
+    const int chunk_max = groups_max * RM_NB * nbat;
+    const int nlaunch = (B + chunk_max - 1) / chunk_max;
+    const int chunk = std::min(chunk_max, ((B + nlaunch - 1) / nlaunch + RM_NB - 1) / RM_NB * RM_NB);
     float* ring = reinterpret_cast<float*>(reinterpret_cast<char*>(xbuf) + REC_MFMA_RING_OFFSET);       // (rec_xbuf_bytes makes room for it)
     constexpr size_t ring_group_dwords = (size_t)RM2_NBMAX * 4 * 3 * RM_NB * (256 / 2) + 1024;        // bf16 planes + dump words (= RGROUP in the kernel)
     for (int b0 = 0; b0 < B; b0 += chunk) {

@@ -25,7 +25,16 @@ for a in 1 0; do
   rocprofv3 --pmc SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_VMEM SQ_INSTS_LDS SQ_WAIT_INST_LDS SQ_ACTIVE_INST_VALU SQ_INSTS_VALU -d $O/pmc_gemm_b$a -o x -- python3 $R/tools/ubench_gemm_pmc.py > $O/pmc_gemm_b$a.log 2>&1
 done
 unset LAS_GEMM_ARITH
+# the matrix-pipe recurrences at B = 512: MFMA-busy / wait / LDS counters and HBM bytes (four separate passes)
+rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU_MFMA_MOPS_BF16 GRBM_GUI_ACTIVE -d $O/pmc_recm_a -o x -- python3 $R/tools/ubench_rec_mfma_pmc.py > $O/pmc_recm_a.log 2>&1
+rocprofv3 --pmc SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_VMEM SQ_INSTS_LDS SQ_WAIT_INST_LDS SQ_ACTIVE_INST_VALU SQ_INSTS_VALU -d $O/pmc_recm_b -o x -- python3 $R/tools/ubench_rec_mfma_pmc.py > $O/pmc_recm_b.log 2>&1
+rocprofv3 --pmc FETCH_SIZE -d $O/pmc_recm_f -o x -- python3 $R/tools/ubench_rec_mfma_pmc.py > $O/pmc_recm_f.log 2>&1
+rocprofv3 --pmc WRITE_SIZE -d $O/pmc_recm_w -o x -- python3 $R/tools/ubench_rec_mfma_pmc.py > $O/pmc_recm_w.log 2>&1
 cd $R
+TRACE=1 BS=128,512,768 python tools/ubench_rec_mfma.py > $O/rec_mfma_trace.log 2>&1
+python tools/ubench_gemm_skf.py 32 > $O/gemm_skf_b32.log 2>&1
+python tools/ubench_gemm_skf.py 128 > $O/gemm_skf_b128.log 2>&1
+./tools/_bin/spin_timeout > $O/spin_timeout.log 2>&1
 python tools/ubench_rec_sweep.py > $O/rec_sweep.log 2>&1
 python tools/ubench_gemm_split.py > $O/gemm_split.log 2>&1
 # soak: 1500 consecutive training steps (~1e7 inter-workgroup hand-offs) must end without a device error word

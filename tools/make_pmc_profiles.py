@@ -14,7 +14,7 @@ import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
-ROUND = os.environ.get("LAS_ROUND", "r03")
+ROUND = os.environ.get("LAS_ROUND", "r04")
 
 
 def csrc_sha16():
@@ -129,8 +129,51 @@ def gemm(dbs):
     print(path)
 
 
+def recmfma(db_a, db_b, db_f, db_w, B, T_l, H):
+    """The matrix-pipe recurrences at large batch (tools/ubench_rec_mfma_pmc.py): MFMA-busy / wait / LDS counters and HBM bytes per launch."""
+    out = {"counters": "rocprofv3 --pmc in four separate passes (SQ set a, SQ set b, FETCH_SIZE, WRITE_SIZE) over tools/ubench_rec_mfma_pmc.py: one "
+                       f"pBLSTM layer forward + backward, B = {B}, T_l = {T_l}, H = {H}, three iterations", "csrc_sha16": csrc_sha16(), "kernels": []}
+    for match in ("rec_fwd_mfma2_kernel", "rec_fwd_mfma_kernel", "rec_bwd_mfma_kernel"):
+        a = rows(db_a, match); b = rows(db_b, match); f = rows(db_f, match); w = rows(db_w, match)
+        for key, d in a.items():
+            e = dict(d)
+            for other in (b, f, w):
+                if key in other:
+                    e.update(other[key])
+            n = e["SQ_VALU_MFMA_BUSY_CYCLES"][1]
+            m = {c: v[0] / v[1] for c, v in e.items()}
+            dur_us = e["SQ_VALU_MFMA_BUSY_CYCLES"][2] / n / 1e3
+            gui_per_xcd = m["GRBM_GUI_ACTIVE"] / 8.0
+            seq_steps = 2.0 * B * T_l
+            alg = B * 4 * T_l * (2 * 80 + 2 * H) + 2 * 4 * (4 * H * 160 + 4 * H * H + 8 * H)
+            out["kernels"].append({
+                "kernel": key[0], "grid_threads": key[1], "launches": n, "duration_us_under_pmc": round(dur_us, 1),
+                "ns_per_utterance_step": round(dur_us * 1e3 / (B * T_l), 2), "sclk_MHz_under_pmc": round(gui_per_xcd / dur_us, 0),
+                "MfmaUtil_pct": round(100.0 * m["SQ_VALU_MFMA_BUSY_CYCLES"] / (gui_per_xcd * 1024.0), 1),
+                "mfma_mops_bf16": m.get("SQ_INSTS_VALU_MFMA_MOPS_BF16"),
+                "mfma_floor_us_at_this_clock": round(seq_steps * 4 * H * H * 6 / 512.0 / 1024.0 / (gui_per_xcd / dur_us), 1),
+                "SQ_WAVE_CYCLES": m.get("SQ_WAVE_CYCLES"), "SQ_WAIT_ANY": m.get("SQ_WAIT_ANY"), "SQ_WAIT_INST_ANY": m.get("SQ_WAIT_INST_ANY"),
+                "SQ_ACTIVE_INST_ANY": m.get("SQ_ACTIVE_INST_ANY"),
+                "wait_any_frac_of_wave_cycles": round(m["SQ_WAIT_ANY"] / m["SQ_WAVE_CYCLES"], 3) if m.get("SQ_WAVE_CYCLES") else None,
+                "SQ_LDS_BANK_CONFLICT": m.get("SQ_LDS_BANK_CONFLICT"), "SQ_LDS_IDX_ACTIVE": m.get("SQ_LDS_IDX_ACTIVE"),
+                "lds_busy_frac_of_kernel": round(m.get("SQ_LDS_IDX_ACTIVE", 0.0) / (gui_per_xcd * 256.0), 3),
+                "SQ_INSTS_LDS": m.get("SQ_INSTS_LDS"), "SQ_INSTS_VALU": m.get("SQ_INSTS_VALU"), "SQ_ACTIVE_INST_VALU": m.get("SQ_ACTIVE_INST_VALU"),
+                "fetch_size_bytes_raw": m["FETCH_SIZE"] * 1024.0 if "FETCH_SIZE" in m else None,
+                "write_size_bytes": m["WRITE_SIZE"] * 1024.0 if "WRITE_SIZE" in m else None,
+                "algorithmic_bytes_layer0": alg,
+            })
+    out["reading"] = ("MfmaUtil = SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE per XCD x 1024 SIMDs); mfma_floor_us = the kernel's recurrent product (2 B T_l "
+                      "sequence-steps x 4H x H MACs x 6 partial products) at 512 MACs per cycle and SIMD at the profiled clock.  Both kernels are far from "
+                      "that floor: the step of a batch is a chain (publish -> tile in at ~41 GB/s per CU -> product -> cell), see DESIGN.md 4.2.")
+    path = os.path.join(ROOT, "profiles", f"{ROUND}_pmc_rec_mfma.json")
+    json.dump(out, open(path, "w"), indent=1)
+    print(path)
+
+
 if __name__ == "__main__":
-    if sys.argv[1] == "rec":
+    if sys.argv[1] == "recmfma":
+        recmfma(*sys.argv[2:6], *[int(v) for v in sys.argv[6:9]])
+    elif sys.argv[1] == "rec":
         rec(sys.argv[2], sys.argv[3], int(sys.argv[4]), int(sys.argv[5]), int(sys.argv[6]))
     elif sys.argv[1] == "speller":
         speller(sys.argv[2], sys.argv[3], *[int(v) for v in sys.argv[4:8]])
