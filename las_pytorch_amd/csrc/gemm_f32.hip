@@ -970,7 +970,10 @@ int gemm_sk_check() {
     return bad ? fail(LAS_ERR_DEVICE, "stream-K fix-up: a contributing workgroup never arrived (GEMM workgroups were not all resident)%s", "") : LAS_OK;
 }
 
-bool gemm_sk_fixup_ready(hipStream_t stream) { return opt_get(OPT_GEMM_STREAMK) != 0 && sk_scratch(stream, gemm_resident_slots()) != nullptr; }
+constexpr long SKF_MIN_TILES = 64;
+bool gemm_sk_fixup_ready(hipStream_t stream, int M, int N) {
+    return opt_get(OPT_GEMM_STREAMK) != 0 && (long)cdiv(M, BM) * cdiv(N, BN) >= SKF_MIN_TILES && sk_scratch(stream, gemm_resident_slots()) != nullptr;
+}
 
 static bool gemm_aligned(const float* ptr, long ld, long bs) { return ((uintptr_t)ptr % 16 == 0) && (ld % 4 == 0) && (bs % 4 == 0); }
 
@@ -1062,9 +1065,10 @@ int gemm_f32(const GemmDesc& d, hipStream_t stream) {
         const long min_run = std::max<long>(tune_skf_min_run(), (kt + 7) / 8);
         const int Wuse = (int)std::min<long>(W, total / std::max<long>(1, min_run) / 8 * 8);
         const bool uneven = (double)tiles / ((double)cdiv(tiles, W) * W) < 0.92;      // share of the resident slots a classic grid keeps busy
-        // (fewer than 16 tiles would need more than 8 sharers per tile to cover the chip: the owner's serial fetch of their parked tiles
-        // then costs more than fire-and-forget atomics — dW_psi, 4 tiles x 200 k-iterations: 47 against 15 us — so those keep the split-K path)
-        if (sk_on && d.splitk <= 1 && Wuse >= 16 && kt >= skf_min_kt && uneven && tiles >= 16) {
+        // (few tiles need many sharers per tile to cover the chip, and the owner's serial fetch of their parked tiles then costs more than
+        // fire-and-forget atomics — dW_psi, 4 tiles x 200 k-iterations: 47 against 15 us; the logits, 32 tiles x 64: 32 against 18 us inside
+        // the training step — so below SKF_MIN_TILES the split-K path stays)
+        if (sk_on && d.splitk <= 1 && Wuse >= 16 && kt >= skf_min_kt && uneven && tiles >= SKF_MIN_TILES) {
             if (const SkScratch* sc = sk_scratch(stream, W)) {
                 p.persistent = 1; p.dp_tiles = 0; p.sk_iters = total; p.sk_per = (total + Wuse - 1) / Wuse;
                 p.sk_part = sc->part; p.sk_flag = sc->flag; p.sk_err = sc->err_dev; p.sk_id = sk_next_id();

@@ -338,7 +338,7 @@ int las_attn_keys_fwd(const las_speller_desc* d, const float* feat, float* keys,
     // a 64-column output gives only B*T'/128 tiles: split K over the chip and apply the activation in a second tiny pass
     // (with the stream-K fix-up schedule the K split and the relu share ONE launch: no zeroing pass, no activation pass)
     const long tiles = (long)cdiv(g.M, 128) * cdiv(g.N, 128);
-    if (tiles < 64 && g.K >= 256 && !gemm_sk_fixup_ready(stream)) {
+    if (tiles < 64 && g.K >= 256 && !gemm_sk_fixup_ready(stream, g.M, g.N)) {
         g.splitk = (int)std::min<long>(g.K / 64, std::max<long>(1, 256 / tiles));
         LAS_TRY(gemm_f32(g, stream));
         if (d->relu) LAS_TRY(act_inplace(keys, (long)g.M * g.N, d->relu, stream));

@@ -30,9 +30,9 @@ int gemm_f32(const GemmDesc& d, hipStream_t stream);
 int gemm_f32_group(const GemmDesc* ds, int n, hipStream_t stream);
 // LAS_ERR_DEVICE once after a stream-K fix-up wait ran into its spin limit (GEMM workgroups not all resident); clears the report
 int gemm_sk_check();
-// true when gemm_f32 on this stream can take the stream-K fix-up schedule (option on, scratch there or creatable): callers that would
-// otherwise split K by hand (zero fill + atomics + a separate activation pass) then leave the split to gemm_f32
-bool gemm_sk_fixup_ready(hipStream_t stream);
+// true when gemm_f32 on this stream takes the stream-K fix-up schedule for an M x N output (option on, enough output tiles, scratch there or
+// creatable): callers that would otherwise split K by hand (zero fill + atomics + a separate activation pass) then leave the split to gemm_f32
+bool gemm_sk_fixup_ready(hipStream_t stream, int M, int N);
 // arithmetic of the interior tiles: 0 = v_mfma_f32_32x32x2_f32, 1 = exact three-way bf16 operand split on the bf16 MFMA pipe
 // (six partial products, fp32 accumulate; as accurate as the fp32 MFMA, see gemm_f32.hip).  Process-wide; LAS_GEMM_ARITH.
 int gemm_get_arith();
