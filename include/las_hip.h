@@ -58,9 +58,10 @@ const char* las_last_error(void);
  * case-insensitive, with or without the LAS_ prefix.  Returns 0, or 1 for an unknown key.
  *   GEMM_ARITH            1* split-operand bf16 MFMA (fp32-faithful, see las_gemm_f32), 0 fp32 MFMA
  *   GEMM_STREAMK, GEMM_SK_MIN_TILES, GEMM_SPLIT_BELOW, GEMM_SPLIT_TARGET   schedule thresholds of the GEMM (-1* = automatic)
- *   GEMM_SK_FIXUP 1*      stream-K with in-kernel fix-up: tiles that straddle workgroup runs are summed from parked partial tiles by the
- *                         workgroup owning the tile's first k-iteration (no atomics, no zeroing pass, any epilogue); 0: the atomic forms;
- *                         2: also in the grouped launches (las_gemm_f32_group), which keep atomics by default (measured faster there)
+ *   GEMM_SK_FIXUP 0*      1: stream-K with in-kernel fix-up for GEMMs of >= 64 output tiles: tiles that straddle workgroup runs are summed from
+ *                         parked partial tiles by the workgroup owning the tile's first k-iteration (no atomics, no zeroing pass, any epilogue,
+ *                         run-to-run deterministic); 2: also in the grouped launches (las_gemm_f32_group).  Off by default: inside the
+ *                         training step it measured 0.05 ms SLOWER than the atomic forms (5.93 against 5.88 ms, alternating in one process)
  *   GEMM_SKF_MIN_KT, GEMM_SKF_MIN_RUN  fewest k-iterations per tile / per workgroup run for that schedule (-1* = automatic: 8 / 8)
  *   GEMM_SLOTS_PER_CU     resident GEMM workgroups per CU (2*; read at the first GEMM)
  *   GEMM_GROUP 1*, GEMM_XCD_SWZ 1*, GEMM_BATCH_DIRS 1*          grouped weight-gradient launches / XCD order / batched directions

@@ -931,7 +931,7 @@ static int g_sk_n = 0;
 static std::atomic<unsigned> g_sk_id{1};
 
 static const SkScratch* sk_scratch(hipStream_t stream, int slots) {
-    if (opt_get(OPT_GEMM_SK_FIXUP) == 0 || slots <= 0) return nullptr;
+    if (opt_get(OPT_GEMM_SK_FIXUP) <= 0 || slots <= 0) return nullptr;
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess) return nullptr;
     std::lock_guard<std::mutex> lk(g_sk_mu);

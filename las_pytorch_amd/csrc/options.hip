@@ -17,7 +17,7 @@ const OptDef kDefs[OPT_COUNT] = {
     {"GEMM_SLOTS_PER_CU", 2}, {"GEMM_GROUP", 1}, {"GEMM_XCD_SWZ", 1}, {"GEMM_BATCH_DIRS", 1},
     {"SPELLER_PERSIST", 1}, {"SPELLER_PERSIST_BWD", 1}, {"SPELLER_PRE", 1}, {"SPELLER_PRE_BWD", 1},
     {"REC_UW", 0}, {"REC_AGENT_HANDOFF", 0}, {"REC_NB", 0}, {"REC_PIPE", 1}, {"REC_MFMA", 1}, {"REC_TRACE", 0}, {"CELL_MT", 0},
-    {"GEMM_SK_FIXUP", 1}, {"GEMM_SKF_MIN_KT", -1}, {"GEMM_SKF_MIN_RUN", -1},
+    {"GEMM_SK_FIXUP", 0}, {"GEMM_SKF_MIN_KT", -1}, {"GEMM_SKF_MIN_RUN", -1},
     {"TIME_KERNELS", 0},
 };
 std::atomic<long> g_val[OPT_COUNT];
