@@ -50,6 +50,10 @@ extern "C" {
 #define LAS_FLAG_GEMM_F32       8   /* this call's MFMA GEMMs run on the fp32 matrix pipe (v_mfma_f32_32x32x2_f32) whatever the
                                        process-wide GEMM_ARITH option says: per-call, per-thread, re-entrant */
 
+#define LAS_FLAG_GRADS_ZEROED   16  /* las_pblstm_bwd / las_speller_bwd: the gradient outputs lie in one block that the caller has ALREADY zeroed
+                                       (the flat gradient buffer, cleared once per step): the entry point skips its own fill of that block
+                                       (~5 us each, launch-bound).  Without the flag the outputs may hold anything. */
+
 int las_abi_version(void);
 const char* las_last_error(void);
 
@@ -73,6 +77,7 @@ const char* las_last_error(void);
  *                                                                pipeline / as the barrier-phased first form)
  *   REC_TRACE 0*          phase stamps of the pipeline form's first workgroup into its id buffer (tools/ubench_rec_mfma.py)
  *   CELL_MT 0*            M-tiles per workgroup of the per-step cell kernel
+ *   TRUST_ZEROED_GRADS 1* honour LAS_FLAG_GRADS_ZEROED (0: fill the gradient blocks regardless; A/B)
  *   TIME_KERNELS 0*       record HIP events around the one-launch decode kernels on their launch stream (las_debug_kernel_ms)
  * Replaces nothing in the reference (pure Python, no switches).
  * ---------------------------------------------------------------------------------------------- */

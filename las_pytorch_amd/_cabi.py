@@ -14,6 +14,7 @@ MAX_L = 4
 FLAG_STASH = 1
 FLAG_FORCE_GENERIC = 2
 FLAG_TEACHER_FORCED = 4     # las_speller_bwd: the forward that filled `reserve` was teacher-forced (same flags / error word)
+FLAG_GRADS_ZEROED = 16      # las_pblstm_bwd / las_speller_bwd: the gradient block was zeroed by the caller (flat buffer, once per step)
 FLAG_GEMM_F32 = 8           # this call's GEMMs on the fp32 matrix pipe (per call; the process-wide default is option GEMM_ARITH)
 
 _f = C.c_void_p   # every device pointer is passed as an integer address

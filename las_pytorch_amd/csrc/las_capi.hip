@@ -101,6 +101,15 @@ struct SpellerBwdLayout {
 // Gradient outputs that lie back to back in memory (the views of one flat gradient buffer, las_pytorch_amd/dp.py) are zeroed
 // with ONE memset; the split-K GEMMs and column sums that fill them then skip theirs (a launch-bound ~5 us each).
 // Returns false (and does nothing) when the outputs are separate allocations.
+// LAS_FLAG_GRADS_ZEROED (a thread-local scope set by the backward entry points): the caller has zeroed the block already — the flat
+// gradient buffer is cleared once per step (dp.FlatGradAllReducer.zero) — so the fill is skipped (one launch-bound ~5 us memset per
+// backward entry point, four per training step).
+static thread_local bool tl_grads_zeroed = false;
+struct GradsZeroedScope {
+    bool saved;
+    explicit GradsZeroedScope(int flags) : saved(tl_grads_zeroed) { tl_grads_zeroed = (flags & LAS_FLAG_GRADS_ZEROED) != 0 && opt_get(OPT_TRUST_ZEROED_GRADS) != 0; }
+    ~GradsZeroedScope() { tl_grads_zeroed = saved; }
+};
 static bool zero_if_contiguous(std::vector<std::pair<float*, size_t>> outs, hipStream_t stream) {
     std::sort(outs.begin(), outs.end(), [](const std::pair<float*, size_t>& a, const std::pair<float*, size_t>& b) { return a.first < b.first; });
     size_t total = 0;
@@ -109,6 +118,7 @@ static bool zero_if_contiguous(std::vector<std::pair<float*, size_t>> outs, hipS
         if (i + 1 < outs.size() && outs[i].first + outs[i].second != outs[i + 1].first) return false;
         total += outs[i].second;
     }
+    if (tl_grads_zeroed) return true;
     return hipMemsetAsync(outs[0].first, 0, sizeof(float) * total, stream) == hipSuccess;
 }
 
@@ -273,6 +283,7 @@ int las_pblstm_bwd(const float* x, const float* dout, int B, int T_in, int D_in,
                    float* db_ih_r, float* db_hh_r, uint32_t* err_word, int flags, void* stream_) {
     hipStream_t stream = (hipStream_t)stream_;
     GemmArithScope arith_scope(flags);
+    GradsZeroedScope zeroed_scope(flags);
     LAS_REQUIRE(B > 0 && T_in > 0 && D_in > 0 && H > 0 && T_in % 2 == 0, "pblstm dims");
     LAS_REQUIRE(x && dout && reserve && workspace && err_word, "pblstm bwd pointers");
     LAS_REQUIRE(dw_ih_f && dw_hh_f && db_ih_f && db_hh_f && dw_ih_r && dw_hh_r && db_ih_r && db_hh_r, "pblstm grad outputs");
@@ -616,6 +627,7 @@ int las_speller_bwd(const las_speller_desc* d, const float* feat, const float* k
                     const las_speller_grads* g, uint32_t* err_word, int flags, void* stream_) {
     hipStream_t stream = (hipStream_t)stream_;
     GemmArithScope arith_scope(flags);
+    GradsZeroedScope zeroed_scope(flags);
     LAS_TRY(check_desc(d));
     LAS_REQUIRE(U > 0 && feat && logp && att && dlogp && reserve && workspace && g, "speller bwd pointers");
     LAS_REQUIRE(!d->use_mlp || keys, "attention keys");

@@ -41,9 +41,12 @@ class FlatGradAllReducer:
         # backward per step — what solver/solver.py:95-97 does.  The tag is per parameter (it names THIS buffer), so
         # other modules in the process keep ordinary autograd accumulation; see las_model._direct_targets.
         base = self.flat.untyped_storage().data_ptr()
+        self.zero_epoch = 0         # zero() calls so far: a backward kernel may skip its own fill of a gradient block that was not written since
         for p in self.params:
             if direct:
                 p._las_direct_base = base
+                p._las_direct_owner = self
+                p._las_written_epoch = -1
             elif hasattr(p, "_las_direct_base"):
                 del p._las_direct_base
         module._las_flat_reducer = self      # solver.batch_iterator picks it up (zero / all-reduce / clip on the flat buffer)
@@ -51,6 +54,7 @@ class FlatGradAllReducer:
     def zero(self):
         """Use instead of ``optimizer.zero_grad()`` (which would drop the views with set_to_none=True)."""
         self.flat_ext.zero_()
+        self.zero_epoch += 1
 
     def _collective(self):
         """True when allreduce_mean() really exchanges data (more than one rank, or ``force``)."""

@@ -23,7 +23,7 @@ import torch
 import torch.nn as nn
 
 from .. import _cabi
-from .._cabi import FLAG_FORCE_GENERIC, FLAG_STASH, FLAG_TEACHER_FORCED, SpellerDesc, SpellerGrads, check, lib, ptr, stream_ptr
+from .._cabi import FLAG_FORCE_GENERIC, FLAG_GRADS_ZEROED, FLAG_STASH, FLAG_TEACHER_FORCED, SpellerDesc, SpellerGrads, check, lib, ptr, stream_ptr
 
 def set_force_generic(module, flag=True):
     """A/B switch for tests and profiling: every pBLSTM layer / Speller under ``module`` uses the generic kernels
@@ -51,6 +51,22 @@ def _direct_targets(params):
             return None
         out.append(g)
     return out
+
+
+def _claim_prezeroed(params):
+    """True when every one of these direct-write parameters' gradient views is still as ``FlatGradAllReducer.zero()`` left it (zeroed this
+    step, not written since): the backward entry point may then skip its own fill of the block (``LAS_FLAG_GRADS_ZEROED``).  Marks them
+    written."""
+    ok = True
+    for p in params:
+        owner = getattr(p, "_las_direct_owner", None)
+        if owner is None or getattr(p, "_las_written_epoch", None) == owner.zero_epoch or owner.zero_epoch == 0:
+            ok = False
+    for p in params:
+        owner = getattr(p, "_las_direct_owner", None)
+        if owner is not None:
+            p._las_written_epoch = owner.zero_epoch
+    return ok
 
 
 def _flags(stash, force_generic=False):
@@ -118,6 +134,7 @@ class _PBLSTMFn(torch.autograd.Function):
         if stash:
             ctx.save_for_backward(x, ws[0], ws[1], ws[4], ws[5], reserve)
             ctx.direct = _direct_targets((w_ih_f, w_hh_f, b_ih_f, b_hh_f, w_ih_r, w_hh_r, b_ih_r, b_hh_r))
+            ctx.direct_params = (w_ih_f, w_hh_f, b_ih_f, b_hh_f, w_ih_r, w_hh_r, b_ih_r, b_hh_r) if ctx.direct else None
             ctx.dims = (B, T_in, D_in, H)
             ctx.need_dx = ctx.needs_input_grad[1]
             ctx.flags = flags
@@ -135,9 +152,10 @@ class _PBLSTMFn(torch.autograd.Function):
         g = ctx.direct or [torch.empty_like(w_ih_f), torch.empty_like(w_hh_f), torch.empty(4 * H, device=dev),
                            torch.empty(4 * H, device=dev), torch.empty_like(w_ih_r), torch.empty_like(w_hh_r),
                            torch.empty(4 * H, device=dev), torch.empty(4 * H, device=dev)]
+        zeroed = FLAG_GRADS_ZEROED if (ctx.direct and _claim_prezeroed(ctx.direct_params)) else 0
         check(L.las_pblstm_bwd(ptr(x), ptr(dout), B, T_in, D_in, H, ptr(w_ih_f), ptr(w_hh_f), ptr(w_ih_r), ptr(w_hh_r),
                                ptr(reserve), ptr(work), ptr(dx), *[ptr(t) for t in g], ptr(_cabi.err_word(dev)),
-                               ctx.flags, stream_ptr()))
+                               ctx.flags | zeroed, stream_ptr()))
         return (None, dx, *([None] * 8 if ctx.direct else g))
 
 
@@ -424,6 +442,7 @@ class _SpellerFn(torch.autograd.Function):
         feat = _f32c(feat)
         B, Tp, D = feat.shape
         direct = _direct_targets(params) if allow_direct else None      # a sliced batch uses every parameter once per slice
+        ctx.direct_params = tuple(params) if direct else None
         params = [_f32c(p) for p in params]
         lstm, rest = params[:4 * L], params[4 * L:]
         Hs = lstm[1].shape[1]
@@ -488,9 +507,10 @@ class _SpellerFn(torch.autograd.Function):
         g.dfeat = ptr(dfeat)
         work = torch.empty(Lh.las_speller_bwd_workspace_floats(d, U), device=dev, dtype=torch.float32)
         mode0 = int((not teacher_forced) and decode_mode == 0)
+        zeroed = FLAG_GRADS_ZEROED if (ctx.direct and _claim_prezeroed(ctx.direct_params)) else 0
         check(Lh.las_speller_bwd(d, ptr(feat), ptr(keys), ptr(logp), ptr(att), ptr(dlogp), U, mode0, ptr(reserve),
                                  ptr(work), g, ptr(_cabi.err_word(dev)),
-                                 _flags(True, force_generic) | (FLAG_TEACHER_FORCED if teacher_forced else 0), stream_ptr()))
+                                 _flags(True, force_generic) | (FLAG_TEACHER_FORCED if teacher_forced else 0) | zeroed, stream_ptr()))
         return (None, dfeat, None, None, *([None] * len(grads) if ctx.direct else grads))
 
 
