@@ -345,12 +345,16 @@ def make_train_step(las, x, lab, reducer, opt, graph=False):
     forced), fused label-smoothing loss + gradient, backward through every HIP kernel, ONE gradient all-reduce (N > 1), global-norm
     clip at 1.0 + Adam as the fused launch pair.  graph=True captures zero + forward + loss + backward into one HIP graph
     (all-reduce / clip / Adam stay eager behind the replay)."""
-    from las_pytorch_amd.solver.solver import label_smoothing_loss_device, stack_steps
+    from las_pytorch_amd.solver.solver import label_smoothing_loss_backward_device, label_smoothing_loss_device, stack_steps
+    seeded = os.environ.get("LAS_BENCH_LOSS_BACKWARD", "seed") == "seed"      # "autograd": loss.backward() from the scalar (A/B)
 
     def fwd_bwd():
         reducer.zero()
         preds, _ = las(batch_data=x, batch_label=lab, teacher_force_rate=1.0, is_training=True)
-        loss = label_smoothing_loss_device(stack_steps(preds), lab, 0.1)      # fused loss + gradient kernel, no copies
+        # fused loss + gradient kernel, no copies; the gradient seeds the backward directly (what solver.batch_iterator does)
+        if seeded:
+            return label_smoothing_loss_backward_device(stack_steps(preds), lab, 0.1)
+        loss = label_smoothing_loss_device(stack_steps(preds), lab, 0.1)
         loss.backward()
         return loss
 

@@ -470,6 +470,7 @@ class _SpellerFn(torch.autograd.Function):
             noise = _f32c(noise)
             if tuple(noise.shape) != (U, B, V):
                 raise RuntimeError(f"decode_mode 2 needs Exp(1) draws of shape {(U, B, V)}, got {tuple(noise.shape)}")
+        ctx.set_materialize_grads(False)       # (the attention output takes no gradient: do not let autograd fill a zero tensor for it)
         check(Lh.las_speller_fwd(d, ptr(feat), ptr(keys), ptr(labels) if teacher_forced else None, u_lab, U,
                                  int(teacher_forced), decode_mode, ptr(noise), ptr(logp), ptr(att), None, ptr(reserve),
                                  ptr(_cabi.err_word(dev)), _flags(stash, force_generic), stream))
@@ -487,6 +488,8 @@ class _SpellerFn(torch.autograd.Function):
         (U, teacher_forced, decode_mode, L, use_mlp, relu, M, V, heads, force_generic, _allow_direct) = ctx.cfg
         B, Tp, D, Hs = ctx.dims
         dev = feat.device
+        if dlogp is None:                      # (set_materialize_grads(False): only the attention output was used downstream)
+            dlogp = torch.zeros_like(logp)
         dlogp = _f32c(dlogp)
         lstm, rest = params[:4 * L], params[4 * L:]
         Lh = lib()

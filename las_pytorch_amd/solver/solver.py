@@ -140,6 +140,20 @@ def label_smoothing_loss_device(pred_y, labels_onehot_int64, label_smoothing=0.1
     return _FusedSmoothedLoss.apply(pred_y, labels_onehot_int64, label_smoothing)
 
 
+def label_smoothing_loss_backward_device(pred_y, labels_onehot_int64, label_smoothing=0.1):
+    """``loss = label_smoothing_loss_device(...); loss.backward()`` without the two launches autograd adds for a scalar root (the
+    ``ones_like(loss)`` fill and ``grad * upstream``): ``las_ls_loss`` produces d(loss)/d(logp) in the same launch as the loss, and
+    that gradient is handed to autograd as the seed of ``pred_y`` directly.  Returns the (detached) loss tensor."""
+    with torch.no_grad():
+        fn = _FusedSmoothedLoss
+        class _Ctx:                      # the Function's forward, outside the graph
+            needs_input_grad = (True, False, False)
+        ctx = _Ctx()
+        loss = fn.forward(ctx, pred_y.detach(), labels_onehot_int64, label_smoothing)
+    pred_y.backward(gradient=ctx.grad)
+    return loss
+
+
 # --------------------------------------------------------------------------------------------------
 # one step
 # --------------------------------------------------------------------------------------------------
@@ -220,10 +234,16 @@ def batch_iterator(batch_data, batch_label, las_model, optimizer, tf_rate, is_tr
         raise RuntimeError(f"the model decoded {len(step_logp)} steps but {steps} are scored")
     logp = stack_steps(step_logp, steps)                     # (B,steps,V); a strided view when the steps share one buffer
     smoothed = bool(is_training) and label_smoothing != 0.0
-    loss, ler = _loss_and_ler(logp, batch_label, steps, smoothed, label_smoothing)
+    fused_bwd = bool(is_training) and smoothed and _on_hip_path(logp, batch_label) and logp.requires_grad
+    if fused_bwd:       # loss, its gradient and the backward seed from one launch (no ones_like fill, no grad * upstream)
+        ler = LetterErrorRate_device(logp, batch_label)
+        loss = label_smoothing_loss_backward_device(logp, batch_label, label_smoothing)
+    else:
+        loss, ler = _loss_and_ler(logp, batch_label, steps, smoothed, label_smoothing)
 
     if is_training:
-        loss.backward()
+        if not fused_bwd:
+            loss.backward()
         if grad_hook is not None:
             grad_hook(las_model)
         if reducer is not None:
