@@ -77,6 +77,9 @@ const char* las_last_error(void);
  *                                                                pipeline / as the barrier-phased first form)
  *   REC_TRACE 0*          phase stamps of the pipeline form's first workgroup into its id buffer (tools/ubench_rec_mfma.py)
  *   CELL_MT 0*            M-tiles per workgroup of the per-step cell kernel
+ *   SIDE_FILLS 0*         1: the sentinel fills of the decode kernels' hand-off slabs run on a library-owned side stream beside the GEMMs that
+ *                         precede the launch (fork / join by events).  Off: measured 0.07 ms SLOWER per training step (the two cross-stream
+ *                         joins cost more than the 23 us of fills they hide)
  *   TRUST_ZEROED_GRADS 1* honour LAS_FLAG_GRADS_ZEROED (0: fill the gradient blocks regardless; A/B)
  *   TIME_KERNELS 0*       record HIP events around the one-launch decode kernels on their launch stream (las_debug_kernel_ms)
  * Replaces nothing in the reference (pure Python, no switches).

@@ -424,6 +424,16 @@ int las_speller_fwd(const las_speller_desc* d, const float* feat, const float* k
     const bool pre_stash = teacher_forced && lay.pre && ((flags & LAS_FLAG_STASH) || pre);
     LAS_TRY(build_w0p(d->w_ih[0], w0p, Hs, V, Vp, stream, pre_stash ? reserve + lay.wperm : nullptr, pre ? reserve + lay.wyperm : nullptr,
                       pre ? reserve + lay.bperm : nullptr, d->b_ih[0], d->b_hh[0]));
+    // the PRE kernel's hand-off slabs (50 MB of sentinel words at paper size) are filled on the side stream, beside the two GEMMs below
+    SideStream& side = side_stream();
+    bool side_fill = false;
+    if (pre && side.ok(stream)) {
+        PersistFwd pf;
+        pf.hx = reserve + lay.hx; pf.r0x = reserve + lay.r0x; pf.U = U; pf.Hs = Hs;
+        LAS_TRY(side.fork(stream));
+        LAS_TRY(speller_persist_fwd_fill(pf, side.s));
+        side_fill = true;
+    }
     if (pre_stash) {
         GemmDesc g;
         g.A = feat; g.lda = D; g.a_kc = true;
@@ -435,6 +445,7 @@ int las_speller_fwd(const las_speller_desc* d, const float* feat, const float* k
     bool pre_ran = false;
     if (persist) {
         PersistFwd p;
+        p.prefilled = side_fill;
         if (pre) {
             // label half of the bottom-layer gates for every step, off the decode chain: yw[s][b] = y_s[b] W_y^T + b_ih0 + b_hh0
             GemmDesc g;
@@ -457,6 +468,7 @@ int las_speller_fwd(const las_speller_desc* d, const float* feat, const float* k
             p.mode = decode_mode == 1 ? 1 : 2;
             p.w_c = d->w_c; p.b_c = d->b_c; p.logp = logp; p.argmax = argmax; p.lgx = reserve + lay.lgx;
         }
+        if (side_fill) LAS_TRY(side.join(stream));
         const int rc = speller_persist_fwd(p, stream);
         if (rc == LAS_ERR_UNSUPPORTED) persist_ran = false;      // residency check failed: the per-step kernels below run instead
         else LAS_TRY(rc);

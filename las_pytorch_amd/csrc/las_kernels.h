@@ -135,6 +135,19 @@ int attn_step_fwd(const AttnFwdArgs& a, hipStream_t stream);
 
 // Persistent teacher-forced decode loop (speller_persist.hip): one launch for all U steps.  Pointers are the
 // SpellerLayout stash arrays; eligibility (shape / residency) must be checked first.
+// A side stream per (host thread, device) for work that is independent of the launches around it (the sentinel fills of the hand-off
+// slabs, 50 - 90 MB of pure writes, beside MFMA-bound GEMMs): fork() makes the side stream wait for everything issued so far on the main
+// stream, join() makes the main stream wait for the side stream.  Both are event record / wait pairs, so they are captured into a HIP
+// graph like any other stream operation.  ok() is false when the handles could not be created (e.g. first use during a stream capture):
+// the caller then does the work inline.  Option SIDE_FILLS = 0 switches the mechanism off (A/B).
+struct SideStream {
+    hipStream_t s = nullptr; hipEvent_t e_fork = nullptr, e_join = nullptr; bool tried = false;
+    bool ok(hipStream_t main);
+    int fork(hipStream_t main);
+    int join(hipStream_t main);
+};
+SideStream& side_stream();
+
 struct PersistFwd {
     const float* w0p; int Vp;                       // [W_y | 0 | W_ctx] shadow of W_ih0, ld = Vp + Hs
     const float* w_hh0; const float* w_ih1; const float* w_hh1;
@@ -155,7 +168,9 @@ struct PersistFwd {
     const float* yw = nullptr;                      // PRE variant: (U*B, 4Hs) label half + biases of the bottom-layer gates, permuted columns
     int B, Tp, U, Hs, V, relu;
     unsigned* err;
+    bool prefilled = false;                         // the caller has sentinel-filled the hand-off slabs already (speller_persist_fwd_fill)
 };
+int speller_persist_fwd_fill(const PersistFwd& p, hipStream_t stream);      // (PRE variant: needs hx, r0x, U, Hs only)
 bool speller_persist_eligible(int B, int Tp, int Hs, int D, int M, int V, int L, int heads, int use_mlp, int free_running);
 int speller_persist_pre_ws(int B, int Tp, int Hs, int cus);   // attention workgroups per utterance of the PRE variant (0: n/a; cus < 0: shape only)
 bool speller_persist_pre_shape(int B, int Tp, int Hs, int D, int M, int V, int L, int heads, int use_mlp);   // shape only (sizes the reserve)

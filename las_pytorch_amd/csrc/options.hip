@@ -2,6 +2,7 @@
 #include "../../include/las_hip.h"
 #include "las_common.h"
 #include "options.h"
+#include "las_kernels.h"
 #include <atomic>
 #include <ctype.h>
 #include <mutex>
@@ -18,7 +19,7 @@ const OptDef kDefs[OPT_COUNT] = {
     {"SPELLER_PERSIST", 1}, {"SPELLER_PERSIST_BWD", 1}, {"SPELLER_PRE", 1}, {"SPELLER_PRE_BWD", 1},
     {"REC_UW", 0}, {"REC_AGENT_HANDOFF", 0}, {"REC_NB", 0}, {"REC_PIPE", 1}, {"REC_MFMA", 1}, {"REC_TRACE", 0}, {"CELL_MT", 0},
     {"GEMM_SK_FIXUP", 0}, {"GEMM_SKF_MIN_KT", -1}, {"GEMM_SKF_MIN_RUN", -1},
-    {"TRUST_ZEROED_GRADS", 1},
+    {"SIDE_FILLS", 0}, {"TRUST_ZEROED_GRADS", 1},
     {"TIME_KERNELS", 0},
 };
 std::atomic<long> g_val[OPT_COUNT];
@@ -91,6 +92,36 @@ KernelTimer::~KernelTimer() {
     std::lock_guard<std::mutex> lk(g_ev_mu);
     if (hipEventRecord(g_ev[dev][which][1], stream) == hipSuccess) g_ev_valid[dev][which] = true;
 }
+SideStream& side_stream() {
+    thread_local SideStream tl[16];
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) dev = 0;
+    return tl[dev];
+}
+bool SideStream::ok(hipStream_t main) {
+    if (opt_get(OPT_SIDE_FILLS) == 0) return false;
+    if (s != nullptr) return true;
+    if (tried) return false;
+    hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+    if (hipStreamIsCapturing(main, &cap) != hipSuccess || cap != hipStreamCaptureStatusNone) return false;      // not now; try again on a later call
+    tried = true;
+    if (hipStreamCreateWithFlags(&s, hipStreamNonBlocking) != hipSuccess) { s = nullptr; (void)hipGetLastError(); return false; }
+    if (hipEventCreateWithFlags(&e_fork, hipEventDisableTiming) != hipSuccess || hipEventCreateWithFlags(&e_join, hipEventDisableTiming) != hipSuccess) {
+        (void)hipGetLastError(); (void)hipStreamDestroy(s); s = nullptr; return false;
+    }
+    return true;
+}
+int SideStream::fork(hipStream_t main) {
+    LAS_HIP_CHECK(hipEventRecord(e_fork, main));
+    LAS_HIP_CHECK(hipStreamWaitEvent(s, e_fork, 0));
+    return LAS_OK;
+}
+int SideStream::join(hipStream_t main) {
+    LAS_HIP_CHECK(hipEventRecord(e_join, s));
+    LAS_HIP_CHECK(hipStreamWaitEvent(main, e_join, 0));
+    return LAS_OK;
+}
+
 int kernel_timer_read(int which, float* ms_out) {
     const int dev = timer_device();
     if (which < 0 || which >= TIMED_COUNT || !ms_out || dev < 0) return fail(LAS_ERR_ARG, "no timed launch of kernel %s%ld", "", (long)which);

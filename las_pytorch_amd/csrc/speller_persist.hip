@@ -1264,6 +1264,18 @@ static int launch_persist_fwd(const PersistArgs& a, int grid, hipStream_t stream
     return a.mode != 0 ? launch_persist_fwd2<HS, SPLIT, true>(a, grid, stream) : launch_persist_fwd2<HS, SPLIT, false>(a, grid, stream);
 }
 
+// sentinel-fill what the phases of the PRE variant hand over: h0 (row-major slabs, first half of hx), h1 (tiled, second half), R0 tiles
+int speller_persist_fwd_fill(const PersistFwd& p, hipStream_t stream) {
+    const size_t r0_floats = (size_t)p.U * 32 * 4 * p.Hs;
+    if (p.r0x == p.hx + (size_t)2 * p.U * 32 * p.Hs) {      // adjacent (the layout las_capi.hip uses): one fill
+        LAS_HIP_CHECK(hipMemsetAsync(p.hx, 0xFF, sizeof(float) * ((size_t)2 * p.U * 32 * p.Hs + r0_floats), stream));
+    } else {
+        LAS_HIP_CHECK(hipMemsetAsync(p.hx, 0xFF, sizeof(float) * 2 * p.U * 32 * p.Hs, stream));
+        LAS_HIP_CHECK(hipMemsetAsync(p.r0x, 0xFF, sizeof(float) * r0_floats, stream));
+    }
+    return LAS_OK;
+}
+
 int speller_persist_fwd(const PersistFwd& p, hipStream_t stream) {
     LAS_REQUIRE(speller_persist_eligible(p.B, p.Tp, p.Hs, p.Hs, PS_M, p.V, 2, 1, 1, p.mode != 0), "persistent speller shape");
     LAS_REQUIRE(p.mode >= 0 && p.mode <= 2, "persistent speller mode");
@@ -1289,14 +1301,7 @@ int speller_persist_fwd(const PersistFwd& p, hipStream_t stream) {
         const int ws = speller_persist_pre_ws(p.B, p.Tp, p.Hs, cus);
         LAS_REQUIRE(p.mode == 0 && p.gx && p.r0x && p.yw && ws != 0 && speller_persist_pre_shape(p.B, p.Tp, p.Hs, p.Hs, PS_M, p.V, 2, 1, 1), "persistent speller (pre) shape");
         a.split = ws;
-        // sentinel-fill what the phases hand over: h0 (row-major slabs, first half of hx), h1 (tiled, second half), R0 tiles
-        const size_t r0_floats = (size_t)p.U * 32 * 4 * p.Hs;
-        if (p.r0x == p.hx + (size_t)2 * p.U * 32 * p.Hs) {      // adjacent (the layout las_capi.hip uses): one fill
-            LAS_HIP_CHECK(hipMemsetAsync(p.hx, 0xFF, sizeof(float) * ((size_t)2 * p.U * 32 * p.Hs + r0_floats), stream));
-        } else {
-            LAS_HIP_CHECK(hipMemsetAsync(p.hx, 0xFF, sizeof(float) * 2 * p.U * 32 * p.Hs, stream));
-            LAS_HIP_CHECK(hipMemsetAsync(p.r0x, 0xFF, sizeof(float) * r0_floats, stream));
-        }
+        if (!p.prefilled) LAS_TRY(speller_persist_fwd_fill(p, stream));
         const int grid = p.Hs / 4 + ws * p.B;
         if (p.Hs == 512)
             return ws == 4 ? launch_persist_fwd_pre<512, 4>(a, grid, stream)

@@ -1379,6 +1379,15 @@ int speller_persist_bwd(const PersistBwd& p, hipStream_t stream) {
         a.dG_all = p.dG_all; a.dctx_all = p.dctx_all; a.de_all = p.de_all;
         a.dx0 = p.dx0; a.ldx0 = p.V + p.Hs;
         a.B = p.B; a.Tp = p.Tp; a.U = p.U; a.relu = p.relu; a.err = p.err; a.trace = g_persist_bwd_trace;
+        // the hand-off slabs (92 MB of sentinel words at paper size) are filled on the side stream, beside the e0 GEMM
+        const size_t slab_floats = (size_t)a.ns * nq + (size_t)2 * p.U * (p.Hs / 16) * 32 * 64 + (size_t)(p.U + 1) * (p.Hs / 16) * 32 * 16 +
+                                   (size_t)(p.U + 1) * 2 * (p.Hs / 16) * 256;
+        SideStream& side = side_stream();
+        const bool side_fill = side.ok(stream);
+        if (side_fill) {
+            LAS_TRY(side.fork(stream));
+            LAS_HIP_CHECK(hipMemsetAsync(slabs, 0xFF, sizeof(float) * slab_floats, side.s));
+        }
         {   // e0[s][b][t] = dcat_ctx[s][b] . feat[b][t]: one batched GEMM over the utterances
             GemmDesc g;
             g.A = p.dcat_all + p.Hs; g.lda = (long)p.B * 2 * p.Hs; g.a_kc = true; g.sA = 2 * p.Hs;
@@ -1393,9 +1402,8 @@ int speller_persist_bwd(const PersistBwd& p, hipStream_t stream) {
             }
             LAS_TRY(gemm_f32(g, stream));
         }
-        const size_t slab_floats = (size_t)a.ns * nq + (size_t)2 * p.U * (p.Hs / 16) * 32 * 64 + (size_t)(p.U + 1) * (p.Hs / 16) * 32 * 16 +
-                                   (size_t)(p.U + 1) * 2 * (p.Hs / 16) * 256;
-        LAS_HIP_CHECK(hipMemsetAsync(slabs, 0xFF, sizeof(float) * slab_floats, stream));
+        if (side_fill) LAS_TRY(side.join(stream));
+        else LAS_HIP_CHECK(hipMemsetAsync(slabs, 0xFF, sizeof(float) * slab_floats, stream));
         const int grid = 2 * (p.Hs / 16) * 2 + a.ns * p.B;
         if (p.Hs == 512) LAS_TRY(launch_persist_bwd_pre<512>(a, grid, stream));
         else LAS_TRY(launch_persist_bwd_pre<256>(a, grid, stream));
