@@ -36,7 +36,7 @@ def main():
     for name in ("rec_mfma_trace", "gemm_skf_b32", "gemm_skf_b128", "spin_timeout"):
         src = os.path.join(E, name + ".log")
         if os.path.exists(src):
-            open(os.path.join(P, f"r04_{name}.txt"), "w").write("".join(l for l in open(src) if "amdgpu.ids" not in l))
+            open(os.path.join(P, f"r04_{name}.txt"), "w").write("".join(l for l in open(src) if "amdgpu.ids" not in l and "trace wg0:" not in l))
     subprocess.run([sys.executable, os.path.join(ROOT, "tools", "make_pmc_profiles.py"), "gemm", "1", find_db("pmc_gemm_a1"), find_db("pmc_gemm_b1"),
                     "0", find_db("pmc_gemm_a0"), find_db("pmc_gemm_b0")], check=True)
     open(os.path.join(P, "r04_gemm_split_vs_fp32.txt"), "w").write(

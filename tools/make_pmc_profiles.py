@@ -27,7 +27,8 @@ def rows(db, match):
     out = {}
     for name, counter, value, grid, dur in con.execute("select kernel_name, counter_name, value, grid_size, duration from counters_collection"):
         if match in name:
-            key = (name.split("(")[0].replace("void ", "").replace("las::", ""), grid)
+            short = name.replace("(anonymous namespace)::", "").split("(")[0].replace("void ", "").replace("las::", "")
+            key = (short, grid)
             d = out.setdefault(key, {}).setdefault(counter, [0.0, 0, 0.0])
             d[0] += value; d[1] += 1; d[2] += dur
     return out

@@ -3,6 +3,7 @@ import ctypes, os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
 from las_pytorch_amd import _cabi
+if os.environ.get("LAS_ABL_LIB"): _cabi.LIB_PATH = os.path.abspath(os.environ["LAS_ABL_LIB"])      # the -DLAS_REC_TRACE build
 L = _cabi.lib()
 L.las_debug_rec_trace.argtypes = [ctypes.c_void_p]; L.las_debug_rec_trace.restype = None
 B, T, H = int(os.environ.get("B", 128)), int(os.environ.get("T", 400)), int(os.environ.get("H", 256))
