@@ -316,13 +316,16 @@ def test_multi_utterance_recurrence_matches_generic(H, B, T):
         assert_close(res[0][k], res[1][k], f"multi-utterance recurrence H={H} B={B}: {k}", rtol=1e-3, atol=2e-5 * scale)
 
 
-@pytest.mark.parametrize("B,T,agent", [(144, 12, 0), (300, 10, 0), (130, 6, 0), (70, 9, 0), (200, 7, 1), (520, 5, 1), (800, 6, 0)])
+@pytest.mark.parametrize("B,T,agent", [(144, 12, 0), (300, 10, 0), (130, 6, 0), (70, 9, 0), (200, 7, 1), (520, 5, 1), (800, 6, 0), (528, 400, 0),
+                                       (272, 130, 1)])
 def test_matrix_pipe_recurrence_matches_generic(B, T, agent):
     """Batches from 64 utterances at H = 256: both recurrences run 16 utterances per group as MFMA tiles on the bf16 matrix pipe
     (pblstm_rec_mfma.hip; partial last batch at B = 144 / 130 / 70, two alternating batches per group in the forward and two launches
     in the backward at B = 300 / 520).  Forward output, dx and all eight parameter gradients against the generic kernels for BOTH forms of
     the forward (REC_MFMA = 3: barrier-phased; 2: the wave-specialised pipeline of pblstm_rec_mfma2.hip, two or three batches in flight
-    at B = 300 / 520); with the option switched off the VALU multi-utterance kernels must give the same.  agent = 1 forces the placement-independent hand-off
+    at B = 300 / 520; (528, 400): the benchmark's 400 steps — the four-slot rings wrap 100 times, 33 batches of 16 of which the last
+    group's are partial; (272, 130, 1): 130 steps of the placement-independent hand-off); with the option switched off the VALU
+    multi-utterance kernels must give the same.  agent = 1 forces the placement-independent hand-off
     (agent-scope stores and loads through memory) that a group uses when its workgroups do not share an XCD."""
     import las_pytorch_amd
     from las_pytorch_amd import _cabi, pBLSTMLayer
