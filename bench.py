@@ -438,6 +438,21 @@ def launch_ranks(n):
     return subprocess.call(cmd, env=env)
 
 
+def preflight_problems(table):
+    """The checks of ``dist_preflight`` on the gathered per-rank rows (pure function: unit-tested on CPU)."""
+    problems = []
+    seen = {}
+    for row in table:
+        key = (row["host"], row["id"] if row["id"] not in ("None", "?:?") else row["device"])
+        if key in seen:
+            problems.append(f"ranks {seen[key]} and {row['rank']} share one GPU ({key})")
+        seen[key] = row["rank"]
+        if row["cus"] != 256:
+            problems.append(f"rank {row['rank']}: {row['name']} reports {row['cus']} CUs (the one-launch kernels are sized for 256; they fall back to "
+                            "the per-step kernels)")
+    return problems
+
+
 def dist_preflight(device, rank, world):
     """First-run diagnostics of a multi-GPU launch, before any timing: every rank reports (host, GPU identity, CU count); the ranks
     of one host must sit on DISTINCT devices (two ranks on one GPU make every persistent kernel wait for the other's CUs — the
@@ -451,16 +466,7 @@ def dist_preflight(device, rank, world):
                 cus=int(props.multi_processor_count), visible=torch.cuda.device_count())
     table = [None] * world
     dist.all_gather_object(table, mine)
-    problems = []
-    seen = {}
-    for row in table:
-        key = (row["host"], row["id"] if row["id"] not in ("None", "?:?") else row["device"])
-        if key in seen:
-            problems.append(f"ranks {seen[key]} and {row['rank']} share one GPU ({key})")
-        seen[key] = row["rank"]
-        if row["cus"] != 256:
-            problems.append(f"rank {row['rank']}: {row['name']} reports {row['cus']} CUs (the one-launch kernels are sized for 256; they fall back to "
-                            "the per-step kernels)")
+    problems = preflight_problems(table)
     fatal = [p for p in problems if "share one GPU" in p]
     if rank == 0 and problems:
         print("bench.py preflight: " + "; ".join(problems), file=sys.stderr, flush=True)

@@ -46,6 +46,23 @@ def test_graft_entry_build_runs():
     mod.build()
 
 
+def test_bench_preflight_detects_shared_devices_and_small_gpus():
+    """bench.py --gpus N pre-flight (no 8-GPU node was ever available to this build: the check itself is what can be tested)."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("_bench_under_test", os.path.join(ROOT, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    row = lambda r, dev, ident, cus=256, host="n0": dict(rank=r, host=host, device=dev, id=ident, name="MI355X", cus=cus, visible=8)
+    assert bench.preflight_problems([row(r, r, f"GPU-{r}") for r in range(8)]) == []
+    p = bench.preflight_problems([row(0, 0, "GPU-a"), row(1, 0, "GPU-a"), row(2, 2, "GPU-c")])
+    assert len(p) == 1 and "ranks 0 and 1 share one GPU" in p[0]
+    assert bench.preflight_problems([row(0, 0, "GPU-a"), row(1, 0, "GPU-a", host="n1")]) == []          # same id on another host is another GPU
+    p = bench.preflight_problems([row(0, 0, "None"), row(1, 0, "None")])                                   # no uuid: fall back to the device index
+    assert len(p) == 1 and "share one GPU" in p[0]
+    p = bench.preflight_problems([row(0, 0, "GPU-a", cus=304)])
+    assert len(p) == 1 and "304 CUs" in p[0]
+
+
 def _build(cfg_name, **kw):
     c = synth.CONFIGS[cfg_name]
     listener = Listener(input_feature_dim=c["F"], hidden_size=c["H"], num_layers=c["L"], rnn_unit="LSTM", use_gpu=False,
