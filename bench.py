@@ -582,7 +582,8 @@ def main():
     # every rank takes part in what contains a collective: the step's all-reduce timed alone, and the training steps under which the
     # two decode kernels are event-timed
     ar_ms = allreduce_alone_ms(reducer) if train else None
-    speller_roof = roofline_speller(step, c, B, T, U) if (train and not args.no_roofline) else {}
+    # (the library's kernel timer records nothing while a HIP graph is replayed: time the two decode kernels under the EAGER step)
+    speller_roof = roofline_speller(eager_step, c, B, T, U) if (train and not args.no_roofline) else {}
     if rank == 0:
         ms = dt / args.steps * 1e3
         try:
