@@ -176,7 +176,9 @@ def test_step_is_rerun_on_the_generic_kernels_after_a_handoff_timeout():
         assert float(opt.state[next(las.parameters())]["step"]) == 1.0
         outs.append((float(loss), torch.cat([p.detach().reshape(-1) for p in las.parameters()]).cpu().numpy()))
     assert abs(outs[0][0] - outs[1][0]) < 1e-5 * abs(outs[0][0])
-    assert_close(outs[1][1], outs[0][1], "parameters after a re-run step", rtol=1e-5, atol=1e-6)
+    # (the two runs use different kernel families; Adam's FIRST update is lr * g / (|g| + eps): where a gradient element is of the order of
+    #  eps = 1e-8 a last-bit difference of g moves the update by a percent of lr = 2e-4 — observed once in 2 086 046 elements: 1.1e-6)
+    assert_close(outs[1][1], outs[0][1], "parameters after a re-run step", rtol=1e-5, atol=5e-6)
     las = build_las(info["cfg"], sd_np, max_label_len=info["free_len"])
     opt = torch.optim.Adam(las.parameters(), lr=2e-4)
     _cabi.err_word("cuda")[0] = 0xDEAD0001 - (1 << 32)
