@@ -20,6 +20,8 @@
 //     consumers poll their own float4 of the tile (same XCD) or watch one dword per producer first (otherwise), always with
 //     agent-scope loads, and check every word against the sentinel (persist_common.h).  `out` receives h_t as an ordinary store.
 // All spins are bounded and report through the device error word.
+// From two batches per group (B > 256) the forward runs as the wave-specialised pipeline of pblstm_rec_mfma2.hip instead (same groups,
+// same arithmetic; rec_fwd_mfma below dispatches); the backward kernel of this file serves every large batch.
 #include "las_common.h"
 #include "las_kernels.h"
 #include "options.h"

@@ -435,6 +435,14 @@ def test_direct_gradient_write_matches_autograd_accumulation(cfg_name, B):
             torch.stack(preds).square().mean().backward()
             red.check_views()
         flats.append(red.flat.detach().cpu().numpy().copy())
+        if direct:
+            # a further backward WITHOUT zero(): the blocks were written in this zero-epoch, so LAS_FLAG_GRADS_ZEROED is not claimed, the
+            # entry points fill their blocks themselves and the direct writes overwrite (they do not accumulate onto the stale values)
+            assert not las_model._claim_prezeroed(list(las.parameters()))
+            preds, _ = las(x, lab, 1.0, True)
+            torch.stack(preds).square().mean().backward()
+            assert_close(red.flat.detach().cpu().numpy(), flats[-1], "direct writes overwrite without zero()", rtol=1e-4,
+                         atol=1e-6 * float(np.abs(flats[-1]).max()))
     # the untagged model accumulates over two backward passes (micro-batching) even while a direct reducer exists
     for _ in range(2):
         preds, _ = other(x, lab, 1.0, True)
