@@ -404,8 +404,7 @@ int las_speller_fwd(const las_speller_desc* d, const float* feat, const float* k
     const int Vp = lay.Vp;
     float* w0p = reserve + lay.w0p;
     LAS_REQUIRE(Hs % 16 == 0, "speller hidden size must be a multiple of 16");
-    LAS_TRY(labels_to_y(teacher_forced ? (const long long*)labels_onehot : nullptr, y_all, B, U, V, Vp, U_lab, stream));
-    LAS_TRY(copy2d(feat, (long)Tp * D, ctx_all, D, B, D, 0, stream));     // ctx_{-1} = feat[:,0,:] (las_model.py:198)
+    // (labels -> y_all, ctx_{-1} = feat[:,0,:] (las_model.py:198) and the W_ih0 shadow below: ONE launch, speller_prologue)
     // 16-byte aligned, tail-free shadow of W_ih0: columns [0,V) = label part, [V,Vp) = 0, [Vp,Vp+Hs) = context part (rebuilt
     // every call: in training the parameters change every step, so there is nothing to cache across calls)
     const bool persist_on = opt_get(OPT_SPELLER_PERSIST) != 0;
@@ -422,8 +421,9 @@ int las_speller_fwd(const las_speller_desc* d, const float* feat, const float* k
     // las_speller_bwd (LAS_FLAG_TEACHER_FORCED) can rely on them whichever forward variant actually ran.
     // (Only a stashing forward has a backward: without LAS_FLAG_STASH the two GEMMs are skipped unless the PRE kernel itself needs P.)
     const bool pre_stash = teacher_forced && lay.pre && ((flags & LAS_FLAG_STASH) || pre);
-    LAS_TRY(build_w0p(d->w_ih[0], w0p, Hs, V, Vp, stream, pre_stash ? reserve + lay.wperm : nullptr, pre ? reserve + lay.wyperm : nullptr,
-                      pre ? reserve + lay.bperm : nullptr, d->b_ih[0], d->b_hh[0]));
+    LAS_TRY(speller_prologue(d->w_ih[0], w0p, Hs, V, Vp, pre_stash ? reserve + lay.wperm : nullptr, pre ? reserve + lay.wyperm : nullptr,
+                             pre ? reserve + lay.bperm : nullptr, d->b_ih[0], d->b_hh[0],
+                             teacher_forced ? (const long long*)labels_onehot : nullptr, y_all, B, U, U_lab, feat, (long)Tp * D, ctx_all, D, stream));
     // the PRE kernel's hand-off slabs (50 MB of sentinel words at paper size) are filled on the side stream, beside the two GEMMs below
     SideStream& side = side_stream();
     bool side_fill = false;

@@ -248,6 +248,10 @@ int ler(const float* logp, long sU, long sB, const long long* labels, int U, int
 int build_w0p(const float* w_ih0, float* w0p, int Hs, int V, int Vp, hipStream_t stream, float* wperm = nullptr,
               float* wyperm = nullptr, float* bperm = nullptr, const float* b_ih0 = nullptr, const float* b_hh0 = nullptr);
 int labels_to_y(const long long* labels, float* y_all, int B, int U, int V, int Vp, int u_lab, hipStream_t stream);
+// build_w0p + labels_to_y + ctx_{-1} = feat[:,0,:] in one launch (the Speller forward's element-wise preparations)
+int speller_prologue(const float* w_ih0, float* w0p, int Hs, int V, int Vp, float* wperm, float* wyperm, float* bperm, const float* b_ih0,
+                     const float* b_hh0, const long long* labels, float* y_all, int B, int U, int u_lab, const float* feat, long ldfeat,
+                     float* ctx0, int D, hipStream_t stream);
 int collate_pad(const float* packed, const long long* foff, const long long* plab, const long long* loff, int B, int T, int F, int U,
                 int V, float* inputs, long long* targets, hipStream_t stream);
 

@@ -191,6 +191,66 @@ int build_w0p(const float* w_ih0, float* w0p, int Hs, int V, int Vp, hipStream_t
     return LAS_OK;
 }
 
+// The three element-wise preparations of a Speller forward in ONE launch (each is launch-bound at ~5 us on its own): the W_ih0 shadow
+// (build_w0p), the teacher-forcing inputs (labels_to_y) and the initial context ctx_{-1} = feat[:,0,:] (reference las_model.py:198).
+// Block ranges select the job; the bodies are the kernels above.
+__global__ __launch_bounds__(256) void speller_prologue_kernel(const float* __restrict__ w, float* __restrict__ w0p, float* __restrict__ wperm,
+                                                               float* __restrict__ wyperm, float* __restrict__ bperm,
+                                                               const float* __restrict__ b_ih0, const float* __restrict__ b_hh0, int Hs, int V, int Vp,
+                                                               const long long* __restrict__ labels, float* __restrict__ y_all, int B, int U, int u_lab,
+                                                               const float* __restrict__ feat, long ldfeat, float* __restrict__ ctx0, int D,
+                                                               int nb_w, int nb_y) {
+    int blk = blockIdx.x;
+    if (blk < nb_w) {
+        const long i = (long)blk * 256 + threadIdx.x;
+        const int ld = Vp + Hs, rows = 4 * Hs;
+        if (i >= (long)rows * ld) return;
+        const int r = i / ld, c = i % ld;
+        const int gate = r / Hs, u = r % Hs;
+        const long pr = (u >> 2) * 16 + (u & 3) * 4 + gate;
+        float v = 0.f;
+        if (c < V) v = w[(long)r * (V + Hs) + c];
+        else if (c >= Vp) {
+            v = w[(long)r * (V + Hs) + V + (c - Vp)];
+            if (wperm) wperm[pr * Hs + (c - Vp)] = v;
+        }
+        if (wyperm && c < Vp) wyperm[pr * Vp + c] = v;
+        if (bperm && c == 0) bperm[pr] = b_ih0[r] + b_hh0[r];
+        w0p[i] = v;
+        return;
+    }
+    blk -= nb_w;
+    if (blk < nb_y) {
+        const long i = (long)blk * 256 + threadIdx.x;
+        const long n = (long)(U + 1) * B * Vp;
+        if (i >= n) return;
+        const int v = i % Vp;
+        const int b = (i / Vp) % B;
+        const int s = i / ((long)Vp * B);
+        float val = 0.f;
+        if (v < V) {
+            if (s == 0) val = (v == 0) ? 1.f : 0.f;
+            else if (labels && s - 1 < u_lab) val = (float)labels[((long)b * u_lab + (s - 1)) * V + v];
+        }
+        y_all[i] = val;
+        return;
+    }
+    blk -= nb_y;
+    const long i = (long)blk * 256 + threadIdx.x;
+    if (i >= (long)B * D) return;
+    const int r = i / D, c = i % D;
+    ctx0[(long)r * D + c] = feat[(long)r * ldfeat + c];
+}
+int speller_prologue(const float* w_ih0, float* w0p, int Hs, int V, int Vp, float* wperm, float* wyperm, float* bperm, const float* b_ih0,
+                     const float* b_hh0, const long long* labels, float* y_all, int B, int U, int u_lab, const float* feat, long ldfeat,
+                     float* ctx0, int D, hipStream_t stream) {
+    const int nb_w = cdiv((long)4 * Hs * (Vp + Hs), 256), nb_y = cdiv((long)(U + 1) * B * Vp, 256), nb_c = cdiv((long)B * D, 256);
+    hipLaunchKernelGGL(speller_prologue_kernel, dim3(nb_w + nb_y + nb_c), dim3(256), 0, stream, w_ih0, w0p, wperm, wyperm, bperm, b_ih0, b_hh0, Hs, V,
+                       Vp, labels, y_all, B, U, u_lab, feat, ldfeat, ctx0, D, nb_w, nb_y);
+    LAS_LAUNCH_CHECK();
+    return LAS_OK;
+}
+
 // Teacher-forcing inputs: y_all[0] = onehot(<sos>=0) (reference las_model.py:193-195),
 // y_all[1+s][b][:] = float(ground_truth[b][s][:]) (las_model.py:216-217; any label rows, incl. all-zero padding)
 __global__ void labels_to_y_kernel(const long long* __restrict__ labels, float* __restrict__ y_all, int B, int U, int V,
@@ -328,38 +388,39 @@ int log_softmax_bwd_rows(const float* dlogp, const float* logp, float* dz, long 
 // loss = -(1/B) sum_b sum_s ( sum_c smooth[b,s,c] logp[b,s,c] ) / len_b ,  smooth = ((1-eps) y + eps/V) * sum_c y,
 // len_b = sum_{s,c} y   (solver.py:33-45).  One workgroup per utterance; per-utterance partial losses are summed in a
 // fixed order by the last-launched tiny kernel (deterministic).  dlogp = -smooth / (B len_b) * gscale.
-__global__ __launch_bounds__(256) void ls_loss_kernel(const float* __restrict__ logp, long sU, long sB,
-                                                      const long long* __restrict__ labels, int U, int U_lab, int B, int V,
-                                                      float eps, float* __restrict__ part, float* __restrict__ dlogp,
-                                                      long dU, long dB) {
+constexpr int LS_THREADS = 1024;      // (four elements per thread at U = 128, V = 30: the kernel is a chain of dependent memory round trips, not work)
+__global__ __launch_bounds__(LS_THREADS) void ls_loss_kernel(const float* __restrict__ logp, long sU, long sB,
+                                                             const long long* __restrict__ labels, int U, int U_lab, int B, int V,
+                                                             float eps, float* __restrict__ part, float* __restrict__ dlogp,
+                                                             long dU, long dB) {
     // one workgroup per utterance, one element (step, class) per thread and pass: the label slab is read coalesced; the row
     // sums the smoothing needs (1 on labelled steps, 0 on padding) are built in LDS first
     extern __shared__ float rowsum[];                 // U floats
-    __shared__ float red[256];
+    __shared__ float red[LS_THREADS];
     const int b = blockIdx.x, tid = threadIdx.x;
     const long long* yb = labels + (long)b * U_lab * V;
     const int n = U * V;
-    for (int s = tid; s < U; s += 256) rowsum[s] = 0.f;
+    for (int s = tid; s < U; s += LS_THREADS) rowsum[s] = 0.f;
     __syncthreads();
     float len = 0.f;
-    for (int i = tid; i < n; i += 256) {
+    for (int i = tid; i < n; i += LS_THREADS) {
         const float y = (float)yb[i];                 // rows s < U of a (U_lab, V) slab are contiguous
         if (y != 0.f) atomicAdd(&rowsum[i / V], y);
         len += y;
     }
     red[tid] = len; __syncthreads();
-    for (int o = 128; o > 0; o >>= 1) { if (tid < o) red[tid] += red[tid + o]; __syncthreads(); }
+    for (int o = LS_THREADS / 2; o > 0; o >>= 1) { if (tid < o) red[tid] += red[tid + o]; __syncthreads(); }
     len = red[0]; __syncthreads();
     float acc = 0.f;
     const float scale = 1.f / (B * len);
-    for (int i = tid; i < n; i += 256) {
+    for (int i = tid; i < n; i += LS_THREADS) {
         const int s = i / V, c = i - s * V;
         const float sm = ((1.f - eps) * (float)yb[i] + eps / V) * rowsum[s];
         acc += sm * logp[(long)s * sU + (long)b * sB + c];
         if (dlogp) dlogp[(long)s * dU + (long)b * dB + c] = -sm * scale;
     }
     red[tid] = acc; __syncthreads();
-    for (int o = 128; o > 0; o >>= 1) { if (tid < o) red[tid] += red[tid + o]; __syncthreads(); }
+    for (int o = LS_THREADS / 2; o > 0; o >>= 1) { if (tid < o) red[tid] += red[tid + o]; __syncthreads(); }
     if (tid == 0) part[b] = red[0] / len;
 }
 __global__ void ls_loss_finish_kernel(const float* __restrict__ part, int B, float* __restrict__ loss) {
@@ -369,7 +430,7 @@ __global__ void ls_loss_finish_kernel(const float* __restrict__ part, int B, flo
 }
 int ls_loss(const float* logp, long sU, long sB, const long long* labels, int U, int U_lab, int B, int V, float eps, float* part,
             float* loss, float* dlogp, long dU, long dB, hipStream_t stream) {
-    hipLaunchKernelGGL(ls_loss_kernel, dim3(B), dim3(256), sizeof(float) * U, stream, logp, sU, sB, labels, U, U_lab, B, V, eps, part, dlogp,
+    hipLaunchKernelGGL(ls_loss_kernel, dim3(B), dim3(LS_THREADS), sizeof(float) * U, stream, logp, sU, sB, labels, U, U_lab, B, V, eps, part, dlogp,
                        dU, dB);
     hipLaunchKernelGGL(ls_loss_finish_kernel, dim3(1), dim3(1), 0, stream, part, B, loss);
     LAS_LAUNCH_CHECK();

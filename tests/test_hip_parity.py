@@ -435,7 +435,7 @@ def test_direct_gradient_write_matches_autograd_accumulation(cfg_name, B):
             torch.stack(preds).square().mean().backward()
             red.check_views()
         flats.append(red.flat.detach().cpu().numpy().copy())
-        if direct:
+        if direct and B <= 32:      # (a sliced decode, B > 32, hands the Speller's gradients to autograd, which accumulates by definition)
             # a further backward WITHOUT zero(): the blocks were written in this zero-epoch, so LAS_FLAG_GRADS_ZEROED is not claimed, the
             # entry points fill their blocks themselves and the direct writes overwrite (they do not accumulate onto the stale values)
             assert not las_model._claim_prezeroed(list(las.parameters()))
