@@ -46,6 +46,26 @@ def test_graft_entry_build_runs():
     mod.build()
 
 
+def test_prezeroed_gradient_claim_follows_the_reducer_epochs():
+    """LAS_FLAG_GRADS_ZEROED may only be passed for a gradient block that FlatGradAllReducer.zero() cleared and nothing has written since
+    (las_model._claim_prezeroed): host logic, no GPU."""
+    from las_pytorch_amd import dp
+    from las_pytorch_amd.model import las_model
+    m = torch.nn.Linear(4, 3)
+    params = list(m.parameters())
+    red = dp.FlatGradAllReducer(m, direct=True)
+    assert not las_model._claim_prezeroed(params)          # never zeroed: the entry point must fill the block itself
+    red.zero()
+    assert las_model._claim_prezeroed(params)              # zeroed, untouched: claim (and mark written)
+    assert not las_model._claim_prezeroed(params)          # a second backward in the same zero-epoch: no claim
+    red.zero()
+    assert las_model._claim_prezeroed(params[:1])          # per parameter: the weight is claimed ...
+    assert not las_model._claim_prezeroed(params)          # ... so a call that includes it cannot claim again
+    red.zero()
+    other = torch.nn.Linear(2, 2)                          # parameters without a direct reducer never claim
+    assert not las_model._claim_prezeroed(list(other.parameters()))
+
+
 def test_bench_preflight_detects_shared_devices_and_small_gpus():
     """bench.py --gpus N pre-flight (no 8-GPU node was ever available to this build: the check itself is what can be tested)."""
     import importlib.util
