@@ -39,7 +39,8 @@ struct PblstmBwdLayout {
 };
 
 struct SpellerLayout {
-    size_t y_all, ctx_all, h_all, c_all, gates_all, q_all, w0p, ctxcat_all, hx, r0x, lgx, wperm, wyperm, bperm, yw, pctx, gx, total;
+    size_t y_all, ctx_all, h_all, c_all, gates_all, q_all, w0p, ctxcat_all, hx, r0x, lgx, wperm, wyperm, bperm, yw, pctx, gx, bqp, bpc, total;
+    bool big;                  // room for the one-launch decode of the Hs = 1024 shape (speller_big.hip)
     bool pre;                  // room for the persistent decode kernel's pre-multiplied context variant
     int Vp;                    // label width padded to a multiple of 16: every cell operand is aligned and tail-free
     SpellerLayout(const las_speller_desc* d, int U) {
@@ -66,6 +67,11 @@ struct SpellerLayout {
         bperm = o; if (pre) o += r4((size_t)4 * d->Hs);
         yw = o; if (pre) o += r4((size_t)U * B * 4 * d->Hs);       // ... and y_s W_y^T + b for every step (label half of the bottom-layer gates)
         pctx = o; if (pre) o += r4((size_t)B * d->Tp * 4 * d->Hs);
+        // Hs = 1024 one-launch decode: label half of the bottom-layer gates, query slices and partial contexts (hand-off slabs, adjacent)
+        big = speller_big_shape(d->B, d->Tp, d->Hs, d->D, d->M, d->V, d->L, d->multi_head, d->use_mlp);
+        if (big && !pre) { yw = o; o += r4((size_t)U * B * 4 * d->Hs); }
+        bqp = o; if (big) o += speller_big_qp_floats(d->B, U);
+        bpc = o; if (big) o += r4(speller_big_pc_floats(d->B, U));
         total = o;
     }
 };
@@ -373,6 +379,7 @@ int las_speller_decode_batch(const las_speller_desc* d, int teacher_forced, int 
 // Profiling aid (declared at the end of include/las_hip.h): per-phase shader-clock stamps of the persistent decode kernel.
 extern "C" void las_debug_persist_trace(unsigned long long* dev_buf) { speller_persist_set_trace(dev_buf); }
 extern "C" void las_debug_persist_bwd_trace(unsigned long long* dev_buf) { speller_persist_bwd_set_trace(dev_buf); }
+extern "C" void las_debug_big_trace(unsigned long long* dev_buf) { speller_big_set_trace(dev_buf); }
 #ifdef LAS_REC_TRACE
 extern "C" void las_debug_rec_trace(unsigned long long* dev_buf) { rec_set_trace(dev_buf); }
 #endif
@@ -481,6 +488,25 @@ int las_speller_fwd(const las_speller_desc* d, const float* feat, const float* k
         g.C = ctx_all + (size_t)B * D; g.ldc = (long)B * D; g.sC = D;
         g.M = U; g.N = D; g.K = Tp; g.batch = B; g.splitk = 1;
         LAS_TRY(gemm_f32(g, stream));
+    }
+    // the reference's shipped sizes (Speller 1024x2, B <= 16): all U steps in one launch with register-resident cell weights
+    if (!persist_ran && teacher_forced && lay.big && err_word && !(flags & LAS_FLAG_FORCE_GENERIC) && d->relu <= LAS_ACT_RELU &&
+        speller_big_eligible(B, Tp, Hs, D, d->M, V, L, d->multi_head, d->use_mlp)) {
+        GemmDesc g;      // label half of the bottom-layer gates for every step, off the decode chain: yw[s][b] = y_s[b] W_y^T
+        g.A = y_all; g.lda = Vp; g.a_kc = true;
+        g.B = w0p; g.ldb = Vp + Hs; g.b_kc = true;
+        g.C = reserve + lay.yw; g.ldc = 4 * Hs; g.M = U * B; g.N = 4 * Hs; g.K = Vp; g.splitk = 1;
+        LAS_TRY(gemm_f32(g, stream));
+        BigFwd p;
+        p.w0p = w0p; p.Vp = Vp;
+        p.w_hh0 = d->w_hh[0]; p.w_ih1 = d->w_ih[1]; p.w_hh1 = d->w_hh[1];
+        p.b_ih0 = d->b_ih[0]; p.b_hh0 = d->b_hh[0]; p.b_ih1 = d->b_ih[1]; p.b_hh1 = d->b_hh[1];
+        p.w_phi = d->w_phi; p.b_phi = d->b_phi; p.feat = feat; p.keys = keys; p.yw = reserve + lay.yw;
+        p.ctx_all = ctx_all; p.h_all = h_all; p.c_all = c_all; p.gates_all = gates_all; p.q_all = q_all; p.att = att;
+        p.qp = reserve + lay.bqp; p.pc = reserve + lay.bpc;
+        p.B = B; p.Tp = Tp; p.U = U; p.V = V; p.relu = d->relu; p.err = err_word;
+        const int rc = speller_big_fwd(p, stream);
+        if (rc != LAS_ERR_UNSUPPORTED) { LAS_TRY(rc); persist_ran = true; }
     }
     for (int s = 0; s < (persist_ran ? 0 : U); ++s) {
         for (int l = 0; l < L; ++l) {

@@ -178,6 +178,26 @@ bool speller_persist_pre_eligible(int B, int Tp, int Hs, int D, int M, int V, in
 int speller_persist_fwd(const PersistFwd& p, hipStream_t stream);
 void speller_persist_set_trace(unsigned long long* dev_buf);   // profiling aid, see tools/ubench_persist_trace.py
 
+// One-launch teacher-forced decode forward for Hs = D = 1024, M = 64, B <= 16 (speller_big.hip): the reference's shipped YAML sizes.
+struct BigFwd {
+    const float* w0p; int Vp;                       // [W_y | 0 | W_ctx] shadow of W_ih0, ld = Vp + Hs
+    const float* w_hh0; const float* w_ih1; const float* w_hh1;
+    const float* b_ih0; const float* b_hh0; const float* b_ih1; const float* b_hh1;
+    const float* w_phi; const float* b_phi;
+    const float* feat; const float* keys;
+    const float* yw;                                // (U*B, 4Hs): y_s W_y^T, rows in PyTorch gate order (no bias)
+    float* ctx_all; float* h_all; float* c_all; float* gates_all; float* q_all; float* att;
+    float* qp; float* pc;                           // hand-off slabs: speller_big_qp_floats / speller_big_pc_floats
+    int B, Tp, U, V, relu;
+    unsigned* err;
+};
+bool speller_big_shape(int B, int Tp, int Hs, int D, int M, int V, int L, int heads, int use_mlp);       // shape only (sizes the reserve)
+bool speller_big_eligible(int B, int Tp, int Hs, int D, int M, int V, int L, int heads, int use_mlp);    // shape + switch + residency
+size_t speller_big_qp_floats(int B, int U);
+size_t speller_big_pc_floats(int B, int U);
+int speller_big_fwd(const BigFwd& p, hipStream_t stream);
+void speller_big_set_trace(unsigned long long* dev_buf);
+
 // Persistent backward of the teacher-forced decode loop (speller_persist_bwd.hip): one launch for all U steps.
 struct PersistBwd {
     const float* w_ih0; const float* w_hh0; const float* w_ih1; const float* w_hh1; const float* w_phi;

@@ -33,6 +33,7 @@ enum Opt : int {
     OPT_GEMM_SKF_MIN_RUN,       // fewest k-iterations per workgroup run                              (-1 = automatic)
     OPT_SIDE_FILLS,             // sentinel fills of the decode kernels' hand-off slabs on a side stream (off: measured slower, see las_hip.h)
     OPT_TRUST_ZEROED_GRADS,     // honour LAS_FLAG_GRADS_ZEROED (skip the gradient-block memsets of the backward entry points); 0: always fill (A/B)
+    OPT_SPELLER_BIG,            // one-launch decode forward for Hs = 1024 (speller_big.hip)
     OPT_TIME_KERNELS,           // record HIP events around the persistent decode kernels (las_debug_kernel_ms reads them)
     OPT_COUNT
 };

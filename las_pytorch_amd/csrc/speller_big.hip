@@ -1,0 +1,468 @@
+// One-launch teacher-forced decode forward for the reference's SHIPPED model size (config/librispeech-config.yaml:16-34:
+// Listener 512x3 -> 1024 features, Speller 1024x2, attention MLP 64, batch 16) on gfx950.
+//
+// Replaces, for that size, the 3 launches per decode step of speller.hip (reference model/las_model.py:178-184, 205-236, 275-297),
+// each of which re-streams 34 MB of LSTM weights from the L2 / Infinity Cache.  Here the four fp32 matrices of the two cells
+// (67 MB) stay in the REGISTERS of 256 workgroups for all U steps:
+//   * workgroup w owns 4 hidden units (16 gate rows) of BOTH layers; its 8 waves split K, a lane holds 8 k-blocks of each of
+//     [W_ctx | W_hh0 | W_ih1 | W_hh1] as v_mfma_f32_16x16x4_f32 B operands (128 VGPRs), the 16 utterances are the M dimension;
+//   * the attention of utterance b is sliced over the 16 workgroups 16b..16b+15 (T'/16 frames each, features and keys in LDS):
+//     partial softmax (local max / sum / unnormalised partial context), combined per 64-column block by the same workgroups;
+//   * the query never needs its own hop: with the top cell's h the owner publishes its K-slice of phi (64 x 4 weights), and an
+//     attention workgroup adds the 256 slices of its utterance.
+// Per step the chain is four hand-offs (ctx -> bottom cell -> top cell -> query parts -> partial contexts -> ctx); every
+// hand-off is the data itself, written agent-scope into slabs pre-filled with the sentinel 0xFFFFFFFF (persist_common.h).
+// The recurrent halves W_hh . h of the next step are multiplied while the hand-offs are in flight.
+// Stash layout (h_all, c_all, gates_all, q_all, ctx_all, att) is the per-step kernels', so las_speller_bwd is unchanged.
+#include "las_common.h"
+#include "las_kernels.h"
+#include "options.h"
+#include "persist_common.h"
+
+namespace las {
+namespace {
+
+constexpr int BG_THREADS = 512, BG_NW = 8, BG_HS = 1024, BG_M = 64, BG_SL = 16, BG_WGS = 256, BG_NB = 16;
+constexpr int BG_PCLD = BG_HS + 4;       // one partial-context row: 1024 columns + (local max, local sum, 0, 0)
+constexpr int BG_KLD = BG_M + 4;         // LDS row stride of the keys
+constexpr int BG_MAXFR = 32;             // frames per attention slice (one lane each)
+constexpr float BG_LOG2E = 1.4426950408889634f;
+constexpr float BG_NEG = -3.0e38f;
+
+struct BigArgs {
+    const float* w0p; long ldw0; int Vp;                 // [W_y | 0 | W_ctx] shadow of W_ih0
+    const float* w_hh0; const float* w_ih1; const float* w_hh1;
+    const float* b_ih0; const float* b_hh0; const float* b_ih1; const float* b_hh1;
+    const float* w_phi; const float* b_phi;
+    const float* feat; const float* keys; const float* yw;
+    float* ctx_all; float* h_all; float* c_all; float* gates_all; float* q_all; float* att;
+    float* qp; float* pc;
+    int B, Tp, U, FR, relu;
+    unsigned* err;
+    u64* trace;
+};
+
+__device__ __forceinline__ void st2_agent(float* p, float x, float y) {
+    ps_f32x2 b;
+    b[0] = __uint_as_float(pub_bits(x)); b[1] = __uint_as_float(pub_bits(y));
+    asm volatile("global_store_dwordx2 %0, %1, off sc1\n\ts_nop 2" : : "v"(p), "v"(b) : "memory");
+}
+__device__ __forceinline__ unsigned ld1_agent(const float* p) {
+    return __hip_atomic_load(reinterpret_cast<const unsigned*>(p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+// eight agent-scope 16-byte loads of one lane, 64 bytes apart (8 k-blocks of one row), in flight together
+__device__ __forceinline__ void ld4x8_row(const float* p, f32x4 (&v)[8]) {
+    asm volatile(
+        "global_load_dwordx4 %0, %8, off sc1\n\t"
+        "global_load_dwordx4 %1, %8, off offset:64 sc1\n\t"
+        "global_load_dwordx4 %2, %8, off offset:128 sc1\n\t"
+        "global_load_dwordx4 %3, %8, off offset:192 sc1\n\t"
+        "global_load_dwordx4 %4, %8, off offset:256 sc1\n\t"
+        "global_load_dwordx4 %5, %8, off offset:320 sc1\n\t"
+        "global_load_dwordx4 %6, %8, off offset:384 sc1\n\t"
+        "global_load_dwordx4 %7, %8, off offset:448 sc1\n\t"
+        "s_waitcnt vmcnt(0)"
+        : "=&v"(v[0]), "=&v"(v[1]), "=&v"(v[2]), "=&v"(v[3]), "=&v"(v[4]), "=&v"(v[5]), "=&v"(v[6]), "=&v"(v[7])
+        : "v"(p)
+        : "memory");
+}
+// ... at an arbitrary byte stride (the 256 query slices of an utterance)
+__device__ __forceinline__ void ld4x8_strided(const float* p, long stride_floats, f32x4 (&v)[8]) {
+    const float* p1 = p + stride_floats; const float* p2 = p1 + stride_floats; const float* p3 = p2 + stride_floats;
+    const float* p4 = p3 + stride_floats; const float* p5 = p4 + stride_floats; const float* p6 = p5 + stride_floats;
+    const float* p7 = p6 + stride_floats;
+    asm volatile(
+        "global_load_dwordx4 %0, %8, off sc1\n\t"
+        "global_load_dwordx4 %1, %9, off sc1\n\t"
+        "global_load_dwordx4 %2, %10, off sc1\n\t"
+        "global_load_dwordx4 %3, %11, off sc1\n\t"
+        "global_load_dwordx4 %4, %12, off sc1\n\t"
+        "global_load_dwordx4 %5, %13, off sc1\n\t"
+        "global_load_dwordx4 %6, %14, off sc1\n\t"
+        "global_load_dwordx4 %7, %15, off sc1\n\t"
+        "s_waitcnt vmcnt(0)"
+        : "=&v"(v[0]), "=&v"(v[1]), "=&v"(v[2]), "=&v"(v[3]), "=&v"(v[4]), "=&v"(v[5]), "=&v"(v[6]), "=&v"(v[7])
+        : "v"(p), "v"(p1), "v"(p2), "v"(p3), "v"(p4), "v"(p5), "v"(p6), "v"(p7)
+        : "memory");
+}
+__device__ __forceinline__ bool any_sentinel8(const f32x4 (&v)[8]) {
+    bool bad = false;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) bad |= has_sentinel(v[i]);
+    return bad;
+}
+__device__ __forceinline__ f32x4 seg_mfma(const f32x4 (&ax)[8], const f32x4 (&w)[8], f32x4 acc) {
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(ax[i][e], w[i][e], acc, 0, 0, 0);
+    return acc;
+}
+__device__ __forceinline__ float quad_bcast(float v, int u) {      // value of lane (quad base + u), u a compile-time constant at the call sites
+    switch (u) {
+        case 0: return __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, v), 0x00, 0xF, 0xF, true));
+        case 1: return __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, v), 0x55, 0xF, 0xF, true));
+        case 2: return __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, v), 0xAA, 0xF, 0xF, true));
+        default: return __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, v), 0xFF, 0xF, 0xF, true));
+    }
+}
+__device__ __forceinline__ float gmax16(float v) {
+    v = fmaxf(v, dpp_f(v, 0)); v = fmaxf(v, dpp_f(v, 1)); v = fmaxf(v, dpp_f(v, 2)); v = fmaxf(v, dpp_f(v, 3));
+    return v;
+}
+
+// wave 0 watches one dword per lane until none of them is the sentinel (a HINT that the producers are through: every consumer
+// still checks the data it loads); returns true when the wait was given up
+__device__ __forceinline__ bool canary(const float* cp, bool active, unsigned* err, unsigned code) {
+    unsigned spins = 0;
+    for (;;) {
+        const unsigned v = ld1_agent(cp);
+        if (!__any(active && v == PS_SENT)) return false;
+        if (spin_expired(spins, err, code)) return true;
+    }
+}
+
+#define BG_STAMP(slot) do { if (a.trace && wg == 0 && tid == 0 && s < 64) a.trace[s * 16 + (slot)] = wall_clock64(); } while (0)
+
+__global__ __launch_bounds__(BG_THREADS, 1) void speller_big_fwd_kernel(const BigArgs a) {
+    extern __shared__ float lds[];
+    float* red = lds;                              // [8 waves][16 utterances][17]: K reduction of a gate tile
+    float* qred = red + BG_NW * 16 * 17;           // [32 producer groups][64]: query reduction
+    float* wphiS = qred + 32 * BG_M;               // [64][4]: this workgroup's K-slice of phi
+    float* keysS = wphiS + BG_M * 4;               // [FR][68]
+    float* featS = keysS + a.FR * BG_KLD;          // [FR][1024]
+    __shared__ int dead_s;
+
+    const int wg = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, r = lane & 15, kq = lane >> 4;
+    const int B = a.B, U = a.U, Tp = a.Tp, FR = a.FR;
+    const int j0 = wg * 4;
+    const size_t sH = (size_t)B * BG_HS;
+
+    // ---- resident weights: 8 k-blocks of each of the four matrices, rows = gate*Hs + unit of this workgroup's 4 units
+    f32x4 wc[8], wh0[8], wi1[8], wh1[8];
+    {
+        const long row = (long)(r >> 2) * BG_HS + j0 + (r & 3);
+        const int k0 = wave * 128 + kq * 4;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            wc[i] = ld4p(a.w0p + row * a.ldw0 + a.Vp + k0 + i * 16);
+            wh0[i] = ld4p(a.w_hh0 + row * BG_HS + k0 + i * 16);
+            wi1[i] = ld4p(a.w_ih1 + row * BG_HS + k0 + i * 16);
+            wh1[i] = ld4p(a.w_hh1 + row * BG_HS + k0 + i * 16);
+        }
+    }
+    // ---- cell lanes (wave 0): utterance cb, unit cu
+    const int cb = lane >> 2, cu = lane & 3;
+    const bool cell_on = wave == 0 && cb < B;
+    float bias0[4] = {0.f, 0.f, 0.f, 0.f}, bias1[4] = {0.f, 0.f, 0.f, 0.f};
+    if (wave == 0) {
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            bias0[g] = a.b_ih0[g * BG_HS + j0 + cu] + a.b_hh0[g * BG_HS + j0 + cu];
+            bias1[g] = a.b_ih1[g * BG_HS + j0 + cu] + a.b_hh1[g * BG_HS + j0 + cu];
+        }
+    }
+    float c0 = 0.f, c1 = 0.f;
+
+    // ---- attention slice of this workgroup
+    const int ab = wg >> 4, aj = wg & 15;
+    const bool att_on = ab < B;
+    const int t0 = aj * FR;
+    const int nfr = att_on ? max(0, min(FR, Tp - t0)) : 0;
+    for (int idx = tid; idx < nfr * 256; idx += BG_THREADS) {
+        const int f = idx >> 8, c4 = idx & 255;
+        *reinterpret_cast<f32x4*>(featS + f * BG_HS + c4 * 4) = ld4p(a.feat + ((size_t)ab * Tp + t0 + f) * BG_HS + c4 * 4);
+    }
+    for (int idx = tid; idx < nfr * 16; idx += BG_THREADS) {
+        const int f = idx >> 4, m4 = idx & 15;
+        *reinterpret_cast<f32x4*>(keysS + f * BG_KLD + m4 * 4) = ld4p(a.keys + ((size_t)ab * Tp + t0 + f) * BG_M + m4 * 4);
+    }
+    if (tid < 256) wphiS[tid] = a.w_phi[(size_t)(tid >> 2) * BG_HS + j0 + (tid & 3)];
+    const float bphi = a.b_phi[lane];
+    if (tid == 0) dead_s = 0;
+    __syncthreads();
+    bool dead = false;
+
+    f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
+    const int rowb = min(r, B - 1);                      // rows beyond the batch repeat the last utterance (never stored)
+    const unsigned aoff = (unsigned)(rowb * BG_HS + wave * 128 + kq * 4) * 4u;      // byte offset of this lane's first k-block in a (B,1024) slab
+
+    // checked load of this lane's 8 k-blocks of a hand-off slab
+    auto load_rows = [&](const float* slab, f32x4 (&ax)[8], unsigned code) {
+        const float* p = at_bytes(slab, opaque(aoff));
+        unsigned spins = 0;
+        for (;;) {
+            ld4x8_row(p, ax);
+            if (!__any(any_sentinel8(ax))) break;
+            if (dead || spin_expired(spins, a.err, code)) { dead = true; break; }
+        }
+    };
+
+    for (int s = 0; s < U; ++s) {
+        BG_STAMP(0);
+        // label half of the bottom-layer gates (one GEMM before the launch), off the chain
+        float ywv[4] = {0.f, 0.f, 0.f, 0.f};
+        if (cell_on) {
+#pragma unroll
+            for (int g = 0; g < 4; ++g) ywv[g] = a.yw[((size_t)s * B + cb) * (4 * BG_HS) + g * BG_HS + j0 + cu];
+        }
+        f32x4 ax[8];
+        // ================= [1] bottom cell: gates0 = yw + W_ctx ctx_{s-1} + W_hh0 h0_{s-1}
+        {
+            const float* ctxp = a.ctx_all + (size_t)s * sH;
+            if (wave == 0 && s > 0 && !dead) {
+                const int row = lane & 15;
+                if (canary(ctxp + (size_t)min(row, B - 1) * BG_HS + ((lane >> 4) * 4 + 3) * 64 + 63, row < B, a.err, 0xB1600001u)) dead_s = 1;
+            }
+            __syncthreads();
+            dead |= dead_s != 0;
+            load_rows(ctxp, ax, 0xB1600002u);
+            acc0 = seg_mfma(ax, wc, acc0);
+#pragma unroll
+            for (int rr = 0; rr < 4; ++rr) red[(wave * 16 + kq * 4 + rr) * 17 + r] = acc0[rr];
+            acc0 = f32x4{0.f, 0.f, 0.f, 0.f};
+            __syncthreads();
+            BG_STAMP(1);
+            if (wave == 0) {
+                float g4[4];
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    float sum = 0.f;
+#pragma unroll
+                    for (int w = 0; w < BG_NW; ++w) sum += red[(w * 16 + cb) * 17 + g * 4 + cu];
+                    g4[g] = sum + (ywv[g] + bias0[g]);
+                }
+                const float ig = sigmoidf_acc(g4[0]), fg = sigmoidf_acc(g4[1]), gg = tanhf_acc(g4[2]), og = sigmoidf_acc(g4[3]);
+                c0 = fg * c0 + ig * gg;
+                const float h = og * tanhf_acc(c0);
+                if (cell_on) {
+                    const size_t o = (size_t)s * sH + (size_t)cb * BG_HS + j0 + cu;       // layer 0
+                    st1_agent(a.h_all + o, h);
+                    a.c_all[o] = c0;
+                    float* go = a.gates_all + 4 * ((size_t)s * sH) + (size_t)cb * 4 * BG_HS + j0 + cu;
+                    go[0] = ig; go[BG_HS] = fg; go[2 * BG_HS] = gg; go[3 * BG_HS] = og;
+                }
+            }
+        }
+        BG_STAMP(2);
+        // ================= [2] top cell: gates1 = b + W_ih1 h0_s + W_hh1 h1_{s-1}
+        {
+            const float* h0p = a.h_all + (size_t)s * sH;
+            if (wave == 0 && !dead) {
+                if (canary(h0p + (size_t)(B - 1) * BG_HS + lane * 16 + 3, true, a.err, 0xB1600003u)) dead_s = 1;
+            }
+            __syncthreads();
+            dead |= dead_s != 0;
+            load_rows(h0p, ax, 0xB1600004u);
+            acc1 = seg_mfma(ax, wi1, acc1);
+#pragma unroll
+            for (int rr = 0; rr < 4; ++rr) red[(wave * 16 + kq * 4 + rr) * 17 + r] = acc1[rr];
+            acc1 = f32x4{0.f, 0.f, 0.f, 0.f};
+            __syncthreads();
+            BG_STAMP(3);
+            if (wave == 0) {
+                float g4[4];
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    float sum = 0.f;
+#pragma unroll
+                    for (int w = 0; w < BG_NW; ++w) sum += red[(w * 16 + cb) * 17 + g * 4 + cu];
+                    g4[g] = sum + bias1[g];
+                }
+                const float ig = sigmoidf_acc(g4[0]), fg = sigmoidf_acc(g4[1]), gg = tanhf_acc(g4[2]), og = sigmoidf_acc(g4[3]);
+                c1 = fg * c1 + ig * gg;
+                const float h = og * tanhf_acc(c1);
+                if (cell_on) {
+                    const size_t o = ((size_t)U + s) * sH + (size_t)cb * BG_HS + j0 + cu;  // layer 1
+                    st1_agent(a.h_all + o, h);
+                    a.c_all[o] = c1;
+                    float* go = a.gates_all + 4 * (((size_t)U + s) * sH) + (size_t)cb * 4 * BG_HS + j0 + cu;
+                    go[0] = ig; go[BG_HS] = fg; go[2 * BG_HS] = gg; go[3 * BG_HS] = og;
+                }
+                // this workgroup's K-slice of the query of every utterance: qp[s][b][wg][m] = sum_u W_phi[m][j0+u] h1[b][j0+u]
+                const float h_0 = quad_bcast(h, 0), h_1 = quad_bcast(h, 1), h_2 = quad_bcast(h, 2), h_3 = quad_bcast(h, 3);
+                float* qo = a.qp + (((size_t)s * B + min(cb, B - 1)) * BG_WGS + wg) * BG_M + cu * 16;
+#pragma unroll
+                for (int i4 = 0; i4 < 4; ++i4) {
+                    f32x4 o4;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const f32x4 w4 = *reinterpret_cast<const f32x4*>(wphiS + (cu * 16 + i4 * 4 + e) * 4);
+                        o4[e] = w4[0] * h_0 + w4[1] * h_1 + w4[2] * h_2 + w4[3] * h_3;
+                    }
+                    if (cell_on) st4_agent(qo + i4 * 4, o4);
+                }
+            }
+            // recurrent half of the NEXT bottom cell while h1 / the query parts travel (the A operand is still in registers)
+            acc0 = seg_mfma(ax, wh0, acc0);
+        }
+        BG_STAMP(4);
+        // ================= [3] attention slice: query, energies, local softmax, partial context
+        float pf = 0.f;      // exp(e_f - local max) of frame f = lane & 31 (every wave holds the whole slice)
+        {
+            const float* qps = a.qp + ((size_t)s * B + min(ab, B - 1)) * BG_WGS * BG_M;
+            if (wave == 0 && att_on && !dead) {
+                if (canary(qps + (size_t)(lane * 4 + 3) * BG_M + 63, true, a.err, 0xB1600005u)) dead_s = 1;
+            }
+            __syncthreads();
+            dead |= dead_s != 0;
+            if (att_on) {
+                const int m4 = tid & 15, pg = tid >> 4;
+                const float* p = qps + (size_t)pg * BG_M + m4 * 4;
+                unsigned spins = 0;
+                for (;;) {
+                    ld4x8_strided(p, 32 * BG_M, ax);
+                    if (!__any(any_sentinel8(ax))) break;
+                    if (dead || spin_expired(spins, a.err, 0xB1600006u)) { dead = true; break; }
+                }
+                f32x4 sum = ax[0];
+#pragma unroll
+                for (int i = 1; i < 8; ++i) sum += ax[i];
+                *reinterpret_cast<f32x4*>(qred + pg * BG_M + m4 * 4) = sum;
+            }
+            __syncthreads();
+            BG_STAMP(5);
+            if (att_on) {
+                float q = bphi;
+#pragma unroll
+                for (int g = 0; g < 32; ++g) q += qred[g * BG_M + lane];
+                q = act_apply(q, a.relu);
+                if (aj == 0 && wave == 0) a.q_all[((size_t)s * B + ab) * BG_M + lane] = q;
+                const int f = lane & 31;
+                const float* kr = keysS + min(f, max(nfr - 1, 0)) * BG_KLD;
+                float e = 0.f;
+#pragma unroll
+                for (int m = 0; m < BG_M; ++m) e = fmaf(lane_f(q, m), kr[m], e);
+                e = f < nfr ? e : BG_NEG;
+                const float mj = wmax(e);
+                pf = f < nfr ? __builtin_amdgcn_exp2f((e - mj) * BG_LOG2E) : 0.f;
+                const float lj = wsum(lane < 32 ? pf : 0.f);
+                // unnormalised partial context of this wave's 128 columns
+                float c_lo = 0.f, c_hi = 0.f;
+                const float* fc = featS + wave * 128 + lane * 2;
+#pragma unroll
+                for (int ff = 0; ff < BG_MAXFR; ++ff) {
+                    if (ff < nfr) {
+                        const ps_f32x2 x = *reinterpret_cast<const ps_f32x2*>(fc + ff * BG_HS);
+                        const float w = lane_f(pf, ff);
+                        c_lo = fmaf(w, x[0], c_lo); c_hi = fmaf(w, x[1], c_hi);
+                    }
+                }
+                float* pcr = a.pc + (((size_t)s * B + ab) * BG_SL + aj) * BG_PCLD;
+                st2_agent(pcr + wave * 128 + lane * 2, c_lo, c_hi);
+                if (wave == 0 && lane == 0) st4_agent(pcr + BG_HS, f32x4{mj, lj, 0.f, 0.f});
+            }
+        }
+        BG_STAMP(6);
+        // ================= [4] combine the 16 partial contexts of this utterance for columns [64 aj, 64 aj + 64) (wave 0)
+        if (wave == 0 && att_on) {
+            const float* pcb = a.pc + ((size_t)s * B + ab) * BG_SL * BG_PCLD;
+            unsigned v[16], mi = 0, li = 0;
+            unsigned spins = 0;
+            for (;;) {
+#pragma unroll
+                for (int i = 0; i < 16; ++i) v[i] = ld1_agent(pcb + (size_t)i * BG_PCLD + aj * 64 + lane);
+                mi = ld1_agent(pcb + (size_t)(lane & 15) * BG_PCLD + BG_HS);
+                li = ld1_agent(pcb + (size_t)(lane & 15) * BG_PCLD + BG_HS + 1);
+                bool bad = mi == PS_SENT || li == PS_SENT;
+#pragma unroll
+                for (int i = 0; i < 16; ++i) bad |= v[i] == PS_SENT;
+                if (!__any(bad)) break;
+                if (dead || spin_expired(spins, a.err, 0xB1600007u)) { dead = true; dead_s = 1; break; }
+            }
+            const float m_i = __uint_as_float(mi), l_i = __uint_as_float(li);
+            const float mx = gmax16(m_i);
+            const float w_i = __builtin_amdgcn_exp2f((m_i - mx) * BG_LOG2E);
+            const float tot = gsum<16>(w_i * l_i);
+            const float sc = w_i / tot;                                   // lanes 0..15: scale of slice i = lane
+            float ctx = 0.f;
+#pragma unroll
+            for (int i = 0; i < 16; ++i) ctx = fmaf(lane_f(sc, i), __uint_as_float(v[i]), ctx);
+            st1_agent(a.ctx_all + ((size_t)(s + 1) * B + ab) * BG_HS + aj * 64 + lane, ctx);
+            // normalised attention weights of this slice's frames
+            const float scj = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, sc), aj));
+            if (lane < nfr) a.att[((size_t)s * B + ab) * Tp + t0 + lane] = pf * scj;
+        }
+        BG_STAMP(7);
+        // ================= [4b] recurrent half of the next top cell
+        if (s + 1 < U) {
+            load_rows(a.h_all + ((size_t)U + s) * sH, ax, 0xB1600008u);
+            acc1 = seg_mfma(ax, wh1, acc1);
+        }
+        BG_STAMP(8);
+    }
+}
+
+size_t big_fwd_smem(int FR) {
+    return sizeof(float) * ((size_t)BG_NW * 16 * 17 + 32 * BG_M + BG_M * 4 + (size_t)FR * BG_KLD + (size_t)FR * BG_HS);
+}
+
+u64* g_big_trace = nullptr;
+
+}  // namespace
+
+void speller_big_set_trace(unsigned long long* dev_buf) { g_big_trace = dev_buf; }
+
+int speller_big_frames(int Tp) { return (Tp + BG_SL - 1) / BG_SL; }
+
+bool speller_big_shape(int B, int Tp, int Hs, int D, int M, int V, int L, int heads, int use_mlp) {
+    if (L != 2 || heads != 1 || !use_mlp || M != BG_M || Hs != BG_HS || D != BG_HS) return false;
+    if (B < 1 || B > BG_NB || Tp < 1 || speller_big_frames(Tp) > BG_MAXFR) return false;
+    return true;
+}
+
+size_t speller_big_qp_floats(int B, int U) { return (size_t)U * B * BG_WGS * BG_M; }
+size_t speller_big_pc_floats(int B, int U) { return (size_t)U * B * BG_SL * BG_PCLD; }
+
+static bool big_fits(int FR) {
+    const size_t smem = big_fwd_smem(FR);
+    if (smem > 160 * 1024) return false;
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&speller_big_fwd_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem) != hipSuccess)
+        return false;
+    return persistent_launch_fits(speller_big_fwd_kernel, BG_THREADS, smem, BG_WGS);
+}
+
+bool speller_big_eligible(int B, int Tp, int Hs, int D, int M, int V, int L, int heads, int use_mlp) {
+    if (opt_get(OPT_SPELLER_BIG) == 0 || !speller_big_shape(B, Tp, Hs, D, M, V, L, heads, use_mlp)) return false;
+    return big_fits(speller_big_frames(Tp));
+}
+
+int speller_big_fwd(const BigFwd& p, hipStream_t stream) {
+    LAS_REQUIRE(speller_big_shape(p.B, p.Tp, BG_HS, BG_HS, BG_M, p.V, 2, 1, 1), "one-launch decode (Hs = 1024) shape");
+    LAS_REQUIRE(p.err != nullptr, "the persistent speller needs the device error word");
+    BigArgs a;
+    a.w0p = p.w0p; a.ldw0 = p.Vp + BG_HS; a.Vp = p.Vp;
+    a.w_hh0 = p.w_hh0; a.w_ih1 = p.w_ih1; a.w_hh1 = p.w_hh1;
+    a.b_ih0 = p.b_ih0; a.b_hh0 = p.b_hh0; a.b_ih1 = p.b_ih1; a.b_hh1 = p.b_hh1;
+    a.w_phi = p.w_phi; a.b_phi = p.b_phi;
+    a.feat = p.feat; a.keys = p.keys; a.yw = p.yw;
+    a.ctx_all = p.ctx_all; a.h_all = p.h_all; a.c_all = p.c_all; a.gates_all = p.gates_all; a.q_all = p.q_all; a.att = p.att;
+    a.qp = p.qp; a.pc = p.pc;
+    a.B = p.B; a.Tp = p.Tp; a.U = p.U; a.FR = speller_big_frames(p.Tp); a.relu = p.relu; a.err = p.err;
+    a.trace = g_big_trace;
+    if (!big_fits(a.FR))
+        return fail(LAS_ERR_UNSUPPORTED, "one-launch decode (Hs = 1024): %s%ld workgroups cannot all be resident", "", (long)BG_WGS);
+    // sentinel-fill what the phases hand over: the contexts of steps 1..U, every h of both layers (adjacent in the reserve), the
+    // query slices and the partial contexts (adjacent)
+    const size_t sH = (size_t)p.B * BG_HS;
+    if (p.h_all == p.ctx_all + (size_t)(p.U + 1) * sH) {
+        LAS_HIP_CHECK(hipMemsetAsync(p.ctx_all + sH, 0xFF, sizeof(float) * (size_t)3 * p.U * sH, stream));
+    } else {
+        LAS_HIP_CHECK(hipMemsetAsync(p.ctx_all + sH, 0xFF, sizeof(float) * (size_t)p.U * sH, stream));
+        LAS_HIP_CHECK(hipMemsetAsync(p.h_all, 0xFF, sizeof(float) * (size_t)2 * p.U * sH, stream));
+    }
+    if (p.pc == p.qp + speller_big_qp_floats(p.B, p.U)) {
+        LAS_HIP_CHECK(hipMemsetAsync(p.qp, 0xFF, sizeof(float) * (speller_big_qp_floats(p.B, p.U) + speller_big_pc_floats(p.B, p.U)), stream));
+    } else {
+        LAS_HIP_CHECK(hipMemsetAsync(p.qp, 0xFF, sizeof(float) * speller_big_qp_floats(p.B, p.U), stream));
+        LAS_HIP_CHECK(hipMemsetAsync(p.pc, 0xFF, sizeof(float) * speller_big_pc_floats(p.B, p.U), stream));
+    }
+    {
+        KernelTimer timer(TIMED_DECODE_FWD, stream);
+        hipLaunchKernelGGL(speller_big_fwd_kernel, dim3(BG_WGS), dim3(BG_THREADS), big_fwd_smem(a.FR), stream, a);
+    }
+    LAS_LAUNCH_CHECK();
+    return LAS_OK;
+}
+
+}  // namespace las

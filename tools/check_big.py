@@ -1,0 +1,98 @@
+"""The one-launch decode forward of the reference's YAML sizes (speller_big.hip: Speller 1024x2, B <= 16) against the per-step
+launch chain it replaces: outputs, every gradient (the per-step backward consumes the stash the kernel wrote), and the time
+of a teacher-forced forward on both paths.   python tools/check_big.py [B Tp U]   (on the GPU box)"""
+import ctypes
+import sys
+import time
+
+import numpy as np
+import torch
+
+sys.path.insert(0, ".")
+from las_pytorch_amd import Speller, _cabi, synth  # noqa: E402
+
+
+def run(B, Tp, U, scale=None, trace_on=True):
+    c = synth.CONFIGS["Y"]
+    torch.manual_seed(5)
+    sp = Speller(vocab_size=c["V"], hidden_size=c["Hs"], rnn_unit="LSTM", num_layers=c["Ls"], max_label_len=U,
+                 use_mlp_in_attention=True, mlp_dim_in_attention=c["M"], mlp_activate_in_attention="relu",
+                 listener_hidden_size=c["H"], multi_head=1, decode_mode=1).cuda()
+    if scale is not None:
+        with torch.no_grad():
+            for p in sp.parameters():
+                p.uniform_(-scale, scale)
+    feat0 = torch.randn(B, Tp, 2 * c["H"], device="cuda") * 0.5
+    idx, lens = synth.make_labels(B, U, c["V"], seed=11, ragged=True)
+    lab = torch.from_numpy(synth.onehot_labels(idx, lens, c["V"])).cuda()
+    w = torch.randn(U, B, c["V"], device="cuda")
+    L = _cabi.lib()
+    L.las_debug_big_trace.argtypes = [ctypes.c_void_p]
+    L.las_debug_big_trace.restype = None
+    trace = torch.zeros(64 * 16, dtype=torch.int64, device="cuda")
+    res = []
+    for force in (False, True):
+        sp.force_generic = force
+        L.las_debug_big_trace(trace.data_ptr() if (trace_on and not force) else None)
+        try:
+            sp.zero_grad(set_to_none=True)
+            feat = feat0.clone().requires_grad_(True)
+            preds, att = sp(feat, ground_truth=lab, teacher_force_rate=1.0)
+            logp = torch.stack(preds)
+            (logp * w).sum().backward()
+            res.append(dict(logp=logp.detach().cpu().numpy(), att=torch.stack([a[0] for a in att]).detach().cpu().numpy(),
+                            dfeat=feat.grad.cpu().numpy(), **{"d" + n: p.grad.cpu().numpy() for n, p in sp.named_parameters()}))
+        finally:
+            sp.force_generic = False
+            L.las_debug_big_trace(None)
+    torch.cuda.synchronize()
+    err = int(_cabi.err_word(torch.device("cuda", 0))[0].item())
+    ran = int(trace.abs().sum().item()) != 0
+    worst = 0.0
+    for k in res[0]:
+        a, b = res[0][k], res[1][k]
+        scale_k = float(np.abs(b).max()) + 1e-30
+        d = float(np.abs(a - b).max())
+        tol = 1e-3 * scale_k + 1e-5 * max(1.0, scale_k)
+        worst = max(worst, d / tol)
+        flag = "" if d <= tol else "   <-- FAIL"
+        print(f"  {k:28s} max|diff| {d:.3e}  scale {scale_k:.3e}{flag}")
+    print(f"B={B} Tp={Tp} U={U}: kernel ran: {ran}, device error word {err:#x}, worst diff/tol {worst:.3f}")
+    # forward time on both paths (no autograd)
+    out = {}
+    with torch.no_grad():
+        for force in (False, True):
+            sp.force_generic = force
+            for _ in range(3):
+                sp(feat0, ground_truth=lab, teacher_force_rate=1.0)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            n = 10
+            for _ in range(n):
+                sp(feat0, ground_truth=lab, teacher_force_rate=1.0)
+            torch.cuda.synchronize()
+            out[force] = (time.perf_counter() - t0) / n * 1e3
+    sp.force_generic = False
+    print(f"  forward: one launch {out[False]:.3f} ms, per-step launches {out[True]:.3f} ms  ({out[False] * 1e3 / U:.2f} / {out[True] * 1e3 / U:.2f} us per decode step)")
+    if ran and trace_on:
+        t = trace.cpu().numpy().reshape(64, 16)
+        n = min(U, 64)
+        if n > 4:
+            d = np.diff(t[2:n, :9].astype(np.float64), axis=1).mean(0) / 100.0     # 100 MHz shader clock counter -> us
+            step = np.diff(t[2:n, 0].astype(np.float64)).mean() / 100.0
+            names = ["ctx wait+mfma", "cell0", "h0 wait+mfma", "cell1+qpart+Whh0", "q wait+sum", "energies+pc", "combine", "Whh1"]
+            print("  trace (workgroup 0, us): " + ", ".join(f"{nm} {v:.2f}" for nm, v in zip(names, d)) + f"; step {step:.2f}")
+    return worst, err, ran
+
+
+if __name__ == "__main__":
+    if len(sys.argv) >= 4:
+        cases = [tuple(int(v) for v in sys.argv[1:4])]
+    else:
+        cases = [(16, 100, 16), (3, 8, 6), (16, 200, 8), (5, 37, 7), (16, 100, 128)]
+    bad = 0
+    for B, Tp, U in cases:
+        worst, err, ran = run(B, Tp, U)
+        bad += (worst > 1.0) or err != 0 or not ran
+    print("RESULT", "FAIL" if bad else "OK")
+    sys.exit(1 if bad else 0)
