@@ -66,11 +66,46 @@ __device__ __forceinline__ void ld4x8_row(const float* p, f32x4 (&v)[8]) {
         : "v"(p)
         : "memory");
 }
+// the same through the L2 (no sc1): after the canaries of ALL producers are in, the 32 workgroups of an XCD share one fetch of the slab
+// instead of 32 trips across the fabric (16 MB per hand-off chip-wide).  A line that was fetched too early still shows the sentinel
+// and sends its readers to the agent-scope form above.
+__device__ __forceinline__ void ld4x8_row_l2(const float* p, f32x4 (&v)[8]) {
+    asm volatile(
+        "global_load_dwordx4 %0, %8, off\n\t"
+        "global_load_dwordx4 %1, %8, off offset:64\n\t"
+        "global_load_dwordx4 %2, %8, off offset:128\n\t"
+        "global_load_dwordx4 %3, %8, off offset:192\n\t"
+        "global_load_dwordx4 %4, %8, off offset:256\n\t"
+        "global_load_dwordx4 %5, %8, off offset:320\n\t"
+        "global_load_dwordx4 %6, %8, off offset:384\n\t"
+        "global_load_dwordx4 %7, %8, off offset:448\n\t"
+        "s_waitcnt vmcnt(0)"
+        : "=&v"(v[0]), "=&v"(v[1]), "=&v"(v[2]), "=&v"(v[3]), "=&v"(v[4]), "=&v"(v[5]), "=&v"(v[6]), "=&v"(v[7])
+        : "v"(p)
+        : "memory");
+}
 // ... at an arbitrary byte stride (the 256 query slices of an utterance)
+template <bool L2>
 __device__ __forceinline__ void ld4x8_strided(const float* p, long stride_floats, f32x4 (&v)[8]) {
     const float* p1 = p + stride_floats; const float* p2 = p1 + stride_floats; const float* p3 = p2 + stride_floats;
     const float* p4 = p3 + stride_floats; const float* p5 = p4 + stride_floats; const float* p6 = p5 + stride_floats;
     const float* p7 = p6 + stride_floats;
+    if (L2) {
+        asm volatile(
+            "global_load_dwordx4 %0, %8, off\n\t"
+            "global_load_dwordx4 %1, %9, off\n\t"
+            "global_load_dwordx4 %2, %10, off\n\t"
+            "global_load_dwordx4 %3, %11, off\n\t"
+            "global_load_dwordx4 %4, %12, off\n\t"
+            "global_load_dwordx4 %5, %13, off\n\t"
+            "global_load_dwordx4 %6, %14, off\n\t"
+            "global_load_dwordx4 %7, %15, off\n\t"
+            "s_waitcnt vmcnt(0)"
+            : "=&v"(v[0]), "=&v"(v[1]), "=&v"(v[2]), "=&v"(v[3]), "=&v"(v[4]), "=&v"(v[5]), "=&v"(v[6]), "=&v"(v[7])
+            : "v"(p), "v"(p1), "v"(p2), "v"(p3), "v"(p4), "v"(p5), "v"(p6), "v"(p7)
+            : "memory");
+        return;
+    }
     asm volatile(
         "global_load_dwordx4 %0, %8, off sc1\n\t"
         "global_load_dwordx4 %1, %9, off sc1\n\t"
@@ -121,15 +156,26 @@ __device__ __forceinline__ bool canary(const float* cp, bool active, unsigned* e
         if (spin_expired(spins, err, code)) return true;
     }
 }
+// ... four dwords per lane, `step` floats apart: one wave covers the canaries of all 256 producers of a slab
+__device__ __forceinline__ bool canary4(const float* cp, int step, bool active, unsigned* err, unsigned code) {
+    unsigned spins = 0;
+    for (;;) {
+        const unsigned v0 = ld1_agent(cp), v1 = ld1_agent(cp + step), v2 = ld1_agent(cp + 2 * step), v3 = ld1_agent(cp + 3 * step);
+        if (!__any(active && (v0 == PS_SENT || v1 == PS_SENT || v2 == PS_SENT || v3 == PS_SENT))) return false;
+        if (spin_expired(spins, err, code)) return true;
+    }
+}
 
 #define BG_STAMP(slot) do { if (a.trace && wg == 0 && tid == 0 && s < 64) a.trace[s * 16 + (slot)] = wall_clock64(); } while (0)
 
 __global__ __launch_bounds__(BG_THREADS, 1) void speller_big_fwd_kernel(const BigArgs a) {
     extern __shared__ float lds[];
     float* red = lds;                              // [8 waves][16 utterances][17]: K reduction of a gate tile
-    float* qred = red + BG_NW * 16 * 17;           // [32 producer groups][64]: query reduction
-    float* wphiS = qred + 32 * BG_M;               // [64][4]: this workgroup's K-slice of phi
-    float* keysS = wphiS + BG_M * 4;               // [FR][68]
+    float* qred = red + BG_NW * 16 * 17;           // [8 waves][64]: query reduction
+    float* wphiS = qred + BG_NW * BG_M;               // [64][4]: this workgroup's K-slice of phi
+    float* qsW = wphiS + BG_M * 4;                 // [8 waves][64]: the query, one copy per wave
+    float* eS = qsW + BG_NW * BG_M;                // [32]: energies of the slice's frames
+    float* keysS = eS + 32;                        // [FR][68]
     float* featS = keysS + a.FR * BG_KLD;          // [FR][1024]
     __shared__ int dead_s;
 
@@ -165,7 +211,8 @@ __global__ __launch_bounds__(BG_THREADS, 1) void speller_big_fwd_kernel(const Bi
     float c0 = 0.f, c1 = 0.f;
 
     // ---- attention slice of this workgroup
-    const int ab = wg >> 4, aj = wg & 15;
+    // the 16 slices of an utterance sit on ONE XCD (workgroup w runs on XCD w % 8): its 64 KB of query parts cross the fabric once
+    const int ab = 2 * (wg & 7) + ((wg >> 3) & 1), aj = wg >> 4;
     const bool att_on = ab < B;
     const int t0 = aj * FR;
     const int nfr = att_on ? max(0, min(FR, Tp - t0)) : 0;
@@ -190,6 +237,9 @@ __global__ __launch_bounds__(BG_THREADS, 1) void speller_big_fwd_kernel(const Bi
     // checked load of this lane's 8 k-blocks of a hand-off slab
     auto load_rows = [&](const float* slab, f32x4 (&ax)[8], unsigned code) {
         const float* p = at_bytes(slab, opaque(aoff));
+        ld4x8_row_l2(p, ax);
+        if (!__any(any_sentinel8(ax))) return;
+        if (a.trace && lane == 0) atomicAdd(a.trace + 14, 1ull);      // diagnostics: a line was fetched into the L2 before its producer was through
         unsigned spins = 0;
         for (;;) {
             ld4x8_row(p, ax);
@@ -200,6 +250,7 @@ __global__ __launch_bounds__(BG_THREADS, 1) void speller_big_fwd_kernel(const Bi
 
     for (int s = 0; s < U; ++s) {
         BG_STAMP(0);
+        if (a.trace && wg == 0 && tid == 0 && s < 64) a.trace[s * 16 + 13] = __builtin_readcyclecounter();      // shader clock (the stamps are 100 MHz)
         // label half of the bottom-layer gates (one GEMM before the launch), off the chain
         float ywv[4] = {0.f, 0.f, 0.f, 0.f};
         if (cell_on) {
@@ -212,7 +263,7 @@ __global__ __launch_bounds__(BG_THREADS, 1) void speller_big_fwd_kernel(const Bi
             const float* ctxp = a.ctx_all + (size_t)s * sH;
             if (wave == 0 && s > 0 && !dead) {
                 const int row = lane & 15;
-                if (canary(ctxp + (size_t)min(row, B - 1) * BG_HS + ((lane >> 4) * 4 + 3) * 64 + 63, row < B, a.err, 0xB1600001u)) dead_s = 1;
+                if (canary4(ctxp + (size_t)min(row, B - 1) * BG_HS + (lane >> 4) * 256 + 63, 64, row < B, a.err, 0xB1600001u)) dead_s = 1;
             }
             __syncthreads();
             dead |= dead_s != 0;
@@ -249,12 +300,16 @@ __global__ __launch_bounds__(BG_THREADS, 1) void speller_big_fwd_kernel(const Bi
         {
             const float* h0p = a.h_all + (size_t)s * sH;
             if (wave == 0 && !dead) {
-                if (canary(h0p + (size_t)(B - 1) * BG_HS + lane * 16 + 3, true, a.err, 0xB1600003u)) dead_s = 1;
+                if (canary4(h0p + (size_t)(B - 1) * BG_HS + lane * 16 + 3, 4, true, a.err, 0xB1600003u)) dead_s = 1;
             }
+            BG_STAMP(9);
             __syncthreads();
+            BG_STAMP(10);
             dead |= dead_s != 0;
             load_rows(h0p, ax, 0xB1600004u);
+            BG_STAMP(11);
             acc1 = seg_mfma(ax, wi1, acc1);
+            BG_STAMP(12);
 #pragma unroll
             for (int rr = 0; rr < 4; ++rr) red[(wave * 16 + kq * 4 + rr) * 17 + r] = acc1[rr];
             acc1 = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -302,51 +357,68 @@ __global__ __launch_bounds__(BG_THREADS, 1) void speller_big_fwd_kernel(const Bi
         {
             const float* qps = a.qp + ((size_t)s * B + min(ab, B - 1)) * BG_WGS * BG_M;
             if (wave == 0 && att_on && !dead) {
-                if (canary(qps + (size_t)(lane * 4 + 3) * BG_M + 63, true, a.err, 0xB1600005u)) dead_s = 1;
+                if (canary4(qps + (size_t)(lane * 4) * BG_M + 63, BG_M, true, a.err, 0xB1600005u)) dead_s = 1;
             }
             __syncthreads();
             dead |= dead_s != 0;
             if (att_on) {
                 const int m4 = tid & 15, pg = tid >> 4;
                 const float* p = qps + (size_t)pg * BG_M + m4 * 4;
-                unsigned spins = 0;
-                for (;;) {
-                    ld4x8_strided(p, 32 * BG_M, ax);
-                    if (!__any(any_sentinel8(ax))) break;
-                    if (dead || spin_expired(spins, a.err, 0xB1600006u)) { dead = true; break; }
+                ld4x8_strided<true>(p, 32 * BG_M, ax);
+                if (__any(any_sentinel8(ax))) {
+                    if (a.trace && lane == 0) atomicAdd(a.trace + 15, 1ull);
+                    unsigned spins = 0;
+                    for (;;) {
+                        ld4x8_strided<false>(p, 32 * BG_M, ax);
+                        if (!__any(any_sentinel8(ax))) break;
+                        if (dead || spin_expired(spins, a.err, 0xB1600006u)) { dead = true; break; }
+                    }
                 }
                 f32x4 sum = ax[0];
 #pragma unroll
                 for (int i = 1; i < 8; ++i) sum += ax[i];
-                *reinterpret_cast<f32x4*>(qred + pg * BG_M + m4 * 4) = sum;
+                // the wave's four producer groups (its four rows of 16 lanes) added in registers, one LDS row per wave
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const unsigned x = __float_as_uint(sum[e]);
+                    auto r16 = __builtin_amdgcn_permlane16_swap(x, x, false, false);
+                    const unsigned y = __float_as_uint(__uint_as_float(r16[0]) + __uint_as_float(r16[1]));
+                    auto r32 = __builtin_amdgcn_permlane32_swap(y, y, false, false);
+                    sum[e] = __uint_as_float(r32[0]) + __uint_as_float(r32[1]);
+                }
+                if (lane < 16) *reinterpret_cast<f32x4*>(qred + wave * BG_M + m4 * 4) = sum;
             }
             __syncthreads();
             BG_STAMP(5);
+            float e = BG_NEG;
             if (att_on) {
                 float q = bphi;
 #pragma unroll
-                for (int g = 0; g < 32; ++g) q += qred[g * BG_M + lane];
+                for (int w = 0; w < BG_NW; ++w) q += qred[w * BG_M + lane];
                 q = act_apply(q, a.relu);
                 if (aj == 0 && wave == 0) a.q_all[((size_t)s * B + ab) * BG_M + lane] = q;
-                const int f = lane & 31;
+                float* qw = qsW + wave * BG_M;
+                qw[lane] = q;                                           // wave-private: no barrier, the LDS queue is in order
+                // energies of frames 4 wave .. 4 wave + 3: 16 lanes per frame, 4 attention dimensions per lane
+                const int f = 4 * wave + (lane >> 4), part = lane & 15;
                 const float* kr = keysS + min(f, max(nfr - 1, 0)) * BG_KLD;
-                float e = 0.f;
-#pragma unroll
-                for (int m = 0; m < BG_M; ++m) e = fmaf(lane_f(q, m), kr[m], e);
-                e = f < nfr ? e : BG_NEG;
+                float ef = dot4p(*reinterpret_cast<const f32x4*>(qw + part * 4), *reinterpret_cast<const f32x4*>(kr + part * 4), 0.f);
+                ef = gsum<16>(ef);
+                if (part == 0) eS[f] = f < nfr ? ef : BG_NEG;
+            }
+            __syncthreads();
+            if (att_on) {
+                e = eS[lane & 31];
                 const float mj = wmax(e);
-                pf = f < nfr ? __builtin_amdgcn_exp2f((e - mj) * BG_LOG2E) : 0.f;
+                pf = (lane & 31) < nfr ? __builtin_amdgcn_exp2f((e - mj) * BG_LOG2E) : 0.f;
                 const float lj = wsum(lane < 32 ? pf : 0.f);
                 // unnormalised partial context of this wave's 128 columns
                 float c_lo = 0.f, c_hi = 0.f;
                 const float* fc = featS + wave * 128 + lane * 2;
-#pragma unroll
-                for (int ff = 0; ff < BG_MAXFR; ++ff) {
-                    if (ff < nfr) {
-                        const ps_f32x2 x = *reinterpret_cast<const ps_f32x2*>(fc + ff * BG_HS);
-                        const float w = lane_f(pf, ff);
-                        c_lo = fmaf(w, x[0], c_lo); c_hi = fmaf(w, x[1], c_hi);
-                    }
+                for (int ff = 0; ff < nfr; ++ff) {
+                    const ps_f32x2 x = *reinterpret_cast<const ps_f32x2*>(fc + ff * BG_HS);
+                    const float w = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, pf), ff));
+                    c_lo = fmaf(w, x[0], c_lo); c_hi = fmaf(w, x[1], c_hi);
                 }
                 float* pcr = a.pc + (((size_t)s * B + ab) * BG_SL + aj) * BG_PCLD;
                 st2_agent(pcr + wave * 128 + lane * 2, c_lo, c_hi);
@@ -394,7 +466,7 @@ __global__ __launch_bounds__(BG_THREADS, 1) void speller_big_fwd_kernel(const Bi
 }
 
 size_t big_fwd_smem(int FR) {
-    return sizeof(float) * ((size_t)BG_NW * 16 * 17 + 32 * BG_M + BG_M * 4 + (size_t)FR * BG_KLD + (size_t)FR * BG_HS);
+    return sizeof(float) * ((size_t)BG_NW * 16 * 17 + BG_NW * BG_M + BG_M * 4 + BG_NW * BG_M + 32 + (size_t)FR * BG_KLD + (size_t)FR * BG_HS);
 }
 
 u64* g_big_trace = nullptr;

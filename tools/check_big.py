@@ -82,6 +82,14 @@ def run(B, Tp, U, scale=None, trace_on=True):
             step = np.diff(t[2:n, 0].astype(np.float64)).mean() / 100.0
             names = ["ctx wait+mfma", "cell0", "h0 wait+mfma", "cell1+qpart+Whh0", "q wait+sum", "energies+pc", "combine", "Whh1"]
             print("  trace (workgroup 0, us): " + ", ".join(f"{nm} {v:.2f}" for nm, v in zip(names, d)) + f"; step {step:.2f}")
+            print(f"    early-fetch fallbacks (all workgroups, whole launch): slabs {t[0, 14]}, query parts {t[0, 15]} of {256 * 8 * 4 * U} / {16 * B * 8 * U} wave loads")
+            if t[2, 13] != 0:
+                tt = t[2:n].astype(np.float64)
+                print(f"    shader clock over the traced steps: {(tt[-1, 13] - tt[0, 13]) / (tt[-1, 0] - tt[0, 0]) * 100.0:.0f} MHz")
+            if t[2, 12] != 0:      # sub-phases of the top cell's hand-off: stamps 2 -> 9 -> 10 -> 11 -> 12 -> 3
+                tt = t[2:n].astype(np.float64)
+                sub = [tt[:, 9] - tt[:, 2], tt[:, 10] - tt[:, 9], tt[:, 11] - tt[:, 10], tt[:, 12] - tt[:, 11], tt[:, 3] - tt[:, 12]]
+                print("    h0 phase: " + ", ".join(f"{nm} {v.mean() / 100.0:.2f}" for nm, v in zip(["canary", "barrier", "load", "mfma issue", "red+barrier"], sub)))
     return worst, err, ran
 
 
