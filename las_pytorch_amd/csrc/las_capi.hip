@@ -39,7 +39,7 @@ struct PblstmBwdLayout {
 };
 
 struct SpellerLayout {
-    size_t y_all, ctx_all, h_all, c_all, gates_all, q_all, w0p, ctxcat_all, hx, r0x, lgx, wperm, wyperm, bperm, yw, pctx, gx, bqp, bpc, total;
+    size_t y_all, ctx_all, h_all, c_all, gates_all, q_all, w0p, ctxcat_all, hx, r0x, lgx, wperm, wyperm, bperm, yw, pctx, gx, bqp, bfl, total;
     bool big;                  // room for the one-launch decode of the Hs = 1024 shape (speller_big.hip)
     bool pre;                  // room for the persistent decode kernel's pre-multiplied context variant
     int Vp;                    // label width padded to a multiple of 16: every cell operand is aligned and tail-free
@@ -71,7 +71,7 @@ struct SpellerLayout {
         big = speller_big_shape(d->B, d->Tp, d->Hs, d->D, d->M, d->V, d->L, d->multi_head, d->use_mlp);
         if (big && !pre) { yw = o; o += r4((size_t)U * B * 4 * d->Hs); }
         bqp = o; if (big) o += speller_big_qp_floats(d->B, U);
-        bpc = o; if (big) o += r4(speller_big_pc_floats(d->B, U));
+        bfl = o; if (big) o += r4(speller_big_flag_words(U));
         total = o;
     }
 };
@@ -503,7 +503,7 @@ int las_speller_fwd(const las_speller_desc* d, const float* feat, const float* k
         p.b_ih0 = d->b_ih[0]; p.b_hh0 = d->b_hh[0]; p.b_ih1 = d->b_ih[1]; p.b_hh1 = d->b_hh[1];
         p.w_phi = d->w_phi; p.b_phi = d->b_phi; p.feat = feat; p.keys = keys; p.yw = reserve + lay.yw;
         p.ctx_all = ctx_all; p.h_all = h_all; p.c_all = c_all; p.gates_all = gates_all; p.q_all = q_all; p.att = att;
-        p.qp = reserve + lay.bqp; p.pc = reserve + lay.bpc;
+        p.hx = reserve + lay.hx; p.qp = reserve + lay.bqp; p.flags = reinterpret_cast<unsigned*>(reserve + lay.bfl);
         p.B = B; p.Tp = Tp; p.U = U; p.V = V; p.relu = d->relu; p.err = err_word;
         const int rc = speller_big_fwd(p, stream);
         if (rc != LAS_ERR_UNSUPPORTED) { LAS_TRY(rc); persist_ran = true; }

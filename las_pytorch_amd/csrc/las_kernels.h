@@ -187,14 +187,15 @@ struct BigFwd {
     const float* feat; const float* keys;
     const float* yw;                                // (U*B, 4Hs): y_s W_y^T, rows in PyTorch gate order (no bias)
     float* ctx_all; float* h_all; float* c_all; float* gates_all; float* q_all; float* att;
-    float* qp; float* pc;                           // hand-off slabs: speller_big_qp_floats / speller_big_pc_floats
+    float* hx; float* qp; unsigned* flags;          // hand-off slabs: speller_big_hx_floats / _qp_floats / _flag_words (16-byte aligned)
     int B, Tp, U, V, relu;
     unsigned* err;
 };
 bool speller_big_shape(int B, int Tp, int Hs, int D, int M, int V, int L, int heads, int use_mlp);       // shape only (sizes the reserve)
 bool speller_big_eligible(int B, int Tp, int Hs, int D, int M, int V, int L, int heads, int use_mlp);    // shape + switch + residency
+size_t speller_big_hx_floats(int U);
 size_t speller_big_qp_floats(int B, int U);
-size_t speller_big_pc_floats(int B, int U);
+size_t speller_big_flag_words(int U);
 int speller_big_fwd(const BigFwd& p, hipStream_t stream);
 void speller_big_set_trace(unsigned long long* dev_buf);
 

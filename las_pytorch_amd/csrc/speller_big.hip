@@ -22,10 +22,9 @@
 namespace las {
 namespace {
 
-constexpr int BG_THREADS = 512, BG_NW = 8, BG_HS = 1024, BG_M = 64, BG_SL = 16, BG_WGS = 256, BG_NB = 16;
-constexpr int BG_PCLD = BG_HS + 4;       // one partial-context row: 1024 columns + (local max, local sum, 0, 0)
+constexpr int BG_THREADS = 512, BG_NW = 8, BG_HS = 1024, BG_M = 64, BG_WGS = 256, BG_NB = 16;
 constexpr int BG_KLD = BG_M + 4;         // LDS row stride of the keys
-constexpr int BG_MAXFR = 32;             // frames per attention slice (one lane each)
+constexpr int BG_MAXTP = 256;            // encoder frames: features and keys of the workgroup's column block stay in LDS (528 B per frame)
 constexpr float BG_LOG2E = 1.4426950408889634f;
 constexpr float BG_NEG = -3.0e38f;
 
@@ -36,8 +35,8 @@ struct BigArgs {
     const float* w_phi; const float* b_phi;
     const float* feat; const float* keys; const float* yw;
     float* ctx_all; float* h_all; float* c_all; float* gates_all; float* q_all; float* att;
-    float* qp; float* pc;
-    int B, Tp, U, FR, relu;
+    float* hx; float* qp; unsigned* flags;
+    int B, Tp, U, relu;
     unsigned* err;
     u64* trace;
 };
@@ -82,6 +81,40 @@ __device__ __forceinline__ void ld4x8_row_l2(const float* p, f32x4 (&v)[8]) {
         "s_waitcnt vmcnt(0)"
         : "=&v"(v[0]), "=&v"(v[1]), "=&v"(v[2]), "=&v"(v[3]), "=&v"(v[4]), "=&v"(v[5]), "=&v"(v[6]), "=&v"(v[7])
         : "v"(p)
+        : "memory");
+}
+// eight k-blocks of a producer-major h slab [256 producers][16 utterances][4 units]: 1 KB apart (the 13-bit offset field ends at 4095)
+template <bool L2>
+__device__ __forceinline__ void ld4x8_kb(const float* p, f32x4 (&v)[8]) {
+    const float* p2 = p + 1024;
+    if (L2) {
+        asm volatile(
+            "global_load_dwordx4 %0, %8, off\n\t"
+            "global_load_dwordx4 %1, %8, off offset:1024\n\t"
+            "global_load_dwordx4 %2, %8, off offset:2048\n\t"
+            "global_load_dwordx4 %3, %8, off offset:3072\n\t"
+            "global_load_dwordx4 %4, %9, off\n\t"
+            "global_load_dwordx4 %5, %9, off offset:1024\n\t"
+            "global_load_dwordx4 %6, %9, off offset:2048\n\t"
+            "global_load_dwordx4 %7, %9, off offset:3072\n\t"
+            "s_waitcnt vmcnt(0)"
+            : "=&v"(v[0]), "=&v"(v[1]), "=&v"(v[2]), "=&v"(v[3]), "=&v"(v[4]), "=&v"(v[5]), "=&v"(v[6]), "=&v"(v[7])
+            : "v"(p), "v"(p2)
+            : "memory");
+        return;
+    }
+    asm volatile(
+        "global_load_dwordx4 %0, %8, off sc1\n\t"
+        "global_load_dwordx4 %1, %8, off offset:1024 sc1\n\t"
+        "global_load_dwordx4 %2, %8, off offset:2048 sc1\n\t"
+        "global_load_dwordx4 %3, %8, off offset:3072 sc1\n\t"
+        "global_load_dwordx4 %4, %9, off sc1\n\t"
+        "global_load_dwordx4 %5, %9, off offset:1024 sc1\n\t"
+        "global_load_dwordx4 %6, %9, off offset:2048 sc1\n\t"
+        "global_load_dwordx4 %7, %9, off offset:3072 sc1\n\t"
+        "s_waitcnt vmcnt(0)"
+        : "=&v"(v[0]), "=&v"(v[1]), "=&v"(v[2]), "=&v"(v[3]), "=&v"(v[4]), "=&v"(v[5]), "=&v"(v[6]), "=&v"(v[7])
+        : "v"(p), "v"(p2)
         : "memory");
 }
 // ... at an arbitrary byte stride (the 256 query slices of an utterance)
@@ -146,41 +179,34 @@ __device__ __forceinline__ float gmax16(float v) {
     return v;
 }
 
-// wave 0 watches one dword per lane until none of them is the sentinel (a HINT that the producers are through: every consumer
-// still checks the data it loads); returns true when the wait was given up
-__device__ __forceinline__ bool canary(const float* cp, bool active, unsigned* err, unsigned code) {
-    unsigned spins = 0;
-    for (;;) {
-        const unsigned v = ld1_agent(cp);
-        if (!__any(active && v == PS_SENT)) return false;
-        if (spin_expired(spins, err, code)) return true;
-    }
-}
-// ... four dwords per lane, `step` floats apart: one wave covers the canaries of all 256 producers of a slab
-__device__ __forceinline__ bool canary4(const float* cp, int step, bool active, unsigned* err, unsigned code) {
-    unsigned spins = 0;
-    for (;;) {
-        const unsigned v0 = ld1_agent(cp), v1 = ld1_agent(cp + step), v2 = ld1_agent(cp + 2 * step), v3 = ld1_agent(cp + 3 * step);
-        if (!__any(active && (v0 == PS_SENT || v1 == PS_SENT || v2 == PS_SENT || v3 == PS_SENT))) return false;
-        if (spin_expired(spins, err, code)) return true;
-    }
-}
-
 #define BG_STAMP(slot) do { if (a.trace && wg == 0 && tid == 0 && s < 64) a.trace[s * 16 + (slot)] = wall_clock64(); } while (0)
+
+// one flag dword per producer and hand-off, four per lane: wave 0 watches the 256 (or 16 B) flags of a slab with ONE 1 KB request per poll.
+// A flag is stored right behind its data by the same wave; it is a HINT (the stores may land in either order): every consumer still
+// checks the data it loads for the sentinel.
+__device__ __forceinline__ bool flags_wait(const unsigned* fl, bool active, unsigned* err, unsigned code) {
+    unsigned spins = 0;
+    for (;;) {
+        const f32x4 v = ld4_agent(reinterpret_cast<const float*>(fl));
+        if (!__any(active && has_sentinel(v))) return false;
+        if (spin_expired(spins, err, code)) return true;
+    }
+}
 
 __global__ __launch_bounds__(BG_THREADS, 1) void speller_big_fwd_kernel(const BigArgs a) {
     extern __shared__ float lds[];
     float* red = lds;                              // [8 waves][16 utterances][17]: K reduction of a gate tile
     float* qred = red + BG_NW * 16 * 17;           // [8 waves][64]: query reduction
-    float* wphiS = qred + BG_NW * BG_M;               // [64][4]: this workgroup's K-slice of phi
-    float* qsW = wphiS + BG_M * 4;                 // [8 waves][64]: the query, one copy per wave
-    float* eS = qsW + BG_NW * BG_M;                // [32]: energies of the slice's frames
-    float* keysS = eS + 32;                        // [FR][68]
-    float* featS = keysS + a.FR * BG_KLD;          // [FR][1024]
+    float* cred = qred + BG_NW * BG_M;             // [8 waves][64]: context reduction
+    float* wphiS = cred + BG_NW * 64;              // [64][4]: this workgroup's K-slice of phi
+    float* wst = wphiS + BG_M * 4;                 // [8 waves][2]: (max, sum) of a wave's energies
+    float* aS = wst + 16;                          // [256]: attention weights of the utterance
+    float* keysS = aS + BG_MAXTP;                  // [Tp][68]
+    float* featS = keysS + a.Tp * BG_KLD;          // [Tp][64]: this workgroup's 64 feature columns of every frame
     __shared__ int dead_s;
 
     const int wg = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, r = lane & 15, kq = lane >> 4;
-    const int B = a.B, U = a.U, Tp = a.Tp, FR = a.FR;
+    const int B = a.B, U = a.U, Tp = a.Tp;
     const int j0 = wg * 4;
     const size_t sH = (size_t)B * BG_HS;
 
@@ -210,19 +236,16 @@ __global__ __launch_bounds__(BG_THREADS, 1) void speller_big_fwd_kernel(const Bi
     }
     float c0 = 0.f, c1 = 0.f;
 
-    // ---- attention slice of this workgroup
-    // the 16 slices of an utterance sit on ONE XCD (workgroup w runs on XCD w % 8): its 64 KB of query parts cross the fabric once
+    // ---- attention role: 64 feature columns of utterance ab, every frame.  The 16 column blocks of an utterance sit on ONE XCD
+    //      (workgroup w runs on XCD w % 8): its 64 KB of query parts cross the fabric once.
     const int ab = 2 * (wg & 7) + ((wg >> 3) & 1), aj = wg >> 4;
     const bool att_on = ab < B;
-    const int t0 = aj * FR;
-    const int nfr = att_on ? max(0, min(FR, Tp - t0)) : 0;
-    for (int idx = tid; idx < nfr * 256; idx += BG_THREADS) {
-        const int f = idx >> 8, c4 = idx & 255;
-        *reinterpret_cast<f32x4*>(featS + f * BG_HS + c4 * 4) = ld4p(a.feat + ((size_t)ab * Tp + t0 + f) * BG_HS + c4 * 4);
-    }
-    for (int idx = tid; idx < nfr * 16; idx += BG_THREADS) {
-        const int f = idx >> 4, m4 = idx & 15;
-        *reinterpret_cast<f32x4*>(keysS + f * BG_KLD + m4 * 4) = ld4p(a.keys + ((size_t)ab * Tp + t0 + f) * BG_M + m4 * 4);
+    if (att_on) {
+        for (int idx = tid; idx < Tp * 16; idx += BG_THREADS) {
+            const int t = idx >> 4, c4 = idx & 15;
+            *reinterpret_cast<f32x4*>(featS + t * 64 + c4 * 4) = ld4p(a.feat + ((size_t)ab * Tp + t) * BG_HS + aj * 64 + c4 * 4);
+            *reinterpret_cast<f32x4*>(keysS + t * BG_KLD + c4 * 4) = ld4p(a.keys + ((size_t)ab * Tp + t) * BG_M + c4 * 4);
+        }
     }
     if (tid < 256) wphiS[tid] = a.w_phi[(size_t)(tid >> 2) * BG_HS + j0 + (tid & 3)];
     const float bphi = a.b_phi[lane];
@@ -232,17 +255,31 @@ __global__ __launch_bounds__(BG_THREADS, 1) void speller_big_fwd_kernel(const Bi
 
     f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
     const int rowb = min(r, B - 1);                      // rows beyond the batch repeat the last utterance (never stored)
-    const unsigned aoff = (unsigned)(rowb * BG_HS + wave * 128 + kq * 4) * 4u;      // byte offset of this lane's first k-block in a (B,1024) slab
+    const unsigned aoff = (unsigned)(rowb * BG_HS + wave * 128 + kq * 4) * 4u;      // this lane's first k-block in a row-major (B,1024) slab
+    const unsigned hoff = (unsigned)(((wave * 32 + kq) * 16 + rowb) * 4) * 4u;      // ... in a producer-major [256][16][4] slab of h
 
-    // checked load of this lane's 8 k-blocks of a hand-off slab
-    auto load_rows = [&](const float* slab, f32x4 (&ax)[8], unsigned code) {
+    // checked loads of this lane's 8 k-blocks of a hand-off slab: through the L2 first (the flags said every producer is through), agent
+    // scope if a line was fetched too early
+    auto load_ctx = [&](const float* slab, f32x4 (&ax)[8], unsigned code) {
         const float* p = at_bytes(slab, opaque(aoff));
         ld4x8_row_l2(p, ax);
         if (!__any(any_sentinel8(ax))) return;
-        if (a.trace && lane == 0) atomicAdd(a.trace + 14, 1ull);      // diagnostics: a line was fetched into the L2 before its producer was through
+        if (a.trace && lane == 0) atomicAdd(a.trace + 14, 1ull);
         unsigned spins = 0;
         for (;;) {
             ld4x8_row(p, ax);
+            if (!__any(any_sentinel8(ax))) break;
+            if (dead || spin_expired(spins, a.err, code)) { dead = true; break; }
+        }
+    };
+    auto load_h = [&](const float* slab, f32x4 (&ax)[8], unsigned code) {
+        const float* p = at_bytes(slab, opaque(hoff));
+        ld4x8_kb<true>(p, ax);
+        if (!__any(any_sentinel8(ax))) return;
+        if (a.trace && lane == 0) atomicAdd(a.trace + 14, 1ull);
+        unsigned spins = 0;
+        for (;;) {
+            ld4x8_kb<false>(p, ax);
             if (!__any(any_sentinel8(ax))) break;
             if (dead || spin_expired(spins, a.err, code)) { dead = true; break; }
         }
@@ -251,6 +288,7 @@ __global__ __launch_bounds__(BG_THREADS, 1) void speller_big_fwd_kernel(const Bi
     for (int s = 0; s < U; ++s) {
         BG_STAMP(0);
         if (a.trace && wg == 0 && tid == 0 && s < 64) a.trace[s * 16 + 13] = __builtin_readcyclecounter();      // shader clock (the stamps are 100 MHz)
+        const unsigned* fl = a.flags + (size_t)s * 3 * BG_WGS;          // flags of this step: [h0 | h1 + query parts | ctx]
         // label half of the bottom-layer gates (one GEMM before the launch), off the chain
         float ywv[4] = {0.f, 0.f, 0.f, 0.f};
         if (cell_on) {
@@ -260,14 +298,12 @@ __global__ __launch_bounds__(BG_THREADS, 1) void speller_big_fwd_kernel(const Bi
         f32x4 ax[8];
         // ================= [1] bottom cell: gates0 = yw + W_ctx ctx_{s-1} + W_hh0 h0_{s-1}
         {
-            const float* ctxp = a.ctx_all + (size_t)s * sH;
             if (wave == 0 && s > 0 && !dead) {
-                const int row = lane & 15;
-                if (canary4(ctxp + (size_t)min(row, B - 1) * BG_HS + (lane >> 4) * 256 + 63, 64, row < B, a.err, 0xB1600001u)) dead_s = 1;
+                if (flags_wait(fl - 3 * BG_WGS + 2 * BG_WGS + lane * 4, lane * 4 < B * 16, a.err, 0xB1600001u)) dead_s = 1;
             }
             __syncthreads();
             dead |= dead_s != 0;
-            load_rows(ctxp, ax, 0xB1600002u);
+            load_ctx(a.ctx_all + (size_t)s * sH, ax, 0xB1600002u);
             acc0 = seg_mfma(ax, wc, acc0);
 #pragma unroll
             for (int rr = 0; rr < 4; ++rr) red[(wave * 16 + kq * 4 + rr) * 17 + r] = acc0[rr];
@@ -286,9 +322,11 @@ __global__ __launch_bounds__(BG_THREADS, 1) void speller_big_fwd_kernel(const Bi
                 const float ig = sigmoidf_acc(g4[0]), fg = sigmoidf_acc(g4[1]), gg = tanhf_acc(g4[2]), og = sigmoidf_acc(g4[3]);
                 c0 = fg * c0 + ig * gg;
                 const float h = og * tanhf_acc(c0);
+                if (cell_on) st1_agent(a.hx + ((size_t)s * BG_WGS + wg) * 64 + lane, h);          // hand-off copy: 256 contiguous bytes
+                if (lane == 0) st1_agent(reinterpret_cast<float*>(const_cast<unsigned*>(fl)) + wg, 0.f);
                 if (cell_on) {
                     const size_t o = (size_t)s * sH + (size_t)cb * BG_HS + j0 + cu;       // layer 0
-                    st1_agent(a.h_all + o, h);
+                    a.h_all[o] = h;
                     a.c_all[o] = c0;
                     float* go = a.gates_all + 4 * ((size_t)s * sH) + (size_t)cb * 4 * BG_HS + j0 + cu;
                     go[0] = ig; go[BG_HS] = fg; go[2 * BG_HS] = gg; go[3 * BG_HS] = og;
@@ -298,15 +336,14 @@ __global__ __launch_bounds__(BG_THREADS, 1) void speller_big_fwd_kernel(const Bi
         BG_STAMP(2);
         // ================= [2] top cell: gates1 = b + W_ih1 h0_s + W_hh1 h1_{s-1}
         {
-            const float* h0p = a.h_all + (size_t)s * sH;
             if (wave == 0 && !dead) {
-                if (canary4(h0p + (size_t)(B - 1) * BG_HS + lane * 16 + 3, 4, true, a.err, 0xB1600003u)) dead_s = 1;
+                if (flags_wait(fl + lane * 4, true, a.err, 0xB1600003u)) dead_s = 1;
             }
             BG_STAMP(9);
             __syncthreads();
             BG_STAMP(10);
             dead |= dead_s != 0;
-            load_rows(h0p, ax, 0xB1600004u);
+            load_h(a.hx + (size_t)s * BG_WGS * 64, ax, 0xB1600004u);
             BG_STAMP(11);
             acc1 = seg_mfma(ax, wi1, acc1);
             BG_STAMP(12);
@@ -327,13 +364,7 @@ __global__ __launch_bounds__(BG_THREADS, 1) void speller_big_fwd_kernel(const Bi
                 const float ig = sigmoidf_acc(g4[0]), fg = sigmoidf_acc(g4[1]), gg = tanhf_acc(g4[2]), og = sigmoidf_acc(g4[3]);
                 c1 = fg * c1 + ig * gg;
                 const float h = og * tanhf_acc(c1);
-                if (cell_on) {
-                    const size_t o = ((size_t)U + s) * sH + (size_t)cb * BG_HS + j0 + cu;  // layer 1
-                    st1_agent(a.h_all + o, h);
-                    a.c_all[o] = c1;
-                    float* go = a.gates_all + 4 * (((size_t)U + s) * sH) + (size_t)cb * 4 * BG_HS + j0 + cu;
-                    go[0] = ig; go[BG_HS] = fg; go[2 * BG_HS] = gg; go[3 * BG_HS] = og;
-                }
+                if (cell_on) st1_agent(a.hx + (((size_t)U + s) * BG_WGS + wg) * 64 + lane, h);
                 // this workgroup's K-slice of the query of every utterance: qp[s][b][wg][m] = sum_u W_phi[m][j0+u] h1[b][j0+u]
                 const float h_0 = quad_bcast(h, 0), h_1 = quad_bcast(h, 1), h_2 = quad_bcast(h, 2), h_3 = quad_bcast(h, 3);
                 float* qo = a.qp + (((size_t)s * B + min(cb, B - 1)) * BG_WGS + wg) * BG_M + cu * 16;
@@ -347,17 +378,24 @@ __global__ __launch_bounds__(BG_THREADS, 1) void speller_big_fwd_kernel(const Bi
                     }
                     if (cell_on) st4_agent(qo + i4 * 4, o4);
                 }
+                if (lane == 0) st1_agent(reinterpret_cast<float*>(const_cast<unsigned*>(fl)) + BG_WGS + wg, 0.f);
+                if (cell_on) {
+                    const size_t o = ((size_t)U + s) * sH + (size_t)cb * BG_HS + j0 + cu;  // layer 1
+                    a.h_all[o] = h;
+                    a.c_all[o] = c1;
+                    float* go = a.gates_all + 4 * (((size_t)U + s) * sH) + (size_t)cb * 4 * BG_HS + j0 + cu;
+                    go[0] = ig; go[BG_HS] = fg; go[2 * BG_HS] = gg; go[3 * BG_HS] = og;
+                }
             }
             // recurrent half of the NEXT bottom cell while h1 / the query parts travel (the A operand is still in registers)
             acc0 = seg_mfma(ax, wh0, acc0);
         }
         BG_STAMP(4);
-        // ================= [3] attention slice: query, energies, local softmax, partial context
-        float pf = 0.f;      // exp(e_f - local max) of frame f = lane & 31 (every wave holds the whole slice)
+        // ================= [3] attention of utterance ab, feature columns [64 aj, 64 aj + 64): query, energies of every frame, softmax, context
         {
             const float* qps = a.qp + ((size_t)s * B + min(ab, B - 1)) * BG_WGS * BG_M;
-            if (wave == 0 && att_on && !dead) {
-                if (canary4(qps + (size_t)(lane * 4) * BG_M + 63, BG_M, true, a.err, 0xB1600005u)) dead_s = 1;
+            if (wave == 0 && !dead) {
+                if (flags_wait(fl + BG_WGS + lane * 4, true, a.err, 0xB1600005u)) dead_s = 1;
             }
             __syncthreads();
             dead |= dead_s != 0;
@@ -390,83 +428,73 @@ __global__ __launch_bounds__(BG_THREADS, 1) void speller_big_fwd_kernel(const Bi
             }
             __syncthreads();
             BG_STAMP(5);
-            float e = BG_NEG;
-            if (att_on) {
+            float pw = 0.f, mw = BG_NEG;
+            const bool fr_on = att_on && tid < Tp;                       // thread t owns frame t
+            if (att_on && wave * 64 < Tp) {
                 float q = bphi;
 #pragma unroll
                 for (int w = 0; w < BG_NW; ++w) q += qred[w * BG_M + lane];
                 q = act_apply(q, a.relu);
                 if (aj == 0 && wave == 0) a.q_all[((size_t)s * B + ab) * BG_M + lane] = q;
-                float* qw = qsW + wave * BG_M;
-                qw[lane] = q;                                           // wave-private: no barrier, the LDS queue is in order
-                // energies of frames 4 wave .. 4 wave + 3: 16 lanes per frame, 4 attention dimensions per lane
-                const int f = 4 * wave + (lane >> 4), part = lane & 15;
-                const float* kr = keysS + min(f, max(nfr - 1, 0)) * BG_KLD;
-                float ef = dot4p(*reinterpret_cast<const f32x4*>(qw + part * 4), *reinterpret_cast<const f32x4*>(kr + part * 4), 0.f);
-                ef = gsum<16>(ef);
-                if (part == 0) eS[f] = f < nfr ? ef : BG_NEG;
+                const float* kr = keysS + min(tid, Tp - 1) * BG_KLD;
+                float e = 0.f;
+#pragma unroll
+                for (int m4 = 0; m4 < BG_M / 4; ++m4) {
+                    const f32x4 kv = *reinterpret_cast<const f32x4*>(kr + m4 * 4);
+                    e = fmaf(lane_f(q, m4 * 4), kv[0], e); e = fmaf(lane_f(q, m4 * 4 + 1), kv[1], e);
+                    e = fmaf(lane_f(q, m4 * 4 + 2), kv[2], e); e = fmaf(lane_f(q, m4 * 4 + 3), kv[3], e);
+                }
+                e = fr_on ? e : BG_NEG;
+                mw = wmax(e);
+                pw = fr_on ? __builtin_amdgcn_exp2f((e - mw) * BG_LOG2E) : 0.f;
+                const float lw = wsum(pw);
+                if (lane == 0) { wst[wave * 2] = mw; wst[wave * 2 + 1] = lw; }
+            } else if (lane == 0) {
+                wst[wave * 2] = BG_NEG; wst[wave * 2 + 1] = 0.f;
             }
             __syncthreads();
             if (att_on) {
-                e = eS[lane & 31];
-                const float mj = wmax(e);
-                pf = (lane & 31) < nfr ? __builtin_amdgcn_exp2f((e - mj) * BG_LOG2E) : 0.f;
-                const float lj = wsum(lane < 32 ? pf : 0.f);
-                // unnormalised partial context of this wave's 128 columns
-                float c_lo = 0.f, c_hi = 0.f;
-                const float* fc = featS + wave * 128 + lane * 2;
-                for (int ff = 0; ff < nfr; ++ff) {
-                    const ps_f32x2 x = *reinterpret_cast<const ps_f32x2*>(fc + ff * BG_HS);
-                    const float w = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, pf), ff));
-                    c_lo = fmaf(w, x[0], c_lo); c_hi = fmaf(w, x[1], c_hi);
+                float mx = BG_NEG;
+#pragma unroll
+                for (int w = 0; w < BG_NW; ++w) mx = fmaxf(mx, wst[w * 2]);
+                float tot = 0.f;
+#pragma unroll
+                for (int w = 0; w < BG_NW; ++w) tot += wst[w * 2 + 1] * __builtin_amdgcn_exp2f((wst[w * 2] - mx) * BG_LOG2E);
+                const float at = pw * __builtin_amdgcn_exp2f((mw - mx) * BG_LOG2E) / tot;
+                if (fr_on) {
+                    aS[tid] = at;
+                    if ((tid & 15) == aj) a.att[((size_t)s * B + ab) * Tp + tid] = at;       // the 16 column blocks share the row's stores
                 }
-                float* pcr = a.pc + (((size_t)s * B + ab) * BG_SL + aj) * BG_PCLD;
-                st2_agent(pcr + wave * 128 + lane * 2, c_lo, c_hi);
-                if (wave == 0 && lane == 0) st4_agent(pcr + BG_HS, f32x4{mj, lj, 0.f, 0.f});
             }
-        }
-        BG_STAMP(6);
-        // ================= [4] combine the 16 partial contexts of this utterance for columns [64 aj, 64 aj + 64) (wave 0)
-        if (wave == 0 && att_on) {
-            const float* pcb = a.pc + ((size_t)s * B + ab) * BG_SL * BG_PCLD;
-            unsigned v[16], mi = 0, li = 0;
-            unsigned spins = 0;
-            for (;;) {
-#pragma unroll
-                for (int i = 0; i < 16; ++i) v[i] = ld1_agent(pcb + (size_t)i * BG_PCLD + aj * 64 + lane);
-                mi = ld1_agent(pcb + (size_t)(lane & 15) * BG_PCLD + BG_HS);
-                li = ld1_agent(pcb + (size_t)(lane & 15) * BG_PCLD + BG_HS + 1);
-                bool bad = mi == PS_SENT || li == PS_SENT;
-#pragma unroll
-                for (int i = 0; i < 16; ++i) bad |= v[i] == PS_SENT;
-                if (!__any(bad)) break;
-                if (dead || spin_expired(spins, a.err, 0xB1600007u)) { dead = true; dead_s = 1; break; }
+            __syncthreads();
+            if (att_on) {
+                float c = 0.f;
+                const float* fc = featS + lane;
+                for (int t = wave; t < Tp; t += BG_NW) c = fmaf(aS[t], fc[t * 64], c);
+                cred[wave * 64 + lane] = c;
             }
-            const float m_i = __uint_as_float(mi), l_i = __uint_as_float(li);
-            const float mx = gmax16(m_i);
-            const float w_i = __builtin_amdgcn_exp2f((m_i - mx) * BG_LOG2E);
-            const float tot = gsum<16>(w_i * l_i);
-            const float sc = w_i / tot;                                   // lanes 0..15: scale of slice i = lane
-            float ctx = 0.f;
+            __syncthreads();
+            BG_STAMP(6);
+            if (wave == 0 && att_on) {
+                float c = 0.f;
 #pragma unroll
-            for (int i = 0; i < 16; ++i) ctx = fmaf(lane_f(sc, i), __uint_as_float(v[i]), ctx);
-            st1_agent(a.ctx_all + ((size_t)(s + 1) * B + ab) * BG_HS + aj * 64 + lane, ctx);
-            // normalised attention weights of this slice's frames
-            const float scj = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, sc), aj));
-            if (lane < nfr) a.att[((size_t)s * B + ab) * Tp + t0 + lane] = pf * scj;
+                for (int w = 0; w < BG_NW; ++w) c += cred[w * 64 + lane];
+                st1_agent(a.ctx_all + ((size_t)(s + 1) * B + ab) * BG_HS + aj * 64 + lane, c);
+                if (lane == 0) st1_agent(reinterpret_cast<float*>(const_cast<unsigned*>(fl)) + 2 * BG_WGS + ab * 16 + aj, 0.f);
+            }
         }
         BG_STAMP(7);
-        // ================= [4b] recurrent half of the next top cell
+        // ================= [4] recurrent half of the next top cell (h1_s is there: the flags of [3] said so)
         if (s + 1 < U) {
-            load_rows(a.h_all + ((size_t)U + s) * sH, ax, 0xB1600008u);
+            load_h(a.hx + ((size_t)U + s) * BG_WGS * 64, ax, 0xB1600008u);
             acc1 = seg_mfma(ax, wh1, acc1);
         }
         BG_STAMP(8);
     }
 }
 
-size_t big_fwd_smem(int FR) {
-    return sizeof(float) * ((size_t)BG_NW * 16 * 17 + BG_NW * BG_M + BG_M * 4 + BG_NW * BG_M + 32 + (size_t)FR * BG_KLD + (size_t)FR * BG_HS);
+size_t big_fwd_smem(int Tp) {
+    return sizeof(float) * ((size_t)BG_NW * 16 * 17 + BG_NW * BG_M + BG_NW * 64 + BG_M * 4 + 16 + BG_MAXTP + (size_t)Tp * BG_KLD + (size_t)Tp * 64);
 }
 
 u64* g_big_trace = nullptr;
@@ -475,19 +503,18 @@ u64* g_big_trace = nullptr;
 
 void speller_big_set_trace(unsigned long long* dev_buf) { g_big_trace = dev_buf; }
 
-int speller_big_frames(int Tp) { return (Tp + BG_SL - 1) / BG_SL; }
-
 bool speller_big_shape(int B, int Tp, int Hs, int D, int M, int V, int L, int heads, int use_mlp) {
     if (L != 2 || heads != 1 || !use_mlp || M != BG_M || Hs != BG_HS || D != BG_HS) return false;
-    if (B < 1 || B > BG_NB || Tp < 1 || speller_big_frames(Tp) > BG_MAXFR) return false;
+    if (B < 1 || B > BG_NB || Tp < 1 || Tp > BG_MAXTP) return false;
     return true;
 }
 
+size_t speller_big_hx_floats(int U) { return (size_t)2 * U * BG_WGS * 64; }
 size_t speller_big_qp_floats(int B, int U) { return (size_t)U * B * BG_WGS * BG_M; }
-size_t speller_big_pc_floats(int B, int U) { return (size_t)U * B * BG_SL * BG_PCLD; }
+size_t speller_big_flag_words(int U) { return (size_t)U * 3 * BG_WGS; }
 
-static bool big_fits(int FR) {
-    const size_t smem = big_fwd_smem(FR);
+static bool big_fits(int Tp) {
+    const size_t smem = big_fwd_smem(Tp);
     if (smem > 160 * 1024) return false;
     if (hipFuncSetAttribute(reinterpret_cast<const void*>(&speller_big_fwd_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem) != hipSuccess)
         return false;
@@ -496,12 +523,13 @@ static bool big_fits(int FR) {
 
 bool speller_big_eligible(int B, int Tp, int Hs, int D, int M, int V, int L, int heads, int use_mlp) {
     if (opt_get(OPT_SPELLER_BIG) == 0 || !speller_big_shape(B, Tp, Hs, D, M, V, L, heads, use_mlp)) return false;
-    return big_fits(speller_big_frames(Tp));
+    return big_fits(Tp);
 }
 
 int speller_big_fwd(const BigFwd& p, hipStream_t stream) {
     LAS_REQUIRE(speller_big_shape(p.B, p.Tp, BG_HS, BG_HS, BG_M, p.V, 2, 1, 1), "one-launch decode (Hs = 1024) shape");
     LAS_REQUIRE(p.err != nullptr, "the persistent speller needs the device error word");
+    LAS_REQUIRE((uintptr_t)p.flags % 16 == 0 && (uintptr_t)p.hx % 16 == 0 && (uintptr_t)p.qp % 16 == 0, "hand-off slab alignment");
     BigArgs a;
     a.w0p = p.w0p; a.ldw0 = p.Vp + BG_HS; a.Vp = p.Vp;
     a.w_hh0 = p.w_hh0; a.w_ih1 = p.w_ih1; a.w_hh1 = p.w_hh1;
@@ -509,29 +537,24 @@ int speller_big_fwd(const BigFwd& p, hipStream_t stream) {
     a.w_phi = p.w_phi; a.b_phi = p.b_phi;
     a.feat = p.feat; a.keys = p.keys; a.yw = p.yw;
     a.ctx_all = p.ctx_all; a.h_all = p.h_all; a.c_all = p.c_all; a.gates_all = p.gates_all; a.q_all = p.q_all; a.att = p.att;
-    a.qp = p.qp; a.pc = p.pc;
-    a.B = p.B; a.Tp = p.Tp; a.U = p.U; a.FR = speller_big_frames(p.Tp); a.relu = p.relu; a.err = p.err;
+    a.hx = p.hx; a.qp = p.qp; a.flags = p.flags;
+    a.B = p.B; a.Tp = p.Tp; a.U = p.U; a.relu = p.relu; a.err = p.err;
     a.trace = g_big_trace;
-    if (!big_fits(a.FR))
+    if (!big_fits(p.Tp))
         return fail(LAS_ERR_UNSUPPORTED, "one-launch decode (Hs = 1024): %s%ld workgroups cannot all be resident", "", (long)BG_WGS);
-    // sentinel-fill what the phases hand over: the contexts of steps 1..U, every h of both layers (adjacent in the reserve), the
-    // query slices and the partial contexts (adjacent)
+    // sentinel-fill what the phases hand over: the contexts of steps 1..U, the producer-major copies of h, the query slices and the flags
     const size_t sH = (size_t)p.B * BG_HS;
-    if (p.h_all == p.ctx_all + (size_t)(p.U + 1) * sH) {
-        LAS_HIP_CHECK(hipMemsetAsync(p.ctx_all + sH, 0xFF, sizeof(float) * (size_t)3 * p.U * sH, stream));
-    } else {
-        LAS_HIP_CHECK(hipMemsetAsync(p.ctx_all + sH, 0xFF, sizeof(float) * (size_t)p.U * sH, stream));
-        LAS_HIP_CHECK(hipMemsetAsync(p.h_all, 0xFF, sizeof(float) * (size_t)2 * p.U * sH, stream));
-    }
-    if (p.pc == p.qp + speller_big_qp_floats(p.B, p.U)) {
-        LAS_HIP_CHECK(hipMemsetAsync(p.qp, 0xFF, sizeof(float) * (speller_big_qp_floats(p.B, p.U) + speller_big_pc_floats(p.B, p.U)), stream));
+    LAS_HIP_CHECK(hipMemsetAsync(p.ctx_all + sH, 0xFF, sizeof(float) * (size_t)p.U * sH, stream));
+    LAS_HIP_CHECK(hipMemsetAsync(p.hx, 0xFF, sizeof(float) * speller_big_hx_floats(p.U), stream));
+    if ((float*)p.flags == p.qp + speller_big_qp_floats(p.B, p.U)) {      // adjacent (the layout las_capi.hip uses): one fill
+        LAS_HIP_CHECK(hipMemsetAsync(p.qp, 0xFF, sizeof(float) * (speller_big_qp_floats(p.B, p.U) + speller_big_flag_words(p.U)), stream));
     } else {
         LAS_HIP_CHECK(hipMemsetAsync(p.qp, 0xFF, sizeof(float) * speller_big_qp_floats(p.B, p.U), stream));
-        LAS_HIP_CHECK(hipMemsetAsync(p.pc, 0xFF, sizeof(float) * speller_big_pc_floats(p.B, p.U), stream));
+        LAS_HIP_CHECK(hipMemsetAsync(p.flags, 0xFF, sizeof(unsigned) * speller_big_flag_words(p.U), stream));
     }
     {
         KernelTimer timer(TIMED_DECODE_FWD, stream);
-        hipLaunchKernelGGL(speller_big_fwd_kernel, dim3(BG_WGS), dim3(BG_THREADS), big_fwd_smem(a.FR), stream, a);
+        hipLaunchKernelGGL(speller_big_fwd_kernel, dim3(BG_WGS), dim3(BG_THREADS), big_fwd_smem(p.Tp), stream, a);
     }
     LAS_LAUNCH_CHECK();
     return LAS_OK;

@@ -80,7 +80,7 @@ def run(B, Tp, U, scale=None, trace_on=True):
         if n > 4:
             d = np.diff(t[2:n, :9].astype(np.float64), axis=1).mean(0) / 100.0     # 100 MHz shader clock counter -> us
             step = np.diff(t[2:n, 0].astype(np.float64)).mean() / 100.0
-            names = ["ctx wait+mfma", "cell0", "h0 wait+mfma", "cell1+qpart+Whh0", "q wait+sum", "energies+pc", "combine", "Whh1"]
+            names = ["ctx wait+mfma", "cell0", "h0 wait+mfma", "cell1+qpart+Whh0", "q wait+sum", "attention", "ctx publish", "Whh1"]
             print("  trace (workgroup 0, us): " + ", ".join(f"{nm} {v:.2f}" for nm, v in zip(names, d)) + f"; step {step:.2f}")
             print(f"    early-fetch fallbacks (all workgroups, whole launch): slabs {t[0, 14]}, query parts {t[0, 15]} of {256 * 8 * 4 * U} / {16 * B * 8 * U} wave loads")
             if t[2, 13] != 0:
