@@ -37,6 +37,7 @@ struct BigArgs {
     float* ctx_all; float* h_all; float* c_all; float* gates_all; float* q_all; float* att;
     float* hx; float* qp; unsigned* flags;
     int B, Tp, U, relu;
+    int tune;                                            // poll pacing (option SPELLER_BIG_TUNE)
     unsigned* err;
     u64* trace;
 };
@@ -83,7 +84,8 @@ __device__ __forceinline__ void ld4x8_row_l2(const float* p, f32x4 (&v)[8]) {
         : "v"(p)
         : "memory");
 }
-// eight k-blocks of a producer-major h slab [256 producers][16 utterances][4 units]: 1 KB apart (the 13-bit offset field ends at 4095)
+// eight k-blocks of a producer-major h slab [256 producers][16 utterances][4 units] (or of a context slab [64 k-blocks][16][16]): 1 KB
+// apart (the 13-bit offset field ends at 4095)
 template <bool L2>
 __device__ __forceinline__ void ld4x8_kb(const float* p, f32x4 (&v)[8]) {
     const float* p2 = p + 1024;
@@ -179,17 +181,25 @@ __device__ __forceinline__ float gmax16(float v) {
     return v;
 }
 
+// per-workgroup stamps of step 10 (skew of the hand-offs over the chip): slots 1024 + 4 wg + k
+#define BG_WSTAMP(k) do { if (a.trace && s == 10 && tid == 0) a.trace[1024 + wg * 8 + (k)] = wall_clock64(); } while (0)
 #define BG_STAMP(slot) do { if (a.trace && wg == 0 && tid == 0 && s < 64) a.trace[s * 16 + (slot)] = wall_clock64(); } while (0)
 
 // one flag dword per producer and hand-off, four per lane: wave 0 watches the 256 (or 16 B) flags of a slab with ONE 1 KB request per poll.
 // A flag is stored right behind its data by the same wave; it is a HINT (the stores may land in either order): every consumer still
 // checks the data it loads for the sentinel.
-__device__ __forceinline__ bool flags_wait(const unsigned* fl, bool active, unsigned* err, unsigned code) {
+__device__ __forceinline__ void sleep_units(int n) {      // n x 64 clocks (s_sleep takes an immediate)
+    for (; n >= 8; n -= 8) __builtin_amdgcn_s_sleep(8);
+    for (; n > 0; --n) __builtin_amdgcn_s_sleep(1);
+}
+__device__ __forceinline__ bool flags_wait(const unsigned* fl, bool active, unsigned* err, unsigned code, int first, int gap) {
     unsigned spins = 0;
+    sleep_units(first);
     for (;;) {
         const f32x4 v = ld4_agent(reinterpret_cast<const float*>(fl));
         if (!__any(active && has_sentinel(v))) return false;
         if (spin_expired(spins, err, code)) return true;
+        sleep_units(gap);
     }
 }
 
@@ -272,6 +282,19 @@ __global__ __launch_bounds__(BG_THREADS, 1) void speller_big_fwd_kernel(const Bi
             if (dead || spin_expired(spins, a.err, code)) { dead = true; break; }
         }
     };
+    const unsigned coff = (unsigned)((wave * 8 * 16 + rowb) * 16 + kq * 4) * 4u;      // ... in a context slab [64 k-blocks][16 utterances][16 columns]
+    auto load_cx = [&](const float* slab, f32x4 (&ax)[8], unsigned code) {
+        const float* p = at_bytes(slab, opaque(coff));
+        ld4x8_kb<true>(p, ax);
+        if (!__any(any_sentinel8(ax))) return;
+        if (a.trace && lane == 0) atomicAdd(a.trace + 14, 1ull);
+        unsigned spins = 0;
+        for (;;) {
+            ld4x8_kb<false>(p, ax);
+            if (!__any(any_sentinel8(ax))) break;
+            if (dead || spin_expired(spins, a.err, code)) { dead = true; break; }
+        }
+    };
     auto load_h = [&](const float* slab, f32x4 (&ax)[8], unsigned code) {
         const float* p = at_bytes(slab, opaque(hoff));
         ld4x8_kb<true>(p, ax);
@@ -299,11 +322,13 @@ __global__ __launch_bounds__(BG_THREADS, 1) void speller_big_fwd_kernel(const Bi
         // ================= [1] bottom cell: gates0 = yw + W_ctx ctx_{s-1} + W_hh0 h0_{s-1}
         {
             if (wave == 0 && s > 0 && !dead) {
-                if (flags_wait(fl - 3 * BG_WGS + 2 * BG_WGS + lane * 4, lane * 4 < B * 16, a.err, 0xB1600001u)) dead_s = 1;
+                if (flags_wait(fl - 3 * BG_WGS + 2 * BG_WGS + lane * 4, lane * 4 < B * 16, a.err, 0xB1600001u, (a.tune >> 16) & 255, (a.tune >> 8) & 255)) dead_s = 1;
             }
+            BG_WSTAMP(0);
             __syncthreads();
             dead |= dead_s != 0;
-            load_ctx(a.ctx_all + (size_t)s * sH, ax, 0xB1600002u);
+            if (s == 0) load_ctx(a.ctx_all, ax, 0xB1600002u);        // ctx_{-1} = feat[:,0,:], row-major, written before the launch
+            else load_cx(a.hx + ((size_t)2 * U + s - 1) * BG_WGS * 64, ax, 0xB1600002u);
             acc0 = seg_mfma(ax, wc, acc0);
 #pragma unroll
             for (int rr = 0; rr < 4; ++rr) red[(wave * 16 + kq * 4 + rr) * 17 + r] = acc0[rr];
@@ -324,6 +349,7 @@ __global__ __launch_bounds__(BG_THREADS, 1) void speller_big_fwd_kernel(const Bi
                 const float h = og * tanhf_acc(c0);
                 if (cell_on) st1_agent(a.hx + ((size_t)s * BG_WGS + wg) * 64 + lane, h);          // hand-off copy: 256 contiguous bytes
                 if (lane == 0) st1_agent(reinterpret_cast<float*>(const_cast<unsigned*>(fl)) + wg, 0.f);
+                BG_WSTAMP(1);
                 if (cell_on) {
                     const size_t o = (size_t)s * sH + (size_t)cb * BG_HS + j0 + cu;       // layer 0
                     a.h_all[o] = h;
@@ -336,10 +362,18 @@ __global__ __launch_bounds__(BG_THREADS, 1) void speller_big_fwd_kernel(const Bi
         BG_STAMP(2);
         // ================= [2] top cell: gates1 = b + W_ih1 h0_s + W_hh1 h1_{s-1}
         {
+            // the recurrent half W_hh1 h1_{s-1} is multiplied while this step's h0 travels (its operand arrived in [3] of the last step; polling the
+            // flags right after publishing only queues reads in front of the flag stores they are waiting for)
+            if (s > 0) {
+                load_h(a.hx + ((size_t)U + s - 1) * BG_WGS * 64, ax, 0xB1600008u);
+                acc1 = seg_mfma(ax, wh1, acc1);
+            }
+            BG_WSTAMP(6);
             if (wave == 0 && !dead) {
-                if (flags_wait(fl + lane * 4, true, a.err, 0xB1600003u)) dead_s = 1;
+                if (flags_wait(fl + lane * 4, true, a.err, 0xB1600003u, a.tune & 255, (a.tune >> 8) & 255)) dead_s = 1;
             }
             BG_STAMP(9);
+            BG_WSTAMP(2);
             __syncthreads();
             BG_STAMP(10);
             dead |= dead_s != 0;
@@ -379,6 +413,7 @@ __global__ __launch_bounds__(BG_THREADS, 1) void speller_big_fwd_kernel(const Bi
                     if (cell_on) st4_agent(qo + i4 * 4, o4);
                 }
                 if (lane == 0) st1_agent(reinterpret_cast<float*>(const_cast<unsigned*>(fl)) + BG_WGS + wg, 0.f);
+                BG_WSTAMP(3);
                 if (cell_on) {
                     const size_t o = ((size_t)U + s) * sH + (size_t)cb * BG_HS + j0 + cu;  // layer 1
                     a.h_all[o] = h;
@@ -395,8 +430,9 @@ __global__ __launch_bounds__(BG_THREADS, 1) void speller_big_fwd_kernel(const Bi
         {
             const float* qps = a.qp + ((size_t)s * B + min(ab, B - 1)) * BG_WGS * BG_M;
             if (wave == 0 && !dead) {
-                if (flags_wait(fl + BG_WGS + lane * 4, true, a.err, 0xB1600005u)) dead_s = 1;
+                if (flags_wait(fl + BG_WGS + lane * 4, true, a.err, 0xB1600005u, (a.tune >> 24) & 255, (a.tune >> 8) & 255)) dead_s = 1;
             }
+            BG_WSTAMP(4);
             __syncthreads();
             dead |= dead_s != 0;
             if (att_on) {
@@ -468,10 +504,16 @@ __global__ __launch_bounds__(BG_THREADS, 1) void speller_big_fwd_kernel(const Bi
             }
             __syncthreads();
             if (att_on) {
-                float c = 0.f;
+                float c0a = 0.f, c1a = 0.f, c2a = 0.f, c3a = 0.f;
                 const float* fc = featS + lane;
-                for (int t = wave; t < Tp; t += BG_NW) c = fmaf(aS[t], fc[t * 64], c);
-                cred[wave * 64 + lane] = c;
+                int t = wave;
+                for (; t + 3 * BG_NW < Tp; t += 4 * BG_NW) {
+                    const float a0 = aS[t], a1 = aS[t + BG_NW], a2 = aS[t + 2 * BG_NW], a3 = aS[t + 3 * BG_NW];
+                    const float x0 = fc[t * 64], x1 = fc[(t + BG_NW) * 64], x2 = fc[(t + 2 * BG_NW) * 64], x3 = fc[(t + 3 * BG_NW) * 64];
+                    c0a = fmaf(a0, x0, c0a); c1a = fmaf(a1, x1, c1a); c2a = fmaf(a2, x2, c2a); c3a = fmaf(a3, x3, c3a);
+                }
+                for (; t < Tp; t += BG_NW) c0a = fmaf(aS[t], fc[t * 64], c0a);
+                cred[wave * 64 + lane] = (c0a + c1a) + (c2a + c3a);
             }
             __syncthreads();
             BG_STAMP(6);
@@ -479,16 +521,15 @@ __global__ __launch_bounds__(BG_THREADS, 1) void speller_big_fwd_kernel(const Bi
                 float c = 0.f;
 #pragma unroll
                 for (int w = 0; w < BG_NW; ++w) c += cred[w * 64 + lane];
-                st1_agent(a.ctx_all + ((size_t)(s + 1) * B + ab) * BG_HS + aj * 64 + lane, c);
+                // hand-off copy [k-block][utterance][16]: half lines from the producer, 1 KB per load instruction of the cells; row-major stash for the
+                // backward pass and the logits
+                st1_agent(a.hx + ((size_t)2 * U + s) * BG_WGS * 64 + (((aj * 4 + (lane >> 4)) * 16 + ab) * 16 + (lane & 15)), c);
+                a.ctx_all[((size_t)(s + 1) * B + ab) * BG_HS + aj * 64 + lane] = c;
                 if (lane == 0) st1_agent(reinterpret_cast<float*>(const_cast<unsigned*>(fl)) + 2 * BG_WGS + ab * 16 + aj, 0.f);
+                BG_WSTAMP(5);
             }
         }
         BG_STAMP(7);
-        // ================= [4] recurrent half of the next top cell (h1_s is there: the flags of [3] said so)
-        if (s + 1 < U) {
-            load_h(a.hx + ((size_t)U + s) * BG_WGS * 64, ax, 0xB1600008u);
-            acc1 = seg_mfma(ax, wh1, acc1);
-        }
         BG_STAMP(8);
     }
 }
@@ -509,7 +550,7 @@ bool speller_big_shape(int B, int Tp, int Hs, int D, int M, int V, int L, int he
     return true;
 }
 
-size_t speller_big_hx_floats(int U) { return (size_t)2 * U * BG_WGS * 64; }
+size_t speller_big_hx_floats(int U) { return (size_t)3 * U * BG_WGS * 64; }
 size_t speller_big_qp_floats(int B, int U) { return (size_t)U * B * BG_WGS * BG_M; }
 size_t speller_big_flag_words(int U) { return (size_t)U * 3 * BG_WGS; }
 
@@ -540,11 +581,10 @@ int speller_big_fwd(const BigFwd& p, hipStream_t stream) {
     a.hx = p.hx; a.qp = p.qp; a.flags = p.flags;
     a.B = p.B; a.Tp = p.Tp; a.U = p.U; a.relu = p.relu; a.err = p.err;
     a.trace = g_big_trace;
+    a.tune = (int)opt_get(OPT_SPELLER_BIG_TUNE);
     if (!big_fits(p.Tp))
         return fail(LAS_ERR_UNSUPPORTED, "one-launch decode (Hs = 1024): %s%ld workgroups cannot all be resident", "", (long)BG_WGS);
-    // sentinel-fill what the phases hand over: the contexts of steps 1..U, the producer-major copies of h, the query slices and the flags
-    const size_t sH = (size_t)p.B * BG_HS;
-    LAS_HIP_CHECK(hipMemsetAsync(p.ctx_all + sH, 0xFF, sizeof(float) * (size_t)p.U * sH, stream));
+    // sentinel-fill what the phases hand over: the operand-order copies of h and of the contexts, the query slices and the flags
     LAS_HIP_CHECK(hipMemsetAsync(p.hx, 0xFF, sizeof(float) * speller_big_hx_floats(p.U), stream));
     if ((float*)p.flags == p.qp + speller_big_qp_floats(p.B, p.U)) {      // adjacent (the layout las_capi.hip uses): one fill
         LAS_HIP_CHECK(hipMemsetAsync(p.qp, 0xFF, sizeof(float) * (speller_big_qp_floats(p.B, p.U) + speller_big_flag_words(p.U)), stream));

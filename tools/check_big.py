@@ -29,7 +29,7 @@ def run(B, Tp, U, scale=None, trace_on=True):
     L = _cabi.lib()
     L.las_debug_big_trace.argtypes = [ctypes.c_void_p]
     L.las_debug_big_trace.restype = None
-    trace = torch.zeros(64 * 16, dtype=torch.int64, device="cuda")
+    trace = torch.zeros(64 * 16 + 256 * 8, dtype=torch.int64, device="cuda")
     res = []
     for force in (False, True):
         sp.force_generic = force
@@ -75,7 +75,14 @@ def run(B, Tp, U, scale=None, trace_on=True):
     sp.force_generic = False
     print(f"  forward: one launch {out[False]:.3f} ms, per-step launches {out[True]:.3f} ms  ({out[False] * 1e3 / U:.2f} / {out[True] * 1e3 / U:.2f} us per decode step)")
     if ran and trace_on:
-        t = trace.cpu().numpy().reshape(64, 16)
+        tall = trace.cpu().numpy()
+        t = tall[:1024].reshape(64, 16)
+        ws = tall[1024:].reshape(256, 8).astype(np.float64) / 100.0
+        if U > 10:
+            base = ws[:, 0].min()
+            for k, nm in enumerate(["ctx flags seen", "h0 published", "h0 flags seen", "h1 + query parts published", "h1 flags seen", "ctx published", "W_hh1 product done"]):
+                v = ws[:, k] - base
+                print(f"    step 10, all workgroups, {nm}: min {v.min():.2f} median {np.median(v):.2f} max {v.max():.2f} us; by XCD (max): " + " ".join(f"{v[x::8].max():.2f}" for x in range(8)))
         n = min(U, 64)
         if n > 4:
             d = np.diff(t[2:n, :9].astype(np.float64), axis=1).mean(0) / 100.0     # 100 MHz shader clock counter -> us
