@@ -322,6 +322,19 @@ def test_persistent_decode_kernel_matches_stepwise(cfg_name, B, Tp, U, scale):
     _persistent_vs_stepwise(cfg_name, B, Tp, U, scale, "relu")
 
 
+@pytest.mark.parametrize("B,Tp,U,scale,activate", [(16, 100, 12, None, "relu"), (3, 8, 6, 0.08, "relu"), (16, 200, 5, None, "relu"),
+                                                    (5, 37, 7, 0.08, "relu"), (1, 1, 3, None, "relu"), (16, 256, 3, None, "relu"),
+                                                    (7, 130, 4, None, "None"), (16, 100, 72, None, "relu")])
+def test_one_launch_decode_of_the_yaml_sizes_matches_stepwise(B, Tp, U, scale, activate):
+    """speller_big.hip (Speller 1024x2, attention MLP 64, B <= 16, T' <= 256: the reference's config/librispeech-config.yaml) against the
+    per-step launch chain: log-probs, attention weights and every gradient (the per-step backward consumes the stash the kernel wrote:
+    h, c, gates, queries, contexts).  Cases: a full batch at T = 800, partial batches (rows beyond B are never stored), a single frame,
+    the longest eligible encoder output, no attention activation, more than 64 steps (the trace buffer's depth; U = 72 and not 70: with
+    this seed one query pre-activation of step 69 is within an ulp of 0, and the PER-STEP path's own run-to-run summation order — atomic
+    split-K — flips its relu mask in about a third of the runs)."""
+    _persistent_vs_stepwise("Y", B, Tp, U, scale, activate, big=True)
+
+
 def test_persistent_decode_kernel_without_attention_activation():
     """mlp_activate_in_attention=None (reference las_model.py:262-264: no activation on phi/psi): the relu masks of the
     forward query and of its backward are switched off by a run-time flag in the persistent kernels."""
@@ -363,7 +376,7 @@ def test_pre_multiplied_context_backward_matches_classic_persistent_backward(cfg
     _check_err()
 
 
-def _persistent_vs_stepwise(cfg_name, B, Tp, U, scale, activate):
+def _persistent_vs_stepwise(cfg_name, B, Tp, U, scale, activate, big=False):
     """The one-launch teacher-forced decode loop (speller_persist.hip) against the per-step launch chain it replaces:
     outputs and every gradient (the backward pass consumes the stash the forward kernel wrote).  The larger-weight
     cases stay at U(-0.1,0.1): with the U(-0.5,0.5) set the attention softmax is an arg-max over energies of order 1e3
@@ -387,11 +400,13 @@ def _persistent_vs_stepwise(cfg_name, B, Tp, U, scale, activate):
     L = _cabi.lib()
     L.las_debug_persist_trace.argtypes = [ctypes.c_void_p]
     L.las_debug_persist_trace.restype = None
-    trace = torch.zeros(3 * U * 8, dtype=torch.int64, device="cuda")      # las_debug_persist_trace: 3 roles x U steps x 8 stamps
+    # las_debug_persist_trace: 3 roles x U steps x 8 stamps; las_debug_big_trace (speller_big.hip): 64 steps x 16 + 256 workgroups x 8
+    trace = torch.zeros(64 * 16 + 256 * 8 if big else 3 * U * 8, dtype=torch.int64, device="cuda")
+    set_trace = L.las_debug_big_trace if big else L.las_debug_persist_trace
     res = []
     for force in (False, True):
         sp.force_generic = force
-        L.las_debug_persist_trace(trace.data_ptr() if not force else None)
+        set_trace(trace.data_ptr() if not force else None)
         try:
             sp.zero_grad(set_to_none=True)
             feat = feat0.clone().requires_grad_(True)
@@ -402,7 +417,7 @@ def _persistent_vs_stepwise(cfg_name, B, Tp, U, scale, activate):
                             dfeat=feat.grad.cpu().numpy(), **{"d" + n: p.grad.cpu().numpy() for n, p in sp.named_parameters()}))
         finally:
             sp.force_generic = False
-            L.las_debug_persist_trace(None)
+            set_trace(None)
     torch.cuda.synchronize()
     assert int(trace.abs().sum().item()) != 0, "the persistent kernel did not run (shape not eligible?)"
     for k in res[0]:
@@ -480,10 +495,11 @@ def test_persistent_free_running_decode_matches_stepwise(cfg_name, B, Tp, U, dec
     L.las_debug_persist_trace.argtypes = [ctypes.c_void_p]
     L.las_debug_persist_trace.restype = None
     trace = torch.zeros(3 * U * 8, dtype=torch.int64, device="cuda")      # las_debug_persist_trace: 3 roles x U steps x 8 stamps
+    set_trace = L.las_debug_persist_trace
     res = []
     for force in (False, True):
         sp.force_generic = force
-        L.las_debug_persist_trace(trace.data_ptr() if not force else None)
+        set_trace(trace.data_ptr() if not force else None)
         try:
             sp.zero_grad(set_to_none=True)
             feat = feat0.clone().requires_grad_(True)
@@ -496,7 +512,7 @@ def test_persistent_free_running_decode_matches_stepwise(cfg_name, B, Tp, U, dec
             res.append(out)
         finally:
             sp.force_generic = False
-            L.las_debug_persist_trace(None)
+            set_trace(None)
     torch.cuda.synchronize()
     assert int(trace.abs().sum().item()) != 0, "the persistent kernel did not run (shape not eligible?)"
     assert (res[0]["logp"].argmax(-1) == res[1]["logp"].argmax(-1)).all(), "arg-max sequences differ"
