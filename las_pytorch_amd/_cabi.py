@@ -53,6 +53,7 @@ PROTOTYPES = {
     "las_debug_persist_trace": (None, [_f]),
     "las_debug_persist_bwd_trace": (None, [_f]),
     "las_debug_big_trace": (None, [_f]),
+    "las_debug_big_bwd_trace": (None, [_f]),
     "las_debug_kernel_ms": (C.c_int, [C.c_int, C.POINTER(C.c_float)]),
     "las_pblstm_reserve_floats": (C.c_size_t, [C.c_int] * 4),
     "las_pblstm_fwd": (C.c_int, [_f, C.c_int, C.c_int, C.c_int, C.c_int] + [_f] * 8 + [_f, _f, _f, C.c_int, _f]),

@@ -78,7 +78,7 @@ struct SpellerLayout {
 
 struct SpellerBwdLayout {
     size_t dG_all, dz_all, dctx_all, de_all, dqpre_all, dh_top, dh_below, dh_carry, dc_carry, dx0, dK, dcat_all, dctxcat_all,
-        pxbuf, total;
+        pxbuf, bxbuf, total;
     SpellerBwdLayout(const las_speller_desc* d, int U) {
         size_t o = 0;
         const size_t B = d->B;
@@ -100,6 +100,9 @@ struct SpellerBwdLayout {
         // persistent backward kernel: the attention workgroups' dqpre parts and the sentinel-prefilled hand-off slabs
         pxbuf = o;
         if (d->L == 2 && d->multi_head == 1 && d->use_mlp) o += r4(speller_persist_bwd_workspace_floats(d->B, d->Tp, U, d->Hs, d->M));
+        // Hs = 1024 one-launch backward (speller_big.hip): gate-gradient slabs, carries, slice triples, flags
+        bxbuf = o;
+        if (speller_big_shape(d->B, d->Tp, d->Hs, d->D, d->M, d->V, d->L, d->multi_head, d->use_mlp)) o += r4(speller_big_bwd_workspace_floats(d->B, U));
         total = o;
     }
 };
@@ -380,6 +383,7 @@ int las_speller_decode_batch(const las_speller_desc* d, int teacher_forced, int 
 extern "C" void las_debug_persist_trace(unsigned long long* dev_buf) { speller_persist_set_trace(dev_buf); }
 extern "C" void las_debug_persist_bwd_trace(unsigned long long* dev_buf) { speller_persist_bwd_set_trace(dev_buf); }
 extern "C" void las_debug_big_trace(unsigned long long* dev_buf) { speller_big_set_trace(dev_buf); }
+extern "C" void las_debug_big_bwd_trace(unsigned long long* dev_buf) { speller_big_bwd_set_trace(dev_buf); }
 #ifdef LAS_REC_TRACE
 extern "C" void las_debug_rec_trace(unsigned long long* dev_buf) { rec_set_trace(dev_buf); }
 #endif
@@ -749,6 +753,22 @@ int las_speller_bwd(const las_speller_desc* d, const float* feat, const float* k
             g.C = dctx_m1; g.ldc = D; g.M = U * B; g.N = D; g.K = 4 * Hs; g.accumulate = true; g.splitk = 1;
             LAS_TRY(gemm_f32(g, stream));
             dx0_ctx = dctx_m1; ld_dx0 = D;
+        }
+    }
+    // the reference's shipped sizes (Speller 1024x2, B <= 16): the whole loop in one launch with column-resident weights
+    if (!persist_ran && hoist && err_word && !(flags & LAS_FLAG_FORCE_GENERIC) && d->relu <= LAS_ACT_RELU &&
+        speller_big_bwd_eligible(B, Tp, Hs, D, M, V, L, NH, d->use_mlp)) {
+        BigBwd p;
+        p.w_ih1 = d->w_ih[1]; p.w_hh1 = d->w_hh[1]; p.w_hh0 = d->w_hh[0]; p.w0p = reserve + lay.w0p; p.Vp = lay.Vp; p.w_phi = d->w_phi;
+        p.feat = feat; p.keys = keys; p.att = att; p.q_all = q_all; p.gates_all = gates_all; p.c_all = c_all; p.dcat_all = dcat_all;
+        p.dG_all = dG_all; p.dctx_all = dctx_all; p.de_all = de_all; p.dqpre_all = dqpre_all;
+        p.xbuf = workspace + wl.bxbuf;
+        p.B = B; p.Tp = Tp; p.U = U; p.V = V; p.relu = d->relu; p.err = err_word;
+        const int rc = speller_big_bwd(p, stream);
+        if (rc != LAS_ERR_UNSUPPORTED) {
+            LAS_TRY(rc);
+            persist_ran = true;
+            dx0_ctx = const_cast<float*>(speller_big_bwd_dx0_ctx(p.xbuf, U)); ld_dx0 = Hs;
         }
     }
     for (int s = persist_ran ? -1 : U - 1; s >= 0; --s) {

@@ -198,6 +198,21 @@ size_t speller_big_qp_floats(int B, int U);
 size_t speller_big_flag_words(int U);
 int speller_big_fwd(const BigFwd& p, hipStream_t stream);
 void speller_big_set_trace(unsigned long long* dev_buf);
+// ... and its backward (speller_big.hip): all U steps of the decode loop's backward in one launch, weights resident column-wise
+struct BigBwd {
+    const float* w_ih1; const float* w_hh1; const float* w_hh0; const float* w0p; int Vp; const float* w_phi;
+    const float* feat; const float* keys; const float* att; const float* q_all; const float* gates_all; const float* c_all;
+    const float* dcat_all;                          // (U*B, Hs + D): dz W_c of every step
+    float* dG_all; float* dctx_all; float* de_all; float* dqpre_all;      // per-step gradients for the deferred GEMMs
+    float* xbuf;                                    // speller_big_bwd_workspace_floats(), 16-byte aligned
+    int B, Tp, U, V, relu;
+    unsigned* err;
+};
+bool speller_big_bwd_eligible(int B, int Tp, int Hs, int D, int M, int V, int L, int heads, int use_mlp);
+size_t speller_big_bwd_workspace_floats(int B, int U);
+int speller_big_bwd(const BigBwd& p, hipStream_t stream);
+const float* speller_big_bwd_dx0_ctx(const float* xbuf, int U);      // (16, 1024) row-major: gradient of the initial context
+void speller_big_bwd_set_trace(unsigned long long* dev_buf);
 
 // Persistent backward of the teacher-forced decode loop (speller_persist_bwd.hip): one launch for all U steps.
 struct PersistBwd {

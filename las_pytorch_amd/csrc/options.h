@@ -34,6 +34,7 @@ enum Opt : int {
     OPT_SIDE_FILLS,             // sentinel fills of the decode kernels' hand-off slabs on a side stream (off: measured slower, see las_hip.h)
     OPT_TRUST_ZEROED_GRADS,     // honour LAS_FLAG_GRADS_ZEROED (skip the gradient-block memsets of the backward entry points); 0: always fill (A/B)
     OPT_SPELLER_BIG,            // one-launch decode forward for Hs = 1024 (speller_big.hip)
+    OPT_SPELLER_BIG_BWD,        // ... and its backward
     OPT_SPELLER_BIG_TUNE,       // ... its poll pacing in units of 64 clocks: byte 0 before the first h0 poll, byte 1 between polls, byte 2 / 3 before the first ctx / h1 poll
     OPT_TIME_KERNELS,           // record HIP events around the persistent decode kernels (las_debug_kernel_ms reads them)
     OPT_COUNT

@@ -538,11 +538,347 @@ size_t big_fwd_smem(int Tp) {
     return sizeof(float) * ((size_t)BG_NW * 16 * 17 + BG_NW * BG_M + BG_NW * 64 + BG_M * 4 + 16 + BG_MAXTP + (size_t)Tp * BG_KLD + (size_t)Tp * 64);
 }
 
+// ==================================================================================================================================
+// Backward of the same loop in one launch (reference: autograd through model/las_model.py:178-184, 205-236, 275-297 for all U steps).
+//
+// Per step the four products dX = dG . W contract over the 4096 gate rows, so the weights are held COLUMN-wise: workgroup (matrix m, block j)
+// keeps 16 columns x 4096 rows of ONE of [W_ih1 | W_hh1 | W_ctx | W_hh0] in registers (128 VGPRs per lane as v_mfma_f32_16x16x4_f32 B
+// operands, 8 waves split K) and multiplies the 16 utterances' gate gradients (a [256 k-blocks][16][16] slab, 256 KB per step and layer)
+// by them.  The workgroup that produces a block of dh also applies that block's cell backward (gates, c from the forward stash; dc is a
+// register carried across steps) and publishes the resulting dG block as four whole 1 KB lines of the next slab:
+//   W_hh1 block j: keeps its product (the recurrent carry of dh1) in registers, adds dcat_h + dqpre . W_phi (16 more MFMAs) at the next step
+//                  and applies the top cell's backward             -> dG1
+//   W_ih1 block j: dh0 = dG1 . W_ih1 + carry (from W_hh0 block j)  -> bottom cell's backward -> dG0
+//   W_ctx block j: the context gradient carried into the previous step; W_hh0 block j: the recurrent carry of dh0.
+// Attention backward of utterance b is sliced over 16 workgroups BY TIME (features of T'/16 frames in LDS): da_t = dctx . feat_t, then the
+// three slice sums S = sum a da, P1 = sum a da keys, P2 = sum a keys; workgroup (b, 0) adds the 16 triples, dq = P1 - S P2, dqpre = dq act'(q).
+// Chain per step: dctx -> slices -> combine -> top cell -> W_ih1 product + bottom cell -> W_ctx product: five hand-offs (flags + sentinel
+// slabs as in the forward kernel).
+constexpr int BB_APLD = 132;     // one slice triple: S, 3 pad, P1[64], P2[64]
+constexpr int BB_FLK = 5;        // flag kinds per step: dctx carry (64 producers) | slice triples (16 B) | dqpre (B) | dG1 (64) | dG0 (64)
+constexpr int BB_MAXFR = 16;
+
+struct BigBwdArgs {
+    const float* w_ih1; const float* w_hh1; const float* w_hh0; const float* w0p; long ldw0; int Vp;
+    const float* w_phi;
+    const float* feat; const float* keys; const float* att; const float* q_all; const float* gates_all; const float* c_all;
+    const float* dcat_all;
+    float* dG_all; float* dctx_all; float* de_all; float* dqpre_all;
+    float* dg1x; float* dg0x; float* dcx; float* dh0c; float* apart; unsigned* flags;
+    int B, Tp, U, FR, relu, tune;
+    unsigned* err;
+    u64* trace;
+};
+
+__device__ __forceinline__ float ld1_checked(const float* p, unsigned* err, unsigned code, bool& dead) {
+    unsigned v = __builtin_nontemporal_load(reinterpret_cast<const unsigned*>(p));
+    unsigned spins = 0;
+    while (v == PS_SENT) {
+        v = ld1_agent(p);
+        if (v != PS_SENT) break;
+        if (dead || spin_expired(spins, err, code)) { dead = true; break; }
+    }
+    return __uint_as_float(v);
+}
+
+#define BB_STAMP(slot) do { if (a.trace && (wg & 63) == 0 && tid == 0 && (U - 1 - s) < 64) a.trace[((wg >> 6) * 64 + (U - 1 - s)) * 16 + (slot)] = wall_clock64(); } while (0)
+
+__global__ __launch_bounds__(BG_THREADS, 1) void speller_big_bwd_kernel(const BigBwdArgs a) {
+    extern __shared__ float lds[];
+    float* red = lds;                              // [8 waves + phi part][16 utterances][17]
+    float* dctxS = red + 9 * 16 * 17;              // [1024]: context gradient of this workgroup's utterance
+    float* part = dctxS + BG_HS;                   // [8 waves][132]: slice triple parts
+    float* adS = part + BG_NW * BB_APLD;           // [16 frames][2]: (a_t, da_t) of the slice
+    float* keysS = adS + 2 * BB_MAXFR;             // [FR][68]
+    float* featS = keysS + a.FR * BG_KLD;          // [FR][1024]
+    __shared__ int dead_s;
+
+    const int wg = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, r = lane & 15, kq = lane >> 4;
+    const int B = a.B, U = a.U, Tp = a.Tp, FR = a.FR;
+    const size_t sH = (size_t)B * BG_HS;
+    const int mt = wg >> 6, jb = wg & 63;          // matrix role: 0 W_ih1, 1 W_hh1, 2 W_ctx, 3 W_hh0; column block jb (16 columns)
+
+    // ---- resident weights: k-blocks [32 wave, 32 wave + 32) of the 4096 gate rows, columns 16 jb + (lane & 15)
+    f32x4 wreg[32];
+    {
+        const float* W = mt == 0 ? a.w_ih1 : mt == 1 ? a.w_hh1 : mt == 2 ? a.w0p + a.Vp : a.w_hh0;
+        const long ld = mt == 2 ? a.ldw0 : BG_HS;
+        const float* wp = W + (long)(wave * 512 + kq * 4) * ld + jb * 16 + r;
+#pragma unroll
+        for (int i = 0; i < 32; ++i)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) wreg[i][e] = wp[(long)(i * 16 + e) * ld];
+    }
+    f32x4 wpr[4];                                   // W_hh1 role, wave 0: phi rows [16 i + 4 kq, +4) x this block's columns
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) wpr[i][e] = (mt == 1 && wave == 0) ? a.w_phi[(long)(i * 16 + kq * 4 + e) * BG_HS + jb * 16 + r] : 0.f;
+
+    // ---- cell-backward threads: utterance pb, column pn of the block
+    const int pb = tid >> 4, pn = tid & 15;
+    const bool pw_on = tid < 256 && pb < B;
+    float dc_st = 0.f, carry1 = 0.f;
+
+    // ---- attention slice of this workgroup: frames [t0, t0 + nfr) of utterance ab
+    const int ab = 2 * (wg & 7) + ((wg >> 3) & 1), aj = wg >> 4;
+    const bool att_on = ab < B;
+    const int t0 = aj * FR;
+    const int nfr = att_on ? max(0, min(FR, Tp - t0)) : 0;
+    for (int idx = tid; idx < nfr * 256; idx += BG_THREADS) {
+        const int f = idx >> 8, c4 = idx & 255;
+        *reinterpret_cast<f32x4*>(featS + f * BG_HS + c4 * 4) = ld4p(a.feat + ((size_t)ab * Tp + t0 + f) * BG_HS + c4 * 4);
+    }
+    for (int idx = tid; idx < nfr * 16; idx += BG_THREADS) {
+        const int f = idx >> 4, m4 = idx & 15;
+        *reinterpret_cast<f32x4*>(keysS + f * BG_KLD + m4 * 4) = ld4p(a.keys + ((size_t)ab * Tp + t0 + f) * BG_M + m4 * 4);
+    }
+    if (tid == 0) dead_s = 0;
+    __syncthreads();
+    bool dead = false;
+    const int rowb = min(r, B - 1);
+    const int gap = (a.tune >> 8) & 255;
+
+    // product of one 256 KB gate-gradient slab with the resident columns: four chunks of 8 k-blocks per wave
+    auto slab_product = [&](const float* slab, unsigned code) {
+        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+        const float* base = slab + ((size_t)(wave * 32) * 16 + rowb) * 16 + kq * 4;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            f32x4 ax[8];
+            const float* p = at_bytes(base, opaque((unsigned)(c * 8 * 256 * 4)));
+            ld4x8_kb<true>(p, ax);
+            if (__any(any_sentinel8(ax))) {
+                unsigned spins = 0;
+                for (;;) {
+                    ld4x8_kb<false>(p, ax);
+                    if (!__any(any_sentinel8(ax))) break;
+                    if (dead || spin_expired(spins, a.err, code)) { dead = true; break; }
+                }
+            }
+#pragma unroll
+            for (int i = 0; i < 8; ++i)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(ax[i][e], wreg[c * 8 + i][e], acc, 0, 0, 0);
+        }
+#pragma unroll
+        for (int rr = 0; rr < 4; ++rr) red[(wave * 16 + kq * 4 + rr) * 17 + r] = acc[rr];
+    };
+    // cell backward of (utterance pb, unit 16 jb + pn) of layer l at step s; publishes the four gate gradients
+    auto cell_bwd = [&](int l, int s, float dh, float* slab) {
+        const int unit = jb * 16 + pn;
+        const size_t o = ((size_t)l * U + s) * sH + (size_t)pb * BG_HS + unit;
+        const float* gp = a.gates_all + 4 * (((size_t)l * U + s) * sH) + (size_t)pb * 4 * BG_HS + unit;
+        const float ig = gp[0], fg = gp[BG_HS], gg = gp[2 * BG_HS], og = gp[3 * BG_HS];
+        const float tc = tanhf_acc(a.c_all[o]);
+        const float cp = s > 0 ? a.c_all[o - sH] : 0.f;
+        const float dct = dc_st + dh * og * (1.f - tc * tc);
+        float dg[4];
+        dg[0] = dct * gg * ig * (1.f - ig);
+        dg[1] = dct * cp * fg * (1.f - fg);
+        dg[2] = dct * ig * (1.f - gg * gg);
+        dg[3] = dh * tc * og * (1.f - og);
+        dc_st = dct * fg;
+        float* go = a.dG_all + 4 * (((size_t)l * U + s) * sH) + (size_t)pb * 4 * BG_HS + unit;
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            st1_agent(slab + ((size_t)(g * 64 + jb) * 16 + pb) * 16 + pn, dg[g]);      // k-block (gate, block): [16 utterances][16 units]
+            go[g * BG_HS] = dg[g];
+        }
+    };
+
+    for (int s = U - 1; s >= 0; --s) {
+        const bool last = s == U - 1;
+        unsigned* fl = a.flags + (size_t)s * BB_FLK * 256;
+        BB_STAMP(0);
+        if (att_on) {
+            // ---- attention weights' gradient of the PREVIOUS iteration's step, off the chain: de_t = a_t (da_t - S), S from the 16 slice triples
+            if (!last && wave == 1) {
+                const float* apb = a.apart + ((size_t)(s + 1) * B + ab) * 16 * BB_APLD;
+                const float si = ld1_checked(apb + (size_t)(lane & 15) * BB_APLD, a.err, 0xB1610001u, dead);
+                const float st = lane_f(gsum<16>(si), 0);
+                if (lane < nfr) a.de_all[((size_t)(s + 1) * B + ab) * Tp + t0 + lane] = adS[lane * 2] * (adS[lane * 2 + 1] - st);
+            }
+            // ================= (A) slice triple of this step
+            if (!last && wave == 0 && !dead) {
+                if (flags_wait(fl + BB_FLK * 256 + lane * 4, lane < 16, a.err, 0xB1610002u, 0, gap)) dead_s = 1;
+            }
+            __syncthreads();
+            dead |= dead_s != 0;
+            {
+                const int c = tid * 2;
+                const float* dc = a.dcat_all + ((size_t)s * B + ab) * (2 * BG_HS) + BG_HS + c;
+                float v0 = dc[0], v1 = dc[1];
+                if (!last) {
+                    const float* cx = a.dcx + ((size_t)(s + 1) * BG_NB + ab) * BG_HS + c;
+                    v0 += ld1_checked(cx, a.err, 0xB1610003u, dead);
+                    v1 += ld1_checked(cx + 1, a.err, 0xB1610003u, dead);
+                }
+                dctxS[c] = v0; dctxS[c + 1] = v1;
+                if (aj == 0) { float* o = a.dctx_all + ((size_t)s * B + ab) * BG_HS + c; o[0] = v0; o[1] = v1; }
+            }
+            __syncthreads();
+            BB_STAMP(1);
+            float p1 = 0.f, p2 = 0.f, ssum = 0.f;
+            for (int f = wave; f < nfr; f += BG_NW) {
+                const float* fr = featS + f * BG_HS + lane * 4;
+                float acc = 0.f;
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+                    acc = dot4p(*reinterpret_cast<const f32x4*>(fr + 256 * i), *reinterpret_cast<const f32x4*>(dctxS + lane * 4 + 256 * i), acc);
+                const float da = wsum(acc);
+                const float af = a.att[((size_t)s * B + ab) * Tp + t0 + f];
+                const float kv = keysS[f * BG_KLD + lane];
+                p1 = fmaf(af * da, kv, p1); p2 = fmaf(af, kv, p2); ssum = fmaf(af, da, ssum);
+                if (lane == 0) { adS[f * 2] = af; adS[f * 2 + 1] = da; }
+            }
+            part[wave * BB_APLD + 4 + lane] = p1; part[wave * BB_APLD + 68 + lane] = p2;
+            if (lane == 0) part[wave * BB_APLD] = ssum;
+            __syncthreads();
+            if (wave == 0) {
+                float q1 = 0.f, q2 = 0.f, qs = 0.f;
+#pragma unroll
+                for (int w = 0; w < BG_NW; ++w) { q1 += part[w * BB_APLD + 4 + lane]; q2 += part[w * BB_APLD + 68 + lane]; qs += part[w * BB_APLD]; }
+                float* ap = a.apart + (((size_t)s * B + ab) * 16 + aj) * BB_APLD;
+                st1_agent(ap + 4 + lane, q1); st1_agent(ap + 68 + lane, q2);
+                if (lane == 0) { st1_agent(ap, qs); st1_agent(reinterpret_cast<float*>(fl) + 256 + ab * 16 + aj, 0.f); }
+                BB_STAMP(2);
+                // ================= (B) workgroup (ab, 0): add the 16 triples, dq = P1 - S P2, dqpre = dq act'(q)
+                if (aj == 0) {
+                    if (!dead && flags_wait(fl + 256 + ab * 16 + lane * 4, lane < 4, a.err, 0xB1610004u, 0, gap)) { dead = true; dead_s = 1; }
+                    const float* apb = a.apart + ((size_t)s * B + ab) * 16 * BB_APLD;
+                    unsigned vs = 0;
+                    float t1 = 0.f, t2 = 0.f;
+                    unsigned spins = 0;
+                    for (;;) {
+                        bool bad = false;
+                        t1 = 0.f; t2 = 0.f;
+#pragma unroll
+                        for (int i = 0; i < 16; ++i) {
+                            const unsigned x1 = ld1_agent(apb + (size_t)i * BB_APLD + 4 + lane), x2 = ld1_agent(apb + (size_t)i * BB_APLD + 68 + lane);
+                            bad |= x1 == PS_SENT || x2 == PS_SENT;
+                            t1 += __uint_as_float(x1); t2 += __uint_as_float(x2);
+                        }
+                        vs = ld1_agent(apb + (size_t)(lane & 15) * BB_APLD);
+                        bad |= vs == PS_SENT;
+                        if (!__any(bad)) break;
+                        if (dead || spin_expired(spins, a.err, 0xB1610005u)) { dead = true; dead_s = 1; break; }
+                    }
+                    const float st = lane_f(gsum<16>(__uint_as_float(vs)), 0);
+                    float dq = t1 - st * t2;
+                    if (a.relu) dq *= act_grad(a.q_all[((size_t)s * B + ab) * BG_M + lane], a.relu);
+                    st1_agent(a.dqpre_all + ((size_t)s * B + ab) * BG_M + lane, dq);
+                    if (lane == 0) st1_agent(reinterpret_cast<float*>(fl) + 2 * 256 + ab, 0.f);
+                    BB_STAMP(3);
+                }
+            }
+        }
+        // ================= (C) top cell's backward: W_hh1 blocks
+        if (mt == 1) {
+            if (wave == 0) {
+                if (!dead && flags_wait(fl + 2 * 256 + lane * 4, lane * 4 < B, a.err, 0xB1610006u, 0, gap)) { dead = true; dead_s = 1; }
+                f32x4 aq[4];
+                const float* qp = a.dqpre_all + ((size_t)s * B + rowb) * BG_M + kq * 4;
+                unsigned spins = 0;
+                for (;;) {
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) aq[i] = ld4_agent(qp + i * 16);
+                    if (!__any(has_sentinel(aq[0]) || has_sentinel(aq[1]) || has_sentinel(aq[2]) || has_sentinel(aq[3]))) break;
+                    if (dead || spin_expired(spins, a.err, 0xB1610007u)) { dead = true; dead_s = 1; break; }
+                }
+                f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(aq[i][e], wpr[i][e], acc, 0, 0, 0);
+#pragma unroll
+                for (int rr = 0; rr < 4; ++rr) red[(8 * 16 + kq * 4 + rr) * 17 + r] = acc[rr];
+            }
+            __syncthreads();
+            dead |= dead_s != 0;
+            BB_STAMP(4);
+            if (pw_on) {
+                const float dh = red[(8 * 16 + pb) * 17 + pn] + a.dcat_all[((size_t)s * B + pb) * (2 * BG_HS) + jb * 16 + pn] + carry1;
+                cell_bwd(1, s, dh, a.dg1x + (size_t)s * 65536);
+            }
+            __syncthreads();
+            if (tid == 0) st1_agent(reinterpret_cast<float*>(fl) + 3 * 256 + jb, 0.f);
+            BB_STAMP(5);
+        }
+        // ================= (D) products with dG1: W_ih1 blocks (+ bottom cell's backward), W_hh1 blocks (recurrent carry of dh1)
+        if (mt <= 1) {
+            if (wave == 0 && !dead) {
+                if (flags_wait(fl + 3 * 256 + lane * 4, lane < 16, a.err, 0xB1610008u, a.tune & 255, gap)) dead_s = 1;
+            }
+            __syncthreads();
+            dead |= dead_s != 0;
+            BB_STAMP(6);
+            slab_product(a.dg1x + (size_t)s * 65536, 0xB1610009u);
+            __syncthreads();
+            BB_STAMP(7);
+            float cs = 0.f;
+            if (tid < 256) {
+#pragma unroll
+                for (int w = 0; w < BG_NW; ++w) cs += red[(w * 16 + pb) * 17 + pn];
+            }
+            if (mt == 1) {
+                carry1 = cs;
+            } else {
+                if (pw_on) {
+                    float dh = cs;
+                    if (!last) dh += ld1_checked(a.dh0c + (((size_t)(s + 1) * 64 + jb) * 16 + pb) * 16 + pn, a.err, 0xB161000Au, dead);
+                    cell_bwd(0, s, dh, a.dg0x + (size_t)s * 65536);
+                }
+                __syncthreads();
+                if (tid == 0) st1_agent(reinterpret_cast<float*>(fl) + 4 * 256 + jb, 0.f);
+            }
+            BB_STAMP(8);
+        }
+        // ================= (E) products with dG0: W_ctx blocks (context gradient carried into step s-1), W_hh0 blocks (recurrent carry of dh0)
+        if (mt >= 2) {
+            if (wave == 0 && !dead) {
+                if (flags_wait(fl + 4 * 256 + lane * 4, lane < 16, a.err, 0xB161000Bu, (a.tune >> 16) & 255, gap)) dead_s = 1;
+            }
+            __syncthreads();
+            dead |= dead_s != 0;
+            BB_STAMP(6);
+            slab_product(a.dg0x + (size_t)s * 65536, 0xB161000Cu);
+            __syncthreads();
+            BB_STAMP(7);
+            if (pw_on) {
+                float cs = 0.f;
+#pragma unroll
+                for (int w = 0; w < BG_NW; ++w) cs += red[(w * 16 + pb) * 17 + pn];
+                if (mt == 2) st1_agent(a.dcx + ((size_t)s * BG_NB + pb) * BG_HS + jb * 16 + pn, cs);
+                else st1_agent(a.dh0c + (((size_t)s * 64 + jb) * 16 + pb) * 16 + pn, cs);
+            }
+            if (mt == 2) {
+                __syncthreads();
+                if (tid == 0) st1_agent(reinterpret_cast<float*>(fl) + jb, 0.f);
+            }
+            BB_STAMP(8);
+        }
+    }
+    // attention weights' gradient of step 0
+    if (att_on && wave == 1) {
+        const float* apb = a.apart + ((size_t)ab) * 16 * BB_APLD;
+        const float si = ld1_checked(apb + (size_t)(lane & 15) * BB_APLD, a.err, 0xB161000Du, dead);
+        const float st = lane_f(gsum<16>(si), 0);
+        if (lane < nfr) a.de_all[((size_t)ab) * Tp + t0 + lane] = adS[lane * 2] * (adS[lane * 2 + 1] - st);
+    }
+}
+
+size_t big_bwd_smem(int FR) {
+    return sizeof(float) * ((size_t)9 * 16 * 17 + BG_HS + BG_NW * BB_APLD + 2 * BB_MAXFR + (size_t)FR * BG_KLD + (size_t)FR * BG_HS);
+}
+
+u64* g_big_bwd_trace = nullptr;
 u64* g_big_trace = nullptr;
 
 }  // namespace
 
 void speller_big_set_trace(unsigned long long* dev_buf) { g_big_trace = dev_buf; }
+void speller_big_bwd_set_trace(unsigned long long* dev_buf) { g_big_bwd_trace = dev_buf; }
 
 bool speller_big_shape(int B, int Tp, int Hs, int D, int M, int V, int L, int heads, int use_mlp) {
     if (L != 2 || heads != 1 || !use_mlp || M != BG_M || Hs != BG_HS || D != BG_HS) return false;
@@ -599,5 +935,54 @@ int speller_big_fwd(const BigFwd& p, hipStream_t stream) {
     LAS_LAUNCH_CHECK();
     return LAS_OK;
 }
+
+// ---- backward
+static int big_bwd_frames(int Tp) { return (Tp + 15) / 16; }
+size_t speller_big_bwd_workspace_floats(int B, int U) {
+    return (size_t)U * (2 * 65536 + BG_NB * BG_HS + 64 * 256 + (size_t)B * 16 * BB_APLD + BB_FLK * 256);
+}
+static bool big_bwd_fits(int FR) {
+    const size_t smem = big_bwd_smem(FR);
+    if (smem > 160 * 1024) return false;
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&speller_big_bwd_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem) != hipSuccess)
+        return false;
+    return persistent_launch_fits(speller_big_bwd_kernel, BG_THREADS, smem, BG_WGS);
+}
+bool speller_big_bwd_eligible(int B, int Tp, int Hs, int D, int M, int V, int L, int heads, int use_mlp) {
+    if (opt_get(OPT_SPELLER_BIG_BWD) == 0 || !speller_big_shape(B, Tp, Hs, D, M, V, L, heads, use_mlp)) return false;
+    return big_bwd_fits(big_bwd_frames(Tp));
+}
+
+int speller_big_bwd(const BigBwd& p, hipStream_t stream) {
+    LAS_REQUIRE(speller_big_shape(p.B, p.Tp, BG_HS, BG_HS, BG_M, p.V, 2, 1, 1), "one-launch decode backward (Hs = 1024) shape");
+    LAS_REQUIRE(p.err != nullptr, "the persistent speller needs the device error word");
+    LAS_REQUIRE((uintptr_t)p.xbuf % 16 == 0, "hand-off slab alignment");
+    BigBwdArgs a;
+    a.w_ih1 = p.w_ih1; a.w_hh1 = p.w_hh1; a.w_hh0 = p.w_hh0; a.w0p = p.w0p; a.ldw0 = p.Vp + BG_HS; a.Vp = p.Vp; a.w_phi = p.w_phi;
+    a.feat = p.feat; a.keys = p.keys; a.att = p.att; a.q_all = p.q_all; a.gates_all = p.gates_all; a.c_all = p.c_all; a.dcat_all = p.dcat_all;
+    a.dG_all = p.dG_all; a.dctx_all = p.dctx_all; a.de_all = p.de_all; a.dqpre_all = p.dqpre_all;
+    float* o = p.xbuf;
+    a.dg1x = o; o += (size_t)p.U * 65536;
+    a.dg0x = o; o += (size_t)p.U * 65536;
+    a.dcx = o; o += (size_t)p.U * BG_NB * BG_HS;
+    a.dh0c = o; o += (size_t)p.U * 64 * 256;
+    a.apart = o; o += (size_t)p.U * p.B * 16 * BB_APLD;
+    a.flags = reinterpret_cast<unsigned*>(o);
+    a.B = p.B; a.Tp = p.Tp; a.U = p.U; a.FR = big_bwd_frames(p.Tp); a.relu = p.relu; a.err = p.err;
+    a.tune = (int)opt_get(OPT_SPELLER_BIG_TUNE);
+    a.trace = g_big_bwd_trace;
+    if (!big_bwd_fits(a.FR))
+        return fail(LAS_ERR_UNSUPPORTED, "one-launch decode backward (Hs = 1024): %s%ld workgroups cannot all be resident", "", (long)BG_WGS);
+    LAS_HIP_CHECK(hipMemsetAsync(p.xbuf, 0xFF, sizeof(float) * speller_big_bwd_workspace_floats(p.B, p.U), stream));
+    LAS_HIP_CHECK(hipMemsetAsync(p.dqpre_all, 0xFF, sizeof(float) * (size_t)p.U * p.B * BG_M, stream));
+    {
+        KernelTimer timer(TIMED_DECODE_BWD, stream);
+        hipLaunchKernelGGL(speller_big_bwd_kernel, dim3(BG_WGS), dim3(BG_THREADS), big_bwd_smem(a.FR), stream, a);
+    }
+    LAS_LAUNCH_CHECK();
+    return LAS_OK;
+}
+// the context gradient carried out of step 0 (gradient of the initial context feat[:,0,:]): row-major (16, 1024) block inside xbuf
+const float* speller_big_bwd_dx0_ctx(const float* xbuf, int U) { return xbuf + (size_t)U * 2 * 65536; }
 
 }  // namespace las

@@ -30,10 +30,12 @@ def run(B, Tp, U, scale=None, trace_on=True):
     L.las_debug_big_trace.argtypes = [ctypes.c_void_p]
     L.las_debug_big_trace.restype = None
     trace = torch.zeros(64 * 16 + 256 * 8, dtype=torch.int64, device="cuda")
+    btrace = torch.zeros(4 * 64 * 16, dtype=torch.int64, device="cuda")
     res = []
     for force in (False, True):
         sp.force_generic = force
         L.las_debug_big_trace(trace.data_ptr() if (trace_on and not force) else None)
+        L.las_debug_big_bwd_trace(btrace.data_ptr() if (trace_on and not force) else None)
         try:
             sp.zero_grad(set_to_none=True)
             feat = feat0.clone().requires_grad_(True)
@@ -45,6 +47,7 @@ def run(B, Tp, U, scale=None, trace_on=True):
         finally:
             sp.force_generic = False
             L.las_debug_big_trace(None)
+            L.las_debug_big_bwd_trace(None)
     torch.cuda.synchronize()
     err = int(_cabi.err_word(torch.device("cuda", 0))[0].item())
     ran = int(trace.abs().sum().item()) != 0
@@ -72,7 +75,32 @@ def run(B, Tp, U, scale=None, trace_on=True):
                 sp(feat0, ground_truth=lab, teacher_force_rate=1.0)
             torch.cuda.synchronize()
             out[force] = (time.perf_counter() - t0) / n * 1e3
+    tb = {}
+    for force in (False, True):
+        sp.force_generic = force
+        def fb():
+            sp.zero_grad(set_to_none=True)
+            feat = feat0.clone().requires_grad_(True)
+            preds, _ = sp(feat, ground_truth=lab, teacher_force_rate=1.0)
+            (torch.stack(preds) * w).sum().backward()
+        for _ in range(2):
+            fb()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(5):
+            fb()
+        torch.cuda.synchronize()
+        tb[force] = (time.perf_counter() - t0) / 5 * 1e3
     sp.force_generic = False
+    print(f"  forward + backward (with the deferred GEMMs): one launch each {tb[False]:.3f} ms, per-step launches {tb[True]:.3f} ms")
+    bt = btrace.cpu().numpy().reshape(4, 64, 16).astype(np.float64) / 100.0
+    if bt[0, 2, 0] != 0 and U > 6:
+        n = min(U, 64)
+        step = np.diff(bt[0, 2:n, 0]).mean()
+        print(f"  backward trace: {step:.2f} us per step; phases by matrix role (us from the step's start):")
+        for role, nm in enumerate(["W_ih1", "W_hh1", "W_ctx", "W_hh0"]):
+            rel = (bt[role, 2:n, :9] - bt[role, 2:n, 0:1]).mean(0)
+            print(f"    {nm}: " + ", ".join(f"{k}:{v:.2f}" for k, v in enumerate(rel) if bt[role, 3, k] != 0))
     print(f"  forward: one launch {out[False]:.3f} ms, per-step launches {out[True]:.3f} ms  ({out[False] * 1e3 / U:.2f} / {out[True] * 1e3 / U:.2f} us per decode step)")
     if ran and trace_on:
         tall = trace.cpu().numpy()
