@@ -192,12 +192,14 @@ __device__ __forceinline__ void sleep_units(int n) {      // n x 64 clocks (s_sl
     for (; n >= 8; n -= 8) __builtin_amdgcn_s_sleep(8);
     for (; n > 0; --n) __builtin_amdgcn_s_sleep(1);
 }
-__device__ __forceinline__ bool flags_wait(const unsigned* fl, bool active, unsigned* err, unsigned code, int first, int gap) {
+__device__ __forceinline__ bool flags_wait(const unsigned* fl, bool active, unsigned* err, unsigned code, int first, int gap, int ncomp = 4) {
     unsigned spins = 0;
     sleep_units(first);
     for (;;) {
         const f32x4 v = ld4_agent(reinterpret_cast<const float*>(fl));
-        if (!__any(active && has_sentinel(v))) return false;
+        const bool pending = (ncomp > 0 && __float_as_uint(v[0]) == PS_SENT) || (ncomp > 1 && __float_as_uint(v[1]) == PS_SENT) ||
+                             (ncomp > 2 && __float_as_uint(v[2]) == PS_SENT) || (ncomp > 3 && __float_as_uint(v[3]) == PS_SENT);
+        if (!__any(active && pending)) return false;
         if (spin_expired(spins, err, code)) return true;
         sleep_units(gap);
     }
@@ -776,7 +778,7 @@ __global__ __launch_bounds__(BG_THREADS, 1) void speller_big_bwd_kernel(const Bi
         // ================= (C) top cell's backward: W_hh1 blocks
         if (mt == 1) {
             if (wave == 0) {
-                if (!dead && flags_wait(fl + 2 * 256 + lane * 4, lane * 4 < B, a.err, 0xB1610006u, 0, gap)) { dead = true; dead_s = 1; }
+                if (!dead && flags_wait(fl + 2 * 256 + lane * 4, lane * 4 < B, a.err, 0xB1610006u, 0, gap, B - lane * 4)) { dead = true; dead_s = 1; }
                 f32x4 aq[4];
                 const float* qp = a.dqpre_all + ((size_t)s * B + rowb) * BG_M + kq * 4;
                 unsigned spins = 0;
