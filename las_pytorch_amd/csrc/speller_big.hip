@@ -119,6 +119,29 @@ __device__ __forceinline__ void ld4x8_kb(const float* p, f32x4 (&v)[8]) {
         : "v"(p), "v"(p2)
         : "memory");
 }
+// the same loads WITHOUT the wait (software pipelining: the matrix pipe works on one chunk while the next is in flight); kb_wait() ends the
+// flight.  Between the two calls nothing may touch the registers (they are outputs of the first block only so that the allocator keeps them).
+__device__ __forceinline__ void kb_issue_l2(const float* p, f32x4 (&v)[8]) {
+    const float* p2 = p + 1024;
+    asm volatile(
+        "global_load_dwordx4 %0, %8, off\n\t"
+        "global_load_dwordx4 %1, %8, off offset:1024\n\t"
+        "global_load_dwordx4 %2, %8, off offset:2048\n\t"
+        "global_load_dwordx4 %3, %8, off offset:3072\n\t"
+        "global_load_dwordx4 %4, %9, off\n\t"
+        "global_load_dwordx4 %5, %9, off offset:1024\n\t"
+        "global_load_dwordx4 %6, %9, off offset:2048\n\t"
+        "global_load_dwordx4 %7, %9, off offset:3072"
+        : "=&v"(v[0]), "=&v"(v[1]), "=&v"(v[2]), "=&v"(v[3]), "=&v"(v[4]), "=&v"(v[5]), "=&v"(v[6]), "=&v"(v[7])
+        : "v"(p), "v"(p2)
+        : "memory");
+}
+__device__ __forceinline__ void kb_wait(f32x4 (&v)[8]) {
+    asm volatile("s_waitcnt vmcnt(0)"
+                 : "+v"(v[0]), "+v"(v[1]), "+v"(v[2]), "+v"(v[3]), "+v"(v[4]), "+v"(v[5]), "+v"(v[6]), "+v"(v[7])
+                 :
+                 : "memory");
+}
 // ... at an arbitrary byte stride (the 256 query slices of an utterance)
 template <bool L2>
 __device__ __forceinline__ void ld4x8_strided(const float* p, long stride_floats, f32x4 (&v)[8]) {
@@ -161,12 +184,18 @@ __device__ __forceinline__ bool any_sentinel8(const f32x4 (&v)[8]) {
     for (int i = 0; i < 8; ++i) bad |= has_sentinel(v[i]);
     return bad;
 }
+// (two accumulation chains: a wave's dependent v_mfma_f32_16x16x4_f32 issue ~100 clocks apart, so one chain per wave and two waves per
+// SIMD leave the matrix pipe at ~60 %)
 __device__ __forceinline__ f32x4 seg_mfma(const f32x4 (&ax)[8], const f32x4 (&w)[8], f32x4 acc) {
+    f32x4 t = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-    for (int i = 0; i < 8; ++i)
+    for (int i = 0; i < 8; i += 2)
 #pragma unroll
-        for (int e = 0; e < 4; ++e) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(ax[i][e], w[i][e], acc, 0, 0, 0);
-    return acc;
+        for (int e = 0; e < 4; ++e) {
+            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(ax[i][e], w[i][e], acc, 0, 0, 0);
+            t = __builtin_amdgcn_mfma_f32_16x16x4f32(ax[i + 1][e], w[i + 1][e], t, 0, 0, 0);
+        }
+    return acc + t;
 }
 __device__ __forceinline__ float quad_bcast(float v, int u) {      // value of lane (quad base + u), u a compile-time constant at the call sites
     switch (u) {
@@ -591,7 +620,8 @@ __global__ __launch_bounds__(BG_THREADS, 1) void speller_big_bwd_kernel(const Bi
     float* dctxS = red + 9 * 16 * 17;              // [1024]: context gradient of this workgroup's utterance
     float* part = dctxS + BG_HS;                   // [8 waves][132]: slice triple parts
     float* adS = part + BG_NW * BB_APLD;           // [16 frames][2]: (a_t, da_t) of the slice
-    float* keysS = adS + 2 * BB_MAXFR;             // [FR][68]
+    float* wphT = adS + 2 * BB_MAXFR;              // [4][64 lanes][4]: phi operands of the W_hh1 role
+    float* keysS = wphT + 1024;                    // [FR][68]
     float* featS = keysS + a.FR * BG_KLD;          // [FR][1024]
     __shared__ int dead_s;
 
@@ -611,11 +641,12 @@ __global__ __launch_bounds__(BG_THREADS, 1) void speller_big_bwd_kernel(const Bi
 #pragma unroll
             for (int e = 0; e < 4; ++e) wreg[i][e] = wp[(long)(i * 16 + e) * ld];
     }
-    f32x4 wpr[4];                                   // W_hh1 role, wave 0: phi rows [16 i + 4 kq, +4) x this block's columns
+    if (mt == 1 && wave == 0) {                     // W_hh1 role: phi rows [16 i + 4 kq, +4) x this block's columns, B operands of wave 0
 #pragma unroll
-    for (int i = 0; i < 4; ++i)
+        for (int i = 0; i < 4; ++i)
 #pragma unroll
-        for (int e = 0; e < 4; ++e) wpr[i][e] = (mt == 1 && wave == 0) ? a.w_phi[(long)(i * 16 + kq * 4 + e) * BG_HS + jb * 16 + r] : 0.f;
+            for (int e = 0; e < 4; ++e) wphT[(i * 64 + lane) * 4 + e] = a.w_phi[(long)(i * 16 + kq * 4 + e) * BG_HS + jb * 16 + r];
+    }
 
     // ---- cell-backward threads: utterance pb, column pn of the block
     const int pb = tid >> 4, pn = tid & 15;
@@ -643,28 +674,50 @@ __global__ __launch_bounds__(BG_THREADS, 1) void speller_big_bwd_kernel(const Bi
 
     // product of one 256 KB gate-gradient slab with the resident columns: four chunks of 8 k-blocks per wave
     auto slab_product = [&](const float* slab, unsigned code) {
-        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+        f32x4 acc = {0.f, 0.f, 0.f, 0.f}, acc2 = {0.f, 0.f, 0.f, 0.f};      // two chains, see seg_mfma
         const float* base = slab + ((size_t)(wave * 32) * 16 + rowb) * 16 + kq * 4;
-#pragma unroll
-        for (int c = 0; c < 4; ++c) {
-            f32x4 ax[8];
-            const float* p = at_bytes(base, opaque((unsigned)(c * 8 * 256 * 4)));
-            ld4x8_kb<true>(p, ax);
-            if (__any(any_sentinel8(ax))) {
-                unsigned spins = 0;
-                for (;;) {
-                    ld4x8_kb<false>(p, ax);
-                    if (!__any(any_sentinel8(ax))) break;
-                    if (dead || spin_expired(spins, a.err, code)) { dead = true; break; }
-                }
+        f32x4 axa[8], axb[8];
+        // a chunk whose lines were fetched into the L2 too early still shows the sentinel: re-read it at agent scope
+        auto settle = [&](const float* p, f32x4 (&ax)[8]) {
+            if (!__any(any_sentinel8(ax))) return;
+            unsigned spins = 0;
+            for (;;) {
+                ld4x8_kb<false>(p, ax);
+                if (!__any(any_sentinel8(ax))) break;
+                if (dead || spin_expired(spins, a.err, code)) { dead = true; break; }
             }
+        };
+        auto mult = [&](const f32x4 (&ax)[8], int c) {
 #pragma unroll
-            for (int i = 0; i < 8; ++i)
+            for (int i = 0; i < 8; i += 2)
 #pragma unroll
-                for (int e = 0; e < 4; ++e) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(ax[i][e], wreg[c * 8 + i][e], acc, 0, 0, 0);
-        }
+                for (int e = 0; e < 4; ++e) {
+                    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(ax[i][e], wreg[c * 8 + i][e], acc, 0, 0, 0);
+                    acc2 = __builtin_amdgcn_mfma_f32_16x16x4f32(ax[i + 1][e], wreg[c * 8 + i + 1][e], acc2, 0, 0, 0);
+                }
+        };
+        const float* p0 = at_bytes(base, opaque(0u));
+        const float* p1 = at_bytes(base, opaque(8192u));
+        const float* p2 = at_bytes(base, opaque(16384u));
+        const float* p3 = at_bytes(base, opaque(24576u));
+        kb_issue_l2(p0, axa); kb_wait(axa); settle(p0, axa);
+        kb_issue_l2(p1, axb); mult(axa, 0); kb_wait(axb); settle(p1, axb);
+        kb_issue_l2(p2, axa); mult(axb, 1); kb_wait(axa); settle(p2, axa);
+        kb_issue_l2(p3, axb); mult(axa, 2); kb_wait(axb); settle(p3, axb);
+        mult(axb, 3);
+        acc += acc2;
 #pragma unroll
         for (int rr = 0; rr < 4; ++rr) red[(wave * 16 + kq * 4 + rr) * 17 + r] = acc[rr];
+    };
+    // (D) / (E) waits last ~15 us: a workgroup that polls all the while only queues reads in front of the flag stores it is waiting for.  It sleeps
+    // three quarters of the wait it saw at the previous step before the first poll.
+    unsigned est_d = 0, est_e = 0;
+    auto long_wait = [&](const unsigned* flp, unsigned code, unsigned& est) {
+        const u64 t0 = wall_clock64();
+        sleep_units((int)min((est * 9u) >> 5, 4000u));          // est in 10 ns ticks, a sleep unit is 64 clocks ~ 28 ns: 0.75 * 10 / 28 ~ 9 / 32
+        const bool gave_up = flags_wait(flp, lane < 16, a.err, code, 0, gap);
+        est = (unsigned)(wall_clock64() - t0);
+        return gave_up;
     };
     // cell backward of (utterance pb, unit 16 jb + pn) of layer l at step s; publishes the four gate gradients
     auto cell_bwd = [&](int l, int s, float dh, float* slab) {
@@ -702,19 +755,20 @@ __global__ __launch_bounds__(BG_THREADS, 1) void speller_big_bwd_kernel(const Bi
                 if (lane < nfr) a.de_all[((size_t)(s + 1) * B + ab) * Tp + t0 + lane] = adS[lane * 2] * (adS[lane * 2 + 1] - st);
             }
             // ================= (A) slice triple of this step
-            if (!last && wave == 0 && !dead) {
-                if (flags_wait(fl + BB_FLK * 256 + lane * 4, lane < 16, a.err, 0xB1610002u, 0, gap)) dead_s = 1;
-            }
-            __syncthreads();
-            dead |= dead_s != 0;
             {
                 const int c = tid * 2;
                 const float* dc = a.dcat_all + ((size_t)s * B + ab) * (2 * BG_HS) + BG_HS + c;
                 float v0 = dc[0], v1 = dc[1];
-                if (!last) {
+                if (!last) {      // the context gradient carried out of step s+1 (W_ctx blocks): polled at agent scope, 4 KB per workgroup
                     const float* cx = a.dcx + ((size_t)(s + 1) * BG_NB + ab) * BG_HS + c;
-                    v0 += ld1_checked(cx, a.err, 0xB1610003u, dead);
-                    v1 += ld1_checked(cx + 1, a.err, 0xB1610003u, dead);
+                    unsigned x0, x1, spins = 0;
+                    for (;;) {
+                        x0 = ld1_agent(cx); x1 = ld1_agent(cx + 1);
+                        if (!__any(x0 == PS_SENT || x1 == PS_SENT)) break;
+                        if (dead || spin_expired(spins, a.err, 0xB1610003u)) { dead = true; break; }
+                        sleep_units(gap);
+                    }
+                    v0 += __uint_as_float(x0); v1 += __uint_as_float(x1);
                 }
                 dctxS[c] = v0; dctxS[c + 1] = v1;
                 if (aj == 0) { float* o = a.dctx_all + ((size_t)s * B + ab) * BG_HS + c; o[0] = v0; o[1] = v1; }
@@ -747,7 +801,6 @@ __global__ __launch_bounds__(BG_THREADS, 1) void speller_big_bwd_kernel(const Bi
                 BB_STAMP(2);
                 // ================= (B) workgroup (ab, 0): add the 16 triples, dq = P1 - S P2, dqpre = dq act'(q)
                 if (aj == 0) {
-                    if (!dead && flags_wait(fl + 256 + ab * 16 + lane * 4, lane < 4, a.err, 0xB1610004u, 0, gap)) { dead = true; dead_s = 1; }
                     const float* apb = a.apart + ((size_t)s * B + ab) * 16 * BB_APLD;
                     unsigned vs = 0;
                     float t1 = 0.f, t2 = 0.f;
@@ -765,6 +818,7 @@ __global__ __launch_bounds__(BG_THREADS, 1) void speller_big_bwd_kernel(const Bi
                         bad |= vs == PS_SENT;
                         if (!__any(bad)) break;
                         if (dead || spin_expired(spins, a.err, 0xB1610005u)) { dead = true; dead_s = 1; break; }
+                        sleep_units(gap);
                     }
                     const float st = lane_f(gsum<16>(__uint_as_float(vs)), 0);
                     float dq = t1 - st * t2;
@@ -778,7 +832,6 @@ __global__ __launch_bounds__(BG_THREADS, 1) void speller_big_bwd_kernel(const Bi
         // ================= (C) top cell's backward: W_hh1 blocks
         if (mt == 1) {
             if (wave == 0) {
-                if (!dead && flags_wait(fl + 2 * 256 + lane * 4, lane * 4 < B, a.err, 0xB1610006u, 0, gap, B - lane * 4)) { dead = true; dead_s = 1; }
                 f32x4 aq[4];
                 const float* qp = a.dqpre_all + ((size_t)s * B + rowb) * BG_M + kq * 4;
                 unsigned spins = 0;
@@ -787,12 +840,15 @@ __global__ __launch_bounds__(BG_THREADS, 1) void speller_big_bwd_kernel(const Bi
                     for (int i = 0; i < 4; ++i) aq[i] = ld4_agent(qp + i * 16);
                     if (!__any(has_sentinel(aq[0]) || has_sentinel(aq[1]) || has_sentinel(aq[2]) || has_sentinel(aq[3]))) break;
                     if (dead || spin_expired(spins, a.err, 0xB1610007u)) { dead = true; dead_s = 1; break; }
+                    sleep_units(gap);
                 }
                 f32x4 acc = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-                for (int i = 0; i < 4; ++i)
+                for (int i = 0; i < 4; ++i) {
+                    const f32x4 wv = *reinterpret_cast<const f32x4*>(wphT + (i * 64 + lane) * 4);
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(aq[i][e], wpr[i][e], acc, 0, 0, 0);
+                    for (int e = 0; e < 4; ++e) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(aq[i][e], wv[e], acc, 0, 0, 0);
+                }
 #pragma unroll
                 for (int rr = 0; rr < 4; ++rr) red[(8 * 16 + kq * 4 + rr) * 17 + r] = acc[rr];
             }
@@ -810,7 +866,7 @@ __global__ __launch_bounds__(BG_THREADS, 1) void speller_big_bwd_kernel(const Bi
         // ================= (D) products with dG1: W_ih1 blocks (+ bottom cell's backward), W_hh1 blocks (recurrent carry of dh1)
         if (mt <= 1) {
             if (wave == 0 && !dead) {
-                if (flags_wait(fl + 3 * 256 + lane * 4, lane < 16, a.err, 0xB1610008u, a.tune & 255, gap)) dead_s = 1;
+                if (long_wait(fl + 3 * 256 + lane * 4, 0xB1610008u, est_d)) dead_s = 1;
             }
             __syncthreads();
             dead |= dead_s != 0;
@@ -839,7 +895,7 @@ __global__ __launch_bounds__(BG_THREADS, 1) void speller_big_bwd_kernel(const Bi
         // ================= (E) products with dG0: W_ctx blocks (context gradient carried into step s-1), W_hh0 blocks (recurrent carry of dh0)
         if (mt >= 2) {
             if (wave == 0 && !dead) {
-                if (flags_wait(fl + 4 * 256 + lane * 4, lane < 16, a.err, 0xB161000Bu, (a.tune >> 16) & 255, gap)) dead_s = 1;
+                if (long_wait(fl + 4 * 256 + lane * 4, 0xB161000Bu, est_e)) dead_s = 1;
             }
             __syncthreads();
             dead |= dead_s != 0;
@@ -871,7 +927,7 @@ __global__ __launch_bounds__(BG_THREADS, 1) void speller_big_bwd_kernel(const Bi
 }
 
 size_t big_bwd_smem(int FR) {
-    return sizeof(float) * ((size_t)9 * 16 * 17 + BG_HS + BG_NW * BB_APLD + 2 * BB_MAXFR + (size_t)FR * BG_KLD + (size_t)FR * BG_HS);
+    return sizeof(float) * ((size_t)9 * 16 * 17 + BG_HS + BG_NW * BB_APLD + 2 * BB_MAXFR + 1024 + (size_t)FR * BG_KLD + (size_t)FR * BG_HS);
 }
 
 u64* g_big_bwd_trace = nullptr;

@@ -326,9 +326,8 @@ def test_persistent_decode_kernel_matches_stepwise(cfg_name, B, Tp, U, scale):
                                                     (5, 37, 7, 0.08, "relu"), (1, 1, 3, None, "relu"), (16, 256, 3, None, "relu"),
                                                     (7, 130, 4, None, "None"), (16, 100, 72, None, "relu")])
 def test_one_launch_decode_of_the_yaml_sizes_matches_stepwise(B, Tp, U, scale, activate):
-    """speller_big.hip (Speller 1024x2, attention MLP 64, B <= 16, T' <= 256: the reference's config/librispeech-config.yaml) against the
-    per-step launch chain: log-probs, attention weights and every gradient (the per-step backward consumes the stash the kernel wrote:
-    h, c, gates, queries, contexts).  Cases: a full batch at T = 800, partial batches (rows beyond B are never stored), a single frame,
+    """speller_big.hip (Speller 1024x2, attention MLP 64, B <= 16, T' <= 256: the reference's config/librispeech-config.yaml), forward AND
+    backward kernel, against the per-step launch chains: log-probs, attention weights and every gradient.  Cases: a full batch at T = 800, partial batches (rows beyond B are never stored), a single frame,
     the longest eligible encoder output, no attention activation, more than 64 steps (the trace buffer's depth; U = 72 and not 70: with
     this seed one query pre-activation of step 69 is within an ulp of 0, and the PER-STEP path's own run-to-run summation order — atomic
     split-K — flips its relu mask in about a third of the runs)."""
@@ -402,7 +401,13 @@ def _persistent_vs_stepwise(cfg_name, B, Tp, U, scale, activate, big=False):
     L.las_debug_persist_trace.restype = None
     # las_debug_persist_trace: 3 roles x U steps x 8 stamps; las_debug_big_trace (speller_big.hip): 64 steps x 16 + 256 workgroups x 8
     trace = torch.zeros(64 * 16 + 256 * 8 if big else 3 * U * 8, dtype=torch.int64, device="cuda")
-    set_trace = L.las_debug_big_trace if big else L.las_debug_persist_trace
+    btrace = torch.zeros(4 * 64 * 16, dtype=torch.int64, device="cuda")      # las_debug_big_bwd_trace: 4 matrix roles x 64 steps x 16 stamps
+    def set_trace(ptr):
+        if big:
+            L.las_debug_big_trace(ptr)
+            L.las_debug_big_bwd_trace(btrace.data_ptr() if ptr else None)
+        else:
+            L.las_debug_persist_trace(ptr)
     res = []
     for force in (False, True):
         sp.force_generic = force
@@ -420,6 +425,7 @@ def _persistent_vs_stepwise(cfg_name, B, Tp, U, scale, activate, big=False):
             set_trace(None)
     torch.cuda.synchronize()
     assert int(trace.abs().sum().item()) != 0, "the persistent kernel did not run (shape not eligible?)"
+    assert not big or int(btrace.abs().sum().item()) != 0, "the one-launch backward did not run"
     for k in res[0]:
         scale_k = float(np.abs(res[1][k]).max()) + 1e-30
         assert_close(res[0][k], res[1][k], f"persistent vs stepwise {k}", rtol=1e-3, atol=1e-5 * max(1.0, scale_k))
