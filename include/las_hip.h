@@ -36,7 +36,7 @@
 extern "C" {
 #endif
 
-#define LAS_ABI_VERSION 7
+#define LAS_ABI_VERSION 8
 #define LAS_MAX_SPELLER_LAYERS 4
 
 /* flags */
@@ -71,6 +71,11 @@ const char* las_last_error(void);
  *   GEMM_GROUP 1*, GEMM_XCD_SWZ 1*, GEMM_BATCH_DIRS 1*          grouped weight-gradient launches / XCD order / batched directions
  *   SPELLER_PERSIST 1*, SPELLER_PERSIST_BWD 1*                   one-launch decode loop forward / backward (0: per-step launches)
  *   SPELLER_PRE 1*, SPELLER_PRE_BWD 1*                           pre-multiplied-context variants of those kernels
+ *   SPELLER_BIG 1*, SPELLER_BIG_BWD 1*                           one-launch teacher-forced decode loop forward / backward for the reference's
+ *                                                                shipped sizes (Speller 1024x2, attention MLP 64, B <= 16, T' <= 256:
+ *                                                                speller_big.hip; 0: per-step launches)
+ *   SPELLER_BIG_TUNE 0*   poll pacing of those two kernels in units of 64 clocks: byte 0 / 2 / 3 before the first poll of the forward's h0 /
+ *                         context / h1 hand-off, byte 1 between polls (A/B aid)
  *   REC_UW 0*, REC_NB 0*, REC_PIPE 1*, REC_AGENT_HANDOFF 0*, REC_MFMA 1*   Listener recurrence: units per workgroup, utterances per
  *                                                                group, pipelined halves, agent-scope hand-off, matrix-pipe form
  *                                                                (0 off, 1 automatic, 2 / 3: forward always as wave-specialised
