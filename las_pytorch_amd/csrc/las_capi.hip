@@ -374,7 +374,10 @@ size_t las_speller_reserve_floats(const las_speller_desc* d, int U) { return Spe
 
 int las_speller_decode_batch(const las_speller_desc* d, int teacher_forced, int decode_mode) {
     if (!d || check_desc(d) != LAS_OK) return 0;
-    if (opt_get(OPT_SPELLER_PERSIST) == 0 || (!teacher_forced && decode_mode == 2) || d->relu > LAS_ACT_RELU) return 0;
+    if (d->relu > LAS_ACT_RELU) return 0;
+    // the YAML sizes (speller_big.hip): 16 utterances per launch, teacher forcing only
+    if (teacher_forced && speller_big_eligible(16, d->Tp, d->Hs, d->D, d->M, d->V, d->L, d->multi_head, d->use_mlp)) return 16;
+    if (opt_get(OPT_SPELLER_PERSIST) == 0 || (!teacher_forced && decode_mode == 2)) return 0;
     constexpr int NB = 32;      // the persistent kernels' utterance limit (two 16-row M tiles)
     return speller_persist_eligible(NB, d->Tp, d->Hs, d->D, d->M, d->V, d->L, d->multi_head, d->use_mlp, !teacher_forced) ? NB : 0;
 }

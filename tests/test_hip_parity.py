@@ -324,7 +324,8 @@ def test_persistent_decode_kernel_matches_stepwise(cfg_name, B, Tp, U, scale):
 
 @pytest.mark.parametrize("B,Tp,U,scale,activate", [(16, 100, 12, None, "relu"), (3, 8, 6, 0.08, "relu"), (16, 200, 5, None, "relu"),
                                                     (5, 37, 7, 0.08, "relu"), (1, 1, 3, None, "relu"), (16, 256, 3, None, "relu"),
-                                                    (7, 130, 4, None, "None"), (16, 100, 72, None, "relu")])
+                                                    (7, 130, 4, None, "None"), (16, 100, 72, None, "relu"),
+                                                    (40, 50, 5, None, "relu")])      # beyond one launch: Speller._run slices 16 + 16 + 8
 def test_one_launch_decode_of_the_yaml_sizes_matches_stepwise(B, Tp, U, scale, activate):
     """speller_big.hip (Speller 1024x2, attention MLP 64, B <= 16, T' <= 256: the reference's config/librispeech-config.yaml), forward AND
     backward kernel, against the per-step launch chains: log-probs, attention weights and every gradient.  Cases: a full batch at T = 800, partial batches (rows beyond B are never stored), a single frame,
