@@ -339,7 +339,7 @@ void las_debug_persist_trace(unsigned long long* dev_buf);
 void las_debug_persist_bwd_trace(unsigned long long* dev_buf);
 /* ... of workgroup 0 of the Hs = 1024 one-launch decode (speller_big.hip): 64 steps x 16 stamps. */
 void las_debug_big_trace(unsigned long long* dev_buf);
-/* ... of workgroups 0 / 64 / 128 / 192 (one per matrix role) of its backward: 4 x 64 steps x 16 stamps. */
+/* ... of workgroups 0 / 64 / 128 / 192 (one per matrix role) of its backward: 4 x 64 steps x 16 stamps + 256 workgroups x 8. */
 void las_debug_big_bwd_trace(unsigned long long* dev_buf);
 /* With option TIME_KERNELS = 1: duration (HIP events on the launch stream) of the most recent launch of the one-launch decode
  * kernel, which = 0 forward (speller_persist_fwd*_kernel), 1 backward (speller_persist_bwd*_kernel).  Synchronises on that launch.

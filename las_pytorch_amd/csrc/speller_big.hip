@@ -586,7 +586,8 @@ size_t big_fwd_smem(int Tp) {
 // Chain per step: dctx -> slices -> combine -> top cell -> W_ih1 product + bottom cell -> W_ctx product: five hand-offs (flags + sentinel
 // slabs as in the forward kernel).
 constexpr int BB_APLD = 132;     // one slice triple: S, 3 pad, P1[64], P2[64]
-constexpr int BB_FLK = 5;        // flag kinds per step: dctx carry (64 producers) | slice triples (16 B) | dqpre (B) | dG1 (64) | dG0 (64)
+constexpr int BB_FLK = 4;        // flag words per step / 256: [dG1: 8 copies x 64 producers | dG0: 8 x 64] — a consumer polls the copy of its XCD (w % 8):
+                                 // 128 pollers on ONE 256-byte flag array serialise on its memory channel, the flag stores queue behind them
 constexpr int BB_MAXFR = 16;
 
 struct BigBwdArgs {
@@ -612,6 +613,8 @@ __device__ __forceinline__ float ld1_checked(const float* p, unsigned* err, unsi
     return __uint_as_float(v);
 }
 
+// per-workgroup wall-clock stamps of the 11th step from the end (hop latencies over the chip): slots 4096 + 8 wg + k
+#define BB_WSTAMP(k) do { if (a.trace && s == U - 11 && tid == 0) a.trace[4096 + wg * 8 + (k)] = wall_clock64(); } while (0)
 #define BB_STAMP(slot) do { if (a.trace && (wg & 63) == 0 && tid == 0 && (U - 1 - s) < 64) a.trace[((wg >> 6) * 64 + (U - 1 - s)) * 16 + (slot)] = wall_clock64(); } while (0)
 
 __global__ __launch_bounds__(BG_THREADS, 1) void speller_big_bwd_kernel(const BigBwdArgs a) {
@@ -625,7 +628,11 @@ __global__ __launch_bounds__(BG_THREADS, 1) void speller_big_bwd_kernel(const Bi
     float* featS = keysS + a.FR * BG_KLD;          // [FR][1024]
     __shared__ int dead_s;
 
-    const int wg = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, r = lane & 15, kq = lane >> 4;
+    // Every per-thread index is re-derived (from an opaque copy of threadIdx.x) at the start of each phase: derived offsets that the optimiser
+    // hoists out of the step loop stay live across the products (128 weight + 32 operand registers) and spill — and a spill reload waits on
+    // vmcnt(0), i.e. on the acknowledgement of every store still in flight (1.8 us on the chain when it happened in the slice role).
+    const int wg = blockIdx.x;
+    int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, r = lane & 15, kq = lane >> 4;
     const int B = a.B, U = a.U, Tp = a.Tp, FR = a.FR;
     const size_t sH = (size_t)B * BG_HS;
     const int mt = wg >> 6, jb = wg & 63;          // matrix role: 0 W_ih1, 1 W_hh1, 2 W_ctx, 3 W_hh0; column block jb (16 columns)
@@ -649,8 +656,8 @@ __global__ __launch_bounds__(BG_THREADS, 1) void speller_big_bwd_kernel(const Bi
     }
 
     // ---- cell-backward threads: utterance pb, column pn of the block
-    const int pb = tid >> 4, pn = tid & 15;
-    const bool pw_on = tid < 256 && pb < B;
+    int pb = tid >> 4, pn = tid & 15;
+    bool pw_on = tid < 256 && pb < B;
     float dc_st = 0.f, carry1 = 0.f;
 
     // ---- attention slice of this workgroup: frames [t0, t0 + nfr) of utterance ab
@@ -669,17 +676,25 @@ __global__ __launch_bounds__(BG_THREADS, 1) void speller_big_bwd_kernel(const Bi
     if (tid == 0) dead_s = 0;
     __syncthreads();
     bool dead = false;
-    const int rowb = min(r, B - 1);
+    int rowb = min(r, B - 1);
+    auto derive = [&]() {
+        tid = (int)opaque(threadIdx.x); lane = tid & 63; wave = tid >> 6; r = lane & 15; kq = lane >> 4;
+        pb = tid >> 4; pn = tid & 15; pw_on = tid < 256 && pb < B; rowb = min(r, B - 1);
+    };
     const int gap = (a.tune >> 8) & 255;
 
     // product of one 256 KB gate-gradient slab with the resident columns: four chunks of 8 k-blocks per wave
     auto slab_product = [&](const float* slab, unsigned code) {
         f32x4 acc = {0.f, 0.f, 0.f, 0.f}, acc2 = {0.f, 0.f, 0.f, 0.f};      // two chains, see seg_mfma
         const float* base = slab + ((size_t)(wave * 32) * 16 + rowb) * 16 + kq * 4;
-        f32x4 axa[8], axb[8];
+        f32x4 ax[8];
         // a chunk whose lines were fetched into the L2 too early still shows the sentinel: re-read it at agent scope
-        auto settle = [&](const float* p, f32x4 (&ax)[8]) {
-            if (!__any(any_sentinel8(ax))) return;
+        auto settle = [&](const float* p) {
+            // one dword per 16-byte piece: a piece is 4 lanes of ONE store instruction inside one 64-byte segment
+            bool bad = false;
+#pragma unroll
+            for (int i = 0; i < 8; ++i) bad |= __float_as_uint(ax[i][3]) == PS_SENT;
+            if (!__any(bad)) return;
             unsigned spins = 0;
             for (;;) {
                 ld4x8_kb<false>(p, ax);
@@ -687,7 +702,13 @@ __global__ __launch_bounds__(BG_THREADS, 1) void speller_big_bwd_kernel(const Bi
                 if (dead || spin_expired(spins, a.err, code)) { dead = true; break; }
             }
         };
-        auto mult = [&](const f32x4 (&ax)[8], int c) {
+        // (loading chunk c+1 into a second register set under the MFMAs of chunk c measured the same 6.3 us per product and cost 32 VGPRs,
+        // i.e. spills — whose reloads wait on vmcnt(0) and with it on the acknowledgement of every store still in flight: 1.8 us on the chain)
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            const float* p = at_bytes(base, opaque((unsigned)(c * 8192)));
+            ld4x8_kb<true>(p, ax);
+            settle(p);
 #pragma unroll
             for (int i = 0; i < 8; i += 2)
 #pragma unroll
@@ -695,38 +716,38 @@ __global__ __launch_bounds__(BG_THREADS, 1) void speller_big_bwd_kernel(const Bi
                     acc = __builtin_amdgcn_mfma_f32_16x16x4f32(ax[i][e], wreg[c * 8 + i][e], acc, 0, 0, 0);
                     acc2 = __builtin_amdgcn_mfma_f32_16x16x4f32(ax[i + 1][e], wreg[c * 8 + i + 1][e], acc2, 0, 0, 0);
                 }
-        };
-        const float* p0 = at_bytes(base, opaque(0u));
-        const float* p1 = at_bytes(base, opaque(8192u));
-        const float* p2 = at_bytes(base, opaque(16384u));
-        const float* p3 = at_bytes(base, opaque(24576u));
-        kb_issue_l2(p0, axa); kb_wait(axa); settle(p0, axa);
-        kb_issue_l2(p1, axb); mult(axa, 0); kb_wait(axb); settle(p1, axb);
-        kb_issue_l2(p2, axa); mult(axb, 1); kb_wait(axa); settle(p2, axa);
-        kb_issue_l2(p3, axb); mult(axa, 2); kb_wait(axb); settle(p3, axb);
-        mult(axb, 3);
+        }
         acc += acc2;
 #pragma unroll
         for (int rr = 0; rr < 4; ++rr) red[(wave * 16 + kq * 4 + rr) * 17 + r] = acc[rr];
     };
     // (D) / (E) waits last ~15 us: a workgroup that polls all the while only queues reads in front of the flag stores it is waiting for.  It sleeps
-    // three quarters of the wait it saw at the previous step before the first poll.
+    // 14/16 (option SPELLER_BIG_TUNE byte 2: sixteenths) of the wait it saw at the previous step before the first poll.
     unsigned est_d = 0, est_e = 0;
     auto long_wait = [&](const unsigned* flp, unsigned code, unsigned& est) {
         const u64 t0 = wall_clock64();
-        sleep_units((int)min((est * 9u) >> 5, 4000u));          // est in 10 ns ticks, a sleep unit is 64 clocks ~ 28 ns: 0.75 * 10 / 28 ~ 9 / 32
+        const unsigned frac = ((a.tune >> 16) & 255) ? ((a.tune >> 16) & 255) : 14u;      // sixteenths of the last wait to sleep through
+        sleep_units((int)min((est * frac * 23u) >> 10, 4000u));          // est in 10 ns ticks, a sleep unit is 64 clocks ~ 28 ns: 10 / 28 / 16 ~ 23 / 1024
         const bool gave_up = flags_wait(flp, lane < 16, a.err, code, 0, gap);
         est = (unsigned)(wall_clock64() - t0);
         return gave_up;
     };
     // cell backward of (utterance pb, unit 16 jb + pn) of layer l at step s; publishes the four gate gradients
-    auto cell_bwd = [&](int l, int s, float dh, float* slab) {
+    // its operands from the forward stash (and the addend of dh) are fetched at the top of the step, long before dh arrives
+    float st_g[4] = {0.f, 0.f, 0.f, 0.f}, st_c = 0.f, st_cp = 0.f, st_add = 0.f;
+    auto cell_fetch = [&](int l, int s) {
         const int unit = jb * 16 + pn;
         const size_t o = ((size_t)l * U + s) * sH + (size_t)pb * BG_HS + unit;
         const float* gp = a.gates_all + 4 * (((size_t)l * U + s) * sH) + (size_t)pb * 4 * BG_HS + unit;
-        const float ig = gp[0], fg = gp[BG_HS], gg = gp[2 * BG_HS], og = gp[3 * BG_HS];
-        const float tc = tanhf_acc(a.c_all[o]);
-        const float cp = s > 0 ? a.c_all[o - sH] : 0.f;
+        st_g[0] = gp[0]; st_g[1] = gp[BG_HS]; st_g[2] = gp[2 * BG_HS]; st_g[3] = gp[3 * BG_HS];
+        st_c = a.c_all[o];
+        st_cp = s > 0 ? a.c_all[o - sH] : 0.f;
+    };
+    auto cell_bwd = [&](int l, int s, float dh, float* slab) {
+        const int unit = jb * 16 + pn;
+        const float ig = st_g[0], fg = st_g[1], gg = st_g[2], og = st_g[3];
+        const float tc = tanhf_acc(st_c);
+        const float cp = st_cp;
         const float dct = dc_st + dh * og * (1.f - tc * tc);
         float dg[4];
         dg[0] = dct * gg * ig * (1.f - ig);
@@ -742,23 +763,35 @@ __global__ __launch_bounds__(BG_THREADS, 1) void speller_big_bwd_kernel(const Bi
         }
     };
 
+    float nd0 = 0.f, nd1 = 0.f;      // this thread's two columns of dcat's context half for the coming step
+    float naf0 = 0.f, naf1 = 0.f, nqv = 0.f;
+    if (att_on) {
+        if (wave < nfr) naf0 = a.att[((size_t)(U - 1) * B + ab) * Tp + t0 + wave];
+        if (wave + BG_NW < nfr) naf1 = a.att[((size_t)(U - 1) * B + ab) * Tp + t0 + wave + BG_NW];
+        if (aj == 0 && wave == 0) nqv = a.q_all[((size_t)(U - 1) * B + ab) * BG_M + lane];
+        const float* dn = a.dcat_all + ((size_t)(U - 1) * B + ab) * (2 * BG_HS) + BG_HS + tid * 2;
+        nd0 = dn[0]; nd1 = dn[1];
+    }
     for (int s = U - 1; s >= 0; --s) {
         const bool last = s == U - 1;
         unsigned* fl = a.flags + (size_t)s * BB_FLK * 256;
+        derive();
         BB_STAMP(0);
+        if (pw_on && mt <= 1) {      // the cell-backward threads' stash operands of this step, and what is added to the product: dcat_h (top) / nothing yet (bottom)
+            cell_fetch(mt == 1 ? 1 : 0, s);
+            if (mt == 1) st_add = a.dcat_all[((size_t)s * B + pb) * (2 * BG_HS) + jb * 16 + pn];
+        }
         if (att_on) {
             // ---- attention weights' gradient of the PREVIOUS iteration's step, off the chain: de_t = a_t (da_t - S), S from the 16 slice triples
-            if (!last && wave == 1) {
-                const float* apb = a.apart + ((size_t)(s + 1) * B + ab) * 16 * BB_APLD;
-                const float si = ld1_checked(apb + (size_t)(lane & 15) * BB_APLD, a.err, 0xB1610001u, dead);
-                const float st = lane_f(gsum<16>(si), 0);
-                if (lane < nfr) a.de_all[((size_t)(s + 1) * B + ab) * Tp + t0 + lane] = adS[lane * 2] * (adS[lane * 2 + 1] - st);
-            }
+            float pa = 0.f, pd = 0.f;
+            if (!last && wave == 1 && lane < nfr) { pa = adS[lane * 2]; pd = adS[lane * 2 + 1]; }      // finished behind this step's triple (below)
             // ================= (A) slice triple of this step
+            // (the attention weights of this wave's two frames and the combine role's query were fetched one step ahead: a cold global load takes
+            // 2 - 3 us here)
+            const float af0 = naf0, af1 = naf1, qv = nqv;
             {
                 const int c = tid * 2;
-                const float* dc = a.dcat_all + ((size_t)s * B + ab) * (2 * BG_HS) + BG_HS + c;
-                float v0 = dc[0], v1 = dc[1];
+                float v0 = nd0, v1 = nd1;
                 if (!last) {      // the context gradient carried out of step s+1 (W_ctx blocks): polled at agent scope, 4 KB per workgroup
                     const float* cx = a.dcx + ((size_t)(s + 1) * BG_NB + ab) * BG_HS + c;
                     unsigned x0, x1, spins = 0;
@@ -770,6 +803,7 @@ __global__ __launch_bounds__(BG_THREADS, 1) void speller_big_bwd_kernel(const Bi
                     }
                     v0 += __uint_as_float(x0); v1 += __uint_as_float(x1);
                 }
+                BB_WSTAMP(0);
                 dctxS[c] = v0; dctxS[c + 1] = v1;
                 if (aj == 0) { float* o = a.dctx_all + ((size_t)s * B + ab) * BG_HS + c; o[0] = v0; o[1] = v1; }
             }
@@ -783,21 +817,39 @@ __global__ __launch_bounds__(BG_THREADS, 1) void speller_big_bwd_kernel(const Bi
                 for (int i = 0; i < 4; ++i)
                     acc = dot4p(*reinterpret_cast<const f32x4*>(fr + 256 * i), *reinterpret_cast<const f32x4*>(dctxS + lane * 4 + 256 * i), acc);
                 const float da = wsum(acc);
-                const float af = a.att[((size_t)s * B + ab) * Tp + t0 + f];
+                const float af = f == wave ? af0 : af1;
                 const float kv = keysS[f * BG_KLD + lane];
                 p1 = fmaf(af * da, kv, p1); p2 = fmaf(af, kv, p2); ssum = fmaf(af, da, ssum);
                 if (lane == 0) { adS[f * 2] = af; adS[f * 2 + 1] = da; }
             }
+            BB_STAMP(9);
             part[wave * BB_APLD + 4 + lane] = p1; part[wave * BB_APLD + 68 + lane] = p2;
             if (lane == 0) part[wave * BB_APLD] = ssum;
             __syncthreads();
+            BB_STAMP(10);
             if (wave == 0) {
                 float q1 = 0.f, q2 = 0.f, qs = 0.f;
 #pragma unroll
                 for (int w = 0; w < BG_NW; ++w) { q1 += part[w * BB_APLD + 4 + lane]; q2 += part[w * BB_APLD + 68 + lane]; qs += part[w * BB_APLD]; }
                 float* ap = a.apart + (((size_t)s * B + ab) * 16 + aj) * BB_APLD;
                 st1_agent(ap + 4 + lane, q1); st1_agent(ap + 68 + lane, q2);
-                if (lane == 0) { st1_agent(ap, qs); st1_agent(reinterpret_cast<float*>(fl) + 256 + ab * 16 + aj, 0.f); }
+                if (lane == 0) st1_agent(ap, qs);
+                BB_WSTAMP(1);
+            } else if (wave == 1 && !last) {
+                const float* apb = a.apart + ((size_t)(s + 1) * B + ab) * 16 * BB_APLD;
+                const float si = ld1_checked(apb + (size_t)(lane & 15) * BB_APLD, a.err, 0xB1610001u, dead);
+                const float st = lane_f(gsum<16>(si), 0);
+                if (lane < nfr) a.de_all[((size_t)(s + 1) * B + ab) * Tp + t0 + lane] = pa * (pd - st);
+            }
+            if (s > 0) {      // operands of the NEXT step, issued behind this step's last chain-critical load of the slice role: loads return in order,
+                              // so a cold one (2 - 3 us) in front of a poll would sit on the chain
+                const float* dn = a.dcat_all + ((size_t)(s - 1) * B + ab) * (2 * BG_HS) + BG_HS + tid * 2;
+                nd0 = dn[0]; nd1 = dn[1];
+                if (wave < nfr) naf0 = a.att[((size_t)(s - 1) * B + ab) * Tp + t0 + wave];
+                if (wave + BG_NW < nfr) naf1 = a.att[((size_t)(s - 1) * B + ab) * Tp + t0 + wave + BG_NW];
+                if (aj == 0 && wave == 0) nqv = a.q_all[((size_t)(s - 1) * B + ab) * BG_M + lane];
+            }
+            if (wave == 0) {
                 BB_STAMP(2);
                 // ================= (B) workgroup (ab, 0): add the 16 triples, dq = P1 - S P2, dqpre = dq act'(q)
                 if (aj == 0) {
@@ -822,22 +874,28 @@ __global__ __launch_bounds__(BG_THREADS, 1) void speller_big_bwd_kernel(const Bi
                     }
                     const float st = lane_f(gsum<16>(__uint_as_float(vs)), 0);
                     float dq = t1 - st * t2;
-                    if (a.relu) dq *= act_grad(a.q_all[((size_t)s * B + ab) * BG_M + lane], a.relu);
+                    if (a.relu) dq *= act_grad(qv, a.relu);
                     st1_agent(a.dqpre_all + ((size_t)s * B + ab) * BG_M + lane, dq);
-                    if (lane == 0) st1_agent(reinterpret_cast<float*>(fl) + 2 * 256 + ab, 0.f);
+                    BB_WSTAMP(2);
                     BB_STAMP(3);
                 }
             }
         }
         // ================= (C) top cell's backward: W_hh1 blocks
+        derive();
         if (mt == 1) {
             if (wave == 0) {
                 f32x4 aq[4];
                 const float* qp = a.dqpre_all + ((size_t)s * B + rowb) * BG_M + kq * 4;
                 unsigned spins = 0;
                 for (;;) {
-#pragma unroll
-                    for (int i = 0; i < 4; ++i) aq[i] = ld4_agent(qp + i * 16);
+                    asm volatile(
+                        "global_load_dwordx4 %0, %4, off sc1\n\t"
+                        "global_load_dwordx4 %1, %4, off offset:64 sc1\n\t"
+                        "global_load_dwordx4 %2, %4, off offset:128 sc1\n\t"
+                        "global_load_dwordx4 %3, %4, off offset:192 sc1\n\t"
+                        "s_waitcnt vmcnt(0)"
+                        : "=&v"(aq[0]), "=&v"(aq[1]), "=&v"(aq[2]), "=&v"(aq[3]) : "v"(qp) : "memory");
                     if (!__any(has_sentinel(aq[0]) || has_sentinel(aq[1]) || has_sentinel(aq[2]) || has_sentinel(aq[3]))) break;
                     if (dead || spin_expired(spins, a.err, 0xB1610007u)) { dead = true; dead_s = 1; break; }
                     sleep_units(gap);
@@ -856,23 +914,29 @@ __global__ __launch_bounds__(BG_THREADS, 1) void speller_big_bwd_kernel(const Bi
             dead |= dead_s != 0;
             BB_STAMP(4);
             if (pw_on) {
-                const float dh = red[(8 * 16 + pb) * 17 + pn] + a.dcat_all[((size_t)s * B + pb) * (2 * BG_HS) + jb * 16 + pn] + carry1;
+                const float dh = red[(8 * 16 + pb) * 17 + pn] + st_add + carry1;
                 cell_bwd(1, s, dh, a.dg1x + (size_t)s * 65536);
             }
             __syncthreads();
-            if (tid == 0) st1_agent(reinterpret_cast<float*>(fl) + 3 * 256 + jb, 0.f);
+            if (tid < 8) st1_agent(reinterpret_cast<float*>(fl) + tid * 64 + jb, 0.f);
+            BB_WSTAMP(3);
             BB_STAMP(5);
         }
+        derive();
         // ================= (D) products with dG1: W_ih1 blocks (+ bottom cell's backward), W_hh1 blocks (recurrent carry of dh1)
         if (mt <= 1) {
             if (wave == 0 && !dead) {
-                if (long_wait(fl + 3 * 256 + lane * 4, 0xB1610008u, est_d)) dead_s = 1;
+                if (long_wait(fl + (wg & 7) * 64 + lane * 4, 0xB1610008u, est_d)) dead_s = 1;
             }
+            BB_WSTAMP(4);
             __syncthreads();
             dead |= dead_s != 0;
             BB_STAMP(6);
+            unsigned h0c_raw = 0;      // W_ih1 role: the recurrent carry of dh0 from the W_hh0 block of the same columns (published during the last step)
+            if (mt == 0 && pw_on && !last) h0c_raw = __builtin_nontemporal_load(reinterpret_cast<const unsigned*>(a.dh0c + (((size_t)(s + 1) * 64 + jb) * 16 + pb) * 16 + pn));
             slab_product(a.dg1x + (size_t)s * 65536, 0xB1610009u);
             __syncthreads();
+            derive();
             BB_STAMP(7);
             float cs = 0.f;
             if (tid < 256) {
@@ -884,24 +948,31 @@ __global__ __launch_bounds__(BG_THREADS, 1) void speller_big_bwd_kernel(const Bi
             } else {
                 if (pw_on) {
                     float dh = cs;
-                    if (!last) dh += ld1_checked(a.dh0c + (((size_t)(s + 1) * 64 + jb) * 16 + pb) * 16 + pn, a.err, 0xB161000Au, dead);
+                    if (!last) {
+                        if (h0c_raw == PS_SENT) h0c_raw = __float_as_uint(ld1_checked(a.dh0c + (((size_t)(s + 1) * 64 + jb) * 16 + pb) * 16 + pn, a.err, 0xB161000Au, dead));
+                        dh += __uint_as_float(h0c_raw);
+                    }
                     cell_bwd(0, s, dh, a.dg0x + (size_t)s * 65536);
                 }
                 __syncthreads();
-                if (tid == 0) st1_agent(reinterpret_cast<float*>(fl) + 4 * 256 + jb, 0.f);
+                if (tid < 8) st1_agent(reinterpret_cast<float*>(fl) + 512 + tid * 64 + jb, 0.f);
+                BB_WSTAMP(5);
             }
             BB_STAMP(8);
         }
+        derive();
         // ================= (E) products with dG0: W_ctx blocks (context gradient carried into step s-1), W_hh0 blocks (recurrent carry of dh0)
         if (mt >= 2) {
             if (wave == 0 && !dead) {
-                if (long_wait(fl + 4 * 256 + lane * 4, 0xB161000Bu, est_e)) dead_s = 1;
+                if (long_wait(fl + 512 + (wg & 7) * 64 + lane * 4, 0xB161000Bu, est_e)) dead_s = 1;
             }
+            BB_WSTAMP(6);
             __syncthreads();
             dead |= dead_s != 0;
             BB_STAMP(6);
             slab_product(a.dg0x + (size_t)s * 65536, 0xB161000Cu);
             __syncthreads();
+            derive();
             BB_STAMP(7);
             if (pw_on) {
                 float cs = 0.f;
@@ -910,10 +981,7 @@ __global__ __launch_bounds__(BG_THREADS, 1) void speller_big_bwd_kernel(const Bi
                 if (mt == 2) st1_agent(a.dcx + ((size_t)s * BG_NB + pb) * BG_HS + jb * 16 + pn, cs);
                 else st1_agent(a.dh0c + (((size_t)s * 64 + jb) * 16 + pb) * 16 + pn, cs);
             }
-            if (mt == 2) {
-                __syncthreads();
-                if (tid == 0) st1_agent(reinterpret_cast<float*>(fl) + jb, 0.f);
-            }
+            BB_WSTAMP(7);
             BB_STAMP(8);
         }
     }

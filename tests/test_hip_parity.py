@@ -402,7 +402,7 @@ def _persistent_vs_stepwise(cfg_name, B, Tp, U, scale, activate, big=False):
     L.las_debug_persist_trace.restype = None
     # las_debug_persist_trace: 3 roles x U steps x 8 stamps; las_debug_big_trace (speller_big.hip): 64 steps x 16 + 256 workgroups x 8
     trace = torch.zeros(64 * 16 + 256 * 8 if big else 3 * U * 8, dtype=torch.int64, device="cuda")
-    btrace = torch.zeros(4 * 64 * 16, dtype=torch.int64, device="cuda")      # las_debug_big_bwd_trace: 4 matrix roles x 64 steps x 16 stamps
+    btrace = torch.zeros(4 * 64 * 16 + 256 * 8, dtype=torch.int64, device="cuda")      # las_debug_big_bwd_trace: 4 roles x 64 steps x 16 + 256 x 8
     def set_trace(ptr):
         if big:
             L.las_debug_big_trace(ptr)

@@ -30,7 +30,7 @@ def run(B, Tp, U, scale=None, trace_on=True):
     L.las_debug_big_trace.argtypes = [ctypes.c_void_p]
     L.las_debug_big_trace.restype = None
     trace = torch.zeros(64 * 16 + 256 * 8, dtype=torch.int64, device="cuda")
-    btrace = torch.zeros(4 * 64 * 16, dtype=torch.int64, device="cuda")
+    btrace = torch.zeros(4 * 64 * 16 + 256 * 8, dtype=torch.int64, device="cuda")
     res = []
     for force in (False, True):
         sp.force_generic = force
@@ -93,13 +93,20 @@ def run(B, Tp, U, scale=None, trace_on=True):
         tb[force] = (time.perf_counter() - t0) / 5 * 1e3
     sp.force_generic = False
     print(f"  forward + backward (with the deferred GEMMs): one launch each {tb[False]:.3f} ms, per-step launches {tb[True]:.3f} ms")
-    bt = btrace.cpu().numpy().reshape(4, 64, 16).astype(np.float64) / 100.0
+    ball = btrace.cpu().numpy().astype(np.float64) / 100.0
+    bt = ball[:4096].reshape(4, 64, 16)
+    bw = ball[4096:].reshape(256, 8)
+    if U > 12 and bw[:, 1].max() > 0:
+        base = bw[:, 0][bw[:, 0] > 0].min()
+        for k, nm in enumerate(["carried dctx seen", "slice triple published", "dqpre published", "dG1 published", "dG1 flags seen", "dG0 published", "dG0 flags seen", "carried dctx published"]):
+            v = bw[:, k][bw[:, k] > 0] - base
+            print(f"    bwd step U-11, {nm}: n={len(v)} min {v.min():.2f} median {np.median(v):.2f} max {v.max():.2f} us")
     if bt[0, 2, 0] != 0 and U > 6:
         n = min(U, 64)
         step = np.diff(bt[0, 2:n, 0]).mean()
         print(f"  backward trace: {step:.2f} us per step; phases by matrix role (us from the step's start):")
         for role, nm in enumerate(["W_ih1", "W_hh1", "W_ctx", "W_hh0"]):
-            rel = (bt[role, 2:n, :9] - bt[role, 2:n, 0:1]).mean(0)
+            rel = (bt[role, 2:n, :11] - bt[role, 2:n, 0:1]).mean(0)
             print(f"    {nm}: " + ", ".join(f"{k}:{v:.2f}" for k, v in enumerate(rel) if bt[role, 3, k] != 0))
     print(f"  forward: one launch {out[False]:.3f} ms, per-step launches {out[True]:.3f} ms  ({out[False] * 1e3 / U:.2f} / {out[True] * 1e3 / U:.2f} us per decode step)")
     if ran and trace_on:
