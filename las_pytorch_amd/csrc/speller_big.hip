@@ -24,6 +24,7 @@ namespace {
 
 constexpr int BG_THREADS = 512, BG_NW = 8, BG_HS = 1024, BG_M = 64, BG_WGS = 256, BG_NB = 16;
 constexpr int BG_KLD = BG_M + 4;         // LDS row stride of the keys
+constexpr int BG_FLW = 3 * 8 * 256;      // flag words per step of the forward kernel: 3 hand-offs x 8 copies x 256 producers
 constexpr int BG_MAXTP = 256;            // encoder frames: features and keys of the workgroup's column block stay in LDS (528 B per frame)
 constexpr float BG_LOG2E = 1.4426950408889634f;
 constexpr float BG_NEG = -3.0e38f;
@@ -342,7 +343,8 @@ __global__ __launch_bounds__(BG_THREADS, 1) void speller_big_fwd_kernel(const Bi
     for (int s = 0; s < U; ++s) {
         BG_STAMP(0);
         if (a.trace && wg == 0 && tid == 0 && s < 64) a.trace[s * 16 + 13] = __builtin_readcyclecounter();      // shader clock (the stamps are 100 MHz)
-        const unsigned* fl = a.flags + (size_t)s * 3 * BG_WGS;          // flags of this step: [h0 | h1 + query parts | ctx]
+        const unsigned* fl = a.flags + (size_t)s * BG_FLW;             // flags of this step: [h0 | h1 + query parts | ctx] x 8 copies x 256 producers
+        const unsigned* flc = fl + (wg & 7) * BG_WGS;                    // the copy this workgroup polls (one per XCD: 256 pollers on one 1 KB array serialise on its channel)
         // label half of the bottom-layer gates (one GEMM before the launch), off the chain
         float ywv[4] = {0.f, 0.f, 0.f, 0.f};
         if (cell_on) {
@@ -353,7 +355,7 @@ __global__ __launch_bounds__(BG_THREADS, 1) void speller_big_fwd_kernel(const Bi
         // ================= [1] bottom cell: gates0 = yw + W_ctx ctx_{s-1} + W_hh0 h0_{s-1}
         {
             if (wave == 0 && s > 0 && !dead) {
-                if (flags_wait(fl - 3 * BG_WGS + 2 * BG_WGS + lane * 4, lane * 4 < B * 16, a.err, 0xB1600001u, (a.tune >> 16) & 255, (a.tune >> 8) & 255)) dead_s = 1;
+                if (flags_wait(flc - BG_FLW + 2 * 8 * BG_WGS + lane * 4, lane * 4 < B * 16, a.err, 0xB1600001u, (a.tune >> 16) & 255, (a.tune >> 8) & 255)) dead_s = 1;
             }
             BG_WSTAMP(0);
             __syncthreads();
@@ -379,7 +381,7 @@ __global__ __launch_bounds__(BG_THREADS, 1) void speller_big_fwd_kernel(const Bi
                 c0 = fg * c0 + ig * gg;
                 const float h = og * tanhf_acc(c0);
                 if (cell_on) st1_agent(a.hx + ((size_t)s * BG_WGS + wg) * 64 + lane, h);          // hand-off copy: 256 contiguous bytes
-                if (lane == 0) st1_agent(reinterpret_cast<float*>(const_cast<unsigned*>(fl)) + wg, 0.f);
+                if (lane < 8) st1_agent(reinterpret_cast<float*>(const_cast<unsigned*>(fl)) + lane * BG_WGS + wg, 0.f);
                 BG_WSTAMP(1);
                 if (cell_on) {
                     const size_t o = (size_t)s * sH + (size_t)cb * BG_HS + j0 + cu;       // layer 0
@@ -401,7 +403,7 @@ __global__ __launch_bounds__(BG_THREADS, 1) void speller_big_fwd_kernel(const Bi
             }
             BG_WSTAMP(6);
             if (wave == 0 && !dead) {
-                if (flags_wait(fl + lane * 4, true, a.err, 0xB1600003u, a.tune & 255, (a.tune >> 8) & 255)) dead_s = 1;
+                if (flags_wait(flc + lane * 4, true, a.err, 0xB1600003u, a.tune & 255, (a.tune >> 8) & 255)) dead_s = 1;
             }
             BG_STAMP(9);
             BG_WSTAMP(2);
@@ -443,7 +445,7 @@ __global__ __launch_bounds__(BG_THREADS, 1) void speller_big_fwd_kernel(const Bi
                     }
                     if (cell_on) st4_agent(qo + i4 * 4, o4);
                 }
-                if (lane == 0) st1_agent(reinterpret_cast<float*>(const_cast<unsigned*>(fl)) + BG_WGS + wg, 0.f);
+                if (lane < 8) st1_agent(reinterpret_cast<float*>(const_cast<unsigned*>(fl)) + (8 + lane) * BG_WGS + wg, 0.f);
                 BG_WSTAMP(3);
                 if (cell_on) {
                     const size_t o = ((size_t)U + s) * sH + (size_t)cb * BG_HS + j0 + cu;  // layer 1
@@ -461,7 +463,7 @@ __global__ __launch_bounds__(BG_THREADS, 1) void speller_big_fwd_kernel(const Bi
         {
             const float* qps = a.qp + ((size_t)s * B + min(ab, B - 1)) * BG_WGS * BG_M;
             if (wave == 0 && !dead) {
-                if (flags_wait(fl + BG_WGS + lane * 4, true, a.err, 0xB1600005u, (a.tune >> 24) & 255, (a.tune >> 8) & 255)) dead_s = 1;
+                if (flags_wait(flc + 8 * BG_WGS + lane * 4, true, a.err, 0xB1600005u, (a.tune >> 24) & 255, (a.tune >> 8) & 255)) dead_s = 1;
             }
             BG_WSTAMP(4);
             __syncthreads();
@@ -556,7 +558,7 @@ __global__ __launch_bounds__(BG_THREADS, 1) void speller_big_fwd_kernel(const Bi
                 // backward pass and the logits
                 st1_agent(a.hx + ((size_t)2 * U + s) * BG_WGS * 64 + (((aj * 4 + (lane >> 4)) * 16 + ab) * 16 + (lane & 15)), c);
                 a.ctx_all[((size_t)(s + 1) * B + ab) * BG_HS + aj * 64 + lane] = c;
-                if (lane == 0) st1_agent(reinterpret_cast<float*>(const_cast<unsigned*>(fl)) + 2 * BG_WGS + ab * 16 + aj, 0.f);
+                if (lane < 8) st1_agent(reinterpret_cast<float*>(const_cast<unsigned*>(fl)) + (16 + lane) * BG_WGS + ab * 16 + aj, 0.f);
                 BG_WSTAMP(5);
             }
         }
@@ -1014,7 +1016,7 @@ bool speller_big_shape(int B, int Tp, int Hs, int D, int M, int V, int L, int he
 
 size_t speller_big_hx_floats(int U) { return (size_t)3 * U * BG_WGS * 64; }
 size_t speller_big_qp_floats(int B, int U) { return (size_t)U * B * BG_WGS * BG_M; }
-size_t speller_big_flag_words(int U) { return (size_t)U * 3 * BG_WGS; }
+size_t speller_big_flag_words(int U) { return (size_t)U * BG_FLW; }
 
 static bool big_fits(int Tp) {
     const size_t smem = big_fwd_smem(Tp);
