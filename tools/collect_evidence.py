@@ -33,7 +33,7 @@ def main():
     subprocess.run([sys.executable, os.path.join(ROOT, "tools", "pmc_step_traffic.py")], check=True)
     subprocess.run([sys.executable, os.path.join(ROOT, "tools", "make_pmc_profiles.py"), "recmfma", find_db("pmc_recm_a"), find_db("pmc_recm_b"),
                     find_db("pmc_recm_f"), find_db("pmc_recm_w"), "512", "400", "256"], check=True)
-    for name in ("rec_mfma_trace", "gemm_skf_b32", "gemm_skf_b128", "spin_timeout"):
+    for name in ("rec_mfma_trace", "gemm_skf_b32", "gemm_skf_b128", "spin_timeout", "big_decode"):
         src = os.path.join(E, name + ".log")
         if os.path.exists(src):
             open(os.path.join(P, f"r04_{name}.txt"), "w").write("".join(l for l in open(src) if "amdgpu.ids" not in l and "trace wg0:" not in l))

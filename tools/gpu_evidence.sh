@@ -35,6 +35,8 @@ TRACE=1 BS=128,512,768 python tools/ubench_rec_mfma.py > $O/rec_mfma_trace.log 2
 python tools/ubench_gemm_skf.py 32 > $O/gemm_skf_b32.log 2>&1
 python tools/ubench_gemm_skf.py 128 > $O/gemm_skf_b128.log 2>&1
 ./tools/_bin/spin_timeout > $O/spin_timeout.log 2>&1
+# the one-launch decode kernels of the reference's YAML sizes against the per-step chains: parity, times, phase traces (tools/check_big.py)
+python tools/check_big.py > $O/big_decode.log 2>&1
 python tools/ubench_rec_sweep.py > $O/rec_sweep.log 2>&1
 python tools/ubench_gemm_split.py > $O/gemm_split.log 2>&1
 # soak: 1500 consecutive training steps (~1e7 inter-workgroup hand-offs) must end without a device error word
