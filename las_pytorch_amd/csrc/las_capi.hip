@@ -39,7 +39,7 @@ struct PblstmBwdLayout {
 };
 
 struct SpellerLayout {
-    size_t y_all, ctx_all, h_all, c_all, gates_all, q_all, w0p, ctxcat_all, hx, r0x, lgx, wperm, wyperm, bperm, yw, pctx, gx, bqp, bfl, total;
+    size_t y_all, ctx_all, h_all, c_all, gates_all, q_all, w0p, ctxcat_all, hx, r0x, lgx, wperm, wyperm, bperm, yw, pctx, gx, bqp, bfl, blg, total;
     bool big;                  // room for the one-launch decode of the Hs = 1024 shape (speller_big.hip)
     bool pre;                  // room for the persistent decode kernel's pre-multiplied context variant
     int Vp;                    // label width padded to a multiple of 16: every cell operand is aligned and tail-free
@@ -72,6 +72,7 @@ struct SpellerLayout {
         if (big && !pre) { yw = o; o += r4((size_t)U * B * 4 * d->Hs); }
         bqp = o; if (big) o += speller_big_qp_floats(d->B, U);
         bfl = o; if (big) o += r4(speller_big_flag_words(U));
+        blg = o; if (big) o += r4(speller_big_greedy_floats(d->B, U));
         total = o;
     }
 };
@@ -376,7 +377,9 @@ int las_speller_decode_batch(const las_speller_desc* d, int teacher_forced, int 
     if (!d || check_desc(d) != LAS_OK) return 0;
     if (d->relu > LAS_ACT_RELU) return 0;
     // the YAML sizes (speller_big.hip): 16 utterances per launch, teacher forcing only
-    if (teacher_forced && speller_big_eligible(16, d->Tp, d->Hs, d->D, d->M, d->V, d->L, d->multi_head, d->use_mlp)) return 16;
+    if ((teacher_forced || decode_mode == 1) &&
+        speller_big_eligible(16, d->Tp, d->Hs, d->D, d->M, d->V, d->L, d->multi_head, d->use_mlp, !teacher_forced))
+        return 16;
     if (opt_get(OPT_SPELLER_PERSIST) == 0 || (!teacher_forced && decode_mode == 2)) return 0;
     constexpr int NB = 32;      // the persistent kernels' utterance limit (two 16-row M tiles)
     return speller_persist_eligible(NB, d->Tp, d->Hs, d->D, d->M, d->V, d->L, d->multi_head, d->use_mlp, !teacher_forced) ? NB : 0;
@@ -497,14 +500,20 @@ int las_speller_fwd(const las_speller_desc* d, const float* feat, const float* k
         LAS_TRY(gemm_f32(g, stream));
     }
     // the reference's shipped sizes (Speller 1024x2, B <= 16): all U steps in one launch with register-resident cell weights
-    if (!persist_ran && teacher_forced && lay.big && err_word && !(flags & LAS_FLAG_FORCE_GENERIC) && d->relu <= LAS_ACT_RELU &&
-        speller_big_eligible(B, Tp, Hs, D, d->M, V, L, d->multi_head, d->use_mlp)) {
-        GemmDesc g;      // label half of the bottom-layer gates for every step, off the decode chain: yw[s][b] = y_s[b] W_y^T
-        g.A = y_all; g.lda = Vp; g.a_kc = true;
-        g.B = w0p; g.ldb = Vp + Hs; g.b_kc = true;
-        g.C = reserve + lay.yw; g.ldc = 4 * Hs; g.M = U * B; g.N = 4 * Hs; g.K = Vp; g.splitk = 1;
-        LAS_TRY(gemm_f32(g, stream));
+    const bool big_greedy = !teacher_forced && decode_mode == 1;
+    if (!persist_ran && (teacher_forced || big_greedy) && lay.big && err_word && !(flags & LAS_FLAG_FORCE_GENERIC) && d->relu <= LAS_ACT_RELU &&
+        speller_big_eligible(B, Tp, Hs, D, d->M, V, L, d->multi_head, d->use_mlp, big_greedy)) {
+        if (teacher_forced) {
+            GemmDesc g;      // label half of the bottom-layer gates for every step, off the decode chain: yw[s][b] = y_s[b] W_y^T
+            g.A = y_all; g.lda = Vp; g.a_kc = true;
+            g.B = w0p; g.ldb = Vp + Hs; g.b_kc = true;
+            g.C = reserve + lay.yw; g.ldc = 4 * Hs; g.M = U * B; g.N = 4 * Hs; g.K = Vp; g.splitk = 1;
+            LAS_TRY(gemm_f32(g, stream));
+        }
         BigFwd p;
+        if (big_greedy) {      // the kernel produces log-probabilities, arg-max and the fed-back one-hot rows itself
+            p.mode = 1; p.w_c = d->w_c; p.b_c = d->b_c; p.logp = logp; p.argmax = argmax; p.y_all = y_all; p.lgp = reserve + lay.blg;
+        }
         p.w0p = w0p; p.Vp = Vp;
         p.w_hh0 = d->w_hh[0]; p.w_ih1 = d->w_ih[1]; p.w_hh1 = d->w_hh[1];
         p.b_ih0 = d->b_ih[0]; p.b_hh0 = d->b_hh[0]; p.b_ih1 = d->b_ih[1]; p.b_hh1 = d->b_hh[1];

@@ -188,11 +188,15 @@ struct BigFwd {
     const float* yw;                                // (U*B, 4Hs): y_s W_y^T, rows in PyTorch gate order (no bias)
     float* ctx_all; float* h_all; float* c_all; float* gates_all; float* q_all; float* att;
     float* hx; float* qp; unsigned* flags;          // hand-off slabs: speller_big_hx_floats / _qp_floats / _flag_words (16-byte aligned)
+    int mode = 0;                                   // 0 teacher forcing, 1 free-running greedy (feed the one-hot arg-max, reference decode_mode 1)
+    const float* w_c = nullptr; const float* b_c = nullptr; float* logp = nullptr; int* argmax = nullptr; float* y_all = nullptr;
+    float* lgp = nullptr;                           // greedy: speller_big_greedy_floats() (partial logits + fed-back symbols)
     int B, Tp, U, V, relu;
     unsigned* err;
 };
 bool speller_big_shape(int B, int Tp, int Hs, int D, int M, int V, int L, int heads, int use_mlp);       // shape only (sizes the reserve)
-bool speller_big_eligible(int B, int Tp, int Hs, int D, int M, int V, int L, int heads, int use_mlp);    // shape + switch + residency
+bool speller_big_eligible(int B, int Tp, int Hs, int D, int M, int V, int L, int heads, int use_mlp, int greedy = 0);    // shape + switch + residency
+size_t speller_big_greedy_floats(int B, int U);
 size_t speller_big_hx_floats(int U);
 size_t speller_big_qp_floats(int B, int U);
 size_t speller_big_flag_words(int U);

@@ -37,6 +37,8 @@ struct BigArgs {
     const float* feat; const float* keys; const float* yw;
     float* ctx_all; float* h_all; float* c_all; float* gates_all; float* q_all; float* att;
     float* hx; float* qp; unsigned* flags;
+    // free-running greedy decode (mode 1: the arg-max symbol is fed back, reference las_model.py:223-227): character distribution inside the loop
+    int mode; int V; const float* w_c; const float* b_c; float* logp; int* argmax; float* y_all; float* lgp; float* ysym;
     int B, Tp, U, relu;
     int tune;                                            // poll pacing (option SPELLER_BIG_TUNE)
     unsigned* err;
@@ -235,6 +237,7 @@ __device__ __forceinline__ bool flags_wait(const unsigned* fl, bool active, unsi
     }
 }
 
+template <bool GREEDY>
 __global__ __launch_bounds__(BG_THREADS, 1) void speller_big_fwd_kernel(const BigArgs a) {
     extern __shared__ float lds[];
     float* red = lds;                              // [8 waves][16 utterances][17]: K reduction of a gate tile
@@ -245,6 +248,9 @@ __global__ __launch_bounds__(BG_THREADS, 1) void speller_big_fwd_kernel(const Bi
     float* aS = wst + 16;                          // [256]: attention weights of the utterance
     float* keysS = aS + BG_MAXTP;                  // [Tp][68]
     float* featS = keysS + a.Tp * BG_KLD;          // [Tp][64]: this workgroup's 64 feature columns of every frame
+    float* wcS = featS + a.Tp * 64;                // greedy: [32 symbols][64 h1 columns | 64 context columns] of W_c for this column block
+    float* wyS = wcS + 32 * 128;                   // greedy: [16 gate rows][32 symbols] of W_y
+    int* symS = reinterpret_cast<int*>(wyS + 16 * 32);      // greedy: the fed-back symbol of every utterance
     __shared__ int dead_s;
 
     const int wg = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, r = lane & 15, kq = lane >> 4;
@@ -291,6 +297,22 @@ __global__ __launch_bounds__(BG_THREADS, 1) void speller_big_fwd_kernel(const Bi
     }
     if (tid < 256) wphiS[tid] = a.w_phi[(size_t)(tid >> 2) * BG_HS + j0 + (tid & 3)];
     const float bphi = a.b_phi[lane];
+    constexpr bool greedy = GREEDY;      // (a template parameter: the teacher-forced instantiation keeps its registers — 0 spills)
+    float bc = 0.f;
+    if (greedy) {
+        if (att_on) {
+            for (int idx = tid; idx < 32 * 128; idx += BG_THREADS) {
+                const int v = idx >> 7, k = idx & 127;
+                wcS[idx] = v < a.V ? a.w_c[(size_t)v * (2 * BG_HS) + (k < 64 ? aj * 64 + k : BG_HS + aj * 64 + (k - 64))] : 0.f;
+            }
+            if (lane < a.V) bc = a.b_c[lane];
+        }
+        {
+            const int n = tid >> 5, v = tid & 31;      // 512 threads = 16 gate rows x 32 symbols
+            wyS[tid] = a.w0p[((size_t)(n >> 2) * BG_HS + j0 + (n & 3)) * a.ldw0 + v];
+        }
+        if (tid < 16) symS[tid] = 0;                     // <sos> = symbol 0 (las_model.py:193-195)
+    }
     if (tid == 0) dead_s = 0;
     __syncthreads();
     bool dead = false;
@@ -347,7 +369,7 @@ __global__ __launch_bounds__(BG_THREADS, 1) void speller_big_fwd_kernel(const Bi
         const unsigned* flc = fl + (wg & 7) * BG_WGS;                    // the copy this workgroup polls (one per XCD: 256 pollers on one 1 KB array serialise on its channel)
         // label half of the bottom-layer gates (one GEMM before the launch), off the chain
         float ywv[4] = {0.f, 0.f, 0.f, 0.f};
-        if (cell_on) {
+        if (cell_on && !greedy) {
 #pragma unroll
             for (int g = 0; g < 4; ++g) ywv[g] = a.yw[((size_t)s * B + cb) * (4 * BG_HS) + g * BG_HS + j0 + cu];
         }
@@ -358,8 +380,22 @@ __global__ __launch_bounds__(BG_THREADS, 1) void speller_big_fwd_kernel(const Bi
                 if (flags_wait(flc - BG_FLW + 2 * 8 * BG_WGS + lane * 4, lane * 4 < B * 16, a.err, 0xB1600001u, (a.tune >> 16) & 255, (a.tune >> 8) & 255)) dead_s = 1;
             }
             BG_WSTAMP(0);
+            if (greedy && wave == 0 && s > 0) {      // the symbol every utterance emitted at step s-1 (published ~2 us behind its context)
+                unsigned v = 0, spins = 0;
+                for (;;) {
+                    v = ld1_agent(a.ysym + (size_t)(s - 1) * 16 + min(lane, B - 1));
+                    if (!__any(v == PS_SENT)) break;
+                    if (dead || spin_expired(spins, a.err, 0xB1600009u)) { dead = true; dead_s = 1; v = 0; break; }
+                }
+                if (lane < 16) symS[lane] = (int)v & 31;
+            }
             __syncthreads();
             dead |= dead_s != 0;
+            if (greedy && cell_on) {
+                const int sym = symS[cb];
+#pragma unroll
+                for (int g = 0; g < 4; ++g) ywv[g] = wyS[(g * 4 + cu) * 32 + sym];
+            }
             if (s == 0) load_ctx(a.ctx_all, ax, 0xB1600002u);        // ctx_{-1} = feat[:,0,:], row-major, written before the launch
             else load_cx(a.hx + ((size_t)2 * U + s - 1) * BG_WGS * 64, ax, 0xB1600002u);
             acc0 = seg_mfma(ax, wc, acc0);
@@ -560,6 +596,56 @@ __global__ __launch_bounds__(BG_THREADS, 1) void speller_big_fwd_kernel(const Bi
                 a.ctx_all[((size_t)(s + 1) * B + ab) * BG_HS + aj * 64 + lane] = c;
                 if (lane < 8) st1_agent(reinterpret_cast<float*>(const_cast<unsigned*>(fl)) + (16 + lane) * BG_WGS + ab * 16 + aj, 0.f);
                 BG_WSTAMP(5);
+                if (greedy) {
+                    // this column block's part of the logits W_c [h1 | ctx] (reference las_model.py:181-182): lane = column
+                    const float* hp = a.hx + ((size_t)U + s) * BG_WGS * 64 + ((size_t)((aj * 64 + lane) >> 2) * 16 + ab) * 4 + (lane & 3);
+                    unsigned hb = __builtin_nontemporal_load(reinterpret_cast<const unsigned*>(hp));
+                    {
+                        unsigned spins = 0;
+                        while (__any(hb == PS_SENT)) {
+                            hb = ld1_agent(hp);
+                            if (dead || spin_expired(spins, a.err, 0xB160000Au)) { dead = true; dead_s = 1; break; }
+                        }
+                    }
+                    const float h1v = __uint_as_float(hb);
+                    float mine = 0.f;
+#pragma unroll
+                    for (int v = 0; v < 32; ++v) {
+                        const float t = wsum(fmaf(wcS[v * 128 + lane], h1v, wcS[v * 128 + 64 + lane] * c));
+                        mine = lane == v ? t : mine;
+                    }
+                    if (lane < 32) st1_agent(a.lgp + (((size_t)s * B + ab) * 16 + aj) * 32 + lane, mine);
+                    if (aj == 0) {      // workgroup (ab, 0): add the 16 parts, log-softmax, first maximal index, feed it back
+                        float lg = 0.f;
+                        unsigned spins = 0;
+                        for (;;) {
+                            bool bad = false;
+                            lg = 0.f;
+#pragma unroll
+                            for (int i = 0; i < 16; ++i) {
+                                const unsigned x = ld1_agent(a.lgp + (((size_t)s * B + ab) * 16 + i) * 32 + (lane & 31));
+                                bad |= x == PS_SENT;
+                                lg += __uint_as_float(x);
+                            }
+                            if (!__any(bad)) break;
+                            if (dead || spin_expired(spins, a.err, 0xB160000Bu)) { dead = true; dead_s = 1; break; }
+                        }
+                        const bool vv = lane < a.V;
+                        lg = vv ? lg + bc : -INFINITY;
+                        const float m = wmax(lg);
+                        const float se = wsum(vv ? expf(lg - m) : 0.f);
+                        const float lse = m + logf(se);
+                        int best = (vv && lg == m) ? lane : 0x7fffffff;
+#pragma unroll
+                        for (int mm = 32; mm >= 1; mm >>= 1) best = min(best, __shfl_xor(best, mm));
+                        if (vv) a.logp[((size_t)s * B + ab) * a.V + lane] = lg - lse;
+                        if (lane == 0) {
+                            if (a.argmax) a.argmax[(size_t)s * B + ab] = best;
+                            st1_agent(a.ysym + (size_t)s * 16 + ab, __int_as_float(best));
+                        }
+                        if (lane < 32) a.y_all[((size_t)(s + 1) * B + ab) * 32 + lane] = lane == best ? 1.f : 0.f;
+                    }
+                }
             }
         }
         BG_STAMP(7);
@@ -567,8 +653,8 @@ __global__ __launch_bounds__(BG_THREADS, 1) void speller_big_fwd_kernel(const Bi
     }
 }
 
-size_t big_fwd_smem(int Tp) {
-    return sizeof(float) * ((size_t)BG_NW * 16 * 17 + BG_NW * BG_M + BG_NW * 64 + BG_M * 4 + 16 + BG_MAXTP + (size_t)Tp * BG_KLD + (size_t)Tp * 64);
+size_t big_fwd_smem(int Tp, int greedy) {
+    return (greedy ? sizeof(float) * (32 * 128 + 16 * 32 + 16) : 0) + sizeof(float) * ((size_t)BG_NW * 16 * 17 + BG_NW * BG_M + BG_NW * 64 + BG_M * 4 + 16 + BG_MAXTP + (size_t)Tp * BG_KLD + (size_t)Tp * 64);
 }
 
 // ==================================================================================================================================
@@ -1018,18 +1104,21 @@ size_t speller_big_hx_floats(int U) { return (size_t)3 * U * BG_WGS * 64; }
 size_t speller_big_qp_floats(int B, int U) { return (size_t)U * B * BG_WGS * BG_M; }
 size_t speller_big_flag_words(int U) { return (size_t)U * BG_FLW; }
 
-static bool big_fits(int Tp) {
-    const size_t smem = big_fwd_smem(Tp);
+static bool big_fits(int Tp, int greedy) {
+    const size_t smem = big_fwd_smem(Tp, greedy);
     if (smem > 160 * 1024) return false;
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&speller_big_fwd_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem) != hipSuccess)
-        return false;
-    return persistent_launch_fits(speller_big_fwd_kernel, BG_THREADS, smem, BG_WGS);
+    const void* fn = greedy ? reinterpret_cast<const void*>(&speller_big_fwd_kernel<true>) : reinterpret_cast<const void*>(&speller_big_fwd_kernel<false>);
+    if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem) != hipSuccess) return false;
+    return greedy ? persistent_launch_fits(speller_big_fwd_kernel<true>, BG_THREADS, smem, BG_WGS)
+                  : persistent_launch_fits(speller_big_fwd_kernel<false>, BG_THREADS, smem, BG_WGS);
 }
 
-bool speller_big_eligible(int B, int Tp, int Hs, int D, int M, int V, int L, int heads, int use_mlp) {
+bool speller_big_eligible(int B, int Tp, int Hs, int D, int M, int V, int L, int heads, int use_mlp, int greedy) {
     if (opt_get(OPT_SPELLER_BIG) == 0 || !speller_big_shape(B, Tp, Hs, D, M, V, L, heads, use_mlp)) return false;
-    return big_fits(Tp);
+    if (greedy && (V > 32 || V <= 16)) return false;      // the fed-back symbol rows are 32 floats wide (Vp = 32)
+    return big_fits(Tp, greedy);
 }
+size_t speller_big_greedy_floats(int B, int U) { return (size_t)U * B * 16 * 32 + (size_t)U * 16; }
 
 int speller_big_fwd(const BigFwd& p, hipStream_t stream) {
     LAS_REQUIRE(speller_big_shape(p.B, p.Tp, BG_HS, BG_HS, BG_M, p.V, 2, 1, 1), "one-launch decode (Hs = 1024) shape");
@@ -1043,10 +1132,13 @@ int speller_big_fwd(const BigFwd& p, hipStream_t stream) {
     a.feat = p.feat; a.keys = p.keys; a.yw = p.yw;
     a.ctx_all = p.ctx_all; a.h_all = p.h_all; a.c_all = p.c_all; a.gates_all = p.gates_all; a.q_all = p.q_all; a.att = p.att;
     a.hx = p.hx; a.qp = p.qp; a.flags = p.flags;
+    a.mode = p.mode; a.V = p.V; a.w_c = p.w_c; a.b_c = p.b_c; a.logp = p.logp; a.argmax = p.argmax; a.y_all = p.y_all;
+    a.lgp = p.lgp; a.ysym = p.lgp ? p.lgp + (size_t)p.U * p.B * 16 * 32 : nullptr;
+    LAS_REQUIRE(p.mode == 0 || (p.mode == 1 && p.w_c && p.b_c && p.logp && p.y_all && p.lgp && p.Vp == 32), "greedy decode operands");
     a.B = p.B; a.Tp = p.Tp; a.U = p.U; a.relu = p.relu; a.err = p.err;
     a.trace = g_big_trace;
     a.tune = (int)opt_get(OPT_SPELLER_BIG_TUNE);
-    if (!big_fits(p.Tp))
+    if (!big_fits(p.Tp, p.mode))
         return fail(LAS_ERR_UNSUPPORTED, "one-launch decode (Hs = 1024): %s%ld workgroups cannot all be resident", "", (long)BG_WGS);
     // sentinel-fill what the phases hand over: the operand-order copies of h and of the contexts, the query slices and the flags
     LAS_HIP_CHECK(hipMemsetAsync(p.hx, 0xFF, sizeof(float) * speller_big_hx_floats(p.U), stream));
@@ -1056,9 +1148,11 @@ int speller_big_fwd(const BigFwd& p, hipStream_t stream) {
         LAS_HIP_CHECK(hipMemsetAsync(p.qp, 0xFF, sizeof(float) * speller_big_qp_floats(p.B, p.U), stream));
         LAS_HIP_CHECK(hipMemsetAsync(p.flags, 0xFF, sizeof(unsigned) * speller_big_flag_words(p.U), stream));
     }
+    if (p.mode == 1) LAS_HIP_CHECK(hipMemsetAsync(p.lgp, 0xFF, sizeof(float) * speller_big_greedy_floats(p.B, p.U), stream));
     {
         KernelTimer timer(TIMED_DECODE_FWD, stream);
-        hipLaunchKernelGGL(speller_big_fwd_kernel, dim3(BG_WGS), dim3(BG_THREADS), big_fwd_smem(p.Tp), stream, a);
+        if (p.mode == 1) hipLaunchKernelGGL(speller_big_fwd_kernel<true>, dim3(BG_WGS), dim3(BG_THREADS), big_fwd_smem(p.Tp, 1), stream, a);
+        else hipLaunchKernelGGL(speller_big_fwd_kernel<false>, dim3(BG_WGS), dim3(BG_THREADS), big_fwd_smem(p.Tp, 0), stream, a);
     }
     LAS_LAUNCH_CHECK();
     return LAS_OK;

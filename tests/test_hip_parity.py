@@ -485,10 +485,13 @@ def test_direct_gradient_write_matches_autograd_accumulation(cfg_name, B):
 
 
 @pytest.mark.parametrize("cfg_name,B,Tp,U,decode_mode", [("P", 32, 100, 20, 1), ("P", 32, 100, 20, 0), ("S", 7, 150, 9, 1),
-                                                          ("S", 32, 60, 6, 0), ("P", 3, 30, 5, 1), ("P", 40, 30, 5, 1)])
+                                                          ("S", 32, 60, 6, 0), ("P", 3, 30, 5, 1), ("P", 40, 30, 5, 1),
+                                                          # the YAML sizes (speller_big.hip, greedy only): full batch, partial batch, a sliced batch
+                                                          ("Y", 16, 100, 20, 1), ("Y", 5, 37, 9, 1), ("Y", 24, 40, 5, 1)])
 def test_persistent_free_running_decode_matches_stepwise(cfg_name, B, Tp, U, decode_mode):
     """Greedy (decode_mode 1) and log-prob-feedback (decode_mode 0) decoding inside the one-launch kernel against the
     per-step launch chain: log-probabilities, attention, arg-max sequences, and (mode 1) the gradients."""
+    big = cfg_name == "Y"
     import ctypes
     from las_pytorch_amd import Speller, _cabi, synth
     c = synth.CONFIGS[cfg_name]
@@ -501,8 +504,9 @@ def test_persistent_free_running_decode_matches_stepwise(cfg_name, B, Tp, U, dec
     L = _cabi.lib()
     L.las_debug_persist_trace.argtypes = [ctypes.c_void_p]
     L.las_debug_persist_trace.restype = None
-    trace = torch.zeros(3 * U * 8, dtype=torch.int64, device="cuda")      # las_debug_persist_trace: 3 roles x U steps x 8 stamps
-    set_trace = L.las_debug_persist_trace
+    # las_debug_persist_trace: 3 roles x U steps x 8 stamps; las_debug_big_trace: 64 steps x 16 + 256 workgroups x 8
+    trace = torch.zeros(64 * 16 + 256 * 8 if big else 3 * U * 8, dtype=torch.int64, device="cuda")
+    set_trace = L.las_debug_big_trace if big else L.las_debug_persist_trace
     res = []
     for force in (False, True):
         sp.force_generic = force

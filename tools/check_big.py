@@ -135,6 +135,55 @@ def run(B, Tp, U, scale=None, trace_on=True):
     return worst, err, ran
 
 
+def run_greedy(B, Tp, U, scale=None):
+    """Free-running greedy decode (decode_mode 1) of the same kernel against the per-step chain: log-probs, arg-max sequences, attention,
+    gradients (the hoisted backward runs the one-launch backward kernel on the greedy stash), time."""
+    c = synth.CONFIGS["Y"]
+    torch.manual_seed(6)
+    sp = Speller(vocab_size=c["V"], hidden_size=c["Hs"], rnn_unit="LSTM", num_layers=c["Ls"], max_label_len=U,
+                 use_mlp_in_attention=True, mlp_dim_in_attention=c["M"], mlp_activate_in_attention="relu",
+                 listener_hidden_size=c["H"], multi_head=1, decode_mode=1).cuda()
+    if scale is not None:
+        with torch.no_grad():
+            for p in sp.parameters():
+                p.uniform_(-scale, scale)
+    feat0 = torch.randn(B, Tp, 2 * c["H"], device="cuda") * 0.5
+    w = torch.randn(U, B, c["V"], device="cuda")
+    res, tms = [], {}
+    for force in (False, True):
+        sp.force_generic = force
+        sp.zero_grad(set_to_none=True)
+        feat = feat0.clone().requires_grad_(True)
+        preds, att = sp(feat, ground_truth=None, teacher_force_rate=0.0)
+        logp = torch.stack(preds)
+        (logp * w).sum().backward()
+        out = dict(logp=logp.detach().cpu().numpy(), att=torch.stack([a[0] for a in att]).detach().cpu().numpy(), dfeat=feat.grad.cpu().numpy())
+        out.update({"d" + n: p.grad.cpu().numpy() for n, p in sp.named_parameters() if p.grad is not None})
+        res.append(out)
+        with torch.no_grad():
+            for _ in range(2):
+                sp(feat0, ground_truth=None, teacher_force_rate=0.0)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(5):
+                sp(feat0, ground_truth=None, teacher_force_rate=0.0)
+            torch.cuda.synchronize()
+            tms[force] = (time.perf_counter() - t0) / 5 * 1e3
+    sp.force_generic = False
+    err = int(_cabi.err_word(torch.device("cuda", 0))[0].item())
+    same = bool((res[0]["logp"].argmax(-1) == res[1]["logp"].argmax(-1)).all())
+    nsym = len(np.unique(res[1]["logp"].argmax(-1)))
+    worst = 0.0
+    for k in res[0]:
+        a, b = res[0][k], res[1][k]
+        scale_k = float(np.abs(b).max()) + 1e-30
+        d = float(np.abs(a - b).max())
+        worst = max(worst, d / (1e-3 * scale_k + 1e-5 * max(1.0, scale_k)))
+    print(f"greedy B={B} Tp={Tp} U={U}: arg-max sequences identical: {same} ({nsym} distinct symbols), worst diff/tol {worst:.3f}, error word {err:#x}; "
+          f"forward {tms[False]:.3f} ms one launch, {tms[True]:.3f} ms per-step ({tms[False] * 1e3 / U:.2f} / {tms[True] * 1e3 / U:.2f} us per step)")
+    return worst, err, same
+
+
 if __name__ == "__main__":
     if len(sys.argv) >= 4:
         cases = [tuple(int(v) for v in sys.argv[1:4])]
@@ -144,5 +193,9 @@ if __name__ == "__main__":
     for B, Tp, U in cases:
         worst, err, ran = run(B, Tp, U)
         bad += (worst > 1.0) or err != 0 or not ran
+    if len(sys.argv) < 4:
+        for B, Tp, U, sc in [(16, 100, 24, None), (5, 37, 9, 0.08), (16, 100, 128, 0.05)]:
+            worst, err, same = run_greedy(B, Tp, U, sc)
+            bad += (worst > 1.0) or err != 0 or not same
     print("RESULT", "FAIL" if bad else "OK")
     sys.exit(1 if bad else 0)
