@@ -71,7 +71,7 @@ const char* las_last_error(void);
  *   GEMM_GROUP 1*, GEMM_XCD_SWZ 1*, GEMM_BATCH_DIRS 1*          grouped weight-gradient launches / XCD order / batched directions
  *   SPELLER_PERSIST 1*, SPELLER_PERSIST_BWD 1*                   one-launch decode loop forward / backward (0: per-step launches)
  *   SPELLER_PRE 1*, SPELLER_PRE_BWD 1*                           pre-multiplied-context variants of those kernels
- *   SPELLER_BIG 1*, SPELLER_BIG_BWD 1*                           one-launch teacher-forced decode loop forward / backward for the reference's
+ *   SPELLER_BIG 1*, SPELLER_BIG_BWD 1*                           one-launch decode loop (teacher-forced or greedy) forward / backward for the reference's
  *                                                                shipped sizes (Speller 1024x2, attention MLP 64, B <= 16, T' <= 256:
  *                                                                speller_big.hip; 0: per-step launches)
  *   SPELLER_BIG_TUNE 0*   poll pacing of those two kernels in units of 64 clocks: byte 0 / 2 / 3 before the first poll of the forward's h0 /
@@ -162,7 +162,7 @@ int las_attn_keys_fwd(const las_speller_desc* d, const float* feat, float* keys,
 size_t las_speller_reserve_floats(const las_speller_desc* d, int U);
 
 /* Utterances per launch of the one-launch decode kernels for this description (d->B is ignored): the largest batch for which
- * las_speller_fwd / las_speller_bwd take the persistent path (today 32, or 0 when the shape, the decode mode or a switch rules it
+ * las_speller_fwd / las_speller_bwd take a one-launch path (today 32 for Hs <= 512, 16 for the Hs = 1024 kernels, or 0 when the shape, the decode mode or a switch rules it
  * out).  A caller with a larger batch gains by running the Speller in slices of that many utterances — every slice then decodes
  * in one launch instead of U per-step launch chains (las_pytorch_amd/model/las_model.py::Speller._run does; the reference's loop
  * model/las_model.py:205-236 has no such notion).  Pure function of its arguments, the option registry and the device's CU count. */

@@ -350,7 +350,7 @@ def test_graph_replay_step_equals_eager_step():
 
 def test_decode_batch_query_and_slicing_decision():
     """las_speller_decode_batch (include/las_hip.h): 32 utterances per launch where the one-launch decode kernels of Hs <= 512 apply, 16 for
-    the teacher-forced loop of the YAML sizes (speller_big.hip), 0 where neither does (free-running Hs = 1024, multi-head, decode mode 2,
+    the teacher-forced and the greedy loop of the YAML sizes (speller_big.hip), 0 where neither does (other feedback modes at Hs = 1024, multi-head, decode mode 2,
     T' beyond the kernels' tables, the switches off) — Speller._run slices larger batches only in the first two cases."""
     from las_pytorch_amd import Speller, _cabi, synth
 
@@ -369,7 +369,8 @@ def test_decode_batch_query_and_slicing_decision():
     assert query("P", teacher=False, mode=2) == 0           # sampled decoding: per-step path
     assert query("P", heads=2) == 0
     assert query("Y") == 16                                 # Hs = 1024, teacher forcing: one launch per 16 utterances (speller_big.hip)
-    assert query("Y", teacher=False, mode=1) == 0           # ... its free-running decode: per-step path, never sliced
+    assert query("Y", teacher=False, mode=1) == 16          # ... and for its greedy decode (the YAML's decode_mode)
+    assert query("Y", teacher=False, mode=0) == 0           # log-prob feedback at that size: per-step path, never sliced
     assert query("Y", Tp=300) == 0                          # T' beyond 256
     assert query("P", Tp=2000) == 0                         # T' beyond the residency table
     _cabi.set_option("SPELLER_PERSIST", 0)
