@@ -380,22 +380,8 @@ __global__ __launch_bounds__(BG_THREADS, 1) void speller_big_fwd_kernel(const Bi
                 if (flags_wait(flc - BG_FLW + 2 * 8 * BG_WGS + lane * 4, lane * 4 < B * 16, a.err, 0xB1600001u, (a.tune >> 16) & 255, (a.tune >> 8) & 255)) dead_s = 1;
             }
             BG_WSTAMP(0);
-            if (greedy && wave == 0 && s > 0) {      // the symbol every utterance emitted at step s-1 (published ~2 us behind its context)
-                unsigned v = 0, spins = 0;
-                for (;;) {
-                    v = ld1_agent(a.ysym + (size_t)(s - 1) * 16 + min(lane, B - 1));
-                    if (!__any(v == PS_SENT)) break;
-                    if (dead || spin_expired(spins, a.err, 0xB1600009u)) { dead = true; dead_s = 1; v = 0; break; }
-                }
-                if (lane < 16) symS[lane] = (int)v & 31;
-            }
             __syncthreads();
             dead |= dead_s != 0;
-            if (greedy && cell_on) {
-                const int sym = symS[cb];
-#pragma unroll
-                for (int g = 0; g < 4; ++g) ywv[g] = wyS[(g * 4 + cu) * 32 + sym];
-            }
             if (s == 0) load_ctx(a.ctx_all, ax, 0xB1600002u);        // ctx_{-1} = feat[:,0,:], row-major, written before the launch
             else load_cx(a.hx + ((size_t)2 * U + s - 1) * BG_WGS * 64, ax, 0xB1600002u);
             acc0 = seg_mfma(ax, wc, acc0);
@@ -405,6 +391,20 @@ __global__ __launch_bounds__(BG_THREADS, 1) void speller_big_fwd_kernel(const Bi
             __syncthreads();
             BG_STAMP(1);
             if (wave == 0) {
+                if (greedy) {      // the symbol every utterance emitted at step s-1: published ~2 us behind its context, i.e. while the product above ran
+                    if (s > 0) {
+                        unsigned v = 0, spins = 0;
+                        for (;;) {
+                            v = ld1_agent(a.ysym + (size_t)(s - 1) * 16 + min(lane, B - 1));
+                            if (!__any(v == PS_SENT)) break;
+                            if (dead || spin_expired(spins, a.err, 0xB1600009u)) { dead = true; dead_s = 1; v = 0; break; }
+                        }
+                        if (lane < 16) symS[lane] = (int)v & 31;
+                    }
+                    const int sym = symS[cb];
+#pragma unroll
+                    for (int g = 0; g < 4; ++g) ywv[g] = wyS[(g * 4 + cu) * 32 + sym];
+                }
                 float g4[4];
 #pragma unroll
                 for (int g = 0; g < 4; ++g) {
