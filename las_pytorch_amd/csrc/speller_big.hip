@@ -253,7 +253,9 @@ __global__ __launch_bounds__(BG_THREADS, 1) void speller_big_fwd_kernel(const Bi
     int* symS = reinterpret_cast<int*>(wyS + 16 * 32);      // greedy: the fed-back symbol of every utterance
     __shared__ int dead_s;
 
-    const int wg = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, r = lane & 15, kq = lane >> 4;
+    // (per-thread indices are re-derived from an opaque copy of threadIdx.x at the start of each phase: see the backward kernel)
+    const int wg = blockIdx.x;
+    int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, r = lane & 15, kq = lane >> 4;
     const int B = a.B, U = a.U, Tp = a.Tp;
     const int j0 = wg * 4;
     const size_t sH = (size_t)B * BG_HS;
@@ -272,8 +274,8 @@ __global__ __launch_bounds__(BG_THREADS, 1) void speller_big_fwd_kernel(const Bi
         }
     }
     // ---- cell lanes (wave 0): utterance cb, unit cu
-    const int cb = lane >> 2, cu = lane & 3;
-    const bool cell_on = wave == 0 && cb < B;
+    int cb = lane >> 2, cu = lane & 3;
+    bool cell_on = wave == 0 && cb < B;
     float bias0[4] = {0.f, 0.f, 0.f, 0.f}, bias1[4] = {0.f, 0.f, 0.f, 0.f};
     if (wave == 0) {
 #pragma unroll
@@ -318,9 +320,9 @@ __global__ __launch_bounds__(BG_THREADS, 1) void speller_big_fwd_kernel(const Bi
     bool dead = false;
 
     f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
-    const int rowb = min(r, B - 1);                      // rows beyond the batch repeat the last utterance (never stored)
-    const unsigned aoff = (unsigned)(rowb * BG_HS + wave * 128 + kq * 4) * 4u;      // this lane's first k-block in a row-major (B,1024) slab
-    const unsigned hoff = (unsigned)(((wave * 32 + kq) * 16 + rowb) * 4) * 4u;      // ... in a producer-major [256][16][4] slab of h
+    int rowb = min(r, B - 1);                            // rows beyond the batch repeat the last utterance (never stored)
+    unsigned aoff = (unsigned)(rowb * BG_HS + wave * 128 + kq * 4) * 4u;      // this lane's first k-block in a row-major (B,1024) slab
+    unsigned hoff = (unsigned)(((wave * 32 + kq) * 16 + rowb) * 4) * 4u;      // ... in a producer-major [256][16][4] slab of h
 
     // checked loads of this lane's 8 k-blocks of a hand-off slab: through the L2 first (the flags said every producer is through), agent
     // scope if a line was fetched too early
@@ -336,7 +338,14 @@ __global__ __launch_bounds__(BG_THREADS, 1) void speller_big_fwd_kernel(const Bi
             if (dead || spin_expired(spins, a.err, code)) { dead = true; break; }
         }
     };
-    const unsigned coff = (unsigned)((wave * 8 * 16 + rowb) * 16 + kq * 4) * 4u;      // ... in a context slab [64 k-blocks][16 utterances][16 columns]
+    unsigned coff = (unsigned)((wave * 8 * 16 + rowb) * 16 + kq * 4) * 4u;      // ... in a context slab [64 k-blocks][16 utterances][16 columns]
+    auto derive = [&]() {
+        tid = (int)opaque(threadIdx.x); lane = tid & 63; wave = tid >> 6; r = lane & 15; kq = lane >> 4;
+        cb = lane >> 2; cu = lane & 3; cell_on = wave == 0 && cb < B; rowb = min(r, B - 1);
+        aoff = (unsigned)(rowb * BG_HS + wave * 128 + kq * 4) * 4u;
+        hoff = (unsigned)(((wave * 32 + kq) * 16 + rowb) * 4) * 4u;
+        coff = (unsigned)((wave * 8 * 16 + rowb) * 16 + kq * 4) * 4u;
+    };
     auto load_cx = [&](const float* slab, f32x4 (&ax)[8], unsigned code) {
         const float* p = at_bytes(slab, opaque(coff));
         ld4x8_kb<true>(p, ax);
@@ -363,6 +372,7 @@ __global__ __launch_bounds__(BG_THREADS, 1) void speller_big_fwd_kernel(const Bi
     };
 
     for (int s = 0; s < U; ++s) {
+        derive();
         BG_STAMP(0);
         if (a.trace && wg == 0 && tid == 0 && s < 64) a.trace[s * 16 + 13] = __builtin_readcyclecounter();      // shader clock (the stamps are 100 MHz)
         const unsigned* fl = a.flags + (size_t)s * BG_FLW;             // flags of this step: [h0 | h1 + query parts | ctx] x 8 copies x 256 producers
@@ -430,6 +440,7 @@ __global__ __launch_bounds__(BG_THREADS, 1) void speller_big_fwd_kernel(const Bi
         }
         BG_STAMP(2);
         // ================= [2] top cell: gates1 = b + W_ih1 h0_s + W_hh1 h1_{s-1}
+        derive();
         {
             // the recurrent half W_hh1 h1_{s-1} is multiplied while this step's h0 travels (its operand arrived in [3] of the last step; polling the
             // flags right after publishing only queues reads in front of the flag stores they are waiting for)
@@ -495,6 +506,7 @@ __global__ __launch_bounds__(BG_THREADS, 1) void speller_big_fwd_kernel(const Bi
             acc0 = seg_mfma(ax, wh0, acc0);
         }
         BG_STAMP(4);
+        derive();
         // ================= [3] attention of utterance ab, feature columns [64 aj, 64 aj + 64): query, energies of every frame, softmax, context
         {
             const float* qps = a.qp + ((size_t)s * B + min(ab, B - 1)) * BG_WGS * BG_M;
