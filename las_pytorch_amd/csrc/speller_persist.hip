@@ -309,9 +309,12 @@ struct CellRole {
                 yv[b * 32 + v] = y;
                 if (v == 0) amax[b] = best;
                 if (writer) {
-                    if (v < a.V) a.logp[((size_t)sp * B + b) * a.V + v] = lp;
-                    if (v < a.Vp) a.y_all[((size_t)(sp + 1) * B + b) * a.Vp + v] = y;
-                    if (v == 0 && a.argmax_out) a.argmax_out[(size_t)sp * B + b] = best;
+                    // (addresses from 32-bit offsets the optimiser cannot hoist: hoisted 64-bit pointers spilled here, and every spill reload
+                    // waits on vmcnt(0), i.e. on the acknowledgement of the store in front of it — three store round trips per step on the chain
+                    // of the writing workgroup)
+                    if (v < a.V) *at_bytes(a.logp, opaque(4u * (unsigned)((sp * B + b) * a.V + v))) = lp;
+                    if (v < a.Vp) *at_bytes(a.y_all, opaque(4u * (unsigned)(((sp + 1) * B + b) * a.Vp + v))) = y;
+                    if (v == 0 && a.argmax_out) *at_bytes(a.argmax_out, opaque(4u * (unsigned)(sp * B + b))) = best;
                 }
             }
         };
