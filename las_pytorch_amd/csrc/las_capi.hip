@@ -39,7 +39,7 @@ struct PblstmBwdLayout {
 };
 
 struct SpellerLayout {
-    size_t y_all, ctx_all, h_all, c_all, gates_all, q_all, w0p, ctxcat_all, hx, r0x, lgx, wperm, wyperm, bperm, yw, pctx, gx, bqp, bfl, blg, total;
+    size_t y_all, ctx_all, h_all, c_all, gates_all, q_all, w0p, ctxcat_all, hx, r0x, lgx, wperm, wyperm, bperm, yw, pctx, gx, bqp, bfl, blg, beg, total;
     bool big;                  // room for the one-launch decode of the Hs = 1024 shape (speller_big.hip)
     bool pre;                  // room for the persistent decode kernel's pre-multiplied context variant
     int Vp;                    // label width padded to a multiple of 16: every cell operand is aligned and tail-free
@@ -73,6 +73,7 @@ struct SpellerLayout {
         bqp = o; if (big) o += speller_big_qp_floats(d->B, U);
         bfl = o; if (big) o += r4(speller_big_flag_words(U));
         blg = o; if (big) o += r4(speller_big_greedy_floats(d->B, U));
+        beg = o; if (big && d->Tp > 256) o += r4((size_t)U * B * 512);
         total = o;
     }
 };
@@ -520,6 +521,7 @@ int las_speller_fwd(const las_speller_desc* d, const float* feat, const float* k
         p.w_phi = d->w_phi; p.b_phi = d->b_phi; p.feat = feat; p.keys = keys; p.yw = reserve + lay.yw;
         p.ctx_all = ctx_all; p.h_all = h_all; p.c_all = c_all; p.gates_all = gates_all; p.q_all = q_all; p.att = att;
         p.hx = reserve + lay.hx; p.qp = reserve + lay.bqp; p.flags = reinterpret_cast<unsigned*>(reserve + lay.bfl);
+        if (Tp > 256) p.eg = reserve + lay.beg;
         p.B = B; p.Tp = Tp; p.U = U; p.V = V; p.relu = d->relu; p.err = err_word;
         const int rc = speller_big_fwd(p, stream);
         if (rc != LAS_ERR_UNSUPPORTED) { LAS_TRY(rc); persist_ran = true; }

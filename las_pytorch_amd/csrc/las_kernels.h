@@ -191,6 +191,7 @@ struct BigFwd {
     int mode = 0;                                   // 0 teacher forcing, 1 free-running greedy (feed the one-hot arg-max, reference decode_mode 1)
     const float* w_c = nullptr; const float* b_c = nullptr; float* logp = nullptr; int* argmax = nullptr; float* y_all = nullptr;
     float* lgp = nullptr;                           // greedy: speller_big_greedy_floats() (partial logits + fed-back symbols)
+    float* eg = nullptr;                            // T' > 256: U*B*512 floats (energy rows exchanged by an utterance's workgroups)
     int B, Tp, U, V, relu;
     unsigned* err;
 };

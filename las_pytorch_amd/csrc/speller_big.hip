@@ -25,7 +25,9 @@ namespace {
 constexpr int BG_THREADS = 512, BG_NW = 8, BG_HS = 1024, BG_M = 64, BG_WGS = 256, BG_NB = 16;
 constexpr int BG_KLD = BG_M + 4;         // LDS row stride of the keys
 constexpr int BG_FLW = 3 * 8 * 256;      // flag words per step of the forward kernel: 3 hand-offs x 8 copies x 256 producers
-constexpr int BG_MAXTP = 256;            // encoder frames: features and keys of the workgroup's column block stay in LDS (528 B per frame)
+constexpr int BG_MAXTP = 512;            // encoder frames (one thread each).  Up to 256 the features AND all keys of the utterance stay in LDS (528 B per frame);
+                                         // above, the 16 workgroups of an utterance split the energies by frames and exchange them (LONG instantiations)
+constexpr int BG_SHORT_TP = 256;
 constexpr float BG_LOG2E = 1.4426950408889634f;
 constexpr float BG_NEG = -3.0e38f;
 
@@ -38,6 +40,7 @@ struct BigArgs {
     float* ctx_all; float* h_all; float* c_all; float* gates_all; float* q_all; float* att;
     float* hx; float* qp; unsigned* flags;
     // free-running greedy decode (mode 1: the arg-max symbol is fed back, reference las_model.py:223-227): character distribution inside the loop
+    float* eg; int FRL;                                  // T' > 256: the utterances' energy rows (U x B x 512), frames per workgroup
     int mode; int V; const float* w_c; const float* b_c; float* logp; int* argmax; float* y_all; float* lgp; float* ysym;
     int B, Tp, U, relu;
     int tune;                                            // poll pacing (option SPELLER_BIG_TUNE)
@@ -237,7 +240,7 @@ __device__ __forceinline__ bool flags_wait(const unsigned* fl, bool active, unsi
     }
 }
 
-template <bool GREEDY>
+template <bool GREEDY, bool LONG>
 __global__ __launch_bounds__(BG_THREADS, 1) void speller_big_fwd_kernel(const BigArgs a) {
     extern __shared__ float lds[];
     float* red = lds;                              // [8 waves][16 utterances][17]: K reduction of a gate tile
@@ -246,8 +249,8 @@ __global__ __launch_bounds__(BG_THREADS, 1) void speller_big_fwd_kernel(const Bi
     float* wphiS = cred + BG_NW * 64;              // [64][4]: this workgroup's K-slice of phi
     float* wst = wphiS + BG_M * 4;                 // [8 waves][2]: (max, sum) of a wave's energies
     float* aS = wst + 16;                          // [256]: attention weights of the utterance
-    float* keysS = aS + BG_MAXTP;                  // [Tp][68]
-    float* featS = keysS + a.Tp * BG_KLD;          // [Tp][64]: this workgroup's 64 feature columns of every frame
+    float* keysS = aS + BG_MAXTP;                  // [Tp][68]; LONG (T' > 256): only the FRL = ceil(T'/16) frames whose energies this workgroup computes
+    float* featS = keysS + (LONG ? a.FRL : a.Tp) * BG_KLD;      // [Tp][64]: this workgroup's 64 feature columns of every frame
     float* wcS = featS + a.Tp * 64;                // greedy: [32 symbols][64 h1 columns | 64 context columns] of W_c for this column block
     float* wyS = wcS + 32 * 128;                   // greedy: [16 gate rows][32 symbols] of W_y
     int* symS = reinterpret_cast<int*>(wyS + 16 * 32);      // greedy: the fed-back symbol of every utterance
@@ -294,7 +297,13 @@ __global__ __launch_bounds__(BG_THREADS, 1) void speller_big_fwd_kernel(const Bi
         for (int idx = tid; idx < Tp * 16; idx += BG_THREADS) {
             const int t = idx >> 4, c4 = idx & 15;
             *reinterpret_cast<f32x4*>(featS + t * 64 + c4 * 4) = ld4p(a.feat + ((size_t)ab * Tp + t) * BG_HS + aj * 64 + c4 * 4);
-            *reinterpret_cast<f32x4*>(keysS + t * BG_KLD + c4 * 4) = ld4p(a.keys + ((size_t)ab * Tp + t) * BG_M + c4 * 4);
+            if (!LONG) *reinterpret_cast<f32x4*>(keysS + t * BG_KLD + c4 * 4) = ld4p(a.keys + ((size_t)ab * Tp + t) * BG_M + c4 * 4);
+        }
+        if (LONG) {      // the keys of frames [aj FRL, aj FRL + FRL): the 16 workgroups of an utterance share the energies (one more hand-off per step)
+            for (int idx = tid; idx < a.FRL * 16; idx += BG_THREADS) {
+                const int t = aj * a.FRL + (idx >> 4), c4 = idx & 15;
+                if (t < Tp) *reinterpret_cast<f32x4*>(keysS + (idx >> 4) * BG_KLD + c4 * 4) = ld4p(a.keys + ((size_t)ab * Tp + t) * BG_M + c4 * 4);
+            }
         }
     }
     if (tid < 256) wphiS[tid] = a.w_phi[(size_t)(tid >> 2) * BG_HS + j0 + (tid & 3)];
@@ -553,13 +562,26 @@ __global__ __launch_bounds__(BG_THREADS, 1) void speller_big_fwd_kernel(const Bi
                 for (int w = 0; w < BG_NW; ++w) q += qred[w * BG_M + lane];
                 q = act_apply(q, a.relu);
                 if (aj == 0 && wave == 0) a.q_all[((size_t)s * B + ab) * BG_M + lane] = q;
-                const float* kr = keysS + min(tid, Tp - 1) * BG_KLD;
                 float e = 0.f;
+                if (!LONG || wave == 0) {
+                    const float* kr = keysS + (LONG ? min(lane, a.FRL - 1) : min(tid, Tp - 1)) * BG_KLD;
 #pragma unroll
-                for (int m4 = 0; m4 < BG_M / 4; ++m4) {
-                    const f32x4 kv = *reinterpret_cast<const f32x4*>(kr + m4 * 4);
-                    e = fmaf(lane_f(q, m4 * 4), kv[0], e); e = fmaf(lane_f(q, m4 * 4 + 1), kv[1], e);
-                    e = fmaf(lane_f(q, m4 * 4 + 2), kv[2], e); e = fmaf(lane_f(q, m4 * 4 + 3), kv[3], e);
+                    for (int m4 = 0; m4 < BG_M / 4; ++m4) {
+                        const f32x4 kv = *reinterpret_cast<const f32x4*>(kr + m4 * 4);
+                        e = fmaf(lane_f(q, m4 * 4), kv[0], e); e = fmaf(lane_f(q, m4 * 4 + 1), kv[1], e);
+                        e = fmaf(lane_f(q, m4 * 4 + 2), kv[2], e); e = fmaf(lane_f(q, m4 * 4 + 3), kv[3], e);
+                    }
+                }
+                if (LONG) {      // this workgroup's frames -> the utterance's energy row; every workgroup of the utterance then reads the whole row
+                    float* eg = a.eg + ((size_t)s * B + ab) * 512;
+                    if (wave == 0 && lane < a.FRL && aj * a.FRL + lane < Tp) st1_agent(eg + aj * a.FRL + lane, e);
+                    unsigned x = 0, spins = 0;
+                    for (;;) {
+                        x = ld1_agent(eg + min(tid, Tp - 1));
+                        if (!__any(x == PS_SENT)) break;
+                        if (dead || spin_expired(spins, a.err, 0xB160000Cu)) { dead = true; break; }
+                    }
+                    e = __uint_as_float(x);
                 }
                 e = fr_on ? e : BG_NEG;
                 mw = wmax(e);
@@ -666,7 +688,8 @@ __global__ __launch_bounds__(BG_THREADS, 1) void speller_big_fwd_kernel(const Bi
 }
 
 size_t big_fwd_smem(int Tp, int greedy) {
-    return (greedy ? sizeof(float) * (32 * 128 + 16 * 32 + 16) : 0) + sizeof(float) * ((size_t)BG_NW * 16 * 17 + BG_NW * BG_M + BG_NW * 64 + BG_M * 4 + 16 + BG_MAXTP + (size_t)Tp * BG_KLD + (size_t)Tp * 64);
+    const size_t krows = Tp > BG_SHORT_TP ? (size_t)((Tp + 15) / 16) : (size_t)Tp;
+    return (greedy ? sizeof(float) * (32 * 128 + 16 * 32 + 16) : 0) + sizeof(float) * ((size_t)BG_NW * 16 * 17 + BG_NW * BG_M + BG_NW * 64 + BG_M * 4 + 16 + BG_MAXTP + krows * BG_KLD + (size_t)Tp * 64);
 }
 
 // ==================================================================================================================================
@@ -688,7 +711,7 @@ size_t big_fwd_smem(int Tp, int greedy) {
 constexpr int BB_APLD = 132;     // one slice triple: S, 3 pad, P1[64], P2[64]
 constexpr int BB_FLK = 4;        // flag words per step / 256: [dG1: 8 copies x 64 producers | dG0: 8 x 64] — a consumer polls the copy of its XCD (w % 8):
                                  // 128 pollers on ONE 256-byte flag array serialise on its memory channel, the flag stores queue behind them
-constexpr int BB_MAXFR = 16;
+constexpr int BB_MAXFR = 32;      // frames per time slice (T' <= 512; the LDS budget — 4 KB of features per frame — admits 30)
 
 struct BigBwdArgs {
     const float* w_ih1; const float* w_hh1; const float* w_hh0; const float* w0p; long ldw0; int Vp;
@@ -864,10 +887,11 @@ __global__ __launch_bounds__(BG_THREADS, 1) void speller_big_bwd_kernel(const Bi
     };
 
     float nd0 = 0.f, nd1 = 0.f;      // this thread's two columns of dcat's context half for the coming step
-    float naf0 = 0.f, naf1 = 0.f, nqv = 0.f;
+    float naf[4] = {0.f, 0.f, 0.f, 0.f}, nqv = 0.f;      // attention weights of this wave's frames (wave, wave + 8, + 16, + 24)
     if (att_on) {
-        if (wave < nfr) naf0 = a.att[((size_t)(U - 1) * B + ab) * Tp + t0 + wave];
-        if (wave + BG_NW < nfr) naf1 = a.att[((size_t)(U - 1) * B + ab) * Tp + t0 + wave + BG_NW];
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+            if (wave + i * BG_NW < nfr) naf[i] = a.att[((size_t)(U - 1) * B + ab) * Tp + t0 + wave + i * BG_NW];
         if (aj == 0 && wave == 0) nqv = a.q_all[((size_t)(U - 1) * B + ab) * BG_M + lane];
         const float* dn = a.dcat_all + ((size_t)(U - 1) * B + ab) * (2 * BG_HS) + BG_HS + tid * 2;
         nd0 = dn[0]; nd1 = dn[1];
@@ -888,7 +912,8 @@ __global__ __launch_bounds__(BG_THREADS, 1) void speller_big_bwd_kernel(const Bi
             // ================= (A) slice triple of this step
             // (the attention weights of this wave's two frames and the combine role's query were fetched one step ahead: a cold global load takes
             // 2 - 3 us here)
-            const float af0 = naf0, af1 = naf1, qv = nqv;
+            const float af[4] = {naf[0], naf[1], naf[2], naf[3]};
+            const float qv = nqv;
             {
                 const int c = tid * 2;
                 float v0 = nd0, v1 = nd1;
@@ -917,10 +942,11 @@ __global__ __launch_bounds__(BG_THREADS, 1) void speller_big_bwd_kernel(const Bi
                 for (int i = 0; i < 4; ++i)
                     acc = dot4p(*reinterpret_cast<const f32x4*>(fr + 256 * i), *reinterpret_cast<const f32x4*>(dctxS + lane * 4 + 256 * i), acc);
                 const float da = wsum(acc);
-                const float af = f == wave ? af0 : af1;
+                const int fi = (f - wave) >> 3;
+                const float afv = fi == 0 ? af[0] : fi == 1 ? af[1] : fi == 2 ? af[2] : af[3];
                 const float kv = keysS[f * BG_KLD + lane];
-                p1 = fmaf(af * da, kv, p1); p2 = fmaf(af, kv, p2); ssum = fmaf(af, da, ssum);
-                if (lane == 0) { adS[f * 2] = af; adS[f * 2 + 1] = da; }
+                p1 = fmaf(afv * da, kv, p1); p2 = fmaf(afv, kv, p2); ssum = fmaf(afv, da, ssum);
+                if (lane == 0) { adS[f * 2] = afv; adS[f * 2 + 1] = da; }
             }
             BB_STAMP(9);
             part[wave * BB_APLD + 4 + lane] = p1; part[wave * BB_APLD + 68 + lane] = p2;
@@ -945,8 +971,9 @@ __global__ __launch_bounds__(BG_THREADS, 1) void speller_big_bwd_kernel(const Bi
                               // so a cold one (2 - 3 us) in front of a poll would sit on the chain
                 const float* dn = a.dcat_all + ((size_t)(s - 1) * B + ab) * (2 * BG_HS) + BG_HS + tid * 2;
                 nd0 = dn[0]; nd1 = dn[1];
-                if (wave < nfr) naf0 = a.att[((size_t)(s - 1) * B + ab) * Tp + t0 + wave];
-                if (wave + BG_NW < nfr) naf1 = a.att[((size_t)(s - 1) * B + ab) * Tp + t0 + wave + BG_NW];
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+                    if (wave + i * BG_NW < nfr) naf[i] = a.att[((size_t)(s - 1) * B + ab) * Tp + t0 + wave + i * BG_NW];
                 if (aj == 0 && wave == 0) nqv = a.q_all[((size_t)(s - 1) * B + ab) * BG_M + lane];
             }
             if (wave == 0) {
@@ -1119,10 +1146,17 @@ size_t speller_big_flag_words(int U) { return (size_t)U * BG_FLW; }
 static bool big_fits(int Tp, int greedy) {
     const size_t smem = big_fwd_smem(Tp, greedy);
     if (smem > 160 * 1024) return false;
-    const void* fn = greedy ? reinterpret_cast<const void*>(&speller_big_fwd_kernel<true>) : reinterpret_cast<const void*>(&speller_big_fwd_kernel<false>);
-    if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem) != hipSuccess) return false;
-    return greedy ? persistent_launch_fits(speller_big_fwd_kernel<true>, BG_THREADS, smem, BG_WGS)
-                  : persistent_launch_fits(speller_big_fwd_kernel<false>, BG_THREADS, smem, BG_WGS);
+    const bool lng = Tp > BG_SHORT_TP;
+#define BG_FITS(G, L)                                                                                                                        \
+    if ((bool)greedy == G && lng == L) {                                                                                                     \
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(&speller_big_fwd_kernel<G, L>), hipFuncAttributeMaxDynamicSharedMemorySize,  \
+                                (int)smem) != hipSuccess)                                                                                    \
+            return false;                                                                                                                    \
+        return persistent_launch_fits(speller_big_fwd_kernel<G, L>, BG_THREADS, smem, BG_WGS);                                               \
+    }
+    BG_FITS(false, false) BG_FITS(false, true) BG_FITS(true, false) BG_FITS(true, true)
+#undef BG_FITS
+    return false;
 }
 
 bool speller_big_eligible(int B, int Tp, int Hs, int D, int M, int V, int L, int heads, int use_mlp, int greedy) {
@@ -1144,6 +1178,9 @@ int speller_big_fwd(const BigFwd& p, hipStream_t stream) {
     a.feat = p.feat; a.keys = p.keys; a.yw = p.yw;
     a.ctx_all = p.ctx_all; a.h_all = p.h_all; a.c_all = p.c_all; a.gates_all = p.gates_all; a.q_all = p.q_all; a.att = p.att;
     a.hx = p.hx; a.qp = p.qp; a.flags = p.flags;
+    const bool lng = p.Tp > BG_SHORT_TP;
+    a.eg = p.eg; a.FRL = (p.Tp + 15) / 16;
+    LAS_REQUIRE(!lng || p.eg, "energy rows for T' > 256");
     a.mode = p.mode; a.V = p.V; a.w_c = p.w_c; a.b_c = p.b_c; a.logp = p.logp; a.argmax = p.argmax; a.y_all = p.y_all;
     a.lgp = p.lgp; a.ysym = p.lgp ? p.lgp + (size_t)p.U * p.B * 16 * 32 : nullptr;
     LAS_REQUIRE(p.mode == 0 || (p.mode == 1 && p.w_c && p.b_c && p.logp && p.y_all && p.lgp && p.Vp == 32), "greedy decode operands");
@@ -1160,11 +1197,15 @@ int speller_big_fwd(const BigFwd& p, hipStream_t stream) {
         LAS_HIP_CHECK(hipMemsetAsync(p.qp, 0xFF, sizeof(float) * speller_big_qp_floats(p.B, p.U), stream));
         LAS_HIP_CHECK(hipMemsetAsync(p.flags, 0xFF, sizeof(unsigned) * speller_big_flag_words(p.U), stream));
     }
+    if (lng) LAS_HIP_CHECK(hipMemsetAsync(p.eg, 0xFF, sizeof(float) * (size_t)p.U * p.B * 512, stream));
     if (p.mode == 1) LAS_HIP_CHECK(hipMemsetAsync(p.lgp, 0xFF, sizeof(float) * speller_big_greedy_floats(p.B, p.U), stream));
     {
         KernelTimer timer(TIMED_DECODE_FWD, stream);
-        if (p.mode == 1) hipLaunchKernelGGL(speller_big_fwd_kernel<true>, dim3(BG_WGS), dim3(BG_THREADS), big_fwd_smem(p.Tp, 1), stream, a);
-        else hipLaunchKernelGGL(speller_big_fwd_kernel<false>, dim3(BG_WGS), dim3(BG_THREADS), big_fwd_smem(p.Tp, 0), stream, a);
+        const size_t smem = big_fwd_smem(p.Tp, p.mode);
+        if (p.mode == 1 && lng) hipLaunchKernelGGL((speller_big_fwd_kernel<true, true>), dim3(BG_WGS), dim3(BG_THREADS), smem, stream, a);
+        else if (p.mode == 1) hipLaunchKernelGGL((speller_big_fwd_kernel<true, false>), dim3(BG_WGS), dim3(BG_THREADS), smem, stream, a);
+        else if (lng) hipLaunchKernelGGL((speller_big_fwd_kernel<false, true>), dim3(BG_WGS), dim3(BG_THREADS), smem, stream, a);
+        else hipLaunchKernelGGL((speller_big_fwd_kernel<false, false>), dim3(BG_WGS), dim3(BG_THREADS), smem, stream, a);
     }
     LAS_LAUNCH_CHECK();
     return LAS_OK;

@@ -371,7 +371,8 @@ def test_decode_batch_query_and_slicing_decision():
     assert query("Y") == 16                                 # Hs = 1024, teacher forcing: one launch per 16 utterances (speller_big.hip)
     assert query("Y", teacher=False, mode=1) == 16          # ... and for its greedy decode (the YAML's decode_mode)
     assert query("Y", teacher=False, mode=0) == 0           # log-prob feedback at that size: per-step path, never sliced
-    assert query("Y", Tp=300) == 0                          # T' beyond 256
+    assert query("Y", Tp=300) == 16                         # T' > 256: the LONG instantiation
+    assert query("Y", Tp=600) == 0                          # T' beyond 512
     assert query("P", Tp=2000) == 0                         # T' beyond the residency table
     _cabi.set_option("SPELLER_PERSIST", 0)
     _cabi.set_option("SPELLER_BIG", 0)

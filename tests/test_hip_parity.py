@@ -325,9 +325,11 @@ def test_persistent_decode_kernel_matches_stepwise(cfg_name, B, Tp, U, scale):
 @pytest.mark.parametrize("B,Tp,U,scale,activate", [(16, 100, 12, None, "relu"), (3, 8, 6, 0.08, "relu"), (16, 200, 5, None, "relu"),
                                                     (5, 37, 7, 0.08, "relu"), (1, 1, 3, None, "relu"), (16, 256, 3, None, "relu"),
                                                     (7, 130, 4, None, "None"), (16, 100, 72, None, "relu"),
-                                                    (40, 50, 5, None, "relu")])      # beyond one launch: Speller._run slices 16 + 16 + 8
+                                                    (40, 50, 5, None, "relu"),       # beyond one launch: Speller._run slices 16 + 16 + 8
+                                                    # T' > 256: the utterance's workgroups split the energies by frames and exchange them
+                                                    (16, 300, 4, None, "relu"), (3, 437, 5, None, "relu"), (7, 480, 3, None, "relu")])
 def test_one_launch_decode_of_the_yaml_sizes_matches_stepwise(B, Tp, U, scale, activate):
-    """speller_big.hip (Speller 1024x2, attention MLP 64, B <= 16, T' <= 256: the reference's config/librispeech-config.yaml), forward AND
+    """speller_big.hip (Speller 1024x2, attention MLP 64, B <= 16, T' <= 512 forward / 480 backward: the reference's config/librispeech-config.yaml), forward AND
     backward kernel, against the per-step launch chains: log-probs, attention weights and every gradient.  Cases: a full batch at T = 800, partial batches (rows beyond B are never stored), a single frame,
     the longest eligible encoder output, no attention activation, more than 64 steps (the trace buffer's depth; U = 72 and not 70: with
     this seed one query pre-activation of step 69 is within an ulp of 0, and the PER-STEP path's own run-to-run summation order — atomic
@@ -487,7 +489,7 @@ def test_direct_gradient_write_matches_autograd_accumulation(cfg_name, B):
 @pytest.mark.parametrize("cfg_name,B,Tp,U,decode_mode", [("P", 32, 100, 20, 1), ("P", 32, 100, 20, 0), ("S", 7, 150, 9, 1),
                                                           ("S", 32, 60, 6, 0), ("P", 3, 30, 5, 1), ("P", 40, 30, 5, 1),
                                                           # the YAML sizes (speller_big.hip, greedy only): full batch, partial batch, a sliced batch
-                                                          ("Y", 16, 100, 20, 1), ("Y", 5, 37, 9, 1), ("Y", 24, 40, 5, 1)])
+                                                          ("Y", 16, 100, 20, 1), ("Y", 5, 37, 9, 1), ("Y", 24, 40, 5, 1), ("Y", 16, 400, 4, 1)])
 def test_persistent_free_running_decode_matches_stepwise(cfg_name, B, Tp, U, decode_mode):
     """Greedy (decode_mode 1) and log-prob-feedback (decode_mode 0) decoding inside the one-launch kernel against the
     per-step launch chain: log-probabilities, attention, arg-max sequences, and (mode 1) the gradients."""
