@@ -72,7 +72,7 @@ const char* las_last_error(void);
  *   SPELLER_PERSIST 1*, SPELLER_PERSIST_BWD 1*                   one-launch decode loop forward / backward (0: per-step launches)
  *   SPELLER_PRE 1*, SPELLER_PRE_BWD 1*                           pre-multiplied-context variants of those kernels
  *   SPELLER_BIG 1*, SPELLER_BIG_BWD 1*                           one-launch decode loop (teacher-forced or greedy) forward / backward for the reference's
- *                                                                shipped sizes (Speller 1024x2, attention MLP 64, B <= 16, T' <= 256:
+ *                                                                shipped sizes (Speller 1024x2, attention MLP 64, B <= 16, T' <= 512 / 480:
  *                                                                speller_big.hip; 0: per-step launches)
  *   SPELLER_BIG_TUNE 0*   poll pacing of those two kernels in units of 64 clocks: byte 0 / 2 / 3 before the first poll of the forward's h0 /
  *                         context / h1 hand-off, byte 1 between polls (A/B aid)
