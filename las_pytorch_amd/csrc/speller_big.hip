@@ -1,19 +1,28 @@
-// One-launch teacher-forced decode forward for the reference's SHIPPED model size (config/librispeech-config.yaml:16-34:
-// Listener 512x3 -> 1024 features, Speller 1024x2, attention MLP 64, batch 16) on gfx950.
+// One-launch decode loop, forward AND backward, for the reference's SHIPPED model size (config/librispeech-config.yaml:16-34:
+// Listener 512x3 -> 1024 features, Speller 1024x2, attention MLP 64, batch 16, decode_mode 1) on gfx950.  DESIGN.md 4.3a.
 //
-// Replaces, for that size, the 3 launches per decode step of speller.hip (reference model/las_model.py:178-184, 205-236, 275-297),
-// each of which re-streams 34 MB of LSTM weights from the L2 / Infinity Cache.  Here the four fp32 matrices of the two cells
-// (67 MB) stay in the REGISTERS of 256 workgroups for all U steps:
+// Replaces, for that size, the 3 + 3 launches per decode step of speller.hip (reference model/las_model.py:178-184, 205-236, 275-297 and
+// their autograd), each of which re-streams 34 MB of LSTM weights from the L2 / Infinity Cache.  Here the four fp32 matrices of the two
+// cells (67 MB) stay in the REGISTERS of 256 workgroups x 512 threads (128 VGPRs per lane) for all U steps.
+//
+// Forward (speller_big_fwd_kernel<GREEDY, LONG>):
 //   * workgroup w owns 4 hidden units (16 gate rows) of BOTH layers; its 8 waves split K, a lane holds 8 k-blocks of each of
-//     [W_ctx | W_hh0 | W_ih1 | W_hh1] as v_mfma_f32_16x16x4_f32 B operands (128 VGPRs), the 16 utterances are the M dimension;
-//   * the attention of utterance b is sliced over the 16 workgroups 16b..16b+15 (T'/16 frames each, features and keys in LDS):
-//     partial softmax (local max / sum / unnormalised partial context), combined per 64-column block by the same workgroups;
-//   * the query never needs its own hop: with the top cell's h the owner publishes its K-slice of phi (64 x 4 weights), and an
-//     attention workgroup adds the 256 slices of its utterance.
-// Per step the chain is four hand-offs (ctx -> bottom cell -> top cell -> query parts -> partial contexts -> ctx); every
-// hand-off is the data itself, written agent-scope into slabs pre-filled with the sentinel 0xFFFFFFFF (persist_common.h).
-// The recurrent halves W_hh . h of the next step are multiplied while the hand-offs are in flight.
-// Stash layout (h_all, c_all, gates_all, q_all, ctx_all, att) is the per-step kernels', so las_speller_bwd is unchanged.
+//     [W_ctx | W_hh0 | W_ih1 | W_hh1] as v_mfma_f32_16x16x4_f32 B operands, the 16 utterances are the M dimension;
+//   * the attention of utterance b is split over 16 workgroups BY FEATURE COLUMNS (64 columns x all T' frames and all keys of b in LDS): every
+//     one computes all energies and the whole softmax itself, so its 64 context columns are final (no exchange of partial contexts); the 16
+//     workgroups of an utterance sit on one XCD.  LONG (T' > 256): the keys no longer fit, the 16 workgroups split the energies by frames
+//     and exchange the energy row (one more hand-off);
+//   * the query needs no hop of its own: with the top cell's h the owner publishes its K-slice of phi (64 x 4 weights), an attention
+//     workgroup adds the 256 slices of its utterance;
+//   * GREEDY (decode_mode 1): the column blocks add their part of the logits W_c [h1 | ctx], workgroup (b, 0) takes log-softmax / arg-max
+//     and publishes the symbol, the cells add W_y[:, symbol].
+//   Per step the chain is three hand-offs (ctx -> bottom cell -> h0 -> top cell -> h1 + query parts -> attention -> ctx): the data itself in
+//   per-step slabs pre-filled with the sentinel 0xFFFFFFFF (persist_common.h) plus one flag dword per producer (8 copies, one per consumer
+//   XCD); operand loads go through the L2 once the flags are in, every piece is still checked for the sentinel.  The recurrent halves
+//   W_hh . h of the next step are multiplied inside the hand-off windows.  The stash (h_all, c_all, gates_all, q_all, ctx_all, att, y_all) is
+//   the per-step kernels'.
+// Backward (speller_big_bwd_kernel): weights held column-wise (workgroup = 16 columns x 4096 rows of ONE matrix), the cell backward fused
+//   behind the products, attention backward sliced by time; five hand-offs per step.  See the comment in front of it.
 #include "las_common.h"
 #include "las_kernels.h"
 #include "options.h"
