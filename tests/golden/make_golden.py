@@ -224,7 +224,7 @@ def main_big4(refmods):
     backward, the decode loop takes more than 32 utterances); (b) the reference's shipped YAML sizes at T = 800, B = 16;
     (c) multi-head attention at paper size (heads = 4 and 2)."""
     big = dict(full=False, light=True, sub_t=10, sub_d=32)
-    which = os.environ.get("BIG4", "abc")
+    which = os.environ.get("BIG4", "abcd")
     if "a" in which:
         # default-scale weights: seed 17 has a top-1 / top-2 margin of 2.6e-3 over the 2048 greedy positions (most seeds: ~1e-6, a coin flip
         # for any fp32 path), its greedy sequence is one repeated symbol; the "_s" case (U(-0.2, 0.2) weights, seed 51: margin 1.4e-3)
@@ -234,6 +234,9 @@ def main_big4(refmods):
         run_case(refmods, "P_B128_T800_U16_s", "P", B=128, T=800, U=16, ragged=True, seed=51, scale=0.2, **big128)
     if "b" in which:
         run_case(refmods, "Y_B16_T800_U16", "Y", B=16, T=800, U=16, scale=0.05, seed=37, **big)
+    if "d" in which:
+        # the YAML sizes with a 24-second utterance batch (T = 2400 -> T' = 300 > 256): the LONG instantiation of the one-launch decode kernels
+        run_case(refmods, "Y_B4_T2400_U8", "Y", B=4, T=2400, U=8, scale=0.05, seed=41, ragged=True, **big)
     if "c" in which:
         run_case(refmods, "P_short_mh4", "P", B=4, T=64, U=8, multi_head=4, scale=0.1, full=False, light=True, seed=23)
         run_case(refmods, "P_B32_T800_U16_mh2", "P", B=32, T=800, U=16, multi_head=2, scale=0.1, seed=23, **big)

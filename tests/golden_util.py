@@ -15,7 +15,9 @@ BIG_CASES = ["Y_short", "P_B40_T64_U6", "P_B32_T800_U32", "P_B16_T1600_U8", "P_B
              "P_B32_T800_U128", "P_B32_T800_U32_s", "P_B8_T3000_U16_s",
              # round 4: 128 utterances per GPU at T = 800 (matrix-pipe recurrences for 400 / 200 / 100 steps, decode beyond 32 utterances;
              # default-scale and U(-0.2, 0.2) weights), the reference's shipped YAML sizes at T = 800, multi-head attention at paper size
-             "P_B128_T800_U16", "P_B128_T800_U16_s", "Y_B16_T800_U16", "P_short_mh4", "P_B32_T800_U16_mh2"]
+             "P_B128_T800_U16", "P_B128_T800_U16_s", "Y_B16_T800_U16", "P_short_mh4", "P_B32_T800_U16_mh2",
+             # ... and a 24-second batch of the YAML sizes (T = 2400, T' = 300): the long-utterance instantiation of its one-launch decode kernels
+             "Y_B4_T2400_U8"]
 
 
 def load_case(name):
