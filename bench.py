@@ -432,10 +432,25 @@ def launch_ranks(n):
         print(f"bench.py: --gpus {n} requested but only {have} GPU(s) are visible on this node", file=sys.stderr)
         return 3
     s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
-    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", MASTER_ADDR="127.0.0.1")
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
-           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    cmd, env = rank_launch_command(n, port, sys.argv[1:], os.environ)
     return subprocess.call(cmd, env=env)
+
+
+def is_rank_process(environ):
+    """True inside a rank started by torch.distributed.run (it exports WORLD_SIZE / RANK / LOCAL_RANK); bare ``python bench.py --gpus N`` is
+    the launcher."""
+    return "WORLD_SIZE" in environ
+
+
+def rank_launch_command(n, port, argv, environ):
+    """Command line and environment of the N-rank launch (pure function: tests/test_cabi_and_host.py checks it on CPU so that the first real
+    ``--gpus 8`` run cannot die on plumbing): the driver's own form — ``python -m torch.distributed.run --nnodes=1 --nproc-per-node N
+    --master-addr 127.0.0.1 --master-port P bench.py <same flags>`` — with the loopback rendezvous (the container hostname may not
+    resolve) and dmabuf IPC (RCCL between processes fails with the legacy IPC mode on this driver)."""
+    env = dict(environ, HSA_ENABLE_IPC_MODE_LEGACY="0", MASTER_ADDR="127.0.0.1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + list(argv)
+    return cmd, env
 
 
 def preflight_problems(table):
@@ -493,7 +508,7 @@ def main():
     ap.add_argument("--global-batch", type=int, default=256, help="total utterances per step with --scaling strong (SURVEY 8d config 3: 256)")
     args = ap.parse_args()
 
-    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+    if not is_rank_process(os.environ) and args.gpus > 1:
         return launch_ranks(args.gpus)
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))

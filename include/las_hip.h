@@ -36,7 +36,7 @@
 extern "C" {
 #endif
 
-#define LAS_ABI_VERSION 8
+#define LAS_ABI_VERSION 9
 #define LAS_MAX_SPELLER_LAYERS 4
 
 /* flags */
@@ -309,8 +309,23 @@ typedef struct las_gemm_desc {
     int M, N, K, K1;
     int64_t lda, ldb, ldc;
     int a_kc, b_kc, accumulate, c_zeroed;
+    int planes;      /* A / B are P8x3 images (las_split_planes) of the fp32 matrices the other fields describe */
 } las_gemm_desc;
 int las_gemm_f32_group(const las_gemm_desc* descs, int n, void* stream);
+/* Pre-split operands.  las_split_planes writes the "P8x3" image of an fp32 R x C matrix (row stride ld_src): every element as the exact sum
+ * of three bf16 terms (x = p1 + p2 + p3, the split of arithmetic mode 1), 16-byte granule (r, c / 8, plane) = that term of elements
+ * (r, 8 (c / 8) .. + 7) at 16-byte index (r (ld_dst / 8) + c / 8) 3 + plane; C and ld_dst multiples of 8, 6 bytes per element
+ * (las_planes_bytes).  las_gemm_planes is las_gemm_f32 on two such images (lda / ldb / sA / sB remain ELEMENT counts of the logical fp32
+ * matrices; K, the leading dimensions and every extent that runs along an operand's contiguous dimension must be multiples of 8):
+ * the same six bf16 partial products and fp32 accumulation as mode 1 — bit-identical results — without the per-tile split arithmetic,
+ * which every workgroup along the other tile dimension would repeat.  The training step splits each layer input, weight matrix and
+ * gate-gradient slab once and feeds every GEMM that reads it from the image.  Replaces nothing in the reference (ATen's GEMMs,
+ * model/las_model.py:90,174,279). */
+size_t las_planes_bytes(int64_t rows, int64_t ld);
+int las_split_planes(const float* src, int64_t ld_src, int R, int C, void* dst, int64_t ld_dst, void* stream);
+int las_gemm_planes(const void* A_planes, const void* B_planes, float* C, const float* bias0, const float* bias1,
+                    int M, int N, int K, int64_t lda, int64_t ldb, int64_t ldc, int a_kc, int b_kc,
+                    int batch, int64_t sA, int64_t sB, int64_t sC, int splitk, int accumulate, int relu, void* stream);
 /* Arithmetic of the MFMA GEMMs' interior tiles (= option GEMM_ARITH; LAS_FLAG_GEMM_F32 overrides it for one call):
  *   0  v_mfma_f32_32x32x2_f32 (fp32 operands on the fp32 matrix pipe)
  *   1  every fp32 operand split EXACTLY into three bf16 terms in registers, six of the nine partial products on
@@ -345,6 +360,12 @@ void las_debug_big_bwd_trace(unsigned long long* dev_buf);
  * kernel, which = 0 forward (speller_persist_fwd*_kernel), 1 backward (speller_persist_bwd*_kernel).  Synchronises on that launch.
  * bench.py prices these two kernels against the roofline with it. */
 int las_debug_kernel_ms(int which, float* ms_out);
+/* Name of the kernel family the most recent call launched for slot `which` (process-wide): 0 Listener recurrence forward
+ * ("rec_fwd_fast" | "rec_fwd_multi" | "rec_fwd_mfma" | "rec_fwd_mfma2" | "rec_fwd_generic"), 1 its backward ("rec_bwd_fast" | "rec_bwd_multi" |
+ * "rec_bwd_mfma" | "rec_bwd_generic"), 2 decode loop forward ("persist_pre" | "persist" | "big" | "stepwise"), 3 decode loop backward (same
+ * names), 4 the most recent GEMM's operand path ("split" | "f32" | "planes").  The parity tests assert it per fixture, so a silent
+ * fall-back (e.g. LAS_ERR_UNSUPPORTED from a residency check) cannot leave a golden green on the wrong kernel.  Returns 0 / LAS_ERR_ARG. */
+int las_debug_last_path(int which, char* out, int cap);
 
 #ifdef __cplusplus
 }

@@ -31,7 +31,7 @@ class SpellerDesc(C.Structure):
 class GemmDescC(C.Structure):
     _fields_ = [("A", _f), ("B", _f), ("C", _f), ("A2", _f), ("B2", _f), ("M", C.c_int), ("N", C.c_int), ("K", C.c_int), ("K1", C.c_int),
                 ("lda", C.c_int64), ("ldb", C.c_int64), ("ldc", C.c_int64), ("a_kc", C.c_int), ("b_kc", C.c_int), ("accumulate", C.c_int),
-                ("c_zeroed", C.c_int)]
+                ("c_zeroed", C.c_int), ("planes", C.c_int)]
 
 
 class SpellerGrads(C.Structure):
@@ -55,6 +55,7 @@ PROTOTYPES = {
     "las_debug_big_trace": (None, [_f]),
     "las_debug_big_bwd_trace": (None, [_f]),
     "las_debug_kernel_ms": (C.c_int, [C.c_int, C.POINTER(C.c_float)]),
+    "las_debug_last_path": (C.c_int, [C.c_int, C.c_char_p, C.c_int]),
     "las_pblstm_reserve_floats": (C.c_size_t, [C.c_int] * 4),
     "las_pblstm_fwd": (C.c_int, [_f, C.c_int, C.c_int, C.c_int, C.c_int] + [_f] * 8 + [_f, _f, _f, C.c_int, _f]),
     "las_pblstm_bwd_workspace_floats": (C.c_size_t, [C.c_int] * 3),
@@ -88,6 +89,10 @@ PROTOTYPES = {
     "las_gemm_f32": (C.c_int, [_f] * 5 + [C.c_int] * 3 + [C.c_int64] * 3 + [C.c_int, C.c_int, C.c_int]
                      + [C.c_int64] * 3 + [C.c_int, C.c_int, C.c_int, _f]),
     "las_gemm_f32_group": (C.c_int, [C.POINTER(GemmDescC), C.c_int, _f]),
+    "las_planes_bytes": (C.c_size_t, [C.c_int64, C.c_int64]),
+    "las_split_planes": (C.c_int, [_f, C.c_int64, C.c_int, C.c_int, _f, C.c_int64, _f]),
+    "las_gemm_planes": (C.c_int, [_f] * 5 + [C.c_int] * 3 + [C.c_int64] * 3 + [C.c_int, C.c_int, C.c_int]
+                        + [C.c_int64] * 3 + [C.c_int, C.c_int, C.c_int, _f]),
     "las_gemm_get_arith": (C.c_int, []),
     "las_gemm_set_arith": (None, [C.c_int]),
     "las_gemm_set_tuning": (None, [C.c_int, C.c_int64]),
@@ -124,6 +129,16 @@ def get_option(key):
     out = C.c_int64(0)
     check(lib().las_get_option(str(key).encode(), C.byref(out)))
     return int(out.value)
+
+
+PATH_REC_FWD, PATH_REC_BWD, PATH_DECODE_FWD, PATH_DECODE_BWD, PATH_GEMM = range(5)
+
+
+def last_path(which):
+    """las_debug_last_path: name of the kernel family the most recent call launched for slot ``which`` (see include/las_hip.h)."""
+    buf = C.create_string_buffer(64)
+    check(lib().las_debug_last_path(int(which), buf, 64))
+    return buf.value.decode()
 
 
 def check(rc):
@@ -211,7 +226,9 @@ def check_device_errors():
     the host (the step's existing synchronisation point); tests, smoke and bench call it after their timed regions."""
     if torch.cuda.is_available() and torch.cuda.is_initialized():
         torch.cuda.synchronize()
-        check(lib().las_gemm_check())     # a stream-K fix-up wait that timed out (host-visible word, needs no device copy)
+        if lib().las_gemm_check() != 0:   # a stream-K fix-up wait that timed out (host-visible word, needs no device copy)
+            raise DeviceHandoffError("liblas_hip: " + lib().las_last_error().decode(errors="replace") +
+                                     " (GEMM_SK_FIXUP: the tile that wait belonged to is wrong; the step must be re-run)")
     for key, w in _err_words.items():
         v = int(w[0].item())
         if v != 0:

@@ -164,6 +164,61 @@ static __device__ __forceinline__ void split_load_guarded(const float* __restric
 }
 struct SplitFrag { u32x4 a[3][2], b[3][2]; };      // [plane][32-row tile]: 8 consecutive k of this lane's row as bf16
 
+// ---- pre-split operands (MODE 2) ------------------------------------------------------------------------------------------
+// The operand split above costs ~88 VALU instructions per k-tile and wave beside 24 MFMAs, and every workgroup along the other tile
+// dimension repeats it (a weight tile is split by every M-tile's workgroup).  An operand that several GEMMs of a step read (layer
+// outputs, weights, gate gradients) can instead be split ONCE, by its producer or by split_planes_kernel below, into the
+// "P8x3" image: for a logical R x C fp32 matrix with row stride ld (elements, a multiple of 8)
+//     granule(r, c / 8, plane) = 16 bytes = the bf16 term `plane` of elements (r, 8 (c / 8) .. + 7),  at 16-byte index (r (ld / 8) + c / 8) 3 + plane
+// — the three planes of an octet are adjacent (48 bytes), so a K-contiguous reader takes 96 contiguous bytes per row and k-tile and a
+// row-contiguous reader 768 contiguous bytes per k.  6 bytes per element instead of 4; x = p1 + p2 + p3 exactly as in split_pair.
+// The GEMM then moves granules global -> registers -> LDS without arithmetic:
+//   K-contiguous operand : a granule IS the fragment's 8 consecutive k: one ds_write_b128 per plane into the [k-half][row][4 dwords] image
+//   row-contiguous       : a granule holds ONE k of 8 rows; the four lanes l, l+16, l+32, l+48 of a wave hold the four k of a quad for the
+//       same row octet, a 4 x 4 dword transpose across them is two v_permlane32_swap + two v_permlane16_swap, four v_perm_b32 pair the
+//       halves: every lane ends with rows (2i, 2i+1) x 4 k = two 8-byte items of the [k-quad][slot(row)][2 dwords] image.
+//       pl_slot keeps those stores (16 lanes: one row class c, all 16 octets) and the fragment reads (32 consecutive rows) conflict-free.
+typedef const u32x4* __restrict__ gran_ptr;
+static __device__ __forceinline__ int pl_slot(int row) {
+    const int a = row >> 5, b = (row >> 3) & 3, c = row & 7;
+    return a * 32 + ((4 * c + b + 4 * a) & 31);
+}
+struct PlaneRegs { u32x4 g[3]; };          // the three planes of one granule position
+// one thread's granule position inside a 128 x 16 operand tile, in 16-byte units relative to the tile origin (r0, k0):
+//   KC: row t / 2, k-octet t % 2;   !KC: k = 4 (t / 64) + (t % 64) / 16, row octet t % 16
+template <bool KC>
+static __device__ __forceinline__ long plane_thread_offset(long ldo) {
+    const int t = threadIdx.x;
+    if constexpr (KC) return ((long)(t >> 1) * ldo + (t & 1)) * 3;
+    else return ((long)(4 * (t >> 6) + ((t & 63) >> 4)) * ldo + (t & 15)) * 3;
+}
+template <bool KC>
+static __device__ __forceinline__ void plane_store(unsigned* S, const PlaneRegs& r, int pl0, int pl1) {
+    const int t = threadIdx.x;
+    if constexpr (KC) {
+        const int row = t >> 1, kh = t & 1;
+#pragma unroll
+        for (int pl = pl0; pl < pl1; ++pl) *reinterpret_cast<u32x4*>(&S[pl * SP_PLANE + kh * SP_KH + row * 4]) = r.g[pl];
+    } else {
+        const int l = t & 63, w = t >> 6, i = l >> 4, row = 8 * (l & 15) + 2 * i;
+        unsigned* dst0 = S + w * SP_KQ + pl_slot(row) * 2;
+        unsigned* dst1 = S + w * SP_KQ + pl_slot(row + 1) * 2;
+#pragma unroll
+        for (int pl = pl0; pl < pl1; ++pl) {
+            // d_j = rows (2j, 2j+1) of this lane's k;  after the two stages lane i holds T_j = rows (2i, 2i+1) at k = j of the quad
+            auto s02 = __builtin_amdgcn_permlane32_swap(r.g[pl][0], r.g[pl][2], false, false);
+            auto s13 = __builtin_amdgcn_permlane32_swap(r.g[pl][1], r.g[pl][3], false, false);
+            auto t01 = __builtin_amdgcn_permlane16_swap(s02[0], s13[0], false, false);
+            auto t23 = __builtin_amdgcn_permlane16_swap(s02[1], s13[1], false, false);
+            const unsigned T0 = t01[0], T1 = t01[1], T2 = t23[0], T3 = t23[1];
+            u32x2 lo = {__builtin_amdgcn_perm(T1, T0, 0x05040100u), __builtin_amdgcn_perm(T3, T2, 0x05040100u)};
+            u32x2 hi = {__builtin_amdgcn_perm(T1, T0, 0x07060302u), __builtin_amdgcn_perm(T3, T2, 0x07060302u)};
+            *reinterpret_cast<u32x2*>(dst0 + pl * SP_PLANE) = lo;
+            *reinterpret_cast<u32x2*>(dst1 + pl * SP_PLANE) = hi;
+        }
+    }
+}
+
 struct GemmParams {
     const float* A; const float* B; float* C; const float* bias0; const float* bias1;
     int M, N, K;
@@ -183,6 +238,7 @@ struct GemmParams {
     // it0 > 0 parks its 128x128 partial sum in sk_part[slot] and raises sk_flag[slot] = sk_id; the workgroup that owns k-iteration 0
     // of the tile (its LAST segment) adds the parked sums of the slots behind it and runs the epilogue (bias / accumulate / relu)
     float* sk_part; unsigned* sk_flag; unsigned* sk_err; unsigned sk_id;
+    unsigned* call_err;      // device error word of the enclosing entry point (null outside one): raised together with sk_err
 };
 
 // what a segment does with its accumulators
@@ -294,12 +350,15 @@ __device__ __forceinline__ void store_tile(float (*S)[BM + PAD], const f32x4 (&r
 // One output tile over the k-iterations [it0, it1) (BK each): main loop + epilogue.  `atomic`: this segment is one of several
 // contributors to the tile (split-K / stream-K): accumulate with atomics onto a C that starts from zero (or from the
 // value to accumulate onto); the contributor that owns k-iteration 0 adds the biases.
-template <bool A_KC, bool B_KC, bool SPLIT>
+// MODE: 0 fp32 operands on the fp32 matrix pipe, 1 fp32 operands split in the kernel, 2 pre-split operands (P8x3 granules: A / B / A2 / B2
+// point at granule buffers, lda / ldb / sA / sB stay ELEMENT counts of the logical fp32 matrices)
+template <bool A_KC, bool B_KC, int MODE>
 __device__ __forceinline__ void gemm_segment(const GemmParams& p, float (*As)[BK][BM + PAD], float (*Bs)[BK][BN + PAD], unsigned* sp, int bz,
                                              int m0, int n0, int kbeg, int kend, const SegRole role) {
     const bool atomic = role.kind == SEG_ATOMIC, add_bias = role.add_bias;
-    const float* A = p.A + (long)bz * p.sA;
-    const float* B = p.B + (long)bz * p.sB;
+    // (MODE 2: A / B are granule buffers, 6 bytes per logical element)
+    const float* A = MODE == 2 ? reinterpret_cast<const float*>(reinterpret_cast<const char*>(p.A) + (long)bz * p.sA * 6) : p.A + (long)bz * p.sA;
+    const float* B = MODE == 2 ? reinterpret_cast<const float*>(reinterpret_cast<const char*>(p.B) + (long)bz * p.sB * 6) : p.B + (long)bz * p.sB;
     float* C = p.C + (long)bz * p.sC;
     const int ntiles = (kend - kbeg + BK - 1) / BK;
     // k-tile loader with the optional second K source (a k-tile never straddles K1)
@@ -331,7 +390,147 @@ __device__ __forceinline__ void gemm_segment(const GemmParams& p, float (*As)[BK
     // four 16-byte loads, and the only branch is the loop itself.  Everything else (edge tiles, odd K, unaligned operands)
     // goes through the guarded loader below.
     const bool fast = p.a_vec && p.b_vec && (m0 + BM <= p.M) && (n0 + BN <= p.N) && ((kend - kbeg) % BK == 0) && ntiles > 0;
-    if constexpr (SPLIT) {
+    constexpr bool SPLIT = MODE == 1;
+    if constexpr (MODE == 2) {
+      if (ntiles > 0) {
+        // Pre-split operands: the pipeline of the split-operand loop below (three LDS buffers, one fragment set, one barrier per k-tile, the
+        // same six MFMA groups and early fragment reloads) with the split arithmetic gone: per k-tile and thread three 16-byte granule loads
+        // per operand, stored as they are (K-contiguous) or after the 4 x 4 lane transpose (row-contiguous).
+        const int t = threadIdx.x;
+        const long ldoA = p.lda >> 3, ldoB = p.ldb >> 3;
+        // granule offsets (16-byte units) of this thread at k = 0; a k-tile advances by kA / kB
+        const long oA = (A_KC ? (long)m0 * ldoA * 3 : (long)(m0 >> 3) * 3) + plane_thread_offset<A_KC>(ldoA);
+        const long oB = (B_KC ? (long)n0 * ldoB * 3 : (long)(n0 >> 3) * 3) + plane_thread_offset<B_KC>(ldoB);
+        const long kA = A_KC ? 3 : ldoA * 24, kB = B_KC ? 3 : ldoB * 24;          // per k-OCTET (KC) / per 8 k rows (!KC): granules
+        // guards of this thread's granule position (whole octets: M, N, K are multiples of 8 wherever they index granules)
+        const int rowA = A_KC ? m0 + (t >> 1) : m0 + 8 * (t & 15), rowB = B_KC ? n0 + (t >> 1) : n0 + 8 * (t & 15);
+        const int kofA = A_KC ? 8 * (t & 1) : 4 * (t >> 6) + ((t & 63) >> 4), kofB = B_KC ? 8 * (t & 1) : 4 * (t >> 6) + ((t & 63) >> 4);
+        const bool rokA = rowA < p.M, rokB = rowB < p.N;
+        auto gload_any = [&](auto FASTC, int k0, PlaneRegs& ra_, PlaneRegs& rb_) {
+            const bool second = p.A2 != nullptr && k0 >= p.K1;          // wave-uniform
+            gran_ptr Ab = reinterpret_cast<gran_ptr>(second ? p.A2 : A);
+            gran_ptr Bb = reinterpret_cast<gran_ptr>(second ? p.B2 : B);
+            const long kk = second ? k0 - p.K1 : k0;
+            gran_ptr pa = Ab + oA + (kk >> 3) * kA, pb = Bb + oB + (kk >> 3) * kB;
+            if constexpr (decltype(FASTC)::value) {
+#pragma unroll
+                for (int pl = 0; pl < 3; ++pl) ra_.g[pl] = pa[pl];
+#pragma unroll
+                for (int pl = 0; pl < 3; ++pl) rb_.g[pl] = pb[pl];
+            } else {
+                const int ke = second ? kend - p.K1 : (p.A2 != nullptr ? min(kend, p.K1) : kend);
+                const bool va = rokA && (int)kk + kofA < ke, vb = rokB && (int)kk + kofB < ke;
+                const u32x4 z = {0u, 0u, 0u, 0u};
+#pragma unroll
+                for (int pl = 0; pl < 3; ++pl) ra_.g[pl] = va ? pa[pl] : z;
+#pragma unroll
+                for (int pl = 0; pl < 3; ++pl) rb_.g[pl] = vb ? pb[pl] : z;
+            }
+        };
+        int fa[2], fb[2], fa2[2], fb2[2];
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            fa[i] = A_KC ? lk * SP_KH + (wm + i * 32 + lr) * 4 : (2 * lk) * SP_KQ + pl_slot(wm + i * 32 + lr) * 2;
+            fb[i] = B_KC ? lk * SP_KH + (wn + i * 32 + lr) * 4 : (2 * lk) * SP_KQ + pl_slot(wn + i * 32 + lr) * 2;
+            fa2[i] = fa[i] + SP_KQ; fb2[i] = fb[i] + SP_KQ;
+            if constexpr (!A_KC) asm volatile("" : "+v"(fa2[i]));
+            if constexpr (!B_KC) asm volatile("" : "+v"(fb2[i]));
+        }
+        SplitFrag f;
+        auto rd_a = [&](int buf, int pl) {
+            const unsigned* pa = sp + buf * SP_BUF + pl * SP_PLANE;
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                if constexpr (A_KC) {
+                    f.a[pl][i] = *reinterpret_cast<const u32x4*>(pa + fa[i]);
+                } else {
+                    const u32x2 lo = *reinterpret_cast<const u32x2*>(pa + fa[i]), hi = *reinterpret_cast<const u32x2*>(pa + fa2[i]);
+                    f.a[pl][i] = u32x4{lo[0], lo[1], hi[0], hi[1]};
+                }
+            }
+        };
+        auto rd_b = [&](int buf, int pl) {
+            const unsigned* pb = sp + buf * SP_BUF + SP_OPER + pl * SP_PLANE;
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                if constexpr (B_KC) {
+                    f.b[pl][i] = *reinterpret_cast<const u32x4*>(pb + fb[i]);
+                } else {
+                    const u32x2 lo = *reinterpret_cast<const u32x2*>(pb + fb[i]), hi = *reinterpret_cast<const u32x2*>(pb + fb2[i]);
+                    f.b[pl][i] = u32x4{lo[0], lo[1], hi[0], hi[1]};
+                }
+            }
+        };
+        auto grp = [&](int pa, int pb) {
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, f.a[pa][i]),
+                                                                         __builtin_bit_cast(bf16x8, f.b[pb][j]), acc[i][j], 0, 0, 0);
+        };
+        auto mainloop = [&](auto FASTC) {
+        auto gload = [&](int k0, PlaneRegs& ra_, PlaneRegs& rb_) { gload_any(FASTC, k0, ra_, rb_); };
+        PlaneRegs ra[3], rb[3];
+        auto store_all = [&](int buf, const PlaneRegs& ra_, const PlaneRegs& rb_) {
+            unsigned* sa = sp + buf * SP_BUF;
+            plane_store<A_KC>(sa, ra_, 0, 3); plane_store<B_KC>(sa + SP_OPER, rb_, 0, 3);
+        };
+        gload(kbeg, ra[0], rb[0]);
+        if (ntiles > 1) gload(kbeg + BK, ra[1], rb[1]);
+        if (ntiles > 2) gload(kbeg + 2 * BK, ra[2], rb[2]);
+        store_all(0, ra[0], rb[0]);
+        if (ntiles > 3) gload(kbeg + 3 * BK, ra[0], rb[0]);
+        if (ntiles > 1) store_all(1, ra[1], rb[1]);
+        __syncthreads();
+#pragma unroll
+        for (int pl = 0; pl < 3; ++pl) { rd_a(0, pl); rd_b(0, pl); }
+        // same buffer / register-set rotation as the split-operand loop (see there)
+        auto step = [&](auto RC, auto FULLC, int kt) {
+            constexpr int R = decltype(RC)::value, R1 = (R + 1) % 3, R2 = (R + 2) % 3;
+            constexpr bool FULL = decltype(FULLC)::value;
+            const bool nxt = FULL || kt + 1 < ntiles, st = FULL || kt + 2 < ntiles;
+            unsigned* sa = sp + R2 * SP_BUF;
+            unsigned* sb = sa + SP_OPER;
+            if (FULL || kt + 4 < ntiles) gload(kbeg + (kt + 4) * BK, ra[R1], rb[R1]);
+            grp(1, 1);
+            if (st) plane_store<A_KC>(sa, ra[R2], 0, 2);
+            __builtin_amdgcn_sched_barrier(0);
+            grp(1, 0);
+            if (nxt) rd_a(R1, 1);
+            if (st) plane_store<A_KC>(sa, ra[R2], 2, 3);
+            __builtin_amdgcn_sched_barrier(0);
+            grp(0, 1);
+            if (nxt) rd_b(R1, 1);
+            if (st) plane_store<B_KC>(sb, rb[R2], 0, 2);
+            __builtin_amdgcn_sched_barrier(0);
+            grp(2, 0);
+            if (nxt) rd_a(R1, 2);
+            if (st) plane_store<B_KC>(sb, rb[R2], 2, 3);
+            __builtin_amdgcn_sched_barrier(0);
+            grp(0, 2);
+            if (nxt) rd_b(R1, 2);
+            __builtin_amdgcn_sched_barrier(0);
+            grp(0, 0);
+            __syncthreads();
+            if (nxt) { rd_a(R1, 0); rd_b(R1, 0); }
+            __builtin_amdgcn_sched_barrier(0);
+        };
+        int kt = 0;
+        for (; kt + 6 < ntiles; kt += 3) {       // all three steps unguarded
+            step(std::integral_constant<int, 0>{}, std::true_type{}, kt);
+            step(std::integral_constant<int, 1>{}, std::true_type{}, kt + 1);
+            step(std::integral_constant<int, 2>{}, std::true_type{}, kt + 2);
+        }
+        for (; kt < ntiles; kt += 3) {
+            step(std::integral_constant<int, 0>{}, std::false_type{}, kt);
+            if (kt + 1 < ntiles) step(std::integral_constant<int, 1>{}, std::false_type{}, kt + 1);
+            if (kt + 2 < ntiles) step(std::integral_constant<int, 2>{}, std::false_type{}, kt + 2);
+        }
+              };
+        if (fast) mainloop(std::true_type{}); else mainloop(std::false_type{});
+      }
+    } else if constexpr (SPLIT) {
       if (ntiles > 0) {
         // Split-operand main loop (see the comment at split_pair).  Per k-tile of 16 and wave: 24 MFMAs in six groups of four (one
         // group = one pair of planes on the 2x2 accumulators).  Three LDS buffers, ONE fragment register set, one barrier per tile:
@@ -651,7 +850,11 @@ __device__ __forceinline__ void gemm_segment(const GemmParams& p, float (*As)[BK
         if (threadIdx.x == 0) {
             unsigned spins = 0;
             while (__hip_atomic_load(p.sk_flag + c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != p.sk_id) {
-                if (++spins > SK_SPIN_LIMIT) { atomicExch(p.sk_err, 1u); break; }      // a contributor that is not resident: reported by the host
+                if (++spins > SK_SPIN_LIMIT) {      // a contributor that is not resident: reported by the host, and the step's update skips itself
+                    atomicExch(p.sk_err, 1u);
+                    if (p.call_err) atomicExch(p.call_err, 0xDEAD0005u);
+                    break;
+                }
                 __builtin_amdgcn_s_sleep(2);
             }
         }
@@ -715,8 +918,8 @@ __device__ __forceinline__ void gemm_segment(const GemmParams& p, float (*As)[BK
 // the fields from the kernel-argument segment inside the loop.)
 // LDS of one workgroup: the fp32 kernels hold two K-major fp32 tiles per operand (static); the split-operand kernels take
 // SP_SMEM_BYTES of dynamic LDS (three buffers of bf16 planes) and carve the fp32 tiles of their guarded path out of it.
-template <bool SPLIT> struct GemmSmem;
-template <> struct GemmSmem<false> {
+template <int MODE> struct GemmSmem;
+template <> struct GemmSmem<0> {
     float (*As)[BK][BM + PAD]; float (*Bs)[BK][BN + PAD]; unsigned* sp;
     __device__ __forceinline__ GemmSmem() {
         __shared__ __attribute__((aligned(16))) float as_[2][BK][BM + PAD];
@@ -724,7 +927,7 @@ template <> struct GemmSmem<false> {
         As = as_; Bs = bs_; sp = nullptr;
     }
 };
-template <> struct GemmSmem<true> {
+template <> struct GemmSmem<1> {
     float (*As)[BK][BM + PAD]; float (*Bs)[BK][BN + PAD]; unsigned* sp;
     __device__ __forceinline__ GemmSmem() {
         extern __shared__ __attribute__((aligned(16))) unsigned dyn_[];
@@ -735,9 +938,10 @@ template <> struct GemmSmem<true> {
     }
 };
 
-template <bool A_KC, bool B_KC, bool SPLIT>
+template <> struct GemmSmem<2> : GemmSmem<1> {};
+template <bool A_KC, bool B_KC, int MODE>
 __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_f32_kernel(GemmParams p) {
-    GemmSmem<SPLIT> sm;
+    GemmSmem<MODE> sm;
     float (*As)[BK][BM + PAD] = sm.As; float (*Bs)[BK][BN + PAD] = sm.Bs; unsigned* sp = sm.sp;
     if (!p.persistent) {
         const int bz = blockIdx.z / p.splitk, kz = blockIdx.z % p.splitk;
@@ -746,7 +950,7 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_f32_kernel(GemmParams p)
         int tile = blockIdx.x;
         if (p.swz) tile = (tile & 7) * (gridDim.x >> 3) + (tile >> 3);
         const int kbeg = kz * p.kper;
-        gemm_segment<A_KC, B_KC, SPLIT>(p, As, Bs, sp, bz, (tile / p.gx) * BM, (tile % p.gx) * BN, kbeg, min(p.K, kbeg + p.kper),
+        gemm_segment<A_KC, B_KC, MODE>(p, As, Bs, sp, bz, (tile / p.gx) * BM, (tile % p.gx) * BN, kbeg, min(p.K, kbeg + p.kper),
                                         p.atomic ? seg_atomic(kz == 0) : seg_store(kz == 0));
         return;
     }
@@ -758,7 +962,7 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_f32_kernel(GemmParams p)
     const int per_batch = p.gx * p.gy;
     for (int tile = w; tile < p.dp_tiles; tile += W) {
         const int bz = tile / per_batch, t = tile % per_batch;
-        gemm_segment<A_KC, B_KC, SPLIT>(p, As, Bs, sp, bz, (t / p.gx) * BM, (t % p.gx) * BN, 0, p.K, seg_store());
+        gemm_segment<A_KC, B_KC, MODE>(p, As, Bs, sp, bz, (t / p.gx) * BM, (t % p.gx) * BN, 0, p.K, seg_store());
     }
     long i0 = (long)w * p.sk_per, i1 = min(i0 + p.sk_per, p.sk_iters);
     while (i0 < i1) {
@@ -777,7 +981,7 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_f32_kernel(GemmParams p)
             const int c1 = (int)min((long)W, (min(tile_end, p.sk_iters) + p.sk_per - 1) / p.sk_per);
             role = SegRole{SEG_STORE, 0, w + 1, whole ? w + 1 : c1, true};
         }
-        gemm_segment<A_KC, B_KC, SPLIT>(p, As, Bs, sp, bz, (t / p.gx) * BM, (t % p.gx) * BN, it0 * BK, min(p.K, it1 * BK), role);
+        gemm_segment<A_KC, B_KC, MODE>(p, As, Bs, sp, bz, (t / p.gx) * BM, (t % p.gx) * BN, it0 * BK, min(p.K, it1 * BK), role);
         i0 += it1 - it0;
     }
 }
@@ -793,11 +997,12 @@ constexpr int GROUP_MAX = 8;
 struct GemmGroupParams {
     GemmParams prob[GROUP_MAX]; long first[GROUP_MAX + 1]; int n; int xcd_swz;
     float* sk_part; unsigned* sk_flag; unsigned* sk_err; unsigned sk_id;      // stream-K fix-up (see GemmParams); null: atomics onto zeroed outputs
+    unsigned* call_err;
 };
 
-template <bool A_KC, bool B_KC, bool SPLIT>
+template <bool A_KC, bool B_KC, int MODE>
 __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_group_kernel(GemmGroupParams g) {
-    GemmSmem<SPLIT> sm;
+    GemmSmem<MODE> sm;
     float (*As)[BK][BM + PAD] = sm.As; float (*Bs)[BK][BN + PAD] = sm.Bs; unsigned* sp = sm.sp;
     const int W = gridDim.x;
     const int w = (W % 8 == 0 && g.xcd_swz) ? (int)(blockIdx.x & 7) * (W >> 3) + (int)(blockIdx.x >> 3) : (int)blockIdx.x;
@@ -809,7 +1014,7 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_group_kernel(GemmGroupPa
     while (i0 < i1) {
         GemmParams p = g.prob[pi];             // by value: the fields live in SGPRs across the k-loop (fetching them from the
                                                // kernel-argument segment inside the loop measured slower)
-        p.sk_part = g.sk_part; p.sk_flag = g.sk_flag; p.sk_err = g.sk_err; p.sk_id = g.sk_id;
+        p.sk_part = g.sk_part; p.sk_flag = g.sk_flag; p.sk_err = g.sk_err; p.sk_id = g.sk_id; p.call_err = g.call_err;
         const long pend = min(i1, g.first[pi + 1]);
         long l0 = i0 - g.first[pi];
         const long l1 = pend - g.first[pi];
@@ -828,7 +1033,7 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_group_kernel(GemmGroupPa
                 const int c1 = (int)min((long)W, (tile_end + per - 1) / per);
                 role = SegRole{SEG_STORE, 0, w + 1, whole ? w + 1 : c1, false};
             }
-            gemm_segment<A_KC, B_KC, SPLIT>(p, As, Bs, sp, 0, (t / p.gx) * BM, (t % p.gx) * BN, it0 * BK, min(p.K, it1 * BK), role);
+            gemm_segment<A_KC, B_KC, MODE>(p, As, Bs, sp, 0, (t / p.gx) * BM, (t % p.gx) * BN, it0 * BK, min(p.K, it1 * BK), role);
             l0 += it1 - it0;
         }
         i0 = pend;
@@ -869,42 +1074,51 @@ static int split_kernel_ready(Kern kernel) {       // dynamic LDS beyond 64 KB h
     return hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, SP_SMEM_BYTES) == hipSuccess;
 }
 template <bool A_KC, bool B_KC>
-static int launch_gemm_ab(const GemmParams& p, bool split, dim3 grid, hipStream_t stream) {
-    if (split) {
-        static const int ready = split_kernel_ready(gemm_f32_kernel<A_KC, B_KC, true>);
+static int launch_gemm_ab(const GemmParams& p, int mode, dim3 grid, hipStream_t stream) {
+    if (mode == 2) {
+        static const int ready = split_kernel_ready(gemm_f32_kernel<A_KC, B_KC, 2>);
+        LAS_REQUIRE(ready, "dynamic LDS of the pre-split-operand GEMM");
+        hipLaunchKernelGGL((gemm_f32_kernel<A_KC, B_KC, 2>), grid, dim3(GEMM_THREADS), SP_SMEM_BYTES, stream, p);
+    } else if (mode == 1) {
+        static const int ready = split_kernel_ready(gemm_f32_kernel<A_KC, B_KC, 1>);
         LAS_REQUIRE(ready, "dynamic LDS of the split-operand GEMM");
-        hipLaunchKernelGGL((gemm_f32_kernel<A_KC, B_KC, true>), grid, dim3(GEMM_THREADS), SP_SMEM_BYTES, stream, p);
+        hipLaunchKernelGGL((gemm_f32_kernel<A_KC, B_KC, 1>), grid, dim3(GEMM_THREADS), SP_SMEM_BYTES, stream, p);
     } else {
-        hipLaunchKernelGGL((gemm_f32_kernel<A_KC, B_KC, false>), grid, dim3(GEMM_THREADS), 0, stream, p);
+        hipLaunchKernelGGL((gemm_f32_kernel<A_KC, B_KC, 0>), grid, dim3(GEMM_THREADS), 0, stream, p);
     }
     LAS_LAUNCH_CHECK();
     return LAS_OK;
 }
-static int launch_gemm(const GemmParams& p, bool a_kc, bool b_kc, dim3 grid, hipStream_t stream) {
-    const bool split = gemm_get_arith() == 1;
-    if (a_kc && b_kc) return launch_gemm_ab<true, true>(p, split, grid, stream);
-    if (a_kc && !b_kc) return launch_gemm_ab<true, false>(p, split, grid, stream);
-    if (!a_kc && b_kc) return launch_gemm_ab<false, true>(p, split, grid, stream);
-    return launch_gemm_ab<false, false>(p, split, grid, stream);
+static int launch_gemm(const GemmParams& p, bool a_kc, bool b_kc, bool planes, dim3 grid, hipStream_t stream) {
+    const int mode = planes ? 2 : (gemm_get_arith() == 1 ? 1 : 0);
+    path_note(PATH_GEMM, mode == 2 ? "planes" : (mode == 1 ? "split" : "f32"));
+    if (a_kc && b_kc) return launch_gemm_ab<true, true>(p, mode, grid, stream);
+    if (a_kc && !b_kc) return launch_gemm_ab<true, false>(p, mode, grid, stream);
+    if (!a_kc && b_kc) return launch_gemm_ab<false, true>(p, mode, grid, stream);
+    return launch_gemm_ab<false, false>(p, mode, grid, stream);
 }
 template <bool A_KC, bool B_KC>
-static int launch_group_ab(const GemmGroupParams& g, bool split, dim3 grid, hipStream_t stream) {
-    if (split) {
-        static const int ready = split_kernel_ready(gemm_group_kernel<A_KC, B_KC, true>);
+static int launch_group_ab(const GemmGroupParams& g, int mode, dim3 grid, hipStream_t stream) {
+    if (mode == 2) {
+        static const int ready = split_kernel_ready(gemm_group_kernel<A_KC, B_KC, 2>);
+        LAS_REQUIRE(ready, "dynamic LDS of the pre-split-operand GEMM");
+        hipLaunchKernelGGL((gemm_group_kernel<A_KC, B_KC, 2>), grid, dim3(GEMM_THREADS), SP_SMEM_BYTES, stream, g);
+    } else if (mode == 1) {
+        static const int ready = split_kernel_ready(gemm_group_kernel<A_KC, B_KC, 1>);
         LAS_REQUIRE(ready, "dynamic LDS of the split-operand GEMM");
-        hipLaunchKernelGGL((gemm_group_kernel<A_KC, B_KC, true>), grid, dim3(GEMM_THREADS), SP_SMEM_BYTES, stream, g);
+        hipLaunchKernelGGL((gemm_group_kernel<A_KC, B_KC, 1>), grid, dim3(GEMM_THREADS), SP_SMEM_BYTES, stream, g);
     } else {
-        hipLaunchKernelGGL((gemm_group_kernel<A_KC, B_KC, false>), grid, dim3(GEMM_THREADS), 0, stream, g);
+        hipLaunchKernelGGL((gemm_group_kernel<A_KC, B_KC, 0>), grid, dim3(GEMM_THREADS), 0, stream, g);
     }
     LAS_LAUNCH_CHECK();
     return LAS_OK;
 }
-static int launch_group(const GemmGroupParams& g, bool a_kc, bool b_kc, dim3 grid, hipStream_t stream) {
-    const bool split = gemm_get_arith() == 1;
-    if (a_kc && b_kc) return launch_group_ab<true, true>(g, split, grid, stream);
-    if (a_kc && !b_kc) return launch_group_ab<true, false>(g, split, grid, stream);
-    if (!a_kc && b_kc) return launch_group_ab<false, true>(g, split, grid, stream);
-    return launch_group_ab<false, false>(g, split, grid, stream);
+static int launch_group(const GemmGroupParams& g, bool a_kc, bool b_kc, bool planes, dim3 grid, hipStream_t stream) {
+    const int mode = planes ? 2 : (gemm_get_arith() == 1 ? 1 : 0);
+    if (a_kc && b_kc) return launch_group_ab<true, true>(g, mode, grid, stream);
+    if (a_kc && !b_kc) return launch_group_ab<true, false>(g, mode, grid, stream);
+    if (!a_kc && b_kc) return launch_group_ab<false, true>(g, mode, grid, stream);
+    return launch_group_ab<false, false>(g, mode, grid, stream);
 }
 
 static int gemm_resident_slots() {      // persistent grid: two 256-thread workgroups per CU (34 KB LDS, <= 128 VGPRs each)
@@ -929,6 +1143,7 @@ static std::mutex g_sk_mu;
 static SkScratch g_sk[SK_MAX_SCRATCH];
 static int g_sk_n = 0;
 static std::atomic<unsigned> g_sk_id{1};
+static std::atomic<int> g_sk_any{0};      // a scratch exists: until then gemm_sk_check is one relaxed load (no mutex on every GEMM call)
 
 static const SkScratch* sk_scratch(hipStream_t stream, int slots) {
     if (opt_get(OPT_GEMM_SK_FIXUP) <= 0 || slots <= 0) return nullptr;
@@ -953,6 +1168,7 @@ static const SkScratch* sk_scratch(hipStream_t stream, int slots) {
     }
     *s.err_host = 0;
     g_sk[g_sk_n] = s;
+    g_sk_any.store(1, std::memory_order_release);
     return &g_sk[g_sk_n++];
 }
 static unsigned sk_next_id() {
@@ -963,6 +1179,7 @@ static unsigned sk_next_id() {
 // A fix-up wait that ran into its spin limit (a contributing workgroup was not resident: another kernel held the CUs) leaves a wrong
 // tile behind; the device raises the host-visible word and the next GEMM call (or las_gemm_check) fails loudly.
 int gemm_sk_check() {
+    if (g_sk_any.load(std::memory_order_acquire) == 0) return LAS_OK;
     std::lock_guard<std::mutex> lk(g_sk_mu);
     bool bad = false;
     for (int i = 0; i < g_sk_n; ++i)
@@ -977,6 +1194,39 @@ bool gemm_sk_fixup_ready(hipStream_t stream, int M, int N) {
 
 static bool gemm_aligned(const float* ptr, long ld, long bs) { return ((uintptr_t)ptr % 16 == 0) && (ld % 4 == 0) && (bs % 4 == 0); }
 
+// Pre-split operands index whole 16-byte granules: 8 consecutive elements along the contiguous dimension of each operand
+static bool planes_shape_ok(const GemmDesc& d) {
+    auto al = [](const void* q) { return q == nullptr || (uintptr_t)q % 16 == 0; };
+    return d.K % 8 == 0 && d.lda % 8 == 0 && d.ldb % 8 == 0 && d.sA % 8 == 0 && d.sB % 8 == 0 && al(d.A) && al(d.B) && al(d.A2) && al(d.B2) &&
+           (d.a_kc || d.M % 8 == 0) && (d.b_kc || d.N % 8 == 0) && (d.A2 == nullptr || d.K1 % 16 == 0);
+}
+
+// fp32 matrix (R x C, row stride ld_src) -> P8x3 granules with row stride ld_dst (elements; multiples of 8): one thread per octet
+__global__ __launch_bounds__(256) void split_planes_kernel(const float* __restrict__ src, long ld_src, int R, int C8, u32x4* __restrict__ dst, long ldo_dst) {
+    const long idx = (long)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= (long)R * C8) return;
+    const int r = (int)(idx / C8), o = (int)(idx % C8);
+    const f32x4 v0 = *reinterpret_cast<const f32x4*>(src + (long)r * ld_src + o * 8);
+    const f32x4 v1 = *reinterpret_cast<const f32x4*>(src + (long)r * ld_src + o * 8 + 4);
+    unsigned a[4], b[4], c[4];
+    split_pair(v0[0], v0[1], a[0], b[0], c[0]);
+    split_pair(v0[2], v0[3], a[1], b[1], c[1]);
+    split_pair(v1[0], v1[1], a[2], b[2], c[2]);
+    split_pair(v1[2], v1[3], a[3], b[3], c[3]);
+    u32x4* q = dst + ((long)r * ldo_dst + o) * 3;
+    q[0] = u32x4{a[0], a[1], a[2], a[3]}; q[1] = u32x4{b[0], b[1], b[2], b[3]}; q[2] = u32x4{c[0], c[1], c[2], c[3]};
+}
+int split_planes(const float* src, long ld_src, int R, int C, void* dst, long ld_dst, hipStream_t stream) {
+    LAS_REQUIRE(src && dst && R > 0 && C > 0, "split_planes arguments");
+    LAS_REQUIRE(C % 8 == 0 && ld_src % 4 == 0 && ld_dst % 8 == 0 && ld_dst >= C && (uintptr_t)src % 16 == 0 && (uintptr_t)dst % 16 == 0,
+                "split_planes: whole, aligned octets");
+    const long n = (long)R * (C / 8);
+    hipLaunchKernelGGL(split_planes_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, src, ld_src, R, C / 8,
+                       reinterpret_cast<u32x4*>(dst), ld_dst / 8);
+    LAS_LAUNCH_CHECK();
+    return LAS_OK;
+}
+
 int gemm_f32_group(const GemmDesc* ds, int n, hipStream_t stream) {
     const int group_on = (int)opt_get(OPT_GEMM_GROUP);
     const int W = gemm_resident_slots();
@@ -989,7 +1239,7 @@ int gemm_f32_group(const GemmDesc* ds, int n, hipStream_t stream) {
     for (int i = 0; ok && i < n; ++i) {
         const GemmDesc& d = ds[i];
         ok = d.batch <= 1 && !d.relu && !d.bias0 && !d.bias1 && (d.c_zeroed || d.accumulate || sc != nullptr) && d.a_kc == ds[0].a_kc && d.b_kc == ds[0].b_kc &&
-             d.A2 == nullptr && d.M > 0 && d.N > 0 && d.K > 0;
+             d.A2 == nullptr && d.M > 0 && d.N > 0 && d.K > 0 && d.planes == ds[0].planes && (!d.planes || planes_shape_ok(d));
     }
     if (!ok) {      // not groupable (or switched off): one launch per problem
         for (int i = 0; i < n; ++i) LAS_TRY(gemm_f32(ds[i], stream));
@@ -1006,27 +1256,29 @@ int gemm_f32_group(const GemmDesc* ds, int n, hipStream_t stream) {
         GemmParams& p = g.prob[i];
         memset(&p, 0, sizeof(p));
         p.A = d.A; p.B = d.B; p.C = d.C; p.M = d.M; p.N = d.N; p.K = d.K; p.lda = d.lda; p.ldb = d.ldb; p.ldc = d.ldc;
-        p.a_vec = gemm_aligned(d.A, d.lda, 0); p.b_vec = gemm_aligned(d.B, d.ldb, 0);
+        p.a_vec = d.planes || gemm_aligned(d.A, d.lda, 0); p.b_vec = d.planes || gemm_aligned(d.B, d.ldb, 0);
         p.gx = cdiv(d.N, BN); p.gy = cdiv(d.M, BM); p.kt = std::max(1, cdiv(d.K, BK));
         p.splitk = 1; p.kper = d.K;
         p.accumulate = d.accumulate;           // whole tiles: plain add onto the caller's values instead of a plain store
         g.first[i + 1] = g.first[i] + (long)p.gx * p.gy * p.kt;
     }
     // fix-up schedule: parked partial sums instead of atomics; runs of at least SKF_MIN_RUN k-iterations (small groups use fewer slots)
-    g.sk_part = nullptr; g.sk_flag = nullptr; g.sk_err = nullptr; g.sk_id = 0;
+    g.sk_part = nullptr; g.sk_flag = nullptr; g.sk_err = nullptr; g.sk_id = 0; g.call_err = gemm_call_err_word();
     int Wg = W;
     if (sc != nullptr) {
         const long min_run = std::max<long>(1, tune_skf_min_run());
         Wg = (int)std::min<long>(W, std::max<long>(8, g.first[n] / min_run / 8 * 8));
         g.sk_part = sc->part; g.sk_flag = sc->flag; g.sk_err = sc->err_dev; g.sk_id = sk_next_id();
     }
-    return launch_group(g, ds[0].a_kc, ds[0].b_kc, dim3(Wg), stream);
+    return launch_group(g, ds[0].a_kc, ds[0].b_kc, ds[0].planes, dim3(Wg), stream);
 }
 
 int gemm_f32(const GemmDesc& d, hipStream_t stream) {
     LAS_REQUIRE(d.M > 0 && d.N > 0 && d.K >= 0, "gemm dims");
     LAS_REQUIRE(d.A && d.B && d.C, "gemm pointers");
     LAS_REQUIRE(d.A2 == nullptr || (d.B2 != nullptr && d.K1 > 0 && d.K1 < d.K && d.K1 % BK == 0 && d.batch <= 1), "second K source");
+    LAS_REQUIRE(!d.planes || planes_shape_ok(d), "pre-split operands: K, leading dimensions and the contiguous extents must be multiples of 8, buffers 16-byte aligned");
+    const bool fastk = d.planes || gemm_get_arith() == 1;      // a k-iteration 2-3x faster than on the fp32 matrix pipe: schedule thresholds follow
     GemmParams p;
     p.A2 = d.A2; p.B2 = d.B2; p.K1 = d.K1;
     p.A = d.A; p.B = d.B; p.C = d.C; p.bias0 = d.bias0; p.bias1 = d.bias1;
@@ -1036,8 +1288,8 @@ int gemm_f32(const GemmDesc& d, hipStream_t stream) {
     const int gx = cdiv(d.N, BN), gy = cdiv(d.M, BM);
     const long tiles = (long)gx * gy * batch;
     const int kt = std::max(1, cdiv(d.K, BK));
-    p.a_vec = gemm_aligned(d.A, d.lda, d.sA) && (d.A2 == nullptr || gemm_aligned(d.A2, d.lda, 0));
-    p.b_vec = gemm_aligned(d.B, d.ldb, d.sB) && (d.B2 == nullptr || gemm_aligned(d.B2, d.ldb, 0));
+    p.a_vec = d.planes || (gemm_aligned(d.A, d.lda, d.sA) && (d.A2 == nullptr || gemm_aligned(d.A2, d.lda, 0)));
+    p.b_vec = d.planes || (gemm_aligned(d.B, d.ldb, d.sB) && (d.B2 == nullptr || gemm_aligned(d.B2, d.ldb, 0)));
     p.gx = gx; p.gy = gy; p.kt = kt;
     p.accumulate = d.accumulate; p.relu = d.relu;
     const int xcd_swz = (int)opt_get(OPT_GEMM_XCD_SWZ);
@@ -1051,8 +1303,8 @@ int gemm_f32(const GemmDesc& d, hipStream_t stream) {
     // split-operand arithmetic runs a k-iteration 2-3x faster, so the fixed costs of the stream-K epilogue (zeroing pass, one atomic
     // per output of every partial tile) weigh more: there the persistent schedule is used only when whole tiles fill every slot at
     // least once (plain stores for those, stream-K for the ragged tail), fewer tiles take the classic grid / split-K
-    const long min_tiles = tune(TUNE_SK_MIN_TILES, gemm_get_arith() == 1 ? W : 0);
-    p.sk_part = nullptr; p.sk_flag = nullptr; p.sk_err = nullptr; p.sk_id = 0;
+    const long min_tiles = tune(TUNE_SK_MIN_TILES, fastk ? W : 0);
+    p.sk_part = nullptr; p.sk_flag = nullptr; p.sk_err = nullptr; p.sk_id = 0; p.call_err = gemm_call_err_word();
     LAS_TRY(gemm_sk_check());
     // Stream-K with in-kernel fix-up: the k-iterations of ALL tiles laid end to end and cut into equal runs, one per resident
     // workgroup; a tile that straddles runs is finished by the workgroup holding its first k-iteration, which adds the partial sums the
@@ -1072,7 +1324,7 @@ int gemm_f32(const GemmDesc& d, hipStream_t stream) {
             if (const SkScratch* sc = sk_scratch(stream, W)) {
                 p.persistent = 1; p.dp_tiles = 0; p.sk_iters = total; p.sk_per = (total + Wuse - 1) / Wuse;
                 p.sk_part = sc->part; p.sk_flag = sc->flag; p.sk_err = sc->err_dev; p.sk_id = sk_next_id();
-                return launch_gemm(p, d.a_kc, d.b_kc, dim3((unsigned)cdiv(total, p.sk_per)), stream);
+                return launch_gemm(p, d.a_kc, d.b_kc, d.planes, dim3((unsigned)cdiv(total, p.sk_per)), stream);
             }
         }
     }
@@ -1097,16 +1349,16 @@ int gemm_f32(const GemmDesc& d, hipStream_t stream) {
             }
         }
         dim3 grid((unsigned)std::min<long>(W, std::max<long>(dp > 0 ? W : 1, cdiv(p.sk_iters, std::max<long>(1, p.sk_per)))));
-        return launch_gemm(p, d.a_kc, d.b_kc, grid, stream);
+        return launch_gemm(p, d.a_kc, d.b_kc, d.planes, grid, stream);
     }
 
     int splitk = d.splitk > 0 ? d.splitk : 1;
     // (callers pass splitk = 1 where the persistent schedule was the measured best in fp32-MFMA arithmetic; in split-operand
     // arithmetic that schedule is not taken below one tile per slot, so the request falls back to the automatic split)
     const bool can_zero = d.accumulate || d.c_zeroed || d.ldc == d.N || batch == 1;      // split-K partials need a zeroed (or accumulated) C
-    if (d.splitk == 0 || (d.splitk == 1 && gemm_get_arith() == 1 && may_split && can_zero)) {
+    if (d.splitk == 0 || (d.splitk == 1 && fastk && may_split && can_zero)) {
         // auto: few output tiles and a long K -> split K so the launch covers the chip (256 CUs)
-        const long below = tune(TUNE_SPLIT_BELOW, gemm_get_arith() == 1 ? W / 2 : 128);
+        const long below = tune(TUNE_SPLIT_BELOW, fastk ? W / 2 : 128);
         if (!d.relu && tiles < below && d.K >= 256) {
             // few output tiles, long K: about two workgroups per CU (they hide each other's barrier stalls) with at least 4 k-tiles each
             const long target = tune(TUNE_SPLIT_TARGET, 512);   // ~2 workgroups per CU: measured best
@@ -1129,7 +1381,7 @@ int gemm_f32(const GemmDesc& d, hipStream_t stream) {
         }
     }
     p.swz = ((gx * gy) % 8 == 0) && (gx * gy >= 64);
-    return launch_gemm(p, d.a_kc, d.b_kc, dim3(gx * gy, 1, batch * splitk), stream);
+    return launch_gemm(p, d.a_kc, d.b_kc, d.planes, dim3(gx * gy, 1, batch * splitk), stream);
 }
 
 }  // namespace las

@@ -252,7 +252,7 @@ int las_pblstm_fwd(const float* x, int B, int T_in, int D_in, int H, const float
                    const float* b_ih_f, const float* b_hh_f, const float* w_ih_r, const float* w_hh_r, const float* b_ih_r,
                    const float* b_hh_r, float* out, float* reserve, uint32_t* err_word, int flags, void* stream_) {
     hipStream_t stream = (hipStream_t)stream_;
-    GemmArithScope arith_scope(flags);
+    GemmArithScope arith_scope(flags, err_word);
     LAS_REQUIRE(B > 0 && T_in > 0 && D_in > 0 && H > 0, "pblstm dims");
     LAS_REQUIRE(T_in % 2 == 0, "pBLSTM needs an even number of frames (reference las_model.py:86-87)");
     LAS_REQUIRE(x && out && reserve && err_word, "pblstm pointers");
@@ -293,7 +293,7 @@ int las_pblstm_bwd(const float* x, const float* dout, int B, int T_in, int D_in,
                    float* dx, float* dw_ih_f, float* dw_hh_f, float* db_ih_f, float* db_hh_f, float* dw_ih_r, float* dw_hh_r,
                    float* db_ih_r, float* db_hh_r, uint32_t* err_word, int flags, void* stream_) {
     hipStream_t stream = (hipStream_t)stream_;
-    GemmArithScope arith_scope(flags);
+    GemmArithScope arith_scope(flags, err_word);
     GradsZeroedScope zeroed_scope(flags);
     LAS_REQUIRE(B > 0 && T_in > 0 && D_in > 0 && H > 0 && T_in % 2 == 0, "pblstm dims");
     LAS_REQUIRE(x && dout && reserve && workspace && err_word, "pblstm bwd pointers");
@@ -358,9 +358,8 @@ int las_attn_keys_fwd(const las_speller_desc* d, const float* feat, float* keys,
     g.C = keys; g.ldc = d->M; g.bias0 = d->b_psi;
     g.M = d->B * d->Tp; g.N = d->M; g.K = d->D;
     // a 64-column output gives only B*T'/128 tiles: split K over the chip and apply the activation in a second tiny pass
-    // (with the stream-K fix-up schedule the K split and the relu share ONE launch: no zeroing pass, no activation pass)
     const long tiles = (long)cdiv(g.M, 128) * cdiv(g.N, 128);
-    if (tiles < 64 && g.K >= 256 && !gemm_sk_fixup_ready(stream, g.M, g.N)) {
+    if (tiles < 64 && g.K >= 256) {
         g.splitk = (int)std::min<long>(g.K / 64, std::max<long>(1, 256 / tiles));
         LAS_TRY(gemm_f32(g, stream));
         if (d->relu) LAS_TRY(act_inplace(keys, (long)g.M * g.N, d->relu, stream));
@@ -399,7 +398,7 @@ int las_speller_fwd(const las_speller_desc* d, const float* feat, const float* k
                     int U, int teacher_forced, int decode_mode, const float* sample_noise, float* logp, float* att,
                     int32_t* argmax, float* reserve, uint32_t* err_word, int flags, void* stream_) {
     hipStream_t stream = (hipStream_t)stream_;
-    GemmArithScope arith_scope(flags);
+    GemmArithScope arith_scope(flags, err_word);
     LAS_TRY(check_desc(d));
     LAS_REQUIRE(U > 0, "decode steps");
     LAS_REQUIRE(feat && logp && att && reserve, "speller pointers");
@@ -445,10 +444,12 @@ int las_speller_fwd(const las_speller_desc* d, const float* feat, const float* k
     // the PRE kernel's hand-off slabs (50 MB of sentinel words at paper size) are filled on the side stream, beside the two GEMMs below
     SideStream& side = side_stream();
     bool side_fill = false;
+    SideJoinGuard side_guard;
     if (pre && side.ok(stream)) {
         PersistFwd pf;
         pf.hx = reserve + lay.hx; pf.r0x = reserve + lay.r0x; pf.U = U; pf.Hs = Hs;
         LAS_TRY(side.fork(stream));
+        side_guard.arm(side, stream);
         LAS_TRY(speller_persist_fwd_fill(pf, side.s));
         side_fill = true;
     }
@@ -486,7 +487,7 @@ int las_speller_fwd(const las_speller_desc* d, const float* feat, const float* k
             p.mode = decode_mode == 1 ? 1 : 2;
             p.w_c = d->w_c; p.b_c = d->b_c; p.logp = logp; p.argmax = argmax; p.lgx = reserve + lay.lgx;
         }
-        if (side_fill) LAS_TRY(side.join(stream));
+        if (side_fill) LAS_TRY(side_guard.join());
         const int rc = speller_persist_fwd(p, stream);
         if (rc == LAS_ERR_UNSUPPORTED) persist_ran = false;      // residency check failed: the per-step kernels below run instead
         else LAS_TRY(rc);
@@ -524,8 +525,9 @@ int las_speller_fwd(const las_speller_desc* d, const float* feat, const float* k
         if (Tp > 256) p.eg = reserve + lay.beg;
         p.B = B; p.Tp = Tp; p.U = U; p.V = V; p.relu = d->relu; p.err = err_word;
         const int rc = speller_big_fwd(p, stream);
-        if (rc != LAS_ERR_UNSUPPORTED) { LAS_TRY(rc); persist_ran = true; }
+        if (rc != LAS_ERR_UNSUPPORTED) { LAS_TRY(rc); persist_ran = true; path_note(PATH_DECODE_FWD, "big"); }
     }
+    if (!persist_ran) path_note(PATH_DECODE_FWD, "stepwise");
     for (int s = 0; s < (persist_ran ? 0 : U); ++s) {
         for (int l = 0; l < L; ++l) {
             CellSeg segs[3];
@@ -682,7 +684,7 @@ int las_speller_bwd(const las_speller_desc* d, const float* feat, const float* k
                     const float* dlogp, int U, int feedback_mode0, const float* reserve, float* workspace,
                     const las_speller_grads* g, uint32_t* err_word, int flags, void* stream_) {
     hipStream_t stream = (hipStream_t)stream_;
-    GemmArithScope arith_scope(flags);
+    GemmArithScope arith_scope(flags, err_word);
     GradsZeroedScope zeroed_scope(flags);
     LAS_TRY(check_desc(d));
     LAS_REQUIRE(U > 0 && feat && logp && att && dlogp && reserve && workspace && g, "speller bwd pointers");
@@ -782,9 +784,11 @@ int las_speller_bwd(const las_speller_desc* d, const float* feat, const float* k
         if (rc != LAS_ERR_UNSUPPORTED) {
             LAS_TRY(rc);
             persist_ran = true;
+            path_note(PATH_DECODE_BWD, "big");
             dx0_ctx = const_cast<float*>(speller_big_bwd_dx0_ctx(p.xbuf, U)); ld_dx0 = Hs;
         }
     }
+    if (!persist_ran) path_note(PATH_DECODE_BWD, "stepwise");
     for (int s = persist_ran ? -1 : U - 1; s >= 0; --s) {
         const bool last = (s == U - 1);
         AttnBwdArgs a;
@@ -1160,6 +1164,20 @@ int las_gemm_f32(const float* A, const float* B, float* C, const float* bias0, c
     return gemm_f32(g, (hipStream_t)stream);
 }
 
+size_t las_planes_bytes(int64_t rows, int64_t ld) { return planes_floats((size_t)rows, (size_t)ld) * sizeof(float); }
+int las_split_planes(const float* src, int64_t ld_src, int R, int C, void* dst, int64_t ld_dst, void* stream) {
+    return split_planes(src, ld_src, R, C, dst, ld_dst, (hipStream_t)stream);
+}
+int las_gemm_planes(const void* A, const void* B, float* C, const float* bias0, const float* bias1, int M, int N, int K,
+                    int64_t lda, int64_t ldb, int64_t ldc, int a_kc, int b_kc, int batch, int64_t sA, int64_t sB, int64_t sC,
+                    int splitk, int accumulate, int relu, void* stream) {
+    GemmDesc g;
+    g.A = reinterpret_cast<const float*>(A); g.B = reinterpret_cast<const float*>(B); g.C = C; g.bias0 = bias0; g.bias1 = bias1;
+    g.M = M; g.N = N; g.K = K; g.lda = lda; g.ldb = ldb; g.ldc = ldc; g.a_kc = a_kc; g.b_kc = b_kc; g.batch = batch; g.sA = sA; g.sB = sB; g.sC = sC;
+    g.splitk = splitk; g.accumulate = accumulate; g.relu = relu; g.planes = true;
+    return gemm_f32(g, (hipStream_t)stream);
+}
+
 int las_gemm_get_arith(void) { return gemm_get_arith(); }
 void las_gemm_set_arith(int mode) { gemm_set_arith(mode); }
 void las_gemm_set_tuning(int key, int64_t value) { gemm_set_tuning(key, (long)value); }
@@ -1172,7 +1190,7 @@ int las_gemm_f32_group(const las_gemm_desc* descs, int n, void* stream) {
         const las_gemm_desc& d = descs[i];
         g[i].A = d.A; g[i].B = d.B; g[i].C = d.C; g[i].A2 = d.A2; g[i].B2 = d.B2; g[i].K1 = d.K1;
         g[i].M = d.M; g[i].N = d.N; g[i].K = d.K; g[i].lda = d.lda; g[i].ldb = d.ldb; g[i].ldc = d.ldc;
-        g[i].a_kc = d.a_kc; g[i].b_kc = d.b_kc; g[i].accumulate = d.accumulate; g[i].c_zeroed = d.c_zeroed;
+        g[i].a_kc = d.a_kc; g[i].b_kc = d.b_kc; g[i].accumulate = d.accumulate; g[i].c_zeroed = d.c_zeroed; g[i].planes = d.planes != 0;
     }
     return gemm_f32_group(g, n, (hipStream_t)stream);
 }

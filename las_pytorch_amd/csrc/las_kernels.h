@@ -23,8 +23,15 @@ struct GemmDesc {
     bool relu = false;
     // optional second source along K (C = [A | A2][B ; B2]): k >= K1 reads A2 / B2 at k - K1; same layouts and leading dimensions
     const float* A2 = nullptr; const float* B2 = nullptr; int K1 = 0;
+    // pre-split operands: A / B / A2 / B2 point at P8x3 granule buffers (split_planes, or a producer kernel) of the fp32 matrices the other
+    // fields describe; lda / ldb / sA / sB stay element counts.  Both operands or neither.  Takes the bf16-MFMA path whatever GEMM_ARITH says.
+    bool planes = false;
 };
 int gemm_f32(const GemmDesc& d, hipStream_t stream);
+// fp32 R x C matrix (row stride ld_src) -> its P8x3 image (three bf16 terms per element, x = p1 + p2 + p3 exactly; 16-byte granule
+// (r, c / 8, plane) at index (r (ld_dst / 8) + c / 8) 3 + plane).  C, ld_dst multiples of 8; 6 bytes per element.
+int split_planes(const float* src, long ld_src, int R, int C, void* dst, long ld_dst, hipStream_t stream);
+inline size_t planes_floats(size_t rows, size_t ld) { return (rows * ld * 6 + 15) / 16 * 4; }      // size of a P8x3 image in floats (16-byte multiple)
 // n independent GEMMs of one operand layout, no bias / activation, outputs pre-zeroed (or accumulated onto): ONE launch, the
 // k-iterations of all problems spread evenly over the resident workgroups.  Falls back to n launches when not groupable.
 int gemm_f32_group(const GemmDesc* ds, int n, hipStream_t stream);
@@ -147,6 +154,14 @@ struct SideStream {
     int join(hipStream_t main);
 };
 SideStream& side_stream();
+// fork() ... join() with every exit path covered: an early return between the two (a failing GEMM, a fall-back) still joins the side
+// stream, so that its fill can never race with whatever the main stream does next with the same slabs
+struct SideJoinGuard {
+    SideStream* side = nullptr; hipStream_t main = nullptr;
+    void arm(SideStream& s, hipStream_t m) { side = &s; main = m; }
+    int join() { SideStream* s = side; side = nullptr; return s ? s->join(main) : 0; }
+    ~SideJoinGuard() { if (side) (void)side->join(main); }
+};
 
 struct PersistFwd {
     const float* w0p; int Vp;                       // [W_y | 0 | W_ctx] shadow of W_ih0, ld = Vp + Hs

@@ -47,10 +47,13 @@ const char* opt_name(int opt);
 
 // Per-call override of OPT_GEMM_ARITH for the calling thread (LAS_FLAG_GEMM_F32): RAII, nests.
 struct GemmArithScope {
-    int saved;
-    explicit GemmArithScope(int flags);
+    int saved; unsigned* saved_err;
+    // err_word: the calling entry point's device error word; a stream-K fix-up wait that times out inside one of this call's GEMMs raises
+    // it too, so that las_clip_adam (which gates on it) skips the update of a step whose gradient holds a wrong tile
+    explicit GemmArithScope(int flags, unsigned* err_word = nullptr);
     ~GemmArithScope();
 };
+unsigned* gemm_call_err_word();          // the enclosing entry point's device error word, or null
 int gemm_arith_effective();              // thread override if any, else the option
 
 // HIP-event timing of single kernels on their launch stream (OPT_TIME_KERNELS; bench.py's roofline blocks): RAII around the launch
@@ -61,5 +64,12 @@ struct KernelTimer {
     ~KernelTimer();
 };
 int kernel_timer_read(int which, float* ms_out);    // synchronises on the closing event
+
+// Which kernel family a dispatcher actually launched (las_debug_last_path): every dispatcher notes its choice, so that a parity
+// test can assert that a fixture really pinned the kernel it was written for — a silent fall-back to the generic path would otherwise
+// leave every golden green.  Process-wide, most recent launch per slot (a debugging aid, like the trace hooks).
+enum : int { PATH_REC_FWD = 0, PATH_REC_BWD = 1, PATH_DECODE_FWD = 2, PATH_DECODE_BWD = 3, PATH_GEMM = 4, PATH_COUNT = 5 };
+void path_note(int which, const char* name);
+int path_read(int which, char* out, int cap);
 
 }  // namespace las

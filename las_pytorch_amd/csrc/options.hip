@@ -59,8 +59,13 @@ int opt_find(const char* name) {
     return -1;
 }
 
-GemmArithScope::GemmArithScope(int flags) : saved(tl_arith) { if (flags & LAS_FLAG_GEMM_F32) tl_arith = 0; }
-GemmArithScope::~GemmArithScope() { tl_arith = saved; }
+thread_local unsigned* tl_call_err = nullptr;
+GemmArithScope::GemmArithScope(int flags, unsigned* err_word) : saved(tl_arith), saved_err(tl_call_err) {
+    if (flags & LAS_FLAG_GEMM_F32) tl_arith = 0;
+    if (err_word) tl_call_err = err_word;
+}
+GemmArithScope::~GemmArithScope() { tl_arith = saved; tl_call_err = saved_err; }
+unsigned* gemm_call_err_word() { return tl_call_err; }
 int gemm_arith_effective() { return tl_arith >= 0 ? tl_arith : (opt_get(OPT_GEMM_ARITH) ? 1 : 0); }
 
 namespace {
@@ -122,6 +127,22 @@ int SideStream::join(hipStream_t main) {
     return LAS_OK;
 }
 
+namespace {
+std::mutex g_path_mu;
+char g_path[PATH_COUNT][48] = {};
+}  // namespace
+void path_note(int which, const char* name) {
+    if (which < 0 || which >= PATH_COUNT || !name) return;
+    std::lock_guard<std::mutex> lk(g_path_mu);
+    snprintf(g_path[which], sizeof(g_path[which]), "%s", name);
+}
+int path_read(int which, char* out, int cap) {
+    if (which < 0 || which >= PATH_COUNT || !out || cap <= 0) return fail(LAS_ERR_ARG, "las_debug_last_path: slot %s%ld", "", (long)which);
+    std::lock_guard<std::mutex> lk(g_path_mu);
+    snprintf(out, (size_t)cap, "%s", g_path[which]);
+    return LAS_OK;
+}
+
 int kernel_timer_read(int which, float* ms_out) {
     const int dev = timer_device();
     if (which < 0 || which >= TIMED_COUNT || !ms_out || dev < 0) return fail(LAS_ERR_ARG, "no timed launch of kernel %s%ld", "", (long)which);
@@ -150,6 +171,7 @@ int las_set_option(const char* key, int64_t value) {
 }
 
 int las_debug_kernel_ms(int which, float* ms_out) { return kernel_timer_read(which, ms_out); }
+int las_debug_last_path(int which, char* out, int cap) { return path_read(which, out, cap); }
 
 int las_get_option(const char* key, int64_t* value_out) {
     const int i = opt_find(key);

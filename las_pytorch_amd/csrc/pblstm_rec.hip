@@ -1005,6 +1005,7 @@ int pblstm_rec_fwd(float* gates, const float* w_hh_f, const float* w_hh_r, float
 #undef TRY_FWD_M
             if (!launched) return fail(LAS_ERR_UNSUPPORTED, "no recurrence kernel for %s H=%ld uw=%ld", "", (long)H, (long)uw);
             LAS_LAUNCH_CHECK();
+            path_note(PATH_REC_FWD, plan.nb == 1 ? "rec_fwd_fast" : "rec_fwd_multi");
         }
     }
     if (plan.nb == 0 || !fits) {
@@ -1013,6 +1014,7 @@ int pblstm_rec_fwd(float* gates, const float* w_hh_f, const float* w_hh_r, float
                                       out, cbuf, hprev, B, T, H);
         else hipLaunchKernelGGL((rec_fwd_generic<false>), dim3(ngroups), dim3(256), smem, stream, gates, w_hh_f, w_hh_r, out,
                                 cbuf, hprev, B, T, H);
+        path_note(PATH_REC_FWD, "rec_fwd_generic");
     }
     LAS_LAUNCH_CHECK();
     return LAS_OK;
@@ -1068,13 +1070,14 @@ int pblstm_rec_bwd(const float* dout, const float* gates, const float* cbuf, con
                 else if (H == 256) hipLaunchKernelGGL((rec_bwd_fast<256>), dim3(grid), dim3(REC_THREADS), 0, stream, dout, gates, cbuf, w_hh_t, dgates, B, T, xbuf, err, db_f, db_r);
                 else hipLaunchKernelGGL((rec_bwd_fast<512>), dim3(grid), dim3(REC_THREADS), 0, stream, dout, gates, cbuf, w_hh_t, dgates, B, T, xbuf, err, db_f, db_r);
                 LAS_LAUNCH_CHECK();
+                path_note(PATH_REC_BWD, "rec_bwd_fast");
                 if (db_done && db_f && db_r) *db_done = 1;
                 continue;
             }
 #define TRY_BWD_M(HH, NBV) if (H == HH && plan.nb == NBV) {                                                                          \
         const int rc = launch_bwd_multi<HH, NBV>(dout, gates, cbuf, w_hh_t, dgates, B, T, xbuf, err, b0, Bc, grid, db_f, db_r, stream); \
         if (rc == LAS_ERR_UNSUPPORTED) { fits = false; break; }                                                                       \
-        LAS_TRY(rc); if (db_done && db_f && db_r) *db_done = 1; continue; }
+        LAS_TRY(rc); path_note(PATH_REC_BWD, "rec_bwd_multi"); if (db_done && db_f && db_r) *db_done = 1; continue; }
             TRY_BWD_M(128, 2) TRY_BWD_M(128, 4) TRY_BWD_M(128, 8)
             TRY_BWD_M(256, 2) TRY_BWD_M(256, 4) TRY_BWD_M(256, 8)
             TRY_BWD_M(512, 2) TRY_BWD_M(512, 4)
@@ -1086,6 +1089,7 @@ int pblstm_rec_bwd(const float* dout, const float* gates, const float* cbuf, con
         if (db_done) *db_done = 0;          // the residency check fails before the first launch: no partial sums were added
         const size_t smem = sizeof(float) * 7 * H;
         hipLaunchKernelGGL(rec_bwd_generic, dim3(ngroups), dim3(256), smem, stream, dout, gates, cbuf, w_hh_t, dgates, B, T, H);
+        path_note(PATH_REC_BWD, "rec_bwd_generic");
     }
     LAS_LAUNCH_CHECK();
     return LAS_OK;

@@ -576,6 +576,7 @@ int rec_fwd_mfma(float* gates, const float* w_hh_f, const float* w_hh_r, float* 
             hipLaunchKernelGGL((rec_fwd_mfma_kernel<256, false>), dim3(grid), dim3(RM_THREADS), smem, stream, a);
         }
         LAS_LAUNCH_CHECK();
+        path_note(PATH_REC_FWD, "rec_fwd_mfma");
     }
     return LAS_OK;
 }
@@ -621,6 +622,7 @@ int rec_bwd_mfma(const float* dout, const float* gates, const float* cbuf, const
         RecMfmaBwdArgs a{dout, gates, cbuf, w_hh_t, dgates, db_f, db_r, ring, B, T, b0, Bc, err, xbuf, (int)opt_get(OPT_REC_AGENT_HANDOFF)};
         hipLaunchKernelGGL((rec_bwd_mfma_kernel<256>), dim3(grid), dim3(RM_THREADS), smem, stream, a);
         LAS_LAUNCH_CHECK();
+        path_note(PATH_REC_BWD, "rec_bwd_mfma");
     }
     return LAS_OK;
 }

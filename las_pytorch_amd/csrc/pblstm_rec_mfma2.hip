@@ -466,6 +466,7 @@ int rec_fwd_mfma2(float* gates, const float* w_hh_f, const float* w_hh_r, float*
             hipLaunchKernelGGL((rec_fwd_mfma2_kernel<256, false>), dim3(grid), dim3(RM2_THREADS), smem, stream, a);
         }
         LAS_LAUNCH_CHECK();
+        path_note(PATH_REC_FWD, "rec_fwd_mfma2");
     }
     return LAS_OK;
 }

@@ -1244,6 +1244,7 @@ static int launch_persist_fwd_pre(const PersistArgs& a, int grid, hipStream_t st
         hipLaunchKernelGGL((speller_persist_fwd_pre_kernel<HS, WS>), dim3(grid), dim3(PS_THREADS), smem, stream, a);
     }
     LAS_LAUNCH_CHECK();
+    path_note(PATH_DECODE_FWD, "persist_pre");
     return LAS_OK;
 }
 
@@ -1260,6 +1261,7 @@ static int launch_persist_fwd2(const PersistArgs& a, int grid, hipStream_t strea
         hipLaunchKernelGGL((speller_persist_fwd_kernel<HS, SPLIT, GREEDY>), dim3(grid), dim3(PS_THREADS), smem, stream, a);
     }
     LAS_LAUNCH_CHECK();
+    path_note(PATH_DECODE_FWD, "persist");
     return LAS_OK;
 }
 template <int HS, int SPLIT>

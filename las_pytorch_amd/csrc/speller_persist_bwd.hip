@@ -1324,6 +1324,7 @@ static int launch_persist_bwd_pre(const PersistBwdArgs& a, int grid, hipStream_t
         hipLaunchKernelGGL((speller_persist_bwd_pre_kernel<HS>), dim3(grid), dim3(PS_THREADS), smem, stream, a);
     }
     LAS_LAUNCH_CHECK();
+    path_note(PATH_DECODE_BWD, "persist_pre");
     return LAS_OK;
 }
 
@@ -1339,6 +1340,7 @@ static int launch_persist_bwd(const PersistBwdArgs& a, int grid, hipStream_t str
         hipLaunchKernelGGL((speller_persist_bwd_kernel<HS>), dim3(grid), dim3(PS_THREADS), smem, stream, a);
     }
     LAS_LAUNCH_CHECK();
+    path_note(PATH_DECODE_BWD, "persist");
     return LAS_OK;
 }
 
@@ -1384,8 +1386,10 @@ int speller_persist_bwd(const PersistBwd& p, hipStream_t stream) {
                                    (size_t)(p.U + 1) * 2 * (p.Hs / 16) * 256;
         SideStream& side = side_stream();
         const bool side_fill = side.ok(stream);
+        SideJoinGuard side_guard;
         if (side_fill) {
             LAS_TRY(side.fork(stream));
+            side_guard.arm(side, stream);
             LAS_HIP_CHECK(hipMemsetAsync(slabs, 0xFF, sizeof(float) * slab_floats, side.s));
         }
         {   // e0[s][b][t] = dcat_ctx[s][b] . feat[b][t]: one batched GEMM over the utterances
@@ -1402,7 +1406,7 @@ int speller_persist_bwd(const PersistBwd& p, hipStream_t stream) {
             }
             LAS_TRY(gemm_f32(g, stream));
         }
-        if (side_fill) LAS_TRY(side.join(stream));
+        if (side_fill) LAS_TRY(side_guard.join());
         else LAS_HIP_CHECK(hipMemsetAsync(slabs, 0xFF, sizeof(float) * slab_floats, stream));
         const int grid = 2 * (p.Hs / 16) * 2 + a.ns * p.B;
         if (p.Hs == 512) LAS_TRY(launch_persist_bwd_pre<512>(a, grid, stream));

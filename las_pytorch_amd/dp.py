@@ -52,9 +52,14 @@ class FlatGradAllReducer:
         module._las_flat_reducer = self      # solver.batch_iterator picks it up (zero / all-reduce / clip on the flat buffer)
 
     def zero(self):
-        """Use instead of ``optimizer.zero_grad()`` (which would drop the views with set_to_none=True)."""
+        """Use instead of ``optimizer.zero_grad()`` (which would drop the views with set_to_none=True).
+
+        HIP-graph note: the backward entry points skip their own fill of a gradient block this call zeroed (``LAS_FLAG_GRADS_ZEROED``), a
+        host-side decision that a stream capture bakes into the graph.  The flag is therefore claimed during a capture only when this
+        ``zero()`` was recorded in the same capture (``zero_in_capture``) — every replay then zeroes before it skips."""
         self.flat_ext.zero_()
         self.zero_epoch += 1
+        self.zero_in_capture = bool(self.flat.is_cuda and torch.cuda.is_current_stream_capturing())
 
     def _collective(self):
         """True when allreduce_mean() really exchanges data (more than one rank, or ``force``)."""

@@ -58,10 +58,13 @@ def _claim_prezeroed(params):
     step, not written since): the backward entry point may then skip its own fill of the block (``LAS_FLAG_GRADS_ZEROED``).  Marks them
     written."""
     ok = True
+    capturing = any(p.is_cuda for p in params) and torch.cuda.is_current_stream_capturing()
     for p in params:
         owner = getattr(p, "_las_direct_owner", None)
         if owner is None or getattr(p, "_las_written_epoch", None) == owner.zero_epoch or owner.zero_epoch == 0:
             ok = False
+        elif capturing and not getattr(owner, "zero_in_capture", False):
+            ok = False      # a replay would skip the fill without the zero() that justified it (dp.FlatGradAllReducer.zero)
     for p in params:
         owner = getattr(p, "_las_direct_owner", None)
         if owner is not None:

@@ -70,13 +70,15 @@ class FusedClipAdam(torch.optim.Optimizer):
             st.fill_(float(steps))
 
     def load_state_dict(self, state_dict):
-        super().load_state_dict(state_dict)       # replaces the state tensors by copies: pour them back into the flat buffers
-        for g in self.param_groups:               # a torch.optim.Adam checkpoint has no clip threshold
-            g.setdefault("max_norm", self.defaults["max_norm"])
-            # las_clip_adam implements plain Adam only: refuse to continue silently under a different update rule
+        # las_clip_adam implements plain Adam only: refuse BEFORE anything is replaced (a caller that catches the error keeps an optimizer
+        # whose state still aliases the flat moment buffers)
+        for g in state_dict.get("param_groups", []):
             bad = [k for k in ("weight_decay", "amsgrad", "maximize") if g.get(k)]
             if bad:
                 raise RuntimeError(f"FusedClipAdam: the checkpoint's param group sets {bad}, which las_clip_adam does not implement")
+        super().load_state_dict(state_dict)       # replaces the state tensors by copies: pour them back into the flat buffers
+        for g in self.param_groups:               # a torch.optim.Adam checkpoint has no clip threshold
+            g.setdefault("max_norm", self.defaults["max_norm"])
         off, steps = 0, 0
         for p in self.reducer.params:
             st, n = self.state[p], p.numel()

@@ -20,6 +20,43 @@ BIG_CASES = ["Y_short", "P_B40_T64_U6", "P_B32_T800_U32", "P_B16_T1600_U8", "P_B
              "Y_B4_T2400_U8"]
 
 
+# Kernel family each fixture pins, per phase of the golden tests (las_debug_last_path names, include/las_hip.h): Listener recurrence forward /
+# backward, decode loop teacher-forced forward, greedy forward, backward.  Asserted by test_forward_golden / test_grads_golden: a silent
+# fall-back (a residency check returning LAS_ERR_UNSUPPORTED, a switch such as SPELLER_BIG=0) fails the fixture instead of leaving it green
+# on the per-step kernels.  Derived from the eligibility rules (H / Hs / batch / heads / activation) and confirmed on hardware.
+def expected_paths(info):
+    c, B = info["cfg"], info["B"]
+    H, Hs = c["H"], c["Hs"]
+    if H not in (128, 256, 512):
+        rec_f = rec_b = "generic"
+    elif H == 256 and B >= 64:
+        rec_f, rec_b = ("mfma2" if B > 256 else "mfma"), "mfma"
+    else:
+        per_dir = 256 // (2 * max(1, H * H // 16384))        # utterances one launch steps one-per-group
+        rec_f = rec_b = "fast" if B <= per_dir else "multi"
+    one_launch = info["multi_head"] == 1 and info["use_mlp"] and info["activate"] in ("relu", "None")
+    if one_launch and Hs in (256, 512):
+        tf, bwd, greedy = "persist_pre", "persist_pre", "persist"
+    elif one_launch and Hs == 1024:
+        tf = bwd = greedy = "big"
+    else:
+        tf = bwd = greedy = "stepwise"
+    return dict(rec_fwd="rec_fwd_" + rec_f, rec_bwd="rec_bwd_" + rec_b, tf=tf, greedy=greedy, bwd=bwd)
+
+
+# fixtures whose path differs from the rule above: BASELINE configs[4] (T = 3000), where an utterance's attention operands no longer fit one
+# workgroup's registers + LDS ("LDS residency vs spill"):
+#   P (T' = 375, Hs 512): teacher forcing keeps P[b] = feat[b] W_ctx^T in 8 workgroups per utterance (persist_pre, both ways); the
+#       free-running kernel holds feat[b] itself (750 KB) in 4 and stops at T' <= 256 -> per-step kernels
+#   S (T' = 750, Hs 256): keys 192 KB > 160 KB of LDS: forward per-step; the backward's attention role tiles T' over 16 workgroups per
+#       utterance (classic persistent kernel, no PRE variant beyond T' = 448)
+PATH_OVERRIDES = {
+    "P_B8_T3000_U16": dict(greedy="stepwise"),
+    "P_B8_T3000_U16_s": dict(greedy="stepwise"),
+    "S_B8_T3000_U8": dict(tf="stepwise", greedy="stepwise", bwd="persist"),
+}
+
+
 def load_case(name):
     g = dict(np.load(os.path.join(GOLDEN_DIR, name + ".npz")))
     B, T, U, seed, multi_head, use_mlp, free_len, ragged, sub_t, sub_d = [int(v) for v in g["meta"]]
@@ -36,6 +73,7 @@ def load_case(name):
                 ragged=bool(ragged), sub_t=sub_t, sub_d=sub_d, scale=scale, cfg_name=cfg_name, cfg=c,
                 activate=str(g["activate"]), with_grads="loss_ls" in g, full=cfg_name == "tiny",
                 sub_u=int(g["sub_u"][0]) if "sub_u" in g else 1)
+    info["paths"] = dict(expected_paths(info), **PATH_OVERRIDES.get(name, {}))
     return g, info, sd, x, idx, lens, onehot
 
 

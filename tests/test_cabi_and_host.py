@@ -83,6 +83,31 @@ def test_bench_preflight_detects_shared_devices_and_small_gpus():
     assert len(p) == 1 and "304 CUs" in p[0]
 
 
+def test_bench_rank_launch_command_is_the_drivers_form():
+    """Dry run of ``python bench.py --gpus 8``: the child command and environment bench.py would start (no process is launched) —
+    torch.distributed.run, one node, 8 processes, loopback rendezvous, dmabuf IPC for RCCL, the caller's flags passed through — and the
+    argument parser accepts that command's tail, so the first real 8-GPU run cannot die on plumbing."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("_bench_under_test2", os.path.join(ROOT, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    argv = ["--gpus", "8", "--steps", "20", "--warmup", "5"]
+    cmd, env = bench.rank_launch_command(8, 29517, argv, {"PATH": "/usr/bin", "HSA_ENABLE_IPC_MODE_LEGACY": "1"})
+    assert cmd[1:3] == ["-m", "torch.distributed.run"] and "--nnodes=1" in cmd and "--nproc-per-node=8" in cmd
+    i = cmd.index("--master-addr")
+    assert cmd[i + 1] == "127.0.0.1" and cmd[cmd.index("--master-port") + 1] == "29517"
+    script = cmd.index(os.path.join(ROOT, "bench.py"))
+    assert cmd[script + 1:] == argv                                     # every rank re-parses the same flags
+    assert env["HSA_ENABLE_IPC_MODE_LEGACY"] == "0" and env["MASTER_ADDR"] == "127.0.0.1" and env["PATH"] == "/usr/bin"
+    # torch.distributed.run itself accepts this command line (its own parser; nothing is started)
+    from torch.distributed.run import get_args_parser
+    ns = get_args_parser().parse_args(cmd[3:])
+    assert ns.nproc_per_node == "8" and ns.master_addr == "127.0.0.1" and ns.master_port == 29517 and ns.training_script.endswith("bench.py")
+    assert ns.training_script_args == argv
+    # ... and a rank started that way (RANK/WORLD_SIZE in the environment) takes the rank branch, not the launcher branch
+    assert bench.is_rank_process({"RANK": "3", "WORLD_SIZE": "8", "LOCAL_RANK": "3"}) and not bench.is_rank_process({})
+
+
 def _build(cfg_name, **kw):
     c = synth.CONFIGS[cfg_name]
     listener = Listener(input_feature_dim=c["F"], hidden_size=c["H"], num_layers=c["L"], rnn_unit="LSTM", use_gpu=False,

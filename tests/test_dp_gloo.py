@@ -189,6 +189,66 @@ def test_error_flag_reaches_every_rank_through_the_gradient_allreduce(tmp_path):
     assert float(r0["flag"]) == 0.0 and float(r1["flag"]) == 0.0          # the next step's zero() cleared it
 
 
+def _eight_worker(rank, world, port, out_dir):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    torch.set_num_threads(1)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from las_pytorch_amd.solver import solver as S
+        sd_np, x, onehot, U = _data(B=16)
+        # (a) the averaged shard gradient is the full-batch gradient
+        model = OracleLAS(sd_np)
+        red = dp.FlatGradAllReducer(model)
+        sl = dp.shard_batch(x.shape[0], rank, world)
+        red.zero()
+        model(x[sl], onehot[sl], U).backward()
+        red.allreduce_mean()
+        grad = red.flat.numpy().copy()
+        # (b) three solver steps (shared coin, clip after the all-reduce, Adam) keep the replicas identical; (c) rank 5 injects the
+        # device-error flag in step 1: every rank must refuse that step
+        model = OracleLASModel(sd_np, max_label_len=U)
+        red = dp.FlatGradAllReducer(model)
+        opt = torch.optim.Adam(model.parameters(), lr=2e-4)
+        np.random.seed(100 + rank)
+        outcome = []
+        for step in range(4):
+            hook = (lambda m: red.inject_error(-3.0)) if (step == 1 and rank == 5) else None
+            try:
+                S.batch_iterator(x[sl], onehot[sl], model, opt, tf_rate=0.5, is_training=True, max_label_len=U, label_smoothing=0.1,
+                                 use_gpu=False, grad_hook=hook)
+                outcome.append(0)
+            except RuntimeError as e:
+                assert "peer rank" in str(e)
+                outcome.append(1)
+        flat = torch.cat([p.detach().reshape(-1) for p in model.parameters()]).numpy()
+        np.savez(os.path.join(out_dir, f"e{rank}.npz"), grad=grad, params=flat, coins=np.array(model.coins), outcome=np.array(outcome))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_eight_ranks_gradient_replicas_and_error_flag(tmp_path):
+    """BASELINE configs[3]'s world size without the hardware: eight gloo ranks, two utterances each.  (a) one all-reduce of the flat
+    gradient gives every rank the full-batch gradient; (b) solver.batch_iterator for four steps with tf_rate = 0.5 and different host RNG
+    streams: the teacher-forcing coin is shared and the replicas end bit-identical; (c) a device-error flag injected on ONE rank (5) in
+    step 1 stops that step on ALL eight.  Replaces the reference's nn.DataParallel (train.py:76-78)."""
+    world = 8
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    mp.start_processes(_eight_worker, args=(world, port, str(tmp_path)), nprocs=world, join=True, start_method="spawn")
+    rs = [np.load(tmp_path / f"e{r}.npz") for r in range(world)]
+    sd_np, x, onehot, U = _data(B=16)
+    model = OracleLAS(sd_np)
+    red = dp.FlatGradAllReducer(model)
+    model(x, onehot, U).backward()
+    for r in rs:
+        np.testing.assert_array_equal(r["grad"], rs[0]["grad"])
+        np.testing.assert_array_equal(r["params"], rs[0]["params"])
+        assert r["coins"].tolist() == rs[0]["coins"].tolist()
+        assert r["outcome"].tolist() == [0, 1, 0, 0]
+    np.testing.assert_allclose(rs[0]["grad"], red.flat.numpy(), rtol=5e-4, atol=5e-7)
+    start = np.concatenate([v.reshape(-1) for v in sd_np.values()])
+    assert np.abs(rs[0]["params"] - start).max() > 1e-5
+
+
 def test_oracle_training_trajectory_matches_reference():
     """Eight consecutive solver steps (this build's batch_iterator: loss, clip, Adam) on the CPU oracle walk the trajectory the
     unmodified reference walked (tests/golden/S_trajectory.npz): per-step loss, per-utterance LER, validation call."""

@@ -76,6 +76,98 @@ def test_split_operand_arithmetic_is_fp32_faithful(a_kc, b_kc, M, N, K, spread):
     assert np.isfinite(err[1]) and err[1] <= (2.0 if spread else 1.25) * err[0] + (1.0 if spread else 0.5), err
 
 
+def _planes(X, ld=None):
+    """P8x3 image of a 2-D fp32 tensor (las_split_planes), as a uint8 tensor."""
+    from las_pytorch_amd import _cabi
+    L = _cabi.lib()
+    R, C = X.shape
+    ld = ld or C
+    out = torch.empty(L.las_planes_bytes(R, ld), dtype=torch.uint8, device="cuda")
+    _cabi.check(L.las_split_planes(_cabi.ptr(X), X.stride(0), R, C, out.data_ptr(), ld, _cabi.stream_ptr()))
+    return out
+
+
+def test_split_planes_image_is_the_exact_three_term_split():
+    """x = p1 + p2 + p3 exactly (p_i bf16), granule (r, c / 8, plane) at 16-byte index (r (ld / 8) + c / 8) 3 + plane."""
+    g = torch.Generator(device="cuda").manual_seed(5)
+    X = torch.randn(37, 64, device="cuda", generator=g) * torch.exp2(torch.randint(-30, 30, (37, 64), device="cuda", generator=g).float())
+    img = _planes(X, ld=72).view(torch.bfloat16).view(-1, 8)[: 37 * 9 * 3].view(37, 9, 3, 8)[:, :8]      # (r, octet, plane, 8)
+    terms = img.permute(2, 0, 1, 3).reshape(3, 37, 64).double()
+    assert torch.equal(terms.sum(0), X.double())
+    assert torch.equal(terms[0].float(), X.to(torch.bfloat16).float())          # first term = round-to-nearest-even bf16
+
+
+@pytest.mark.parametrize("a_kc,b_kc", [(True, True), (True, False), (False, False), (False, True)])
+@pytest.mark.parametrize("M,N,K", [(512, 384, 1024), (3200, 1024, 1024), (1024, 160, 12800), (264, 200, 1000), (128, 128, 16), (6400, 2048, 1024),
+                                   (96, 64, 40)])
+def test_planes_gemm_equals_split_operand_gemm(a_kc, b_kc, M, N, K):
+    """The GEMM on pre-split operand images computes the same six bf16 partial products in the same order as arithmetic mode 1 does on
+    the fp32 operands: bit-identical wherever the schedule has no atomics (whole tiles), fp32-faithful against float64 everywhere.
+    Edge tiles (M, N not multiples of 128), a K tail (1000, 40) and bias / relu / accumulate epilogues included."""
+    from las_pytorch_amd import _cabi
+    L = _cabi.lib()
+    g = torch.Generator(device="cuda").manual_seed(M + 3 * N + 7 * K)
+    A = torch.randn(M, K, device="cuda", generator=g)
+    B = torch.randn(K, N, device="cuda", generator=g)
+    bias = torch.randn(N, device="cuda", generator=g)
+    Ad = (A if a_kc else A.t()).contiguous()
+    Bd = (B.t() if b_kc else B).contiguous()
+    lda, ldb = (K if a_kc else M), (K if b_kc else N)
+    Ap, Bp = _planes(Ad), _planes(Bd)
+    old = L.las_gemm_get_arith()
+    try:
+        L.las_gemm_set_arith(1)
+        for splitk, relu in ((1, 1), (0, 0)):
+            C0 = torch.randn(M, N, device="cuda", generator=g)
+            C1 = C0.clone()
+            acc = 0 if relu else 1
+            _gemm(Ad, Bd, C0, bias, M=M, N=N, K=K, lda=lda, ldb=ldb, ldc=N, a_kc=a_kc, b_kc=b_kc, splitk=splitk, relu=relu, accumulate=acc)
+            _cabi.check(L.las_gemm_planes(Ap.data_ptr(), Bp.data_ptr(), _cabi.ptr(C1), _cabi.ptr(bias), None, M, N, K, lda, ldb, N, int(a_kc), int(b_kc),
+                                          1, 0, 0, 0, splitk, acc, relu, _cabi.stream_ptr()))
+            assert _cabi.last_path(_cabi.PATH_GEMM) == "planes"
+            if splitk == 1:
+                assert torch.equal(C0, C1), float((C0 - C1).abs().max())
+            else:
+                torch.testing.assert_close(C1, C0, rtol=2e-6, atol=2e-6 * float(C0.abs().max()))
+        C = torch.full((M, N), float("nan"), device="cuda")
+        _cabi.check(L.las_gemm_planes(Ap.data_ptr(), Bp.data_ptr(), _cabi.ptr(C), None, None, M, N, K, lda, ldb, N, int(a_kc), int(b_kc),
+                                      1, 0, 0, 0, 0, 0, 0, _cabi.stream_ptr()))
+        err = _err_ulp(C, A.double(), B.double())
+        record(f"gemm_planes_vs_f64/{int(a_kc)}{int(b_kc)}_{M}x{N}x{K}", err_ulp=err)
+        assert np.isfinite(err) and err < 12.0, err
+    finally:
+        L.las_gemm_set_arith(old)
+
+
+def test_planes_gemm_batched_and_grouped():
+    """Batched form (two 'directions' through element strides) and the grouped stream-K launch on pre-split operands."""
+    from las_pytorch_amd import _cabi
+    L = _cabi.lib()
+    g = torch.Generator(device="cuda").manual_seed(11)
+    M, N, K = 640, 256, 512
+    A = torch.randn(M, K, device="cuda", generator=g)
+    W = torch.randn(2, N, K, device="cuda", generator=g)
+    Ap, Wp = _planes(A), _planes(W.view(2 * N, K))
+    C = torch.empty(2, M, N, device="cuda")
+    _cabi.check(L.las_gemm_planes(Ap.data_ptr(), Wp.data_ptr(), _cabi.ptr(C), None, None, M, N, K, K, K, N, 1, 1, 2, 0, N * K, M * N, 1, 0, 0,
+                                  _cabi.stream_ptr()))
+    for d in range(2):
+        torch.testing.assert_close(C[d], (A.double() @ W[d].double().t()).float(), rtol=1e-5, atol=1e-4)
+    # grouped: dW_i = G_i^T X  (both operands row-contiguous), outputs pre-zeroed
+    Kb = 3200
+    G = [torch.randn(Kb, 256, device="cuda", generator=g) for _ in range(3)]
+    X = torch.randn(Kb, 384, device="cuda", generator=g)
+    Xp = _planes(X)
+    Gp = [_planes(t) for t in G]
+    outs = [torch.zeros(256, 384, device="cuda") for _ in range(3)]
+    descs = (_cabi.GemmDescC * 3)()
+    for i in range(3):
+        descs[i] = _cabi.GemmDescC(Gp[i].data_ptr(), Xp.data_ptr(), outs[i].data_ptr(), None, None, 256, 384, Kb, 0, 256, 384, 384, 0, 0, 0, 1, 1)
+    _cabi.check(L.las_gemm_f32_group(descs, 3, _cabi.stream_ptr()))
+    for i in range(3):
+        torch.testing.assert_close(outs[i], (G[i].double().t() @ X.double()).float(), rtol=1e-5, atol=2e-4)
+
+
 def test_split_operand_arithmetic_keeps_all_three_terms():
     """Operands with full 24-bit significands and products that are exactly representable (one power-of-two entry per column
     of B): the result must be within one fp32 ulp of the exact product in both arithmetic modes.  A split that lost its third

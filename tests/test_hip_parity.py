@@ -7,6 +7,7 @@ import torch
 
 from golden_util import ALL_CASES, BIG_CASES, load_case, oracle_cfg, tf_argmax_mask
 from hip_util import assert_close, build_las, grad_close, record
+from las_pytorch_amd import _cabi
 
 pytestmark = pytest.mark.gpu
 
@@ -17,6 +18,19 @@ def _check_err():
     import las_pytorch_amd
     torch.cuda.synchronize()
     las_pytorch_amd.check_device_errors()
+
+
+def _assert_path(name, info, **slots):
+    """The fixture ran the kernel family it pins (golden_util.expected_paths): slots maps a phase key of info["paths"] to a
+    las_debug_last_path slot.  LAS_PATH_PROBE=1 records the observed names instead of asserting (to rebuild the table)."""
+    import os
+    from las_pytorch_amd import _cabi
+    torch.cuda.synchronize()
+    for key, slot in slots.items():
+        got = _cabi.last_path(slot)
+        record(f"{name}/path/{key}", path=got, expected=info["paths"][key])
+        if os.environ.get("LAS_PATH_PROBE") != "1":
+            assert got == info["paths"][key], f"{name}: {key} ran on '{got}', the fixture pins '{info['paths'][key]}'"
 
 
 @pytest.mark.parametrize("name", HIP_CASES)
@@ -34,6 +48,7 @@ def test_forward_golden(name):
             assert_close(h.cpu().numpy()[:, ::info["sub_t"], ::info["sub_d"]], g[f"listener_l{l}"], f"{name}/listener_l{l}")
         preds, atts = las(batch_data=xt, batch_label=lab, teacher_force_rate=1.0, is_training=True)
         logp = torch.stack(preds).cpu().numpy()
+        _assert_path(name, info, rec_fwd=_cabi.PATH_REC_FWD, tf=_cabi.PATH_DECODE_FWD)
         assert_close(logp, g["tf_logp"], f"{name}/tf_logp")
         mask = tf_argmax_mask(g["tf_logp"])
         assert (logp.argmax(-1) == g["tf_argmax"])[mask].all() and mask.mean() > 0.99, f"{name}: teacher-forced argmax differs"
@@ -42,6 +57,7 @@ def test_forward_golden(name):
         assert_close(att if info["full"] else att[:, :, :, ::info["sub_t"]], want, f"{name}/tf_att", atol=1e-6)
         preds, _ = las(batch_data=xt, batch_label=lab, teacher_force_rate=0.0, is_training=False)
         logp = torch.stack(preds).cpu().numpy()
+        _assert_path(name, info, greedy=_cabi.PATH_DECODE_FWD)
         assert (logp.argmax(-1) == g["greedy_argmax"]).all(), f"{name}: greedy argmax sequence differs"
         assert_close(logp[::info["sub_u"]], g["greedy_logp"], f"{name}/greedy_logp")
         if "mode0_logp" in g:
@@ -95,6 +111,7 @@ def test_grads_golden(name):
     preds, _ = las(batch_data=xt, batch_label=lab, teacher_force_rate=1.0, is_training=True)
     loss = _loss_ls(preds, lab, info["U"])
     loss.backward()
+    _assert_path(name, info, rec_fwd=_cabi.PATH_REC_FWD, tf=_cabi.PATH_DECODE_FWD, rec_bwd=_cabi.PATH_REC_BWD, bwd=_cabi.PATH_DECODE_BWD)
     assert abs(loss.item() - g["loss_ls"][0]) <= 1e-4 * abs(g["loss_ls"][0]) + 1e-6
     names = [k for k, _ in las.named_parameters()]
     assert names == list(sd_np.keys())
@@ -164,6 +181,43 @@ def test_forward_backward_vs_oracle(cfg_name, B, T, U, scale):
             want = sd[k].grad.numpy()
             grad_close(p.grad.cpu().numpy(), want, f"oracle_{cfg_name}_B{B}_T{T}/grad/{k}", rtol=GRAD_RTOL, floor=GRAD_FLOOR,
                        global_scale=gscale)
+    _check_err()
+
+
+def test_listener_batch320_vs_oracle():
+    """First-hand check of the B > 256 matrix-pipe recurrence (``rec_fwd_mfma2``: two batches of 16 sequences per group, wave-specialised
+    pipeline) and of ``rec_bwd_mfma`` at that batch: the whole paper-size Listener at (B, T) = (320, 800), forward and backward (a fixed
+    random cotangent), against the CPU oracle — every layer output gradient path, dX and all 24 parameter gradients.  The launch path is
+    asserted, so a residency fall-back cannot leave this green on the generic kernels."""
+    from las_pytorch_amd import _cabi, synth
+    from oracle import las_oracle as O
+    c = synth.CONFIGS["P"]
+    B, T = 320, 800
+    sd_np = {k: v for k, v in synth.make_state_dict(synth.config_shapes("P"), seed=23, scale=0.1).items() if k.startswith("listener.")}
+    x = synth.make_inputs(B, T, c["F"], seed=23)
+    rng = np.random.default_rng(23)
+    cot = rng.standard_normal((B, T // 8, 2 * c["H"])).astype(np.float32)
+    sd = O.to_torch_sd(sd_np, requires_grad=True)
+    xo = torch.from_numpy(x).requires_grad_(True)
+    feat_o = O.listener_forward(xo, sd, c["L"])
+    (feat_o * torch.from_numpy(cot)).sum().backward()
+    from las_pytorch_amd import Listener
+    lis = Listener(input_feature_dim=c["F"], hidden_size=c["H"], num_layers=c["L"], rnn_unit="LSTM", use_gpu=True)
+    lis.load_state_dict({k[len("listener."):]: torch.from_numpy(v.copy()) for k, v in sd_np.items()}, strict=True)
+    lis = lis.cuda()
+    xg = torch.from_numpy(x).cuda().requires_grad_(True)
+    feat = lis(xg)
+    assert _cabi.last_path(_cabi.PATH_REC_FWD) == "rec_fwd_mfma2", _cabi.last_path(_cabi.PATH_REC_FWD)
+    assert_close(feat.detach().cpu().numpy(), feat_o.detach().numpy(), "P_B320/listener")
+    (feat * torch.from_numpy(cot).cuda()).sum().backward()
+    torch.cuda.synchronize()
+    assert _cabi.last_path(_cabi.PATH_REC_BWD) == "rec_bwd_mfma", _cabi.last_path(_cabi.PATH_REC_BWD)
+    gscale = max(float(sd[k].grad.norm()) for k in sd)
+    want_dx = xo.grad.numpy()
+    grad_close(xg.grad.cpu().numpy(), want_dx, "oracle_P_B320_T800/grad/x", rtol=GRAD_RTOL, floor=GRAD_FLOOR, global_scale=0.0)
+    for k, p in lis.named_parameters():
+        grad_close(p.grad.cpu().numpy(), sd["listener." + k].grad.numpy(), f"oracle_P_B320_T800/grad/{k}", rtol=GRAD_RTOL, floor=GRAD_FLOOR,
+                   global_scale=gscale)
     _check_err()
 
 
