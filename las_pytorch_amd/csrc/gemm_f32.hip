@@ -15,6 +15,7 @@
 #include "las_common.h"
 #include "las_kernels.h"
 #include "options.h"
+#include "gemm_common.h"
 #include <stdlib.h>
 #include <algorithm>
 #include <atomic>
@@ -34,6 +35,9 @@ namespace las {
 #endif
 #ifndef LAS_SPLIT_ABL
 #define LAS_SPLIT_ABL 0     // timing ablations of the split-operand loop (wrong results): 1 no global loads, 2 no split/store, 4 no fragment reloads
+#endif
+#ifndef LAS_PLANES_ABL
+#define LAS_PLANES_ABL 0    // timing ablations of the pre-split-operand loop (wrong results): 1 no global loads, 2 no LDS stores, 4 no fragment reloads, 8 no barrier
 #endif
 #ifndef LAS_GEMM_ARITH_DEFAULT
 #define LAS_GEMM_ARITH_DEFAULT 1
@@ -55,11 +59,6 @@ static __device__ __forceinline__ lds_ptr_t to_lds(float* p) { return (lds_ptr_t
 // (tests/test_hip_kernels.py compares both against float64).  The split happens in registers on the way from global memory to
 // LDS; LDS holds three bf16 planes per operand as k-pairs ([plane][k/2][row] dwords), conflict-free for both store patterns and
 // for the fragment reads (4 dwords = 8 consecutive k per lane and plane).
-typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
-typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2;
-typedef __attribute__((ext_vector_type(2))) float f32x2;
-typedef __attribute__((ext_vector_type(4))) unsigned u32x4;
-typedef __attribute__((ext_vector_type(2))) unsigned u32x2;
 // Two LDS images of a bf16 plane (128 rows x 16 k, at most 1088 dwords), chosen by the operand's memory orientation so that
 // stores AND fragment reads are wide and conflict-free:
 //   K-contiguous operand  : [k-half (2)][row][4 dwords]  (SP_KH dwords per half)  store 8 B per thread and plane, read one b128
@@ -80,18 +79,6 @@ constexpr int SP_BUF = 2 * SP_OPER;              // A and B
 constexpr int SP_NBUF = 3;                       // tile kt is multiplied while kt+1 is read into fragments and kt+2 is stored
 constexpr int SP_SMEM_BYTES = SP_NBUF * SP_BUF * 4;
 
-static __device__ __forceinline__ unsigned pk_bf16(float a, float b) {
-    f32x2 v = {a, b};
-    return __builtin_bit_cast(unsigned, __builtin_convertvector(v, bf16x2));      // v_cvt_pk_bf16_f32 (round to nearest even)
-}
-// (x0, x1) -> three packed bf16 pairs (low half = x0) with x = p1 + p2 + p3 exactly
-static __device__ __forceinline__ void split_pair(float x0, float x1, unsigned& p1, unsigned& p2, unsigned& p3) {
-    p1 = pk_bf16(x0, x1);
-    x0 -= __uint_as_float(p1 << 16); x1 -= __uint_as_float(p1 & 0xffff0000u);
-    p2 = pk_bf16(x0, x1);
-    x0 -= __uint_as_float(p2 << 16); x1 -= __uint_as_float(p2 & 0xffff0000u);
-    p3 = pk_bf16(x0, x1);
-}
 // registers of one operand tile (two 16-byte loads per thread) -> the three LDS planes, in two halves so that the caller can
 // spread the work between its MFMA groups
 //  KC : load i covers row (t + 256 i) / 4, k = 4 ((t + 256 i) % 4) .. +3         -> half i: two k-pair dwords per plane
@@ -218,39 +205,6 @@ static __device__ __forceinline__ void plane_store(unsigned* S, const PlaneRegs&
         }
     }
 }
-
-struct GemmParams {
-    const float* A; const float* B; float* C; const float* bias0; const float* bias1;
-    int M, N, K;
-    long lda, ldb, ldc;
-    long sA, sB, sC, sBias0, sBias1;
-    int splitk, kper;
-    int accumulate, relu, atomic;
-    int a_vec, b_vec;   // 16-byte vector loads legal for this operand
-    // optional second source along K: k >= K1 reads A2 / B2 at k - K1 (same leading dimensions and layouts; K1 % BK == 0):
-    // C = [A | A2] [B ; B2] in one pass instead of a second accumulating GEMM
-    const float* A2; const float* B2; int K1;
-    int gx, swz;
-    // persistent (data-parallel + stream-K) schedule
-    int persistent, gy, kt, dp_tiles, sk_atomic_whole, xcd_swz;
-    long sk_iters, sk_per;
-    // stream-K with in-kernel fix-up (no atomics, no zeroing pass): a workgroup that covers a tile's k-range only from k-iteration
-    // it0 > 0 parks its 128x128 partial sum in sk_part[slot] and raises sk_flag[slot] = sk_id; the workgroup that owns k-iteration 0
-    // of the tile (its LAST segment) adds the parked sums of the slots behind it and runs the epilogue (bias / accumulate / relu)
-    float* sk_part; unsigned* sk_flag; unsigned* sk_err; unsigned sk_id;
-    unsigned* call_err;      // device error word of the enclosing entry point (null outside one): raised together with sk_err
-};
-
-// what a segment does with its accumulators
-enum : int { SEG_STORE = 0, SEG_ATOMIC = 1, SEG_PART = 2 };
-struct SegRole {
-    int kind;           // SEG_STORE: epilogue + plain store (after adding the partial sums of slots [c0, c1));  SEG_ATOMIC: atomicAdd onto C;
-    int slot;           // SEG_PART: park the partial sum in sk_part[slot]
-    int c0, c1;
-    bool add_bias;
-};
-static __device__ __forceinline__ SegRole seg_store(bool add_bias = true) { return SegRole{SEG_STORE, 0, 0, 0, add_bias}; }
-static __device__ __forceinline__ SegRole seg_atomic(bool add_bias) { return SegRole{SEG_ATOMIC, 0, 0, 0, add_bias}; }
 
 // 16-byte agent-scope accesses (sc1: L2 write-through / L2-bypassing), the hand-off idiom of the persistent kernels (persist_common.h)
 static __device__ __forceinline__ void sk_st4(float* p, const f32x4 v) {
@@ -489,10 +443,10 @@ __device__ __forceinline__ void gemm_segment(const GemmParams& p, float (*As)[BK
         auto step = [&](auto RC, auto FULLC, int kt) {
             constexpr int R = decltype(RC)::value, R1 = (R + 1) % 3, R2 = (R + 2) % 3;
             constexpr bool FULL = decltype(FULLC)::value;
-            const bool nxt = FULL || kt + 1 < ntiles, st = FULL || kt + 2 < ntiles;
+            const bool nxt = !(LAS_PLANES_ABL & 4) && (FULL || kt + 1 < ntiles), st = !(LAS_PLANES_ABL & 2) && (FULL || kt + 2 < ntiles);
             unsigned* sa = sp + R2 * SP_BUF;
             unsigned* sb = sa + SP_OPER;
-            if (FULL || kt + 4 < ntiles) gload(kbeg + (kt + 4) * BK, ra[R1], rb[R1]);
+            if (!(LAS_PLANES_ABL & 1) && (FULL || kt + 4 < ntiles)) gload(kbeg + (kt + 4) * BK, ra[R1], rb[R1]);
             grp(1, 1);
             if (st) plane_store<A_KC>(sa, ra[R2], 0, 2);
             __builtin_amdgcn_sched_barrier(0);
@@ -512,7 +466,7 @@ __device__ __forceinline__ void gemm_segment(const GemmParams& p, float (*As)[BK
             if (nxt) rd_b(R1, 2);
             __builtin_amdgcn_sched_barrier(0);
             grp(0, 0);
-            __syncthreads();
+            if (!(LAS_PLANES_ABL & 8)) __syncthreads();
             if (nxt) { rd_a(R1, 0); rd_b(R1, 0); }
             __builtin_amdgcn_sched_barrier(0);
         };
@@ -993,13 +947,6 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_f32_kernel(GemmParams p)
 // is no tail between the GEMMs, a 16-tile problem no longer holds the chip, and a tile is split between as few workgroups
 // as the balance allows (the atomic traffic is W + #tiles partial tiles, not W per problem).  Partial tiles accumulate with
 // atomics onto buffers the caller has zeroed (the flat gradient buffer); whole tiles are stored (or added) plainly.
-constexpr int GROUP_MAX = 8;
-struct GemmGroupParams {
-    GemmParams prob[GROUP_MAX]; long first[GROUP_MAX + 1]; int n; int xcd_swz;
-    float* sk_part; unsigned* sk_flag; unsigned* sk_err; unsigned sk_id;      // stream-K fix-up (see GemmParams); null: atomics onto zeroed outputs
-    unsigned* call_err;
-};
-
 template <bool A_KC, bool B_KC, int MODE>
 __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_group_kernel(GemmGroupParams g) {
     GemmSmem<MODE> sm;
@@ -1230,6 +1177,10 @@ int split_planes(const float* src, long ld_src, int R, int C, void* dst, long ld
 int gemm_f32_group(const GemmDesc* ds, int n, hipStream_t stream) {
     const int group_on = (int)opt_get(OPT_GEMM_GROUP);
     const int W = gemm_resident_slots();
+    if (group_on) {      // 256-tile form where the group's tiles are big enough
+        const int rc = gemm_big_group(ds, n, stream);
+        if (rc != LAS_ERR_UNSUPPORTED) return rc;
+    }
     bool ok = group_on && W > 0 && n >= 1 && n <= GROUP_MAX;
     // The grouped weight-gradient launches keep the atomic combination by default: their tiles have K = 3 200 .. 12 800 and span 4 - 9
     // workgroup runs, so an owner would fetch up to 512 KB of parked tiles serially at the end of its run, where atomics are fire-and-
@@ -1278,6 +1229,10 @@ int gemm_f32(const GemmDesc& d, hipStream_t stream) {
     LAS_REQUIRE(d.A && d.B && d.C, "gemm pointers");
     LAS_REQUIRE(d.A2 == nullptr || (d.B2 != nullptr && d.K1 > 0 && d.K1 < d.K && d.K1 % BK == 0 && d.batch <= 1), "second K source");
     LAS_REQUIRE(!d.planes || planes_shape_ok(d), "pre-split operands: K, leading dimensions and the contiguous extents must be multiples of 8, buffers 16-byte aligned");
+    {
+        const int rc = gemm_big(d, stream);
+        if (rc != LAS_ERR_UNSUPPORTED) return rc;
+    }
     const bool fastk = d.planes || gemm_get_arith() == 1;      // a k-iteration 2-3x faster than on the fp32 matrix pipe: schedule thresholds follow
     GemmParams p;
     p.A2 = d.A2; p.B2 = d.B2; p.K1 = d.K1;

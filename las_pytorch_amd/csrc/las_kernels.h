@@ -28,6 +28,10 @@ struct GemmDesc {
     bool planes = false;
 };
 int gemm_f32(const GemmDesc& d, hipStream_t stream);
+// 256 x 256 tiles of the split-operand arithmetic (gemm_big.hip): LAS_ERR_UNSUPPORTED (no error text) when the shape does not fill such
+// tiles / the chip or the arithmetic mode is not 1 — gemm_f32 / gemm_f32_group try these first and fall through to the 128-tile kernels
+int gemm_big(const GemmDesc& d, hipStream_t stream);
+int gemm_big_group(const GemmDesc* ds, int n, hipStream_t stream);
 // fp32 R x C matrix (row stride ld_src) -> its P8x3 image (three bf16 terms per element, x = p1 + p2 + p3 exactly; 16-byte granule
 // (r, c / 8, plane) at index (r (ld_dst / 8) + c / 8) 3 + plane).  C, ld_dst multiples of 8; 6 bytes per element.
 int split_planes(const float* src, long ld_src, int R, int C, void* dst, long ld_dst, hipStream_t stream);

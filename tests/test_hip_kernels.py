@@ -168,6 +168,80 @@ def test_planes_gemm_batched_and_grouped():
         torch.testing.assert_close(outs[i], (G[i].double().t() @ X.double()).float(), rtol=1e-5, atol=2e-4)
 
 
+@pytest.mark.parametrize("a_kc,b_kc", [(True, True), (True, False), (False, False), (False, True)])
+@pytest.mark.parametrize("M,N,K,batch", [(512, 512, 1024, 1), (6400, 1024, 1024, 2), (3200, 2048, 512, 1), (1000, 520, 1000, 1), (4096, 512, 2048, 1),
+                                         (300, 256, 2050, 1)])
+def test_tile256_matches_the_128_tile_kernel(a_kc, b_kc, M, N, K, batch):
+    """gemm_big.hip (256 x 256 tiles, GEMM_BIG = 2: whenever the shape allows) against the 128-tile kernel (GEMM_BIG = 0) in the same
+    split-operand arithmetic: whole-K tiles are bit-identical (same products, same order); where either side splits K the sums differ by
+    rounding only.  Edge tiles, a K tail, unaligned K (2050: guarded scalar loads), batches, bias + relu and accumulate epilogues."""
+    from las_pytorch_amd import _cabi
+    L = _cabi.lib()
+    g = torch.Generator(device="cuda").manual_seed(M + 3 * N + 7 * K)
+    A = torch.randn(batch, M, K, device="cuda", generator=g)
+    B = torch.randn(batch, K, N, device="cuda", generator=g)
+    bias = torch.randn(batch, N, device="cuda", generator=g)
+    Ad = (A if a_kc else A.transpose(1, 2)).contiguous()
+    Bd = (B.transpose(1, 2) if b_kc else B).contiguous()
+    lda, ldb = (K if a_kc else M), (K if b_kc else N)
+    old_arith, old_big = L.las_gemm_get_arith(), _cabi.get_option("GEMM_BIG")
+    try:
+        L.las_gemm_set_arith(1)
+        for splitk, relu, acc in ((1, 1, 0), (0, 0, 1)):
+            outs = []
+            for big in (0, 2):
+                _cabi.set_option("GEMM_BIG", big)
+                C = torch.ones(batch, M, N, device="cuda") * 0.5
+                _gemm(Ad, Bd, C, bias, M=M, N=N, K=K, lda=lda, ldb=ldb, ldc=N, a_kc=a_kc, b_kc=b_kc, batch=batch, sA=M * K, sB=N * K, sC=M * N,
+                      splitk=splitk, relu=relu, accumulate=acc)       # (the C-ABI form has no bias stride: row 0 serves every batch)
+                if big == 2:
+                    assert _cabi.last_path(_cabi.PATH_GEMM) == "split256", _cabi.last_path(_cabi.PATH_GEMM)
+                outs.append(C)
+            if splitk == 1:
+                assert torch.equal(outs[0], outs[1]), float((outs[0] - outs[1]).abs().max())
+            else:
+                torch.testing.assert_close(outs[1], outs[0], rtol=2e-6, atol=2e-6 * float(outs[0].abs().max()))
+        _cabi.set_option("GEMM_BIG", 2)
+        C = torch.full((batch, M, N), float("nan"), device="cuda")
+        _gemm(Ad, Bd, C, M=M, N=N, K=K, lda=lda, ldb=ldb, ldc=N, a_kc=a_kc, b_kc=b_kc, batch=batch, sA=M * K, sB=N * K, sC=M * N)
+        err = max(_err_ulp(C[i], A[i].double(), B[i].double()) for i in range(batch))
+        record(f"tile256_vs_f64/{int(a_kc)}{int(b_kc)}_{M}x{N}x{K}", err_ulp=err)
+        assert np.isfinite(err) and err < 12.0, err
+    finally:
+        L.las_gemm_set_arith(old_arith)
+        _cabi.set_option("GEMM_BIG", old_big)
+
+
+def test_tile256_grouped_launch():
+    """The grouped stream-K launch on 256-tiles (weight-gradient shapes: both operands row-contiguous, outputs pre-zeroed or accumulated)."""
+    from las_pytorch_amd import _cabi
+    L = _cabi.lib()
+    g = torch.Generator(device="cuda").manual_seed(13)
+    Kb = 6400
+    G = [torch.randn(Kb, 1024, device="cuda", generator=g) for _ in range(2)]
+    X = torch.randn(Kb, 1024, device="cuda", generator=g)
+    Hp = [torch.randn(Kb, 256, device="cuda", generator=g) for _ in range(2)]
+    old_arith, old_big = L.las_gemm_get_arith(), _cabi.get_option("GEMM_BIG")
+    try:
+        L.las_gemm_set_arith(1)
+        _cabi.set_option("GEMM_BIG", 2)
+        outs = [torch.zeros(1024, 1024, device="cuda"), torch.full((1024, 256), 0.25, device="cuda"), torch.zeros(1024, 1024, device="cuda"),
+                torch.full((1024, 256), 0.25, device="cuda")]
+        descs = (_cabi.GemmDescC * 4)()
+        for i in range(2):
+            descs[2 * i] = _cabi.GemmDescC(G[i].data_ptr(), X.data_ptr(), outs[2 * i].data_ptr(), None, None, 1024, 1024, Kb, 0, 1024, 1024, 1024, 0, 0, 0, 1, 0)
+            descs[2 * i + 1] = _cabi.GemmDescC(G[i].data_ptr(), Hp[i].data_ptr(), outs[2 * i + 1].data_ptr(), None, None, 1024, 256, Kb, 0, 1024, 256, 256, 0, 0,
+                                               1, 0, 0)
+        _cabi.check(L.las_gemm_f32_group(descs, 4, _cabi.stream_ptr()))
+        assert _cabi.last_path(_cabi.PATH_GEMM) == "split256"
+        for i in range(2):
+            torch.testing.assert_close(outs[2 * i], (G[i].double().t() @ X.double()).float(), rtol=1e-5, atol=3e-4)
+            torch.testing.assert_close(outs[2 * i + 1], (0.25 + G[i].double().t() @ Hp[i].double()).float(), rtol=1e-5, atol=3e-4)
+    finally:
+        L.las_gemm_set_arith(old_arith)
+        _cabi.set_option("GEMM_BIG", old_big)
+
+
 def test_split_operand_arithmetic_keeps_all_three_terms():
     """Operands with full 24-bit significands and products that are exactly representable (one power-of-two entry per column
     of B): the result must be within one fp32 ulp of the exact product in both arithmetic modes.  A split that lost its third

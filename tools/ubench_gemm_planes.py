@@ -4,6 +4,7 @@ import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from las_pytorch_amd import _cabi
+if os.environ.get("LAS_ABL_LIB"): _cabi.LIB_PATH = os.path.abspath(os.environ["LAS_ABL_LIB"])      # an ablation build (-DLAS_PLANES_ABL=mask)
 L = _cabi.lib()
 L.las_gemm_set_arith(1)
 def timed(fn, reps=20):
@@ -35,6 +36,14 @@ def run(name, M, N, K, a_kc, b_kc, batch=1, splitk=0):
     fl = 2.0 * batch * M * N * K / 1e6
     print(f"{name:<26} M={M:<6} N={N:<5} K={K:<6} b={batch} akc={int(a_kc)} bkc={int(b_kc)}: split {us0:7.1f} us {fl/us0:6.1f} TF | planes {us1:7.1f} us {fl/us1:6.1f} TF"
           f" | split_planes A {timed(sa):6.1f} B {timed(sb):6.1f} us", flush=True)
+if os.environ.get("QUICK"):
+    print(os.environ.get("LAS_ABL_LIB", "product"))
+    run("L1 fwd proj (2 dirs)", 6400, 1024, 1024, True, True, batch=2, splitk=1)
+    run("L1 dW_ih", 1024, 1024, 6400, False, False)
+    run("L1 dX", 6400, 1024, 2048, True, False, splitk=1)
+    run("4096^3 NT", 4096, 4096, 4096, True, True, splitk=1)
+    run("4096^3 TN", 4096, 4096, 4096, False, False, splitk=1)
+    sys.exit(0)
 for l, (BT, D) in enumerate([(12800, 160), (6400, 1024), (3200, 1024)]):
     run(f"L{l} fwd proj (2 dirs)", BT, 1024, D, True, True, batch=2, splitk=1)
     run(f"L{l} dW_ih", 1024, D, BT, False, False)
