@@ -38,6 +38,7 @@ WORKLOADS = {
     "P_fwd": ("P", 800, 128, False),
     "S_fwd": ("S", 800, 128, False),       # BASELINE configs[1]
     "P_long": ("P", 3000, 128, True),      # BASELINE configs[4] (use --batch 8)
+    "S_long": ("S", 3000, 128, True),      # ... with the small model: T' = 750, keys 192 KB (do not fit the LDS: per-step decode forward)
     "Y_train": ("Y", 800, 128, True),      # config/librispeech-config.yaml sizes (512x3 / 1024x2, 40-mel; yaml batch 16)
 }
 HBM_PEAK_GBS = 8000.0    # MI355X HBM3E spec peak (guides/MI355X_MICROARCH.md)
@@ -322,6 +323,47 @@ def roofline_speller(step, c, B, T, U, iters=10):
         out[key] = dict(bound="hbm", kernel=("speller_persist_fwd_pre_kernel" if which == 0 else "speller_persist_bwd_pre_kernel") + f"<{c['Hs']}> (B={B},T'={Tp},U={U})",
                         achieved=round(ach, 2), peak=HBM_PEAK_GBS, unit="GB/s", frac=round(ach / HBM_PEAK_GBS, 5), traffic=traffic,
                         traffic_source=src, kernel_ms=round(t, 4), us_per_decode_step=round(t * 1e3 / U, 3), algorithmic_bytes=int(alg))
+    return out
+
+
+def secondary_long(device, U, B=8, T=3000, steps=10, warmup=3, with_roofline=True):
+    """BASELINE.json configs[4] beside the headline: the paper-size model on a batch of 8 thirty-second utterances (T = 3000 frames,
+    T' = 375), the same full training step.  The Listener recurrences are 2 625 dependent steps each way on 64 of the 256 CUs
+    (8 utterances x 2 directions x 4 CUs: a longer sequence offers no more parallelism), the decode loop keeps P[b] = feat[b] W_ctx^T
+    resident in 8 workgroups per utterance (T' = 375 exceeds what 4 hold).  Returns the block with its own roofline entries: the
+    layer-0 recurrence at T_l = 1500 and the two decode kernels at T' = 375, event-timed like the headline's."""
+    from las_pytorch_amd import dp, synth
+    from las_pytorch_amd.optim import FusedClipAdam
+    las, c, _ = build_model("P", U, device)
+    x = torch.from_numpy(synth.make_inputs(B, T, c["F"], seed=17)).to(device)
+    idx, lens = synth.make_labels(B, U, c["V"], seed=17)
+    lab = torch.from_numpy(synth.onehot_labels(idx, lens, c["V"])).to(device)
+    reducer = dp.FlatGradAllReducer(las, direct=True)
+    opt = FusedClipAdam(reducer, lr=2e-4)
+    step = make_train_step(las, x, lab, reducer, opt)
+    for _ in range(warmup):
+        step()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        last = step()
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / steps
+    import las_pytorch_amd
+    las_pytorch_amd.check_device_errors()
+    assert np.isfinite(float(last.item()))
+    out = {"workload": f"P_long (BASELINE configs[4]): Listener 256x3 / Speller 512x2, (B={B},T={T},F=80), teacher-forced U={U}, the same full "
+                       "training step (fwd + loss + bwd + clip + Adam)",
+           "value": round(B / dt, 1), "unit": "utt/s", "ms_per_step": round(dt * 1e3, 3), "steps": steps,
+           "serial_recurrence_steps_each_way": sum(T >> (l + 1) for l in range(c["L"])), "recurrence_cus": 2 * B * (c["H"] * c["H"] // 16384),
+           "residency": "P keys 96 KB + P[b] slice in registers: 8 attention workgroups per utterance (persist_pre both ways); greedy decode at this T' "
+                        "falls to the per-step kernels (feat[b] = 750 KB does not fit 4 workgroups' registers)"}
+    if with_roofline:
+        r = roofline_rec_fwd(c, B, T, iters=5, with_traffic=True)
+        out["roofline"] = r
+        out.update(roofline_speller(step, c, B, T, U, iters=5))
+    del las, reducer, opt
+    torch.cuda.empty_cache()
     return out
 
 
@@ -671,6 +713,9 @@ def main():
                 dts = (time.perf_counter() - t1) / 10
             res["config"]["secondary"] = {"workload": "S_fwd (BASELINE configs[1]): Listener 128x2 / Speller 256x2, forward only, same inputs",
                                           "value": round(B / dts, 1), "unit": "utt/s", "ms_per_step": round(dts * 1e3, 3)}
+            del las_s, xs
+            torch.cuda.empty_cache()
+            res["config"]["secondary_long"] = secondary_long(device, U, with_roofline=not args.no_roofline)
         print(json.dumps(res), flush=True)
     if use_dist:
         dist.barrier()

@@ -34,7 +34,7 @@ __device__ unsigned long long* g_rec_trace = nullptr;
 #else
 #define REC_STAMP(who, step, k) do { } while (0)
 #endif
-constexpr unsigned SPIN_LIMIT = 1u << 22;
+constexpr unsigned SPIN_LIMIT = 1u << 18;      // ~40 ms of bounded spinning (see persist_common.h)
 using u64 = unsigned long long;
 
 __device__ __forceinline__ float poll_granule(u64* g, unsigned epoch, unsigned* err) {

@@ -10,7 +10,9 @@ namespace {
 using u64 = unsigned long long;
 constexpr int PS_THREADS = 1024, PS_NW = 16;
 constexpr unsigned PS_SENT = 0xFFFFFFFFu;
-constexpr unsigned PS_SPIN_LIMIT = 1u << 21;
+// bounded spins: ~160 ns each, i.e. ~42 ms until a wait gives up (round 4: 1 << 21 = 336 ms of dead time per timeout; a hand-off normally
+// lands within microseconds, so this is still four orders of magnitude of margin — and a false alarm only costs one step on the generic kernels)
+constexpr unsigned PS_SPIN_LIMIT = 1u << 18;
 constexpr int PS_M = 64;           // attention MLP width handled by the persistent kernel
 constexpr int PS_KLD = PS_M + 4;   // LDS row stride of the keys (bank spread)
 

@@ -233,10 +233,13 @@ def main_big4(refmods):
         run_case(refmods, "P_B128_T800_U16", "P", B=128, T=800, U=16, ragged=True, seed=17, **big128)
         run_case(refmods, "P_B128_T800_U16_s", "P", B=128, T=800, U=16, ragged=True, seed=51, scale=0.2, **big128)
     if "b" in which:
-        run_case(refmods, "Y_B16_T800_U16", "Y", B=16, T=800, U=16, scale=0.05, seed=37, **big)
+        # seed chosen with tests/golden/seed_search.py: smallest top-1 / top-2 gap over the 256 greedy positions 8.8e-4 (two distinct symbols);
+        # round 4's seed 37 had 7.2e-5, a thin margin for an arg-max identity test
+        run_case(refmods, "Y_B16_T800_U16", "Y", B=16, T=800, U=16, scale=0.05, seed=69, **big)
     if "d" in which:
         # the YAML sizes with a 24-second utterance batch (T = 2400 -> T' = 300 > 256): the LONG instantiation of the one-launch decode kernels
-        run_case(refmods, "Y_B4_T2400_U8", "Y", B=4, T=2400, U=8, scale=0.05, seed=41, ragged=True, **big)
+        # (seed from tests/golden/seed_search.py: greedy / teacher-forced top-1 / top-2 gap 1.8e-2; round 4's seed 41 had 2.2e-4)
+        run_case(refmods, "Y_B4_T2400_U8", "Y", B=4, T=2400, U=8, scale=0.05, seed=45, ragged=True, **big)
     if "c" in which:
         run_case(refmods, "P_short_mh4", "P", B=4, T=64, U=8, multi_head=4, scale=0.1, full=False, light=True, seed=23)
         run_case(refmods, "P_B32_T800_U16_mh2", "P", B=32, T=800, U=16, multi_head=2, scale=0.1, seed=23, **big)

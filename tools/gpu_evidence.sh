@@ -17,6 +17,22 @@ rocprofv3 --pmc FETCH_SIZE -d $O/pmc_step/fetch -o x -- python3 $R/bench.py $F >
 rocprofv3 --pmc WRITE_SIZE -d $O/pmc_step/write -o x -- python3 $R/bench.py $F > $O/pmc_step_write.log 2>&1
 rocprofv3 --pmc FETCH_SIZE -d $O/pmc_fetch -o x -- python3 $R/tools/ubench_rec.py > $O/pmc_fetch.log 2>&1
 rocprofv3 --pmc WRITE_SIZE -d $O/pmc_write -o x -- python3 $R/tools/ubench_rec.py > $O/pmc_write.log 2>&1
+# BASELINE configs[4] (B = 8, T = 3000): kernel stats of the step, HBM counters of the layer-0 recurrence (T_l = 1500) and of the decode kernels
+# (T' = 375), LDS counters of the decode kernels (P: keys resident; S at this T: keys do not fit, per-step kernels)
+FL="--workload P_long --batch 8 --steps 10 --warmup 3 --no-cpu-baseline --no-sweep --no-mfma --no-roofline --no-secondary"
+rocprofv3 --kernel-trace --stats -d $O/stats_long -o x -- python3 $R/bench.py $FL > $O/stats_long.log 2>&1
+export B=8 T=1500
+rocprofv3 --pmc FETCH_SIZE -d $O/pmc_long_fetch -o x -- python3 $R/tools/ubench_rec.py > $O/pmc_long_fetch.log 2>&1
+rocprofv3 --pmc WRITE_SIZE -d $O/pmc_long_write -o x -- python3 $R/tools/ubench_rec.py > $O/pmc_long_write.log 2>&1
+unset B T
+FL4="--workload P_long --batch 8 --steps 4 --warmup 2 --no-cpu-baseline --no-sweep --no-mfma --no-roofline --no-secondary"
+rocprofv3 --pmc FETCH_SIZE -d $O/pmc_long_step/fetch -o x -- python3 $R/bench.py $FL4 > $O/pmc_long_step_fetch.log 2>&1
+rocprofv3 --pmc WRITE_SIZE -d $O/pmc_long_step/write -o x -- python3 $R/bench.py $FL4 > $O/pmc_long_step_write.log 2>&1
+rocprofv3 --pmc SQ_INSTS_LDS SQ_LDS_IDX_ACTIVE SQ_LDS_BANK_CONFLICT SQ_ACTIVE_INST_LDS SQ_WAVE_CYCLES SQ_WAIT_ANY -d $O/pmc_long_lds -o x -- python3 $R/bench.py $FL4 > $O/pmc_long_lds.log 2>&1
+FS4="--workload S_long --batch 8 --steps 4 --warmup 2 --no-cpu-baseline --no-sweep --no-mfma --no-roofline --no-secondary"
+rocprofv3 --pmc SQ_INSTS_LDS SQ_LDS_IDX_ACTIVE SQ_LDS_BANK_CONFLICT SQ_ACTIVE_INST_LDS SQ_WAVE_CYCLES SQ_WAIT_ANY -d $O/pmc_slong_lds -o x -- python3 $R/bench.py $FS4 > $O/pmc_slong_lds.log 2>&1
+rocprofv3 --kernel-trace --stats -d $O/stats_slong -o x -- python3 $R/bench.py $FS4 > $O/stats_slong.log 2>&1
+python3 $R/tools/lds_long_table.py $O > $O/lds_long.log 2>&1
 # MFMA-busy / stall / LDS counters of the GEMM in both arithmetic modes (1 = split-operand bf16 MFMA, the default; 0 = fp32 MFMA)
 for a in 1 0; do
   export LAS_GEMM_ARITH=$a
@@ -39,7 +55,9 @@ python tools/ubench_gemm_skf.py 128 > $O/gemm_skf_b128.log 2>&1
 python tools/check_big.py > $O/big_decode.log 2>&1
 python tools/ubench_rec_sweep.py > $O/rec_sweep.log 2>&1
 python tools/ubench_gemm_split.py > $O/gemm_split.log 2>&1
+python tools/ubench_gemm_big.py > $O/gemm_big.log 2>&1
+python tools/ubench_gemm_planes.py > $O/gemm_planes.log 2>&1
 # soak: 1500 consecutive training steps (~1e7 inter-workgroup hand-offs) must end without a device error word
 python bench.py --steps 1500 --warmup 5 --no-cpu-baseline --no-sweep --no-mfma --no-roofline --no-secondary > $O/soak.json 2> $O/soak.err
-for w in "P_long 8" "S_train 32" "Y_train 16" "P_fwd 32" "S_fwd 32" "P_train 128"; do set -- $w; python bench.py --workload $1 --batch $2 --steps 10 --warmup 3 --no-cpu-baseline --no-sweep --no-mfma --no-secondary --no-roofline 2>/dev/null | tail -1; done > $O/variants.jsonl
+for w in "P_long 8" "S_long 8" "S_train 32" "Y_train 16" "P_fwd 32" "S_fwd 32" "P_train 128"; do set -- $w; python bench.py --workload $1 --batch $2 --steps 10 --warmup 3 --no-cpu-baseline --no-sweep --no-mfma --no-secondary --no-roofline 2>/dev/null | tail -1; done > $O/variants.jsonl
 tail -3 $O/pytest_gpu.log; tail -1 $O/smoke.log; tail -c 300 $O/bench.json

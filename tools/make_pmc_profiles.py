@@ -14,7 +14,8 @@ import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
-ROUND = os.environ.get("LAS_ROUND", "r04")
+ROUND = os.environ.get("LAS_ROUND", "r05")
+SUFFIX = os.environ.get("LAS_PROFILE_SUFFIX", "")      # e.g. "_long": the T = 3000 shapes beside the headline ones
 
 
 def csrc_sha16():
@@ -68,7 +69,7 @@ def rec(fetch_db, write_db, B, T_l, H):
                 "WRITE_SIZE is exact on the copy; on the kernel it exceeds the expected stash bytes by the hand-off granules "
                 "(2*B*G workgroups x T_l steps x 64 units x 8 B = 52.4 MB at this shape), which reach memory once.",
     }
-    path = os.path.join(ROOT, "profiles", f"{ROUND}_pmc_rec_fwd.json")
+    path = os.path.join(ROOT, "profiles", f"{ROUND}_pmc_rec_fwd{SUFFIX}.json")
     json.dump(out, open(path, "w"), indent=1)
     print(path, json.dumps(out)[:400])
 
@@ -89,7 +90,7 @@ def speller(fetch_db, write_db, B, Tp, U, Hs):
                        "workload); per launch of this kernel. FETCH_SIZE raw: the guide's x2 gfx950 correction applies to wide 16-B/lane "
                        "streams, most of this kernel's reads are agent-scope polls and 16-B tile loads that hit the XCD's L2 after the "
                        "first workgroup, so the raw counter is quoted. Hand-off slabs and the backward stash are written through (sc1)."}
-        path = os.path.join(ROOT, "profiles", f"{ROUND}_pmc_speller_{tag}.json")
+        path = os.path.join(ROOT, "profiles", f"{ROUND}_pmc_speller_{tag}{SUFFIX}.json")
         json.dump(out, open(path, "w"), indent=1)
         print(path, json.dumps(out)[:300])
 
