@@ -39,7 +39,7 @@ struct PblstmBwdLayout {
 };
 
 struct SpellerLayout {
-    size_t y_all, ctx_all, h_all, c_all, gates_all, q_all, w0p, ctxcat_all, hx, r0x, lgx, wperm, wyperm, bperm, yw, pctx, gx, bqp, bfl, blg, beg, total;
+    size_t y_all, ctx_all, h_all, c_all, gates_all, q_all, w0p, ctxcat_all, hx, r0x, lgx, wperm, wyperm, bperm, yw, pctx, gx, bqp, bfl, blg, beg, qct, wyT, plx, total;
     bool big;                  // room for the one-launch decode of the Hs = 1024 shape (speller_big.hip)
     bool pre;                  // room for the persistent decode kernel's pre-multiplied context variant
     int Vp;                    // label width padded to a multiple of 16: every cell operand is aligned and tail-free
@@ -67,6 +67,10 @@ struct SpellerLayout {
         bperm = o; if (pre) o += r4((size_t)4 * d->Hs);
         yw = o; if (pre) o += r4((size_t)U * B * 4 * d->Hs);       // ... and y_s W_y^T + b for every step (label half of the bottom-layer gates)
         pctx = o; if (pre) o += r4((size_t)B * d->Tp * 4 * d->Hs);
+        // free-running form of the PRE kernel (arg-max feedback, no backward): Q^T = W_c[:, Hs:] feat^T, W_y^T (permuted columns), partial-logit slabs
+        qct = o; if (pre) o += r4((size_t)B * 32 * d->Tp);
+        wyT = o; if (pre) o += r4((size_t)Vp * 4 * d->Hs);
+        plx = o; if (pre) o += r4((size_t)U * (d->Hs / 4) * 512);
         // Hs = 1024 one-launch decode: label half of the bottom-layer gates, query slices and partial contexts (hand-off slabs, adjacent)
         big = speller_big_shape(d->B, d->Tp, d->Hs, d->D, d->M, d->V, d->L, d->multi_head, d->use_mlp);
         if (big && !pre) { yw = o; o += r4((size_t)U * B * 4 * d->Hs); }
@@ -438,8 +442,13 @@ int las_speller_fwd(const las_speller_desc* d, const float* feat, const float* k
     // las_speller_bwd (LAS_FLAG_TEACHER_FORCED) can rely on them whichever forward variant actually ran.
     // (Only a stashing forward has a backward: without LAS_FLAG_STASH the two GEMMs are skipped unless the PRE kernel itself needs P.)
     const bool pre_stash = teacher_forced && lay.pre && ((flags & LAS_FLAG_STASH) || pre);
-    LAS_TRY(speller_prologue(d->w_ih[0], w0p, Hs, V, Vp, pre_stash ? reserve + lay.wperm : nullptr, pre ? reserve + lay.wyperm : nullptr,
-                             pre ? reserve + lay.bperm : nullptr, d->b_ih[0], d->b_hh[0],
+    // ... and its free-running form (decode_mode 1 without a backward pass: the reference's validation decode, train.py:149-169): the character
+    // distribution moves into the attention workgroups, one launch at ~8 instead of ~13 us per step
+    const bool preg = !teacher_forced && decode_mode == 1 && !(flags & LAS_FLAG_STASH) && lay.pre && persist_on && err_word &&
+                      !(flags & LAS_FLAG_FORCE_GENERIC) && d->relu <= LAS_ACT_RELU && logp &&
+                      speller_persist_pre_greedy_eligible(B, Tp, Hs, D, d->M, V, L, d->multi_head, d->use_mlp);
+    LAS_TRY(speller_prologue(d->w_ih[0], w0p, Hs, V, Vp, (pre_stash || preg) ? reserve + lay.wperm : nullptr, (pre || preg) ? reserve + lay.wyperm : nullptr,
+                             (pre || preg) ? reserve + lay.bperm : nullptr, d->b_ih[0], d->b_hh[0],
                              teacher_forced ? (const long long*)labels_onehot : nullptr, y_all, B, U, U_lab, feat, (long)Tp * D, ctx_all, D, stream));
     // the PRE kernel's hand-off slabs (50 MB of sentinel words at paper size) are filled on the side stream, beside the two GEMMs below
     SideStream& side = side_stream();
@@ -453,24 +462,37 @@ int las_speller_fwd(const las_speller_desc* d, const float* feat, const float* k
         LAS_TRY(speller_persist_fwd_fill(pf, side.s));
         side_fill = true;
     }
-    if (pre_stash) {
+    if (pre_stash || preg) {
         GemmDesc g;
         g.A = feat; g.lda = D; g.a_kc = true;
         g.B = reserve + lay.wperm; g.ldb = Hs; g.b_kc = true;
         g.C = reserve + lay.pctx; g.ldc = 4 * Hs; g.M = B * Tp; g.N = 4 * Hs; g.K = D; g.splitk = 1;
         LAS_TRY(gemm_f32(g, stream));
     }
-    bool persist_ran = persist;
+    bool persist_ran = persist || preg;
     bool pre_ran = false;
-    if (persist) {
+    if (persist || preg) {
         PersistFwd p;
         p.prefilled = side_fill;
-        if (pre) {
+        if (preg) {
+            // Q^T[b] = W_c[:, Hs:] feat[b]^T (V x T' per utterance): the context share of the logits becomes sum_t a_t Q[:, t]
+            GemmDesc g;
+            g.A = d->w_c + Hs; g.lda = Hs + D; g.a_kc = true;
+            g.B = feat; g.ldb = D; g.b_kc = true; g.sB = (long)Tp * D;
+            g.C = reserve + lay.qct; g.ldc = Tp; g.sC = (long)32 * Tp;
+            g.M = V; g.N = Tp; g.K = D; g.batch = B; g.splitk = 1;
+            LAS_TRY(gemm_f32(g, stream));
+            // W_y^T in the permuted gate-column order: the bottom cell's lanes fetch the fed-back symbol's row
+            LAS_TRY(transpose2d(reserve + lay.wyperm, reserve + lay.wyT, 4 * Hs, Vp, stream));
+            p.qct = reserve + lay.qct; p.wyT = reserve + lay.wyT; p.plx = reserve + lay.plx;
+        }
+        if (pre || preg) {
             // label half of the bottom-layer gates for every step, off the decode chain: yw[s][b] = y_s[b] W_y^T + b_ih0 + b_hh0
             GemmDesc g;
             g.A = y_all; g.lda = Vp; g.a_kc = true;
             g.B = reserve + lay.wyperm; g.ldb = Vp; g.b_kc = true; g.bias0 = reserve + lay.bperm;
-            g.C = reserve + lay.yw; g.ldc = 4 * Hs; g.M = U * B; g.N = 4 * Hs; g.K = Vp; g.splitk = 1;
+            // (free-running: y_0 = <sos>, every later label half is the bias alone — two step blocks suffice, the kernel reads block min(s, 1))
+            g.C = reserve + lay.yw; g.ldc = 4 * Hs; g.M = (preg ? std::min(U, 2) : U) * B; g.N = 4 * Hs; g.K = Vp; g.splitk = 1;
             LAS_TRY(gemm_f32(g, stream));
             p.pctx = reserve + lay.pctx; p.gx = reserve + lay.gx; p.r0x = reserve + lay.r0x; p.yw = reserve + lay.yw;
         }
@@ -492,6 +514,14 @@ int las_speller_fwd(const las_speller_desc* d, const float* feat, const float* k
         if (rc == LAS_ERR_UNSUPPORTED) persist_ran = false;      // residency check failed: the per-step kernels below run instead
         else LAS_TRY(rc);
         pre_ran = persist_ran && pre;
+        if (preg && !persist_ran && !persist) {      // (residency check failed and the classic kernel does not take this shape either)
+            path_note(PATH_DECODE_FWD, "stepwise");
+        } else if (preg && !persist_ran) {           // fall back to the classic free-running kernel
+            PersistFwd q = p;
+            q.pctx = nullptr; q.gx = nullptr; q.r0x = nullptr; q.yw = nullptr; q.qct = nullptr; q.wyT = nullptr; q.plx = nullptr; q.prefilled = false;
+            const int rc2 = speller_persist_fwd(q, stream);
+            if (rc2 != LAS_ERR_UNSUPPORTED) { LAS_TRY(rc2); persist_ran = true; }
+        }
     }
     if (pre_ran) {   // contexts of every step: ctx_all[1+s][b] = att[s][b] . feat[b], one batched GEMM over the utterances
         GemmDesc g;

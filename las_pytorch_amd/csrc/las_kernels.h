@@ -185,6 +185,9 @@ struct PersistFwd {
     const float* pctx = nullptr; float* gx = nullptr;
     float* r0x = nullptr;                           // PRE variant: U*32*4Hs floats, the cell workgroups' part of the bottom-layer gates
     const float* yw = nullptr;                      // PRE variant: (U*B, 4Hs) label half + biases of the bottom-layer gates, permuted columns
+    // PRE variant with mode 1 (free-running arg-max feedback, speller_persist_pre_greedy_eligible): Q^T = W_c[:, Hs:] feat^T (B, 32, Tp), W_y^T in
+    // the permuted gate-column order (Vp, 4Hs), and U*(Hs/4)*512 floats of partial-logit slabs
+    const float* qct = nullptr; const float* wyT = nullptr; float* plx = nullptr;
     int B, Tp, U, Hs, V, relu;
     unsigned* err;
     bool prefilled = false;                         // the caller has sentinel-filled the hand-off slabs already (speller_persist_fwd_fill)
@@ -194,6 +197,7 @@ bool speller_persist_eligible(int B, int Tp, int Hs, int D, int M, int V, int L,
 int speller_persist_pre_ws(int B, int Tp, int Hs, int cus);   // attention workgroups per utterance of the PRE variant (0: n/a; cus < 0: shape only)
 bool speller_persist_pre_shape(int B, int Tp, int Hs, int D, int M, int V, int L, int heads, int use_mlp);   // shape only (sizes the reserve)
 bool speller_persist_pre_eligible(int B, int Tp, int Hs, int D, int M, int V, int L, int heads, int use_mlp);   // shape + residency
+bool speller_persist_pre_greedy_eligible(int B, int Tp, int Hs, int D, int M, int V, int L, int heads, int use_mlp);   // ... of its free-running (mode 1) form
 int speller_persist_fwd(const PersistFwd& p, hipStream_t stream);
 void speller_persist_set_trace(unsigned long long* dev_buf);   // profiling aid, see tools/ubench_persist_trace.py
 

@@ -38,6 +38,7 @@ enum Opt : int {
     OPT_SPELLER_BIG_TUNE,       // ... its poll pacing in units of 64 clocks: byte 0 before the first h0 poll, byte 1 between polls, byte 2 / 3 before the first ctx / h1 poll
     OPT_TIME_KERNELS,           // record HIP events around the persistent decode kernels (las_debug_kernel_ms reads them)
     OPT_GEMM_BIG,               // 256 x 256 tiles (gemm_big.hip) where they fill the chip: 1 automatic, 0 never, 2 whenever the shape allows (A/B)
+    OPT_SPELLER_PRE_GREEDY,     // free-running (arg-max feedback) decode without a backward pass on the pre-multiplied-context kernel
     OPT_COUNT
 };
 

@@ -49,6 +49,9 @@ struct PersistArgs {
     const float* pctx; float* gx;          // PRE variant: feat . W_ctx^T (B*Tp, 4Hs) and its per-step weighted sums [U][B][4Hs] (stash for the backward)
     float* r0x;                            // PRE variant: layer-0 gates minus the context half, [U][Hs/4][32][16] (cell -> attention, sentinel-prefilled)
     const float* yw;                       // PRE variant: y_s W_y^T + b_ih0 + b_hh0 for every step, (U*B, 4Hs), columns in unit*4 + gate order
+    // PRE variant, free-running (mode 1): Q^T = W_c[:, Hs:] feat^T per utterance (B, 32, Tp); W_y^T in the permuted gate-column order
+    // (Vp, 4Hs); partial logits W_c[:, units] h1 of every cell workgroup, [U][Hs/4][16 utterances][32], sentinel-prefilled
+    const float* qct; const float* wyT; float* plx;
     int B, Tp, U, relu;
     int split;                     // attention workgroups per utterance (each owns D/split context columns)
     unsigned* err;
@@ -460,14 +463,19 @@ struct CellRole {
 //   * the label half W_y y_s + biases comes from ONE GEMM before the launch (a.yw) and is staged in LDS a step ahead;
 //   * one LDS exchange buffer serves both layers in turn: top-layer gates -> barrier -> waves 0-1 reduce / apply / publish the top
 //     cell; then R0's product (same h0_s tile, still in registers) -> barrier -> waves 2-3 reduce and publish R0.
-template <int HS>
+// GREEDY (free-running decode, mode 1): the workgroup also publishes its units' share of the character-distribution logits,
+//     PL_s[utterance][v] = sum_{u in its 8 units} W_c[v][u] h1_s[utterance][u],
+// one 2 KB tile per step next to h1_s; the attention workgroups add the 64 tiles of their utterance to the context share they compute
+// themselves and pick the arg-max (AttnPreRole) — the label half of R0 then holds the biases only (the caller's yw is built from y = 0).
+template <int HS, bool GREEDY = false>
 struct CellPreRole {
     static constexpr int NF = HS / 256;                 // 16-wide k-blocks of an Hs-wide operand per wave
     static constexpr int NK = 4 * NF;
     static constexpr int RLD = 36;                      // row stride of a partial tile: 32 columns + pad, 16-byte aligned
     static constexpr int RED = PS_NW * 16 * RLD;
     static constexpr int WPL = 2 * 3 * (NK / 2) * PS_THREADS;      // dwords of one matrix' bf16 planes (two column tiles)
-    static constexpr int LDS_FLOATS = RED + 4 * 128 + 4 + 2 * 128 * 4 + WPL + 32;
+    static constexpr int LDS_BASE = RED + 4 * 128 + 4 + 2 * 128 * 4 + WPL + 32;
+    static constexpr int LDS_FLOATS = LDS_BASE + (GREEDY ? 128 + 32 * 8 : 0);      // + h1 of the step, W_c columns of the 8 units
     static constexpr int NWG = 2 * (HS / 8);
     using WSplit = PsPlanes<NK>;
 
@@ -547,6 +555,12 @@ struct CellPreRole {
         volatile unsigned* cflags = reinterpret_cast<volatile unsigned*>(smem + RED + 4 * 128);
         float* ywl = smem + RED + 4 * 128 + 4;        // [step parity][R0 lane][4 gates]
         unsigned* wl = reinterpret_cast<unsigned*>(ywl + 2 * 128 * 4);     // W_hh0: [column tile][plane][thread][NK / 2]
+        float* hl = smem + LDS_BASE;                  // GREEDY: h1_s of the 128 cell lanes, [utterance][unit]
+        float* wcl = hl + 128;                        // GREEDY: W_c[v][8 j8 + u], [32][8]
+        if (GREEDY && tid < 256) {
+            const int v = tid >> 3, u = tid & 7;
+            wcl[tid] = v < a.V ? a.w_c[(size_t)v * 2 * HS + j8 * 8 + u] : 0.f;
+        }
 
         // ---- weights: column n of tile nt = gate n / 4 of unit 8 j8 + 4 nt + n % 4;  W[row][16*blk + 4*kq + e]
         WSplit Si1[2];
@@ -626,7 +640,8 @@ struct CellPreRole {
             const unsigned t = opaque((unsigned)tid) - 128u;
             if (t < 128u && (int)(t >> 3) < nrows)
                 *reinterpret_cast<f32x4*>(ywl + ((s & 1) * 128 + t) * 4) =
-                    ld4p(at_bytes(a.yw + (size_t)s * B * (4 * HS), 4u * ((16u * mh + (t >> 3)) * (4 * HS) + ((unsigned)j8 * 8 + (t & 7)) * 4)));
+                    // (GREEDY: the caller's yw holds two step blocks — <sos> for step 0, the biases alone for every later step)
+                    ld4p(at_bytes(a.yw + (size_t)(GREEDY ? min(s, 1) : s) * B * (4 * HS), 4u * ((16u * mh + (t >> 3)) * (4 * HS) + ((unsigned)j8 * 8 + (t & 7)) * 4)));
         };
         auto publish_r0 = [&](int s, bool with_red) {
             const unsigned t = opaque((unsigned)tid) - 128u;
@@ -648,6 +663,7 @@ struct CellPreRole {
                 const float ig = sigmoidf_acc(g4[0]), fg = sigmoidf_acc(g4[1]), gg = tanhf_acc(g4[2]), og = sigmoidf_acc(g4[3]);
                 c1 = fg * c1 + ig * gg;
                 const float h = og * tanhf_acc(c1);
+                if (GREEDY) hl[tq] = h;
                 const size_t slab = ((size_t)U + s) * sH;
                 const unsigned o = 4u * (pbq * HS + unit);
                 st1_agent(at_bytes(a.hx + ((size_t)U + s) * HXS, 4u * (((unit >> 2) * 32 + pbq) * 4 + (unit & 3))), h);
@@ -699,6 +715,24 @@ struct CellPreRole {
             PS_STAMP(1, s, 6);
             if (tid < 128) top_cell(read_red(opaque((unsigned)tid)), s);
             PS_STAMP(0, s, 5);
+            if (GREEDY) {      // partial logits of h1_s: thread (utterance, v) of the upper eight waves, one 16-byte store per four v
+                lds_barrier();
+                const unsigned t = opaque((unsigned)tid) - 512u;
+                if (t < 512u) {
+                    const unsigned utt = t >> 5, v = t & 31u;
+                    const f32x4 w0 = *reinterpret_cast<const f32x4*>(wcl + v * 8), w1 = *reinterpret_cast<const f32x4*>(wcl + v * 8 + 4);
+                    const f32x4 h0 = *reinterpret_cast<const f32x4*>(hl + utt * 8), h1 = *reinterpret_cast<const f32x4*>(hl + utt * 8 + 4);
+                    const float acc = dot4p(w1, h1, dot4p(w0, h0, 0.f));
+                    const int ai = __builtin_bit_cast(int, acc);
+                    f32x4 q4;
+                    q4[0] = __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(ai, 0x00, 0xF, 0xF, true));      // quad_perm broadcasts
+                    q4[1] = __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(ai, 0x55, 0xF, 0xF, true));
+                    q4[2] = __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(ai, 0xAA, 0xF, 0xF, true));
+                    q4[3] = __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(ai, 0xFF, 0xF, 0xF, true));
+                    if ((v & 3u) == 0u && (int)utt < nrows)
+                        st4_agent(at_bytes(a.plx + (size_t)s * ((size_t)NWG * 512), 4u * (((unsigned)blockIdx.x * 16 + utt) * 32 + v)), q4);
+                }
+            }
             if (!more) break;
             // ---- off the chain (the attention workgroups are working now): next step's R0 from the h0_s tile still in registers
             accR0[0] = accR0[1] = zero;
@@ -906,7 +940,11 @@ struct AttnRole {
 // floats, register-resident: lane = (column group, time slice)) is contracted with the step's attention weights and published
 // as whole 128-byte lines.  Query, energies and softmax are computed redundantly by the four (as the two of AttnRole do);
 // the context itself is not needed on the chain any more and is left to one batched GEMM after the launch.
-template <int HS, int WS>
+// GREEDY (free-running decode, mode 1; round 5): the workgroup also forms the character distribution of its utterance — the decoder-state
+// share arrives as 64 partial tiles from the cell workgroups (CellPreRole), the context share is sum_t a_t Q_t with Q = feat W_c[:, Hs:]^T
+// resident in LDS (the context itself never exists on the chain) — every wave picks the arg-max itself, and the bottom cell's lanes fetch the
+// symbol's W_y column (2 KB per workgroup from the L2: the one dependent load this mode adds to the chain).
+template <int HS, int WS, bool GREEDY = false>
 struct AttnPreRole {
     static constexpr int SPLIT = WS;                     // workgroups per utterance: 4, 8 or 16 (longer T' at smaller batches)
     static constexpr int GC = 4 * HS / SPLIT;            // gate columns of this workgroup
@@ -921,7 +959,9 @@ struct AttnPreRole {
     // alone take up to 122 KB of LDS) all of it stays in registers and R0 is fetched with a blocking load instead
     static constexpr int NJR = WS == 16 ? NJ : NJ / 2;
     static constexpr bool R0_BLOCKING = WS == 16;
-    static __host__ __device__ constexpr int lds_floats(int Tp) { return HS + PS_M + EP + MAX_TP + 2 * GC + Tp * PS_KLD + PS_M * 4 * (NJ - NJR) * 16; }
+    static constexpr int NJ8 = HS / 8;                   // cell-workgroup column groups = partial-logit tiles per utterance
+    static __host__ __device__ constexpr int lds_base(int Tp) { return HS + PS_M + EP + MAX_TP + 2 * GC + Tp * PS_KLD + PS_M * 4 * (NJ - NJR) * 16; }
+    static __host__ __device__ constexpr int lds_floats(int Tp) { return lds_base(Tp) + (GREEDY ? 32 * MAX_TP + 32 * NJ8 + 64 : 0); }
 
     static __device__ void run(const PersistArgs& a, float* smem, const int widx) {
         const int b = widx / SPLIT, part_id = widx % SPLIT;
@@ -964,6 +1004,18 @@ struct AttnPreRole {
         for (int j = NJR; j < NJ; ++j)
             *reinterpret_cast<f32x4*>(wpl + prow * (64 * (NJ - NJR)) + 4 * (pk + 16 * (j - NJR))) = ld4p(a.w_phi + (size_t)prow * HS + 4 * (pk + 16 * j));
         const float bphi = a.b_phi[prow];
+        // GREEDY: Q^T of this utterance [v][t] (zero past V / T'), the staging area of the partial logits [v][tile], the step's logits
+        float* qt = smem + lds_base(Tp);
+        float* plv = qt + 32 * MAX_TP;
+        float* lgl = plv + 32 * NJ8;
+        float bcv = 0.f;
+        if (GREEDY) {
+            for (int idx = tid; idx < 32 * MAX_TP; idx += PS_THREADS) {
+                const int v = idx / MAX_TP, t = idx % MAX_TP;
+                qt[idx] = (v < a.V && t < Tp) ? a.qct[((size_t)b * 32 + v) * Tp + t] : 0.f;
+            }
+            bcv = (tid >> 5) < a.V ? a.b_c[tid >> 5] : 0.f;
+        }
         lds_barrier();
 
         // ---- the bottom LSTM cell of this workgroup's CG hidden units, one per lane of the first CG/64 waves, state in a register:
@@ -1005,11 +1057,12 @@ struct AttnPreRole {
             }
         };
         // after the barrier that follows the ts == 0 lanes' LDS hand-over of the reduced sums (gxl): apply the cell, publish h0_s
-        auto bottom_cell = [&](int s) {
+        auto bottom_cell = [&](int s, const f32x4 wy = f32x4{0.f, 0.f, 0.f, 0.f}) {      // wy: GREEDY, the fed-back symbol's W_y entries of this unit's gates
             if (tid >= CG) return;                               // whole waves (CG is a multiple of 64)
             const int unit = part_id * CG + tid;                 // hidden unit; its four gates are columns col0 + 4 tid .. + 3
-            const f32x4 g4 = *reinterpret_cast<const f32x4*>(gxl + tid * 4);
+            f32x4 g4 = *reinterpret_cast<const f32x4*>(gxl + tid * 4);
             const f32x4 r = *reinterpret_cast<const f32x4*>(r0l + tid * 4);
+            if (GREEDY) { g4[0] += wy[0]; g4[1] += wy[1]; g4[2] += wy[2]; g4[3] += wy[3]; }
             const float ig = sigmoidf_acc(g4[0] + r[0]), fg = sigmoidf_acc(g4[1] + r[1]), gg = tanhf_acc(g4[2] + r[2]), og = sigmoidf_acc(g4[3] + r[3]);
             c0 = fg * c0 + ig * gg;
             const float h = og * tanhf_acc(c0);
@@ -1019,6 +1072,33 @@ struct AttnPreRole {
             *at_bytes(a.c_all + (size_t)s * sH, o) = c0;
             float* go = at_bytes(a.gates_all + 4 * (size_t)s * sH, opaque(4u * ((unsigned)b * 4 * HS + unit)));
             go[0] = ig; go[HS] = fg; go[2 * HS] = gg; go[3 * HS] = og;
+        };
+        // GREEDY: the partial logits of h1_s (64 tiles of 32 floats for this utterance): waves 8.. fetch one 16-byte piece each while the
+        // energies are computed (like R0) and drop it transposed into LDS; a piece that was not complete yet is re-polled when it lands
+        const bool plane = GREEDY && tid >= 512 && tid < 512 + NJ8 * 8;
+        auto pl_src = [&](int s) {
+            const unsigned k = plane ? opaque((unsigned)tid) - 512u : 0u;
+            return at_bytes(a.plx + (size_t)s * ((size_t)(HS / 4) * 512), 4u * ((((k >> 3) * 2 + ((unsigned)b >> 4)) * 16 + ((unsigned)b & 15u)) * 32 + (k & 7u) * 4));
+        };
+        // (first read: ONE ordinary 16-byte load — a slot of this step's slab is either still the sentinel, possibly a stale copy of it in
+        // this XCD's L2, or final: whatever looks incomplete is re-read with agent-scope loads when it lands)
+        auto pl_issue = [&](int s, f32x4& pv) { pv = plane ? *reinterpret_cast<const f32x4*>(pl_src(s)) : f32x4{0.f, 0.f, 0.f, 0.f}; };
+        auto pl_land = [&](int s, const f32x4& pv) {
+            if (tid >= 512 && tid < 512 + NJ8 * 8) {       // whole waves
+                f32x4 v = pv;
+                if (__any(has_sentinel(v))) {
+                    const float* src = pl_src(s);
+                    unsigned spins = 0;
+                    for (;;) {
+                        v = ld4_agent(src);
+                        if (!__any(has_sentinel(v))) break;
+                        if (spin_expired(spins, a.err, 0xDEAD0016u)) break;
+                    }
+                }
+                const unsigned k = (unsigned)tid - 512u, j = k >> 3, q = k & 7u;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) plv[(q * 4 + e) * NJ8 + j] = v[e];
+            }
         };
         {   // step 0: the context is the first listener frame (las_model.py:198): W_ctx feat_0 = P row 0 = pr[0] of the ts == 0 lanes
             unsigned rv0[4];
@@ -1084,6 +1164,8 @@ struct AttnPreRole {
             }
             lds_barrier();
             PS_STAMP(1, s, 3);
+            f32x4 pv = zero;
+            if (GREEDY) pl_issue(s, pv);         // (published ~0.4 us after h1_s: issued now, the first read usually finds them complete)
             // ---- softmax over ALL frames (no mask, reference las_model.py:292), statistics redundantly per wave
             float mx = -INFINITY;
 #pragma unroll
@@ -1098,8 +1180,47 @@ struct AttnPreRole {
                 as[tid] = w;
                 if (part_id == 0) *at_bytes(a.att + ((size_t)s * B + b) * Tp, opaque(4u * (unsigned)tid)) = w;
             }
+            if (GREEDY) pl_land(s, pv);          // (visible to every wave behind the barrier)
             lds_barrier();
             PS_STAMP(1, s, 4);
+            f32x4 wy = zero;
+            int ysym = 0;
+            float lval = 0.f, lmax = 0.f;
+            if (GREEDY) {
+                // ---- character distribution of step s: logit[v] = b_c[v] + sum_tiles PL[v] + sum_t a_t Q[v][t]; 32 lanes per symbol.  It comes
+                // BEFORE the weighted sum of P: the fetch of the symbol's W_y column, the one dependent load of this mode, then runs under it
+                {
+                    const int v = tid >> 5, l = tid & 31;
+                    float acc = 0.f;
+#pragma unroll
+                    for (int i = 0; i < (MAX_TP + 31) / 32; ++i) {
+                        const int t = l + 32 * i;
+                        if (MAX_TP % 32 == 0 || t < MAX_TP) acc = fmaf(as[t], qt[v * MAX_TP + t], acc);
+                    }
+#pragma unroll
+                    for (int i = 0; i < NJ8 / 32; ++i) acc += plv[v * NJ8 + l + 32 * i];
+                    acc = gsum<16>(acc);                                  // row sums: the two 16-lane rows of a symbol meet as scalars
+                    const float s0 = lane_f(acc, 0) + lane_f(acc, 16), s1 = lane_f(acc, 32) + lane_f(acc, 48);
+                    if (l == 0) lgl[v] = v < a.V ? (lane < 32 ? s0 : s1) + bcv : -INFINITY;
+                }
+                lds_barrier();
+                // every wave: arg-max (first maximal index, as torch.argmax / torch.max do) from the 32 logits: DPP row reductions, the two
+                // rows of 16 meet as scalars (no LDS round trips on the chain)
+                lval = lgl[lane & 31];
+                float m = lval;
+                m = fmaxf(m, dpp_f(m, 0)); m = fmaxf(m, dpp_f(m, 1)); m = fmaxf(m, dpp_f(m, 2)); m = fmaxf(m, dpp_f(m, 3));
+                m = fmaxf(lane_f(m, 0), lane_f(m, 16));
+                int best = lval == m ? (lane & 31) : 64;
+                {
+                    float bf = __builtin_bit_cast(float, best);               // (non-negative ints order like their float bit patterns)
+                    bf = fminf(bf, dpp_f(bf, 0)); bf = fminf(bf, dpp_f(bf, 1)); bf = fminf(bf, dpp_f(bf, 2)); bf = fminf(bf, dpp_f(bf, 3));
+                    best = min(__builtin_amdgcn_readlane(__builtin_bit_cast(int, bf), 0), __builtin_amdgcn_readlane(__builtin_bit_cast(int, bf), 16));
+                }
+                ysym = best;
+                lmax = m;
+                if (s + 1 < U && tid < CG)        // the symbol's W_y entries of this lane's four gates (permuted column order)
+                    wy = ld4p(at_bytes(a.wyT + (size_t)ysym * (4 * HS), opaque(4u * (unsigned)(col0 + tid * 4))));
+            }
             // ---- sum_t a_t P_t over this workgroup's gate columns; the TS time slices of a column group are adjacent lanes
             {
                 f32x4 acc = zero;
@@ -1130,19 +1251,29 @@ struct AttnPreRole {
                 r0_land(s + 1, rv);
                 lds_barrier();
                 PS_STAMP(2, s + 1, 0);
-                bottom_cell(s + 1);
+                bottom_cell(s + 1, wy);
+            }
+            if (GREEDY && part_id == 0 && tid < 32) {
+                // outputs of step s (off the chain): log-probabilities, the arg-max, the one-hot row fed to step s+1
+                float se = tid < a.V ? expf(lval - lmax) : 0.f;
+                se = gsum<16>(se);
+                se += __shfl_xor(se, 16);
+                const float lp = lval - (lmax + logf(se));
+                if (tid < a.V) *at_bytes(a.logp, opaque(4u * (unsigned)((s * B + b) * a.V + tid))) = lp;
+                if (tid == 0 && a.argmax_out) *at_bytes(a.argmax_out, opaque(4u * (unsigned)(s * B + b))) = ysym;
+                if (a.y_all && tid < a.Vp) *at_bytes(a.y_all, opaque(4u * (unsigned)(((s + 1) * B + b) * a.Vp + tid))) = tid == ysym ? 1.f : 0.f;
             }
             PS_STAMP(1, s, 5);
         }
     }
 };
 
-template <int HS, int WS>
+template <int HS, int WS, bool GREEDY>
 __global__ __launch_bounds__(PS_THREADS) void speller_persist_fwd_pre_kernel(PersistArgs a) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     constexpr int NC = HS / 4;
-    if ((int)blockIdx.x >= NC) AttnPreRole<HS, WS>::run(a, smem, blockIdx.x - NC);
-    else CellPreRole<HS>::run(a, smem);
+    if ((int)blockIdx.x >= NC) AttnPreRole<HS, WS, GREEDY>::run(a, smem, blockIdx.x - NC);
+    else CellPreRole<HS, GREEDY>::run(a, smem);
 }
 
 template <int HS, int SPLIT, bool GREEDY>
@@ -1204,20 +1335,25 @@ bool speller_persist_pre_shape(int B, int Tp, int Hs, int D, int M, int V, int L
     if (B < 1 || B > 32 || ((V + 15) & ~15) > 32) return false;      // the label half is a 32-wide dot product from LDS
     return speller_persist_pre_ws(B, Tp, Hs, -1) != 0;
 }
-template <int HS, int WS>
+template <int HS, int WS, bool GREEDY = false>
 static size_t persist_fwd_pre_smem(int Tp) {
-    return sizeof(float) * (size_t)std::max(CellPreRole<HS>::LDS_FLOATS, AttnPreRole<HS, WS>::lds_floats(Tp));
+    return sizeof(float) * (size_t)std::max(CellPreRole<HS, GREEDY>::LDS_FLOATS, AttnPreRole<HS, WS, GREEDY>::lds_floats(Tp));
 }
-template <int HS, int WS>
+template <int HS, int WS, bool GREEDY = false>
 static bool persist_fwd_pre_fits(int Tp, int grid) {
-    const size_t smem = persist_fwd_pre_smem<HS, WS>(Tp);
+    const size_t smem = persist_fwd_pre_smem<HS, WS, GREEDY>(Tp);
     if (smem > 160 * 1024) return false;
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&speller_persist_fwd_pre_kernel<HS, WS>), hipFuncAttributeMaxDynamicSharedMemorySize,
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&speller_persist_fwd_pre_kernel<HS, WS, GREEDY>), hipFuncAttributeMaxDynamicSharedMemorySize,
                             (int)smem) != hipSuccess)
         return false;
-    return persistent_launch_fits(speller_persist_fwd_pre_kernel<HS, WS>, PS_THREADS, smem, grid);
+    return persistent_launch_fits(speller_persist_fwd_pre_kernel<HS, WS, GREEDY>, PS_THREADS, smem, grid);
 }
-static bool persist_fwd_pre_fits_rt(int Hs, int ws, int Tp, int grid) {
+static bool persist_fwd_pre_fits_rt(int Hs, int ws, int Tp, int grid, bool greedy = false) {
+    if (greedy) {      // free-running instantiations: 4 or 8 attention workgroups per utterance (T' <= 224; beyond that Q^T does not fit the LDS)
+        if (ws == 16) return false;
+        if (Hs == 512) return ws == 4 ? persist_fwd_pre_fits<512, 4, true>(Tp, grid) : persist_fwd_pre_fits<512, 8, true>(Tp, grid);
+        return ws == 4 ? persist_fwd_pre_fits<256, 4, true>(Tp, grid) : persist_fwd_pre_fits<256, 8, true>(Tp, grid);
+    }
     if (Hs == 512) return ws == 4 ? persist_fwd_pre_fits<512, 4>(Tp, grid) : ws == 8 ? persist_fwd_pre_fits<512, 8>(Tp, grid) : persist_fwd_pre_fits<512, 16>(Tp, grid);
     return ws == 4 ? persist_fwd_pre_fits<256, 4>(Tp, grid) : persist_fwd_pre_fits<256, 8>(Tp, grid);
 }
@@ -1233,18 +1369,31 @@ bool speller_persist_pre_eligible(int B, int Tp, int Hs, int D, int M, int V, in
     if (ws == 0) return false;
     return persist_fwd_pre_fits_rt(Hs, ws, Tp, Hs / 4 + ws * B);
 }
+// ... and its free-running (decode_mode 1: fed-back arg-max) form: the same structure with the character distribution inside the attention
+// workgroups (AttnPreRole<.., GREEDY>); forward only — a stashing forward (free-running training step) keeps the classic kernels, whose
+// backward needs the context the PRE forward never forms on the chain
+bool speller_persist_pre_greedy_eligible(int B, int Tp, int Hs, int D, int M, int V, int L, int heads, int use_mlp) {
+    if (opt_get(OPT_SPELLER_PRE) == 0 || opt_get(OPT_SPELLER_PRE_GREEDY) == 0) return false;
+    if (!speller_persist_pre_shape(B, Tp, Hs, D, M, V, L, heads, use_mlp) || V > 32) return false;
+    int cus = 0, dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess)
+        return false;
+    const int ws = speller_persist_pre_ws(B, Tp, Hs, cus);
+    if (ws == 0) return false;
+    return persist_fwd_pre_fits_rt(Hs, ws, Tp, Hs / 4 + ws * B, true);
+}
 
-template <int HS, int WS>
+template <int HS, int WS, bool GREEDY = false>
 static int launch_persist_fwd_pre(const PersistArgs& a, int grid, hipStream_t stream) {
-    const size_t smem = persist_fwd_pre_smem<HS, WS>(a.Tp);
-    if (!persist_fwd_pre_fits<HS, WS>(a.Tp, grid))
+    const size_t smem = persist_fwd_pre_smem<HS, WS, GREEDY>(a.Tp);
+    if (!persist_fwd_pre_fits<HS, WS, GREEDY>(a.Tp, grid))
         return fail(LAS_ERR_UNSUPPORTED, "persistent decode kernel: %s%ld workgroups cannot all be resident", "", (long)grid);
     {
         KernelTimer timer(TIMED_DECODE_FWD, stream);
-        hipLaunchKernelGGL((speller_persist_fwd_pre_kernel<HS, WS>), dim3(grid), dim3(PS_THREADS), smem, stream, a);
+        hipLaunchKernelGGL((speller_persist_fwd_pre_kernel<HS, WS, GREEDY>), dim3(grid), dim3(PS_THREADS), smem, stream, a);
     }
     LAS_LAUNCH_CHECK();
-    path_note(PATH_DECODE_FWD, "persist_pre");
+    path_note(PATH_DECODE_FWD, GREEDY ? "persist_pre_greedy" : "persist_pre");
     return LAS_OK;
 }
 
@@ -1282,9 +1431,9 @@ int speller_persist_fwd_fill(const PersistFwd& p, hipStream_t stream) {
 }
 
 int speller_persist_fwd(const PersistFwd& p, hipStream_t stream) {
-    LAS_REQUIRE(speller_persist_eligible(p.B, p.Tp, p.Hs, p.Hs, PS_M, p.V, 2, 1, 1, p.mode != 0), "persistent speller shape");
+    LAS_REQUIRE(p.pctx != nullptr || speller_persist_eligible(p.B, p.Tp, p.Hs, p.Hs, PS_M, p.V, 2, 1, 1, p.mode != 0), "persistent speller shape");
     LAS_REQUIRE(p.mode >= 0 && p.mode <= 2, "persistent speller mode");
-    LAS_REQUIRE(p.mode == 0 || (p.w_c && p.b_c && p.logp && p.lgx), "free-running decode needs the character distribution");
+    LAS_REQUIRE(p.mode == 0 || (p.w_c && p.b_c && p.logp && (p.lgx || p.pctx)), "free-running decode needs the character distribution");
     PersistArgs a;
     a.mode = p.mode; a.V = p.V; a.w_c = p.w_c; a.b_c = p.b_c; a.logp = p.logp; a.argmax_out = p.argmax; a.lgx = p.lgx;
     a.w0p = p.w0p; a.ldw0 = p.Vp + p.Hs; a.Vp = p.Vp;
@@ -1298,16 +1447,23 @@ int speller_persist_fwd(const PersistFwd& p, hipStream_t stream) {
     a.split = persist_split(p.B, p.Tp, p.Hs, p.V, p.mode != 0);
     a.trace = g_persist_trace;
     a.pctx = p.pctx; a.gx = p.gx; a.r0x = p.r0x; a.yw = p.yw;
+    a.qct = p.qct; a.wyT = p.wyT; a.plx = p.plx;
     LAS_REQUIRE(p.err != nullptr, "the persistent speller needs the device error word");
     if (p.pctx) {      // pre-multiplied context variant (the caller checked speller_persist_pre_eligible)
         int cus = 0, dev = 0;
         LAS_HIP_CHECK(hipGetDevice(&dev));
         LAS_HIP_CHECK(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
         const int ws = speller_persist_pre_ws(p.B, p.Tp, p.Hs, cus);
-        LAS_REQUIRE(p.mode == 0 && p.gx && p.r0x && p.yw && ws != 0 && speller_persist_pre_shape(p.B, p.Tp, p.Hs, p.Hs, PS_M, p.V, 2, 1, 1), "persistent speller (pre) shape");
+        LAS_REQUIRE((p.mode == 0 || p.mode == 1) && p.gx && p.r0x && p.yw && ws != 0 && speller_persist_pre_shape(p.B, p.Tp, p.Hs, p.Hs, PS_M, p.V, 2, 1, 1), "persistent speller (pre) shape");
         a.split = ws;
         if (!p.prefilled) LAS_TRY(speller_persist_fwd_fill(p, stream));
         const int grid = p.Hs / 4 + ws * p.B;
+        if (p.mode == 1) {      // free-running: the character distribution inside the attention workgroups
+            LAS_REQUIRE(p.qct && p.wyT && p.plx && p.logp && p.w_c && p.b_c && ws != 16, "persistent speller (pre, free-running) buffers");
+            LAS_HIP_CHECK(hipMemsetAsync(p.plx, 0xFF, sizeof(float) * (size_t)p.U * (p.Hs / 4) * 512, stream));
+            if (p.Hs == 512) return ws == 4 ? launch_persist_fwd_pre<512, 4, true>(a, grid, stream) : launch_persist_fwd_pre<512, 8, true>(a, grid, stream);
+            return ws == 4 ? launch_persist_fwd_pre<256, 4, true>(a, grid, stream) : launch_persist_fwd_pre<256, 8, true>(a, grid, stream);
+        }
         if (p.Hs == 512)
             return ws == 4 ? launch_persist_fwd_pre<512, 4>(a, grid, stream)
                            : ws == 8 ? launch_persist_fwd_pre<512, 8>(a, grid, stream) : launch_persist_fwd_pre<512, 16>(a, grid, stream);

@@ -120,14 +120,16 @@ def _require_lstm(rnn_unit):
 # --------------------------------------------------------------------------------------------------
 class _PBLSTMFn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, force_generic, x, w_ih_f, w_hh_f, b_ih_f, b_hh_f, w_ih_r, w_hh_r, b_ih_r, b_hh_r):
+    def forward(ctx, mode, x, w_ih_f, w_hh_f, b_ih_f, b_hh_f, w_ih_r, w_hh_r, b_ih_r, b_hh_r):
+        force_generic, grad_on = mode      # grad_on: the CALLER's grad mode (inside Function.forward it is always off)
         x = _f32c(x)
         B, T_in, D_in = x.shape
         H = w_hh_f.shape[1]
         if T_in % 2 != 0:
             raise RuntimeError(f"pBLSTM needs an even number of frames, got {T_in} (reference las_model.py:86-87)")
         ws = [_f32c(w) for w in (w_ih_f, w_hh_f, b_ih_f, b_hh_f, w_ih_r, w_hh_r, b_ih_r, b_hh_r)]
-        stash = any(ctx.needs_input_grad)      # grad mode is off inside Function.forward; this is the reliable signal
+        # needs_input_grad stays True under torch.no_grad() (it mirrors requires_grad): no backward can follow then, so nothing is stashed
+        stash = grad_on and any(ctx.needs_input_grad)
         flags = _flags(stash, force_generic)
         L = lib()
         out = torch.empty(B, T_in // 2, 2 * H, device=x.device, dtype=torch.float32)
@@ -179,7 +181,7 @@ class pBLSTMLayer(nn.Module):
         p = self.BLSTM
         if input_x.is_cuda:
             _cabi.poll_device_errors(input_x.device)
-        out = _PBLSTMFn.apply(self.force_generic, input_x, p.weight_ih_l0, p.weight_hh_l0, p.bias_ih_l0, p.bias_hh_l0,
+        out = _PBLSTMFn.apply((self.force_generic, torch.is_grad_enabled()), input_x, p.weight_ih_l0, p.weight_hh_l0, p.bias_ih_l0, p.bias_hh_l0,
                               p.weight_ih_l0_reverse, p.weight_hh_l0_reverse, p.bias_ih_l0_reverse, p.bias_hh_l0_reverse)
         return out, None
 
@@ -441,7 +443,7 @@ def _speller_grads(grads, L, use_mlp, heads):
 class _SpellerFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, cfg, feat, labels, noise, *params):
-        (U, teacher_forced, decode_mode, L, use_mlp, relu, M, V, heads, force_generic, allow_direct) = cfg
+        (U, teacher_forced, decode_mode, L, use_mlp, relu, M, V, heads, force_generic, allow_direct, grad_on) = cfg
         feat = _f32c(feat)
         B, Tp, D = feat.shape
         direct = _direct_targets(params) if allow_direct else None      # a sliced batch uses every parameter once per slice
@@ -468,7 +470,9 @@ class _SpellerFn(torch.autograd.Function):
         logp = torch.empty(U, B, V, device=dev, dtype=torch.float32)
         att = torch.empty(U, heads, B, Tp, device=dev, dtype=torch.float32)
         reserve = torch.empty(Lh.las_speller_reserve_floats(d, U), device=dev, dtype=torch.float32)
-        stash = any(ctx.needs_input_grad)      # no backward will follow otherwise (validation / inference): skip the backward-only products
+        # no backward will follow otherwise (validation / inference under torch.no_grad(): needs_input_grad alone stays True there): skip the
+        # backward-only products — and a free-running decode then takes the forward-only kernel (speller_persist_pre_greedy_eligible)
+        stash = grad_on and any(ctx.needs_input_grad)
         if noise is not None:
             noise = _f32c(noise)
             if tuple(noise.shape) != (U, B, V):
@@ -488,7 +492,7 @@ class _SpellerFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, dlogp, _datt):
         feat, keys, logp, att, reserve, *params = ctx.saved_tensors
-        (U, teacher_forced, decode_mode, L, use_mlp, relu, M, V, heads, force_generic, _allow_direct) = ctx.cfg
+        (U, teacher_forced, decode_mode, L, use_mlp, relu, M, V, heads, force_generic, _allow_direct, _grad_on) = ctx.cfg
         B, Tp, D, Hs = ctx.dims
         dev = feat.device
         if dlogp is None:                      # (set_materialize_grads(False): only the attention output was used downstream)
@@ -577,11 +581,12 @@ class Speller(nn.Module):
                 noise = torch.stack([torch.empty(B, self.label_dim, device=listener_feature.device).exponential_(1)
                                      for _ in range(int(steps))])
         params = self._params()
+        grad_on = torch.is_grad_enabled()
         labels = ground_truth if teacher_force else None
         B = listener_feature.shape[0]
         nb = self._decode_slice(listener_feature, params, cfg) if listener_feature.is_cuda else 0
         if nb <= 0 or B <= nb:
-            return _SpellerFn.apply(cfg + (True,), listener_feature, labels, noise, *params)
+            return _SpellerFn.apply(cfg + (True, grad_on), listener_feature, labels, noise, *params)
         # Batches beyond what one launch of the decode kernels takes: slices of nb utterances, each decoded in ONE launch (the per-step
         # kernels would need U launch chains for the whole batch: P at B=128 26 ms -> see DESIGN.md 4.3).  The utterances of a batch
         # are independent in the Speller (reference las_model.py:205-236), so this is the same arithmetic per utterance; parameter
@@ -589,7 +594,7 @@ class Speller(nn.Module):
         feats = listener_feature.split(nb, 0)
         labs = labels.split(nb, 0) if labels is not None else [None] * len(feats)
         noises = noise.split(nb, 1) if noise is not None else [None] * len(feats)
-        outs = [_SpellerFn.apply(cfg + (False,), f, l, n, *params) for f, l, n in zip(feats, labs, noises)]
+        outs = [_SpellerFn.apply(cfg + (False, grad_on), f, l, n, *params) for f, l, n in zip(feats, labs, noises)]
         return torch.cat([o[0] for o in outs], 1), torch.cat([o[1] for o in outs], 2)
 
     def _decode_slice(self, feat, params, cfg):

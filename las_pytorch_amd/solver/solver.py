@@ -227,7 +227,9 @@ def batch_iterator(batch_data, batch_label, las_model, optimizer, tf_rate, is_tr
     coin_state = np.random.get_state() if (is_training and not _retry) else None
     coin_token = dp.sync_coin() if (is_training and 0.0 < float(tf_rate) < 1.0) else None
 
-    with _cabi.polls_deferred():              # a hand-off timeout is dealt with below, for the step as a whole
+    # validation (is_training False: the reference's train.py:149-169) has no backward: run it without a graph, so that the kernels keep no
+    # stash and the free-running decode takes its forward-only form (the reference keeps autograd on there, to no effect on the results)
+    with _cabi.polls_deferred(), torch.set_grad_enabled(bool(is_training) and torch.is_grad_enabled()):      # a hand-off timeout is dealt with below, for the step as a whole
         step_logp, _ = las_model(batch_data=batch_data, batch_label=batch_label, teacher_force_rate=tf_rate, is_training=is_training)
     dp.restore_coin(coin_token)
     if len(step_logp) < steps:
