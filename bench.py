@@ -326,6 +326,24 @@ def roofline_speller(step, c, B, T, U, iters=10):
     return out
 
 
+def greedy_decode_block(las, x, U, iters=10):
+    """The validation path (reference train.py:149-169: free-running decode_mode 1 for max_label_len steps, no backward): the Speller's greedy
+    decode of the headline batch alone, under torch.no_grad(), whole ``Speller.forward`` calls including their pre-products."""
+    from las_pytorch_amd import _cabi
+    with torch.no_grad():
+        feat = las.listener(x)
+        for _ in range(3):
+            las.speller(feat, ground_truth=None, teacher_force_rate=0.0)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(iters):
+            las.speller(feat, ground_truth=None, teacher_force_rate=0.0)
+        e1.record(); torch.cuda.synchronize()
+    ms = e0.elapsed_time(e1) / iters
+    return {"workload": f"greedy (decode_mode 1) decode of the headline batch, {U} steps, no backward", "ms_per_call": round(ms, 3),
+            "us_per_decode_step": round(ms * 1e3 / U, 2), "kernel_path": _cabi.last_path(_cabi.PATH_DECODE_FWD)}
+
+
 def secondary_long(device, U, B=8, T=3000, steps=10, warmup=3, with_roofline=True):
     """BASELINE.json configs[4] beside the headline: the paper-size model on a batch of 8 thirty-second utterances (T = 3000 frames,
     T' = 375), the same full training step.  The Listener recurrences are 2 625 dependent steps each way on 64 of the 256 CUs
@@ -697,6 +715,7 @@ def main():
         if world == 1 and not args.no_cpu_baseline:
             res["cpu_baseline"] = cpu_baseline(cfg_name, B, T, U, train)
         if world == 1 and args.workload == "P_train" and not args.no_secondary:
+            res["config"]["greedy_decode"] = greedy_decode_block(las, x, U)
             # BASELINE.json configs[1] (small 128/256 model, forward only) measured beside the headline for reference
             del las
             torch.cuda.empty_cache()

@@ -589,6 +589,42 @@ def test_persistent_free_running_decode_matches_stepwise(cfg_name, B, Tp, U, dec
     _check_err()
 
 
+@pytest.mark.parametrize("cfg_name,B,Tp,U", [("P", 32, 100, 24), ("P", 7, 57, 9), ("P", 16, 200, 6), ("S", 32, 200, 12), ("S", 20, 100, 5),
+                                             ("P", 40, 100, 5), ("P", 32, 112, 3)])
+def test_free_running_decode_without_backward_runs_the_pre_kernel(cfg_name, B, Tp, U):
+    """Validation-style greedy decode (decode_mode 1 under torch.no_grad(): reference train.py:149-169, las_model.py:223-227) takes the
+    free-running form of the pre-multiplied-context kernel — character distribution inside the attention workgroups, 4 and 8 of them per
+    utterance, partial batches, a sliced batch (40), the largest T' of the 4-workgroup form (112) — and must give the per-step kernels'
+    log-probabilities, attention weights and arg-max sequence.  With autograd on (a free-running TRAINING step) the classic kernel runs."""
+    from las_pytorch_amd import Speller, _cabi, synth
+    c = synth.CONFIGS[cfg_name]
+    torch.manual_seed(8)
+    sp = Speller(vocab_size=c["V"], hidden_size=c["Hs"], rnn_unit="LSTM", num_layers=c["Ls"], max_label_len=U,
+                 use_mlp_in_attention=True, mlp_dim_in_attention=c["M"], mlp_activate_in_attention="relu",
+                 listener_hidden_size=c["H"], multi_head=1, decode_mode=1).cuda()
+    feat = torch.randn(B, Tp, 2 * c["H"], device="cuda") * 0.5
+    res = []
+    for force in (False, True):
+        sp.force_generic = force
+        try:
+            with torch.no_grad():
+                preds, att = sp(feat, ground_truth=None, teacher_force_rate=0.0)
+            torch.cuda.synchronize()
+            if not force:
+                assert _cabi.last_path(_cabi.PATH_DECODE_FWD) == "persist_pre_greedy", _cabi.last_path(_cabi.PATH_DECODE_FWD)
+            res.append((torch.stack(preds).cpu().numpy(), torch.stack([a[0] for a in att]).cpu().numpy()))
+        finally:
+            sp.force_generic = False
+    assert (res[0][0].argmax(-1) == res[1][0].argmax(-1)).all(), "arg-max sequences differ"
+    assert_close(res[0][0], res[1][0], "pre free-running vs stepwise logp")
+    assert_close(res[0][1], res[1][1], "pre free-running vs stepwise att", atol=1e-6)
+    preds, _ = sp(feat.clone().requires_grad_(True), ground_truth=None, teacher_force_rate=0.0)      # autograd on: a backward may follow
+    torch.cuda.synchronize()
+    assert _cabi.last_path(_cabi.PATH_DECODE_FWD) == "persist"
+    assert_close(torch.stack(preds).detach().cpu().numpy(), res[1][0], "classic free-running vs stepwise logp")
+    _check_err()
+
+
 @pytest.mark.parametrize("name", ["tiny_mode2", "S_mode2"])
 def test_decode_mode2_golden(name):
     """decode_mode 2 (reference las_model.py:229-234) on the device from the reference's own Exp(1) draws: the sampled
