@@ -42,8 +42,10 @@ extern "C" {
 /* flags */
 #define LAS_FLAG_STASH          1   /* keep what the backward pass needs (training) */
 #define LAS_FLAG_FORCE_GENERIC  2   /* use the generic kernels (L2-streaming recurrence, per-step speller launches): A/B tests */
-#define LAS_FLAG_TEACHER_FORCED 4   /* las_speller_bwd only: the las_speller_fwd call that filled `reserve` ran teacher-forced with
-                                       the same flags / err_word.  Lets the backward use what that forward left in the reserve
+#define LAS_FLAG_TEACHER_FORCED 4   /* las_speller_bwd only: the las_speller_fwd call that filled `reserve` ran teacher-forced — or free-running
+                                       with decode_mode 1, whose one-hot feedback carries no gradient: its backward is the teacher-forced
+                                       one over the emitted symbols — with the same flags / err_word.  Lets the backward use what that
+                                       forward left in the reserve
                                        (feat.W_ctx^T and its per-step attention-weighted sums); without it the backward
                                        recomputes nothing and runs its classic path — always correct, about 0.4 ms slower. */
 

@@ -441,12 +441,15 @@ int las_speller_fwd(const las_speller_desc* d, const float* feat, const float* k
     // or the occupancy calculator: P = feat . W_ctx^T and the per-step sums gx_s = sum_t a_t P_t are always there, so that
     // las_speller_bwd (LAS_FLAG_TEACHER_FORCED) can rely on them whichever forward variant actually ran.
     // (Only a stashing forward has a backward: without LAS_FLAG_STASH the two GEMMs are skipped unless the PRE kernel itself needs P.)
-    const bool pre_stash = teacher_forced && lay.pre && ((flags & LAS_FLAG_STASH) || pre);
-    // ... and its free-running form (decode_mode 1 without a backward pass: the reference's validation decode, train.py:149-169): the character
-    // distribution moves into the attention workgroups, one launch at ~8 instead of ~13 us per step
-    const bool preg = !teacher_forced && decode_mode == 1 && !(flags & LAS_FLAG_STASH) && lay.pre && persist_on && err_word &&
+    // ... and its free-running form (decode_mode 1: the reference's validation decode, train.py:149-169, and the free-running training steps of a
+    // teacher-forcing schedule below 1): the character distribution moves into the attention workgroups, one launch at ~8 instead of ~13 us per
+    // step.  A one-hot fed-back symbol carries no gradient, so the backward of such a pass IS the teacher-forced backward over the emitted
+    // symbols: a stashing forward leaves the same P / gx in the reserve (tf_like) and las_speller_bwd takes its PRE path for it too.
+    const bool tf_like = teacher_forced || decode_mode == 1;
+    const bool preg = !teacher_forced && decode_mode == 1 && lay.pre && persist_on && err_word &&
                       !(flags & LAS_FLAG_FORCE_GENERIC) && d->relu <= LAS_ACT_RELU && logp &&
                       speller_persist_pre_greedy_eligible(B, Tp, Hs, D, d->M, V, L, d->multi_head, d->use_mlp);
+    const bool pre_stash = tf_like && lay.pre && ((flags & LAS_FLAG_STASH) || pre || preg);
     LAS_TRY(speller_prologue(d->w_ih[0], w0p, Hs, V, Vp, (pre_stash || preg) ? reserve + lay.wperm : nullptr, (pre || preg) ? reserve + lay.wyperm : nullptr,
                              (pre || preg) ? reserve + lay.bperm : nullptr, d->b_ih[0], d->b_hh[0],
                              teacher_forced ? (const long long*)labels_onehot : nullptr, y_all, B, U, U_lab, feat, (long)Tp * D, ctx_all, D, stream));
@@ -470,7 +473,8 @@ int las_speller_fwd(const las_speller_desc* d, const float* feat, const float* k
         LAS_TRY(gemm_f32(g, stream));
     }
     bool persist_ran = persist || preg;
-    bool pre_ran = false;
+    bool pre_ran = false;           // a PRE kernel ran AND the contexts of every step are wanted: they are recovered by one GEMM below
+    bool gx_written = false;        // ... a PRE kernel ran: the per-step sums gx are in the reserve already
     if (persist || preg) {
         PersistFwd p;
         p.prefilled = side_fill;
@@ -513,7 +517,8 @@ int las_speller_fwd(const las_speller_desc* d, const float* feat, const float* k
         const int rc = speller_persist_fwd(p, stream);
         if (rc == LAS_ERR_UNSUPPORTED) persist_ran = false;      // residency check failed: the per-step kernels below run instead
         else LAS_TRY(rc);
-        pre_ran = persist_ran && pre;
+        gx_written = persist_ran && (pre || preg);
+        pre_ran = persist_ran && (pre || (preg && (flags & LAS_FLAG_STASH)));      // (free-running: only a backward pass reads the contexts)
         if (preg && !persist_ran && !persist) {      // (residency check failed and the classic kernel does not take this shape either)
             path_note(PATH_DECODE_FWD, "stepwise");
         } else if (preg && !persist_ran) {           // fall back to the classic free-running kernel
@@ -521,6 +526,7 @@ int las_speller_fwd(const las_speller_desc* d, const float* feat, const float* k
             q.pctx = nullptr; q.gx = nullptr; q.r0x = nullptr; q.yw = nullptr; q.qct = nullptr; q.wyT = nullptr; q.plx = nullptr; q.prefilled = false;
             const int rc2 = speller_persist_fwd(q, stream);
             if (rc2 != LAS_ERR_UNSUPPORTED) { LAS_TRY(rc2); persist_ran = true; }
+            pre_ran = false; gx_written = false;     // (the classic kernel wrote the contexts itself; gx is recovered below)
         }
     }
     if (pre_ran) {   // contexts of every step: ctx_all[1+s][b] = att[s][b] . feat[b], one batched GEMM over the utterances
@@ -608,7 +614,7 @@ int las_speller_fwd(const las_speller_desc* d, const float* feat, const float* k
             }
         }
     }
-    if (pre_stash && !pre_ran) {   // the per-step / classic persistent kernels ran: gx_s[b] = att_s[b] . P[b], one batched GEMM
+    if (pre_stash && !gx_written && (flags & LAS_FLAG_STASH)) {   // the per-step / classic persistent kernels ran: gx_s[b] = att_s[b] . P[b], one batched GEMM
         GemmDesc g;
         g.A = att; g.lda = (long)B * Tp; g.a_kc = true; g.sA = Tp;
         g.B = reserve + lay.pctx; g.ldb = 4 * Hs; g.b_kc = false; g.sB = (long)Tp * 4 * Hs;

@@ -520,7 +520,8 @@ class _SpellerFn(torch.autograd.Function):
         zeroed = FLAG_GRADS_ZEROED if (ctx.direct and _claim_prezeroed(ctx.direct_params)) else 0
         check(Lh.las_speller_bwd(d, ptr(feat), ptr(keys), ptr(logp), ptr(att), ptr(dlogp), U, mode0, ptr(reserve),
                                  ptr(work), g, ptr(_cabi.err_word(dev)),
-                                 _flags(True, force_generic) | (FLAG_TEACHER_FORCED if teacher_forced else 0) | zeroed, stream_ptr()))
+                                 _flags(True, force_generic) | (FLAG_TEACHER_FORCED if (teacher_forced or decode_mode == 1) else 0) | zeroed,
+                                 stream_ptr()))
         return (None, dfeat, None, None, *([None] * len(grads) if ctx.direct else grads))
 
 

@@ -595,7 +595,8 @@ def test_free_running_decode_without_backward_runs_the_pre_kernel(cfg_name, B, T
     """Validation-style greedy decode (decode_mode 1 under torch.no_grad(): reference train.py:149-169, las_model.py:223-227) takes the
     free-running form of the pre-multiplied-context kernel — character distribution inside the attention workgroups, 4 and 8 of them per
     utterance, partial batches, a sliced batch (40), the largest T' of the 4-workgroup form (112) — and must give the per-step kernels'
-    log-probabilities, attention weights and arg-max sequence.  With autograd on (a free-running TRAINING step) the classic kernel runs."""
+    log-probabilities, attention weights and arg-max sequence.  With autograd on (a free-running TRAINING step) the same kernel runs and stashes
+    for the teacher-forced-style backward (gradients: test_persistent_free_running_decode_matches_stepwise)."""
     from las_pytorch_amd import Speller, _cabi, synth
     c = synth.CONFIGS[cfg_name]
     torch.manual_seed(8)
@@ -620,8 +621,8 @@ def test_free_running_decode_without_backward_runs_the_pre_kernel(cfg_name, B, T
     assert_close(res[0][1], res[1][1], "pre free-running vs stepwise att", atol=1e-6)
     preds, _ = sp(feat.clone().requires_grad_(True), ground_truth=None, teacher_force_rate=0.0)      # autograd on: a backward may follow
     torch.cuda.synchronize()
-    assert _cabi.last_path(_cabi.PATH_DECODE_FWD) == "persist"
-    assert_close(torch.stack(preds).detach().cpu().numpy(), res[1][0], "classic free-running vs stepwise logp")
+    assert _cabi.last_path(_cabi.PATH_DECODE_FWD) == "persist_pre_greedy"
+    assert_close(torch.stack(preds).detach().cpu().numpy(), res[1][0], "stashing free-running vs stepwise logp")
     _check_err()
 
 
