@@ -184,6 +184,43 @@ def test_forward_backward_vs_oracle(cfg_name, B, T, U, scale):
     _check_err()
 
 
+def test_free_running_training_step_vs_oracle():
+    """A free-running TRAINING step (the coin of a teacher-forcing schedule below 1 came up 'free': decode_mode 1 feedback for max_label_len
+    steps, then loss and backward; reference las_model.py:189,205-206,223-227) at the benchmark's T against the CPU oracle: log-probabilities,
+    arg-max sequence, loss and all 38 gradients.  Forward on the free-running PRE kernel, backward on the teacher-forced PRE kernel over the
+    emitted symbols (paths asserted).  Weights of the "_s" fixtures (U(-0.2, 0.2), seed 43: greedy margin 7.5e-4, ~6 symbol changes)."""
+    from las_pytorch_amd import synth
+    from oracle import las_oracle as O
+    c = synth.CONFIGS["P"]
+    B, T, U = 32, 800, 12
+    sd_np = synth.make_state_dict(synth.config_shapes("P"), seed=43, scale=0.2)
+    x = synth.make_inputs(B, T, c["F"], seed=43)
+    idx, lens = synth.make_labels(B, U, c["V"], seed=43, ragged=True)
+    onehot = synth.onehot_labels(idx, lens, c["V"])
+    sd = O.to_torch_sd(sd_np, requires_grad=True)
+    lab = torch.from_numpy(onehot)
+    cfg = dict(listener_layers=c["L"], speller_layers=c["Ls"], max_label_len=U, decode_mode=1)
+    preds_o, _ = O.las_forward(torch.from_numpy(x), lab, sd, cfg, teacher_force=False)
+    loss_o, _ = O.solver_step_loss(preds_o, lab, U, 0.1)
+    loss_o.backward()
+    las = build_las(c, sd_np, max_label_len=U)
+    xg, labg = torch.from_numpy(x).cuda(), lab.cuda()
+    preds, _ = las(batch_data=xg, batch_label=labg, teacher_force_rate=0.0, is_training=True)
+    assert _cabi.last_path(_cabi.PATH_DECODE_FWD) == "persist_pre_greedy", _cabi.last_path(_cabi.PATH_DECODE_FWD)
+    logp, logp_o = torch.stack(preds), torch.stack(preds_o).detach()
+    assert (logp.argmax(-1).cpu() == logp_o.argmax(-1)).all(), "free-running arg-max sequence differs from the oracle's"
+    assert_close(logp.detach().cpu().numpy(), logp_o.numpy(), "free_P/logp")
+    loss = _loss_ls(preds, labg, U)
+    loss.backward()
+    torch.cuda.synchronize()
+    assert _cabi.last_path(_cabi.PATH_DECODE_BWD) == "persist_pre", _cabi.last_path(_cabi.PATH_DECODE_BWD)
+    assert abs(loss.item() - loss_o.item()) <= 1e-4 * abs(loss_o.item()) + 1e-6
+    gscale = max(float(sd[k].grad.norm()) for k in sd)
+    for k, p in las.named_parameters():
+        grad_close(p.grad.cpu().numpy(), sd[k].grad.numpy(), f"oracle_free_P_B{B}_T{T}/grad/{k}", rtol=GRAD_RTOL, floor=GRAD_FLOOR, global_scale=gscale)
+    _check_err()
+
+
 def test_listener_batch320_vs_oracle():
     """First-hand check of the B > 256 matrix-pipe recurrence (``rec_fwd_mfma2``: two batches of 16 sequences per group, wave-specialised
     pipeline) and of ``rec_bwd_mfma`` at that batch: the whole paper-size Listener at (B, T) = (320, 800), forward and backward (a fixed

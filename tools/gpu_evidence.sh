@@ -61,3 +61,10 @@ python tools/ubench_gemm_planes.py > $O/gemm_planes.log 2>&1
 python bench.py --steps 1500 --warmup 5 --no-cpu-baseline --no-sweep --no-mfma --no-roofline --no-secondary > $O/soak.json 2> $O/soak.err
 for w in "P_long 8" "S_long 8" "S_train 32" "Y_train 16" "P_fwd 32" "S_fwd 32" "P_train 128"; do set -- $w; python bench.py --workload $1 --batch $2 --steps 10 --warmup 3 --no-cpu-baseline --no-sweep --no-mfma --no-secondary --no-roofline 2>/dev/null | tail -1; done > $O/variants.jsonl
 tail -3 $O/pytest_gpu.log; tail -1 $O/smoke.log; tail -c 300 $O/bench.json
+# summaries are made HERE (the rocprofv3 databases are too large to travel: gpurun merges at most 64 MiB back) and copied next to the logs
+LAS_ROUND=r05 python tools/collect_evidence.py > $O/collect.log 2>&1
+mkdir -p $R/gpurun_out/r05_profiles && cp $R/profiles/r05_* $R/gpurun_out/r05_profiles/ 2>/dev/null
+find $O -name "*.db" -delete
+find $O -name "*.csv" -size +1M -delete
+du -sh $R/gpurun_out
+tail -3 $O/collect.log
