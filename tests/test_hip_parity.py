@@ -663,6 +663,41 @@ def test_free_running_decode_without_backward_runs_the_pre_kernel(cfg_name, B, T
     _check_err()
 
 
+def test_free_running_training_step_at_long_t_mixes_per_step_forward_and_pre_backward():
+    """T' = 375 (BASELINE configs[4]) with decode_mode 1 and a backward pass: the free-running forward has no one-launch kernel at this length
+    (per-step launches), yet it must leave P / gx in the reserve exactly as a teacher-forced forward does, because the backward takes the
+    teacher-forced PRE kernel over the emitted symbols.  Against the all-generic path."""
+    from las_pytorch_amd import Speller, _cabi, synth
+    c = synth.CONFIGS["P"]
+    B, Tp, U = 8, 375, 4
+    torch.manual_seed(9)
+    sp = Speller(vocab_size=c["V"], hidden_size=c["Hs"], rnn_unit="LSTM", num_layers=c["Ls"], max_label_len=U, use_mlp_in_attention=True,
+                 mlp_dim_in_attention=c["M"], mlp_activate_in_attention="relu", listener_hidden_size=c["H"], multi_head=1, decode_mode=1).cuda()
+    feat0 = torch.randn(B, Tp, 2 * c["H"], device="cuda") * 0.5
+    w = torch.randn(U, B, c["V"], device="cuda")
+    res = []
+    for force in (False, True):
+        sp.force_generic = force
+        try:
+            sp.zero_grad(set_to_none=True)
+            feat = feat0.clone().requires_grad_(True)
+            preds, _ = sp(feat, ground_truth=None, teacher_force_rate=0.0)
+            logp = torch.stack(preds)
+            (logp * w).sum().backward()
+            torch.cuda.synchronize()
+            if not force:
+                assert (_cabi.last_path(_cabi.PATH_DECODE_FWD), _cabi.last_path(_cabi.PATH_DECODE_BWD)) == ("stepwise", "persist_pre")
+            out = dict(logp=logp.detach().cpu().numpy(), dfeat=feat.grad.cpu().numpy())
+            out.update({"d" + n: p.grad.cpu().numpy() for n, p in sp.named_parameters() if p.grad is not None})
+            res.append(out)
+        finally:
+            sp.force_generic = False
+    for k in res[0]:
+        scale_k = float(np.abs(res[1][k]).max()) + 1e-30
+        assert_close(res[0][k], res[1][k], f"long-T free-running {k}", rtol=1e-3, atol=1e-5 * max(1.0, scale_k))
+    _check_err()
+
+
 @pytest.mark.parametrize("name", ["tiny_mode2", "S_mode2"])
 def test_decode_mode2_golden(name):
     """decode_mode 2 (reference las_model.py:229-234) on the device from the reference's own Exp(1) draws: the sampled

@@ -23,6 +23,13 @@ def main():
     line = open(os.path.join(E, "bench.json")).read().strip().splitlines()[-1]
     j = json.loads(line)
     json.dump(j, open(os.path.join(P, "r05_bench_line.json"), "w"), indent=1)
+    if os.environ.get("LAS_COLLECT_LOGS_ONLY") != "1":
+        databases()
+    logs(j)
+
+
+def databases():
+    """Everything that reads a rocprofv3 database: runs on the GPU box (tools/gpu_evidence.sh), the databases do not travel."""
     stats = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "rocpd_stats.py"), find_db("stats"), "40"], capture_output=True, text=True).stdout
     with open(os.path.join(P, "r05_kernel_stats.txt"), "w") as f:
         f.write("# rocprofv3 --kernel-trace --stats over `python3 bench.py --steps 20 --warmup 5` (25 training steps incl. warm-up), round 5;\n"
@@ -43,20 +50,25 @@ def main():
                 "# 14 training steps incl. warm-up and the first-loss step), round 5\n" + stats_long)
     subprocess.run([sys.executable, os.path.join(ROOT, "tools", "make_pmc_profiles.py"), "recmfma", find_db("pmc_recm_a"), find_db("pmc_recm_b"),
                     find_db("pmc_recm_f"), find_db("pmc_recm_w"), "512", "400", "256"], check=True)
+
+    subprocess.run([sys.executable, os.path.join(ROOT, "tools", "make_pmc_profiles.py"), "gemm", "1", find_db("pmc_gemm_a1"), find_db("pmc_gemm_b1"),
+                    "0", find_db("pmc_gemm_a0"), find_db("pmc_gemm_b0")], check=True)
+
+
+def logs(j):
     for name in ("rec_mfma_trace", "gemm_skf_b32", "gemm_skf_b128", "spin_timeout", "big_decode", "gemm_big", "gemm_planes", "gemm_planes_ablation", "lds_long"):
         src = os.path.join(E, name + ".log")
         if os.path.exists(src):
             open(os.path.join(P, f"r05_{name}.txt"), "w").write("".join(l for l in open(src) if "amdgpu.ids" not in l and "trace wg0:" not in l))
-    subprocess.run([sys.executable, os.path.join(ROOT, "tools", "make_pmc_profiles.py"), "gemm", "1", find_db("pmc_gemm_a1"), find_db("pmc_gemm_b1"),
-                    "0", find_db("pmc_gemm_a0"), find_db("pmc_gemm_b0")], check=True)
     open(os.path.join(P, "r05_gemm_split_vs_fp32.txt"), "w").write(
         "# tools/ubench_gemm_split.py on one MI355X: fp32-MFMA GEMM against the split-operand bf16-MFMA GEMM, same operands; err = max |C - ref| /\n"
         "# (|A||B|) in units of 2^-24 against a float64 reference\n" + open(os.path.join(E, "gemm_split.log")).read())
     rows = [json.loads(l) for l in open(os.path.join(ROOT, "gpurun_out", "parity_observed.jsonl"))]
     by = collections.OrderedDict()
     gemm_rows = [r for r in rows if r["name"].startswith("gemm_")]
+    paths = collections.OrderedDict((r["name"], r["path"]) for r in rows if "/path/" in r["name"])
     for r in rows:
-        if r["name"].startswith("gemm_"):
+        if r["name"].startswith("gemm_") or "max_abs_err" not in r:      # (path records: name/path/<phase> with the kernel family observed)
             continue
         k = r["name"].split("/grad/")[0] if "/grad/" in r["name"] else r["name"]
         d = by.setdefault(k, {"tensors": 0, "worst_ratio_of_tolerance": 0.0, "max_abs_err": 0.0})
@@ -65,6 +77,7 @@ def main():
         d["max_abs_err"] = max(d["max_abs_err"], r["max_abs_err"])
     json.dump({"source": "tests/hip_util.py::record during `pytest tests -m gpu` on MI355X (round 5)",
                "tolerance": "|a-b| <= 1e-3*|b| + 1e-5*max|b| + 5e-7*max grad norm; ratio 1.0 = at tolerance", "cases": by,
+               "kernel_paths_asserted": paths,
                "gemm_arithmetic_vs_float64": {"unit": "max |C - AB| / (|A||B|) in units of 2^-24; name = layout_MxNxK_s<exponent spread>",
                                               "rows": gemm_rows}},
               open(os.path.join(P, "r05_parity_observed.json"), "w"), indent=1)
