@@ -400,7 +400,7 @@ def allreduce_alone_ms(reducer, iters=10):
     return e0.elapsed_time(e1) / iters
 
 
-def make_train_step(las, x, lab, reducer, opt, graph=False):
+def make_train_step(las, x, lab, reducer, opt, graph=False, tf_rate=1.0):
     """One training step of the benchmark as a callable returning the loss tensor: zero the flat gradient, forward (teacher
     forced), fused label-smoothing loss + gradient, backward through every HIP kernel, ONE gradient all-reduce (N > 1), global-norm
     clip at 1.0 + Adam as the fused launch pair.  graph=True captures zero + forward + loss + backward into one HIP graph
@@ -410,7 +410,7 @@ def make_train_step(las, x, lab, reducer, opt, graph=False):
 
     def fwd_bwd():
         reducer.zero()
-        preds, _ = las(batch_data=x, batch_label=lab, teacher_force_rate=1.0, is_training=True)
+        preds, _ = las(batch_data=x, batch_label=lab, teacher_force_rate=tf_rate, is_training=True)
         # fused loss + gradient kernel, no copies; the gradient seeds the backward directly (what solver.batch_iterator does)
         if seeded:
             return label_smoothing_loss_backward_device(stack_steps(preds), lab, 0.1)
@@ -700,6 +700,21 @@ def main():
             res["gemm_arith_variant"] = {"arith": "fp32 operands on v_mfma_f32_32x32x2_f32 (LAS_GEMM_ARITH=0)" if mode0 == 1 else "split-operand bf16 MFMA (LAS_GEMM_ARITH=1)",
                                          "value": round(B / dta, 2), "unit": "utt/s", "ms_per_step": round(dta * 1e3, 3), "steps": nalt}
             res["gemm_accuracy"] = gemm_accuracy()
+            # the same step when the teacher-forcing coin comes up "free" (reference las_model.py:189,205-206: the YAML's schedule makes that
+            # 10-50 % of the training steps): decode_mode 1 feedback for max_label_len steps, loss, backward — PRE kernels both ways
+            free_step = make_train_step(las, x, lab, reducer, opt, tf_rate=0.0)
+            for _ in range(3):
+                free_step()
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            for _ in range(nalt):
+                free_step()
+            torch.cuda.synchronize()
+            dtf = (time.perf_counter() - t1) / nalt
+            from las_pytorch_amd import _cabi as _c
+            res["free_running_step_variant"] = {"workload": "the same training step with the decode free-running (decode_mode 1, teacher_force_rate 0)", "value": round(B / dtf, 2),
+                                                "unit": "utt/s", "ms_per_step": round(dtf * 1e3, 3), "steps": nalt,
+                                                "decode_paths": [_c.last_path(_c.PATH_DECODE_FWD), _c.last_path(_c.PATH_DECODE_BWD)]}
         if not args.no_roofline:
             res["roofline"] = roofline_rec_fwd(c, B, T)
             res.update(speller_roof)
