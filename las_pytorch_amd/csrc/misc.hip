@@ -438,43 +438,116 @@ int ls_loss(const float* logp, long sU, long sB, const long long* labels, int U,
 }
 
 // Letter error rate (solver.py:11-24): prediction = argmax over V per step, zeros skipped, stop at the first 1; truth =
-// argmax of the label rows with 0 and 1 dropped; Levenshtein distance / len(truth).  One thread per utterance
-// (U <= 1024 symbols; rolling DP row in `work`, 2*(U+1) ints per utterance).  len(truth) == 0 gives +inf where the
+// argmax of the label rows with 0 and 1 dropped; Levenshtein distance / len(truth).  len(truth) == 0 gives NaN / +inf where the
 // reference raises ZeroDivisionError.
-__global__ void ler_kernel(const float* __restrict__ logp, long sU, long sB, const long long* __restrict__ labels, int U,
-                           int U_lab, int B, int V, float* __restrict__ out, int* __restrict__ work) {
-    const int b = blockIdx.x * blockDim.x + threadIdx.x;
-    if (b >= B) return;
-    int* seqp = work + (long)b * 4 * (U + 1);      // [pred | truth | row0 | row1]
-    int* seqt = seqp + (U + 1);
-    int* prev = seqt + (U + 1);
-    int* cur = prev + (U + 1);
-    int np = 0, nt = 0;
-    bool stop = false;
-    for (int s = 0; s < U; ++s) {
+// One WAVE per utterance (round 5; the first version ran one thread per utterance with its DP rows in global memory: 2.2 ms per call
+// at B = 32, U = 128 — a third of a training step of the solver path).  Phase 1: every lane takes steps lane, lane + 64, ...: arg-max of the
+// log-prob row and of the label row, then an order-preserving compaction with wave ballots.  Phase 2: the DP table by anti-diagonals —
+// a lane owns CPL consecutive truth columns, cell (i, j) on diagonal d = i + j needs (i-1, j) and (i, j-1) from diagonal d-1 and
+// (i-1, j-1) from d-2: its own registers plus ONE value pair from the lane below per diagonal.  np + nt diagonals of CPL cells each.
+constexpr int LER_CPL_MAX = 16;          // truth symbols per lane: U <= 64 * 16 - 1
+constexpr int LER_THREADS = 256;         // phase 1 (arg-max per step) uses every thread, the DP the first wave
+// D[np][nt] with every lane of the wave owning columns lane * C .. lane * C + C - 1 (wave-uniform result).  State per owned column: its cell on
+// diagonal d-1 (a) and d-2 (p); per diagonal the lane fetches the lane below's LAST column of both (two DPP wave shifts) and updates its C
+// cells.  The prediction symbols a lane's cells compare against slide by one per diagonal: a register window, one (prefetched) LDS read each.
+template <int C>
+static __device__ __forceinline__ int ler_dp(const int* seqp, const int* seqt, int np, int nt) {
+    const int lane = threadIdx.x;
+    int a[C], p[C], tj[C], w[C];
+#pragma unroll
+    for (int c = 0; c < C; ++c) {
+        const int j = lane * C + c;
+        a[c] = 0; p[c] = 0; w[c] = -2;
+        tj[c] = (j >= 1 && j <= nt) ? seqt[j - 1] : -1;
+    }
+    // w[c] = pred[i - 1] of cell (i, j = lane C + c) on the current diagonal, i.e. pred[d - lane C - c - 1]; entering diagonal d the window
+    // shifts up by one and w[0] takes pred[d - lane C - 1] (fetched one diagonal ahead)
+    auto pred_at = [&](int k) { return (k >= 0 && k < np) ? seqp[k] : -2; };
+    int nxt = pred_at(0 - lane * C - 1);
+    for (int d = 0; d <= np + nt; ++d) {
+#pragma unroll
+        for (int c = C - 1; c >= 1; --c) w[c] = w[c - 1];
+        w[0] = nxt;
+        nxt = pred_at(d + 1 - lane * C - 1);
+        // lane - 1's last column as DPP wave_shr:1 (one VALU move each instead of an LDS round trip; lane 0's column 0 is the border: unused there)
+        const int left_a = __builtin_amdgcn_mov_dpp(a[C - 1], 0x138, 0xF, 0xF, true), left_p = __builtin_amdgcn_mov_dpp(p[C - 1], 0x138, 0xF, 0xF, true);
+        int n[C];
+#pragma unroll
+        for (int c = 0; c < C; ++c) {
+            const int j = lane * C + c, i = d - j;
+            n[c] = a[c];
+            if (j <= nt && i >= 0 && i <= np) {
+                if (j == 0) n[c] = i;
+                else if (i == 0) n[c] = j;
+                else {
+                    const int la = c == 0 ? left_a : a[c - 1], lp = c == 0 ? left_p : p[c - 1];
+                    n[c] = min(min(a[c] + 1, la + 1), lp + (w[c] != tj[c] ? 1 : 0));
+                }
+            }
+        }
+#pragma unroll
+        for (int c = 0; c < C; ++c) { p[c] = a[c]; a[c] = n[c]; }
+    }
+    int mine = 0;      // the owner of column nt holds D[np][nt]
+#pragma unroll
+    for (int c = 0; c < C; ++c) if (lane * C + c == nt) mine = a[c];
+    return __shfl(mine, nt / C);
+}
+__global__ __launch_bounds__(LER_THREADS) void ler_kernel(const float* __restrict__ logp, long sU, long sB, const long long* __restrict__ labels,
+                                                          int U, int U_lab, int B, int V, float* __restrict__ out) {
+    extern __shared__ int ler_lds[];      // [pred U][truth U][arg-max per step U][label per step U]
+    int* seqp = ler_lds;
+    int* seqt = ler_lds + U;
+    int* amv = ler_lds + 2 * U;
+    int* tmv = ler_lds + 3 * U;
+    const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63;
+    // ---- phase 1a (all threads): the symbol of every step
+    for (int s = tid; s < U; s += LER_THREADS) {
         const float* lp = logp + (long)s * sU + (long)b * sB;
         int am = 0; float best = lp[0];
-        for (int c = 1; c < V; ++c) if (lp[c] > best) { best = lp[c]; am = c; }
-        if (!stop) { if (am == 1) stop = true; else if (am != 0) seqp[np++] = am; }
+        for (int c = 1; c < V; ++c) { const float v = lp[c]; if (v > best) { best = v; am = c; } }
         const long long* y = labels + ((long)b * U_lab + s) * V;
         int tm = 0; long long tb = y[0];
-        for (int c = 1; c < V; ++c) if (y[c] > tb) { tb = y[c]; tm = c; }
-        if (tm != 0 && tm != 1) seqt[nt++] = tm;
+        for (int c = 1; c < V; ++c) { const long long v = y[c]; if (v > tb) { tb = v; tm = c; } }
+        amv[s] = am; tmv[s] = tm;
     }
-    for (int j = 0; j <= nt; ++j) prev[j] = j;
-    for (int i = 1; i <= np; ++i) {
-        cur[0] = i;
-        for (int j = 1; j <= nt; ++j) {
-            const int sub = prev[j - 1] + (seqp[i - 1] != seqt[j - 1]);
-            cur[j] = min(min(prev[j] + 1, cur[j - 1] + 1), sub);
-        }
-        int* t = prev; prev = cur; cur = t;
+    __syncthreads();
+    if (tid >= 64) return;
+    // ---- phase 1b (first wave): the first <eos> of the prediction, order-preserving compaction with wave ballots
+    const unsigned long long below = (1ull << lane) - 1ull;
+    int stop = U;
+    for (int s0 = 0; s0 < U && stop == U; s0 += 64) {
+        const unsigned long long eos = __ballot(s0 + lane < U && amv[s0 + lane] == 1);
+        if (eos != 0ull) stop = s0 + __builtin_ctzll(eos);
     }
-    out[b] = (float)prev[nt] / (float)nt;
+    int np = 0, nt = 0;
+    for (int s0 = 0; s0 < U; s0 += 64) {
+        const int s = s0 + lane;
+        const int am = s < U ? amv[s] : 0, tm = s < U ? tmv[s] : 0;
+        const bool kp = s < U && s < stop && am != 0;              // (am == 1 cannot occur before `stop`)
+        const bool kt = s < U && tm != 0 && tm != 1;
+        const unsigned long long mp = __ballot(kp), mt = __ballot(kt);
+        if (kp) seqp[np + __builtin_popcountll(mp & below)] = am;
+        if (kt) seqt[nt + __builtin_popcountll(mt & below)] = tm;
+        np += __builtin_popcountll(mp); nt += __builtin_popcountll(mt);
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    __builtin_amdgcn_wave_barrier();
+    // ---- phase 2: Levenshtein distance, rows = prediction (np), columns = truth (nt); a lane owns C consecutive columns of 0..nt
+    const int cpl = (nt + 1 + 63) / 64;
+    int dist;
+    if (cpl <= 1) dist = ler_dp<1>(seqp, seqt, np, nt);
+    else if (cpl <= 2) dist = ler_dp<2>(seqp, seqt, np, nt);
+    else if (cpl <= 4) dist = ler_dp<4>(seqp, seqt, np, nt);
+    else if (cpl <= 8) dist = ler_dp<8>(seqp, seqt, np, nt);
+    else dist = ler_dp<LER_CPL_MAX>(seqp, seqt, np, nt);
+    if (lane == 0) out[b] = (float)dist / (float)nt;
 }
 int ler(const float* logp, long sU, long sB, const long long* labels, int U, int U_lab, int B, int V, float* out, int* work,
         hipStream_t stream) {
-    hipLaunchKernelGGL(ler_kernel, dim3(cdiv(B, 64)), dim3(64), 0, stream, logp, sU, sB, labels, U, U_lab, B, V, out, work);
+    (void)work;      // (the one-thread-per-utterance kernel of rounds 1-4 kept its DP rows there; the ABI keeps the argument)
+    LAS_REQUIRE(U <= 64 * LER_CPL_MAX - 1, "letter error rate: at most 1023 decode steps");
+    hipLaunchKernelGGL(ler_kernel, dim3(B), dim3(LER_THREADS), sizeof(int) * 4 * (size_t)U, stream, logp, sU, sB, labels, U, U_lab, B, V, out);
     LAS_LAUNCH_CHECK();
     return LAS_OK;
 }
