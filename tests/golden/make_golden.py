@@ -299,6 +299,46 @@ def make_trajectory_golden(refmods):
     print("S_trajectory: losses", [round(l, 5) for l in losses], "val", float(vloss), "ler", lers[-1])
 
 
+def make_free_training_golden(refmods, which="tsp"):
+    """Round 5: a TRAINING step of the unmodified reference that takes the free-running branch (teacher_force_rate 0 with is_training
+    True: las_model.py:189 draws False, the loop runs max_label_len steps feeding back the one-hot arg-max, :205-227) followed by the
+    label-smoothing loss and ``backward()``.  The fed-back symbols are not differentiable, so the gradient flows through the decoder state
+    and the context only — what the drop-in's free-running forward + teacher-forced-style backward pair must reproduce.  Stored: log-probs,
+    arg-max sequences and their top-1 / top-2 margin, the loss, per-parameter gradient norms and 64-element gradient slices."""
+    LAS, Listener, Speller, batch_iterator, ls_loss = refmods
+    cases = []
+    if "t" in which: cases.append(("tiny_free_train", "tiny", 3, 32, 6, 0.3, 17))
+    if "s" in which: cases.append(("S_free_train", "S", 4, 64, 8, 0.2, 43))
+    if "p" in which: cases.append(("P_B32_T800_U16_free_train", "P", 32, 800, 16, 0.2, 43))      # weights / inputs of P_B32_T800_U32_s
+    for name, cfg_name, B, T, U, scale, seed in cases:
+        c = synth.CONFIGS[cfg_name]
+        sd_np = synth.make_state_dict(synth.config_shapes(cfg_name), seed=seed, scale=scale)
+        x = torch.from_numpy(synth.make_inputs(B, T, c["F"], seed=seed))
+        idx, lens = synth.make_labels(B, U, c["V"], seed=seed, ragged=(cfg_name != "P"))
+        labels = torch.from_numpy(synth.onehot_labels(idx, lens, c["V"]))
+        las = build_ref(LAS, Listener, Speller, c, sd_np, max_label_len=U, decode_mode=1)
+        las.zero_grad()
+        preds, _ = las(batch_data=x, batch_label=labels, teacher_force_rate=0.0, is_training=True)
+        assert len(preds) == U
+        pred_y = torch.cat([p.unsqueeze(1) for p in preds], 1)
+        loss = ls_loss(pred_y, labels.float(), label_smoothing=0.1)
+        loss.backward()
+        logp = stack(preds)
+        top2 = np.sort(logp, axis=-1)[..., -2:]
+        gn = {k: p.grad.detach().numpy() for k, p in las.named_parameters()}
+        out = dict(meta=np.array([B, T, U, seed], dtype=np.int64), scale=np.array([scale]), cfg=np.array(cfg_name),
+                   ragged=np.array([int(cfg_name != "P")]), free_logp=logp, free_argmax=logp.argmax(-1),
+                   free_margin=np.array([float((top2[..., 1] - top2[..., 0]).min())]), loss_ls=np.array([loss.item()]),
+                   gradnorm_ls=np.array([np.linalg.norm(g.astype(np.float64)) for g in gn.values()]),
+                   gradtotal_ls=np.array([np.sqrt(sum((g.astype(np.float64) ** 2).sum() for g in gn.values()))]),
+                   grad_keys=np.array(list(gn.keys())))
+        for k, g in gn.items():
+            out["grad/" + k] = g.reshape(-1)[:: max(1, g.size // 64)][:64].copy()
+        np.savez_compressed(os.path.join(HERE, name + ".npz"), **out)
+        print(f"{name}: {os.path.getsize(os.path.join(HERE, name + '.npz')) / 1024:.1f} KB margin={out['free_margin'][0]:.2e} loss={loss.item():.5f} "
+              f"distinct symbols={len(np.unique(out['free_argmax']))} first utterance={out['free_argmax'][:, 0].tolist()}")
+
+
 def make_collate_golden():
     """The reference's own ``collate_fn`` (utils/data.py:116-149) on a synthetic ragged batch.  ``utils/data.py`` imports
     torchaudio / enlighten / pydub at module top (unused by collate_fn): stubbed in sys.modules, nothing else is touched."""
@@ -382,6 +422,11 @@ if __name__ == "__main__" and len(sys.argv) > 1 and sys.argv[1] == "extra":
     make_trajectory_golden(import_reference())
     make_collate_golden()
 
+if __name__ == "__main__" and len(sys.argv) > 1 and sys.argv[1] == "free":
+    torch.manual_seed(0)
+    torch.set_num_threads(8)
+    make_free_training_golden(import_reference(), sys.argv[2] if len(sys.argv) > 2 else "tsp")
+
 if __name__ == "__main__" and len(sys.argv) > 1 and sys.argv[1] == "big":
     torch.manual_seed(0)
     torch.set_num_threads(8)
@@ -394,6 +439,7 @@ if __name__ == "__main__" and len(sys.argv) == 1:
     make_mode2_golden(import_reference())
     make_trajectory_golden(import_reference())
     make_collate_golden()
+    make_free_training_golden(import_reference())
 
 
 # tests/golden/ref_checkpoint_tiny.pth.tar: a checkpoint package written by the REFERENCE's own LAS.serialize

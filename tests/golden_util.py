@@ -129,3 +129,21 @@ def tf_argmax_mask(tf_logp, min_gap=5e-5):
     position says nothing about the decoded sequence.  Greedy sequences are always compared in full."""
     top2 = np.sort(tf_logp, axis=-1)[..., -2:]
     return (top2[..., 1] - top2[..., 0]) > min_gap
+
+
+FREE_TRAIN_CASES = ["tiny_free_train", "S_free_train", "P_B32_T800_U16_free_train"]
+
+
+def load_free_train_case(name):
+    """A free-running TRAINING step of the reference (tests/golden/make_golden.py::make_free_training_golden): the inputs by recipe and
+    the stored log-probs / arg-max / loss / gradient norms and slices."""
+    from las_pytorch_amd import synth
+    g = np.load(os.path.join(GOLDEN_DIR, name + ".npz"))
+    cfg_name = str(g["cfg"])
+    c = synth.CONFIGS[cfg_name]
+    B, T, U, seed = (int(v) for v in g["meta"])
+    sd_np = synth.make_state_dict(synth.config_shapes(cfg_name), seed=seed, scale=float(g["scale"][0]))
+    x = synth.make_inputs(B, T, c["F"], seed=seed)
+    idx, lens = synth.make_labels(B, U, c["V"], seed=seed, ragged=bool(int(g["ragged"][0])))
+    onehot = synth.onehot_labels(idx, lens, c["V"])
+    return g, c, cfg_name, (B, T, U), sd_np, x, onehot

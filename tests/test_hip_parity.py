@@ -5,7 +5,7 @@ import numpy as np
 import pytest
 import torch
 
-from golden_util import ALL_CASES, BIG_CASES, load_case, oracle_cfg, tf_argmax_mask
+from golden_util import ALL_CASES, BIG_CASES, FREE_TRAIN_CASES, load_case, load_free_train_case, oracle_cfg, tf_argmax_mask
 from hip_util import assert_close, build_las, grad_close, record
 from las_pytorch_amd import _cabi
 
@@ -218,6 +218,40 @@ def test_free_running_training_step_vs_oracle():
     gscale = max(float(sd[k].grad.norm()) for k in sd)
     for k, p in las.named_parameters():
         grad_close(p.grad.cpu().numpy(), sd[k].grad.numpy(), f"oracle_free_P_B{B}_T{T}/grad/{k}", rtol=GRAD_RTOL, floor=GRAD_FLOOR, global_scale=gscale)
+    _check_err()
+
+
+@pytest.mark.parametrize("name", FREE_TRAIN_CASES)
+def test_free_running_training_step_golden(name):
+    """A free-running training step against the UNMODIFIED reference's (fixtures of make_golden.py::make_free_training_golden): log-probs,
+    arg-max sequences, the label-smoothing loss, all per-parameter gradient norms and 64-element slices.  The paper-size fixture (B = 32,
+    T = 800, weights of the "_s" cases: 19 distinct symbols, margin 1.3e-3) must run the free-running PRE forward and the PRE backward."""
+    g, c, cfg_name, (B, T, U), sd_np, x, onehot = load_free_train_case(name)
+    las = build_las(c, sd_np, max_label_len=U)
+    xg, labg = torch.from_numpy(x).cuda(), torch.from_numpy(onehot).cuda()
+    preds, _ = las(batch_data=xg, batch_label=labg, teacher_force_rate=0.0, is_training=True)
+    assert len(preds) == U
+    if cfg_name == "P":
+        assert _cabi.last_path(_cabi.PATH_DECODE_FWD) == "persist_pre_greedy", _cabi.last_path(_cabi.PATH_DECODE_FWD)
+    logp = torch.stack(preds).detach().cpu().numpy()
+    assert (logp.argmax(-1) == g["free_argmax"]).all(), "free-running arg-max sequence differs from the reference's"
+    assert_close(logp, g["free_logp"], f"{name}/free_logp")
+    loss = _loss_ls(preds, labg, U)
+    loss.backward()
+    torch.cuda.synchronize()
+    if cfg_name == "P":
+        assert _cabi.last_path(_cabi.PATH_DECODE_BWD) == "persist_pre", _cabi.last_path(_cabi.PATH_DECODE_BWD)
+    assert abs(loss.item() - g["loss_ls"][0]) <= 1e-4 * abs(g["loss_ls"][0]) + 1e-6
+    assert [k for k, _ in las.named_parameters()] == [str(k) for k in g["grad_keys"]]
+    norms = np.array([p.grad.double().norm().item() for _, p in las.named_parameters()])
+    scale = float(g["gradnorm_ls"].max())
+    np.testing.assert_allclose(norms, g["gradnorm_ls"], rtol=1e-3, atol=1e-6 * scale)
+    for (k, p), want_norm in zip(las.named_parameters(), g["gradnorm_ls"]):
+        got = p.grad.cpu().numpy()
+        got = got.reshape(-1)[:: max(1, got.size // 64)][:64]
+        want = g["grad/" + k]
+        rms = want_norm / np.sqrt(max(1, p.numel()))
+        grad_close(got, want, f"{name}/grad/{k}", rtol=GRAD_RTOL, floor=GRAD_FLOOR * max(1.0, rms / (np.abs(want).max() + 1e-30)), global_scale=scale)
     _check_err()
 
 

@@ -5,7 +5,7 @@ import numpy as np
 import pytest
 import torch
 
-from golden_util import ALL_CASES, BIG_CASES, load_case, oracle_cfg, tf_argmax_mask
+from golden_util import ALL_CASES, BIG_CASES, FREE_TRAIN_CASES, load_case, load_free_train_case, oracle_cfg, tf_argmax_mask
 from oracle import las_oracle as O
 
 ATOL = 2e-6
@@ -75,6 +75,30 @@ def test_loss_and_grads_match_reference(name):
                 if not info["full"]:
                     got = got.reshape(-1)[:: max(1, got.size // 64)][:64]
                 np.testing.assert_allclose(got, want, rtol=1e-3, atol=2e-7)
+
+
+@pytest.mark.parametrize("name", FREE_TRAIN_CASES[:2])
+def test_free_running_training_step_matches_reference(name):
+    """The oracle's free-running training step (decode_mode-1 feedback for max_label_len steps with autograd on, then the label-smoothing
+    loss and backward; reference las_model.py:189,205-227 + solver.py:33-45,95) against the unmodified reference's: log-probs, arg-max
+    sequence, loss, all gradient norms and slices.  (The paper-size fixture is checked on the GPU only: 40 s of CPU per run.)"""
+    g, c, cfg_name, (B, T, U), sd_np, x, onehot = load_free_train_case(name)
+    sd = O.to_torch_sd(sd_np, requires_grad=True)
+    lab = torch.from_numpy(onehot)
+    cfg = dict(listener_layers=c["L"], speller_layers=c["Ls"], max_label_len=U, decode_mode=1)
+    preds, _ = O.las_forward(torch.from_numpy(x), lab, sd, cfg, teacher_force=False)
+    logp = torch.stack(preds).detach().numpy()
+    assert (logp.argmax(-1) == g["free_argmax"]).all()
+    np.testing.assert_allclose(logp, g["free_logp"], atol=5e-6, rtol=0)
+    loss, _ = O.solver_step_loss(preds, lab, U, 0.1)
+    loss.backward()
+    assert abs(loss.item() - g["loss_ls"][0]) < 2e-6 * max(1, abs(g["loss_ls"][0]))
+    assert list(sd_np.keys()) == [str(k) for k in g["grad_keys"]]
+    norms = np.array([sd[k].grad.double().norm().item() for k in sd_np])
+    np.testing.assert_allclose(norms, g["gradnorm_ls"], rtol=2e-4, atol=1e-8)
+    for k in sd_np:
+        got = sd[k].grad.numpy()
+        np.testing.assert_allclose(got.reshape(-1)[:: max(1, got.size // 64)][:64], g["grad/" + k], rtol=1e-3, atol=2e-7)
 
 
 @pytest.mark.parametrize("name", ["tiny_mode2", "S_mode2"])
