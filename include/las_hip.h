@@ -235,8 +235,9 @@ int las_speller_bwd(const las_speller_desc* d, const float* feat, const float* k
  *   (B,U,V) tensor solver.py:68 builds can be passed; labels_onehot int64 (B, U_lab, V); U = min(U_lab, max_label_len).
  * las_ls_loss: label_smoothing_loss (solver.py:33-45) and, if dlogp != NULL, its gradient wrt logp (same addressing
  *   with dstride_*).  loss: 1 float; scratch: B floats.
- * las_letter_error_rate: LetterErrorRate (solver.py:11-24) of the argmax sequences; ler_out: B floats;
- *   work: 4*B*(U+1) int32.
+ * las_letter_error_rate: LetterErrorRate (solver.py:11-24) of the argmax sequences; ler_out: B floats; U <= 4095.  One wave per
+ *   utterance walks the anti-diagonals of the edit-distance table in registers; work is unused since ABI 9 (may be NULL; rounds 1-4
+ *   kept the DP rows there: 4*B*(U+1) int32).
  * ---------------------------------------------------------------------------------------------- */
 int las_ls_loss(const float* logp, int64_t stride_u, int64_t stride_b, const int64_t* labels_onehot, int U, int U_lab,
                 int B, int V, float smoothing, float* loss, float* dlogp, int64_t dstride_u, int64_t dstride_b,

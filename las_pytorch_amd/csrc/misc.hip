@@ -445,7 +445,7 @@ int ls_loss(const float* logp, long sU, long sB, const long long* labels, int U,
 // log-prob row and of the label row, then an order-preserving compaction with wave ballots.  Phase 2: the DP table by anti-diagonals —
 // a lane owns CPL consecutive truth columns, cell (i, j) on diagonal d = i + j needs (i-1, j) and (i, j-1) from diagonal d-1 and
 // (i-1, j-1) from d-2: its own registers plus ONE value pair from the lane below per diagonal.  np + nt diagonals of CPL cells each.
-constexpr int LER_CPL_MAX = 16;          // truth symbols per lane: U <= 64 * 16 - 1
+constexpr int LER_CPL_MAX = 64;          // truth symbols per lane: U <= 64 * 64 - 1 (one wave per SIMD: the 5 C registers per lane fit)
 constexpr int LER_THREADS = 256;         // phase 1 (arg-max per step) uses every thread, the DP the first wave
 // D[np][nt] with every lane of the wave owning columns lane * C .. lane * C + C - 1 (wave-uniform result).  State per owned column: its cell on
 // diagonal d-1 (a) and d-2 (p); per diagonal the lane fetches the lane below's LAST column of both (two DPP wave shifts) and updates its C
@@ -540,13 +540,15 @@ __global__ __launch_bounds__(LER_THREADS) void ler_kernel(const float* __restric
     else if (cpl <= 2) dist = ler_dp<2>(seqp, seqt, np, nt);
     else if (cpl <= 4) dist = ler_dp<4>(seqp, seqt, np, nt);
     else if (cpl <= 8) dist = ler_dp<8>(seqp, seqt, np, nt);
+    else if (cpl <= 16) dist = ler_dp<16>(seqp, seqt, np, nt);
+    else if (cpl <= 32) dist = ler_dp<32>(seqp, seqt, np, nt);
     else dist = ler_dp<LER_CPL_MAX>(seqp, seqt, np, nt);
     if (lane == 0) out[b] = (float)dist / (float)nt;
 }
 int ler(const float* logp, long sU, long sB, const long long* labels, int U, int U_lab, int B, int V, float* out, int* work,
         hipStream_t stream) {
     (void)work;      // (the one-thread-per-utterance kernel of rounds 1-4 kept its DP rows there; the ABI keeps the argument)
-    LAS_REQUIRE(U <= 64 * LER_CPL_MAX - 1, "letter error rate: at most 1023 decode steps");
+    LAS_REQUIRE(U >= 1 && U <= 64 * LER_CPL_MAX - 1, "letter error rate: 1 .. 4095 decode steps");
     hipLaunchKernelGGL(ler_kernel, dim3(B), dim3(LER_THREADS), sizeof(int) * 4 * (size_t)U, stream, logp, sU, sB, labels, U, U_lab, B, V, out);
     LAS_LAUNCH_CHECK();
     return LAS_OK;

@@ -406,6 +406,35 @@ def test_device_loss_and_ler_match_solver_counterpart():
     _check_err()
 
 
+@pytest.mark.parametrize("B,U,eos_rate", [(32, 128, 0.0), (5, 63, 0.05), (4, 64, 0.0), (3, 65, 0.2), (6, 300, 0.0), (3, 700, 0.01), (3, 1100, 0.0), (2, 2500, 0.0),
+                                          (2, 4095, 0.0), (3, 2, 0.0), (4, 3, 0.5)])
+def test_device_letter_error_rate_wave_kernel(B, U, eos_rate):
+    """``las_letter_error_rate`` (one wave per utterance; anti-diagonal Levenshtein with 1 / 2 / 4 / 8 / 16 / 32 / 64 truth columns per lane) against
+    the Python ``LetterErrorRate`` of the solver (reference solver/solver.py:11-24) on random predictions: <sos>/pad symbols inside the
+    prediction (skipped), early <eos> (stops the prediction), ragged truths, every columns-per-lane instantiation, U = 2 and the 4095 limit;
+    and on the (U,B,V) layout the decode kernels write (strided view)."""
+    from las_pytorch_amd import synth
+    from las_pytorch_amd.solver import solver as S
+    V = 30
+    rng = np.random.default_rng(1000 * B + U)
+    idx, lens = synth.make_labels(B, U, V, seed=U, ragged=U > 2)
+    onehot = torch.from_numpy(synth.onehot_labels(idx, lens, V))
+    pred = rng.integers(2, V, size=(B, U))
+    keep = rng.random((B, U)) < 0.6                     # 60 % of the steps repeat the truth: distances well below the maximum
+    pred[keep] = np.maximum(idx, 2)[keep]
+    pred[rng.random((B, U)) < 0.1] = 0                  # pad / <sos> inside the prediction
+    pred[rng.random((B, U)) < eos_rate] = 1             # early <eos>
+    logp = torch.full((U, B, V), -5.0)
+    logp.scatter_(2, torch.from_numpy(pred.T.copy()).unsqueeze(-1), -0.1)
+    want = np.array(S.LetterErrorRate(pred, onehot.argmax(-1).numpy()))
+    dev = logp.cuda()
+    got_ubv = S.LetterErrorRate_device(dev.transpose(0, 1), onehot.cuda()).cpu().numpy()       # strided (B,U,V) view of the (U,B,V) buffer
+    got_buv = S.LetterErrorRate_device(dev.transpose(0, 1).contiguous(), onehot.cuda()).cpu().numpy()
+    np.testing.assert_allclose(got_ubv, want, rtol=1e-6)
+    np.testing.assert_allclose(got_buv, want, rtol=1e-6)
+    _check_err()
+
+
 @pytest.mark.parametrize("cfg_name,B,T,U", [("P", 1, 8, 1), ("S", 1, 4, 2), ("tiny", 1, 4, 1), ("P", 2, 16, 3)])
 def test_edge_shapes_vs_oracle(cfg_name, B, T, U):
     """Smallest legal shapes: one utterance, one encoder frame after the pyramid (T = 2**L), a single decode step
