@@ -180,14 +180,39 @@ def _dev_index(device):
     return d.index if d.index is not None else torch.cuda.current_device()
 
 
+_STEP_READBACK_MAX = 4096      # utterances whose letter error rates ride in the step's one device-to-host copy
+_err_bufs = {}                 # device index -> int32 [4 error words | 4 floats (loss, spare) | _STEP_READBACK_MAX floats (LER)]
+
+
 def err_word(device):
-    """Per-device uint32 the kernels write a nonzero code into when a bounded hand-off spin expires."""
+    """Per-device uint32 the kernels write a nonzero code into when a bounded hand-off spin expires.  It is the head of a small buffer
+    whose tail takes a training step's loss and letter error rates (``step_readback``), so that the solver reads all three with one copy."""
     key = _dev_index(device)
     w = _err_words.get(key)
     if w is None:
-        w = torch.zeros(4, dtype=torch.int32, device=f"cuda:{key}")
+        buf = torch.zeros(8 + _STEP_READBACK_MAX, dtype=torch.int32, device=f"cuda:{key}")
+        _err_bufs[key] = buf
+        w = buf[:4]
         _err_words[key] = w
     return w
+
+
+def step_readback(device, B):
+    """``(loss_out, ler_out)``: a 1-element and a B-element fp32 view behind the device's error word, for ``las_ls_loss`` / ``las_letter_error_rate``
+    to write into; ``read_step`` then fetches error word, loss and rates in ONE device-to-host copy.  None when B does not fit."""
+    if B > _STEP_READBACK_MAX:
+        return None
+    err_word(device)
+    f = _err_bufs[_dev_index(device)][4:].view(torch.float32)
+    return f[0:1], f[4:4 + B]
+
+
+def read_step(device, B):
+    """The step's one synchronisation point: ``(error word, loss (numpy float32 scalar), [B letter error rates])``."""
+    key = _dev_index(device)
+    host = _err_bufs[key][:8 + B].cpu()
+    f = host[4:].view(torch.float32).numpy()
+    return int(host[0]), f[0].copy(), f[4:4 + B].tolist()
 
 
 class DeviceHandoffError(RuntimeError):
@@ -220,17 +245,20 @@ def _raise_device_error(key, v):
                        "per-step kernels, which need no co-residency.")
 
 
-def check_device_errors():
+def check_device_errors(words=None):
     """Synchronising check of the device error words: raises if any persistent kernel reported a hand-off timeout and
     clears the word so later launches run normally.  ``solver.batch_iterator`` calls this right after the loss reaches
-    the host (the step's existing synchronisation point); tests, smoke and bench call it after their timed regions."""
+    the host (the step's existing synchronisation point); tests, smoke and bench call it after their timed regions.
+    ``words`` ({device index: value}): error words the caller has just read together with its results (``read_step``: the stream is
+    drained, no second copy is made for those devices)."""
     if torch.cuda.is_available() and torch.cuda.is_initialized():
-        torch.cuda.synchronize()
+        if words is None:
+            torch.cuda.synchronize()
         if lib().las_gemm_check() != 0:   # a stream-K fix-up wait that timed out (host-visible word, needs no device copy)
             raise DeviceHandoffError("liblas_hip: " + lib().las_last_error().decode(errors="replace") +
                                      " (GEMM_SK_FIXUP: the tile that wait belonged to is wrong; the step must be re-run)")
     for key, w in _err_words.items():
-        v = int(w[0].item())
+        v = int(words[key]) if (words is not None and key in words) else int(w[0].item())
         if v != 0:
             w.zero_()
             _err_snap.pop(key, None)

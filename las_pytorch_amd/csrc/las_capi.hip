@@ -1174,7 +1174,7 @@ int las_ls_loss(const float* logp, int64_t stride_u, int64_t stride_b, const int
 
 int las_letter_error_rate(const float* logp, int64_t stride_u, int64_t stride_b, const int64_t* labels_onehot, int U, int U_lab,
                           int B, int V, float* ler_out, int32_t* work, void* stream) {
-    LAS_REQUIRE(logp && labels_onehot && ler_out && work, "LER pointers");
+    LAS_REQUIRE(logp && labels_onehot && ler_out, "LER pointers");      // work: unused since ABI 9 (may be NULL)
     LAS_REQUIRE(U > 0 && U <= U_lab && B > 0 && V > 0, "LER dims");
     return ler(logp, stride_u, stride_b, (const long long*)labels_onehot, U, U_lab, B, V, ler_out, work, (hipStream_t)stream);
 }

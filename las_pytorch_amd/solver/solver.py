@@ -67,19 +67,19 @@ def LetterErrorRate(pred_y, true_y):
     return rates
 
 
-def LetterErrorRate_device(pred_y, labels_onehot_int64):
+def LetterErrorRate_device(pred_y, labels_onehot_int64, out=None):
     """The same quantity from log-probs (B,U,V) and int64 one-hot labels without leaving the GPU; returns a (B,)
-    float tensor on the device."""
+    float tensor on the device (``out`` when given)."""
     from .. import _cabi
     pred_y = pred_y.detach()
     if pred_y.dtype != torch.float32:
         raise RuntimeError("LetterErrorRate_device needs fp32 log-probs")
     B, U, V = pred_y.shape
     labels = labels_onehot_int64.contiguous()
-    out = torch.empty(B, device=pred_y.device)
-    work = torch.empty(4 * B * (U + 1), dtype=torch.int32, device=pred_y.device)
+    if out is None:
+        out = torch.empty(B, device=pred_y.device)
     _cabi.check(_cabi.lib().las_letter_error_rate(_cabi.ptr_strided(pred_y), pred_y.stride(1), pred_y.stride(0), _cabi.ptr(labels), U,
-                                                  labels.shape[1], B, V, _cabi.ptr(out), _cabi.ptr(work), _cabi.stream_ptr()))
+                                                  labels.shape[1], B, V, _cabi.ptr(out), None, _cabi.stream_ptr()))
     return out
 
 
@@ -109,14 +109,14 @@ class _FusedSmoothedLoss(torch.autograd.Function):
     along V — in particular the transposed view of the decode kernel's (U,B,V) buffer — so no copy is made."""
 
     @staticmethod
-    def forward(ctx, logp, labels, smoothing):
+    def forward(ctx, logp, labels, smoothing, loss_out=None):
         from .. import _cabi
         if logp.dtype != torch.float32 or logp.stride(2) != 1:
             logp = logp.float().contiguous()
         B, U, V = logp.shape
         labels = labels.contiguous()
         dev = logp.device
-        loss = torch.empty(1, device=dev)
+        loss = torch.empty(1, device=dev) if loss_out is None else loss_out
         scratch = torch.empty(B, device=dev)
         # the gradient is laid out like its input (for the (U,B,V)-based view: step-major), so that it reaches the decode
         # kernel's backward as a contiguous (U,B,V) tensor without a transposing copy
@@ -132,7 +132,7 @@ class _FusedSmoothedLoss(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, upstream):
-        return ctx.grad * upstream, None, None
+        return ctx.grad * upstream, None, None, None
 
 
 def label_smoothing_loss_device(pred_y, labels_onehot_int64, label_smoothing=0.1):
@@ -140,16 +140,17 @@ def label_smoothing_loss_device(pred_y, labels_onehot_int64, label_smoothing=0.1
     return _FusedSmoothedLoss.apply(pred_y, labels_onehot_int64, label_smoothing)
 
 
-def label_smoothing_loss_backward_device(pred_y, labels_onehot_int64, label_smoothing=0.1):
+def label_smoothing_loss_backward_device(pred_y, labels_onehot_int64, label_smoothing=0.1, loss_out=None):
     """``loss = label_smoothing_loss_device(...); loss.backward()`` without the two launches autograd adds for a scalar root (the
     ``ones_like(loss)`` fill and ``grad * upstream``): ``las_ls_loss`` produces d(loss)/d(logp) in the same launch as the loss, and
-    that gradient is handed to autograd as the seed of ``pred_y`` directly.  Returns the (detached) loss tensor."""
+    that gradient is handed to autograd as the seed of ``pred_y`` directly.  Returns the (detached) loss tensor (``loss_out[0]`` when a
+    1-element fp32 device tensor is given)."""
     with torch.no_grad():
         fn = _FusedSmoothedLoss
         class _Ctx:                      # the Function's forward, outside the graph
             needs_input_grad = (True, False, False)
         ctx = _Ctx()
-        loss = fn.forward(ctx, pred_y.detach(), labels_onehot_int64, label_smoothing)
+        loss = fn.forward(ctx, pred_y.detach(), labels_onehot_int64, label_smoothing, loss_out)
     pred_y.backward(gradient=ctx.grad)
     return loss
 
@@ -237,9 +238,12 @@ def batch_iterator(batch_data, batch_label, las_model, optimizer, tf_rate, is_tr
     logp = stack_steps(step_logp, steps)                     # (B,steps,V); a strided view when the steps share one buffer
     smoothed = bool(is_training) and label_smoothing != 0.0
     fused_bwd = bool(is_training) and smoothed and _on_hip_path(logp, batch_label) and logp.requires_grad
+    packed = None       # single-rank device path: loss and letter error rates land behind the device error word, ONE copy fetches all three
     if fused_bwd:       # loss, its gradient and the backward seed from one launch (no ones_like fill, no grad * upstream)
-        ler = LetterErrorRate_device(logp, batch_label)
-        loss = label_smoothing_loss_backward_device(logp, batch_label, label_smoothing)
+        if not (reducer is not None and reducer._collective()):
+            packed = _cabi.step_readback(logp.device, logp.shape[0])
+        ler = LetterErrorRate_device(logp, batch_label, out=None if packed is None else packed[1])
+        loss = label_smoothing_loss_backward_device(logp, batch_label, label_smoothing, loss_out=None if packed is None else packed[0])
     else:
         loss, ler = _loss_and_ler(logp, batch_label, steps, smoothed, label_smoothing)
 
@@ -261,7 +265,11 @@ def batch_iterator(batch_data, batch_label, las_model, optimizer, tf_rate, is_tr
 
     # the step's ONE host synchronisation point: the loss and, in a multi-rank run, the all-reduced device-error flag travel together
     peer_flag = 0.0
-    if is_training and reducer is not None and reducer._collective() and not loss.is_cuda:
+    own_words = None
+    if packed is not None:
+        word, batch_loss, ler = _cabi.read_step(logp.device, logp.shape[0])
+        own_words = {_cabi._dev_index(logp.device): word}
+    elif is_training and reducer is not None and reducer._collective() and not loss.is_cuda:
         batch_loss = loss.detach().numpy()
         peer_flag = float(reducer.flag[0])
     elif is_training and reducer is not None and reducer._collective():
@@ -280,7 +288,7 @@ def batch_iterator(batch_data, batch_label, las_model, optimizer, tf_rate, is_tr
     if logp.is_cuda:
         failed = None
         try:
-            _cabi.check_device_errors()       # a hand-off timeout in a persistent kernel invalidates this step
+            _cabi.check_device_errors(own_words)       # a hand-off timeout in a persistent kernel invalidates this step
         except _cabi.DeviceHandoffError as e:
             failed = e
         peer_failed = peer_flag != 0.0
