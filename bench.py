@@ -715,6 +715,24 @@ def main():
             res["free_running_step_variant"] = {"workload": "the same training step with the decode free-running (decode_mode 1, teacher_force_rate 0)", "value": round(B / dtf, 2),
                                                 "unit": "utt/s", "ms_per_step": round(dtf * 1e3, 3), "steps": nalt,
                                                 "decode_paths": [_c.last_path(_c.PATH_DECODE_FWD), _c.last_path(_c.PATH_DECODE_BWD)]}
+            # the step as a train.py-style driver runs it: solver.batch_iterator (the same launches + the device letter error rate + the loss,
+            # the rates and the device error word read back to the host every step, reference solver/solver.py:48-101) — NOT the metric (the
+            # headline step never reads the loss), reported beside it
+            from las_pytorch_amd.solver.solver import batch_iterator
+            np.random.seed(0)
+            it = lambda: batch_iterator(x, lab, las, opt, tf_rate=1.0, is_training=True, max_label_len=U, label_smoothing=0.1, use_gpu=True)
+            nsol = max(50, args.steps)
+            for _ in range(10):
+                it()
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            for _ in range(nsol):
+                it()
+            torch.cuda.synchronize()
+            dts = (time.perf_counter() - t1) / nsol
+            res["caller_step_variant"] = {"workload": "solver.batch_iterator on the headline batch: the same training step + las_letter_error_rate + one host read of "
+                                                      "(loss, B letter error rates, device error word) per step", "value": round(B / dts, 2), "unit": "utt/s",
+                                          "ms_per_step": round(dts * 1e3, 3), "steps": nsol}
         if not args.no_roofline:
             res["roofline"] = roofline_rec_fwd(c, B, T)
             res.update(speller_roof)
