@@ -39,7 +39,9 @@ struct PblstmBwdLayout {
 };
 
 struct SpellerLayout {
-    size_t y_all, ctx_all, h_all, c_all, gates_all, q_all, w0p, ctxcat_all, hx, r0x, lgx, wperm, wyperm, bperm, yw, pctx, gx, bqp, bfl, blg, beg, qct, wyT, plx, total;
+    size_t y_all, ctx_all, h_all, c_all, gates_all, q_all, w0p, ctxcat_all, hx, r0x, lgx, wperm, wyperm, bperm, yw, pctx, gx, bqp, bfl, blg, beg, qct, wyT, plx,
+        mperm, pbias, p0, total;
+    bool pre_mh;               // ... its multi-head form (heads 2..4): P, gx per head, the folded matrices W_ctx W_dr[:, h]
     bool big;                  // room for the one-launch decode of the Hs = 1024 shape (speller_big.hip)
     bool pre;                  // room for the persistent decode kernel's pre-multiplied context variant
     int Vp;                    // label width padded to a multiple of 16: every cell operand is aligned and tail-free
@@ -58,15 +60,22 @@ struct SpellerLayout {
         // pre-multiplied context variant: row-permuted W_ctx, feat . W_ctx^T, and the per-step hand-off slabs of its weighted sums
         // (r0x directly behind hx: one sentinel fill covers both)
         pre = speller_persist_pre_shape(d->B, d->Tp, d->Hs, d->D, d->M, d->V, d->L, d->multi_head, d->use_mlp);
+        pre_mh = speller_persist_pre_mh_shape(d->B, d->Tp, d->Hs, d->D, d->M, d->V, d->L, d->multi_head, d->use_mlp);
+        const bool anypre = pre || pre_mh;
+        const size_t NHp = pre_mh ? d->multi_head : 1;
         hx = o; if (d->L == 2) o += r4((size_t)2 * U * 32 * d->Hs);   // hand-off copy of h for the persistent decode kernel
-        r0x = o; if (pre) o += r4((size_t)U * 32 * 4 * d->Hs);        // ... and the cell workgroups' part of the bottom-layer gates
-        gx = o; if (pre) o += r4((size_t)U * B * 4 * d->Hs);
+        r0x = o; if (anypre) o += r4((size_t)U * 32 * 4 * d->Hs);     // ... and the cell workgroups' part of the bottom-layer gates
+        gx = o; if (anypre) o += r4((size_t)U * B * NHp * 4 * d->Hs);
         lgx = o; if (d->L == 2) o += r4((size_t)U * B * 8 * 32);      // ... and its partial logits (free-running decode)
-        wperm = o; if (pre) o += r4((size_t)4 * d->Hs * d->Hs);
-        wyperm = o; if (pre) o += r4((size_t)4 * d->Hs * Vp);      // W_y rows and b_ih0 + b_hh0 in the same row order ...
-        bperm = o; if (pre) o += r4((size_t)4 * d->Hs);
-        yw = o; if (pre) o += r4((size_t)U * B * 4 * d->Hs);       // ... and y_s W_y^T + b for every step (label half of the bottom-layer gates)
-        pctx = o; if (pre) o += r4((size_t)B * d->Tp * 4 * d->Hs);
+        wperm = o; if (anypre) o += r4((size_t)4 * d->Hs * d->Hs);
+        wyperm = o; if (anypre) o += r4((size_t)4 * d->Hs * Vp);   // W_y rows and b_ih0 + b_hh0 in the same row order ...
+        bperm = o; if (anypre) o += r4((size_t)4 * d->Hs);
+        yw = o; if (anypre) o += r4((size_t)U * B * 4 * d->Hs);    // ... and y_s W_y^T + b for every step (label half of the bottom-layer gates)
+        pctx = o; if (anypre) o += r4((size_t)B * d->Tp * NHp * 4 * d->Hs);
+        // multi-head: (W_ctx W_dr[:, h]) stacked over the heads (NH*4Hs, D), the bias of P's head-0 block (W_ctx b_dr, then zeros), feat[:, 0] . W_ctx^T
+        mperm = o; if (pre_mh) o += r4(NHp * 4 * d->Hs * d->D);
+        pbias = o; if (pre_mh) o += r4(NHp * 4 * d->Hs);
+        p0 = o; if (pre_mh) o += r4(B * 4 * d->Hs);
         // free-running form of the PRE kernel (arg-max feedback, no backward): Q^T = W_c[:, Hs:] feat^T, W_y^T (permuted columns), partial-logit slabs
         qct = o; if (pre) o += r4((size_t)B * 32 * d->Tp);
         wyT = o; if (pre) o += r4((size_t)Vp * 4 * d->Hs);
@@ -386,6 +395,10 @@ int las_speller_decode_batch(const las_speller_desc* d, int teacher_forced, int 
         return 16;
     if (opt_get(OPT_SPELLER_PERSIST) == 0 || (!teacher_forced && decode_mode == 2)) return 0;
     constexpr int NB = 32;      // the persistent kernels' utterance limit (two 16-row M tiles)
+    if (d->multi_head > 1) {    // one set of attention workgroups per (utterance, head): 32 / heads utterances per launch, teacher forcing
+        const int nb = NB / d->multi_head;
+        return (teacher_forced && nb > 0 && speller_persist_pre_mh_eligible(nb, d->Tp, d->Hs, d->D, d->M, d->V, d->L, d->multi_head, d->use_mlp)) ? nb : 0;
+    }
     return speller_persist_eligible(NB, d->Tp, d->Hs, d->D, d->M, d->V, d->L, d->multi_head, d->use_mlp, !teacher_forced) ? NB : 0;
 }
 
@@ -450,8 +463,11 @@ int las_speller_fwd(const las_speller_desc* d, const float* feat, const float* k
                       !(flags & LAS_FLAG_FORCE_GENERIC) && d->relu <= LAS_ACT_RELU && logp &&
                       speller_persist_pre_greedy_eligible(B, Tp, Hs, D, d->M, V, L, d->multi_head, d->use_mlp);
     const bool pre_stash = tf_like && lay.pre && ((flags & LAS_FLAG_STASH) || pre || preg);
-    LAS_TRY(speller_prologue(d->w_ih[0], w0p, Hs, V, Vp, (pre_stash || preg) ? reserve + lay.wperm : nullptr, (pre || preg) ? reserve + lay.wyperm : nullptr,
-                             (pre || preg) ? reserve + lay.bperm : nullptr, d->b_ih[0], d->b_hh[0],
+    // ... and its multi-head form (heads 2..4, teacher forcing): one set of attention workgroups per (utterance, head), dim_reduce folded into P
+    const bool pre_mh = persist_on && err_word && !(flags & LAS_FLAG_FORCE_GENERIC) && teacher_forced && d->relu <= LAS_ACT_RELU && lay.pre_mh &&
+                        speller_persist_pre_mh_eligible(B, Tp, Hs, D, d->M, V, L, d->multi_head, d->use_mlp);
+    LAS_TRY(speller_prologue(d->w_ih[0], w0p, Hs, V, Vp, (pre_stash || preg || pre_mh) ? reserve + lay.wperm : nullptr, (pre || preg || pre_mh) ? reserve + lay.wyperm : nullptr,
+                             (pre || preg || pre_mh) ? reserve + lay.bperm : nullptr, d->b_ih[0], d->b_hh[0],
                              teacher_forced ? (const long long*)labels_onehot : nullptr, y_all, B, U, U_lab, feat, (long)Tp * D, ctx_all, D, stream));
     // the PRE kernel's hand-off slabs (50 MB of sentinel words at paper size) are filled on the side stream, beside the two GEMMs below
     SideStream& side = side_stream();
@@ -475,6 +491,76 @@ int las_speller_fwd(const las_speller_desc* d, const float* feat, const float* k
     bool persist_ran = persist || preg;
     bool pre_ran = false;           // a PRE kernel ran AND the contexts of every step are wanted: they are recovered by one GEMM below
     bool gx_written = false;        // ... a PRE kernel ran: the per-step sums gx are in the reserve already
+    if (pre_mh) {
+        // Multi-head attention on the PRE kernel (las_model.py:298-314).  context_s = W_dr cat_h(ctx^h_s) + b_dr enters the bottom cell as
+        // W_ctx context_s = sum_h sum_t a^h_{s,t} (feat_t M_h^T) + W_ctx b_dr with M_h = W_ctx W_dr[:, h D:(h+1) D]: the same pre-multiplied
+        // form as the single head, one P block per head; W_ctx b_dr rides as a bias of head 0's block (its weights sum to 1)
+        const int NH = d->multi_head;
+        float* wperm = reserve + lay.wperm; float* mperm = reserve + lay.mperm; float* pbias = reserve + lay.pbias; float* p0 = reserve + lay.p0;
+        {
+            GemmDesc g;      // M_h (4Hs x D) for every head: one batched launch
+            g.A = wperm; g.lda = Hs; g.a_kc = true; g.sA = 0;
+            g.B = d->w_dr; g.ldb = (long)NH * D; g.b_kc = false; g.sB = D;
+            g.C = mperm; g.ldc = D; g.sC = (long)4 * Hs * D;
+            g.M = 4 * Hs; g.N = D; g.K = Hs; g.batch = NH; g.splitk = 1;
+            LAS_TRY(gemm_f32(g, stream));
+        }
+        LAS_HIP_CHECK(hipMemsetAsync(pbias, 0, sizeof(float) * (size_t)NH * 4 * Hs, stream));
+        LAS_TRY(matvec_rows(wperm, Hs, d->b_dr, pbias, 4 * Hs, Hs, stream));
+        {
+            GemmDesc g;      // P (B*T', NH*4Hs)
+            g.A = feat; g.lda = D; g.a_kc = true;
+            g.B = mperm; g.ldb = D; g.b_kc = true; g.bias0 = pbias;
+            g.C = reserve + lay.pctx; g.ldc = (long)NH * 4 * Hs; g.M = B * Tp; g.N = NH * 4 * Hs; g.K = D; g.splitk = 1;
+            LAS_TRY(gemm_f32(g, stream));
+        }
+        {
+            GemmDesc g;      // step 0: the context is the first listener frame itself (las_model.py:198), no dim_reduce
+            g.A = feat; g.lda = (long)Tp * D; g.a_kc = true;
+            g.B = wperm; g.ldb = Hs; g.b_kc = true;
+            g.C = p0; g.ldc = 4 * Hs; g.M = B; g.N = 4 * Hs; g.K = D; g.splitk = 1;
+            LAS_TRY(gemm_f32(g, stream));
+        }
+        {
+            GemmDesc g;      // label half of the bottom-layer gates for every step
+            g.A = y_all; g.lda = Vp; g.a_kc = true;
+            g.B = reserve + lay.wyperm; g.ldb = Vp; g.b_kc = true; g.bias0 = reserve + lay.bperm;
+            g.C = reserve + lay.yw; g.ldc = 4 * Hs; g.M = U * B; g.N = 4 * Hs; g.K = Vp; g.splitk = 1;
+            LAS_TRY(gemm_f32(g, stream));
+        }
+        PersistFwd p;
+        p.NH = NH; p.p0 = p0;
+        p.pctx = reserve + lay.pctx; p.gx = reserve + lay.gx; p.r0x = reserve + lay.r0x; p.yw = reserve + lay.yw;
+        p.w0p = w0p; p.Vp = Vp;
+        p.w_hh0 = d->w_hh[0]; p.w_ih1 = d->w_ih[1]; p.w_hh1 = d->w_hh[1];
+        p.b_ih0 = d->b_ih[0]; p.b_hh0 = d->b_hh[0]; p.b_ih1 = d->b_ih[1]; p.b_hh1 = d->b_hh[1];
+        p.w_phi = d->w_phi; p.b_phi = d->b_phi;
+        p.feat = feat; p.keys = keys; p.y_all = y_all;
+        p.ctx_all = ctx_all; p.h_all = h_all; p.c_all = c_all; p.gates_all = gates_all; p.q_all = q_all; p.att = att;
+        p.B = B; p.Tp = Tp; p.U = U; p.Hs = Hs; p.V = V; p.relu = d->relu;
+        p.hx = reserve + lay.hx;
+        p.err = err_word;
+        const int rc = speller_persist_fwd(p, stream);
+        if (rc != LAS_ERR_UNSUPPORTED) {
+            LAS_TRY(rc);
+            persist_ran = true;
+            // per-head contexts (the dim_reduce input, stashed for the backward), then the reduced context of every step
+            float* ctxcat = reserve + lay.ctxcat_all;
+            for (int hd = 0; hd < NH; ++hd) {
+                GemmDesc g;
+                g.A = att + (size_t)hd * B * Tp; g.lda = (long)NH * B * Tp; g.a_kc = true; g.sA = Tp;
+                g.B = feat; g.ldb = D; g.b_kc = false; g.sB = (long)Tp * D;
+                g.C = ctxcat + (size_t)hd * D; g.ldc = (long)B * NH * D; g.sC = (long)NH * D;
+                g.M = U; g.N = D; g.K = Tp; g.batch = B; g.splitk = 1;
+                LAS_TRY(gemm_f32(g, stream));
+            }
+            GemmDesc q;
+            q.A = ctxcat; q.lda = (long)NH * D; q.a_kc = true;
+            q.B = d->w_dr; q.ldb = (long)NH * D; q.b_kc = true; q.bias0 = d->b_dr;
+            q.C = ctx_all + (size_t)B * D; q.ldc = D; q.M = U * B; q.N = D; q.K = NH * D; q.splitk = 1;
+            LAS_TRY(gemm_f32(q, stream));
+        }
+    }
     if (persist || preg) {
         PersistFwd p;
         p.prefilled = side_fill;

@@ -188,6 +188,9 @@ struct PersistFwd {
     // PRE variant with mode 1 (free-running arg-max feedback, speller_persist_pre_greedy_eligible): Q^T = W_c[:, Hs:] feat^T (B, 32, Tp), W_y^T in
     // the permuted gate-column order (Vp, 4Hs), and U*(Hs/4)*512 floats of partial-logit slabs
     const float* qct = nullptr; const float* wyT = nullptr; float* plx = nullptr;
+    // PRE variant with NH > 1 attention heads (speller_persist_pre_mh_eligible; teacher forcing): pctx is (B*Tp, NH*4Hs), gx U*B*NH*4Hs floats (stash and the
+    // heads' exchange slab), p0 = feat[:, 0] . W_ctx^T (B, 4Hs); q_all is (U*B, NH*M), att [U][NH][B][Tp] as the per-step kernels lay them out
+    int NH = 1; const float* p0 = nullptr;
     int B, Tp, U, Hs, V, relu;
     unsigned* err;
     bool prefilled = false;                         // the caller has sentinel-filled the hand-off slabs already (speller_persist_fwd_fill)
@@ -198,6 +201,8 @@ int speller_persist_pre_ws(int B, int Tp, int Hs, int cus);   // attention workg
 bool speller_persist_pre_shape(int B, int Tp, int Hs, int D, int M, int V, int L, int heads, int use_mlp);   // shape only (sizes the reserve)
 bool speller_persist_pre_eligible(int B, int Tp, int Hs, int D, int M, int V, int L, int heads, int use_mlp);   // shape + residency
 bool speller_persist_pre_greedy_eligible(int B, int Tp, int Hs, int D, int M, int V, int L, int heads, int use_mlp);   // ... of its free-running (mode 1) form
+bool speller_persist_pre_mh_shape(int B, int Tp, int Hs, int D, int M, int V, int L, int heads, int use_mlp);      // ... of its multi-head form (heads 2..4): shape only
+bool speller_persist_pre_mh_eligible(int B, int Tp, int Hs, int D, int M, int V, int L, int heads, int use_mlp);   // ... shape + switches + residency
 int speller_persist_fwd(const PersistFwd& p, hipStream_t stream);
 void speller_persist_set_trace(unsigned long long* dev_buf);   // profiling aid, see tools/ubench_persist_trace.py
 
@@ -313,6 +318,7 @@ int build_w0p(const float* w_ih0, float* w0p, int Hs, int V, int Vp, hipStream_t
               float* wyperm = nullptr, float* bperm = nullptr, const float* b_ih0 = nullptr, const float* b_hh0 = nullptr);
 int labels_to_y(const long long* labels, float* y_all, int B, int U, int V, int Vp, int u_lab, hipStream_t stream);
 // build_w0p + labels_to_y + ctx_{-1} = feat[:,0,:] in one launch (the Speller forward's element-wise preparations)
+int matvec_rows(const float* w, long ld, const float* x, float* out, int rows, int K, hipStream_t stream);      // out[r] = w[r, :] . x
 int speller_prologue(const float* w_ih0, float* w0p, int Hs, int V, int Vp, float* wperm, float* wyperm, float* bperm, const float* b_ih0,
                      const float* b_hh0, const long long* labels, float* y_all, int B, int U, int u_lab, const float* feat, long ldfeat,
                      float* ctx0, int D, hipStream_t stream);

@@ -39,6 +39,7 @@ enum Opt : int {
     OPT_TIME_KERNELS,           // record HIP events around the persistent decode kernels (las_debug_kernel_ms reads them)
     OPT_GEMM_BIG,               // 256 x 256 tiles (gemm_big.hip) where they fill the chip: 1 automatic, 0 never, 2 whenever the shape allows (A/B)
     OPT_SPELLER_PRE_GREEDY,     // free-running (arg-max feedback) decode without a backward pass on the pre-multiplied-context kernel
+    OPT_SPELLER_PRE_MH,         // multi-head attention (heads 2..4, teacher forcing) on the pre-multiplied-context kernels
     OPT_COUNT
 };
 

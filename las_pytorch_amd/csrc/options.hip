@@ -20,7 +20,7 @@ const OptDef kDefs[OPT_COUNT] = {
     {"REC_UW", 0}, {"REC_AGENT_HANDOFF", 0}, {"REC_NB", 0}, {"REC_PIPE", 1}, {"REC_MFMA", 1}, {"REC_TRACE", 0}, {"CELL_MT", 0},
     {"GEMM_SK_FIXUP", 0}, {"GEMM_SKF_MIN_KT", -1}, {"GEMM_SKF_MIN_RUN", -1},
     {"SIDE_FILLS", 0}, {"TRUST_ZEROED_GRADS", 1}, {"SPELLER_BIG", 1}, {"SPELLER_BIG_BWD", 1}, {"SPELLER_BIG_TUNE", 0},
-    {"TIME_KERNELS", 0}, {"GEMM_BIG", 1}, {"SPELLER_PRE_GREEDY", 1},
+    {"TIME_KERNELS", 0}, {"GEMM_BIG", 1}, {"SPELLER_PRE_GREEDY", 1}, {"SPELLER_PRE_MH", 1},
 };
 std::atomic<long> g_val[OPT_COUNT];
 std::atomic<int> g_init{0};

@@ -52,6 +52,10 @@ struct PersistArgs {
     // PRE variant, free-running (mode 1): Q^T = W_c[:, Hs:] feat^T per utterance (B, 32, Tp); W_y^T in the permuted gate-column order
     // (Vp, 4Hs); partial logits W_c[:, units] h1 of every cell workgroup, [U][Hs/4][16 utterances][32], sentinel-prefilled
     const float* qct; const float* wyT; float* plx;
+    // PRE variant, multi-head (heads = NH > 1, teacher forcing; las_model.py:298-314): pctx is (B*Tp, NH*4Hs) — head h's block is
+    // feat . (W_ctx W_dr[:, h])^T, head 0's carrying W_ctx b_dr as a bias (the attention weights sum to 1) — gx is [U][B][NH][4Hs] and doubles as
+    // the heads' exchange slab (sentinel-prefilled, agent-scope stores); p0 = feat[:, 0] . W_ctx^T (B, 4Hs) is the step-0 context product
+    int NH; const float* p0;
     int B, Tp, U, relu;
     int split;                     // attention workgroups per utterance (each owns D/split context columns)
     unsigned* err;
@@ -944,8 +948,9 @@ struct AttnRole {
 // share arrives as 64 partial tiles from the cell workgroups (CellPreRole), the context share is sum_t a_t Q_t with Q = feat W_c[:, Hs:]^T
 // resident in LDS (the context itself never exists on the chain) — every wave picks the arg-max itself, and the bottom cell's lanes fetch the
 // symbol's W_y column (2 KB per workgroup from the L2: the one dependent load this mode adds to the chain).
-template <int HS, int WS, bool GREEDY = false>
+template <int HS, int WS, bool GREEDY = false, bool MH = false>
 struct AttnPreRole {
+    static_assert(!(GREEDY && MH), "the free-running form is single-head");
     static constexpr int SPLIT = WS;                     // workgroups per utterance: 4, 8 or 16 (longer T' at smaller batches)
     static constexpr int GC = 4 * HS / SPLIT;            // gate columns of this workgroup
     static constexpr int CG = GC / 4;                    // column groups (one float4 each)
@@ -964,7 +969,11 @@ struct AttnPreRole {
     static __host__ __device__ constexpr int lds_floats(int Tp) { return lds_base(Tp) + (GREEDY ? 32 * MAX_TP + 32 * NJ8 + 64 : 0); }
 
     static __device__ void run(const PersistArgs& a, float* smem, const int widx) {
-        const int b = widx / SPLIT, part_id = widx % SPLIT;
+        // MH: one set of SPLIT workgroups per (utterance, head) — query rows, softmax and P block of that head; the heads' weighted sums meet
+        // through gx before the bottom cell, which every head's workgroup applies (identical arithmetic) and head 0 publishes
+        const int NH = MH ? a.NH : 1;
+        const int pu = widx / SPLIT, part_id = widx % SPLIT;
+        const int b = MH ? pu / NH : pu, hd = MH ? pu % NH : 0;
         const int col0 = part_id * GC;
         const bool first_wg = widx == 0;
         const int tid = threadIdx.x, lane = tid & 63;
@@ -984,7 +993,7 @@ struct AttnPreRole {
 #pragma unroll
         for (int i = 0; i < NIP; ++i) {
             const int t = ts + TS * i;
-            const f32x4 v = ld4p(a.pctx + ((size_t)b * Tp + (t < Tp ? t : 0)) * (4 * HS) + col0 + cg * 4);
+            const f32x4 v = ld4p(a.pctx + (((size_t)b * Tp + (t < Tp ? t : 0)) * NH + hd) * (4 * HS) + col0 + cg * 4);
             pr[i] = t < Tp ? v : zero;
         }
         if (tid >= Tp && tid < MAX_TP) as[tid] = 0.f;         // frames past T' carry zero weight (MAX_TP <= 448 < threads)
@@ -999,11 +1008,11 @@ struct AttnPreRole {
         f32x4 wphi[NJR];
         float* wpl = ks + Tp * PS_KLD;
 #pragma unroll
-        for (int j = 0; j < NJR; ++j) wphi[j] = ld4p(a.w_phi + (size_t)prow * HS + 4 * (pk + 16 * j));
+        for (int j = 0; j < NJR; ++j) wphi[j] = ld4p(a.w_phi + (size_t)(hd * PS_M + prow) * HS + 4 * (pk + 16 * j));
 #pragma unroll
         for (int j = NJR; j < NJ; ++j)
-            *reinterpret_cast<f32x4*>(wpl + prow * (64 * (NJ - NJR)) + 4 * (pk + 16 * (j - NJR))) = ld4p(a.w_phi + (size_t)prow * HS + 4 * (pk + 16 * j));
-        const float bphi = a.b_phi[prow];
+            *reinterpret_cast<f32x4*>(wpl + prow * (64 * (NJ - NJR)) + 4 * (pk + 16 * (j - NJR))) = ld4p(a.w_phi + (size_t)(hd * PS_M + prow) * HS + 4 * (pk + 16 * j));
+        const float bphi = a.b_phi[hd * PS_M + prow];
         // GREEDY: Q^T of this utterance [v][t] (zero past V / T'), the staging area of the partial logits [v][tile], the step's logits
         float* qt = smem + lds_base(Tp);
         float* plv = qt + 32 * MAX_TP;
@@ -1066,6 +1075,7 @@ struct AttnPreRole {
             const float ig = sigmoidf_acc(g4[0] + r[0]), fg = sigmoidf_acc(g4[1] + r[1]), gg = tanhf_acc(g4[2] + r[2]), og = sigmoidf_acc(g4[3] + r[3]);
             c0 = fg * c0 + ig * gg;
             const float h = og * tanhf_acc(c0);
+            if (MH && hd != 0) return;                               // (the other heads only carry the cell state along)
             const unsigned o = opaque(4u * ((unsigned)b * HS + unit));
             st1_agent(at_bytes(a.hx + (size_t)s * HXS, o), h);       // hand-off to the cell workgroups: a wave writes 256 contiguous bytes
             *at_bytes(a.h_all + (size_t)s * sH, o) = h;              // stash for the backward pass
@@ -1104,7 +1114,7 @@ struct AttnPreRole {
             unsigned rv0[4];
             r0_issue(0, rv0);
             r0_land(0, rv0);
-            if (clane) *reinterpret_cast<f32x4*>(gxl + cg * 4) = pr[0];
+            if (clane) *reinterpret_cast<f32x4*>(gxl + cg * 4) = MH ? ld4p(a.p0 + (size_t)b * (4 * HS) + col0 + cg * 4) : pr[0];
             lds_barrier();
             bottom_cell(0);
         }
@@ -1141,7 +1151,7 @@ struct AttnPreRole {
                     acc += bphi;
                     if (a.relu) acc = fmaxf(acc, 0.f);
                     qs[prow] = acc;
-                    if (part_id == 0) *at_bytes(a.q_all + ((size_t)s * B + b) * PS_M, opaque(4u * (unsigned)prow)) = acc;
+                    if (part_id == 0) *at_bytes(a.q_all + (((size_t)s * B + b) * NH + hd) * PS_M, opaque(4u * (unsigned)prow)) = acc;
                 }
             }
             lds_barrier();
@@ -1178,7 +1188,7 @@ struct AttnPreRole {
             if (tid < Tp) {
                 const float w = __builtin_amdgcn_exp2f((es[tid] - mx) * 1.4426950408889634f) * inv;
                 as[tid] = w;
-                if (part_id == 0) *at_bytes(a.att + ((size_t)s * B + b) * Tp, opaque(4u * (unsigned)tid)) = w;
+                if (part_id == 0) *at_bytes(a.att + (((size_t)s * NH + hd) * B + b) * Tp, opaque(4u * (unsigned)tid)) = w;
             }
             if (GREEDY) pl_land(s, pv);          // (visible to every wave behind the barrier)
             lds_barrier();
@@ -1239,10 +1249,31 @@ struct AttnPreRole {
                     }
                 }
                 // stash for the backward pass (its softmax-backward statistic reuses this sum): off the chain, plain stores
-                float* dst = a.gx + ((size_t)s * B + b) * (4 * HS) + col0;
-                if (clane) {
-                    *reinterpret_cast<f32x4*>(at_bytes(dst, opaque(16u * (unsigned)cg))) = acc;
-                    *reinterpret_cast<f32x4*>(gxl + cg * 4) = acc;
+                float* dst = a.gx + (((size_t)s * B + b) * NH + hd) * (4 * HS) + col0;
+                if (!MH) {
+                    if (clane) {
+                        *reinterpret_cast<f32x4*>(at_bytes(dst, opaque(16u * (unsigned)cg))) = acc;
+                        *reinterpret_cast<f32x4*>(gxl + cg * 4) = acc;
+                    }
+                } else if (clane) {
+                    // the heads' sums meet here: publish this head's (agent scope; the slab is the backward's stash as well), collect the others'
+                    // and add them in head order, so that every head's workgroup holds bit-identical gate pre-activations
+                    st4_agent(at_bytes(dst, opaque(16u * (unsigned)cg)), acc);
+                    f32x4 tot = zero;
+                    for (int h2 = 0; h2 < NH; ++h2) {
+                        f32x4 v = acc;
+                        if (h2 != hd) {
+                            const float* src = at_bytes(a.gx + (((size_t)s * B + b) * NH + h2) * (4 * HS) + col0, opaque(16u * (unsigned)cg));
+                            unsigned spins = 0;
+                            for (;;) {
+                                v = ld4_agent(src);
+                                if (!has_sentinel(v)) break;
+                                if (spin_expired(spins, a.err, 0xDEAD0017u)) break;
+                            }
+                        }
+                        tot[0] += v[0]; tot[1] += v[1]; tot[2] += v[2]; tot[3] += v[3];
+                    }
+                    *reinterpret_cast<f32x4*>(gxl + cg * 4) = tot;
                 }
             }
             // ---- bottom cell of step s+1 and its hand-off to the top layer
@@ -1268,11 +1299,11 @@ struct AttnPreRole {
     }
 };
 
-template <int HS, int WS, bool GREEDY>
+template <int HS, int WS, bool GREEDY, bool MH = false>
 __global__ __launch_bounds__(PS_THREADS) void speller_persist_fwd_pre_kernel(PersistArgs a) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     constexpr int NC = HS / 4;
-    if ((int)blockIdx.x >= NC) AttnPreRole<HS, WS, GREEDY>::run(a, smem, blockIdx.x - NC);
+    if ((int)blockIdx.x >= NC) AttnPreRole<HS, WS, GREEDY, MH>::run(a, smem, blockIdx.x - NC);
     else CellPreRole<HS, GREEDY>::run(a, smem);
 }
 
@@ -1339,14 +1370,19 @@ template <int HS, int WS, bool GREEDY = false>
 static size_t persist_fwd_pre_smem(int Tp) {
     return sizeof(float) * (size_t)std::max(CellPreRole<HS, GREEDY>::LDS_FLOATS, AttnPreRole<HS, WS, GREEDY>::lds_floats(Tp));
 }
-template <int HS, int WS, bool GREEDY = false>
+template <int HS, int WS, bool GREEDY = false, bool MH = false>
 static bool persist_fwd_pre_fits(int Tp, int grid) {
     const size_t smem = persist_fwd_pre_smem<HS, WS, GREEDY>(Tp);
     if (smem > 160 * 1024) return false;
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&speller_persist_fwd_pre_kernel<HS, WS, GREEDY>), hipFuncAttributeMaxDynamicSharedMemorySize,
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&speller_persist_fwd_pre_kernel<HS, WS, GREEDY, MH>), hipFuncAttributeMaxDynamicSharedMemorySize,
                             (int)smem) != hipSuccess)
         return false;
-    return persistent_launch_fits(speller_persist_fwd_pre_kernel<HS, WS, GREEDY>, PS_THREADS, smem, grid);
+    return persistent_launch_fits(speller_persist_fwd_pre_kernel<HS, WS, GREEDY, MH>, PS_THREADS, smem, grid);
+}
+static bool persist_fwd_pre_mh_fits_rt(int Hs, int ws, int Tp, int grid) {
+    if (Hs == 512) return ws == 4 ? persist_fwd_pre_fits<512, 4, false, true>(Tp, grid) : ws == 8 ? persist_fwd_pre_fits<512, 8, false, true>(Tp, grid)
+                                                                                                  : persist_fwd_pre_fits<512, 16, false, true>(Tp, grid);
+    return ws == 4 ? persist_fwd_pre_fits<256, 4, false, true>(Tp, grid) : persist_fwd_pre_fits<256, 8, false, true>(Tp, grid);
 }
 static bool persist_fwd_pre_fits_rt(int Hs, int ws, int Tp, int grid, bool greedy = false) {
     if (greedy) {      // free-running instantiations: 4 or 8 attention workgroups per utterance (T' <= 224; beyond that Q^T does not fit the LDS)
@@ -1369,6 +1405,24 @@ bool speller_persist_pre_eligible(int B, int Tp, int Hs, int D, int M, int V, in
     if (ws == 0) return false;
     return persist_fwd_pre_fits_rt(Hs, ws, Tp, Hs / 4 + ws * B);
 }
+// Multi-head attention (heads 2..4, teacher forcing; reference las_model.py:298-314) on the same kernel: one set of attention workgroups per
+// (utterance, head), so B * heads takes the place of B in the workgroup budget (heads = 2: 16 utterances per launch at T' <= 112)
+bool speller_persist_pre_mh_shape(int B, int Tp, int Hs, int D, int M, int V, int L, int heads, int use_mlp) {
+    if (L != 2 || heads < 2 || heads > 4 || !use_mlp || M != PS_M || D != Hs) return false;
+    if (Hs != 256 && Hs != 512) return false;
+    if (B < 1 || B * heads > 32 || ((V + 15) & ~15) > 32) return false;
+    return speller_persist_pre_ws(B * heads, Tp, Hs, -1) != 0;
+}
+bool speller_persist_pre_mh_eligible(int B, int Tp, int Hs, int D, int M, int V, int L, int heads, int use_mlp) {
+    if (opt_get(OPT_SPELLER_PRE) == 0 || opt_get(OPT_SPELLER_PRE_MH) == 0) return false;
+    if (!speller_persist_pre_mh_shape(B, Tp, Hs, D, M, V, L, heads, use_mlp)) return false;
+    int cus = 0, dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess)
+        return false;
+    const int ws = speller_persist_pre_ws(B * heads, Tp, Hs, cus);
+    if (ws == 0) return false;
+    return persist_fwd_pre_mh_fits_rt(Hs, ws, Tp, Hs / 4 + ws * B * heads);
+}
 // ... and its free-running (decode_mode 1: fed-back arg-max) form: the same structure with the character distribution inside the attention
 // workgroups (AttnPreRole<.., GREEDY>); forward only — a stashing forward (free-running training step) keeps the classic kernels, whose
 // backward needs the context the PRE forward never forms on the chain
@@ -1383,14 +1437,14 @@ bool speller_persist_pre_greedy_eligible(int B, int Tp, int Hs, int D, int M, in
     return persist_fwd_pre_fits_rt(Hs, ws, Tp, Hs / 4 + ws * B, true);
 }
 
-template <int HS, int WS, bool GREEDY = false>
+template <int HS, int WS, bool GREEDY = false, bool MH = false>
 static int launch_persist_fwd_pre(const PersistArgs& a, int grid, hipStream_t stream) {
     const size_t smem = persist_fwd_pre_smem<HS, WS, GREEDY>(a.Tp);
-    if (!persist_fwd_pre_fits<HS, WS, GREEDY>(a.Tp, grid))
+    if (!persist_fwd_pre_fits<HS, WS, GREEDY, MH>(a.Tp, grid))
         return fail(LAS_ERR_UNSUPPORTED, "persistent decode kernel: %s%ld workgroups cannot all be resident", "", (long)grid);
     {
         KernelTimer timer(TIMED_DECODE_FWD, stream);
-        hipLaunchKernelGGL((speller_persist_fwd_pre_kernel<HS, WS, GREEDY>), dim3(grid), dim3(PS_THREADS), smem, stream, a);
+        hipLaunchKernelGGL((speller_persist_fwd_pre_kernel<HS, WS, GREEDY, MH>), dim3(grid), dim3(PS_THREADS), smem, stream, a);
     }
     LAS_LAUNCH_CHECK();
     path_note(PATH_DECODE_FWD, GREEDY ? "persist_pre_greedy" : "persist_pre");
@@ -1431,6 +1485,7 @@ int speller_persist_fwd_fill(const PersistFwd& p, hipStream_t stream) {
 }
 
 int speller_persist_fwd(const PersistFwd& p, hipStream_t stream) {
+    LAS_REQUIRE(p.NH >= 1, "attention heads");
     LAS_REQUIRE(p.pctx != nullptr || speller_persist_eligible(p.B, p.Tp, p.Hs, p.Hs, PS_M, p.V, 2, 1, 1, p.mode != 0), "persistent speller shape");
     LAS_REQUIRE(p.mode >= 0 && p.mode <= 2, "persistent speller mode");
     LAS_REQUIRE(p.mode == 0 || (p.w_c && p.b_c && p.logp && (p.lgx || p.pctx)), "free-running decode needs the character distribution");
@@ -1448,7 +1503,24 @@ int speller_persist_fwd(const PersistFwd& p, hipStream_t stream) {
     a.trace = g_persist_trace;
     a.pctx = p.pctx; a.gx = p.gx; a.r0x = p.r0x; a.yw = p.yw;
     a.qct = p.qct; a.wyT = p.wyT; a.plx = p.plx;
+    a.NH = p.NH; a.p0 = p.p0;
     LAS_REQUIRE(p.err != nullptr, "the persistent speller needs the device error word");
+    if (p.pctx && p.NH > 1) {      // multi-head form of the pre-multiplied context variant (the caller checked speller_persist_pre_mh_eligible)
+        int cus = 0, dev = 0;
+        LAS_HIP_CHECK(hipGetDevice(&dev));
+        LAS_HIP_CHECK(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
+        const int ws = speller_persist_pre_ws(p.B * p.NH, p.Tp, p.Hs, cus);
+        LAS_REQUIRE(p.mode == 0 && p.gx && p.r0x && p.yw && p.p0 && ws != 0 &&
+                    speller_persist_pre_mh_shape(p.B, p.Tp, p.Hs, p.Hs, PS_M, p.V, 2, p.NH, 1), "persistent speller (pre, multi-head) shape");
+        a.split = ws;
+        if (!p.prefilled) LAS_TRY(speller_persist_fwd_fill(p, stream));
+        LAS_HIP_CHECK(hipMemsetAsync(p.gx, 0xFF, sizeof(float) * (size_t)p.U * p.B * p.NH * 4 * p.Hs, stream));      // the heads' exchange slab
+        const int grid = p.Hs / 4 + ws * p.B * p.NH;
+        if (p.Hs == 512)
+            return ws == 4 ? launch_persist_fwd_pre<512, 4, false, true>(a, grid, stream)
+                           : ws == 8 ? launch_persist_fwd_pre<512, 8, false, true>(a, grid, stream) : launch_persist_fwd_pre<512, 16, false, true>(a, grid, stream);
+        return ws == 4 ? launch_persist_fwd_pre<256, 4, false, true>(a, grid, stream) : launch_persist_fwd_pre<256, 8, false, true>(a, grid, stream);
+    }
     if (p.pctx) {      // pre-multiplied context variant (the caller checked speller_persist_pre_eligible)
         int cus = 0, dev = 0;
         LAS_HIP_CHECK(hipGetDevice(&dev));
