@@ -115,6 +115,8 @@ struct SpellerBwdLayout {
         // persistent backward kernel: the attention workgroups' dqpre parts and the sentinel-prefilled hand-off slabs
         pxbuf = o;
         if (d->L == 2 && d->multi_head == 1 && d->use_mlp) o += r4(speller_persist_bwd_workspace_floats(d->B, d->Tp, U, d->Hs, d->M));
+        else if (speller_persist_pre_mh_shape(d->B, d->Tp, d->Hs, d->D, d->M, d->V, d->L, d->multi_head, d->use_mlp))
+            o += r4(speller_persist_bwd_mh_workspace_floats(d->B, d->Tp, U, d->Hs, d->M, d->multi_head));
         // Hs = 1024 one-launch backward (speller_big.hip): gate-gradient slabs, carries, slice triples, flags
         bxbuf = o;
         if (speller_big_shape(d->B, d->Tp, d->Hs, d->D, d->M, d->V, d->L, d->multi_head, d->use_mlp)) o += r4(speller_big_bwd_workspace_floats(d->B, U));
@@ -466,7 +468,11 @@ int las_speller_fwd(const las_speller_desc* d, const float* feat, const float* k
     // ... and its multi-head form (heads 2..4, teacher forcing): one set of attention workgroups per (utterance, head), dim_reduce folded into P
     const bool pre_mh = persist_on && err_word && !(flags & LAS_FLAG_FORCE_GENERIC) && teacher_forced && d->relu <= LAS_ACT_RELU && lay.pre_mh &&
                         speller_persist_pre_mh_eligible(B, Tp, Hs, D, d->M, V, L, d->multi_head, d->use_mlp);
-    LAS_TRY(speller_prologue(d->w_ih[0], w0p, Hs, V, Vp, (pre_stash || preg || pre_mh) ? reserve + lay.wperm : nullptr, (pre || preg || pre_mh) ? reserve + lay.wyperm : nullptr,
+    // (as for the single head: what a teacher-forced stashing forward leaves — P and gx per head — depends on the shape only, so that
+    // las_speller_bwd can take its multi-head PRE path whichever forward kernels ran)
+    const bool pre_mh_stash = teacher_forced && lay.pre_mh && ((flags & LAS_FLAG_STASH) || pre_mh);
+    bool mh_gx_written = false;
+    LAS_TRY(speller_prologue(d->w_ih[0], w0p, Hs, V, Vp, (pre_stash || preg || pre_mh_stash) ? reserve + lay.wperm : nullptr, (pre || preg || pre_mh) ? reserve + lay.wyperm : nullptr,
                              (pre || preg || pre_mh) ? reserve + lay.bperm : nullptr, d->b_ih[0], d->b_hh[0],
                              teacher_forced ? (const long long*)labels_onehot : nullptr, y_all, B, U, U_lab, feat, (long)Tp * D, ctx_all, D, stream));
     // the PRE kernel's hand-off slabs (50 MB of sentinel words at paper size) are filled on the side stream, beside the two GEMMs below
@@ -491,7 +497,7 @@ int las_speller_fwd(const las_speller_desc* d, const float* feat, const float* k
     bool persist_ran = persist || preg;
     bool pre_ran = false;           // a PRE kernel ran AND the contexts of every step are wanted: they are recovered by one GEMM below
     bool gx_written = false;        // ... a PRE kernel ran: the per-step sums gx are in the reserve already
-    if (pre_mh) {
+    if (pre_mh_stash) {
         // Multi-head attention on the PRE kernel (las_model.py:298-314).  context_s = W_dr cat_h(ctx^h_s) + b_dr enters the bottom cell as
         // W_ctx context_s = sum_h sum_t a^h_{s,t} (feat_t M_h^T) + W_ctx b_dr with M_h = W_ctx W_dr[:, h D:(h+1) D]: the same pre-multiplied
         // form as the single head, one P block per head; W_ctx b_dr rides as a bias of head 0's block (its weights sum to 1)
@@ -514,6 +520,7 @@ int las_speller_fwd(const las_speller_desc* d, const float* feat, const float* k
             g.C = reserve + lay.pctx; g.ldc = (long)NH * 4 * Hs; g.M = B * Tp; g.N = NH * 4 * Hs; g.K = D; g.splitk = 1;
             LAS_TRY(gemm_f32(g, stream));
         }
+      if (pre_mh) {
         {
             GemmDesc g;      // step 0: the context is the first listener frame itself (las_model.py:198), no dim_reduce
             g.A = feat; g.lda = (long)Tp * D; g.a_kc = true;
@@ -544,6 +551,7 @@ int las_speller_fwd(const las_speller_desc* d, const float* feat, const float* k
         if (rc != LAS_ERR_UNSUPPORTED) {
             LAS_TRY(rc);
             persist_ran = true;
+            mh_gx_written = true;
             // per-head contexts (the dim_reduce input, stashed for the backward), then the reduced context of every step
             float* ctxcat = reserve + lay.ctxcat_all;
             for (int hd = 0; hd < NH; ++hd) {
@@ -560,6 +568,7 @@ int las_speller_fwd(const las_speller_desc* d, const float* feat, const float* k
             q.C = ctx_all + (size_t)B * D; q.ldc = D; q.M = U * B; q.N = D; q.K = NH * D; q.splitk = 1;
             LAS_TRY(gemm_f32(q, stream));
         }
+      }
     }
     if (persist || preg) {
         PersistFwd p;
@@ -707,6 +716,17 @@ int las_speller_fwd(const las_speller_desc* d, const float* feat, const float* k
         g.C = reserve + lay.gx; g.ldc = (long)B * 4 * Hs; g.sC = 4 * Hs;
         g.M = U; g.N = 4 * Hs; g.K = Tp; g.batch = B; g.splitk = 1;
         LAS_TRY(gemm_f32(g, stream));
+    }
+    if (pre_mh_stash && !mh_gx_written && (flags & LAS_FLAG_STASH)) {   // the per-step kernels ran: gx[s][b][h] = att[s][h][b] . P[b][:, h], batched over the utterances
+        const int NH = d->multi_head;
+        for (int hd = 0; hd < NH; ++hd) {
+            GemmDesc g;
+            g.A = att + (size_t)hd * B * Tp; g.lda = (long)NH * B * Tp; g.a_kc = true; g.sA = Tp;
+            g.B = reserve + lay.pctx + (size_t)hd * 4 * Hs; g.ldb = (long)NH * 4 * Hs; g.b_kc = false; g.sB = (long)Tp * NH * 4 * Hs;
+            g.C = reserve + lay.gx + (size_t)hd * 4 * Hs; g.ldc = (long)B * NH * 4 * Hs; g.sC = (long)NH * 4 * Hs;
+            g.M = U; g.N = 4 * Hs; g.K = Tp; g.batch = B; g.splitk = 1;
+            LAS_TRY(gemm_f32(g, stream));
+        }
     }
     if (teacher_forced) {
         // character distribution of all U steps at once (reference las_model.py:181-182, per step there):
@@ -865,6 +885,40 @@ int las_speller_bwd(const las_speller_desc* d, const float* feat, const float* k
     bool persist_ran = persist;
     float* dx0_ctx = dx0 + V;              // gradient of the initial context (step 0's context input) and its row stride
     long ld_dx0 = V + D;
+    // multi-head (heads 2..4) on the PRE backward: the forward left P and gx per head for this shape (pre_mh_stash)
+    const bool pre_mh = NH > 1 && hoist && err_word && !(flags & LAS_FLAG_FORCE_GENERIC) && d->relu <= LAS_ACT_RELU && lay.pre_mh &&
+                        (flags & LAS_FLAG_TEACHER_FORCED) && speller_persist_bwd_pre_mh_eligible(B, Tp, Hs, D, M, V, L, NH, d->use_mlp);
+    if (pre_mh) {
+        PersistBwd p;
+        p.w_ih0 = d->w_ih[0]; p.w_hh0 = d->w_hh[0]; p.w_ih1 = d->w_ih[1]; p.w_hh1 = d->w_hh[1]; p.w_phi = d->w_phi;
+        p.feat = feat; p.keys = keys; p.att = att; p.q_all = q_all; p.ctx_all = ctx_all;
+        p.gates_all = gates_all; p.c_all = c_all; p.dcat_all = dcat_all;
+        p.dG_all = dG_all; p.dctx_all = dctx_all; p.de_all = de_all; p.dqpre_all = dqpre_all;
+        p.dx0 = dx0; p.xbuf = workspace + wl.pxbuf;
+        p.B = B; p.Tp = Tp; p.U = U; p.Hs = Hs; p.V = V; p.relu = d->relu; p.err = err_word;
+        p.pctx = reserve + lay.pctx; p.gxf = reserve + lay.gx; p.NH = NH; p.w_dr = d->w_dr; p.dctxcat = dctxcat_all;
+        const int rc = speller_persist_bwd(p, stream);
+        if (rc != LAS_ERR_UNSUPPORTED) {
+            LAS_TRY(rc);
+            persist_ran = true;
+            // total context gradient of every step, off the chain: dctx_s = dcat_ctx_s + dG0_{s+1} W_ctx (row block -1: the initial context's),
+            // then through dim_reduce for the per-head contractions of attention_deferred
+            float* dctx_m1 = dctx_all - (size_t)B * D;
+            LAS_HIP_CHECK(hipMemsetAsync(dctx_m1, 0, sizeof(float) * (size_t)B * D, stream));
+            LAS_TRY(copy2d(dcat_all + Hs, Hs + D, dctx_all, D, (long)U * B, D, 0, stream));
+            GemmDesc q;
+            q.A = dG_all; q.lda = 4 * Hs; q.a_kc = true;
+            q.B = reserve + lay.w0p + lay.Vp; q.ldb = lay.Vp + Hs; q.b_kc = false;
+            q.C = dctx_m1; q.ldc = D; q.M = U * B; q.N = D; q.K = 4 * Hs; q.accumulate = true; q.splitk = 1;
+            LAS_TRY(gemm_f32(q, stream));
+            dx0_ctx = dctx_m1; ld_dx0 = D;
+            GemmDesc r;
+            r.A = dctx_all; r.lda = D; r.a_kc = true;
+            r.B = d->w_dr; r.ldb = (long)NH * D; r.b_kc = false;
+            r.C = dctxcat_all; r.ldc = (long)NH * D; r.M = U * B; r.N = NH * D; r.K = D; r.splitk = 1;
+            LAS_TRY(gemm_f32(r, stream));
+        }
+    }
     if (persist) {
         PersistBwd p;
         p.w_ih0 = d->w_ih[0]; p.w_hh0 = d->w_hh[0]; p.w_ih1 = d->w_ih[1]; p.w_hh1 = d->w_hh[1]; p.w_phi = d->w_phi;

@@ -258,9 +258,13 @@ struct PersistBwd {
     // PRE variant (speller_persist_bwd_pre_eligible; the forward ran its PRE variant): feat . W_ctx^T and the forward's gx slabs.
     // The kernel then leaves dctx_all and the context part of dx0 to the caller (one GEMM over the stashed dG0 afterwards).
     const float* pctx = nullptr; const float* gxf = nullptr;
+    // ... its multi-head form (speller_persist_bwd_pre_mh_eligible): NH heads, dim_reduce weight (D, NH*D), U*B*NH*D floats of scratch
+    int NH = 1; const float* w_dr = nullptr; float* dctxcat = nullptr;
     int B, Tp, U, Hs, V, relu;
     unsigned* err;
 };
+size_t speller_persist_bwd_mh_workspace_floats(int B, int Tp, int U, int Hs, int M, int heads);
+bool speller_persist_bwd_pre_mh_eligible(int B, int Tp, int Hs, int D, int M, int V, int L, int heads, int use_mlp);
 bool speller_persist_bwd_eligible(int B, int Tp, int Hs, int D, int M, int V, int L, int heads, int use_mlp);
 size_t speller_persist_bwd_workspace_floats(int B, int Tp, int U, int Hs, int M);
 bool speller_persist_bwd_pre_eligible(int B, int Tp, int Hs, int D, int M, int V, int L, int heads, int use_mlp);

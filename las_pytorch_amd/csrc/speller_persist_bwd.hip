@@ -56,6 +56,8 @@ struct PersistBwdArgs {
     float* dqpre_all;   // (U*B, M)              PRE variant: the summed parts (what dW_phi needs), written by slice 0
     int B, Tp, U, relu;
     int ns;          // attention-backward workgroups per utterance (each owns ceil(T'/ns) frames)
+    int NH;          // PRE variant, multi-head: ns = NH * (frame slices per head); workgroup `part` = head * (ns / NH) + slice owns that head's
+                     // frame slice and Hs / ns top-layer units; pctx (B*Tp, NH*4Hs), gxf / q_all [U][B][NH][.], att / e0 / de_all [U][NH][B][Tp]
     unsigned* err;
     unsigned long long* trace;
 };
@@ -956,7 +958,7 @@ struct AttnBwdPreRole {
 //   stage 2 (UNIT slice: Hs / ns hidden units of the top layer, one per lane): dq = sum of the parts, decoder-state gradient
 //           W_phi^T dq for its units (its W_phi columns live in LDS), + dz W_c part + recurrent carry (R workgroups) -> top cell
 //           backward (cell-state gradient in a register) -> its piece of the tiled dG1 slab, whole 256-byte rows, straight to X.
-template <int HS>
+template <int HS, bool MH = false>
 struct AttnBwdPre2Role {
     static constexpr int GC = 4 * HS;                      // length of a P row / of a gate-gradient row
     static constexpr int LPS = HS / 16;                    // lanes per frame slot: 32 (Hs=512) or 16 (Hs=256)
@@ -967,9 +969,10 @@ struct AttnBwdPre2Role {
     static constexpr int NJ = HS / 16;                     // producer tiles of a gate-gradient row (256 B each)
     static constexpr int MAXUN = HS / 4;                   // units per workgroup at ns = 4 (fewer with more slices)
     static constexpr int WLD = PS_M + 4;                   // LDS row stride of a unit's W_phi column (16-byte aligned, bank spread)
+    static constexpr int MAXNH = MH ? 4 : 1;               // heads whose summed dq a workgroup keeps (multi-head: its units need all of them)
     static_assert(LPS == 16 || LPS == 32, "slot layout");
     static __host__ __device__ constexpr int lds_floats() {
-        return GC + 2 * MAXTP + PS_M + 64 + PS_M + 64 + TH * PS_KLD + WLD * MAXUN + 16 * PS_M + PS_M + 9 * MAXUN;
+        return GC + 2 * MAXTP + PS_M + 64 + PS_M + 64 + TH * PS_KLD + WLD * MAXUN + 16 * PS_M + MAXNH * PS_M + 9 * MAXUN;
     }
 
     static __device__ void run(const PersistBwdArgs& a, float* smem, const int widx) {
@@ -982,7 +985,12 @@ struct AttnBwdPre2Role {
         const bool first_wg = widx == 0;
         const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);      // wave: scalar register
         const int B = a.B, U = a.U, Tp = a.Tp;
-        const int th = (Tp + NS - 1) / NS, t0 = part * th, nt = max(0, min(th, Tp - t0));     // this workgroup's frames
+        // multi-head: the NS workgroups of an utterance are NH heads x NSF frame slices; a workgroup works on ITS head's attention and on
+        // Hs / NS top-layer units, for which it needs the summed dq of every head
+        const int NH = MH ? a.NH : 1, NSF = MH ? NS / NH : NS;
+        const int hd = MH ? part / NSF : 0, fsl = MH ? part % NSF : part;
+        const int WLDH = MH ? NH * PS_M + 4 : WLD;          // LDS row stride of a unit's W_phi columns (all heads)
+        const int th = (Tp + NSF - 1) / NSF, t0 = fsl * th, nt = max(0, min(th, Tp - t0));     // this workgroup's frames
         const int UN = HS / NS, u0 = part * UN;             // ... and its hidden units of the top layer
         float* dg = smem;
         float* attr = dg + GC;
@@ -994,8 +1002,8 @@ struct AttnBwdPre2Role {
         float* ks = slotv + 64;
         float* wps = ks + TH * PS_KLD;           // W_phi columns of its units: [unit][WLD]
         float* dqp = wps + WLD * MAXUN;          // the ns parts of dq as they arrive: [part][m]
-        float* dqf = dqp + 16 * PS_M;            // their sum
-        float* stl = dqf + PS_M;                 // stash of its units for this step: [i, f, g, o, c, c_prev, dz W_c part, dc][MAXUN]
+        float* dqf = dqp + 16 * PS_M;            // their sum (per head)
+        float* stl = dqf + MAXNH * PS_M;                 // stash of its units for this step: [i, f, g, o, c, c_prev, dz W_c part, dc][MAXUN]
         float* dhl = stl + 8 * MAXUN;            // W_phi^T dq of its units
         const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
 
@@ -1027,14 +1035,14 @@ struct AttnBwdPre2Role {
         f32x4 pr[NC4];
 #pragma unroll
         for (int i = 0; i < NC4; ++i) {
-            const f32x4 v = ld4p(a.pctx + ((size_t)b * Tp + (slot < nt ? t0 + slot : 0)) * GC + 4 * (l32 + LPS * i));
+            const f32x4 v = ld4p(a.pctx + (((size_t)b * Tp + (slot < nt ? t0 + slot : 0)) * NH + hd) * GC + 4 * (l32 + LPS * i));
             pr[i] = slot < nt ? v : zero;
         }
         for (int idx = tid; idx < nt * (PS_M / 4); idx += PS_THREADS) {
             const int t = idx / (PS_M / 4), m4 = idx % (PS_M / 4);
             *reinterpret_cast<f32x4*>(ks + t * PS_KLD + m4 * 4) = ld4p(a.keys + ((size_t)b * Tp + t0 + t) * PS_M + m4 * 4);
         }
-        for (int idx = tid; idx < PS_M * UN; idx += PS_THREADS) wps[(idx % UN) * WLD + idx / UN] = a.w_phi[(size_t)(idx / UN) * HS + u0 + idx % UN];
+        for (int idx = tid; idx < NH * PS_M * UN; idx += PS_THREADS) wps[(idx % UN) * WLDH + idx / UN] = a.w_phi[(size_t)(idx / UN) * HS + u0 + idx % UN];
         lds_barrier();
         constexpr size_t GXS = (size_t)NJ * 32 * 64, CXS = (size_t)NJ * 32 * 16;
         const bool ulane = tid < UN;                         // stage-2 lane: hidden unit u0 + tid of utterance b
@@ -1043,15 +1051,17 @@ struct AttnBwdPre2Role {
         for (int s = U - 1; s >= 0; --s) {
             // ---- stash operands of this step (plain loads, issued before the wait)
             const size_t sb = (size_t)s * B + b;
+            const size_t sbh = MH ? ((size_t)s * NH + hd) * B + b : sb;       // [U][NH][B] rows (attention weights, e0, de)
+            const size_t sbq = MH ? sb * NH + hd : sb;                         // [U][B][NH] rows (queries, gx)
             if (tid < MAXTP) {
                 const unsigned o = opaque(4u * (unsigned)(tid < Tp ? tid : 0));
-                const float av = *at_bytes(a.att + sb * Tp, o), ev = *at_bytes(a.e0 + sb * Tp, o);
+                const float av = *at_bytes(a.att + sbh * Tp, o), ev = *at_bytes(a.e0 + sbh * Tp, o);
                 attr[tid] = tid < Tp ? av : 0.f;
                 e0r[tid] = tid < Tp ? ev : 0.f;
             }
-            if (tid >= MAXTP && tid < MAXTP + PS_M) qs[tid - MAXTP] = *at_bytes(a.q_all + sb * PS_M, opaque(4u * (unsigned)(tid - MAXTP)));
+            if (tid >= MAXTP && tid < MAXTP + PS_M) qs[tid - MAXTP] = *at_bytes(a.q_all + sbq * PS_M, opaque(4u * (unsigned)(tid - MAXTP)));
             if (slot == NSLOT - 1) {
-                const float* gp = at_bytes(a.gxf + sb * GC, opaque(16u * (unsigned)l32));
+                const float* gp = at_bytes(a.gxf + sbq * GC, opaque(16u * (unsigned)l32));
 #pragma unroll
                 for (int i = 0; i < NC4; ++i) pr[i] = ld4p(gp + 4 * LPS * i);
             }
@@ -1137,7 +1147,7 @@ struct AttnBwdPre2Role {
                     const int tt = valid ? t0 + lane : 0;
                     const float v = valid ? attr[tt] * (e0r[tt] + slotv[lane] - sd) : 0.f;
                     de[lane] = v;
-                    if (valid) *at_bytes(a.de_all + sb * Tp, opaque(4u * (unsigned)tt)) = v;
+                    if (valid) *at_bytes(a.de_all + sbh * Tp, opaque(4u * (unsigned)tt)) = v;
                 }
             }
             lds_barrier();
@@ -1181,21 +1191,28 @@ struct AttnBwdPre2Role {
                 *reinterpret_cast<f32x4*>(dqp + tid * 4) = v;
             }
             lds_barrier();
-            if (tid < PS_M) {
+            if (tid < NH * PS_M) {      // (multi-head: head tid / M sums its own NSF frame slices)
+                const int h2 = MH ? tid / PS_M : 0, m = MH ? tid % PS_M : tid;
                 float acc = 0.f;
-                for (int p = 0; p < NS; ++p) acc += dqp[p * PS_M + tid];
+                for (int p = 0; p < NSF; ++p) acc += dqp[(h2 * NSF + p) * PS_M + m];
                 dqf[tid] = acc;
-                if (part == 0) *at_bytes(a.dqpre_all + sb * PS_M, opaque(4u * (unsigned)tid)) = acc;
+                if (part == 0) *at_bytes(a.dqpre_all + sb * (NH * PS_M), opaque(4u * (unsigned)tid)) = acc;
             }
             lds_barrier();
             PB_STAMP(2, s, 4);
             // ---- stage 2: decoder-state gradient of its units (W_phi^T dq: 8 adjacent lanes per unit, 8 terms each, DPP row sum) ...
             if (tid < 8 * UN) {
                 const unsigned t8 = opaque((unsigned)tid), un = t8 >> 3, ms = t8 & 7;
-                const float* wr = wps + un * WLD + ms * 8;
+                const float* wr = wps + un * WLDH + ms * 8;
                 const float* qr = dqf + ms * 8;
                 float acc = dot4p(*reinterpret_cast<const f32x4*>(wr), *reinterpret_cast<const f32x4*>(qr), 0.f);
                 acc = dot4p(*reinterpret_cast<const f32x4*>(wr + 4), *reinterpret_cast<const f32x4*>(qr + 4), acc);
+                if (MH) {
+                    for (int h2 = 1; h2 < NH; ++h2) {
+                        acc = dot4p(*reinterpret_cast<const f32x4*>(wr + h2 * PS_M), *reinterpret_cast<const f32x4*>(qr + h2 * PS_M), acc);
+                        acc = dot4p(*reinterpret_cast<const f32x4*>(wr + h2 * PS_M + 4), *reinterpret_cast<const f32x4*>(qr + h2 * PS_M + 4), acc);
+                    }
+                }
                 acc = gsum<8>(acc);
                 if (ms == 0) dhl[un] = acc;
             }
@@ -1230,14 +1247,14 @@ struct AttnBwdPre2Role {
     }
 };
 
-template <int HS>
+template <int HS, bool MH = false>
 __global__ __launch_bounds__(PS_THREADS) void speller_persist_bwd_pre_kernel(PersistBwdArgs a) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     constexpr int NXY = (HS / 16) * 2;
     const int bx = blockIdx.x;
     if (bx < NXY) ProdPre2Role<HS>::template run<true>(a, smem, bx);
     else if (bx < 2 * NXY) ProdPre2Role<HS>::template run<false>(a, smem, bx - NXY);
-    else AttnBwdPre2Role<HS>::run(a, smem, bx - 2 * NXY);
+    else AttnBwdPre2Role<HS, MH>::run(a, smem, bx - 2 * NXY);
 }
 
 template <int HS>
@@ -1291,6 +1308,29 @@ static int persist_bwd_pre_ns(int B, int Tp, int Hs, int cus) {
 }
 // floats of the hand-off slabs + the attention workgroups' dqpre parts; 0 when the shape is not covered.  The PRE variant
 // (4 attention workgroups per utterance, no dcx / dhc slabs, plus the e0 rows) fits in the same block.
+// multi-head form of the PRE variant: frame slices per head (0 = n/a) — B * heads takes B's place in the workgroup budget, every (head, slice)
+// workgroup also owns Hs / (heads * slices) top-layer units (whole 16-unit tiles, at most 16 workgroups per utterance)
+static int persist_bwd_pre_mh_nsf(int B, int Tp, int Hs, int heads, int cus) {
+    const int nsf = persist_bwd_pre_ns(B * heads, Tp, Hs, cus);
+    if (nsf == 0 || nsf * heads > 16 || (Hs / 16) % (nsf * heads) != 0) return 0;
+    return nsf;
+}
+size_t speller_persist_bwd_mh_workspace_floats(int B, int Tp, int U, int Hs, int M, int heads) {
+    if ((Hs != 256 && Hs != 512) || heads < 2 || heads > 4 || Tp > 448) return 0;
+    const size_t nsf = (size_t)persist_bwd_pre_mh_nsf(B, Tp, Hs, heads, -1);
+    if (nsf == 0) return 0;
+    // [e0 (per head) | sentinel-prefilled slabs: dq exchange (heads * nsf parts) | tiled dG (2 layers) | recurrent carry of the top layer | R's partial sums]
+    return (size_t)U * B * Tp * heads + 4 + nsf * heads * U * B * M + (size_t)2 * U * (Hs / 16) * 32 * 64 + (size_t)(U + 1) * (Hs / 16) * 32 * 16 +
+           (size_t)(U + 1) * 2 * (Hs / 16) * 256;
+}
+bool speller_persist_bwd_pre_mh_eligible(int B, int Tp, int Hs, int D, int M, int V, int L, int heads, int use_mlp) {
+    if (opt_get(OPT_SPELLER_PERSIST_BWD) == 0 || opt_get(OPT_SPELLER_PRE_BWD) == 0 || opt_get(OPT_SPELLER_PRE_MH) == 0 || Tp > 448) return false;
+    if (!speller_persist_pre_mh_shape(B, Tp, Hs, D, M, V, L, heads, use_mlp)) return false;      // (the forward left P and gx for exactly these shapes)
+    int cus = 0, dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess)
+        return false;
+    return persist_bwd_pre_mh_nsf(B, Tp, Hs, heads, cus) != 0;
+}
 size_t speller_persist_bwd_workspace_floats(int B, int Tp, int U, int Hs, int M) {
     if (Hs != 256 && Hs != 512) return 0;
     const int ns = persist_bwd_ns(B, Tp, Hs, -1);
@@ -1312,16 +1352,16 @@ bool speller_persist_bwd_pre_eligible(int B, int Tp, int Hs, int D, int M, int V
     return persist_bwd_pre_ns(B, Tp, Hs, cus) != 0;
 }
 
-template <int HS>
+template <int HS, bool MH = false>
 static int launch_persist_bwd_pre(const PersistBwdArgs& a, int grid, hipStream_t stream) {
-    const size_t smem = sizeof(float) * (size_t)std::max(ProdRole<HS>::LDS_FLOATS, AttnBwdPre2Role<HS>::lds_floats());
-    LAS_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&speller_persist_bwd_pre_kernel<HS>),
+    const size_t smem = sizeof(float) * (size_t)std::max(ProdRole<HS>::LDS_FLOATS, AttnBwdPre2Role<HS, MH>::lds_floats());
+    LAS_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&speller_persist_bwd_pre_kernel<HS, MH>),
                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
-    if (!persistent_launch_fits(speller_persist_bwd_pre_kernel<HS>, PS_THREADS, smem, grid))
+    if (!persistent_launch_fits(speller_persist_bwd_pre_kernel<HS, MH>, PS_THREADS, smem, grid))
         return fail(LAS_ERR_UNSUPPORTED, "persistent decode backward: %s%ld workgroups cannot all be resident", "", (long)grid);
     {
         KernelTimer timer(TIMED_DECODE_BWD, stream);
-        hipLaunchKernelGGL((speller_persist_bwd_pre_kernel<HS>), dim3(grid), dim3(PS_THREADS), smem, stream, a);
+        hipLaunchKernelGGL((speller_persist_bwd_pre_kernel<HS, MH>), dim3(grid), dim3(PS_THREADS), smem, stream, a);
     }
     LAS_LAUNCH_CHECK();
     path_note(PATH_DECODE_BWD, "persist_pre");
@@ -1344,13 +1384,68 @@ static int launch_persist_bwd(const PersistBwdArgs& a, int grid, hipStream_t str
     return LAS_OK;
 }
 
+// Multi-head form of the PRE backward (heads 2..4; the forward left P (B*Tp, NH*4Hs) and gx [U][B][NH][4Hs]): the same roles, the attention
+// workgroups of an utterance being NH heads x nsf frame slices.  p.dctxcat: U*B*NH*D floats of scratch (dz W_c's context part through dim_reduce).
+static int speller_persist_bwd_mh(const PersistBwd& p, hipStream_t stream) {
+    LAS_REQUIRE(p.err && p.xbuf && p.dqpre_all && p.pctx && p.gxf && p.w_dr && p.dctxcat, "persistent speller backward (multi-head) buffers");
+    LAS_REQUIRE(speller_persist_pre_mh_shape(p.B, p.Tp, p.Hs, p.Hs, PS_M, p.V, 2, p.NH, 1), "persistent speller backward (multi-head) shape");
+    int cus = 0, dev = 0;
+    LAS_HIP_CHECK(hipGetDevice(&dev));
+    LAS_HIP_CHECK(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
+    const int NH = p.NH, nsf = persist_bwd_pre_mh_nsf(p.B, p.Tp, p.Hs, NH, cus);
+    if (nsf == 0) return fail(LAS_ERR_UNSUPPORTED, "persistent decode backward (multi-head): %s%ld heads do not fit the chip", "", (long)NH);
+    PersistBwdArgs a;
+    a.pctx = p.pctx; a.gxf = p.gxf; a.NH = NH; a.ns = nsf * NH;
+    const size_t nq = (size_t)p.U * p.B * PS_M;
+    float* e0 = p.xbuf;
+    float* slabs = e0 + (((size_t)p.U * p.B * p.Tp * NH + 3) & ~(size_t)3);
+    a.e0 = e0;
+    a.dqx = slabs;
+    a.dGx = a.dqx + (size_t)a.ns * nq;
+    a.dhc = a.dGx + (size_t)2 * p.U * (p.Hs / 16) * 32 * 64;
+    a.dhp = a.dhc + (size_t)(p.U + 1) * (p.Hs / 16) * 32 * 16;
+    a.dcx = nullptr; a.dhA = nullptr; a.dqpre_part = nullptr;
+    a.dqpre_all = p.dqpre_all;
+    a.w_ih0 = p.w_ih0; a.ldw0 = p.V + p.Hs; a.V = p.V;
+    a.w_hh0 = p.w_hh0; a.w_ih1 = p.w_ih1; a.w_hh1 = p.w_hh1; a.w_phi = p.w_phi;
+    a.feat = p.feat; a.keys = p.keys; a.att = p.att; a.q_all = p.q_all; a.ctx_all = p.ctx_all;
+    a.gates_all = p.gates_all; a.c_all = p.c_all; a.dcat_all = p.dcat_all;
+    a.dG_all = p.dG_all; a.dctx_all = p.dctx_all; a.de_all = p.de_all;
+    a.dx0 = p.dx0; a.ldx0 = p.V + p.Hs;
+    a.B = p.B; a.Tp = p.Tp; a.U = p.U; a.relu = p.relu; a.err = p.err; a.trace = g_persist_bwd_trace;
+    const size_t slab_floats = (size_t)a.ns * nq + (size_t)2 * p.U * (p.Hs / 16) * 32 * 64 + (size_t)(p.U + 1) * (p.Hs / 16) * 32 * 16 +
+                               (size_t)(p.U + 1) * 2 * (p.Hs / 16) * 256;
+    LAS_HIP_CHECK(hipMemsetAsync(slabs, 0xFF, sizeof(float) * slab_floats, stream));
+    {   // the character distribution's context gradient through dim_reduce: (U*B, D) x (D, NH*D)
+        GemmDesc g;
+        g.A = p.dcat_all + p.Hs; g.lda = 2 * p.Hs; g.a_kc = true;
+        g.B = p.w_dr; g.ldb = (long)NH * p.Hs; g.b_kc = false;
+        g.C = p.dctxcat; g.ldc = (long)NH * p.Hs; g.M = p.U * p.B; g.N = NH * p.Hs; g.K = p.Hs; g.splitk = 1;
+        LAS_TRY(gemm_f32(g, stream));
+    }
+    for (int hd = 0; hd < NH; ++hd) {   // e0[s][hd][b][t] = (that gradient's head block)[s][b] . feat[b][t]
+        GemmDesc g;
+        g.A = p.dctxcat + (size_t)hd * p.Hs; g.lda = (long)p.B * NH * p.Hs; g.a_kc = true; g.sA = (long)NH * p.Hs;
+        g.B = p.feat; g.ldb = p.Hs; g.b_kc = true; g.sB = (long)p.Tp * p.Hs;
+        g.C = e0 + (size_t)hd * p.B * p.Tp; g.ldc = (long)NH * p.B * p.Tp; g.sC = p.Tp;
+        g.M = p.U; g.N = p.Tp; g.K = p.Hs; g.batch = p.B; g.splitk = 1;
+        LAS_TRY(gemm_f32(g, stream));
+    }
+    const int grid = 2 * (p.Hs / 16) * 2 + a.ns * p.B;
+    if (p.Hs == 512) LAS_TRY((launch_persist_bwd_pre<512, true>(a, grid, stream)));
+    else LAS_TRY((launch_persist_bwd_pre<256, true>(a, grid, stream)));
+    return LAS_OK;
+}
+
 int speller_persist_bwd(const PersistBwd& p, hipStream_t stream) {
+    if (p.NH > 1) return speller_persist_bwd_mh(p, stream);
     LAS_REQUIRE(speller_persist_bwd_eligible(p.B, p.Tp, p.Hs, p.Hs, PS_M, p.V, 2, 1, 1), "persistent speller backward shape");
     LAS_REQUIRE(p.err != nullptr && p.xbuf != nullptr && p.dqpre_all != nullptr, "persistent speller backward buffers");
     int cus = 0, dev = 0;
     LAS_HIP_CHECK(hipGetDevice(&dev));
     LAS_HIP_CHECK(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
     PersistBwdArgs a;
+    a.NH = 1;
     a.pctx = p.pctx; a.gxf = p.gxf; a.e0 = nullptr;
     a.ns = p.pctx ? persist_bwd_pre_ns(p.B, p.Tp, p.Hs, cus) : persist_bwd_ns(p.B, p.Tp, p.Hs, cus);
     a.w_ih0 = p.w_ih0; a.ldw0 = p.V + p.Hs; a.V = p.V;
