@@ -1405,10 +1405,10 @@ bool speller_persist_pre_eligible(int B, int Tp, int Hs, int D, int M, int V, in
     if (ws == 0) return false;
     return persist_fwd_pre_fits_rt(Hs, ws, Tp, Hs / 4 + ws * B);
 }
-// Multi-head attention (heads 2..4, teacher forcing; reference las_model.py:298-314) on the same kernel: one set of attention workgroups per
+// Multi-head attention (heads 2 or 4, teacher forcing; reference las_model.py:298-314) on the same kernel: one set of attention workgroups per
 // (utterance, head), so B * heads takes the place of B in the workgroup budget (heads = 2: 16 utterances per launch at T' <= 112)
 bool speller_persist_pre_mh_shape(int B, int Tp, int Hs, int D, int M, int V, int L, int heads, int use_mlp) {
-    if (L != 2 || heads < 2 || heads > 4 || !use_mlp || M != PS_M || D != Hs) return false;
+    if (L != 2 || (heads != 2 && heads != 4) || !use_mlp || M != PS_M || D != Hs) return false;      // (the backward's unit slices are whole 16-unit tiles)
     if (Hs != 256 && Hs != 512) return false;
     if (B < 1 || B * heads > 32 || ((V + 15) & ~15) > 32) return false;
     return speller_persist_pre_ws(B * heads, Tp, Hs, -1) != 0;

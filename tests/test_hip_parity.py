@@ -532,7 +532,21 @@ def test_pre_multiplied_context_backward_matches_classic_persistent_backward(cfg
     _check_err()
 
 
-def _persistent_vs_stepwise(cfg_name, B, Tp, U, scale, activate, big=False):
+@pytest.mark.parametrize("cfg_name,heads,B,Tp,U,scale,activate", [("P", 2, 16, 100, 12, None, "relu"), ("P", 2, 5, 37, 7, 0.1, "relu"), ("P", 4, 8, 100, 6, None, "relu"),
+                                                                    ("P", 4, 3, 100, 4, 0.1, "relu"), ("P", 2, 10, 60, 5, None, "relu"), ("S", 2, 16, 200, 6, None, "relu"),
+                                                                    ("S", 4, 8, 100, 5, 0.1, "None"), ("P", 2, 8, 224, 4, None, "relu"), ("P", 2, 1, 1, 3, None, "relu"),
+                                                                    ("S", 2, 4, 400, 3, None, "relu"),
+                                                                    # two slices of 16 / of 8 (Speller._run), then a ragged last slice
+                                                                    ("P", 2, 32, 50, 5, None, "relu"), ("P", 4, 13, 40, 4, None, "relu")])
+def test_multi_head_one_launch_decode_matches_stepwise(cfg_name, heads, B, Tp, U, scale, activate):
+    """Multi-head attention (reference las_model.py:298-314) on the one-launch decode kernels — one set of attention workgroups per (utterance,
+    head), dim_reduce folded into the pre-multiplied context, the heads' sums exchanged before the bottom cell; backward: heads x frame slices —
+    against the per-step launch chains: log-probs, every head's attention weights, dfeat and all parameter gradients (dim_reduce included)."""
+    _persistent_vs_stepwise(cfg_name, B, Tp, U, scale, activate, heads=heads)
+    assert _cabi.last_path(_cabi.PATH_DECODE_FWD) == "stepwise"        # (the second pass of the helper is the forced per-step one)
+
+
+def _persistent_vs_stepwise(cfg_name, B, Tp, U, scale, activate, big=False, heads=1):
     """The one-launch teacher-forced decode loop (speller_persist.hip) against the per-step launch chain it replaces:
     outputs and every gradient (the backward pass consumes the stash the forward kernel wrote).  The larger-weight
     cases stay at U(-0.1,0.1): with the U(-0.5,0.5) set the attention softmax is an arg-max over energies of order 1e3
@@ -544,7 +558,7 @@ def _persistent_vs_stepwise(cfg_name, B, Tp, U, scale, activate, big=False):
     torch.manual_seed(5)
     sp = Speller(vocab_size=c["V"], hidden_size=c["Hs"], rnn_unit="LSTM", num_layers=c["Ls"], max_label_len=U,
                  use_mlp_in_attention=True, mlp_dim_in_attention=c["M"], mlp_activate_in_attention=activate,
-                 listener_hidden_size=c["H"], multi_head=1, decode_mode=1).cuda()
+                 listener_hidden_size=c["H"], multi_head=heads, decode_mode=1).cuda()
     if scale is not None:
         with torch.no_grad():
             for p in sp.parameters():
@@ -575,12 +589,16 @@ def _persistent_vs_stepwise(cfg_name, B, Tp, U, scale, activate, big=False):
             preds, att = sp(feat, ground_truth=lab, teacher_force_rate=1.0)
             logp = torch.stack(preds)
             (logp * w).sum().backward()
-            res.append(dict(logp=logp.detach().cpu().numpy(), att=torch.stack([a[0] for a in att]).detach().cpu().numpy(),
+            res.append(dict(logp=logp.detach().cpu().numpy(), att=torch.stack([torch.stack(list(a)) for a in att]).detach().cpu().numpy(),
                             dfeat=feat.grad.cpu().numpy(), **{"d" + n: p.grad.cpu().numpy() for n, p in sp.named_parameters()}))
+            if not force:
+                paths = (_cabi.last_path(_cabi.PATH_DECODE_FWD), _cabi.last_path(_cabi.PATH_DECODE_BWD))
         finally:
             sp.force_generic = False
             set_trace(None)
     torch.cuda.synchronize()
+    if heads > 1:
+        assert paths == ("persist_pre", "persist_pre"), paths
     assert int(trace.abs().sum().item()) != 0, "the persistent kernel did not run (shape not eligible?)"
     assert not big or int(btrace.abs().sum().item()) != 0, "the one-launch backward did not run"
     for k in res[0]:
