@@ -89,6 +89,10 @@ const char* las_last_error(void);
  *                         joins cost more than the 23 us of fills they hide)
  *   TRUST_ZEROED_GRADS 1* honour LAS_FLAG_GRADS_ZEROED (0: fill the gradient blocks regardless; A/B)
  *   TIME_KERNELS 0*       record HIP events around the one-launch decode kernels on their launch stream (las_debug_kernel_ms)
+ *   SPELLER_PRE_GREEDY 1  free-running (decode_mode 1) decode on the pre-multiplied-context kernel (0: classic persistent kernel; A/B)
+ *   SPELLER_PRE_MH 1      multi-head attention (heads 2 or 4, teacher forcing) on the pre-multiplied-context kernels, forward and backward
+ *                         (0: per-step kernels; A/B)
+ *   GEMM_BIG 1            256 x 256-tile GEMM where it fills the chip (0 never, 2 whenever the shape allows; A/B)
  * Replaces nothing in the reference (pure Python, no switches).
  * ---------------------------------------------------------------------------------------------- */
 int las_set_option(const char* key, int64_t value);

@@ -57,6 +57,12 @@ python tools/ubench_rec_sweep.py > $O/rec_sweep.log 2>&1
 python tools/ubench_gemm_split.py > $O/gemm_split.log 2>&1
 python tools/ubench_gemm_big.py > $O/gemm_big.log 2>&1
 python tools/ubench_gemm_planes.py > $O/gemm_planes.log 2>&1
+# round 5: multi-head attention on the one-launch kernels against the per-step chains; the caller's step (solver.batch_iterator); the device LER
+python tools/ubench_multihead.py 2>&1 | grep -v amdgpu.ids > $O/multihead.log
+B=16 python tools/ubench_multihead.py 2>&1 | grep -v amdgpu.ids >> $O/multihead.log
+python tools/solver_step_profile.py 300 2>&1 | grep -v amdgpu.ids > $O/solver_step.log
+python tools/soak_mixed.py 1500 2>&1 | grep -v amdgpu.ids > $O/soak_mixed.log
+(python tools/ubench_ler.py; B=7 U=600 python tools/ubench_ler.py; B=3 U=4095 python tools/ubench_ler.py) 2>&1 | grep "las_letter_error_rate" > $O/ler.log
 # soak: 1500 consecutive training steps (~1e7 inter-workgroup hand-offs) must end without a device error word
 python bench.py --steps 1500 --warmup 5 --no-cpu-baseline --no-sweep --no-mfma --no-roofline --no-secondary > $O/soak.json 2> $O/soak.err
 for w in "P_long 8" "S_long 8" "S_train 32" "Y_train 16" "P_fwd 32" "S_fwd 32" "P_train 128"; do set -- $w; python bench.py --workload $1 --batch $2 --steps 10 --warmup 3 --no-cpu-baseline --no-sweep --no-mfma --no-secondary --no-roofline 2>/dev/null | tail -1; done > $O/variants.jsonl
