@@ -65,7 +65,7 @@ struct SpellerLayout {
         const size_t NHp = pre_mh ? d->multi_head : 1;
         hx = o; if (d->L == 2) o += r4((size_t)2 * U * 32 * d->Hs);   // hand-off copy of h for the persistent decode kernel
         r0x = o; if (anypre) o += r4((size_t)U * 32 * 4 * d->Hs);     // ... and the cell workgroups' part of the bottom-layer gates
-        gx = o; if (anypre) o += r4((size_t)U * B * NHp * 4 * d->Hs);
+        gx = o; if (anypre) o += r4((size_t)U * B * NHp * 4 * d->Hs + (pre_mh ? B * 16 * 4 : 0));      // (+ the placement check's XCC ids, multi-head)
         lgx = o; if (d->L == 2) o += r4((size_t)U * B * 8 * 32);      // ... and its partial logits (free-running decode)
         wperm = o; if (anypre) o += r4((size_t)4 * d->Hs * d->Hs);
         wyperm = o; if (anypre) o += r4((size_t)4 * d->Hs * Vp);   // W_y rows and b_ih0 + b_hh0 in the same row order ...

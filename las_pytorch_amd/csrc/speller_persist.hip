@@ -972,8 +972,12 @@ struct AttnPreRole {
         // MH: one set of SPLIT workgroups per (utterance, head) — query rows, softmax and P block of that head; the heads' weighted sums meet
         // through gx before the bottom cell, which every head's workgroup applies (identical arithmetic) and head 0 publishes
         const int NH = MH ? a.NH : 1;
-        const int pu = widx / SPLIT, part_id = widx % SPLIT;
-        const int b = MH ? pu / NH : pu, hd = MH ? pu % NH : 0;
+        // (MH placement: the NH workgroups that exchange their sums — same utterance, same column part — get block indices 8 apart whenever
+        // B * SPLIT is a multiple of 8, i.e. ONE XCD under round-robin dispatch; verified at run time below, never assumed)
+        const bool xmap = MH && ((a.B * SPLIT) & 7) == 0;
+        const int qx = xmap ? (widx / (8 * NH)) * 8 + (widx & 7) : 0;
+        const int pu = xmap ? 0 : widx / SPLIT, part_id = xmap ? qx % SPLIT : widx % SPLIT;
+        const int b = xmap ? qx / SPLIT : (MH ? pu / NH : pu), hd = xmap ? (widx >> 3) % NH : (MH ? pu % NH : 0);
         const int col0 = part_id * GC;
         const bool first_wg = widx == 0;
         const int tid = threadIdx.x, lane = tid & 63;
@@ -1026,6 +1030,28 @@ struct AttnPreRole {
             bcv = (tid >> 5) < a.V ? a.b_c[tid >> 5] : 0.f;
         }
         lds_barrier();
+        bool l2x = false;
+        if (MH) {
+            // every workgroup publishes its XCC id behind the gx slabs (sentinel-prefilled with them) and reads its partners'
+            unsigned xcc;
+            asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID, 0, 4)" : "=s"(xcc));
+            unsigned* ids = reinterpret_cast<unsigned*>(a.gx + (size_t)a.U * a.B * NH * (4 * HS)) + ((size_t)b * SPLIT + part_id) * 4;
+            volatile int* flag = reinterpret_cast<volatile int*>(gxl);
+            if (tid == 0) { *flag = 1; __hip_atomic_store(ids + hd, 0xC0DE0000u | xcc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+            lds_barrier();
+            if (tid < NH) {
+                unsigned spins = 0, v;
+                for (;;) {
+                    v = __hip_atomic_load(ids + tid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    if (v != PS_SENT) break;
+                    if (spin_expired(spins, a.err, 0xDEAD0018u)) break;
+                }
+                if (v != (0xC0DE0000u | xcc)) *flag = 0;
+            }
+            lds_barrier();
+            l2x = *flag != 0;
+            lds_barrier();
+        }
 
         // ---- the bottom LSTM cell of this workgroup's CG hidden units, one per lane of the first CG/64 waves, state in a register:
         //      gates_s = sum_t a_{s-1,t} P_t (reduced by the ts == 0 lanes, handed over through LDS) + R0_s (the cell workgroups'
@@ -1258,7 +1284,14 @@ struct AttnPreRole {
                 } else if (clane) {
                     // the heads' sums meet here: publish this head's (agent scope; the slab is the backward's stash as well), collect the others'
                     // and add them in head order, so that every head's workgroup holds bit-identical gate pre-activations
-                    st4_agent(at_bytes(dst, opaque(16u * (unsigned)cg)), acc);
+                    if (l2x) {      // same XCD: an ordinary store reaches the shared L2, where the partners' L1-bypassing polls find it
+                        f32x4 cv;
+#pragma unroll
+                        for (int k = 0; k < 4; ++k) cv[k] = __uint_as_float(pub_bits(acc[k]));
+                        *reinterpret_cast<f32x4*>(at_bytes(dst, opaque(16u * (unsigned)cg))) = cv;
+                    } else {
+                        st4_agent(at_bytes(dst, opaque(16u * (unsigned)cg)), acc);
+                    }
                     f32x4 tot = zero;
                     for (int h2 = 0; h2 < NH; ++h2) {
                         f32x4 v = acc;
@@ -1514,7 +1547,8 @@ int speller_persist_fwd(const PersistFwd& p, hipStream_t stream) {
                     speller_persist_pre_mh_shape(p.B, p.Tp, p.Hs, p.Hs, PS_M, p.V, 2, p.NH, 1), "persistent speller (pre, multi-head) shape");
         a.split = ws;
         if (!p.prefilled) LAS_TRY(speller_persist_fwd_fill(p, stream));
-        LAS_HIP_CHECK(hipMemsetAsync(p.gx, 0xFF, sizeof(float) * (size_t)p.U * p.B * p.NH * 4 * p.Hs, stream));      // the heads' exchange slab
+        // the heads' exchange slab + 4 words per (utterance, column part) of XCC ids behind it
+        LAS_HIP_CHECK(hipMemsetAsync(p.gx, 0xFF, sizeof(float) * ((size_t)p.U * p.B * p.NH * 4 * p.Hs + (size_t)p.B * 16 * 4), stream));
         const int grid = p.Hs / 4 + ws * p.B * p.NH;
         if (p.Hs == 512)
             return ws == 4 ? launch_persist_fwd_pre<512, 4, false, true>(a, grid, stream)
