@@ -462,7 +462,11 @@ int gemm_big(const GemmDesc& d, hipStream_t stream) {
     p.splitk = splitk; p.kper = kper; p.atomic = splitk > 1;
     if (p.atomic && !d.accumulate && !d.c_zeroed) {      // split-K partials are summed with atomics: C must start from zero
         if (d.ldc == d.N) {
-            LAS_HIP_CHECK(hipMemsetAsync(d.C, 0, sizeof(float) * ((size_t)(batch - 1) * d.sC + (size_t)d.M * d.N), stream));
+            // (batches with gaps between their outputs — interleaved with another GEMM's — are zeroed block by block: the gaps may hold live data)
+            if (batch > 1 && d.sC != (long)d.M * d.N)
+                LAS_HIP_CHECK(hipMemset2DAsync(d.C, sizeof(float) * (size_t)d.sC, 0, sizeof(float) * (size_t)d.M * d.N, (size_t)batch, stream));
+            else
+                LAS_HIP_CHECK(hipMemsetAsync(d.C, 0, sizeof(float) * ((size_t)(batch - 1) * d.sC + (size_t)d.M * d.N), stream));
         } else {
             LAS_HIP_CHECK(hipMemset2DAsync(d.C, sizeof(float) * d.ldc, 0, sizeof(float) * d.N, (size_t)d.M, stream));
         }

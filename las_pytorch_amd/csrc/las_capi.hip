@@ -40,7 +40,7 @@ struct PblstmBwdLayout {
 
 struct SpellerLayout {
     size_t y_all, ctx_all, h_all, c_all, gates_all, q_all, w0p, ctxcat_all, hx, r0x, lgx, wperm, wyperm, bperm, yw, pctx, gx, bqp, bfl, blg, beg, qct, wyT, plx,
-        mperm, pbias, p0, total;
+        mperm, pbias, p0, wcd, bcp, total;
     bool pre_mh;               // ... its multi-head form (heads 2..4): P, gx per head, the folded matrices W_ctx W_dr[:, h]
     bool big;                  // room for the one-launch decode of the Hs = 1024 shape (speller_big.hip)
     bool pre;                  // room for the persistent decode kernel's pre-multiplied context variant
@@ -66,7 +66,7 @@ struct SpellerLayout {
         hx = o; if (d->L == 2) o += r4((size_t)2 * U * 32 * d->Hs);   // hand-off copy of h for the persistent decode kernel
         r0x = o; if (anypre) o += r4((size_t)U * 32 * 4 * d->Hs);     // ... and the cell workgroups' part of the bottom-layer gates
         gx = o; if (anypre) o += r4((size_t)U * B * NHp * 4 * d->Hs + (pre_mh ? B * 16 * 4 : 0));      // (+ the placement check's XCC ids, multi-head)
-        lgx = o; if (d->L == 2) o += r4((size_t)U * B * 8 * 32);      // ... and its partial logits (free-running decode)
+        lgx = o; if (d->L == 2) o += r4((size_t)U * B * 8 * 32 * NHp);   // ... and its partial logits (free-running decode; multi-head: the heads' logit shares)
         wperm = o; if (anypre) o += r4((size_t)4 * d->Hs * d->Hs);
         wyperm = o; if (anypre) o += r4((size_t)4 * d->Hs * Vp);   // W_y rows and b_ih0 + b_hh0 in the same row order ...
         bperm = o; if (anypre) o += r4((size_t)4 * d->Hs);
@@ -77,9 +77,12 @@ struct SpellerLayout {
         pbias = o; if (pre_mh) o += r4(NHp * 4 * d->Hs);
         p0 = o; if (pre_mh) o += r4(B * 4 * d->Hs);
         // free-running form of the PRE kernel (arg-max feedback, no backward): Q^T = W_c[:, Hs:] feat^T, W_y^T (permuted columns), partial-logit slabs
-        qct = o; if (pre) o += r4((size_t)B * 32 * d->Tp);
-        wyT = o; if (pre) o += r4((size_t)Vp * 4 * d->Hs);
-        plx = o; if (pre) o += r4((size_t)U * (d->Hs / 4) * 512);
+        qct = o; if (anypre) o += r4((size_t)B * NHp * 32 * d->Tp);
+        wyT = o; if (anypre) o += r4((size_t)Vp * 4 * d->Hs);
+        plx = o; if (anypre) o += r4((size_t)U * (d->Hs / 4) * 512);
+        // multi-head, free-running: W_c[:, Hs:] W_dr (V rows of NH*D, stored 32 rows) and b_c + W_c[:, Hs:] b_dr
+        wcd = o; if (pre_mh) o += r4((size_t)32 * NHp * d->D);
+        bcp = o; if (pre_mh) o += r4(32);
         // Hs = 1024 one-launch decode: label half of the bottom-layer gates, query slices and partial contexts (hand-off slabs, adjacent)
         big = speller_big_shape(d->B, d->Tp, d->Hs, d->D, d->M, d->V, d->L, d->multi_head, d->use_mlp);
         if (big && !pre) { yw = o; o += r4((size_t)U * B * 4 * d->Hs); }
@@ -401,8 +404,10 @@ int las_speller_decode_batch(const las_speller_desc* d, int teacher_forced, int 
         // (a batch of more than two such slices is faster on the per-step kernels, which take all of it at once: heads = 4, B = 32 measured
         // 17.3 ms per step in four slices against 15.1)
         const int nb = NB / d->multi_head;
-        if (!teacher_forced || nb == 0 || d->B > 2 * nb) return 0;
-        return speller_persist_pre_mh_eligible(std::min(nb, d->B), d->Tp, d->Hs, d->D, d->M, d->V, d->L, d->multi_head, d->use_mlp) ? nb : 0;
+        if (nb == 0 || d->B > 2 * nb) return 0;
+        const int bb = std::min(nb, d->B);
+        if (teacher_forced) return speller_persist_pre_mh_eligible(bb, d->Tp, d->Hs, d->D, d->M, d->V, d->L, d->multi_head, d->use_mlp) ? nb : 0;
+        return (decode_mode == 1 && speller_persist_pre_mh_greedy_eligible(bb, d->Tp, d->Hs, d->D, d->M, d->V, d->L, d->multi_head, d->use_mlp)) ? nb : 0;
     }
     return speller_persist_eligible(NB, d->Tp, d->Hs, d->D, d->M, d->V, d->L, d->multi_head, d->use_mlp, !teacher_forced) ? NB : 0;
 }
@@ -473,10 +478,14 @@ int las_speller_fwd(const las_speller_desc* d, const float* feat, const float* k
                         speller_persist_pre_mh_eligible(B, Tp, Hs, D, d->M, V, L, d->multi_head, d->use_mlp);
     // (as for the single head: what a teacher-forced stashing forward leaves — P and gx per head — depends on the shape only, so that
     // las_speller_bwd can take its multi-head PRE path whichever forward kernels ran)
-    const bool pre_mh_stash = teacher_forced && lay.pre_mh && ((flags & LAS_FLAG_STASH) || pre_mh);
+    // Free-running decode_mode 1 with several heads runs the per-step kernels forward, but its backward is the teacher-forced one over the emitted
+    // symbols (tf_like, as for the single head): a stashing forward leaves P and gx for it too.
+    const bool preg_mh = !teacher_forced && decode_mode == 1 && lay.pre_mh && persist_on && err_word && !(flags & LAS_FLAG_FORCE_GENERIC) &&
+                         d->relu <= LAS_ACT_RELU && logp && speller_persist_pre_mh_greedy_eligible(B, Tp, Hs, D, d->M, V, L, d->multi_head, d->use_mlp);
+    const bool pre_mh_stash = tf_like && lay.pre_mh && ((flags & LAS_FLAG_STASH) || pre_mh || preg_mh);
     bool mh_gx_written = false;
-    LAS_TRY(speller_prologue(d->w_ih[0], w0p, Hs, V, Vp, (pre_stash || preg || pre_mh_stash) ? reserve + lay.wperm : nullptr, (pre || preg || pre_mh) ? reserve + lay.wyperm : nullptr,
-                             (pre || preg || pre_mh) ? reserve + lay.bperm : nullptr, d->b_ih[0], d->b_hh[0],
+    LAS_TRY(speller_prologue(d->w_ih[0], w0p, Hs, V, Vp, (pre_stash || preg || pre_mh_stash) ? reserve + lay.wperm : nullptr, (pre || preg || pre_mh || preg_mh) ? reserve + lay.wyperm : nullptr,
+                             (pre || preg || pre_mh || preg_mh) ? reserve + lay.bperm : nullptr, d->b_ih[0], d->b_hh[0],
                              teacher_forced ? (const long long*)labels_onehot : nullptr, y_all, B, U, U_lab, feat, (long)Tp * D, ctx_all, D, stream));
     // the PRE kernel's hand-off slabs (50 MB of sentinel words at paper size) are filled on the side stream, beside the two GEMMs below
     SideStream& side = side_stream();
@@ -523,7 +532,7 @@ int las_speller_fwd(const las_speller_desc* d, const float* feat, const float* k
             g.C = reserve + lay.pctx; g.ldc = (long)NH * 4 * Hs; g.M = B * Tp; g.N = NH * 4 * Hs; g.K = D; g.splitk = 1;
             LAS_TRY(gemm_f32(g, stream));
         }
-      if (pre_mh) {
+      if (pre_mh || preg_mh) {
         {
             GemmDesc g;      // step 0: the context is the first listener frame itself (las_model.py:198), no dim_reduce
             g.A = feat; g.lda = (long)Tp * D; g.a_kc = true;
@@ -532,13 +541,37 @@ int las_speller_fwd(const las_speller_desc* d, const float* feat, const float* k
             LAS_TRY(gemm_f32(g, stream));
         }
         {
-            GemmDesc g;      // label half of the bottom-layer gates for every step
+            GemmDesc g;      // label half of the bottom-layer gates for every step (free-running: <sos> and the biases alone, two step blocks)
             g.A = y_all; g.lda = Vp; g.a_kc = true;
             g.B = reserve + lay.wyperm; g.ldb = Vp; g.b_kc = true; g.bias0 = reserve + lay.bperm;
-            g.C = reserve + lay.yw; g.ldc = 4 * Hs; g.M = U * B; g.N = 4 * Hs; g.K = Vp; g.splitk = 1;
+            g.C = reserve + lay.yw; g.ldc = 4 * Hs; g.M = (preg_mh ? std::min(U, 2) : U) * B; g.N = 4 * Hs; g.K = Vp; g.splitk = 1;
             LAS_TRY(gemm_f32(g, stream));
         }
         PersistFwd p;
+        if (preg_mh) {
+            // the context share of the logits through dim_reduce: W_c[:, Hs:] context = sum_h sum_t a^h_t (W_cd,h feat_t) + W_c[:, Hs:] b_dr,
+            // W_cd = W_c[:, Hs:] W_dr (V x NH*D); Q^T[b][h] = W_cd,h feat[b]^T (V x T')
+            float* wcd = reserve + lay.wcd; float* bcp = reserve + lay.bcp;
+            {
+                GemmDesc g;
+                g.A = d->w_c + Hs; g.lda = Hs + D; g.a_kc = true;
+                g.B = d->w_dr; g.ldb = (long)NH * D; g.b_kc = false;
+                g.C = wcd; g.ldc = (long)NH * D; g.M = V; g.N = NH * D; g.K = D; g.splitk = 1;
+                LAS_TRY(gemm_f32(g, stream));
+            }
+            for (int hd = 0; hd < NH; ++hd) {
+                GemmDesc g;
+                g.A = wcd + (size_t)hd * D; g.lda = (long)NH * D; g.a_kc = true;
+                g.B = feat; g.ldb = D; g.b_kc = true; g.sB = (long)Tp * D;
+                g.C = reserve + lay.qct + (size_t)hd * 32 * Tp; g.ldc = Tp; g.sC = (long)NH * 32 * Tp;
+                g.M = V; g.N = Tp; g.K = D; g.batch = B; g.splitk = 1;
+                LAS_TRY(gemm_f32(g, stream));
+            }
+            LAS_TRY(matvec_rows(d->w_c + Hs, Hs + D, d->b_dr, bcp, V, D, stream, d->b_c));
+            LAS_TRY(transpose2d(reserve + lay.wyperm, reserve + lay.wyT, 4 * Hs, Vp, stream));
+            p.mode = 1; p.w_c = d->w_c; p.b_c = bcp; p.logp = logp; p.argmax = argmax; p.lgx = reserve + lay.lgx;
+            p.qct = reserve + lay.qct; p.wyT = reserve + lay.wyT; p.plx = reserve + lay.plx;
+        }
         p.NH = NH; p.p0 = p0;
         p.pctx = reserve + lay.pctx; p.gx = reserve + lay.gx; p.r0x = reserve + lay.r0x; p.yw = reserve + lay.yw;
         p.w0p = w0p; p.Vp = Vp;
@@ -555,6 +588,7 @@ int las_speller_fwd(const las_speller_desc* d, const float* feat, const float* k
             LAS_TRY(rc);
             persist_ran = true;
             mh_gx_written = true;
+          if (teacher_forced || (flags & LAS_FLAG_STASH)) {      // (a free-running decode without a backward needs no contexts)
             // per-head contexts (the dim_reduce input, stashed for the backward), then the reduced context of every step
             float* ctxcat = reserve + lay.ctxcat_all;
             for (int hd = 0; hd < NH; ++hd) {
@@ -570,6 +604,7 @@ int las_speller_fwd(const las_speller_desc* d, const float* feat, const float* k
             q.B = d->w_dr; q.ldb = (long)NH * D; q.b_kc = true; q.bias0 = d->b_dr;
             q.C = ctx_all + (size_t)B * D; q.ldc = D; q.M = U * B; q.N = D; q.K = NH * D; q.splitk = 1;
             LAS_TRY(gemm_f32(q, stream));
+          }
         }
       }
     }

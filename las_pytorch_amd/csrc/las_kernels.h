@@ -203,6 +203,7 @@ bool speller_persist_pre_eligible(int B, int Tp, int Hs, int D, int M, int V, in
 bool speller_persist_pre_greedy_eligible(int B, int Tp, int Hs, int D, int M, int V, int L, int heads, int use_mlp);   // ... of its free-running (mode 1) form
 bool speller_persist_pre_mh_shape(int B, int Tp, int Hs, int D, int M, int V, int L, int heads, int use_mlp);      // ... of its multi-head form (heads 2..4): shape only
 bool speller_persist_pre_mh_eligible(int B, int Tp, int Hs, int D, int M, int V, int L, int heads, int use_mlp);   // ... shape + switches + residency
+bool speller_persist_pre_mh_greedy_eligible(int B, int Tp, int Hs, int D, int M, int V, int L, int heads, int use_mlp);   // ... of its free-running (mode 1) form
 int speller_persist_fwd(const PersistFwd& p, hipStream_t stream);
 void speller_persist_set_trace(unsigned long long* dev_buf);   // profiling aid, see tools/ubench_persist_trace.py
 
@@ -322,7 +323,7 @@ int build_w0p(const float* w_ih0, float* w0p, int Hs, int V, int Vp, hipStream_t
               float* wyperm = nullptr, float* bperm = nullptr, const float* b_ih0 = nullptr, const float* b_hh0 = nullptr);
 int labels_to_y(const long long* labels, float* y_all, int B, int U, int V, int Vp, int u_lab, hipStream_t stream);
 // build_w0p + labels_to_y + ctx_{-1} = feat[:,0,:] in one launch (the Speller forward's element-wise preparations)
-int matvec_rows(const float* w, long ld, const float* x, float* out, int rows, int K, hipStream_t stream);      // out[r] = w[r, :] . x
+int matvec_rows(const float* w, long ld, const float* x, float* out, int rows, int K, hipStream_t stream, const float* addend = nullptr);      // out[r] = w[r, :] . x (+ addend[r])
 int speller_prologue(const float* w_ih0, float* w0p, int Hs, int V, int Vp, float* wperm, float* wyperm, float* bperm, const float* b_ih0,
                      const float* b_hh0, const long long* labels, float* y_all, int B, int U, int u_lab, const float* feat, long ldfeat,
                      float* ctx0, int D, hipStream_t stream);

@@ -546,17 +546,18 @@ __global__ __launch_bounds__(LER_THREADS) void ler_kernel(const float* __restric
     if (lane == 0) out[b] = (float)dist / (float)nt;
 }
 // out[r] = sum_k w[r * ld + k] x[k] for r < rows: one wave per row (the bias W_ctx b_dr of the multi-head decode kernel: 4Hs rows, once per call)
-__global__ __launch_bounds__(256) void matvec_rows_kernel(const float* __restrict__ w, long ld, const float* __restrict__ x, float* __restrict__ out, int rows, int K) {
+__global__ __launch_bounds__(256) void matvec_rows_kernel(const float* __restrict__ w, long ld, const float* __restrict__ x, float* __restrict__ out, int rows, int K,
+                                                          const float* __restrict__ addend) {
     const int r = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
     if (r >= rows) return;
     float acc = 0.f;
     for (int k = lane; k < K; k += 64) acc = fmaf(w[(long)r * ld + k], x[k], acc);
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o);
-    if (lane == 0) out[r] = acc;
+    if (lane == 0) out[r] = acc + (addend ? addend[r] : 0.f);
 }
-int matvec_rows(const float* w, long ld, const float* x, float* out, int rows, int K, hipStream_t stream) {
-    hipLaunchKernelGGL(matvec_rows_kernel, dim3((rows + 3) / 4), dim3(256), 0, stream, w, ld, x, out, rows, K);
+int matvec_rows(const float* w, long ld, const float* x, float* out, int rows, int K, hipStream_t stream, const float* addend) {
+    hipLaunchKernelGGL(matvec_rows_kernel, dim3((rows + 3) / 4), dim3(256), 0, stream, w, ld, x, out, rows, K, addend);
     LAS_LAUNCH_CHECK();
     return LAS_OK;
 }

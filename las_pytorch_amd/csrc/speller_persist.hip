@@ -950,7 +950,6 @@ struct AttnRole {
 // symbol's W_y column (2 KB per workgroup from the L2: the one dependent load this mode adds to the chain).
 template <int HS, int WS, bool GREEDY = false, bool MH = false>
 struct AttnPreRole {
-    static_assert(!(GREEDY && MH), "the free-running form is single-head");
     static constexpr int SPLIT = WS;                     // workgroups per utterance: 4, 8 or 16 (longer T' at smaller batches)
     static constexpr int GC = 4 * HS / SPLIT;            // gate columns of this workgroup
     static constexpr int CG = GC / 4;                    // column groups (one float4 each)
@@ -1022,12 +1021,15 @@ struct AttnPreRole {
         float* plv = qt + 32 * MAX_TP;
         float* lgl = plv + 32 * NJ8;
         float bcv = 0.f;
+        float* lgp = lgl + 32;      // GREEDY, MH: this head's share of the logits before the heads' shares meet
         if (GREEDY) {
+            // (MH: Q^T per (utterance, head) with dim_reduce folded in; the decoder-state share and the bias enter through head 0 only)
             for (int idx = tid; idx < 32 * MAX_TP; idx += PS_THREADS) {
                 const int v = idx / MAX_TP, t = idx % MAX_TP;
-                qt[idx] = (v < a.V && t < Tp) ? a.qct[((size_t)b * 32 + v) * Tp + t] : 0.f;
+                qt[idx] = (v < a.V && t < Tp) ? a.qct[(((size_t)b * NH + hd) * 32 + v) * Tp + t] : 0.f;
             }
-            bcv = (tid >> 5) < a.V ? a.b_c[tid >> 5] : 0.f;
+            bcv = ((tid >> 5) < a.V && (!MH || hd == 0)) ? a.b_c[tid >> 5] : 0.f;
+            if (MH && hd != 0) for (int idx = tid; idx < 32 * NJ8; idx += PS_THREADS) plv[idx] = 0.f;
         }
         lds_barrier();
         bool l2x = false;
@@ -1111,7 +1113,7 @@ struct AttnPreRole {
         };
         // GREEDY: the partial logits of h1_s (64 tiles of 32 floats for this utterance): waves 8.. fetch one 16-byte piece each while the
         // energies are computed (like R0) and drop it transposed into LDS; a piece that was not complete yet is re-polled when it lands
-        const bool plane = GREEDY && tid >= 512 && tid < 512 + NJ8 * 8;
+        const bool plane = GREEDY && (!MH || hd == 0) && tid >= 512 && tid < 512 + NJ8 * 8;
         auto pl_src = [&](int s) {
             const unsigned k = plane ? opaque((unsigned)tid) - 512u : 0u;
             return at_bytes(a.plx + (size_t)s * ((size_t)(HS / 4) * 512), 4u * ((((k >> 3) * 2 + ((unsigned)b >> 4)) * 16 + ((unsigned)b & 15u)) * 32 + (k & 7u) * 4));
@@ -1120,7 +1122,7 @@ struct AttnPreRole {
         // this XCD's L2, or final: whatever looks incomplete is re-read with agent-scope loads when it lands)
         auto pl_issue = [&](int s, f32x4& pv) { pv = plane ? *reinterpret_cast<const f32x4*>(pl_src(s)) : f32x4{0.f, 0.f, 0.f, 0.f}; };
         auto pl_land = [&](int s, const f32x4& pv) {
-            if (tid >= 512 && tid < 512 + NJ8 * 8) {       // whole waves
+            if ((!MH || hd == 0) && tid >= 512 && tid < 512 + NJ8 * 8) {       // whole waves
                 f32x4 v = pv;
                 if (__any(has_sentinel(v))) {
                     const float* src = pl_src(s);
@@ -1237,9 +1239,45 @@ struct AttnPreRole {
                     for (int i = 0; i < NJ8 / 32; ++i) acc += plv[v * NJ8 + l + 32 * i];
                     acc = gsum<16>(acc);                                  // row sums: the two 16-lane rows of a symbol meet as scalars
                     const float s0 = lane_f(acc, 0) + lane_f(acc, 16), s1 = lane_f(acc, 32) + lane_f(acc, 48);
-                    if (l == 0) lgl[v] = v < a.V ? (lane < 32 ? s0 : s1) + bcv : -INFINITY;
+                    if (l == 0) {
+                        if (MH) lgp[v] = (lane < 32 ? s0 : s1) + bcv;
+                        else lgl[v] = v < a.V ? (lane < 32 ? s0 : s1) + bcv : -INFINITY;
+                    }
                 }
                 lds_barrier();
+                if (MH) {
+                    // the heads' shares of the logits meet (one 128-byte line per workgroup and step, as the weighted sums below do)
+                    if (tid < 8) {
+                        float* lx = a.lgx + ((((size_t)s * B + b) * SPLIT + part_id) * NH) * 32;
+                        const f32x4 own = *reinterpret_cast<const f32x4*>(lgp + tid * 4);
+                        float* dstl = at_bytes(lx + hd * 32, opaque(16u * (unsigned)tid));
+                        if (l2x) {
+                            f32x4 cv;
+#pragma unroll
+                            for (int k = 0; k < 4; ++k) cv[k] = __uint_as_float(pub_bits(own[k]));
+                            *reinterpret_cast<f32x4*>(dstl) = cv;
+                        } else {
+                            st4_agent(dstl, own);
+                        }
+                        f32x4 tot = zero;
+                        for (int h2 = 0; h2 < NH; ++h2) {
+                            f32x4 v4 = own;
+                            if (h2 != hd) {
+                                const float* src = at_bytes(lx + h2 * 32, opaque(16u * (unsigned)tid));
+                                unsigned spins = 0;
+                                for (;;) {
+                                    v4 = ld4_agent(src);
+                                    if (!has_sentinel(v4)) break;
+                                    if (spin_expired(spins, a.err, 0xDEAD0019u)) break;
+                                }
+                            }
+                            tot[0] += v4[0]; tot[1] += v4[1]; tot[2] += v4[2]; tot[3] += v4[3];
+                        }
+#pragma unroll
+                        for (int k = 0; k < 4; ++k) lgl[tid * 4 + k] = (tid * 4 + k) < a.V ? tot[k] : -INFINITY;
+                    }
+                    lds_barrier();
+                }
                 // every wave: arg-max (first maximal index, as torch.argmax / torch.max do) from the 32 logits: DPP row reductions, the two
                 // rows of 16 meet as scalars (no LDS round trips on the chain)
                 lval = lgl[lane & 31];
@@ -1317,7 +1355,7 @@ struct AttnPreRole {
                 PS_STAMP(2, s + 1, 0);
                 bottom_cell(s + 1, wy);
             }
-            if (GREEDY && part_id == 0 && tid < 32) {
+            if (GREEDY && part_id == 0 && (!MH || hd == 0) && tid < 32) {
                 // outputs of step s (off the chain): log-probabilities, the arg-max, the one-hot row fed to step s+1
                 float se = tid < a.V ? expf(lval - lmax) : 0.f;
                 se = gsum<16>(se);
@@ -1412,6 +1450,11 @@ static bool persist_fwd_pre_fits(int Tp, int grid) {
         return false;
     return persistent_launch_fits(speller_persist_fwd_pre_kernel<HS, WS, GREEDY, MH>, PS_THREADS, smem, grid);
 }
+static bool persist_fwd_pre_mh_greedy_fits_rt(int Hs, int ws, int Tp, int grid) {      // free-running, several heads: 4 or 8 workgroups per (utterance, head)
+    if (ws == 16) return false;
+    if (Hs == 512) return ws == 4 ? persist_fwd_pre_fits<512, 4, true, true>(Tp, grid) : persist_fwd_pre_fits<512, 8, true, true>(Tp, grid);
+    return ws == 4 ? persist_fwd_pre_fits<256, 4, true, true>(Tp, grid) : persist_fwd_pre_fits<256, 8, true, true>(Tp, grid);
+}
 static bool persist_fwd_pre_mh_fits_rt(int Hs, int ws, int Tp, int grid) {
     if (Hs == 512) return ws == 4 ? persist_fwd_pre_fits<512, 4, false, true>(Tp, grid) : ws == 8 ? persist_fwd_pre_fits<512, 8, false, true>(Tp, grid)
                                                                                                   : persist_fwd_pre_fits<512, 16, false, true>(Tp, grid);
@@ -1455,6 +1498,17 @@ bool speller_persist_pre_mh_eligible(int B, int Tp, int Hs, int D, int M, int V,
     const int ws = speller_persist_pre_ws(B * heads, Tp, Hs, cus);
     if (ws == 0) return false;
     return persist_fwd_pre_mh_fits_rt(Hs, ws, Tp, Hs / 4 + ws * B * heads);
+}
+// ... free-running (decode_mode 1) with several heads: the heads' shares of the character distribution meet like their weighted sums
+bool speller_persist_pre_mh_greedy_eligible(int B, int Tp, int Hs, int D, int M, int V, int L, int heads, int use_mlp) {
+    if (opt_get(OPT_SPELLER_PRE) == 0 || opt_get(OPT_SPELLER_PRE_MH) == 0 || opt_get(OPT_SPELLER_PRE_GREEDY) == 0 || V > 32) return false;
+    if (!speller_persist_pre_mh_shape(B, Tp, Hs, D, M, V, L, heads, use_mlp)) return false;
+    int cus = 0, dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess)
+        return false;
+    const int ws = speller_persist_pre_ws(B * heads, Tp, Hs, cus);
+    if (ws == 0) return false;
+    return persist_fwd_pre_mh_greedy_fits_rt(Hs, ws, Tp, Hs / 4 + ws * B * heads);
 }
 // ... and its free-running (decode_mode 1: fed-back arg-max) form: the same structure with the character distribution inside the attention
 // workgroups (AttnPreRole<.., GREEDY>); forward only — a stashing forward (free-running training step) keeps the classic kernels, whose
@@ -1543,13 +1597,20 @@ int speller_persist_fwd(const PersistFwd& p, hipStream_t stream) {
         LAS_HIP_CHECK(hipGetDevice(&dev));
         LAS_HIP_CHECK(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
         const int ws = speller_persist_pre_ws(p.B * p.NH, p.Tp, p.Hs, cus);
-        LAS_REQUIRE(p.mode == 0 && p.gx && p.r0x && p.yw && p.p0 && ws != 0 &&
+        LAS_REQUIRE((p.mode == 0 || p.mode == 1) && p.gx && p.r0x && p.yw && p.p0 && ws != 0 &&
                     speller_persist_pre_mh_shape(p.B, p.Tp, p.Hs, p.Hs, PS_M, p.V, 2, p.NH, 1), "persistent speller (pre, multi-head) shape");
         a.split = ws;
         if (!p.prefilled) LAS_TRY(speller_persist_fwd_fill(p, stream));
         // the heads' exchange slab + 4 words per (utterance, column part) of XCC ids behind it
         LAS_HIP_CHECK(hipMemsetAsync(p.gx, 0xFF, sizeof(float) * ((size_t)p.U * p.B * p.NH * 4 * p.Hs + (size_t)p.B * 16 * 4), stream));
         const int grid = p.Hs / 4 + ws * p.B * p.NH;
+        if (p.mode == 1) {      // free-running: partial logits of h1 (cell workgroups -> head 0) and the heads' logit shares, both sentinel-prefilled
+            LAS_REQUIRE(p.qct && p.wyT && p.plx && p.lgx && p.logp && p.w_c && p.b_c && ws != 16, "persistent speller (pre, multi-head, free-running) buffers");
+            LAS_HIP_CHECK(hipMemsetAsync(p.plx, 0xFF, sizeof(float) * (size_t)p.U * (p.Hs / 4) * 512, stream));
+            LAS_HIP_CHECK(hipMemsetAsync(p.lgx, 0xFF, sizeof(float) * (size_t)p.U * p.B * ws * p.NH * 32, stream));
+            if (p.Hs == 512) return ws == 4 ? launch_persist_fwd_pre<512, 4, true, true>(a, grid, stream) : launch_persist_fwd_pre<512, 8, true, true>(a, grid, stream);
+            return ws == 4 ? launch_persist_fwd_pre<256, 4, true, true>(a, grid, stream) : launch_persist_fwd_pre<256, 8, true, true>(a, grid, stream);
+        }
         if (p.Hs == 512)
             return ws == 4 ? launch_persist_fwd_pre<512, 4, false, true>(a, grid, stream)
                            : ws == 8 ? launch_persist_fwd_pre<512, 8, false, true>(a, grid, stream) : launch_persist_fwd_pre<512, 16, false, true>(a, grid, stream);

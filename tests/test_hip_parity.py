@@ -707,6 +707,76 @@ def test_persistent_free_running_decode_matches_stepwise(cfg_name, B, Tp, U, dec
     _check_err()
 
 
+@pytest.mark.parametrize("cfg_name,heads,B,Tp,U", [("P", 2, 16, 100, 8), ("P", 4, 5, 37, 6), ("S", 2, 9, 120, 5), ("P", 2, 3, 20, 4)])
+def test_multi_head_free_running_training_step_backward_on_the_one_launch_kernel(cfg_name, heads, B, Tp, U):
+    """A free-running (decode_mode 1) TRAINING step with several attention heads: the forward is the free-running multi-head PRE kernel (the heads'
+    shares of the character distribution meet inside the attention workgroups), the backward the teacher-forced multi-head PRE backward over the
+    emitted symbols (it reads P and gx per head, which a stashing forward leaves whichever kernels it ran).  Against the per-step kernels both
+    ways: log-probs, arg-max sequences, every gradient."""
+    from las_pytorch_amd import Speller, synth
+    c = synth.CONFIGS[cfg_name]
+    torch.manual_seed(8)
+    sp = Speller(vocab_size=c["V"], hidden_size=c["Hs"], rnn_unit="LSTM", num_layers=c["Ls"], max_label_len=U,
+                 use_mlp_in_attention=True, mlp_dim_in_attention=c["M"], mlp_activate_in_attention="relu",
+                 listener_hidden_size=c["H"], multi_head=heads, decode_mode=1).cuda()
+    feat0 = torch.randn(B, Tp, 2 * c["H"], device="cuda") * 0.5
+    w = torch.randn(U, B, c["V"], device="cuda")
+    res, paths = [], []
+    for force in (False, True):
+        sp.force_generic = force
+        try:
+            sp.zero_grad(set_to_none=True)
+            feat = feat0.clone().requires_grad_(True)
+            preds, att = sp(feat, ground_truth=None, teacher_force_rate=0.0)
+            logp = torch.stack(preds)
+            (logp * w).sum().backward()
+            torch.cuda.synchronize()
+            paths.append((_cabi.last_path(_cabi.PATH_DECODE_FWD), _cabi.last_path(_cabi.PATH_DECODE_BWD)))
+            out = dict(logp=logp.detach().cpu().numpy(), dfeat=feat.grad.cpu().numpy())
+            out.update({"d" + n: p.grad.cpu().numpy() for n, p in sp.named_parameters() if p.grad is not None})
+            res.append(out)
+        finally:
+            sp.force_generic = False
+    assert paths == [("persist_pre_greedy", "persist_pre"), ("stepwise", "stepwise")], paths
+    assert (res[0]["logp"].argmax(-1) == res[1]["logp"].argmax(-1)).all()
+    assert set(res[0]) == set(res[1])
+    for k in res[0]:
+        scale_k = float(np.abs(res[1][k]).max()) + 1e-30
+        assert_close(res[0][k], res[1][k], f"multi-head free-running training {k}", rtol=1e-3, atol=1e-5 * max(1.0, scale_k))
+    _check_err()
+
+
+@pytest.mark.parametrize("cfg_name,heads,B,Tp,U", [("P", 2, 16, 100, 20), ("P", 4, 8, 100, 9), ("P", 2, 7, 57, 6), ("S", 2, 16, 200, 8), ("S", 4, 5, 90, 5),
+                                                   ("P", 2, 8, 200, 4), ("P", 2, 32, 60, 5), ("P", 4, 11, 30, 4)])
+def test_multi_head_free_running_decode_without_backward(cfg_name, heads, B, Tp, U):
+    """Validation-style greedy decode (decode_mode 1 under torch.no_grad()) with several attention heads on the free-running multi-head PRE kernel
+    against the per-step kernels: log-probabilities, arg-max sequences, every head's attention weights; partial batches, two slices (32 at
+    heads = 2, 11 at heads = 4), 4 and 8 workgroups per (utterance, head)."""
+    from las_pytorch_amd import Speller, synth
+    c = synth.CONFIGS[cfg_name]
+    torch.manual_seed(9)
+    sp = Speller(vocab_size=c["V"], hidden_size=c["Hs"], rnn_unit="LSTM", num_layers=c["Ls"], max_label_len=U,
+                 use_mlp_in_attention=True, mlp_dim_in_attention=c["M"], mlp_activate_in_attention="relu",
+                 listener_hidden_size=c["H"], multi_head=heads, decode_mode=1).cuda()
+    feat = torch.randn(B, Tp, 2 * c["H"], device="cuda") * 0.5
+    res, paths = [], []
+    for force in (False, True):
+        sp.force_generic = force
+        try:
+            with torch.no_grad():
+                preds, att = sp(feat, ground_truth=None, teacher_force_rate=0.0)
+            torch.cuda.synchronize()
+            paths.append(_cabi.last_path(_cabi.PATH_DECODE_FWD))
+            res.append((torch.stack(preds).cpu().numpy(), torch.stack([torch.stack(list(a)) for a in att]).cpu().numpy()))
+        finally:
+            sp.force_generic = False
+    assert paths == ["persist_pre_greedy", "stepwise"], paths
+    assert (res[0][0].argmax(-1) == res[1][0].argmax(-1)).all(), "arg-max sequences differ"
+    assert_close(res[0][0], res[1][0], "multi-head free-running logp")
+    assert_close(res[0][1], res[1][1], "multi-head free-running attention", rtol=1e-3, atol=1e-6)
+    _check_err()
+
+
 @pytest.mark.parametrize("cfg_name,B,Tp,U", [("P", 32, 100, 24), ("P", 7, 57, 9), ("P", 16, 200, 6), ("S", 32, 200, 12), ("S", 20, 100, 5),
                                              ("P", 40, 100, 5), ("P", 32, 112, 3)])
 def test_free_running_decode_without_backward_runs_the_pre_kernel(cfg_name, B, Tp, U):
