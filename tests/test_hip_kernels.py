@@ -643,3 +643,24 @@ def test_gemm_dual_k_source(a_kc, b_kc, M, N, K1):
     _cabi.check(L.las_gemm_f32_group(d, 1, _cabi.stream_ptr()))
     torch.cuda.synchronize()
     assert_close(C.cpu().numpy(), want, f"dual-K gemm {M}x{N}x2*{K1}", rtol=1e-4, atol=2e-4 * np.sqrt(2 * K1))
+
+
+@pytest.mark.parametrize("splitk", [0, 1])
+def test_gemm_batched_outputs_with_gaps_keep_their_neighbours(splitk, gemm_arith):
+    """Two batched GEMMs whose outputs interleave in ONE buffer (batch b of problem h at block 2 b + h: the per-head Q^T of the multi-head
+    free-running decode): few output tiles and a long K make the library split K, whose zero fill must clear each batch's own block only —
+    a fill over the whole strided span erased the other problem's results (round 5)."""
+    import torch
+    torch.manual_seed(3)
+    nb, M, N, K = 5, 30, 40, 512
+    A = [torch.randn(M, K, device="cuda") for _ in range(2)]
+    Bm = torch.randn(nb, N, K, device="cuda")
+    out = torch.full((nb, 2, 32, N), 7.0, device="cuda")           # rows 30, 31 of every block are gaps: they must keep the 7s
+    for h in range(2):
+        _gemm(A[h], Bm, out[0, h], M=M, N=N, K=K, lda=K, ldb=K, ldc=N, a_kc=True, b_kc=True, batch=nb, sA=0, sB=N * K, sC=2 * 32 * N, splitk=splitk)
+    torch.cuda.synchronize()
+    for h in range(2):
+        want = torch.einsum("mk,bnk->bmn", A[h].double(), Bm.double())
+        got = out[:, h, :M].double()
+        assert float((got - want).abs().max()) <= 1e-4 * float(want.abs().max()), f"problem {h} was clobbered"
+    assert bool((out[:, :, M:] == 7.0).all()), "the gap rows were overwritten"
