@@ -1,4 +1,4 @@
-"""Multi-head attention at paper size: the Speller's teacher-forced decode (and the whole training step) with the one-launch PRE kernels
+"""Multi-head attention at paper size: the Speller's teacher-forced decode, the whole training step, the greedy (validation) decode and a free-running training step with the one-launch PRE kernels
 against the per-step kernels (SPELLER_PRE_MH=0), heads = 2 / 4, (B, T) = (32, 800), U = 128.   python tools/ubench_multihead.py"""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -26,13 +26,21 @@ for heads in (2, 4):
             for p in las.parameters(): p.grad = None
             preds, _ = las(batch_data=x, batch_label=lab, teacher_force_rate=1.0, is_training=True)
             label_smoothing_loss_backward_device(stack_steps(preds), lab, 0.1)
-        res = []
-        for fn, n in ((fwd, 10), (step, 5)):
-            for _ in range(2): fn()
+        def greedy():
+            with torch.no_grad():
+                return las.speller(feat, ground_truth=None, teacher_force_rate=0.0)
+        def free_step():
+            for p in las.parameters(): p.grad = None
+            preds, _ = las(batch_data=x, batch_label=lab, teacher_force_rate=0.0, is_training=True)
+            label_smoothing_loss_backward_device(stack_steps(preds), lab, 0.1)
+        res, paths = [], []
+        for fn, n in ((fwd, 10), (step, 5), (greedy, 10), (free_step, 5)):
+            for _ in range(3): fn()
             torch.cuda.synchronize(); t0 = time.perf_counter()
             for _ in range(n): fn()
             torch.cuda.synchronize(); res.append((time.perf_counter() - t0) / n * 1e3)
-        print(f"heads={heads} B={B} SPELLER_PRE_MH={mh}: decode forward {res[0]:.2f} ms ({res[0] * 1e3 / U:.1f} us per step, path {_cabi.last_path(_cabi.PATH_DECODE_FWD)}), "
-              f"fwd + loss + bwd {res[1]:.2f} ms (backward path {_cabi.last_path(_cabi.PATH_DECODE_BWD)})")
+            paths.append(f"{_cabi.last_path(_cabi.PATH_DECODE_FWD)} / {_cabi.last_path(_cabi.PATH_DECODE_BWD)}")
+        print(f"heads={heads} B={B} SPELLER_PRE_MH={mh}: teacher-forced decode {res[0]:.2f} ms ({res[0] * 1e3 / U:.1f} us per step), training step (fwd + loss + bwd) {res[1]:.2f} ms "
+              f"[{paths[1]}]; greedy decode {res[2]:.2f} ms ({res[2] * 1e3 / U:.1f} us per step), free-running training step {res[3]:.2f} ms [{paths[3]}]")
     _cabi.set_option("SPELLER_PRE_MH", 1)
     _cabi.check_device_errors()
