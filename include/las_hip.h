@@ -90,7 +90,7 @@ const char* las_last_error(void);
  *   TRUST_ZEROED_GRADS 1* honour LAS_FLAG_GRADS_ZEROED (0: fill the gradient blocks regardless; A/B)
  *   TIME_KERNELS 0*       record HIP events around the one-launch decode kernels on their launch stream (las_debug_kernel_ms)
  *   SPELLER_PRE_GREEDY 1  free-running (decode_mode 1) decode on the pre-multiplied-context kernel (0: classic persistent kernel; A/B)
- *   SPELLER_PRE_MH 1      multi-head attention (heads 2 or 4, teacher forcing) on the pre-multiplied-context kernels, forward and backward
+ *   SPELLER_PRE_MH 1      multi-head attention (heads 2 or 4; teacher forcing and decode_mode 1) on the pre-multiplied-context kernels, forward and backward
  *                         (0: per-step kernels; A/B)
  *   GEMM_BIG 1            256 x 256-tile GEMM where it fills the chip (0 never, 2 whenever the shape allows; A/B)
  * Replaces nothing in the reference (pure Python, no switches).
@@ -167,9 +167,10 @@ int las_attn_keys_fwd(const las_speller_desc* d, const float* feat, float* keys,
 
 size_t las_speller_reserve_floats(const las_speller_desc* d, int U);
 
-/* Utterances per launch of the one-launch decode kernels for this description (d->B is ignored): the largest batch for which
- * las_speller_fwd / las_speller_bwd take a one-launch path (today 32 for Hs <= 512, 16 for the Hs = 1024 kernels, or 0 when the shape, the decode mode or a switch rules it
- * out).  A caller with a larger batch gains by running the Speller in slices of that many utterances — every slice then decodes
+/* Utterances per launch of the one-launch decode kernels for this description: the largest batch for which
+ * las_speller_fwd / las_speller_bwd take a one-launch path (today 32 for Hs <= 512, 16 for the Hs = 1024 kernels, 32 / heads with 2 or 4 attention heads, or 0
+ * when the shape, the decode mode or a switch rules it out).  d->B is ignored except with several heads, where 0 is returned for a batch of more than two such slices
+ * (the per-step kernels, which take the whole batch at once, are faster there).  A caller with a larger batch gains by running the Speller in slices of that many utterances — every slice then decodes
  * in one launch instead of U per-step launch chains (las_pytorch_amd/model/las_model.py::Speller._run does; the reference's loop
  * model/las_model.py:205-236 has no such notion).  Pure function of its arguments, the option registry and the device's CU count. */
 int las_speller_decode_batch(const las_speller_desc* d, int teacher_forced, int decode_mode);
