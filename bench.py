@@ -126,6 +126,50 @@ def build_model(cfg_name, U, device):
     return las.to(device), c, sd_np
 
 
+def multi_head_block(device, T, U, heads=2, B=16, iters=5):
+    """The same training step (fwd + label-smoothing loss + bwd; no optimizer) with TWO attention heads (reference las_model.py:298-314;
+    multi_head is 1 in the shipped YAMLs) at 16 utterances — what one launch of the multi-head decode kernels holds — on the one-launch
+    kernels and, for comparison, on the per-step launch chains (option SPELLER_PRE_MH = 0).  Never the metric; reported beside it."""
+    from las_pytorch_amd import LAS, Listener, Speller, _cabi, synth
+    from las_pytorch_amd.solver.solver import label_smoothing_loss_backward_device, stack_steps
+    c = synth.CONFIGS["P"]
+    sd_np = synth.make_state_dict(synth.config_shapes("P", multi_head=heads), seed=23, scale=0.1)
+    listener = Listener(input_feature_dim=c["F"], hidden_size=c["H"], num_layers=c["L"], rnn_unit="LSTM", use_gpu=True)
+    speller = Speller(vocab_size=c["V"], hidden_size=c["Hs"], rnn_unit="LSTM", num_layers=c["Ls"], max_label_len=U, use_mlp_in_attention=True,
+                      mlp_dim_in_attention=c["M"], mlp_activate_in_attention="relu", listener_hidden_size=c["H"], multi_head=heads, decode_mode=1, use_gpu=True)
+    las = LAS(listener, speller)
+    las.load_state_dict({k: torch.from_numpy(v.copy()) for k, v in sd_np.items()}, strict=True)
+    las = las.to(device)
+    x = torch.from_numpy(synth.make_inputs(B, T, c["F"], seed=23)).to(device)
+    idx, lens = synth.make_labels(B, U, c["V"], seed=23)
+    lab = torch.from_numpy(synth.onehot_labels(idx, lens, c["V"])).to(device)
+
+    def step():
+        for p in las.parameters():
+            p.grad = None
+        preds, _ = las(batch_data=x, batch_label=lab, teacher_force_rate=1.0, is_training=True)
+        label_smoothing_loss_backward_device(stack_steps(preds), lab, 0.1)
+
+    out = {"workload": f"P sizes with multi_head = {heads}, (B={B},T={T}), teacher-forced U={U}: fwd + loss + bwd"}
+    old = _cabi.get_option("SPELLER_PRE_MH")
+    try:
+        for key, mh in (("one_launch", 1), ("per_step", 0)):
+            _cabi.set_option("SPELLER_PRE_MH", mh)
+            for _ in range(2):
+                step()
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(iters):
+                step()
+            torch.cuda.synchronize()
+            out[key] = {"ms_per_step": round((time.perf_counter() - t0) / iters * 1e3, 3),
+                        "decode_paths": [_cabi.last_path(_cabi.PATH_DECODE_FWD), _cabi.last_path(_cabi.PATH_DECODE_BWD)]}
+    finally:
+        _cabi.set_option("SPELLER_PRE_MH", old)
+    _cabi.check_device_errors()
+    return out
+
+
 def roofline_rec_fwd(c, B, T, iters=20, with_traffic=True):
     """Times the dominant kernel (layer-0 forward recurrence, rec_fwd_fast<H>) alone with HIP events on the stream it
     is launched on, on real pre-activations, and prices it against the HBM roofline with the ALGORITHMIC bytes of the
@@ -749,6 +793,10 @@ def main():
             res["cpu_baseline"] = cpu_baseline(cfg_name, B, T, U, train)
         if world == 1 and args.workload == "P_train" and not args.no_secondary:
             res["config"]["greedy_decode"] = greedy_decode_block(las, x, U)
+            try:
+                res["multi_head_variant"] = multi_head_block(device, T, U)
+            except Exception as e:      # (an optional side figure must never cost the driver line)
+                res["multi_head_variant"] = {"error": f"{type(e).__name__}: {e}"[:200]}
             # BASELINE.json configs[1] (small 128/256 model, forward only) measured beside the headline for reference
             del las
             torch.cuda.empty_cache()
