@@ -40,7 +40,7 @@ struct PblstmBwdLayout {
 
 struct SpellerLayout {
     size_t y_all, ctx_all, h_all, c_all, gates_all, q_all, w0p, ctxcat_all, hx, r0x, lgx, wperm, wyperm, bperm, yw, pctx, gx, bqp, bfl, blg, beg, qct, wyT, plx,
-        mperm, pbias, p0, wcd, bcp, total;
+        mperm, pbias, p0, wcd, bcp, exs, total;
     bool pre_mh;               // ... its multi-head form (heads 2..4): P, gx per head, the folded matrices W_ctx W_dr[:, h]
     bool big;                  // room for the one-launch decode of the Hs = 1024 shape (speller_big.hip)
     bool pre;                  // room for the persistent decode kernel's pre-multiplied context variant
@@ -80,6 +80,8 @@ struct SpellerLayout {
         qct = o; if (anypre) o += r4((size_t)B * NHp * 32 * d->Tp);
         wyT = o; if (anypre) o += r4((size_t)Vp * 4 * d->Hs);
         plx = o; if (anypre) o += r4((size_t)U * (d->Hs / 4) * 512);
+        // Hs = 256 with 16 attention workgroups per utterance (long T'): the frame slices' energies, exchanged every step
+        exs = o; if (pre && d->Hs == 256 && speller_persist_pre_ws(d->B, d->Tp, d->Hs, -1) == 16) o += r4((size_t)U * B * 16 * 64);
         // multi-head, free-running: W_c[:, Hs:] W_dr (V rows of NH*D, stored 32 rows) and b_c + W_c[:, Hs:] b_dr
         wcd = o; if (pre_mh) o += r4((size_t)32 * NHp * d->D);
         bcp = o; if (pre_mh) o += r4(32);
@@ -458,7 +460,8 @@ int las_speller_fwd(const las_speller_desc* d, const float* feat, const float* k
     // the pre-multiplied context variant of the persistent kernel (teacher forcing): P = feat . W_ctx^T in the cell
     // workgroups' column order; the kernel then publishes sum_t a_t P_t instead of the context, which one batched GEMM
     // recovers afterwards (the backward pass and the character distribution need it)
-    const bool pre = persist && teacher_forced && lay.pre &&
+    // (independent of the classic kernel's eligibility: at Hs = 256 and T' > 448 only the PRE variant, with the keys split by frames, applies)
+    const bool pre = persist_on && err_word && !(flags & LAS_FLAG_FORCE_GENERIC) && d->relu <= LAS_ACT_RELU && teacher_forced && lay.pre &&
                      speller_persist_pre_eligible(B, Tp, Hs, D, d->M, V, L, d->multi_head, d->use_mlp);
     // What a teacher-forced forward leaves in `reserve` depends on the SHAPE only (lay.pre), never on switches, the error word
     // or the occupancy calculator: P = feat . W_ctx^T and the per-step sums gx_s = sum_t a_t P_t are always there, so that
@@ -506,7 +509,7 @@ int las_speller_fwd(const las_speller_desc* d, const float* feat, const float* k
         g.C = reserve + lay.pctx; g.ldc = 4 * Hs; g.M = B * Tp; g.N = 4 * Hs; g.K = D; g.splitk = 1;
         LAS_TRY(gemm_f32(g, stream));
     }
-    bool persist_ran = persist || preg;
+    bool persist_ran = persist || pre || preg;
     bool pre_ran = false;           // a PRE kernel ran AND the contexts of every step are wanted: they are recovered by one GEMM below
     bool gx_written = false;        // ... a PRE kernel ran: the per-step sums gx are in the reserve already
     if (pre_mh_stash) {
@@ -608,7 +611,7 @@ int las_speller_fwd(const las_speller_desc* d, const float* feat, const float* k
         }
       }
     }
-    if (persist || preg) {
+    if (persist || pre || preg) {
         PersistFwd p;
         p.prefilled = side_fill;
         if (preg) {
@@ -632,6 +635,7 @@ int las_speller_fwd(const las_speller_desc* d, const float* feat, const float* k
             g.C = reserve + lay.yw; g.ldc = 4 * Hs; g.M = (preg ? std::min(U, 2) : U) * B; g.N = 4 * Hs; g.K = Vp; g.splitk = 1;
             LAS_TRY(gemm_f32(g, stream));
             p.pctx = reserve + lay.pctx; p.gx = reserve + lay.gx; p.r0x = reserve + lay.r0x; p.yw = reserve + lay.yw;
+            p.ex = reserve + lay.exs;
         }
         p.w0p = w0p; p.Vp = Vp;
         p.w_hh0 = d->w_hh[0]; p.w_ih1 = d->w_ih[1]; p.w_hh1 = d->w_hh[1];

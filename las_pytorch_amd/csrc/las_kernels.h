@@ -191,6 +191,7 @@ struct PersistFwd {
     // PRE variant with NH > 1 attention heads (speller_persist_pre_mh_eligible; teacher forcing): pctx is (B*Tp, NH*4Hs), gx U*B*NH*4Hs floats (stash and the
     // heads' exchange slab), p0 = feat[:, 0] . W_ctx^T (B, 4Hs); q_all is (U*B, NH*M), att [U][NH][B][Tp] as the per-step kernels lay them out
     int NH = 1; const float* p0 = nullptr;
+    float* ex = nullptr;                            // PRE variant at Hs = 256 with 16 workgroups per utterance (speller_persist_pre_ws): U*B*16*64 floats, the frame slices' energies
     int B, Tp, U, Hs, V, relu;
     unsigned* err;
     bool prefilled = false;                         // the caller has sentinel-filled the hand-off slabs already (speller_persist_fwd_fill)

@@ -56,6 +56,7 @@ struct PersistArgs {
     // feat . (W_ctx W_dr[:, h])^T, head 0's carrying W_ctx b_dr as a bias (the attention weights sum to 1) — gx is [U][B][NH][4Hs] and doubles as
     // the heads' exchange slab (sentinel-prefilled, agent-scope stores); p0 = feat[:, 0] . W_ctx^T (B, 4Hs) is the step-0 context product
     int NH; const float* p0;
+    float* ex;                             // PRE variant, Hs = 256 with 16 workgroups per utterance: the frame slices' energies, [U][B][16][64], sentinel-prefilled
     int B, Tp, U, relu;
     int split;                     // attention workgroups per utterance (each owns D/split context columns)
     unsigned* err;
@@ -958,15 +959,23 @@ struct AttnPreRole {
     static constexpr int MAX_TP = NIP * TS;              // 112, 224 or 448 frames
     static constexpr int EP = (MAX_TP + 63) & ~63;       // energies padded to whole waves (pad = -inf)
     static constexpr int NJ = HS / 64;
-    static_assert(TS == 8 || TS == 16 || TS == 32, "time-slice layout");
+    static_assert(TS == 8 || TS == 16 || TS == 32 || TS == 64, "time-slice layout");
+    // Hs = 256 with 16 workgroups per utterance (T' up to 896, B <= 12: BASELINE configs[4] for the small model, T' = 750): a column group spans a
+    // whole wave, and the KEYS no longer fit one workgroup's LDS (192 KB at T' = 750) — each workgroup keeps the keys of ITS ceil(T'/16) frames,
+    // computes their energies and the sixteen exchange them (64 floats each, one more hand-off per step) before the softmax
+    static constexpr bool FSPLIT = TS == 64;
+    static_assert(!FSPLIT || (!GREEDY && !MH), "the frame-split form is teacher-forced, single-head");
     // float4 of a W_phi row slice kept in registers; the rest lives in LDS.  With 16 workgroups per utterance (T' up to 448: the keys
     // alone take up to 122 KB of LDS) all of it stays in registers and R0 is fetched with a blocking load instead
     static constexpr int NJR = WS == 16 ? NJ : NJ / 2;
     static constexpr bool R0_BLOCKING = WS == 16;
     static constexpr int NJ8 = HS / 8;                   // cell-workgroup column groups = partial-logit tiles per utterance
-    static __host__ __device__ constexpr int lds_base(int Tp) { return HS + PS_M + EP + MAX_TP + 2 * GC + Tp * PS_KLD + PS_M * 4 * (NJ - NJR) * 16; }
+    static __host__ __device__ constexpr int lds_base(int Tp) {
+        return HS + PS_M + EP + MAX_TP + 2 * GC + (FSPLIT ? (Tp + SPLIT - 1) / SPLIT : Tp) * PS_KLD + PS_M * 4 * (NJ - NJR) * 16 + (FSPLIT ? 64 : 0);
+    }
     static __host__ __device__ constexpr int lds_floats(int Tp) { return lds_base(Tp) + (GREEDY ? 32 * MAX_TP + 32 * NJ8 + 64 : 0); }
 
+    static __host__ __device__ constexpr int fnt_max(int Tp) { return FSPLIT ? (Tp + SPLIT - 1) / SPLIT : Tp; }      // key rows held in LDS
     static __device__ void run(const PersistArgs& a, float* smem, const int widx) {
         // MH: one set of SPLIT workgroups per (utterance, head) — query rows, softmax and P block of that head; the heads' weighted sums meet
         // through gx before the bottom cell, which every head's workgroup applies (identical arithmetic) and head 0 publishes
@@ -1001,15 +1010,18 @@ struct AttnPreRole {
         }
         if (tid >= Tp && tid < MAX_TP) as[tid] = 0.f;         // frames past T' carry zero weight (MAX_TP <= 448 < threads)
         if (tid >= Tp && tid < EP) es[tid] = -INFINITY;
-        for (int idx = tid; idx < Tp * (PS_M / 4); idx += PS_THREADS) {
+        // (FSPLIT: the keys of this workgroup's frames [ft0, ft0 + fnt) only)
+        const int fth = (Tp + SPLIT - 1) / SPLIT, ft0 = FSPLIT ? part_id * fth : 0, fnt = FSPLIT ? max(0, min(fth, Tp - ft0)) : Tp;
+        for (int idx = tid; idx < fnt * (PS_M / 4); idx += PS_THREADS) {
             const int t = idx / (PS_M / 4), m4 = idx % (PS_M / 4);
-            *reinterpret_cast<f32x4*>(ks + t * PS_KLD + m4 * 4) = ld4p(a.keys + ((size_t)b * Tp + t) * PS_M + m4 * 4);
+            *reinterpret_cast<f32x4*>(ks + t * PS_KLD + m4 * 4) = ld4p(a.keys + ((size_t)b * Tp + ft0 + t) * PS_M + m4 * 4);
         }
         const int prow = tid >> 4, pk = tid & 15;         // phi: 64 rows x 16 lanes
         // W_phi row prow, columns 4 (pk + 16 j): j < NJR in registers, the rest in LDS ([row][HS / 2], a wave's 16-lane row groups read
         // 256 contiguous bytes each: conflict-free b128 reads) — the P rows and the query weights together do not fit 128 registers
         f32x4 wphi[NJR];
-        float* wpl = ks + Tp * PS_KLD;
+        float* wpl = ks + fnt_max(Tp) * PS_KLD;
+        float* esp = wpl + PS_M * 4 * (NJ - NJR) * 16;      // FSPLIT: this workgroup's energies before the exchange (64 floats)
 #pragma unroll
         for (int j = 0; j < NJR; ++j) wphi[j] = ld4p(a.w_phi + (size_t)(hd * PS_M + prow) * HS + 4 * (pk + 16 * j));
 #pragma unroll
@@ -1190,17 +1202,49 @@ struct AttnPreRole {
             {
                 const int sub = tid & 7;
                 const f32x4 q0 = *reinterpret_cast<const f32x4*>(qs + sub * 8), q1 = *reinterpret_cast<const f32x4*>(qs + sub * 8 + 4);
+                if (!FSPLIT) {
 #pragma unroll
-                for (int t = tid >> 3; t < EP; t += PS_THREADS / 8) {
-                    if (t >= Tp) break;
-                    const float* kr = ks + t * PS_KLD + sub * 8;
-                    float acc = dot4p(*reinterpret_cast<const f32x4*>(kr), q0, 0.f);
-                    acc = dot4p(*reinterpret_cast<const f32x4*>(kr + 4), q1, acc);
+                    for (int t = tid >> 3; t < EP; t += PS_THREADS / 8) {
+                        if (t >= Tp) break;
+                        const float* kr = ks + t * PS_KLD + sub * 8;
+                        float acc = dot4p(*reinterpret_cast<const f32x4*>(kr), q0, 0.f);
+                        acc = dot4p(*reinterpret_cast<const f32x4*>(kr + 4), q1, acc);
+                        acc = gsum<8>(acc);
+                        if (sub == 0) es[t] = acc;
+                    }
+                } else if (tid < 64 * 8) {      // own frames: at most 64, 8 lanes each (slots past the slice publish 0: a slot is complete or the sentinel)
+                    const int t = tid >> 3;
+                    float acc = 0.f;
+                    if (t < fnt) {
+                        const float* kr = ks + t * PS_KLD + sub * 8;
+                        acc = dot4p(*reinterpret_cast<const f32x4*>(kr), q0, 0.f);
+                        acc = dot4p(*reinterpret_cast<const f32x4*>(kr + 4), q1, acc);
+                    }
                     acc = gsum<8>(acc);
-                    if (sub == 0) es[t] = acc;
+                    if (sub == 0) esp[t] = acc;
                 }
             }
             lds_barrier();
+            if (FSPLIT) {
+                // ---- the sixteen slices of the energies meet: publish 256 bytes (two whole lines), collect every part (the own one included)
+                float* ex = a.ex + ((size_t)s * B + b) * (SPLIT * 64);
+                if (tid < 16) st4_agent(at_bytes(ex + part_id * 64, opaque(16u * (unsigned)tid)), *reinterpret_cast<const f32x4*>(esp + tid * 4));
+                if (tid < SPLIT * 16) {
+                    const float* src = at_bytes(ex, opaque(16u * (unsigned)tid));
+                    unsigned spins = 0;
+                    f32x4 v;
+                    for (;;) {
+                        v = ld4_agent(src);
+                        if (!__any(has_sentinel(v))) break;
+                        if (spin_expired(spins, a.err, 0xDEAD001Au)) break;
+                    }
+                    const int pp = tid >> 4, j0 = (tid & 15) * 4;
+#pragma unroll
+                    for (int k = 0; k < 4; ++k)
+                        if (j0 + k < fth && pp * fth + j0 + k < Tp) es[pp * fth + j0 + k] = v[k];
+                }
+                lds_barrier();
+            }
             PS_STAMP(1, s, 3);
             f32x4 pv = zero;
             if (GREEDY) pl_issue(s, pv);         // (published ~0.4 us after h1_s: issued now, the first read usually finds them complete)
@@ -1311,6 +1355,7 @@ struct AttnPreRole {
                         const float lo = lane_f(acc[k], 0) + lane_f(acc[k], 16), hi = lane_f(acc[k], 32) + lane_f(acc[k], 48);
                         acc[k] = lane < 32 ? lo : hi;
                     }
+                    if (TS == 64) acc[k] = (lane_f(acc[k], 0) + lane_f(acc[k], 16)) + (lane_f(acc[k], 32) + lane_f(acc[k], 48));      // a whole wave per column group
                 }
                 // stash for the backward pass (its softmax-backward statistic reuses this sum): off the chain, plain stores
                 float* dst = a.gx + (((size_t)s * B + b) * NH + hd) * (4 * HS) + col0;
@@ -1426,7 +1471,7 @@ bool speller_persist_eligible(int B, int Tp, int Hs, int D, int M, int V, int L,
 int speller_persist_pre_ws(int B, int Tp, int Hs, int cus) {
     for (int ws = 4; ws <= 16; ws *= 2) {
         const int ts = PS_THREADS / (Hs / ws);           // time slices = threads / column groups
-        if (ts > 32) break;
+        if (ts > 64) break;                              // (64: Hs = 256 with 16 workgroups per utterance, the frame-split form)
         if (Tp <= 14 * ts && (cus < 0 || Hs / 4 + ws * B <= cus)) return ws;
     }
     return 0;
@@ -1456,6 +1501,7 @@ static bool persist_fwd_pre_mh_greedy_fits_rt(int Hs, int ws, int Tp, int grid) 
     return ws == 4 ? persist_fwd_pre_fits<256, 4, true, true>(Tp, grid) : persist_fwd_pre_fits<256, 8, true, true>(Tp, grid);
 }
 static bool persist_fwd_pre_mh_fits_rt(int Hs, int ws, int Tp, int grid) {
+    if (Hs == 256 && ws == 16) return false;      // (the frame-split form is single-head)
     if (Hs == 512) return ws == 4 ? persist_fwd_pre_fits<512, 4, false, true>(Tp, grid) : ws == 8 ? persist_fwd_pre_fits<512, 8, false, true>(Tp, grid)
                                                                                                   : persist_fwd_pre_fits<512, 16, false, true>(Tp, grid);
     return ws == 4 ? persist_fwd_pre_fits<256, 4, false, true>(Tp, grid) : persist_fwd_pre_fits<256, 8, false, true>(Tp, grid);
@@ -1467,7 +1513,7 @@ static bool persist_fwd_pre_fits_rt(int Hs, int ws, int Tp, int grid, bool greed
         return ws == 4 ? persist_fwd_pre_fits<256, 4, true>(Tp, grid) : persist_fwd_pre_fits<256, 8, true>(Tp, grid);
     }
     if (Hs == 512) return ws == 4 ? persist_fwd_pre_fits<512, 4>(Tp, grid) : ws == 8 ? persist_fwd_pre_fits<512, 8>(Tp, grid) : persist_fwd_pre_fits<512, 16>(Tp, grid);
-    return ws == 4 ? persist_fwd_pre_fits<256, 4>(Tp, grid) : persist_fwd_pre_fits<256, 8>(Tp, grid);
+    return ws == 4 ? persist_fwd_pre_fits<256, 4>(Tp, grid) : ws == 8 ? persist_fwd_pre_fits<256, 8>(Tp, grid) : persist_fwd_pre_fits<256, 16>(Tp, grid);
 }
 // Shape, switch, CU count AND the occupancy calculator: las_speller_bwd repeats this call to learn what las_speller_fwd did
 // (its PRE variant needs the P matrix and the gx slabs the forward's PRE variant left in the reserve).
@@ -1590,7 +1636,7 @@ int speller_persist_fwd(const PersistFwd& p, hipStream_t stream) {
     a.trace = g_persist_trace;
     a.pctx = p.pctx; a.gx = p.gx; a.r0x = p.r0x; a.yw = p.yw;
     a.qct = p.qct; a.wyT = p.wyT; a.plx = p.plx;
-    a.NH = p.NH; a.p0 = p.p0;
+    a.NH = p.NH; a.p0 = p.p0; a.ex = p.ex;
     LAS_REQUIRE(p.err != nullptr, "the persistent speller needs the device error word");
     if (p.pctx && p.NH > 1) {      // multi-head form of the pre-multiplied context variant (the caller checked speller_persist_pre_mh_eligible)
         int cus = 0, dev = 0;
@@ -1634,6 +1680,11 @@ int speller_persist_fwd(const PersistFwd& p, hipStream_t stream) {
         if (p.Hs == 512)
             return ws == 4 ? launch_persist_fwd_pre<512, 4>(a, grid, stream)
                            : ws == 8 ? launch_persist_fwd_pre<512, 8>(a, grid, stream) : launch_persist_fwd_pre<512, 16>(a, grid, stream);
+        if (ws == 16) {      // frame-split keys: the slices' energies are exchanged through a sentinel-prefilled slab
+            LAS_REQUIRE(p.ex != nullptr, "persistent speller (pre, frame-split keys) exchange slab");
+            LAS_HIP_CHECK(hipMemsetAsync(p.ex, 0xFF, sizeof(float) * (size_t)p.U * p.B * 16 * 64, stream));
+            return launch_persist_fwd_pre<256, 16>(a, grid, stream);
+        }
         return ws == 4 ? launch_persist_fwd_pre<256, 4>(a, grid, stream) : launch_persist_fwd_pre<256, 8>(a, grid, stream);
     }
     // sentinel-fill what the phases hand over: every h of both layers and the contexts of steps 1..U

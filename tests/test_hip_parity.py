@@ -471,9 +471,32 @@ def test_edge_shapes_vs_oracle(cfg_name, B, T, U):
                                                     ("P", 8, 375, 5, None), ("P", 32, 200, 4, None), ("S", 8, 500, 4, None),
                                                     ("S", 16, 300, 4, None),
                                                     # batches beyond one launch: Speller._run slices them (32 + 32 + 6, 32 + 1)
-                                                    ("P", 70, 50, 6, None), ("S", 33, 40, 5, None)])
+                                                    ("P", 70, 50, 6, None), ("S", 33, 40, 5, None),
+                                                    # Hs = 256 beyond T' = 448: the keys split by frames over 16 workgroups per utterance (round 5)
+                                                    ("S", 8, 750, 6, None), ("S", 12, 896, 3, None), ("S", 3, 449, 4, 0.1), ("S", 1, 600, 3, None)])
 def test_persistent_decode_kernel_matches_stepwise(cfg_name, B, Tp, U, scale):
     _persistent_vs_stepwise(cfg_name, B, Tp, U, scale, "relu")
+
+
+@pytest.mark.parametrize("B,Tp", [(8, 750), (12, 896), (2, 449)])
+def test_long_utterance_small_model_decode_takes_the_frame_split_kernel(B, Tp):
+    """BASELINE configs[4] for the small model (Hs = 256, T' = 750): 192 KB of keys do not fit one workgroup's LDS — the teacher-forced forward
+    keeps them split by frames over the 16 attention workgroups of an utterance, which exchange their energies every step
+    (``AttnPreRole<256, 16>``); asserts that path (the per-step kernels took these shapes until round 5) and the classic one-launch backward."""
+    from las_pytorch_amd import Speller, synth
+    c = synth.CONFIGS["S"]
+    U = 4
+    torch.manual_seed(5)
+    sp = Speller(vocab_size=c["V"], hidden_size=c["Hs"], rnn_unit="LSTM", num_layers=c["Ls"], max_label_len=U, use_mlp_in_attention=True,
+                 mlp_dim_in_attention=c["M"], mlp_activate_in_attention="relu", listener_hidden_size=c["H"], multi_head=1, decode_mode=1).cuda()
+    feat = (torch.randn(B, Tp, 2 * c["H"], device="cuda") * 0.5).requires_grad_(True)
+    idx, lens = synth.make_labels(B, U, c["V"], seed=11, ragged=True)
+    lab = torch.from_numpy(synth.onehot_labels(idx, lens, c["V"])).cuda()
+    preds, _ = sp(feat, ground_truth=lab, teacher_force_rate=1.0)
+    torch.stack(preds).sum().backward()
+    torch.cuda.synchronize()
+    assert (_cabi.last_path(_cabi.PATH_DECODE_FWD), _cabi.last_path(_cabi.PATH_DECODE_BWD)) == ("persist_pre", "persist")
+    _check_err()
 
 
 @pytest.mark.parametrize("B,Tp,U,scale,activate", [(16, 100, 12, None, "relu"), (3, 8, 6, 0.08, "relu"), (16, 200, 5, None, "relu"),
