@@ -983,9 +983,11 @@ struct AttnPreRole {
         // (MH placement: the NH workgroups that exchange their sums — same utterance, same column part — get block indices 8 apart whenever
         // B * SPLIT is a multiple of 8, i.e. ONE XCD under round-robin dispatch; verified at run time below, never assumed)
         const bool xmap = MH && ((a.B * SPLIT) & 7) == 0;
+        // (FSPLIT placement: the SPLIT workgroups of an utterance exchange their energies — with B a multiple of 8 they get block indices 8 apart)
+        const bool fmap = FSPLIT && (a.B & 7) == 0;
         const int qx = xmap ? (widx / (8 * NH)) * 8 + (widx & 7) : 0;
-        const int pu = xmap ? 0 : widx / SPLIT, part_id = xmap ? qx % SPLIT : widx % SPLIT;
-        const int b = xmap ? qx / SPLIT : (MH ? pu / NH : pu), hd = xmap ? (widx >> 3) % NH : (MH ? pu % NH : 0);
+        const int pu = xmap ? 0 : widx / SPLIT, part_id = xmap ? qx % SPLIT : fmap ? (widx >> 3) % SPLIT : widx % SPLIT;
+        const int b = xmap ? qx / SPLIT : fmap ? (widx / (8 * SPLIT)) * 8 + (widx & 7) : (MH ? pu / NH : pu), hd = xmap ? (widx >> 3) % NH : (MH ? pu % NH : 0);
         const int col0 = part_id * GC;
         const bool first_wg = widx == 0;
         const int tid = threadIdx.x, lane = tid & 63;
@@ -1045,6 +1047,27 @@ struct AttnPreRole {
         }
         lds_barrier();
         bool l2x = false;
+        if (FSPLIT && fmap) {
+            // the utterance's workgroups publish their XCC ids behind the energy slabs (sentinel-prefilled with them) and compare
+            unsigned xcc;
+            asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID, 0, 4)" : "=s"(xcc));
+            unsigned* ids = reinterpret_cast<unsigned*>(a.ex + (size_t)a.U * a.B * (SPLIT * 64)) + (size_t)b * SPLIT;
+            volatile int* flag = reinterpret_cast<volatile int*>(gxl);
+            if (tid == 0) { *flag = 1; __hip_atomic_store(ids + part_id, 0xC0DE0000u | xcc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+            lds_barrier();
+            if (tid < SPLIT) {
+                unsigned spins = 0, v;
+                for (;;) {
+                    v = __hip_atomic_load(ids + tid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    if (v != PS_SENT) break;
+                    if (spin_expired(spins, a.err, 0xDEAD001Bu)) break;
+                }
+                if (v != (0xC0DE0000u | xcc)) *flag = 0;
+            }
+            lds_barrier();
+            l2x = *flag != 0;
+            lds_barrier();
+        }
         if (MH) {
             // every workgroup publishes its XCC id behind the gx slabs (sentinel-prefilled with them) and reads its partners'
             unsigned xcc;
@@ -1228,7 +1251,18 @@ struct AttnPreRole {
             if (FSPLIT) {
                 // ---- the sixteen slices of the energies meet: publish 256 bytes (two whole lines), collect every part (the own one included)
                 float* ex = a.ex + ((size_t)s * B + b) * (SPLIT * 64);
-                if (tid < 16) st4_agent(at_bytes(ex + part_id * 64, opaque(16u * (unsigned)tid)), *reinterpret_cast<const f32x4*>(esp + tid * 4));
+                if (tid < 16) {
+                    const f32x4 ev = *reinterpret_cast<const f32x4*>(esp + tid * 4);
+                    float* dste = at_bytes(ex + part_id * 64, opaque(16u * (unsigned)tid));
+                    if (l2x) {      // same XCD: plain store into the shared L2
+                        f32x4 cv;
+#pragma unroll
+                        for (int k = 0; k < 4; ++k) cv[k] = __uint_as_float(pub_bits(ev[k]));
+                        *reinterpret_cast<f32x4*>(dste) = cv;
+                    } else {
+                        st4_agent(dste, ev);
+                    }
+                }
                 if (tid < SPLIT * 16) {
                     const float* src = at_bytes(ex, opaque(16u * (unsigned)tid));
                     unsigned spins = 0;
@@ -1682,7 +1716,7 @@ int speller_persist_fwd(const PersistFwd& p, hipStream_t stream) {
                            : ws == 8 ? launch_persist_fwd_pre<512, 8>(a, grid, stream) : launch_persist_fwd_pre<512, 16>(a, grid, stream);
         if (ws == 16) {      // frame-split keys: the slices' energies are exchanged through a sentinel-prefilled slab
             LAS_REQUIRE(p.ex != nullptr, "persistent speller (pre, frame-split keys) exchange slab");
-            LAS_HIP_CHECK(hipMemsetAsync(p.ex, 0xFF, sizeof(float) * (size_t)p.U * p.B * 16 * 64, stream));
+            LAS_HIP_CHECK(hipMemsetAsync(p.ex, 0xFF, sizeof(float) * ((size_t)p.U * p.B * 16 * 64 + (size_t)p.B * 16), stream));      // (+ the XCC ids of the placement check)
             return launch_persist_fwd_pre<256, 16>(a, grid, stream);
         }
         return ws == 4 ? launch_persist_fwd_pre<256, 4>(a, grid, stream) : launch_persist_fwd_pre<256, 8>(a, grid, stream);
