@@ -965,7 +965,8 @@ struct AttnBwdPre2Role {
     static constexpr int NSLOT = PS_THREADS / LPS;         // 32 or 64 slots; the last one holds the forward's gx row
     static constexpr int NC4 = GC / LPS / 4;               // float4 per lane: 16 (64 VGPRs of P)
     static constexpr int TH = NSLOT - 1;                   // frames per workgroup: 31 or 63
-    static constexpr int MAXTP = 512;                      // rows of attention weights / e0 kept in LDS (T' <= 448)
+    static constexpr int MAXTP = HS == 256 ? 1024 : 512;   // rows of attention weights / e0 kept in LDS (T' <= 448; Hs = 256: <= 896, the frame-split forward's range)
+    static constexpr int QBASE = MAXTP < PS_THREADS ? MAXTP : 0;      // first of the PS_M lanes that fetch the step's query
     static constexpr int NJ = HS / 16;                     // producer tiles of a gate-gradient row (256 B each)
     static constexpr int MAXUN = HS / 4;                   // units per workgroup at ns = 4 (fewer with more slices)
     static constexpr int WLD = PS_M + 4;                   // LDS row stride of a unit's W_phi column (16-byte aligned, bank spread)
@@ -1059,7 +1060,7 @@ struct AttnBwdPre2Role {
                 attr[tid] = tid < Tp ? av : 0.f;
                 e0r[tid] = tid < Tp ? ev : 0.f;
             }
-            if (tid >= MAXTP && tid < MAXTP + PS_M) qs[tid - MAXTP] = *at_bytes(a.q_all + sbq * PS_M, opaque(4u * (unsigned)(tid - MAXTP)));
+            if (tid >= QBASE && tid < QBASE + PS_M) qs[tid - QBASE] = *at_bytes(a.q_all + sbq * PS_M, opaque(4u * (unsigned)(tid - QBASE)));
             if (slot == NSLOT - 1) {
                 const float* gp = at_bytes(a.gxf + sbq * GC, opaque(16u * (unsigned)l32));
 #pragma unroll
@@ -1138,8 +1139,13 @@ struct AttnBwdPre2Role {
             // ---- softmax backward de_t = a_t (e0_t + dG0 . P_t - ctx . dctx) for its frames (one wave)
             if (wave == 0) {
                 float cp = 0.f;
+                if (HS == 256) {      // (a 1024-row table: walk the rows that exist)
+                    const int kmax = (Tp + 63) >> 6;
+                    for (int k = 0; k < kmax; ++k) cp = fmaf(attr[lane + 64 * k], e0r[lane + 64 * k], cp);
+                } else {
 #pragma unroll
-                for (int k = 0; k < MAXTP / 64; ++k) cp = fmaf(attr[lane + 64 * k], e0r[lane + 64 * k], cp);
+                    for (int k = 0; k < MAXTP / 64; ++k) cp = fmaf(attr[lane + 64 * k], e0r[lane + 64 * k], cp);
+                }
                 const float c0 = wsum(cp);
                 const float sd = c0 + slotv[NSLOT - 1];
                 {
@@ -1338,13 +1344,13 @@ size_t speller_persist_bwd_workspace_floats(int B, int Tp, int U, int Hs, int M)
     const size_t classic = (size_t)ns * U * B * M + (size_t)U * B * ns * Hs + (size_t)2 * U * (Hs / 16) * 32 * 64 + (size_t)2 * (U + 1) * (Hs / 16) * 32 * 16;
     const size_t nsp = (size_t)persist_bwd_pre_ns(B, Tp, Hs, -1);
     // PRE variant: [e0 | sentinel-prefilled slabs: dq exchange (ns parts) | tiled dG (2 layers) | recurrent carry of the top layer]
-    const size_t pre = (nsp && Tp <= 448) ? (size_t)U * B * Tp + 4 + nsp * U * B * M + (size_t)2 * U * (Hs / 16) * 32 * 64 + (size_t)(U + 1) * (Hs / 16) * 32 * 16 +
+    const size_t pre = (nsp && Tp <= (Hs == 256 ? 896 : 448)) ? (size_t)U * B * Tp + 4 + nsp * U * B * M + (size_t)2 * U * (Hs / 16) * 32 * 64 + (size_t)(U + 1) * (Hs / 16) * 32 * 16 +
                                             (size_t)(U + 1) * 2 * (Hs / 16) * 256 : 0;
     return std::max(classic, pre);
 }
 bool speller_persist_bwd_pre_eligible(int B, int Tp, int Hs, int D, int M, int V, int L, int heads, int use_mlp) {
     const bool on = opt_get(OPT_SPELLER_PRE_BWD) != 0;
-    if (!on || !persist_bwd_shape(B, Hs, D, M, L, heads, use_mlp) || Tp > 448) return false;
+    if (!on || !persist_bwd_shape(B, Hs, D, M, L, heads, use_mlp) || Tp > (Hs == 256 ? 896 : 448)) return false;      // (Hs = 256: the frame-split forward's range)
     if (!speller_persist_pre_eligible(B, Tp, Hs, D, M, V, L, heads, use_mlp)) return false;      // the forward must have produced P and gx
     int cus = 0, dev = 0;
     if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess)

@@ -55,11 +55,11 @@ def expected_paths(info):
 #       free-running kernel holds feat[b] itself (750 KB) in 4 and stops at T' <= 256 -> per-step kernels
 #   S (T' = 750, Hs 256): keys 192 KB > 160 KB of LDS: the teacher-forced forward splits them by frames over the 16 workgroups of an utterance,
 #       which exchange their energies every step (persist_pre, round 5; per-step kernels until then); free-running decode per-step; the
-#       backward's attention role tiles T' over 16 workgroups per utterance (classic persistent kernel, no PRE variant beyond T' = 448)
+#       backward is the PRE kernel too (its attention role tiles T' over 16 workgroups per utterance; table extended to T' = 896 at Hs 256)
 PATH_OVERRIDES = {
     "P_B8_T3000_U16": dict(greedy="stepwise"),
     "P_B8_T3000_U16_s": dict(greedy="stepwise"),
-    "S_B8_T3000_U8": dict(tf="persist_pre", greedy="stepwise", bwd="persist"),
+    "S_B8_T3000_U8": dict(tf="persist_pre", greedy="stepwise"),
 }
 
 

@@ -482,7 +482,7 @@ def test_persistent_decode_kernel_matches_stepwise(cfg_name, B, Tp, U, scale):
 def test_long_utterance_small_model_decode_takes_the_frame_split_kernel(B, Tp):
     """BASELINE configs[4] for the small model (Hs = 256, T' = 750): 192 KB of keys do not fit one workgroup's LDS — the teacher-forced forward
     keeps them split by frames over the 16 attention workgroups of an utterance, which exchange their energies every step
-    (``AttnPreRole<256, 16>``); asserts that path (the per-step kernels took these shapes until round 5) and the classic one-launch backward."""
+    (``AttnPreRole<256, 16>``); asserts that path (the per-step kernels took these shapes until round 5) and the PRE backward, whose frame table now reaches T' = 896 at Hs = 256."""
     from las_pytorch_amd import Speller, synth
     c = synth.CONFIGS["S"]
     U = 4
@@ -495,7 +495,7 @@ def test_long_utterance_small_model_decode_takes_the_frame_split_kernel(B, Tp):
     preds, _ = sp(feat, ground_truth=lab, teacher_force_rate=1.0)
     torch.stack(preds).sum().backward()
     torch.cuda.synchronize()
-    assert (_cabi.last_path(_cabi.PATH_DECODE_FWD), _cabi.last_path(_cabi.PATH_DECODE_BWD)) == ("persist_pre", "persist")
+    assert (_cabi.last_path(_cabi.PATH_DECODE_FWD), _cabi.last_path(_cabi.PATH_DECODE_BWD)) == ("persist_pre", "persist_pre")
     _check_err()
 
 
