@@ -424,8 +424,30 @@ def secondary_long(device, U, B=8, T=3000, steps=10, warmup=3, with_roofline=Tru
         r = roofline_rec_fwd(c, B, T, iters=5, with_traffic=True)
         out["roofline"] = r
         out.update(roofline_speller(step, c, B, T, U, iters=5))
-    del las, reducer, opt
+    del las, reducer, opt, step
     torch.cuda.empty_cache()
+    try:      # the small model at the same T (T' = 750: 192 KB of keys per utterance exceed one workgroup's LDS; split by frames over 16 workgroups)
+        las_s, c_s, _ = build_model("S", U, device)
+        xs = torch.from_numpy(synth.make_inputs(B, T, c_s["F"], seed=17)).to(device)
+        red_s = dp.FlatGradAllReducer(las_s, direct=True)
+        opt_s = FusedClipAdam(red_s, lr=2e-4)
+        step_s = make_train_step(las_s, xs, lab, red_s, opt_s)
+        for _ in range(warmup):
+            step_s()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            step_s()
+        torch.cuda.synchronize()
+        dts = (time.perf_counter() - t0) / steps
+        from las_pytorch_amd import _cabi
+        las_pytorch_amd.check_device_errors()
+        out["small_model"] = {"workload": f"S_long: Listener 128x2 / Speller 256x2, (B={B},T={T}), the same training step", "value": round(B / dts, 1), "unit": "utt/s",
+                              "ms_per_step": round(dts * 1e3, 3), "decode_paths": [_cabi.last_path(_cabi.PATH_DECODE_FWD), _cabi.last_path(_cabi.PATH_DECODE_BWD)]}
+        del las_s, red_s, opt_s, step_s
+        torch.cuda.empty_cache()
+    except Exception as e:      # (an optional side figure must never cost the driver line)
+        out["small_model"] = {"error": f"{type(e).__name__}: {e}"[:200]}
     return out
 
 
