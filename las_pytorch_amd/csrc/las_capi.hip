@@ -81,7 +81,7 @@ struct SpellerLayout {
         wyT = o; if (anypre) o += r4((size_t)Vp * 4 * d->Hs);
         plx = o; if (anypre) o += r4((size_t)U * (d->Hs / 4) * 512);
         // Hs = 256 with 16 attention workgroups per utterance (long T'): the frame slices' energies, exchanged every step
-        exs = o; if (pre && d->Hs == 256 && speller_persist_pre_ws(d->B, d->Tp, d->Hs, -1) == 16) o += r4((size_t)U * B * 16 * 64 + B * 16);
+        exs = o; if (pre && speller_persist_pre_ws(d->B, d->Tp, d->Hs, -1) == 16) o += r4((size_t)U * B * 16 * 64 + B * 16);      // (Hs = 512: the free-running form only)
         // multi-head, free-running: W_c[:, Hs:] W_dr (V rows of NH*D, stored 32 rows) and b_c + W_c[:, Hs:] b_dr
         wcd = o; if (pre_mh) o += r4((size_t)32 * NHp * d->D);
         bcp = o; if (pre_mh) o += r4(32);

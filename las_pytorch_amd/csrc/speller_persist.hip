@@ -963,8 +963,9 @@ struct AttnPreRole {
     // Hs = 256 with 16 workgroups per utterance (T' up to 896, B <= 12: BASELINE configs[4] for the small model, T' = 750): a column group spans a
     // whole wave, and the KEYS no longer fit one workgroup's LDS (192 KB at T' = 750) — each workgroup keeps the keys of ITS ceil(T'/16) frames,
     // computes their energies and the sixteen exchange them (64 floats each, one more hand-off per step) before the softmax
-    static constexpr bool FSPLIT = TS == 64;
-    static_assert(!FSPLIT || (!GREEDY && !MH), "the frame-split form is teacher-forced, single-head");
+    // ... and the free-running form with 16 workgroups per utterance (either Hs): Q^T (up to 115 KB) takes the LDS the whole keys would need
+    static constexpr bool FSPLIT = TS == 64 || (GREEDY && WS == 16);
+    static_assert(!FSPLIT || !MH, "the frame-split form is single-head");
     // float4 of a W_phi row slice kept in registers; the rest lives in LDS.  With 16 workgroups per utterance (T' up to 448: the keys
     // alone take up to 122 KB of LDS) all of it stays in registers and R0 is fetched with a blocking load instead
     static constexpr int NJR = WS == 16 ? NJ : NJ / 2;
@@ -1541,10 +1542,9 @@ static bool persist_fwd_pre_mh_fits_rt(int Hs, int ws, int Tp, int grid) {
     return ws == 4 ? persist_fwd_pre_fits<256, 4, false, true>(Tp, grid) : persist_fwd_pre_fits<256, 8, false, true>(Tp, grid);
 }
 static bool persist_fwd_pre_fits_rt(int Hs, int ws, int Tp, int grid, bool greedy = false) {
-    if (greedy) {      // free-running instantiations: 4 or 8 attention workgroups per utterance (T' <= 224; beyond that Q^T does not fit the LDS)
-        if (ws == 16) return false;
-        if (Hs == 512) return ws == 4 ? persist_fwd_pre_fits<512, 4, true>(Tp, grid) : persist_fwd_pre_fits<512, 8, true>(Tp, grid);
-        return ws == 4 ? persist_fwd_pre_fits<256, 4, true>(Tp, grid) : persist_fwd_pre_fits<256, 8, true>(Tp, grid);
+    if (greedy) {      // free-running instantiations: 4 or 8 attention workgroups per utterance with the whole keys in LDS beside Q^T; 16 with the keys split by frames
+        if (Hs == 512) return ws == 4 ? persist_fwd_pre_fits<512, 4, true>(Tp, grid) : ws == 8 ? persist_fwd_pre_fits<512, 8, true>(Tp, grid) : persist_fwd_pre_fits<512, 16, true>(Tp, grid);
+        return ws == 4 ? persist_fwd_pre_fits<256, 4, true>(Tp, grid) : ws == 8 ? persist_fwd_pre_fits<256, 8, true>(Tp, grid) : persist_fwd_pre_fits<256, 16, true>(Tp, grid);
     }
     if (Hs == 512) return ws == 4 ? persist_fwd_pre_fits<512, 4>(Tp, grid) : ws == 8 ? persist_fwd_pre_fits<512, 8>(Tp, grid) : persist_fwd_pre_fits<512, 16>(Tp, grid);
     return ws == 4 ? persist_fwd_pre_fits<256, 4>(Tp, grid) : ws == 8 ? persist_fwd_pre_fits<256, 8>(Tp, grid) : persist_fwd_pre_fits<256, 16>(Tp, grid);
@@ -1706,10 +1706,15 @@ int speller_persist_fwd(const PersistFwd& p, hipStream_t stream) {
         if (!p.prefilled) LAS_TRY(speller_persist_fwd_fill(p, stream));
         const int grid = p.Hs / 4 + ws * p.B;
         if (p.mode == 1) {      // free-running: the character distribution inside the attention workgroups
-            LAS_REQUIRE(p.qct && p.wyT && p.plx && p.logp && p.w_c && p.b_c && ws != 16, "persistent speller (pre, free-running) buffers");
+            LAS_REQUIRE(p.qct && p.wyT && p.plx && p.logp && p.w_c && p.b_c && (ws != 16 || p.ex), "persistent speller (pre, free-running) buffers");
             LAS_HIP_CHECK(hipMemsetAsync(p.plx, 0xFF, sizeof(float) * (size_t)p.U * (p.Hs / 4) * 512, stream));
-            if (p.Hs == 512) return ws == 4 ? launch_persist_fwd_pre<512, 4, true>(a, grid, stream) : launch_persist_fwd_pre<512, 8, true>(a, grid, stream);
-            return ws == 4 ? launch_persist_fwd_pre<256, 4, true>(a, grid, stream) : launch_persist_fwd_pre<256, 8, true>(a, grid, stream);
+            if (ws == 16)      // keys split by frames: the slices' energies meet through this slab (+ the XCC ids of the placement check)
+                LAS_HIP_CHECK(hipMemsetAsync(p.ex, 0xFF, sizeof(float) * ((size_t)p.U * p.B * 16 * 64 + (size_t)p.B * 16), stream));
+            if (p.Hs == 512)
+                return ws == 4 ? launch_persist_fwd_pre<512, 4, true>(a, grid, stream)
+                               : ws == 8 ? launch_persist_fwd_pre<512, 8, true>(a, grid, stream) : launch_persist_fwd_pre<512, 16, true>(a, grid, stream);
+            return ws == 4 ? launch_persist_fwd_pre<256, 4, true>(a, grid, stream)
+                           : ws == 8 ? launch_persist_fwd_pre<256, 8, true>(a, grid, stream) : launch_persist_fwd_pre<256, 16, true>(a, grid, stream);
         }
         if (p.Hs == 512)
             return ws == 4 ? launch_persist_fwd_pre<512, 4>(a, grid, stream)

@@ -51,16 +51,12 @@ def expected_paths(info):
 
 # fixtures whose path differs from the rule above: BASELINE configs[4] (T = 3000), where an utterance's attention operands no longer fit one
 # workgroup's registers + LDS ("LDS residency vs spill"):
-#   P (T' = 375, Hs 512): teacher forcing keeps P[b] = feat[b] W_ctx^T in 8 workgroups per utterance (persist_pre, both ways); the
-#       free-running kernel holds feat[b] itself (750 KB) in 4 and stops at T' <= 256 -> per-step kernels
+#   P (T' = 375, Hs 512): teacher forcing keeps P[b] = feat[b] W_ctx^T in 16 workgroups per utterance (persist_pre, both ways); the
+#       free-running form of that kernel needs Q^T (57 KB) beside the keys (102 KB): the keys are split by frames over the 16 workgroups
 #   S (T' = 750, Hs 256): keys 192 KB > 160 KB of LDS: the teacher-forced forward splits them by frames over the 16 workgroups of an utterance,
-#       which exchange their energies every step (persist_pre, round 5; per-step kernels until then); free-running decode per-step; the
+#       which exchange their energies every step (persist_pre, round 5; per-step kernels until then); free-running decode likewise; the
 #       backward is the PRE kernel too (its attention role tiles T' over 16 workgroups per utterance; table extended to T' = 896 at Hs 256)
-PATH_OVERRIDES = {
-    "P_B8_T3000_U16": dict(greedy="stepwise"),
-    "P_B8_T3000_U16_s": dict(greedy="stepwise"),
-    "S_B8_T3000_U8": dict(tf="persist_pre", greedy="stepwise"),
-}
+PATH_OVERRIDES = {}      # (round 5, late: the T = 3000 fixtures run the PRE kernels in every phase — see the comment above)
 
 
 def load_case(name):

@@ -801,7 +801,9 @@ def test_multi_head_free_running_decode_without_backward(cfg_name, heads, B, Tp,
 
 
 @pytest.mark.parametrize("cfg_name,B,Tp,U", [("P", 32, 100, 24), ("P", 7, 57, 9), ("P", 16, 200, 6), ("S", 32, 200, 12), ("S", 20, 100, 5),
-                                             ("P", 40, 100, 5), ("P", 32, 112, 3)])
+                                             ("P", 40, 100, 5), ("P", 32, 112, 3),
+                                             # 16 workgroups per utterance, keys split by frames (BASELINE configs[4]: T' = 375 / 750), and the table's ends
+                                             ("P", 8, 375, 6), ("S", 8, 750, 5), ("P", 3, 448, 3), ("S", 12, 896, 3), ("P", 5, 225, 4)])
 def test_free_running_decode_without_backward_runs_the_pre_kernel(cfg_name, B, Tp, U):
     """Validation-style greedy decode (decode_mode 1 under torch.no_grad(): reference train.py:149-169, las_model.py:223-227) takes the
     free-running form of the pre-multiplied-context kernel — character distribution inside the attention workgroups, 4 and 8 of them per
@@ -838,9 +840,10 @@ def test_free_running_decode_without_backward_runs_the_pre_kernel(cfg_name, B, T
 
 
 def test_free_running_training_step_at_long_t_mixes_per_step_forward_and_pre_backward():
-    """T' = 375 (BASELINE configs[4]) with decode_mode 1 and a backward pass: the free-running forward has no one-launch kernel at this length
-    (per-step launches), yet it must leave P / gx in the reserve exactly as a teacher-forced forward does, because the backward takes the
-    teacher-forced PRE kernel over the emitted symbols.  Against the all-generic path."""
+    """T' = 375 (BASELINE configs[4]) with decode_mode 1 and a backward pass: the free-running forward (since round 5, late: the one-launch kernel
+    with the keys split by frames over 16 workgroups per utterance; per-step launches until then — the test's name is from that time) must leave
+    P / gx in the reserve exactly as a teacher-forced forward does, because the backward takes the teacher-forced PRE kernel over the emitted
+    symbols.  Against the all-generic path."""
     from las_pytorch_amd import Speller, _cabi, synth
     c = synth.CONFIGS["P"]
     B, Tp, U = 8, 375, 4
@@ -860,7 +863,7 @@ def test_free_running_training_step_at_long_t_mixes_per_step_forward_and_pre_bac
             (logp * w).sum().backward()
             torch.cuda.synchronize()
             if not force:
-                assert (_cabi.last_path(_cabi.PATH_DECODE_FWD), _cabi.last_path(_cabi.PATH_DECODE_BWD)) == ("stepwise", "persist_pre")
+                assert (_cabi.last_path(_cabi.PATH_DECODE_FWD), _cabi.last_path(_cabi.PATH_DECODE_BWD)) == ("persist_pre_greedy", "persist_pre")
             out = dict(logp=logp.detach().cpu().numpy(), dfeat=feat.grad.cpu().numpy())
             out.update({"d" + n: p.grad.cpu().numpy() for n, p in sp.named_parameters() if p.grad is not None})
             res.append(out)
