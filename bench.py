@@ -418,8 +418,8 @@ def secondary_long(device, U, B=8, T=3000, steps=10, warmup=3, with_roofline=Tru
                        "training step (fwd + loss + bwd + clip + Adam)",
            "value": round(B / dt, 1), "unit": "utt/s", "ms_per_step": round(dt * 1e3, 3), "steps": steps,
            "serial_recurrence_steps_each_way": sum(T >> (l + 1) for l in range(c["L"])), "recurrence_cus": 2 * B * (c["H"] * c["H"] // 16384),
-           "residency": "P keys 96 KB + P[b] slice in registers: 8 attention workgroups per utterance (persist_pre both ways); greedy decode at this T' "
-                        "falls to the per-step kernels (feat[b] = 750 KB does not fit 4 workgroups' registers)"}
+           "residency": "P keys 96 KB in LDS + P[b] column slices in registers: 16 attention workgroups per utterance (persist_pre both ways); greedy decode at this T' "
+                        "keeps Q^T (57 KB) in LDS and splits the keys by frames over those 16 workgroups (persist_pre_greedy)"}
     if with_roofline:
         r = roofline_rec_fwd(c, B, T, iters=5, with_traffic=True)
         out["roofline"] = r
