@@ -403,7 +403,15 @@ def secondary_long(device, U, B=8, T=3000, steps=10, warmup=3, with_roofline=Tru
     reducer = dp.FlatGradAllReducer(las, direct=True)
     opt = FusedClipAdam(reducer, lr=2e-4)
     step = make_train_step(las, x, lab, reducer, opt)
-    for _ in range(warmup):
+    # parity hook, as for the headline: the loss at the initial weights equals what the UNMODIFIED reference computes on the same inputs
+    # (tests/golden/P_B8_T3000_U128.npz: same seeds, same shapes, U = 128)
+    first_loss = float(step().item())
+    ref_loss = None
+    gpath = os.path.join(ROOT, "tests", "golden", f"P_B{B}_T{T}_U{U}.npz")
+    if os.path.exists(gpath):
+        ref_loss = float(np.load(gpath)["loss_ls"][0])
+        assert abs(first_loss - ref_loss) <= 1e-4 * abs(ref_loss), f"P_long first-step loss {first_loss} != reference {ref_loss}"
+    for _ in range(max(0, warmup - 1)):
         step()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
@@ -417,6 +425,7 @@ def secondary_long(device, U, B=8, T=3000, steps=10, warmup=3, with_roofline=Tru
     out = {"workload": f"P_long (BASELINE configs[4]): Listener 256x3 / Speller 512x2, (B={B},T={T},F=80), teacher-forced U={U}, the same full "
                        "training step (fwd + loss + bwd + clip + Adam)",
            "value": round(B / dt, 1), "unit": "utt/s", "ms_per_step": round(dt * 1e3, 3), "steps": steps,
+           "first_step_loss": first_loss, "first_step_loss_reference": ref_loss,
            "serial_recurrence_steps_each_way": sum(T >> (l + 1) for l in range(c["L"])), "recurrence_cus": 2 * B * (c["H"] * c["H"] // 16384),
            "residency": "P keys 96 KB in LDS + P[b] column slices in registers: 16 attention workgroups per utterance (persist_pre both ways); greedy decode at this T' "
                         "keeps Q^T (57 KB) in LDS and splits the keys by frames over those 16 workgroups (persist_pre_greedy)"}
@@ -534,8 +543,8 @@ def cpu_baseline(cfg_name, B, T, U, train):
     host_threads = torch.get_num_threads()
     threads = CB.best_threads(c, sd_np, x, onehot, train=train)
     r = CB.time_cpu(c, sd_np, x, onehot, train=train, iters=3, warmup=1, threads=threads)
-    # single thread (SURVEY.md section 8d asks for it: the decode loop is dispatch-bound), on a quarter of the batch to stay bounded
-    Bs = max(1, B // 4)
+    # single thread (SURVEY.md section 8d asks for it: the decode loop is dispatch-bound), on the full batch (~8 s per step at paper size)
+    Bs = B
     r1 = CB.time_cpu(c, sd_np, x[:Bs], onehot[:Bs], train=train, iters=1, warmup=1, threads=1)
     torch.set_num_threads(host_threads)
     return dict(value=round(r["utt_per_s"], 3), unit="utt/s", cores=r["threads"], kind="port",
@@ -544,7 +553,7 @@ def cpu_baseline(cfg_name, B, T, U, train):
                        f"loop slows down beyond that), torch {torch.__version__} oneDNN LSTM path, {r['ms_per_step']:.0f} ms/step",
                 ms_per_step=round(r["ms_per_step"], 1), cpu_model=cpu_model_name(), host_threads=host_threads,
                 single_thread={"value": round(r1["utt_per_s"], 3), "unit": "utt/s", "cores": 1, "ms_per_step": round(r1["ms_per_step"], 1),
-                               "sample": f"1 step after 1 warm-up of the same workload at B={Bs} (a quarter of the batch), one torch thread"})
+                               "sample": f"1 step after 1 warm-up of the same workload (B={Bs}, the full batch), one torch thread"})
 
 
 def launch_ranks(n):

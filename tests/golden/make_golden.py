@@ -205,6 +205,7 @@ def main_big(refmods):
     run_case(refmods, "S_B32_T800_U32", "S", B=32, T=800, U=32, ragged=True, **big)  # T'=200
     run_case(refmods, "S_B8_T3000_U8", "S", B=8, T=3000, U=8, **big)                 # T'=750
     main_big3(refmods)
+    main_r6(refmods)
 
 
 def main_big3(refmods):
@@ -245,6 +246,20 @@ def main_big4(refmods):
         run_case(refmods, "P_B32_T800_U16_mh2", "P", B=32, T=800, U=16, multi_head=2, scale=0.1, seed=23, **big)
 
 
+
+
+def main_r6(refmods):
+    """Round 6: (a) BASELINE configs[4] at the benchmark's own decode length (P, B = 8, T = 3000, U = 128: the hand-off rings of the
+    16-workgroups-per-utterance decode kernels wrap 128 times; bench.py's secondary_long block asserts its first-step loss against
+    this fixture's); (b) multi-head attention at real sizes: heads = 4 at (16, 800) and heads = 2 at T = 3000."""
+    big = dict(full=False, light=True, sub_t=10, sub_d=32)
+    which = os.environ.get("R6", "abc")
+    if "a" in which:
+        run_case(refmods, "P_B8_T3000_U128", "P", B=8, T=3000, U=128, sub_u=4, **big)
+    if "b" in which:
+        run_case(refmods, "P_B16_T800_U16_mh4", "P", B=16, T=800, U=16, multi_head=4, scale=0.1, seed=23, **big)
+    if "c" in which:
+        run_case(refmods, "P_B8_T3000_U8_mh2", "P", B=8, T=3000, U=8, multi_head=2, scale=0.1, seed=23, **big)
 
 
 def make_mode2_golden(refmods):
@@ -310,13 +325,16 @@ def make_free_training_golden(refmods, which="tsp"):
     if "t" in which: cases.append(("tiny_free_train", "tiny", 3, 32, 6, 0.3, 17))
     if "s" in which: cases.append(("S_free_train", "S", 4, 64, 8, 0.2, 43))
     if "p" in which: cases.append(("P_B32_T800_U16_free_train", "P", 32, 800, 16, 0.2, 43))      # weights / inputs of P_B32_T800_U32_s
-    for name, cfg_name, B, T, U, scale, seed in cases:
+    # round 6: the multi-head free-running training step at paper size (heads = 2: one slice of 16 utterances per launch)
+    if "m" in which: cases.append(("P_B16_T800_U12_mh2_free_train", "P", 16, 800, 12, 0.1, 23, 2))
+    for name, cfg_name, B, T, U, scale, seed, *rest in cases:
+        heads = rest[0] if rest else 1
         c = synth.CONFIGS[cfg_name]
-        sd_np = synth.make_state_dict(synth.config_shapes(cfg_name), seed=seed, scale=scale)
+        sd_np = synth.make_state_dict(synth.config_shapes(cfg_name, multi_head=heads), seed=seed, scale=scale)
         x = torch.from_numpy(synth.make_inputs(B, T, c["F"], seed=seed))
         idx, lens = synth.make_labels(B, U, c["V"], seed=seed, ragged=(cfg_name != "P"))
         labels = torch.from_numpy(synth.onehot_labels(idx, lens, c["V"]))
-        las = build_ref(LAS, Listener, Speller, c, sd_np, max_label_len=U, decode_mode=1)
+        las = build_ref(LAS, Listener, Speller, c, sd_np, max_label_len=U, decode_mode=1, multi_head=heads)
         las.zero_grad()
         preds, _ = las(batch_data=x, batch_label=labels, teacher_force_rate=0.0, is_training=True)
         assert len(preds) == U
@@ -326,7 +344,7 @@ def make_free_training_golden(refmods, which="tsp"):
         logp = stack(preds)
         top2 = np.sort(logp, axis=-1)[..., -2:]
         gn = {k: p.grad.detach().numpy() for k, p in las.named_parameters()}
-        out = dict(meta=np.array([B, T, U, seed], dtype=np.int64), scale=np.array([scale]), cfg=np.array(cfg_name),
+        out = dict(meta=np.array([B, T, U, seed], dtype=np.int64), scale=np.array([scale]), cfg=np.array(cfg_name), heads=np.array([heads]),
                    ragged=np.array([int(cfg_name != "P")]), free_logp=logp, free_argmax=logp.argmax(-1),
                    free_margin=np.array([float((top2[..., 1] - top2[..., 0]).min())]), loss_ls=np.array([loss.item()]),
                    gradnorm_ls=np.array([np.linalg.norm(g.astype(np.float64)) for g in gn.values()]),
@@ -426,6 +444,11 @@ if __name__ == "__main__" and len(sys.argv) > 1 and sys.argv[1] == "free":
     torch.manual_seed(0)
     torch.set_num_threads(8)
     make_free_training_golden(import_reference(), sys.argv[2] if len(sys.argv) > 2 else "tsp")
+
+if __name__ == "__main__" and len(sys.argv) > 1 and sys.argv[1] == "r6":
+    torch.manual_seed(0)
+    torch.set_num_threads(8)
+    main_r6(import_reference())
 
 if __name__ == "__main__" and len(sys.argv) > 1 and sys.argv[1] == "big":
     torch.manual_seed(0)

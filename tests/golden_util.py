@@ -17,7 +17,11 @@ BIG_CASES = ["Y_short", "P_B40_T64_U6", "P_B32_T800_U32", "P_B16_T1600_U8", "P_B
              # default-scale and U(-0.2, 0.2) weights), the reference's shipped YAML sizes at T = 800, multi-head attention at paper size
              "P_B128_T800_U16", "P_B128_T800_U16_s", "Y_B16_T800_U16", "P_short_mh4", "P_B32_T800_U16_mh2",
              # ... and a 24-second batch of the YAML sizes (T = 2400, T' = 300): the long-utterance instantiation of its one-launch decode kernels
-             "Y_B4_T2400_U8"]
+             "Y_B4_T2400_U8",
+             # round 6: BASELINE configs[4] at the benchmark's own decode length (U = 128: the hand-off rings of the 16-workgroups-per-utterance
+             # decode kernels wrap 128 times; bench.py's secondary_long block asserts its first-step loss against this fixture's), and
+             # multi-head attention at real sizes: heads = 4 at (16, 800) — two slices of 8 utterances — and heads = 2 at T = 3000
+             "P_B8_T3000_U128", "P_B16_T800_U16_mh4", "P_B8_T3000_U8_mh2"]
 
 
 # Kernel family each fixture pins, per phase of the golden tests (las_debug_last_path names, include/las_hip.h): Listener recurrence forward /
@@ -132,7 +136,9 @@ def tf_argmax_mask(tf_logp, min_gap=5e-5):
     return (top2[..., 1] - top2[..., 0]) > min_gap
 
 
-FREE_TRAIN_CASES = ["tiny_free_train", "S_free_train", "P_B32_T800_U16_free_train"]
+FREE_TRAIN_CASES = ["tiny_free_train", "S_free_train", "P_B32_T800_U16_free_train",
+                    # round 6: the multi-head (heads = 2) free-running training step at paper size
+                    "P_B16_T800_U12_mh2_free_train"]
 
 
 def load_free_train_case(name):
@@ -143,8 +149,9 @@ def load_free_train_case(name):
     cfg_name = str(g["cfg"])
     c = synth.CONFIGS[cfg_name]
     B, T, U, seed = (int(v) for v in g["meta"])
-    sd_np = synth.make_state_dict(synth.config_shapes(cfg_name), seed=seed, scale=float(g["scale"][0]))
+    heads = int(g["heads"][0]) if "heads" in g else 1
+    sd_np = synth.make_state_dict(synth.config_shapes(cfg_name, multi_head=heads), seed=seed, scale=float(g["scale"][0]))
     x = synth.make_inputs(B, T, c["F"], seed=seed)
     idx, lens = synth.make_labels(B, U, c["V"], seed=seed, ragged=bool(int(g["ragged"][0])))
     onehot = synth.onehot_labels(idx, lens, c["V"])
-    return g, c, cfg_name, (B, T, U), sd_np, x, onehot
+    return g, c, cfg_name, (B, T, U), sd_np, x, onehot, heads

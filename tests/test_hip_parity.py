@@ -136,9 +136,12 @@ def test_grads_golden(name):
                                                   ("Y", 3, 64, 5, 0.08),
                                                   ("S", 32, 800, 16, None), ("P", 32, 800, 16, None),
                                                   ("P", 32, 800, 128, None),
-                                                  ("P", 72, 800, 8, None)])
+                                                  ("P", 72, 800, 8, None),
+                                                  ("P", 8, 3000, 128, None), ("S", 8, 3000, 128, None)])
 def test_forward_backward_vs_oracle(cfg_name, B, T, U, scale):
-    """Fresh seeded inputs, sizes the goldens do not cover (odd batch, full LibriSpeech shape); ("P", 72, 800, 8) runs the matrix-pipe
+    """Fresh seeded inputs, sizes the goldens do not cover (odd batch, full LibriSpeech shape); the last two rows are BASELINE configs[4]
+    at the benchmark's own decode length (B = 8, T = 3000, U = 128: the 16-workgroups-per-utterance decode kernels, whose per-step
+    hand-off slabs are walked 128 times, forward and backward; paths asserted); ("P", 72, 800, 8) runs the matrix-pipe
     recurrences (B >= 64) with a partial last group of 8 utterances for 400 / 200 / 100 steps and the decode in slices of 32 + 32 + 8;
     the row before it is the benchmark's
     EXACT shape (P, B=32, T=800, U=128): log-probs, loss and every gradient of all 128 steps of the one-launch decode kernels
@@ -181,6 +184,10 @@ def test_forward_backward_vs_oracle(cfg_name, B, T, U, scale):
             want = sd[k].grad.numpy()
             grad_close(p.grad.cpu().numpy(), want, f"oracle_{cfg_name}_B{B}_T{T}/grad/{k}", rtol=GRAD_RTOL, floor=GRAD_FLOOR,
                        global_scale=gscale)
+        if T == 3000:      # configs[4]: both decode kernels in their one-launch (frame-split) form, not the per-step chains
+            torch.cuda.synchronize()
+            assert _cabi.last_path(_cabi.PATH_DECODE_FWD) == "persist_pre", _cabi.last_path(_cabi.PATH_DECODE_FWD)
+            assert _cabi.last_path(_cabi.PATH_DECODE_BWD) == "persist_pre", _cabi.last_path(_cabi.PATH_DECODE_BWD)
     _check_err()
 
 
@@ -226,8 +233,8 @@ def test_free_running_training_step_golden(name):
     """A free-running training step against the UNMODIFIED reference's (fixtures of make_golden.py::make_free_training_golden): log-probs,
     arg-max sequences, the label-smoothing loss, all per-parameter gradient norms and 64-element slices.  The paper-size fixture (B = 32,
     T = 800, weights of the "_s" cases: 19 distinct symbols, margin 1.3e-3) must run the free-running PRE forward and the PRE backward."""
-    g, c, cfg_name, (B, T, U), sd_np, x, onehot = load_free_train_case(name)
-    las = build_las(c, sd_np, max_label_len=U)
+    g, c, cfg_name, (B, T, U), sd_np, x, onehot, heads = load_free_train_case(name)
+    las = build_las(c, sd_np, max_label_len=U, multi_head=heads)
     xg, labg = torch.from_numpy(x).cuda(), torch.from_numpy(onehot).cuda()
     preds, _ = las(batch_data=xg, batch_label=labg, teacher_force_rate=0.0, is_training=True)
     assert len(preds) == U

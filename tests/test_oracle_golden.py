@@ -77,15 +77,15 @@ def test_loss_and_grads_match_reference(name):
                 np.testing.assert_allclose(got, want, rtol=1e-3, atol=2e-7)
 
 
-@pytest.mark.parametrize("name", FREE_TRAIN_CASES[:2])
+@pytest.mark.parametrize("name", FREE_TRAIN_CASES[:2] + FREE_TRAIN_CASES[3:])
 def test_free_running_training_step_matches_reference(name):
     """The oracle's free-running training step (decode_mode-1 feedback for max_label_len steps with autograd on, then the label-smoothing
     loss and backward; reference las_model.py:189,205-227 + solver.py:33-45,95) against the unmodified reference's: log-probs, arg-max
     sequence, loss, all gradient norms and slices.  (The paper-size fixture is checked on the GPU only: 40 s of CPU per run.)"""
-    g, c, cfg_name, (B, T, U), sd_np, x, onehot = load_free_train_case(name)
+    g, c, cfg_name, (B, T, U), sd_np, x, onehot, heads = load_free_train_case(name)
     sd = O.to_torch_sd(sd_np, requires_grad=True)
     lab = torch.from_numpy(onehot)
-    cfg = dict(listener_layers=c["L"], speller_layers=c["Ls"], max_label_len=U, decode_mode=1)
+    cfg = dict(listener_layers=c["L"], speller_layers=c["Ls"], max_label_len=U, decode_mode=1, multi_head=heads)
     preds, _ = O.las_forward(torch.from_numpy(x), lab, sd, cfg, teacher_force=False)
     logp = torch.stack(preds).detach().numpy()
     assert (logp.argmax(-1) == g["free_argmax"]).all()
