@@ -13,8 +13,11 @@
  *   - Return value: 0 = ok; nonzero = error (1 argument/shape precondition, 2 HIP runtime error,
  *     3 unsupported configuration, 4 device-side failure).  las_last_error() returns a thread-local
  *     message.  Never throws, never exits.
- *   - `err_word` is a caller-owned, zero-initialised device uint32: kernels that hand data between
- *     workgroups write a nonzero code there if a bounded spin expires (results are then invalid).
+ *   - `err_word` points at TWO caller-owned, zero-initialised device uint32: kernels that hand data between
+ *     workgroups write a nonzero code into err_word[0] if a bounded spin expires (results are then invalid).
+ *     err_word[1] is an optional spin budget: 0 keeps the built-in 2^18 spins (~42 ms, sized for callers that can re-run a
+ *     step); a caller that cannot (no fused update to skip) stores a larger count there (2^21 = ~340 ms).  It is read only
+ *     after the built-in budget is spent.
  *   - Re-entrant per device.  Process-wide state is limited to (a) the mutex-guarded per-device RCCL handles, (b) the option
  *     registry below (atomics, initialised once from LAS_<NAME> environment variables: A/B and profiling switches whose
  *     defaults are the measured best) and (c) the las_debug_* profiling hooks declared at the end of this header.  Nothing a
@@ -36,7 +39,7 @@
 extern "C" {
 #endif
 
-#define LAS_ABI_VERSION 9
+#define LAS_ABI_VERSION 10
 #define LAS_MAX_SPELLER_LAYERS 4
 
 /* flags */
@@ -370,8 +373,9 @@ void las_debug_big_bwd_trace(unsigned long long* dev_buf);
 int las_debug_kernel_ms(int which, float* ms_out);
 /* Name of the kernel family the most recent call launched for slot `which` (process-wide): 0 Listener recurrence forward
  * ("rec_fwd_fast" | "rec_fwd_multi" | "rec_fwd_mfma" | "rec_fwd_mfma2" | "rec_fwd_generic"), 1 its backward ("rec_bwd_fast" | "rec_bwd_multi" |
- * "rec_bwd_mfma" | "rec_bwd_generic"), 2 decode loop forward ("persist_pre" | "persist" | "big" | "stepwise"), 3 decode loop backward (same
- * names), 4 the most recent GEMM's operand path ("split" | "f32" | "planes").  The parity tests assert it per fixture, so a silent
+ * "rec_bwd_mfma" | "rec_bwd_generic"), 2 decode loop forward ("persist_pre" | "persist_pre_greedy" (free-running form) | "persist_pre_mh" |
+ * "persist_pre_mh_greedy" (multi-head instantiations) | "persist" | "big" | "stepwise"), 3 decode loop backward ("persist_pre" | "persist_pre_mh" |
+ * "persist" | "big" | "stepwise"), 4 the most recent GEMM's operand path ("split" | "split256" (256 x 256 tiles, gemm_big.hip) | "f32" | "planes").  The parity tests assert it per fixture, so a silent
  * fall-back (e.g. LAS_ERR_UNSUPPORTED from a residency check) cannot leave a golden green on the wrong kernel.  Returns 0 / LAS_ERR_ARG. */
 int las_debug_last_path(int which, char* out, int cap);
 

@@ -4,7 +4,9 @@ from __future__ import annotations
 
 import ctypes as C
 import os
+import time
 
+import numpy as np
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
@@ -173,6 +175,8 @@ def stream_ptr():
 
 _err_words = {}
 _err_snap = {}      # device index -> (pinned host copy, event): the asynchronous snapshot poll_device_errors() looks at
+_err_snap_time = {}  # device index -> host time the last snapshot was enqueued
+_POLL_PERIOD_S = 0.05
 
 
 def _dev_index(device):
@@ -184,9 +188,13 @@ _STEP_READBACK_MAX = 4096      # utterances whose letter error rates ride in the
 _err_bufs = {}                 # device index -> int32 [4 error words | 4 floats (loss, spare) | _STEP_READBACK_MAX floats (LER)]
 
 
+_spin_log2 = 0                 # 0: the kernels' built-in spin budget (2^18 spins, ~42 ms); see set_handoff_spin_log2
+
+
 def err_word(device):
-    """Per-device uint32 the kernels write a nonzero code into when a bounded hand-off spin expires.  It is the head of a small buffer
-    whose tail takes a training step's loss and letter error rates (``step_readback``), so that the solver reads all three with one copy."""
+    """Per-device uint32 the kernels write a nonzero code into when a bounded hand-off spin expires (word 1 behind it: the optional
+    extended spin budget, include/las_hip.h).  It is the head of a small buffer whose tail takes a training step's loss and letter error
+    rates (``step_readback``), so that the solver reads all three with one copy."""
     key = _dev_index(device)
     w = _err_words.get(key)
     if w is None:
@@ -194,7 +202,31 @@ def err_word(device):
         _err_bufs[key] = buf
         w = buf[:4]
         _err_words[key] = w
+        if _spin_log2:
+            w[1] = 1 << _spin_log2
     return w
+
+
+def set_handoff_spin_log2(n):
+    """Spin budget of the persistent kernels' bounded hand-off waits: ``2**n`` spins of ~160 ns (0 / <= 18: the built-in 2^18, ~42 ms, sized
+    for callers that can re-run a step — ``solver.batch_iterator`` with ``FusedClipAdam`` or in validation).  A caller that cannot roll a
+    step back (plain torch optimizer, foreign gradient exchange) asks for 21 (~340 ms, the margin of rounds 1-4): a shared GPU, a debugger
+    or a pre-empted queue then has eight times longer before the step is declared lost.  Also read from LAS_HANDOFF_SPIN_LOG2 at import."""
+    global _spin_log2
+    n = int(n)
+    if n and not 18 < n < 31:
+        n = 0
+    _spin_log2 = n
+    for w in _err_words.values():
+        w[1] = (1 << n) if n else 0
+
+
+def handoff_spin_log2():
+    return _spin_log2 or 18
+
+
+def _clear_error(w):
+    w[:1].zero_()              # word 1 (the spin budget) stays
 
 
 def step_readback(device, B):
@@ -208,11 +240,11 @@ def step_readback(device, B):
 
 
 def read_step(device, B):
-    """The step's one synchronisation point: ``(error word, loss (numpy float32 scalar), [B letter error rates])``."""
+    """The step's one synchronisation point: ``(error word, loss (0-d float32 ndarray), [B letter error rates])``."""
     key = _dev_index(device)
     host = _err_bufs[key][:8 + B].cpu()
     f = host[4:].view(torch.float32).numpy()
-    return int(host[0]), f[0].copy(), f[4:4 + B].tolist()
+    return int(host[0]), np.array(f[0], dtype=np.float32), f[4:4 + B].tolist()      # the loss as a 0-d ndarray, like loss.cpu().data.numpy()
 
 
 class DeviceHandoffError(RuntimeError):
@@ -260,7 +292,7 @@ def check_device_errors(words=None):
     for key, w in _err_words.items():
         v = int(words[key]) if (words is not None and key in words) else int(w[0].item())
         if v != 0:
-            w.zero_()
+            _clear_error(w)
             _err_snap.pop(key, None)
             _raise_device_error(key, v)
 
@@ -280,14 +312,27 @@ def poll_device_errors(device):
             return                        # the previous snapshot has not landed yet: look again next call
         v = int(host[0])
         if v != 0:
-            w.zero_()
+            _clear_error(w)
             _err_snap.pop(key, None)
             _raise_device_error(key, v)
+        # a new snapshot at most every _POLL_PERIOD_S: each one is a device-to-host copy on the compute stream (4 us + a 6 us bubble in
+        # the step's timeline; four forwards per step would otherwise enqueue one almost every step).  Detection through THIS path is
+        # therefore up to that much later; solver.batch_iterator reads the word itself at every step's synchronisation point.
+        now = time.monotonic()
+        if now - _err_snap_time.get(key, 0.0) < _POLL_PERIOD_S:
+            return
     else:
         host = torch.zeros(4, dtype=torch.int32).pin_memory()
         ev = torch.cuda.Event()
         _err_snap[key] = (host, ev)
     host, ev = _err_snap[key]
+    _err_snap_time[key] = time.monotonic()
     with torch.cuda.device(key):
         host.copy_(w, non_blocking=True)
         ev.record()
+
+
+try:
+    set_handoff_spin_log2(int(os.environ.get("LAS_HANDOFF_SPIN_LOG2", "0")))
+except ValueError:
+    pass

@@ -44,7 +44,9 @@ __device__ __forceinline__ float poll_granule(u64* g, unsigned epoch, unsigned* 
         if ((unsigned)(x >> 32) == epoch) return __uint_as_float((unsigned)x);
         ++spins;
         if ((spins & 255u) == 0) {
-            if (spins > SPIN_LIMIT) { atomicExch(err, 0xDEAD0001u); return 0.f; }
+            if (spins > SPIN_LIMIT && spins > __hip_atomic_load(err + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) {      // err[1]: the caller's extended budget
+                atomicExch(err, 0xDEAD0001u); return 0.f;
+            }
             if (__hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) return 0.f;
         }
         __builtin_amdgcn_s_sleep(1);
@@ -83,7 +85,7 @@ __device__ __forceinline__ bool same_xcd_group(u64* idbuf, int member, unsigned*
         for (;;) {
             x = __hip_atomic_load(idbuf + tid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             if ((unsigned)(x >> 32) == 0xC0DE0001u) break;
-            if (++spins > SPIN_LIMIT) { atomicExch(err, 0xDEAD0002u); break; }
+            if (++spins > SPIN_LIMIT && spins > __hip_atomic_load(err + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) { atomicExch(err, 0xDEAD0002u); break; }
             __builtin_amdgcn_s_sleep(2);
         }
         if ((unsigned)x != xcc || (unsigned)(x >> 32) != 0xC0DE0001u) *lds_flag = 0;

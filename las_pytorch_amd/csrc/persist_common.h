@@ -11,8 +11,14 @@ using u64 = unsigned long long;
 constexpr int PS_THREADS = 1024, PS_NW = 16;
 constexpr unsigned PS_SENT = 0xFFFFFFFFu;
 // bounded spins: ~160 ns each, i.e. ~42 ms until a wait gives up (round 4: 1 << 21 = 336 ms of dead time per timeout; a hand-off normally
-// lands within microseconds, so this is still four orders of magnitude of margin — and a false alarm only costs one step on the generic kernels)
+// lands within microseconds, so this is still four orders of magnitude of margin — and a false alarm only costs one step on the generic kernels).
+// A caller that cannot re-run a step (no fused update to skip: a plain torch optimizer) extends the budget through the word BEHIND the error
+// word (err[1], option HANDOFF_SPIN_LOG2 / las_pytorch_amd._cabi.set_handoff_spin_log2): it is read only once the built-in budget is spent.
 constexpr unsigned PS_SPIN_LIMIT = 1u << 18;
+__device__ __forceinline__ bool spin_budget_spent(unsigned spins, const unsigned* err, unsigned builtin) {
+    if (spins <= builtin) return false;
+    return spins > __hip_atomic_load(err + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      // 0 (the default): the built-in budget stands
+}
 constexpr int PS_M = 64;           // attention MLP width handled by the persistent kernel
 constexpr int PS_KLD = PS_M + 4;   // LDS row stride of the keys (bank spread)
 
@@ -65,7 +71,7 @@ __device__ __forceinline__ bool spin_expired(unsigned& spins, unsigned* err, uns
     // the error word is looked at rarely: that agent-scope load takes ~1 us, and a poller that is inside it when its data arrives
     // delays its whole workgroup (with a check every 128 spins one of a workgroup's 16 waves was caught in almost every wait)
     if ((spins & 8191u) == 0) {
-        if (spins > PS_SPIN_LIMIT) { atomicExch(err, code); return true; }
+        if (spin_budget_spent(spins, err, PS_SPIN_LIMIT)) { atomicExch(err, code); return true; }
         if (__hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) return true;
     }
     __builtin_amdgcn_s_sleep(1);

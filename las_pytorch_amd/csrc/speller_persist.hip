@@ -1614,7 +1614,7 @@ static int launch_persist_fwd_pre(const PersistArgs& a, int grid, hipStream_t st
         hipLaunchKernelGGL((speller_persist_fwd_pre_kernel<HS, WS, GREEDY, MH>), dim3(grid), dim3(PS_THREADS), smem, stream, a);
     }
     LAS_LAUNCH_CHECK();
-    path_note(PATH_DECODE_FWD, GREEDY ? "persist_pre_greedy" : "persist_pre");
+    path_note(PATH_DECODE_FWD, GREEDY ? (MH ? "persist_pre_mh_greedy" : "persist_pre_greedy") : (MH ? "persist_pre_mh" : "persist_pre"));
     return LAS_OK;
 }
 

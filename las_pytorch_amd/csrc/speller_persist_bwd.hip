@@ -1370,7 +1370,7 @@ static int launch_persist_bwd_pre(const PersistBwdArgs& a, int grid, hipStream_t
         hipLaunchKernelGGL((speller_persist_bwd_pre_kernel<HS, MH>), dim3(grid), dim3(PS_THREADS), smem, stream, a);
     }
     LAS_LAUNCH_CHECK();
-    path_note(PATH_DECODE_BWD, "persist_pre");
+    path_note(PATH_DECODE_BWD, MH ? "persist_pre_mh" : "persist_pre");
     return LAS_OK;
 }
 

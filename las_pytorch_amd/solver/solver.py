@@ -67,6 +67,9 @@ def LetterErrorRate(pred_y, true_y):
     return rates
 
 
+DEVICE_LER_MAX_STEPS = 4095
+
+
 def LetterErrorRate_device(pred_y, labels_onehot_int64, out=None):
     """The same quantity from log-probs (B,U,V) and int64 one-hot labels without leaving the GPU; returns a (B,)
     float tensor on the device (``out`` when given)."""
@@ -76,6 +79,15 @@ def LetterErrorRate_device(pred_y, labels_onehot_int64, out=None):
         raise RuntimeError("LetterErrorRate_device needs fp32 log-probs")
     B, U, V = pred_y.shape
     labels = labels_onehot_int64.contiguous()
+    if max(U, labels.shape[1]) > DEVICE_LER_MAX_STEPS:
+        # the wave kernel keeps a row of the edit-distance table in registers (<= 4095 steps); the reference has no length limit:
+        # longer decodes take the host form (one copy of the arg-max sequences)
+        rates = LetterErrorRate(pred_y.argmax(-1).cpu().numpy(), labels.argmax(-1).cpu().numpy())
+        res = torch.tensor(rates, dtype=torch.float32, device=pred_y.device)
+        if out is not None:
+            out.copy_(res)
+            return out
+        return res
     if out is None:
         out = torch.empty(B, device=pred_y.device)
     _cabi.check(_cabi.lib().las_letter_error_rate(_cabi.ptr_strided(pred_y), pred_y.stride(1), pred_y.stride(0), _cabi.ptr(labels), U,
@@ -220,6 +232,10 @@ def batch_iterator(batch_data, batch_label, las_model, optimizer, tf_rate, is_tr
     fused = isinstance(optimizer, FusedClipAdam)
     if fused and reducer is not optimizer.reducer:
         raise RuntimeError("FusedClipAdam was built on a different FlatGradAllReducer than the one attached to the model")
+    if is_training and not fused and batch_data.is_cuda and _cabi.handoff_spin_log2() < 21:
+        # this step cannot be rolled back after a hand-off timeout (no fused update to skip itself): give the persistent kernels' bounded
+        # waits the long budget (~340 ms instead of ~42 ms) before a shared GPU / debugger / pre-empted queue costs the training run
+        _cabi.set_handoff_spin_log2(21)
     if reducer is not None:
         reducer.zero()                        # keeps every p.grad a view of the flat buffer
     else:
@@ -267,7 +283,7 @@ def batch_iterator(batch_data, batch_label, las_model, optimizer, tf_rate, is_tr
     peer_flag = 0.0
     own_words = None
     if packed is not None:
-        word, batch_loss, ler = _cabi.read_step(logp.device, logp.shape[0])
+        word, batch_loss, ler = _cabi.read_step(logp.device, logp.shape[0])      # (batch_loss: a 0-d float32 ndarray, as the other branches)
         own_words = {_cabi._dev_index(logp.device): word}
     elif is_training and reducer is not None and reducer._collective() and not loss.is_cuda:
         batch_loss = loss.detach().numpy()

@@ -46,8 +46,9 @@ def expected_paths(info):
         tf = bwd = greedy = "big"
     elif (2 <= info["multi_head"] <= 4 and info["use_mlp"] and info["activate"] in ("relu", "None") and Hs in (256, 512)):
         # multi-head (round 5): the PRE kernels both ways, one set of attention workgroups per (utterance, head), 32 // heads utterances per
-        # launch; the free-running form exchanges the heads' shares of the character distribution as well
-        tf, bwd, greedy = "persist_pre", "persist_pre", "persist_pre_greedy"
+        # launch; the free-running form exchanges the heads' shares of the character distribution as well (distinct names: the multi-head
+        # instantiations are different kernels)
+        tf, bwd, greedy = "persist_pre_mh", "persist_pre_mh", "persist_pre_mh_greedy"
     else:
         tf = bwd = greedy = "stepwise"
     return dict(rec_fwd="rec_fwd_" + rec_f, rec_bwd="rec_bwd_" + rec_b, tf=tf, greedy=greedy, bwd=bwd)

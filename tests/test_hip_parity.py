@@ -238,8 +238,9 @@ def test_free_running_training_step_golden(name):
     xg, labg = torch.from_numpy(x).cuda(), torch.from_numpy(onehot).cuda()
     preds, _ = las(batch_data=xg, batch_label=labg, teacher_force_rate=0.0, is_training=True)
     assert len(preds) == U
+    mh = "_mh" if heads > 1 else ""
     if cfg_name == "P":
-        assert _cabi.last_path(_cabi.PATH_DECODE_FWD) == "persist_pre_greedy", _cabi.last_path(_cabi.PATH_DECODE_FWD)
+        assert _cabi.last_path(_cabi.PATH_DECODE_FWD) == f"persist_pre{mh}_greedy", _cabi.last_path(_cabi.PATH_DECODE_FWD)
     logp = torch.stack(preds).detach().cpu().numpy()
     assert (logp.argmax(-1) == g["free_argmax"]).all(), "free-running arg-max sequence differs from the reference's"
     assert_close(logp, g["free_logp"], f"{name}/free_logp")
@@ -247,7 +248,7 @@ def test_free_running_training_step_golden(name):
     loss.backward()
     torch.cuda.synchronize()
     if cfg_name == "P":
-        assert _cabi.last_path(_cabi.PATH_DECODE_BWD) == "persist_pre", _cabi.last_path(_cabi.PATH_DECODE_BWD)
+        assert _cabi.last_path(_cabi.PATH_DECODE_BWD) == f"persist_pre{mh}", _cabi.last_path(_cabi.PATH_DECODE_BWD)
     assert abs(loss.item() - g["loss_ls"][0]) <= 1e-4 * abs(g["loss_ls"][0]) + 1e-6
     assert [k for k, _ in las.named_parameters()] == [str(k) for k in g["grad_keys"]]
     norms = np.array([p.grad.double().norm().item() for _, p in las.named_parameters()])
@@ -567,7 +568,10 @@ def test_pre_multiplied_context_backward_matches_classic_persistent_backward(cfg
                                                                     ("S", 4, 8, 100, 5, 0.1, "None"), ("P", 2, 8, 224, 4, None, "relu"), ("P", 2, 1, 1, 3, None, "relu"),
                                                                     ("S", 2, 4, 400, 3, None, "relu"),
                                                                     # two slices of 16 / of 8 (Speller._run), then a ragged last slice
-                                                                    ("P", 2, 32, 50, 5, None, "relu"), ("P", 4, 13, 40, 4, None, "relu")])
+                                                                    ("P", 2, 32, 50, 5, None, "relu"), ("P", 4, 13, 40, 4, None, "relu"),
+                                                                    # ragged remainder slices (16 + 8 at heads = 2, 8 + 4 at heads = 4): the tail slice takes the
+                                                                    # one-launch kernel under the workgroup map of ITS size (path asserted on the tail)
+                                                                    ("P", 2, 24, 50, 5, None, "relu"), ("P", 4, 12, 40, 4, None, "relu")])
 def test_multi_head_one_launch_decode_matches_stepwise(cfg_name, heads, B, Tp, U, scale, activate):
     """Multi-head attention (reference las_model.py:298-314) on the one-launch decode kernels — one set of attention workgroups per (utterance,
     head), dim_reduce folded into the pre-multiplied context, the heads' sums exchanged before the bottom cell; backward: heads x frame slices —
@@ -628,7 +632,7 @@ def _persistent_vs_stepwise(cfg_name, B, Tp, U, scale, activate, big=False, head
             set_trace(None)
     torch.cuda.synchronize()
     if heads > 1:
-        assert paths == ("persist_pre", "persist_pre"), paths
+        assert paths == ("persist_pre_mh", "persist_pre_mh"), paths      # (of the LAST slice: the ragged tail of a sliced batch included)
     assert int(trace.abs().sum().item()) != 0, "the persistent kernel did not run (shape not eligible?)"
     assert not big or int(btrace.abs().sum().item()) != 0, "the one-launch backward did not run"
     for k in res[0]:
@@ -767,7 +771,7 @@ def test_multi_head_free_running_training_step_backward_on_the_one_launch_kernel
             res.append(out)
         finally:
             sp.force_generic = False
-    assert paths == [("persist_pre_greedy", "persist_pre"), ("stepwise", "stepwise")], paths
+    assert paths == [("persist_pre_mh_greedy", "persist_pre_mh"), ("stepwise", "stepwise")], paths
     assert (res[0]["logp"].argmax(-1) == res[1]["logp"].argmax(-1)).all()
     assert set(res[0]) == set(res[1])
     for k in res[0]:
@@ -800,7 +804,7 @@ def test_multi_head_free_running_decode_without_backward(cfg_name, heads, B, Tp,
             res.append((torch.stack(preds).cpu().numpy(), torch.stack([torch.stack(list(a)) for a in att]).cpu().numpy()))
         finally:
             sp.force_generic = False
-    assert paths == ["persist_pre_greedy", "stepwise"], paths
+    assert paths == ["persist_pre_mh_greedy", "stepwise"], paths
     assert (res[0][0].argmax(-1) == res[1][0].argmax(-1)).all(), "arg-max sequences differ"
     assert_close(res[0][0], res[1][0], "multi-head free-running logp")
     assert_close(res[0][1], res[1][1], "multi-head free-running attention", rtol=1e-3, atol=1e-6)
@@ -846,9 +850,9 @@ def test_free_running_decode_without_backward_runs_the_pre_kernel(cfg_name, B, T
     _check_err()
 
 
-def test_free_running_training_step_at_long_t_mixes_per_step_forward_and_pre_backward():
-    """T' = 375 (BASELINE configs[4]) with decode_mode 1 and a backward pass: the free-running forward (since round 5, late: the one-launch kernel
-    with the keys split by frames over 16 workgroups per utterance; per-step launches until then — the test's name is from that time) must leave
+def test_free_running_training_step_at_long_t_runs_the_one_launch_kernels_both_ways():
+    """T' = 375 (BASELINE configs[4]) with decode_mode 1 and a backward pass: the free-running forward (the one-launch kernel with the keys
+    split by frames over 16 workgroups per utterance) must leave
     P / gx in the reserve exactly as a teacher-forced forward does, because the backward takes the teacher-forced PRE kernel over the emitted
     symbols.  Against the all-generic path."""
     from las_pytorch_amd import Speller, _cabi, synth

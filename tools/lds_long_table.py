@@ -41,7 +41,7 @@ def table(db, title):
 if __name__ == "__main__":
     E = sys.argv[1]
     for sub, title in (("pmc_long_lds", "P_long (Listener 256x3 / Speller 512x2, B = 8, T = 3000, T' = 375): keys 96 KB resident in LDS, P[b] in registers"),
-                       ("pmc_slong_lds", "S_long (Listener 128x2 / Speller 256x2, B = 8, T = 3000, T' = 750): keys 192 KB exceed the LDS -> per-step decode forward")):
+                       ("pmc_slong_lds", "S_long (Listener 128x2 / Speller 256x2, B = 8, T = 3000, T' = 750): keys 192 KB exceed one workgroup's LDS -> split by frames over the 16 workgroups of an utterance (speller_persist_fwd_pre_kernel<256, 16>)")):
         db = find_db(os.path.join(E, sub))
         if db:
             table(db, title)
