@@ -59,7 +59,17 @@ extern "C" {
                                        (the flat gradient buffer, cleared once per step): the entry point skips its own fill of that block
                                        (~5 us each, launch-bound).  Without the flag the outputs may hold anything. */
 
+#define LAS_FLAG_DEFER_DW       32  /* las_pblstm_bwd / las_speller_bwd: the weight-gradient GEMM group (and bias column sums) of this call may be left
+                                       running on a library-owned side stream when the call returns; the caller MUST call las_join_deferred(stream)
+                                       before anything reads those gradients, and must keep every buffer it passed alive until then.  Taken only
+                                       where it pays: batches whose backward recurrences fit 2 or 4 of the 8 XCDs (B <= 16 at H = 256) — those
+                                       launches are then confined to these XCDs and the deferred group runs on the others (their CUs and L2s),
+                                       hidden under the NEXT layer's recurrence.  Taken at 2 of 8 XCDs only (B <= 8 at H = 256: the long-utterance batches of
+                                       BASELINE configs[4]; measured slower at 4).  Ignored otherwise (and during stream capture). */
+
 int las_abi_version(void);
+/* Make `stream` wait for the deferred work of this thread's earlier LAS_FLAG_DEFER_DW calls on the current device (no-op if none). */
+int las_join_deferred(void* stream);
 const char* las_last_error(void);
 
 /* ------------------------------------------------------------------------------------------------
@@ -371,11 +381,15 @@ void las_debug_big_bwd_trace(unsigned long long* dev_buf);
  * kernel, which = 0 forward (speller_persist_fwd*_kernel), 1 backward (speller_persist_bwd*_kernel).  Synchronises on that launch.
  * bench.py prices these two kernels against the roofline with it. */
 int las_debug_kernel_ms(int which, float* ms_out);
+/* Placement probe of the XCD-partitioned launches (LAS_FLAG_DEFER_DW): dev_buf = 2048 device uint32 (NULL: off).  The confined backward recurrence
+ * writes XCC id + 1 of block b at [b], the partitioned GEMM group at [1024 + b]. */
+void las_debug_xcd_probe(unsigned* dev_buf);
 /* Name of the kernel family the most recent call launched for slot `which` (process-wide): 0 Listener recurrence forward
  * ("rec_fwd_fast" | "rec_fwd_multi" | "rec_fwd_mfma" | "rec_fwd_mfma2" | "rec_fwd_generic"), 1 its backward ("rec_bwd_fast" | "rec_bwd_multi" |
  * "rec_bwd_mfma" | "rec_bwd_generic"), 2 decode loop forward ("persist_pre" | "persist_pre_greedy" (free-running form) | "persist_pre_mh" |
  * "persist_pre_mh_greedy" (multi-head instantiations) | "persist" | "big" | "stepwise"), 3 decode loop backward ("persist_pre" | "persist_pre_mh" |
- * "persist" | "big" | "stepwise"), 4 the most recent GEMM's operand path ("split" | "split256" (256 x 256 tiles, gemm_big.hip) | "f32" | "planes").  The parity tests assert it per fixture, so a silent
+ * "persist" | "big" | "stepwise"), 5 the weight-gradient group of the most recent backward entry point ("deferred": left on the side stream under
+ * LAS_FLAG_DEFER_DW | "inline"), 4 the most recent GEMM's operand path ("split" | "split256" (256 x 256 tiles, gemm_big.hip) | "f32" | "planes").  The parity tests assert it per fixture, so a silent
  * fall-back (e.g. LAS_ERR_UNSUPPORTED from a residency check) cannot leave a golden green on the wrong kernel.  Returns 0 / LAS_ERR_ARG. */
 int las_debug_last_path(int which, char* out, int cap);
 

@@ -17,6 +17,7 @@ FLAG_STASH = 1
 FLAG_FORCE_GENERIC = 2
 FLAG_TEACHER_FORCED = 4     # las_speller_bwd: the forward that filled `reserve` was teacher-forced (same flags / error word)
 FLAG_GRADS_ZEROED = 16      # las_pblstm_bwd / las_speller_bwd: the gradient block was zeroed by the caller (flat buffer, once per step)
+FLAG_DEFER_DW = 32          # ... their weight-gradient GEMM group may still be running on the library's side stream on return (las_join_deferred)
 FLAG_GEMM_F32 = 8           # this call's GEMMs on the fp32 matrix pipe (per call; the process-wide default is option GEMM_ARITH)
 
 _f = C.c_void_p   # every device pointer is passed as an integer address
@@ -48,6 +49,7 @@ PROTOTYPES = {
     "las_last_error": (C.c_char_p, []),
     "las_set_option": (C.c_int, [C.c_char_p, C.c_int64]),
     "las_gemm_check": (C.c_int, []),
+    "las_join_deferred": (C.c_int, [C.c_void_p]),
     "las_get_option": (C.c_int, [C.c_char_p, C.POINTER(C.c_int64)]),
     "las_clip_adam_workspace_floats": (C.c_size_t, []),
     "las_clip_adam": (C.c_int, [C.POINTER(_f), C.POINTER(C.c_int64), C.c_int, _f, _f, _f, C.c_float, C.c_double, C.c_double, C.c_double,
@@ -133,7 +135,7 @@ def get_option(key):
     return int(out.value)
 
 
-PATH_REC_FWD, PATH_REC_BWD, PATH_DECODE_FWD, PATH_DECODE_BWD, PATH_GEMM = range(5)
+PATH_REC_FWD, PATH_REC_BWD, PATH_DECODE_FWD, PATH_DECODE_BWD, PATH_GEMM, PATH_DW = range(6)
 
 
 def last_path(which):

@@ -61,6 +61,11 @@ static __device__ __forceinline__ SegRole seg_atomic(bool add_bias) { return Seg
 constexpr int GROUP_MAX = 8;
 struct GemmGroupParams {
     GemmParams prob[GROUP_MAX]; long first[GROUP_MAX + 1]; int n; int xcd_swz;
+    unsigned* xcd_probe;
+    unsigned* run_counter;      // xcd_lo > 0: zeroed before the launch; the surviving workgroups draw their runs from it
+    int xcd_lo;      // > 0: the workgroups that find themselves on XCDs [0, xcd_lo) (actual XCC id) leave at once; the others draw the W' =
+                     // gridDim.x / 8 * (8 - xcd_lo) equal runs of the whole problem from run_counter — correct for ANY placement of the blocks
+                     // (XCD partition beside a latency-bound chain kernel confined to those XCDs)
     float* sk_part; unsigned* sk_flag; unsigned* sk_err; unsigned sk_id;      // stream-K fix-up (see GemmParams); null: atomics onto zeroed outputs
     unsigned* call_err;
 };

@@ -947,44 +947,66 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_f32_kernel(GemmParams p)
 // is no tail between the GEMMs, a 16-tile problem no longer holds the chip, and a tile is split between as few workgroups
 // as the balance allows (the atomic traffic is W + #tiles partial tiles, not W per problem).  Partial tiles accumulate with
 // atomics onto buffers the caller has zeroed (the flat gradient buffer); whole tiles are stored (or added) plainly.
-template <bool A_KC, bool B_KC, int MODE>
+// PART: the XCD-partitioned form (g.xcd_lo > 0; instantiated for the weight-gradient operand layout only)
+template <bool A_KC, bool B_KC, int MODE, bool PART = false>
 __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_group_kernel(GemmGroupParams g) {
     GemmSmem<MODE> sm;
     float (*As)[BK][BM + PAD] = sm.As; float (*Bs)[BK][BN + PAD] = sm.Bs; unsigned* sp = sm.sp;
-    const int W = gridDim.x;
-    const int w = (W % 8 == 0 && g.xcd_swz) ? (int)(blockIdx.x & 7) * (W >> 3) + (int)(blockIdx.x >> 3) : (int)blockIdx.x;
+    int W = gridDim.x;
+    int w = (W % 8 == 0 && g.xcd_swz) ? (int)(blockIdx.x & 7) * (W >> 3) + (int)(blockIdx.x >> 3) : (int)blockIdx.x;
+    // (mailbox of the run draw: the first word of the operand buffers, free between two runs — no second __shared__ object in front of the
+    // dynamic LDS, whose 16-byte alignment the fragment reads rely on)
+    volatile unsigned* mbox = MODE == 0 ? reinterpret_cast<volatile unsigned*>(&As[0][0][0]) : reinterpret_cast<volatile unsigned*>(sp);
+    if (PART) {      // XCD partition (host guarantees W % 8 == 0 and the atomic combination): runs are drawn, not assigned
+        unsigned xcc;
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID, 0, 4)" : "=s"(xcc));
+        if (g.xcd_probe && threadIdx.x == 0 && blockIdx.x < 1024) g.xcd_probe[1024 + blockIdx.x] = xcc + 1;
+        if ((int)xcc < g.xcd_lo) return;
+        W = (W >> 3) * (8 - g.xcd_lo);
+    }
     const long total = g.first[g.n];
     const long per = (total + W - 1) / W;
-    long i0 = (long)w * per, i1 = min(i0 + per, total);
-    int pi = 0;
-    while (pi + 1 < g.n && g.first[pi + 1] <= i0) ++pi;
-    while (i0 < i1) {
-        GemmParams p = g.prob[pi];             // by value: the fields live in SGPRs across the k-loop (fetching them from the
-                                               // kernel-argument segment inside the loop measured slower)
-        p.sk_part = g.sk_part; p.sk_flag = g.sk_flag; p.sk_err = g.sk_err; p.sk_id = g.sk_id; p.call_err = g.call_err;
-        const long pend = min(i1, g.first[pi + 1]);
-        long l0 = i0 - g.first[pi];
-        const long l1 = pend - g.first[pi];
-        while (l0 < l1) {
-            const int t = (int)(l0 / p.kt);
-            const int it0 = (int)(l0 % p.kt), it1 = (int)min((long)p.kt, it0 + (l1 - l0));
-            const bool whole = it0 == 0 && it1 == p.kt;
-            SegRole role;
-            if (g.sk_part == nullptr) {
-                role = whole ? SegRole{SEG_STORE, 0, 0, 0, false} : seg_atomic(false);
-            } else if (it0 > 0) {
-                role = SegRole{SEG_PART, w, 0, 0, false};
-            } else {
-                // owner: the slots behind this one whose runs start before the tile's last k-iteration (global iteration space)
-                const long tile_end = g.first[pi] + (l0 - it0) + p.kt;
-                const int c1 = (int)min((long)W, (tile_end + per - 1) / per);
-                role = SegRole{SEG_STORE, 0, w + 1, whole ? w + 1 : c1, false};
-            }
-            gemm_segment<A_KC, B_KC, MODE>(p, As, Bs, sp, 0, (t / p.gx) * BM, (t % p.gx) * BN, it0 * BK, min(p.K, it1 * BK), role);
-            l0 += it1 - it0;
+    for (;;) {
+        if (PART) {
+            __syncthreads();                         // (the previous run's last LDS reads / the previous draw are done)
+            if (threadIdx.x == 0) *mbox = atomicAdd(g.run_counter, 1u);
+            __syncthreads();
+            w = (int)*mbox;
+            __syncthreads();                         // (everybody has it: the run's first LDS stores may overwrite the word)
+            if (w >= W) return;
         }
-        i0 = pend;
-        ++pi;
+        long i0 = (long)w * per, i1 = min(i0 + per, total);
+        int pi = 0;
+        while (pi + 1 < g.n && g.first[pi + 1] <= i0) ++pi;
+        while (i0 < i1) {
+            GemmParams p = g.prob[pi];             // by value: the fields live in SGPRs across the k-loop (fetching them from the
+                                                   // kernel-argument segment inside the loop measured slower)
+            p.sk_part = g.sk_part; p.sk_flag = g.sk_flag; p.sk_err = g.sk_err; p.sk_id = g.sk_id; p.call_err = g.call_err;
+            const long pend = min(i1, g.first[pi + 1]);
+            long l0 = i0 - g.first[pi];
+            const long l1 = pend - g.first[pi];
+            while (l0 < l1) {
+                const int t = (int)(l0 / p.kt);
+                const int it0 = (int)(l0 % p.kt), it1 = (int)min((long)p.kt, it0 + (l1 - l0));
+                const bool whole = it0 == 0 && it1 == p.kt;
+                SegRole role;
+                if (g.sk_part == nullptr) {
+                    role = whole ? SegRole{SEG_STORE, 0, 0, 0, false} : seg_atomic(false);
+                } else if (it0 > 0) {
+                    role = SegRole{SEG_PART, w, 0, 0, false};
+                } else {
+                    // owner: the slots behind this one whose runs start before the tile's last k-iteration (global iteration space)
+                    const long tile_end = g.first[pi] + (l0 - it0) + p.kt;
+                    const int c1 = (int)min((long)W, (tile_end + per - 1) / per);
+                    role = SegRole{SEG_STORE, 0, w + 1, whole ? w + 1 : c1, false};
+                }
+                gemm_segment<A_KC, B_KC, MODE>(p, As, Bs, sp, 0, (t / p.gx) * BM, (t % p.gx) * BN, it0 * BK, min(p.K, it1 * BK), role);
+                l0 += it1 - it0;
+            }
+            i0 = pend;
+            ++pi;
+        }
+        if (!PART) return;
     }
 }
 
@@ -1060,8 +1082,20 @@ static int launch_group_ab(const GemmGroupParams& g, int mode, dim3 grid, hipStr
     LAS_LAUNCH_CHECK();
     return LAS_OK;
 }
+static int launch_group_part(const GemmGroupParams& g, int mode, dim3 grid, hipStream_t stream) {      // weight-gradient layout, modes 0 / 1
+    if (mode == 1) {
+        static const int ready = split_kernel_ready(gemm_group_kernel<false, false, 1, true>);
+        LAS_REQUIRE(ready, "dynamic LDS of the split-operand GEMM");
+        hipLaunchKernelGGL((gemm_group_kernel<false, false, 1, true>), grid, dim3(GEMM_THREADS), SP_SMEM_BYTES, stream, g);
+    } else {
+        hipLaunchKernelGGL((gemm_group_kernel<false, false, 0, true>), grid, dim3(GEMM_THREADS), 0, stream, g);
+    }
+    LAS_LAUNCH_CHECK();
+    return LAS_OK;
+}
 static int launch_group(const GemmGroupParams& g, bool a_kc, bool b_kc, bool planes, dim3 grid, hipStream_t stream) {
     const int mode = planes ? 2 : (gemm_get_arith() == 1 ? 1 : 0);
+    if (g.xcd_lo > 0) return launch_group_part(g, mode, grid, stream);
     if (a_kc && b_kc) return launch_group_ab<true, true>(g, mode, grid, stream);
     if (a_kc && !b_kc) return launch_group_ab<true, false>(g, mode, grid, stream);
     if (!a_kc && b_kc) return launch_group_ab<false, true>(g, mode, grid, stream);
@@ -1174,10 +1208,31 @@ int split_planes(const float* src, long ld_src, int R, int C, void* dst, long ld
     return LAS_OK;
 }
 
-int gemm_f32_group(const GemmDesc* ds, int n, hipStream_t stream) {
+// the run counter of the XCD-partitioned group launches: 64 words per device, created on first use; consecutive launches (in-order side stream)
+// take consecutive words, each zeroed in front of its launch
+static unsigned* group_run_counter(hipStream_t stream) {
+    static std::mutex mu;
+    static unsigned* buf[16] = {};
+    static unsigned next[16] = {};
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) return nullptr;
+    std::lock_guard<std::mutex> lk(mu);
+    if (buf[dev] == nullptr) {
+        hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+        if (hipStreamIsCapturing(stream, &cap) != hipSuccess || cap != hipStreamCaptureStatusNone) return nullptr;
+        if (hipMalloc(&buf[dev], sizeof(unsigned) * 64) != hipSuccess) { (void)hipGetLastError(); buf[dev] = nullptr; return nullptr; }
+    }
+    unsigned* p = buf[dev] + (next[dev]++ & 63u);
+    if (hipMemsetAsync(p, 0, sizeof(unsigned), stream) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
+    return p;
+}
+
+int gemm_f32_group(const GemmDesc* ds, int n, hipStream_t stream, int xcd_lo) {
     const int group_on = (int)opt_get(OPT_GEMM_GROUP);
     const int W = gemm_resident_slots();
-    if (group_on) {      // 256-tile form where the group's tiles are big enough
+    if (xcd_lo < 0 || xcd_lo > 6 || W % 8 != 0) xcd_lo = 0;
+    unsigned* run_counter = nullptr;
+    if (group_on && xcd_lo == 0) {      // 256-tile form where the group's tiles are big enough
         const int rc = gemm_big_group(ds, n, stream);
         if (rc != LAS_ERR_UNSUPPORTED) return rc;
     }
@@ -1186,7 +1241,7 @@ int gemm_f32_group(const GemmDesc* ds, int n, hipStream_t stream) {
     // workgroup runs, so an owner would fetch up to 512 KB of parked tiles serially at the end of its run, where atomics are fire-and-
     // forget and overlap the next segment (measured: L0 dW group 185 against 164 us, the others +3 .. +7 us).  GEMM_SK_FIXUP=2 selects
     // the fix-up form here too (outputs then need not start from zero; results are run-to-run deterministic).
-    const SkScratch* sc = (ok && opt_get(OPT_GEMM_SK_FIXUP) >= 2) ? sk_scratch(stream, W) : nullptr;
+    const SkScratch* sc = (ok && xcd_lo == 0 && opt_get(OPT_GEMM_SK_FIXUP) >= 2) ? sk_scratch(stream, W) : nullptr;
     for (int i = 0; ok && i < n; ++i) {
         const GemmDesc& d = ds[i];
         ok = d.batch <= 1 && !d.relu && !d.bias0 && !d.bias1 && (d.c_zeroed || d.accumulate || sc != nullptr) && d.a_kc == ds[0].a_kc && d.b_kc == ds[0].b_kc &&
@@ -1197,11 +1252,13 @@ int gemm_f32_group(const GemmDesc* ds, int n, hipStream_t stream) {
         return LAS_OK;
     }
     LAS_TRY(gemm_sk_check());
+    if (xcd_lo > 0 && (ds[0].a_kc || ds[0].b_kc || ds[0].planes || (run_counter = group_run_counter(stream)) == nullptr)) xcd_lo = 0;
     GemmGroupParams g;
     g.n = n;
     g.first[0] = 0;
     const int xcd_swz = (int)opt_get(OPT_GEMM_XCD_SWZ);
     g.xcd_swz = xcd_swz;
+    g.xcd_lo = xcd_lo; g.xcd_probe = xcd_lo > 0 ? xcd_probe_ptr() : nullptr; g.run_counter = run_counter;
     for (int i = 0; i < n; ++i) {
         const GemmDesc& d = ds[i];
         GemmParams& p = g.prob[i];

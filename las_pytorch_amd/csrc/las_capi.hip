@@ -335,9 +335,11 @@ int las_pblstm_bwd(const float* x, const float* dout, int B, int T_in, int D_in,
     // zeroed 8H block (the layout of the flat gradient buffer); otherwise a column-sum kernel runs below
     const bool db_in_kernel = zg && db_hh_f == db_ih_f + n_b && db_hh_r == db_ih_r + n_b;
     int db_done = 0;
+    // (deferral needs a next recurrence to hide under — dx != null: not the input layer — and a batch that leaves XCDs free)
+    const int confine = ((flags & LAS_FLAG_DEFER_DW) && dx && !(flags & LAS_FLAG_FORCE_GENERIC) && opt_get(OPT_DEFER_DW) != 0) ? rec_confine_xcds(B, H) : 0;
     LAS_TRY(pblstm_rec_bwd(dout, gates, cbuf, wt, dgates, B, T, H, (unsigned long long*)(workspace + wl.xbuf), err_word,
                            flags & LAS_FLAG_FORCE_GENERIC, stream, db_in_kernel ? db_ih_f : nullptr, db_in_kernel ? db_ih_r : nullptr,
-                           &db_done));
+                           &db_done, confine));
     // the four weight-gradient contractions (few output tiles, K = B*T) go out as ONE grouped stream-K launch
     GemmDesc dw[4];
     for (int dir = 0; dir < 2; ++dir) {
@@ -352,9 +354,19 @@ int las_pblstm_bwd(const float* x, const float* dout, int B, int T_in, int D_in,
         gh.B = hp; gh.ldb = H; gh.b_kc = false;
         gh.C = dir ? dw_hh_r : dw_hh_f; gh.ldc = H; gh.M = 4 * H; gh.N = H; gh.K = BT; gh.c_zeroed = zg;
     }
-    LAS_TRY(gemm_f32_group(dw, 4, stream));
-    for (int dir = 0; dir < 2 && !db_done; ++dir)
-        LAS_TRY(colsum(dgates + (size_t)dir * BT * 4 * H, 4 * H, BT, 4 * H, dir ? db_ih_r : db_ih_f, zg, stream, dir ? db_hh_r : db_hh_f));
+    // LAS_FLAG_DEFER_DW: the weight-gradient group leaves the critical path — it goes to the library's side stream, restricted to the XCDs the
+    // confined recurrence above (and the next layer's, launched by the next call) does not use, and is joined by las_join_deferred
+    hipStream_t ws = stream;
+    bool deferred = false;
+    if (confine > 0) {
+        if (hipStream_t s = defer_side().begin(stream)) { ws = s; deferred = true; }
+    }
+    path_note(PATH_DW, deferred ? "deferred" : "inline");
+    if (!deferred) {
+        LAS_TRY(gemm_f32_group(dw, 4, stream));
+        for (int dir = 0; dir < 2 && !db_done; ++dir)
+            LAS_TRY(colsum(dgates + (size_t)dir * BT * 4 * H, 4 * H, BT, 4 * H, dir ? db_ih_r : db_ih_f, zg, stream, dir ? db_hh_r : db_hh_f));
+    }
     if (dx) {   // dX = [dG_f | dG_r] [W_ih_f ; W_ih_r]: both directions in one pass over K = 2 * 4H
         GemmDesc g;
         g.A = dgates; g.lda = 4 * H; g.a_kc = true;
@@ -362,6 +374,12 @@ int las_pblstm_bwd(const float* x, const float* dout, int B, int T_in, int D_in,
         g.A2 = dgates + (size_t)BT * 4 * H; g.B2 = w_ih_r; g.K1 = 4 * H;
         g.C = dx; g.ldc = D; g.M = BT; g.N = D; g.K = 8 * H; g.splitk = 1;
         LAS_TRY(gemm_f32(g, stream));
+    }
+    if (deferred) {      // (issued after dX so that the critical-path GEMM is first in the hardware queues; both start once the recurrence is done)
+        LAS_TRY(gemm_f32_group(dw, 4, ws, confine));
+        for (int dir = 0; dir < 2 && !db_done; ++dir)
+            LAS_TRY(colsum(dgates + (size_t)dir * BT * 4 * H, 4 * H, BT, 4 * H, dir ? db_ih_r : db_ih_f, zg, ws, dir ? db_hh_r : db_hh_f));
+        LAS_TRY(defer_side().end());
     }
     return LAS_OK;
 }
@@ -379,7 +397,7 @@ int las_attn_keys_fwd(const las_speller_desc* d, const float* feat, float* keys,
     g.M = d->B * d->Tp; g.N = d->M; g.K = d->D;
     // a 64-column output gives only B*T'/128 tiles: split K over the chip and apply the activation in a second tiny pass
     const long tiles = (long)cdiv(g.M, 128) * cdiv(g.N, 128);
-    if (tiles < 64 && g.K >= 256) {
+    if (tiles < 64 && g.K >= 256 && opt_get(OPT_KEYS_SPLITK) != 0) {
         g.splitk = (int)std::min<long>(g.K / 64, std::max<long>(1, 256 / tiles));
         LAS_TRY(gemm_f32(g, stream));
         if (d->relu) LAS_TRY(act_inplace(keys, (long)g.M * g.N, d->relu, stream));
@@ -402,14 +420,19 @@ int las_speller_decode_batch(const las_speller_desc* d, int teacher_forced, int 
         return 16;
     if (opt_get(OPT_SPELLER_PERSIST) == 0 || (!teacher_forced && decode_mode == 2)) return 0;
     constexpr int NB = 32;      // the persistent kernels' utterance limit (two 16-row M tiles)
-    if (d->multi_head > 1) {    // one set of attention workgroups per (utterance, head): 32 / heads utterances per launch, teacher forcing
+    if (d->multi_head > 1) {    // one set of attention workgroups per (utterance, head): 32 / heads utterances per launch at most
         // (a batch of more than two such slices is faster on the per-step kernels, which take all of it at once: heads = 4, B = 32 measured
-        // 17.3 ms per step in four slices against 15.1)
-        const int nb = NB / d->multi_head;
-        if (nb == 0 || d->B > 2 * nb) return 0;
-        const int bb = std::min(nb, d->B);
-        if (teacher_forced) return speller_persist_pre_mh_eligible(bb, d->Tp, d->Hs, d->D, d->M, d->V, d->L, d->multi_head, d->use_mlp) ? nb : 0;
-        return (decode_mode == 1 && speller_persist_pre_mh_greedy_eligible(bb, d->Tp, d->Hs, d->D, d->M, d->V, d->L, d->multi_head, d->use_mlp)) ? nb : 0;
+        // 17.3 ms per step in four slices against 15.1).  Long utterances need more attention workgroups per (utterance, head) — 16 at
+        // T' = 375 — so fewer utterances fit one launch: the slice is halved until the launch is resident (heads = 2, B = 8, T' = 375: two
+        // slices of 4), under the same two-slice rule.
+        for (int nb = NB / d->multi_head; nb >= 1; nb >>= 1) {
+            if (d->B > 2 * nb) break;
+            const int bb = std::min(nb, d->B);
+            const bool ok = teacher_forced ? speller_persist_pre_mh_eligible(bb, d->Tp, d->Hs, d->D, d->M, d->V, d->L, d->multi_head, d->use_mlp)
+                                           : (decode_mode == 1 && speller_persist_pre_mh_greedy_eligible(bb, d->Tp, d->Hs, d->D, d->M, d->V, d->L, d->multi_head, d->use_mlp));
+            if (ok) return nb;
+        }
+        return 0;
     }
     return speller_persist_eligible(NB, d->Tp, d->Hs, d->D, d->M, d->V, d->L, d->multi_head, d->use_mlp, !teacher_forced) ? NB : 0;
 }
@@ -1081,6 +1104,14 @@ int las_speller_bwd(const las_speller_desc* d, const float* feat, const float* k
         LAS_TRY(attention_deferred(d, x, g, stream));
     }
     {   // every remaining weight gradient (K = U*B rows each) in ONE grouped stream-K launch
+        // LAS_FLAG_DEFER_DW: off the critical path (side stream, XCD partition, joined by las_join_deferred) — dfeat above is what the caller waits for
+        hipStream_t main_stream = stream;
+        int xcd_lo = ((flags & LAS_FLAG_DEFER_DW) && !(flags & LAS_FLAG_FORCE_GENERIC) && opt_get(OPT_DEFER_DW) != 0) ? rec_confine_xcds(B, Hs / 2) : 0;
+        bool deferred = false;
+        if (xcd_lo > 0) {
+            if (hipStream_t s = defer_side().begin(main_stream)) { stream = s; deferred = true; } else xcd_lo = 0;
+        }
+        path_note(PATH_DW, deferred ? "deferred" : "inline");
         GemmDesc gs[8];
         int n = 0;
         auto add = [&](const float* A, long lda, const float* Bm, long ldb, float* C, long ldc, int Mv, int Nv, int Kv) {
@@ -1088,7 +1119,7 @@ int las_speller_bwd(const las_speller_desc* d, const float* feat, const float* k
             q.A = A; q.lda = lda; q.a_kc = false; q.B = Bm; q.ldb = ldb; q.b_kc = false; q.C = C; q.ldc = ldc; q.M = Mv; q.N = Nv; q.K = Kv;
             q.c_zeroed = zg;
         };
-        auto flush = [&]() { const int rc = gemm_f32_group(gs, n, stream); n = 0; return rc; };
+        auto flush = [&]() { const int rc = gemm_f32_group(gs, n, stream, xcd_lo); n = 0; return rc; };
         // dW_c = dz^T [h_top | ctx]
         add(dz_all, V, h_top_all, Hs, g->dw_c, Hs + D, V, Hs, UB);
         add(dz_all, V, ctx_all + (size_t)B * D, D, g->dw_c + Hs, Hs + D, V, D, UB);
@@ -1114,6 +1145,7 @@ int las_speller_bwd(const las_speller_desc* d, const float* feat, const float* k
         cj[nj++] = {dz_all, V, UB, V, g->db_c, nullptr};
         for (int l = 0; l < L; ++l) cj[nj++] = {dG_all + (size_t)l * U * 4 * sH, (long)4 * Hs, UB, 4 * Hs, g->db_ih[l], g->db_hh[l]};
         LAS_TRY(colsum_multi(cj, nj, zg, stream));       // every LSTM / character-distribution bias gradient in one launch
+        if (deferred) LAS_TRY(defer_side().end());
     }
     return LAS_OK;
 }

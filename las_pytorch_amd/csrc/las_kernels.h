@@ -38,7 +38,9 @@ int split_planes(const float* src, long ld_src, int R, int C, void* dst, long ld
 inline size_t planes_floats(size_t rows, size_t ld) { return (rows * ld * 6 + 15) / 16 * 4; }      // size of a P8x3 image in floats (16-byte multiple)
 // n independent GEMMs of one operand layout, no bias / activation, outputs pre-zeroed (or accumulated onto): ONE launch, the
 // k-iterations of all problems spread evenly over the resident workgroups.  Falls back to n launches when not groupable.
-int gemm_f32_group(const GemmDesc* ds, int n, hipStream_t stream);
+// xcd_lo > 0: the launch leaves XCDs [0, xcd_lo) alone (their workgroups exit at once; the 128-tile group kernel only): for a group that runs on a
+// side stream beside a chain kernel confined to those XCDs (pblstm_rec_bwd's confine_nx).  Falls back to one launch per problem as before.
+int gemm_f32_group(const GemmDesc* ds, int n, hipStream_t stream, int xcd_lo = 0);
 // LAS_ERR_DEVICE once after a stream-K fix-up wait ran into its spin limit (GEMM workgroups not all resident); clears the report
 int gemm_sk_check();
 // true when gemm_f32 on this stream takes the stream-K fix-up schedule for an M x N output (option on, enough output tiles, scratch there or
@@ -66,9 +68,13 @@ int pblstm_rec_fwd(float* gates, const float* w_hh_f, const float* w_hh_r, float
 //   w_hh_t: (2, H, 4H) transposed recurrent weights (see transpose_w_hh)
 // db_f / db_r (optional, pre-zeroed): (2, 4H) bias gradients [b_ih | b_hh] of each direction, summed inside the persistent
 // kernels; *db_done reports whether that happened (0: the generic kernels ran — the caller column-sums dgates itself).
+// confine_nx in {2, 4}: the one-utterance-per-group kernel keeps to XCDs [0, confine_nx) (grid over-subscribed 8 / confine_nx times, the
+// workgroups dispatched to the other XCDs leave at once): a weight-gradient GEMM group on a side stream then has the other XCDs' CUs
+// AND their L2s to itself.  rec_confine_xcds() says whether / how far a batch can be confined.
 int pblstm_rec_bwd(const float* dout, const float* gates, const float* cbuf, const float* w_hh_t, float* dgates,
                    int B, int T, int H, unsigned long long* xbuf, unsigned* err, int force_generic,
-                   hipStream_t stream, float* db_f = nullptr, float* db_r = nullptr, int* db_done = nullptr);
+                   hipStream_t stream, float* db_f = nullptr, float* db_r = nullptr, int* db_done = nullptr, int confine_nx = 0);
+int rec_confine_xcds(int B, int H);      // 0: the backward recurrence of this batch needs the whole chip (or the device is not 8 x 32 CUs)
 size_t rec_xbuf_bytes(int B, int H);
 // pblstm_rec_mfma.hip: the forward recurrence for batches that fill MFMA tiles (16 utterances per group of H/32 workgroups, bf16
 // matrix pipe with the exact three-way operand split).  pblstm_rec_fwd dispatches to it by itself when eligible.
@@ -158,6 +164,19 @@ struct SideStream {
     int join(hipStream_t main);
 };
 SideStream& side_stream();
+// Deferred weight-gradient work (LAS_FLAG_DEFER_DW): a second library-owned stream per (host thread, device) whose launches are NOT joined
+// before the entry point returns; las_join_deferred makes a stream wait for everything issued there.  begin() records the fork on `main`
+// and returns the side stream (nullptr: unavailable — stream capture, creation failure — do the work on `main`); end() marks the work pending.
+struct DeferSide {
+    hipStream_t s = nullptr; hipEvent_t e_fork = nullptr, e_done = nullptr; bool tried = false, pending = false;
+    hipStream_t begin(hipStream_t main);
+    int end();
+    int join(hipStream_t main);
+};
+DeferSide& defer_side();
+// placement probe (las_debug_xcd_probe): 2 x 1024 words; the XCD-confined recurrence writes XCC id + 1 of block b at [b], the XCD-partitioned
+// GEMM group at [1024 + b] (b < 1024) — to check the round-robin block -> XCD assumption the two launches' SPEED rests on
+unsigned* xcd_probe_ptr();
 // fork() ... join() with every exit path covered: an early return between the two (a failing GEMM, a fall-back) still joins the side
 // stream, so that its fill can never race with whatever the main stream does next with the same slabs
 struct SideJoinGuard {

@@ -40,6 +40,9 @@ enum Opt : int {
     OPT_GEMM_BIG,               // 256 x 256 tiles (gemm_big.hip) where they fill the chip: 1 automatic, 0 never, 2 whenever the shape allows (A/B)
     OPT_SPELLER_PRE_GREEDY,     // free-running (arg-max feedback) decode without a backward pass on the pre-multiplied-context kernel
     OPT_SPELLER_PRE_MH,         // multi-head attention (heads 2..4, teacher forcing) on the pre-multiplied-context kernels
+    OPT_REC_EPOCH_SCRATCH,      // hand-off granules of the register-resident recurrences in the library's persistent, epoch-tagged scratch (no fill per launch); 0: fill the caller's buffer (A/B)
+    OPT_KEYS_SPLITK,            // psi keys GEMM (64 output columns: few tiles) split over K with a separate activation pass (1) or one pass with the activation in its epilogue (0)
+    OPT_DEFER_DW,               // honour LAS_FLAG_DEFER_DW (weight-gradient groups on a side stream beside XCD-confined backward recurrences); 0: inline (A/B)
     OPT_COUNT
 };
 
@@ -71,7 +74,7 @@ int kernel_timer_read(int which, float* ms_out);    // synchronises on the closi
 // Which kernel family a dispatcher actually launched (las_debug_last_path): every dispatcher notes its choice, so that a parity
 // test can assert that a fixture really pinned the kernel it was written for — a silent fall-back to the generic path would otherwise
 // leave every golden green.  Process-wide, most recent launch per slot (a debugging aid, like the trace hooks).
-enum : int { PATH_REC_FWD = 0, PATH_REC_BWD = 1, PATH_DECODE_FWD = 2, PATH_DECODE_BWD = 3, PATH_GEMM = 4, PATH_COUNT = 5 };
+enum : int { PATH_REC_FWD = 0, PATH_REC_BWD = 1, PATH_DECODE_FWD = 2, PATH_DECODE_BWD = 3, PATH_GEMM = 4, PATH_DW = 5, PATH_COUNT = 6 };
 void path_note(int which, const char* name);
 int path_read(int which, char* out, int cap);
 

@@ -21,6 +21,7 @@ const OptDef kDefs[OPT_COUNT] = {
     {"GEMM_SK_FIXUP", 0}, {"GEMM_SKF_MIN_KT", -1}, {"GEMM_SKF_MIN_RUN", -1},
     {"SIDE_FILLS", 0}, {"TRUST_ZEROED_GRADS", 1}, {"SPELLER_BIG", 1}, {"SPELLER_BIG_BWD", 1}, {"SPELLER_BIG_TUNE", 0},
     {"TIME_KERNELS", 0}, {"GEMM_BIG", 1}, {"SPELLER_PRE_GREEDY", 1}, {"SPELLER_PRE_MH", 1},
+    {"REC_EPOCH_SCRATCH", 1}, {"KEYS_SPLITK", 1}, {"DEFER_DW", 1},
 };
 std::atomic<long> g_val[OPT_COUNT];
 std::atomic<int> g_init{0};
@@ -127,6 +128,42 @@ int SideStream::join(hipStream_t main) {
     return LAS_OK;
 }
 
+static std::atomic<unsigned*> g_xcd_probe{nullptr};
+unsigned* xcd_probe_ptr() { return g_xcd_probe.load(std::memory_order_relaxed); }
+DeferSide& defer_side() {
+    thread_local DeferSide tl[16];
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) dev = 0;
+    return tl[dev];
+}
+hipStream_t DeferSide::begin(hipStream_t main) {
+    hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+    if (hipStreamIsCapturing(main, &cap) != hipSuccess || cap != hipStreamCaptureStatusNone) return nullptr;      // a capture keeps everything on one stream
+    if (s == nullptr) {
+        if (tried) return nullptr;
+        tried = true;
+        int lo = 0, hi = 0;      // lowest priority: the critical-path GEMM on the caller's stream wins the CUs both could use
+        if (hipDeviceGetStreamPriorityRange(&lo, &hi) != hipSuccess) { lo = 0; (void)hipGetLastError(); }
+        if (hipStreamCreateWithPriority(&s, hipStreamNonBlocking, lo) != hipSuccess) { s = nullptr; (void)hipGetLastError(); return nullptr; }
+        if (hipEventCreateWithFlags(&e_fork, hipEventDisableTiming) != hipSuccess || hipEventCreateWithFlags(&e_done, hipEventDisableTiming) != hipSuccess) {
+            (void)hipGetLastError(); (void)hipStreamDestroy(s); s = nullptr; return nullptr;
+        }
+    }
+    if (hipEventRecord(e_fork, main) != hipSuccess || hipStreamWaitEvent(s, e_fork, 0) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
+    return s;
+}
+int DeferSide::end() {
+    LAS_HIP_CHECK(hipEventRecord(e_done, s));
+    pending = true;
+    return LAS_OK;
+}
+int DeferSide::join(hipStream_t main) {
+    if (!pending) return LAS_OK;
+    pending = false;
+    LAS_HIP_CHECK(hipStreamWaitEvent(main, e_done, 0));
+    return LAS_OK;
+}
+
 namespace {
 std::mutex g_path_mu;
 char g_path[PATH_COUNT][48] = {};
@@ -169,6 +206,9 @@ int las_set_option(const char* key, int64_t value) {
     opt_set(i, (long)value);
     return LAS_OK;
 }
+
+void las_debug_xcd_probe(unsigned* dev_buf) { g_xcd_probe.store(dev_buf, std::memory_order_relaxed); }
+int las_join_deferred(void* stream) { return defer_side().join((hipStream_t)stream); }
 
 int las_debug_kernel_ms(int which, float* ms_out) { return kernel_timer_read(which, ms_out); }
 int las_debug_last_path(int which, char* out, int cap) { return path_read(which, out, cap); }

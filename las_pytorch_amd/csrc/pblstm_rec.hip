@@ -22,6 +22,7 @@
 #include "options.h"
 #include <stdlib.h>
 #include <algorithm>
+#include <mutex>
 
 namespace las {
 
@@ -68,15 +69,17 @@ constexpr int XID_SLOTS = 32;        // id granules per group (G <= 32)
 
 // Run-time placement check, placement-independent itself: every member publishes its XCC id with the agent-scope
 // protocol and reads all the others'.  Returns true iff all G members of this group run on the same XCD.
+// `tag` marks this launch's ids: 0xC0DE0001 on a buffer the host zeroed, the launch's epoch base on the library's persistent scratch
+// (rec_scratch below), whose slots still hold the ids of earlier launches under THEIR (smaller) bases.
 template <int G>
-__device__ __forceinline__ bool same_xcd_group(u64* idbuf, int member, unsigned* err, int* lds_flag) {
+__device__ __forceinline__ bool same_xcd_group(u64* idbuf, int member, unsigned* err, int* lds_flag, unsigned tag = 0xC0DE0001u) {
     if (G == 1) return true;
     unsigned xcc;
     asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID, 0, 4)" : "=s"(xcc));
     const int tid = threadIdx.x;
     if (tid == 0) {
         *lds_flag = 1;
-        __hip_atomic_store(idbuf + member, ((u64)0xC0DE0001u << 32) | (u64)xcc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(idbuf + member, ((u64)tag << 32) | (u64)xcc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
     __syncthreads();
     if (tid < G) {
@@ -84,11 +87,11 @@ __device__ __forceinline__ bool same_xcd_group(u64* idbuf, int member, unsigned*
         u64 x;
         for (;;) {
             x = __hip_atomic_load(idbuf + tid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            if ((unsigned)(x >> 32) == 0xC0DE0001u) break;
+            if ((unsigned)(x >> 32) == tag) break;
             if (++spins > SPIN_LIMIT && spins > __hip_atomic_load(err + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) { atomicExch(err, 0xDEAD0002u); break; }
             __builtin_amdgcn_s_sleep(2);
         }
-        if ((unsigned)x != xcc || (unsigned)(x >> 32) != 0xC0DE0001u) *lds_flag = 0;
+        if ((unsigned)x != xcc || (unsigned)(x >> 32) != tag) *lds_flag = 0;
     }
     __syncthreads();
     return *lds_flag != 0;
@@ -138,7 +141,9 @@ template <int H, int UW, bool STASH>
 __global__ __launch_bounds__(UW * (H / 16)) void rec_fwd_fast(float* __restrict__ gates, const float* __restrict__ w_hh_f,
                                                               const float* __restrict__ w_hh_r, float* __restrict__ out,
                                                               float* __restrict__ cbuf, float* __restrict__ hprev, int B,
-                                                              int T, u64* xbuf, unsigned* err, int force_agent) {
+                                                              int T, u64* xbuf, unsigned* err, int force_agent, unsigned ebase) {
+    // ebase: epoch base of this launch's hand-off granules (0: the host zeroed xbuf; else xbuf is the library's persistent scratch, whose
+    // stale granules all carry smaller epochs — no fill between launches, see rec_scratch)
     constexpr int LPU = H / 16;             // lanes cooperating on one hidden unit (16 k-values each)
     constexpr int NT = UW * LPU;            // threads: UW hidden units owned by this workgroup
     constexpr int G = H / UW;               // workgroups per (utterance, direction)
@@ -151,7 +156,7 @@ __global__ __launch_bounds__(UW * (H / 16)) void rec_fwd_fast(float* __restrict_
 
     int group, member;
     decode_block<G>(2 * B, group, member);
-    const bool l2x = !force_agent && same_xcd_group<G>(xbuf + (long)2 * B * 2 * H + (long)group * XID_SLOTS, member, err, &xcd_flag);
+    const bool l2x = !force_agent && same_xcd_group<G>(xbuf + (long)2 * B * 2 * H + (long)group * XID_SLOTS, member, err, &xcd_flag, ebase ? ebase : 0xC0DE0001u);
     const int dir = group & 1, b = group >> 1;
     const float* __restrict__ w_hh = dir ? w_hh_r : w_hh_f;
     const int tid = threadIdx.x;
@@ -191,7 +196,7 @@ __global__ __launch_bounds__(UW * (H / 16)) void rec_fwd_fast(float* __restrict_
     int cur = 0;
     for (int step = 0; step < T; ++step) {
         const int t = dir ? T - 1 - step : step;
-        const unsigned epoch = (unsigned)step + 1u;
+        const unsigned epoch = ebase + (unsigned)step + 1u;
         REC_STAMP(0, step, 0); REC_STAMP(512, step, 0);
         float nxt[4] = {0.f, 0.f, 0.f, 0.f};
         if (cell && step + 1 < T) {
@@ -273,7 +278,7 @@ __global__ __launch_bounds__(UW * (H / 16)) void rec_fwd_multi(float* __restrict
                                                                const float* __restrict__ w_hh_r, float* __restrict__ out,
                                                                float* __restrict__ cbuf, float* __restrict__ hprev, int B,
                                                                int T, u64* xbuf, unsigned* err, int force_agent, int b0,
-                                                               int Bc) {
+                                                               int Bc, unsigned ebase) {
     // b0 / Bc: this launch steps utterances [b0, b0 + Bc) of the B in the buffers (host-side chunking of very large batches)
     constexpr int LPU = H / 16;
     constexpr int NT = UW * LPU;
@@ -289,7 +294,7 @@ __global__ __launch_bounds__(UW * (H / 16)) void rec_fwd_multi(float* __restrict
     const int nblk = (Bc + NB - 1) / NB;        // utterance blocks per direction
     int group, member;
     decode_block<G>(2 * nblk, group, member);
-    const bool l2x = !force_agent && same_xcd_group<G>(xbuf + (long)2 * nblk * 2 * NB * H + (long)group * XID_SLOTS, member, err, &xcd_flag);
+    const bool l2x = !force_agent && same_xcd_group<G>(xbuf + (long)2 * nblk * 2 * NB * H + (long)group * XID_SLOTS, member, err, &xcd_flag, ebase ? ebase : 0xC0DE0001u);
     const int dir = group & 1, blk = group >> 1;
     const float* __restrict__ w_hh = dir ? w_hh_r : w_hh_f;
     const int tid = threadIdx.x;
@@ -388,7 +393,7 @@ __global__ __launch_bounds__(UW * (H / 16)) void rec_fwd_multi(float* __restrict
         lds_barrier();
         for (int step = 0; step < T; ++step) {
             const int t = dir ? T - 1 - step : step;
-            const unsigned epoch = (unsigned)step + 1u;
+            const unsigned epoch = ebase + (unsigned)step + 1u;
             // phase 1: cells of the first half | mat-vecs of the second half | foreign h of the first half
             if (cell && cu < NBH) cellstep(step, t, epoch);
             matvec(NBH, cur);
@@ -405,7 +410,7 @@ __global__ __launch_bounds__(UW * (H / 16)) void rec_fwd_multi(float* __restrict
     }
     for (int step = 0; step < T; ++step) {
         const int t = dir ? T - 1 - step : step;
-        const unsigned epoch = (unsigned)step + 1u;
+        const unsigned epoch = ebase + (unsigned)step + 1u;
         REC_STAMP(0, step, 0); REC_STAMP(512, step, 0);
         float nxt[4] = {0.f, 0.f, 0.f, 0.f};
         if (cell && step + 1 < T) {
@@ -535,7 +540,10 @@ template <int H>
 __global__ __launch_bounds__(REC_THREADS) void rec_bwd_fast(const float* __restrict__ dout, const float* __restrict__ gates,
                                                             const float* __restrict__ cbuf, const float* __restrict__ w_hh_t,
                                                             float* __restrict__ dgates, int B, int T, u64* xbuf,
-                                                            unsigned* err, float* __restrict__ db_f, float* __restrict__ db_r) {
+                                                            unsigned* err, float* __restrict__ db_f, float* __restrict__ db_r, unsigned ebase,
+                                                            int nx, unsigned* probe) {
+    // nx in {2, 4}: XCD-confined launch — the grid is over-subscribed 8 / nx times and only the workgroups that round-robin dispatch puts on
+    // XCDs [0, nx) take part (the placement check below still decides which hand-off protocol is safe); 0: the whole chip
     // db_f / db_r (optional): 2 x (4H) bias gradients per direction [b_ih | b_hh], pre-zeroed by the caller: the threads
     // that copy this workgroup's dG rows to memory also sum them over time and add the totals once at the end
     // (replaces a column-sum kernel over the (B*T, 4H) gate gradients per direction).
@@ -556,8 +564,22 @@ __global__ __launch_bounds__(REC_THREADS) void rec_bwd_fast(const float* __restr
     __shared__ int xcd_flag;
 
     int group, member;
-    decode_block<G>(2 * B, group, member);
-    const bool l2x = same_xcd_group<G>(xbuf + (long)2 * B * 2 * H + (long)group * XID_SLOTS, member, err, &xcd_flag);
+    if (nx > 0) {
+        // Which XCD a block lands on is (blockIdx + c) % 8 with a queue-history-dependent rotation c (measured: tools/xcd_probe.py), so the
+        // workgroups that take part are chosen by their ACTUAL XCC id — the ones on XCDs [0, nx), which the partitioned GEMM group avoids by the
+        // same test — and numbered within their XCD by blockIdx / 8 (one residue class of blockIdx per XCD).  Should the dispatcher ever place
+        // blocks differently, a role is missing and the bounded hand-off spins report it through the error word (never a wrong result).
+        unsigned xcc;
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID, 0, 4)" : "=s"(xcc));
+        const int xcd = (int)xcc, q = (int)(blockIdx.x >> 3);
+        if (probe && threadIdx.x == 0 && blockIdx.x < 1024) probe[blockIdx.x] = xcc + 1;
+        if (xcd >= nx) return;                       // (whole workgroup, before any barrier)
+        member = q % G;
+        group = (q / G) * nx + xcd;
+    } else {
+        decode_block<G>(2 * B, group, member);
+    }
+    const bool l2x = same_xcd_group<G>(xbuf + (long)2 * B * 2 * H + (long)group * XID_SLOTS, member, err, &xcd_flag, ebase ? ebase : 0xC0DE0001u);
     const int dir = group & 1, b = group >> 1;
     const int tid = threadIdx.x;
     const int rc = tid % LPU, kl = tid / LPU;
@@ -643,7 +665,7 @@ __global__ __launch_bounds__(REC_THREADS) void rec_bwd_fast(const float* __restr
         if (rc == 0) {
             if (G > 1) {
                 u64* gp64 = xg + (step & 1) * H + k;
-                if (l2x) publish_granule_l2(gp64, (unsigned)step + 1u, acc); else publish_granule(gp64, (unsigned)step + 1u, acc);
+                if (l2x) publish_granule_l2(gp64, ebase + (unsigned)step + 1u, acc); else publish_granule(gp64, ebase + (unsigned)step + 1u, acc);
             }
             dhs[cur ^ 1][k] = acc;
         }
@@ -666,7 +688,7 @@ __global__ __launch_bounds__(REC_THREADS) void rec_bwd_fast(const float* __restr
         if (G > 1) {
             const int u = tid - PB;
             if (tid >= PB && u < H && u / UW != member)
-                dhs[cur ^ 1][u] = poll_granule(xg + (step & 1) * H + u, (unsigned)step + 1u, err);
+                dhs[cur ^ 1][u] = poll_granule(xg + (step & 1) * H + u, ebase + (unsigned)step + 1u, err);
         }
         REC_STAMP(0, step, 4); REC_STAMP(512, step, 4);
         lds_barrier();
@@ -699,7 +721,7 @@ __global__ __launch_bounds__(REC_THREADS) void rec_bwd_multi(const float* __rest
                                                              const float* __restrict__ cbuf, const float* __restrict__ w_hh_t,
                                                              float* __restrict__ dgates, int B, int T, u64* xbuf,
                                                              unsigned* err, int b0, int Bc, float* __restrict__ db_f,
-                                                             float* __restrict__ db_r) {
+                                                             float* __restrict__ db_r, unsigned ebase) {
     constexpr int LPU = H / 16;
     constexpr int UW = REC_THREADS / LPU;
     constexpr int G = H / UW;
@@ -713,7 +735,7 @@ __global__ __launch_bounds__(REC_THREADS) void rec_bwd_multi(const float* __rest
     const int nblk = (Bc + NB - 1) / NB;
     int group, member;
     decode_block<G>(2 * nblk, group, member);
-    const bool l2x = same_xcd_group<G>(xbuf + (long)2 * nblk * 2 * NB * H + (long)group * XID_SLOTS, member, err, &xcd_flag);
+    const bool l2x = same_xcd_group<G>(xbuf + (long)2 * nblk * 2 * NB * H + (long)group * XID_SLOTS, member, err, &xcd_flag, ebase ? ebase : 0xC0DE0001u);
     const int dir = group & 1, blk = group >> 1;
     const int tid = threadIdx.x;
     const int rc = tid % LPU, kl = tid / LPU;
@@ -769,7 +791,7 @@ __global__ __launch_bounds__(REC_THREADS) void rec_bwd_multi(const float* __rest
     int cur = 0;
     for (int step = 0; step < T; ++step) {
         const int t = dir ? step : T - 1 - step;
-        const unsigned epoch = (unsigned)step + 1u;
+        const unsigned epoch = ebase + (unsigned)step + 1u;
 #pragma unroll
         for (int q = 0; q < CI; ++q) {
             const int it = tid + q * REC_THREADS;
@@ -913,6 +935,53 @@ size_t rec_xbuf_bytes(int B, int H) {
     return std::max(base, rec_mfma_xbuf_extra_bytes(B, H));
 }
 
+// ---- hand-off scratch of the register-resident recurrences: one per (device, stream), created on first use ------------------------------
+// The granules between the CUs of a group carry {epoch, value}; a poller waits for EXACTLY its step's epoch.  On a buffer the caller owns
+// (torch.empty: arbitrary contents) every launch needed a fill first — six 5-us launches per training step.  The library's own scratch is
+// zeroed once, when it is created, and every launch draws a fresh, monotonically increasing epoch range [base, base + T]: everything an
+// earlier launch left behind carries a smaller epoch and can never match.  Kernels of one stream run in order, so one scratch per stream is
+// race-free.  No scratch during stream capture (a replayed graph would re-use its epoch range), on allocation failure, or beyond
+// RS_MAX streams: those launches fill the caller's buffer as before (ebase = 0).  Wrap-around (2^32 epochs: ~10^6 training steps) re-zeroes.
+struct RecScratch { int dev; hipStream_t stream; u64* buf; size_t bytes; unsigned next; };
+constexpr int RS_MAX = 16;
+static std::mutex g_rs_mu;
+static RecScratch g_rs[RS_MAX];
+static int g_rs_n = 0;
+
+static u64* rec_scratch(size_t bytes, unsigned epochs, hipStream_t stream, unsigned* ebase) {
+    *ebase = 0;
+    if (opt_get(OPT_REC_EPOCH_SCRATCH) == 0) return nullptr;
+    hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+    if (hipStreamIsCapturing(stream, &cap) != hipSuccess || cap != hipStreamCaptureStatusNone) return nullptr;
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return nullptr;
+    std::lock_guard<std::mutex> lk(g_rs_mu);
+    RecScratch* r = nullptr;
+    for (int i = 0; i < g_rs_n; ++i)
+        if (g_rs[i].dev == dev && g_rs[i].stream == stream) { r = &g_rs[i]; break; }
+    if (r == nullptr) {
+        if (g_rs_n >= RS_MAX) return nullptr;
+        r = &g_rs[g_rs_n];
+        *r = RecScratch{dev, stream, nullptr, 0, 1u};
+        ++g_rs_n;
+    }
+    if (r->bytes < bytes) {      // (re)allocate: rare (first use, a larger batch); hipFree waits for the stream's earlier launches
+        u64* nb = nullptr;
+        const size_t want = std::max(bytes, (size_t)1 << 20);
+        if (hipMalloc(&nb, want) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
+        if (hipMemsetAsync(nb, 0, want, stream) != hipSuccess) { (void)hipGetLastError(); (void)hipFree(nb); return nullptr; }
+        if (r->buf) (void)hipFree(r->buf);
+        r->buf = nb; r->bytes = want; r->next = 1u;
+    }
+    if (r->next > 0xFFFF0000u - epochs - 2u) {
+        if (hipMemsetAsync(r->buf, 0, r->bytes, stream) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
+        r->next = 1u;
+    }
+    *ebase = r->next;
+    r->next += epochs + 2u;
+    return r->buf;
+}
+
 static bool fast_h(int H) { return H == 128 || H == 256 || H == 512; }
 
 static int device_cus() {
@@ -963,7 +1032,12 @@ int pblstm_rec_fwd(float* gates, const float* w_hh_f, const float* w_hh_r, float
         for (int b0 = 0; b0 < B; b0 += plan.chunk) {
             const int Bc = std::min(plan.chunk, B - b0);
             const int nblk = (Bc + plan.nb - 1) / plan.nb;
-            LAS_HIP_CHECK(hipMemsetAsync(xbuf, 0, rec_xbuf_bytes(B, H), stream));
+            unsigned ebase = 0;
+            u64* xb = G > 1 ? rec_scratch(rec_xbuf_bytes(B, H), (unsigned)T, stream, &ebase) : nullptr;
+            if (xb == nullptr) {
+                xb = xbuf; ebase = 0;
+                if (G > 1) LAS_HIP_CHECK(hipMemsetAsync(xbuf, 0, rec_xbuf_bytes(B, H), stream));      // (G == 1: nothing is handed between CUs)
+            }
             dim3 grid(2 * nblk * G), block(uw * (H / 16));
             bool launched = false;
 #define TRY_FWD(HH, UWV)                                                                                                  \
@@ -973,9 +1047,9 @@ int pblstm_rec_fwd(float* gates, const float* w_hh_f, const float* w_hh_r, float
         fits = persistent_launch_fits(rec_fwd_fast<HH, UWV, true>, block.x, 0, grid.x);                                   \
         if (!fits) break;                                                                                                 \
         if (stash) hipLaunchKernelGGL((rec_fwd_fast<HH, UWV, true>), grid, block, 0, stream, gates, w_hh_f, w_hh_r, out,  \
-                                      cbuf, hprev, B, T, xbuf, err, dbg);                                                 \
+                                      cbuf, hprev, B, T, xb, err, dbg, ebase);                                            \
         else hipLaunchKernelGGL((rec_fwd_fast<HH, UWV, false>), grid, block, 0, stream, gates, w_hh_f, w_hh_r, out, cbuf, \
-                                hprev, B, T, xbuf, err, dbg);                                                             \
+                                hprev, B, T, xb, err, dbg, ebase);                                                        \
     }
 #define TRY_FWD_M(HH, UWV, NBV)                                                                                           \
     if (!launched && plan.nb == NBV && H == HH && uw == UWV) {                                                           \
@@ -985,16 +1059,16 @@ int pblstm_rec_fwd(float* gates, const float* w_hh_f, const float* w_hh_r, float
             fits = persistent_launch_fits(rec_fwd_multi<HH, UWV, NBV, true, PP>, block.x, 0, grid.x);                     \
             if (!fits) break;                                                                                             \
             if (stash) hipLaunchKernelGGL((rec_fwd_multi<HH, UWV, NBV, true, PP>), grid, block, 0, stream, gates, w_hh_f, \
-                                          w_hh_r, out, cbuf, hprev, B, T, xbuf, err, dbg, b0, Bc);                        \
+                                          w_hh_r, out, cbuf, hprev, B, T, xb, err, dbg, b0, Bc, ebase);                   \
             else hipLaunchKernelGGL((rec_fwd_multi<HH, UWV, NBV, false, PP>), grid, block, 0, stream, gates, w_hh_f,      \
-                                    w_hh_r, out, cbuf, hprev, B, T, xbuf, err, dbg, b0, Bc);                              \
+                                    w_hh_r, out, cbuf, hprev, B, T, xb, err, dbg, b0, Bc, ebase);                         \
         } else {                                                                                                          \
             fits = persistent_launch_fits(rec_fwd_multi<HH, UWV, NBV, true>, block.x, 0, grid.x);                         \
             if (!fits) break;                                                                                             \
             if (stash) hipLaunchKernelGGL((rec_fwd_multi<HH, UWV, NBV, true>), grid, block, 0, stream, gates, w_hh_f,     \
-                                          w_hh_r, out, cbuf, hprev, B, T, xbuf, err, dbg, b0, Bc);                        \
+                                          w_hh_r, out, cbuf, hprev, B, T, xb, err, dbg, b0, Bc, ebase);                   \
             else hipLaunchKernelGGL((rec_fwd_multi<HH, UWV, NBV, false>), grid, block, 0, stream, gates, w_hh_f, w_hh_r,  \
-                                    out, cbuf, hprev, B, T, xbuf, err, dbg, b0, Bc);                                      \
+                                    out, cbuf, hprev, B, T, xb, err, dbg, b0, Bc, ebase);                                 \
         }                                                                                                                 \
     }
             TRY_FWD(128, 128) TRY_FWD(128, 64) TRY_FWD(128, 32) TRY_FWD(128, 16)
@@ -1024,19 +1098,32 @@ int pblstm_rec_fwd(float* gates, const float* w_hh_f, const float* w_hh_r, float
 
 template <int H, int NB>
 static int launch_bwd_multi(const float* dout, const float* gates, const float* cbuf, const float* w_hh_t, float* dgates, int B, int T,
-                            u64* xbuf, unsigned* err, int b0, int Bc, int grid, float* db_f, float* db_r, hipStream_t stream) {
+                            u64* xbuf, unsigned* err, int b0, int Bc, int grid, float* db_f, float* db_r, hipStream_t stream, unsigned ebase) {
     const size_t smem = sizeof(float) * ((size_t)2 * NB * H + (size_t)NB * 4 * H);
     LAS_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&rec_bwd_multi<H, NB>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
     if (!persistent_launch_fits(rec_bwd_multi<H, NB>, REC_THREADS, smem, grid)) return fail(LAS_ERR_UNSUPPORTED, "backward recurrence: %s%ld workgroups cannot all be resident", "", (long)grid);
     hipLaunchKernelGGL((rec_bwd_multi<H, NB>), dim3(grid), dim3(REC_THREADS), smem, stream, dout, gates, cbuf, w_hh_t, dgates, B, T, xbuf,
-                       err, b0, Bc, db_f, db_r);
+                       err, b0, Bc, db_f, db_r, ebase);
     LAS_LAUNCH_CHECK();
     return LAS_OK;
 }
 
+// XCDs the one-utterance-per-group backward recurrence of this batch can be confined to (2 or 4 of the 8; 0: not at all): a device of
+// 8 XCDs x 32 CUs, G > 1 workgroups per group, whole groups per XCD, at most one workgroup per CU
+int rec_confine_xcds(int B, int H) {
+    if (!fast_h(H) || device_cus() != 256) return 0;
+    const int G = H * H / 16384;
+    if (G < 2) return 0;
+    // (2 XCDs only: measured, tools/ab_step_option.py DEFER_DW — at 4 of 8 XCDs (B = 16 at H = 256) the deferred groups slow the critical-path
+    // launches around the short recurrences more than they save: 5.23 against 5.19 ms per step)
+    for (int nx = 2; nx <= 2; nx *= 2)
+        if ((2 * B) % nx == 0 && 2 * B * G <= 32 * nx) return nx;
+    return 0;
+}
+
 int pblstm_rec_bwd(const float* dout, const float* gates, const float* cbuf, const float* w_hh_t, float* dgates, int B,
                    int T, int H, u64* xbuf, unsigned* err, int force_generic, hipStream_t stream, float* db_f, float* db_r,
-                   int* db_done) {
+                   int* db_done, int confine_nx) {
     LAS_REQUIRE(B > 0 && T > 0 && H > 0, "rec dims");
     if (db_done) *db_done = 0;
     if (!force_generic && err && xbuf && rec_bwd_mfma_eligible(B, H)) {      // large batches: 16 utterances per group on the matrix pipe
@@ -1060,24 +1147,31 @@ int pblstm_rec_bwd(const float* dout, const float* gates, const float* cbuf, con
         for (int b0 = 0; b0 < B && fits; b0 += plan.chunk) {
             const int Bc = std::min(plan.chunk, B - b0);
             const int nblk = (Bc + plan.nb - 1) / plan.nb;
-            const int grid = 2 * nblk * G;
-            if (G > 1) LAS_HIP_CHECK(hipMemsetAsync(xbuf, 0, rec_xbuf_bytes(B, H), stream));
+            int grid = 2 * nblk * G;
+            const int nx = (plan.nb == 1 && confine_nx > 0 && confine_nx == rec_confine_xcds(B, H)) ? confine_nx : 0;
+            if (nx > 0) grid = grid * 8 / nx;
+            unsigned ebase = 0;
+            u64* xb = G > 1 ? rec_scratch(rec_xbuf_bytes(B, H), (unsigned)T, stream, &ebase) : nullptr;
+            if (xb == nullptr) {
+                xb = xbuf; ebase = 0;
+                if (G > 1) LAS_HIP_CHECK(hipMemsetAsync(xbuf, 0, rec_xbuf_bytes(B, H), stream));
+            }
             if (plan.nb == 1) {
                 if (b0 != 0 || Bc != B) return fail(LAS_ERR_UNSUPPORTED, "chunked launch needs the multi kernel%s", "");
                 fits = H == 128 ? persistent_launch_fits(rec_bwd_fast<128>, REC_THREADS, 0, grid)
                      : H == 256 ? persistent_launch_fits(rec_bwd_fast<256>, REC_THREADS, 0, grid)
                                 : persistent_launch_fits(rec_bwd_fast<512>, REC_THREADS, 0, grid);
                 if (!fits) break;
-                if (H == 128) hipLaunchKernelGGL((rec_bwd_fast<128>), dim3(grid), dim3(REC_THREADS), 0, stream, dout, gates, cbuf, w_hh_t, dgates, B, T, xbuf, err, db_f, db_r);
-                else if (H == 256) hipLaunchKernelGGL((rec_bwd_fast<256>), dim3(grid), dim3(REC_THREADS), 0, stream, dout, gates, cbuf, w_hh_t, dgates, B, T, xbuf, err, db_f, db_r);
-                else hipLaunchKernelGGL((rec_bwd_fast<512>), dim3(grid), dim3(REC_THREADS), 0, stream, dout, gates, cbuf, w_hh_t, dgates, B, T, xbuf, err, db_f, db_r);
+                if (H == 128) hipLaunchKernelGGL((rec_bwd_fast<128>), dim3(grid), dim3(REC_THREADS), 0, stream, dout, gates, cbuf, w_hh_t, dgates, B, T, xb, err, db_f, db_r, ebase, nx, nx > 0 ? xcd_probe_ptr() : nullptr);
+                else if (H == 256) hipLaunchKernelGGL((rec_bwd_fast<256>), dim3(grid), dim3(REC_THREADS), 0, stream, dout, gates, cbuf, w_hh_t, dgates, B, T, xb, err, db_f, db_r, ebase, nx, nx > 0 ? xcd_probe_ptr() : nullptr);
+                else hipLaunchKernelGGL((rec_bwd_fast<512>), dim3(grid), dim3(REC_THREADS), 0, stream, dout, gates, cbuf, w_hh_t, dgates, B, T, xb, err, db_f, db_r, ebase, nx, nx > 0 ? xcd_probe_ptr() : nullptr);
                 LAS_LAUNCH_CHECK();
                 path_note(PATH_REC_BWD, "rec_bwd_fast");
                 if (db_done && db_f && db_r) *db_done = 1;
                 continue;
             }
 #define TRY_BWD_M(HH, NBV) if (H == HH && plan.nb == NBV) {                                                                          \
-        const int rc = launch_bwd_multi<HH, NBV>(dout, gates, cbuf, w_hh_t, dgates, B, T, xbuf, err, b0, Bc, grid, db_f, db_r, stream); \
+        const int rc = launch_bwd_multi<HH, NBV>(dout, gates, cbuf, w_hh_t, dgates, B, T, xb, err, b0, Bc, grid, db_f, db_r, stream, ebase); \
         if (rc == LAS_ERR_UNSUPPORTED) { fits = false; break; }                                                                       \
         LAS_TRY(rc); path_note(PATH_REC_BWD, "rec_bwd_multi"); if (db_done && db_f && db_r) *db_done = 1; continue; }
             TRY_BWD_M(128, 2) TRY_BWD_M(128, 4) TRY_BWD_M(128, 8)

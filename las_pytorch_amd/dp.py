@@ -50,6 +50,36 @@ class FlatGradAllReducer:
             elif hasattr(p, "_las_direct_base"):
                 del p._las_direct_base
         module._las_flat_reducer = self      # solver.batch_iterator picks it up (zero / all-reduce / clip on the flat buffer)
+        # Deferred weight gradients (LAS_FLAG_DEFER_DW, direct writes only): inside ``with reducer.deferring():`` the backward entry points may
+        # leave their weight-gradient GEMM groups running on the library's side stream — hidden under the next layer's recurrence where the
+        # batch leaves XCDs free (B <= 16 at paper size) — and ``join_deferred()`` (called by every consumer of the flat buffer here, and at
+        # the end of the block) makes the current stream wait for them.  The tensors those GEMMs read are kept alive until then.
+        self._defer_active = False
+        self._deferred_keep = []
+
+    def deferring(self):
+        """Context manager around forward + backward of one step: see ``_defer_active`` above.  Only callers that reach the gradients through
+        this object (``allreduce_mean`` / ``clip_`` / ``FusedClipAdam``) or after the block may use it."""
+        red = self
+
+        class _Ctx:
+            def __enter__(self_inner):
+                red._defer_active = bool(red.direct and red.flat.is_cuda)
+                return red
+
+            def __exit__(self_inner, *exc):
+                red._defer_active = False
+                red.join_deferred()
+                return False
+        return _Ctx()
+
+    def join_deferred(self):
+        """The current stream waits for the deferred weight-gradient work of this step (no-op when there is none)."""
+        if self._deferred_keep:
+            from . import _cabi
+            with torch.cuda.device(self.flat.device):
+                _cabi.check(_cabi.lib().las_join_deferred(_cabi.stream_ptr()))
+            self._deferred_keep.clear()
 
     def zero(self):
         """Use instead of ``optimizer.zero_grad()`` (which would drop the views with set_to_none=True).
@@ -57,6 +87,7 @@ class FlatGradAllReducer:
         HIP-graph note: the backward entry points skip their own fill of a gradient block this call zeroed (``LAS_FLAG_GRADS_ZEROED``), a
         host-side decision that a stream capture bakes into the graph.  The flag is therefore claimed during a capture only when this
         ``zero()`` was recorded in the same capture (``zero_in_capture``) — every replay then zeroes before it skips."""
+        self.join_deferred()
         self.flat_ext.zero_()
         self.zero_epoch += 1
         self.zero_in_capture = bool(self.flat.is_cuda and torch.cuda.is_current_stream_capturing())
@@ -86,6 +117,7 @@ class FlatGradAllReducer:
         """Every ``p.grad`` must still be its view of the flat buffer: ``optimizer.zero_grad()`` with torch's default
         ``set_to_none=True`` silently replaces them, after which the collective would reduce a buffer of zeros while
         the optimizer steps on unsynchronised local gradients.  Fail loudly instead."""
+        self.join_deferred()              # every consumer of the flat gradient comes through here first
         base = self.flat.untyped_storage().data_ptr()
         for p in self.params:
             if p.grad is None or p.grad.untyped_storage().data_ptr() != base:
@@ -110,6 +142,7 @@ class FlatGradAllReducer:
 
     def clip_(self, max_norm=1.0):
         """clip_grad_norm_(params, max_norm) on the flat buffer (solver/solver.py:96), same formula as torch's."""
+        self.join_deferred()
         total = torch.linalg.vector_norm(self.flat)
         coef = torch.clamp(max_norm / (total + 1e-6), max=1.0)
         self.flat.mul_(coef)

@@ -23,7 +23,8 @@ import torch
 import torch.nn as nn
 
 from .. import _cabi
-from .._cabi import FLAG_FORCE_GENERIC, FLAG_GRADS_ZEROED, FLAG_STASH, FLAG_TEACHER_FORCED, SpellerDesc, SpellerGrads, check, lib, ptr, stream_ptr
+from .._cabi import (FLAG_DEFER_DW, FLAG_FORCE_GENERIC, FLAG_GRADS_ZEROED, FLAG_STASH, FLAG_TEACHER_FORCED, SpellerDesc, SpellerGrads, check, lib,
+                     ptr, stream_ptr)
 
 def set_force_generic(module, flag=True):
     """A/B switch for tests and profiling: every pBLSTM layer / Speller under ``module`` uses the generic kernels
@@ -70,6 +71,17 @@ def _claim_prezeroed(params):
         if owner is not None:
             p._las_written_epoch = owner.zero_epoch
     return ok
+
+
+def _defer_owner(direct_params):
+    """The flat-gradient reducer that owns these direct-write parameters, when the caller opened ``reducer.deferring()`` (the weight-gradient
+    GEMM group of this backward call may then stay on the library's side stream: LAS_FLAG_DEFER_DW); None otherwise."""
+    if not direct_params:
+        return None
+    owner = getattr(direct_params[0], "_las_direct_owner", None)
+    if owner is None or not getattr(owner, "_defer_active", False) or torch.cuda.is_current_stream_capturing():
+        return None
+    return owner
 
 
 def _flags(stash, force_generic=False):
@@ -158,9 +170,12 @@ class _PBLSTMFn(torch.autograd.Function):
                            torch.empty(4 * H, device=dev), torch.empty_like(w_ih_r), torch.empty_like(w_hh_r),
                            torch.empty(4 * H, device=dev), torch.empty(4 * H, device=dev)]
         zeroed = FLAG_GRADS_ZEROED if (ctx.direct and _claim_prezeroed(ctx.direct_params)) else 0
+        owner = _defer_owner(ctx.direct_params) if ctx.direct else None
         check(L.las_pblstm_bwd(ptr(x), ptr(dout), B, T_in, D_in, H, ptr(w_ih_f), ptr(w_hh_f), ptr(w_ih_r), ptr(w_hh_r),
                                ptr(reserve), ptr(work), ptr(dx), *[ptr(t) for t in g], ptr(_cabi.err_word(dev)),
-                               ctx.flags | zeroed, stream_ptr()))
+                               ctx.flags | zeroed | (FLAG_DEFER_DW if owner is not None else 0), stream_ptr()))
+        if owner is not None:      # what the deferred GEMM group reads must outlive this call (autograd frees the saved tensors on return)
+            owner._deferred_keep.append((x, dout, reserve, work))
         return (None, dx, *([None] * 8 if ctx.direct else g))
 
 
@@ -518,10 +533,13 @@ class _SpellerFn(torch.autograd.Function):
         work = torch.empty(Lh.las_speller_bwd_workspace_floats(d, U), device=dev, dtype=torch.float32)
         mode0 = int((not teacher_forced) and decode_mode == 0)
         zeroed = FLAG_GRADS_ZEROED if (ctx.direct and _claim_prezeroed(ctx.direct_params)) else 0
+        owner = _defer_owner(ctx.direct_params) if ctx.direct else None
         check(Lh.las_speller_bwd(d, ptr(feat), ptr(keys), ptr(logp), ptr(att), ptr(dlogp), U, mode0, ptr(reserve),
                                  ptr(work), g, ptr(_cabi.err_word(dev)),
-                                 _flags(True, force_generic) | (FLAG_TEACHER_FORCED if (teacher_forced or decode_mode == 1) else 0) | zeroed,
-                                 stream_ptr()))
+                                 _flags(True, force_generic) | (FLAG_TEACHER_FORCED if (teacher_forced or decode_mode == 1) else 0) | zeroed |
+                                 (FLAG_DEFER_DW if owner is not None else 0), stream_ptr()))
+        if owner is not None:
+            owner._deferred_keep.append((feat, keys, logp, att, dlogp, reserve, work))
         return (None, dfeat, None, None, *([None] * len(grads) if ctx.direct else grads))
 
 

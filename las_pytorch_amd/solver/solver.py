@@ -259,13 +259,21 @@ def batch_iterator(batch_data, batch_label, las_model, optimizer, tf_rate, is_tr
         if not (reducer is not None and reducer._collective()):
             packed = _cabi.step_readback(logp.device, logp.shape[0])
         ler = LetterErrorRate_device(logp, batch_label, out=None if packed is None else packed[1])
-        loss = label_smoothing_loss_backward_device(logp, batch_label, label_smoothing, loss_out=None if packed is None else packed[0])
+        if reducer is not None:      # (weight-gradient GEMM groups may run beside the next layer's recurrence: dp.FlatGradAllReducer.deferring)
+            with reducer.deferring():
+                loss = label_smoothing_loss_backward_device(logp, batch_label, label_smoothing, loss_out=None if packed is None else packed[0])
+        else:
+            loss = label_smoothing_loss_backward_device(logp, batch_label, label_smoothing, loss_out=None if packed is None else packed[0])
     else:
         loss, ler = _loss_and_ler(logp, batch_label, steps, smoothed, label_smoothing)
 
     if is_training:
         if not fused_bwd:
-            loss.backward()
+            if reducer is not None:
+                with reducer.deferring():
+                    loss.backward()
+            else:
+                loss.backward()
         if grad_hook is not None:
             grad_hook(las_model)
         if reducer is not None:
@@ -316,6 +324,10 @@ def batch_iterator(batch_data, batch_label, las_model, optimizer, tf_rate, is_tr
             from ..model.las_model import set_force_generic
             warnings.warn(f"liblas_hip: persistent-kernel hand-off timeout ({failed or 'reported by a peer rank'}); re-running this "
                           "step once on the generic kernels (another kernel was resident on the GPU?)")
+            if is_training and reducer is not None and reducer.direct:
+                # (the XCD-confined recurrences number their workgroups by the XCC id they find themselves on: should a dispatcher ever place
+                # blocks differently, a role is missing and the spin timeout lands here — leave that mode for the rest of the process)
+                _cabi.set_option("DEFER_DW", 0)
             if fused and is_training:
                 optimizer.rollback_step()
             if coin_state is not None:

@@ -61,7 +61,10 @@ def expected_paths(info):
 #   S (T' = 750, Hs 256): keys 192 KB > 160 KB of LDS: the teacher-forced forward splits them by frames over the 16 workgroups of an utterance,
 #       which exchange their energies every step (persist_pre, round 5; per-step kernels until then); free-running decode likewise; the
 #       backward is the PRE kernel too (its attention role tiles T' over 16 workgroups per utterance; table extended to T' = 896 at Hs 256)
-PATH_OVERRIDES = {}      # (round 5, late: the T = 3000 fixtures run the PRE kernels in every phase — see the comment above)
+#   multi-head at T' = 375 (round 6): 16 attention workgroups per (utterance, head) leave room for 4 utterances per launch at heads = 2 — the
+#       teacher-forced forward decodes the batch of 8 in two such slices (las_speller_decode_batch halves the slice until the launch is resident);
+#       the multi-head backward's frame table and the multi-head free-running form stop at 8 workgroups per (utterance, head): per-step chains
+PATH_OVERRIDES = {"P_B8_T3000_U8_mh2": {"bwd": "stepwise", "greedy": "stepwise"}}
 
 
 def load_case(name):

@@ -151,6 +151,43 @@ def test_solver_step_golden_with_fused_optimizer_and_trajectory():
     np.testing.assert_allclose(sums, g["param_sum"], rtol=1e-3, atol=1e-3 * float(np.abs(g["param_abs"]).max()) * 1e-3)
 
 
+@pytest.mark.parametrize("name", ["P_short", "P_B8_T3000_U16"])
+def test_solver_step_with_deferred_weight_gradients(name):
+    """Small batches at paper size (B <= 8: the backward recurrences fit 2 of the 8 XCDs): solver.batch_iterator leaves the weight-gradient GEMM
+    groups of the Speller and of Listener layers 2 / 1 on the library's side stream (LAS_FLAG_DEFER_DW: XCD-confined recurrences, XCD-partitioned
+    groups drawing their runs from a counter) and joins them in front of the clip.  Against the REFERENCE's golden solver step (loss, LER,
+    post-Adam parameter checksums) and against the same step with the groups inline (option DEFER_DW = 0): every gradient."""
+    from golden_util import load_case
+    from las_pytorch_amd import _cabi, dp
+    from las_pytorch_amd.optim import FusedClipAdam
+    from las_pytorch_amd.solver import solver as S
+    gold, info, sd_np, x, _, _, oh = load_case(name)
+    xg, lab = torch.from_numpy(x).cuda(), torch.from_numpy(oh).cuda()
+    grads = {}
+    for defer in (1, 0):
+        _cabi.set_option("DEFER_DW", defer)
+        try:
+            las = build_las(info["cfg"], sd_np, max_label_len=info["free_len"])
+            red = dp.FlatGradAllReducer(las, direct=True)
+            opt = FusedClipAdam(red, lr=2e-4)
+            np.random.seed(0)
+            loss, ler = S.batch_iterator(xg, lab, las, opt, tf_rate=1.0, is_training=True, max_label_len=info["U"], label_smoothing=0.1)
+            torch.cuda.synchronize()
+            assert _cabi.last_path(_cabi.PATH_DW) == ("deferred" if defer else "inline"), _cabi.last_path(_cabi.PATH_DW)
+            assert not red._deferred_keep, "the deferred work was not joined"
+            assert abs(float(loss) - gold["step_loss"][0]) < 2e-5 * max(1.0, abs(gold["step_loss"][0]))
+            np.testing.assert_allclose(np.array(ler), gold["step_ler"], rtol=1e-6)
+            sums = np.array([p.detach().double().sum().item() for p in las.parameters()])
+            np.testing.assert_allclose(sums, gold["step_param_sum"], rtol=1e-4, atol=2e-4)
+            grads[defer] = red.flat.detach().cpu().numpy().copy()      # (the clipped gradient the update consumed)
+        finally:
+            _cabi.set_option("DEFER_DW", 1)
+    scale = float(np.abs(grads[0]).max())
+    np.testing.assert_allclose(grads[1], grads[0], rtol=1e-4, atol=1e-6 * scale)
+    import las_pytorch_amd
+    las_pytorch_amd.check_device_errors()
+
+
 def test_step_is_rerun_on_the_generic_kernels_after_a_handoff_timeout():
     """A device error word set during the step (here: planted before it) makes the fused update skip itself; batch_iterator
     warns, re-runs the step once with force_generic and ends where an undisturbed step ends.  With torch.optim.Adam (the update

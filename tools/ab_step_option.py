@@ -10,9 +10,10 @@ key, va, vb = sys.argv[1], int(sys.argv[2]), int(sys.argv[3])
 steps = int(sys.argv[4]) if len(sys.argv) > 4 else 60
 rounds = int(sys.argv[5]) if len(sys.argv) > 5 else 4
 B = int(os.environ.get("B", 32))
+T = int(os.environ.get("T", 800))
 dev = torch.device("cuda", 0)
 las, c, _ = bench.build_model("P", 128, dev)
-x = torch.from_numpy(synth.make_inputs(B, 800, c["F"], seed=17)).to(dev)
+x = torch.from_numpy(synth.make_inputs(B, T, c["F"], seed=17)).to(dev)
 idx, lens = synth.make_labels(B, 128, c["V"], seed=17)
 lab = torch.from_numpy(synth.onehot_labels(idx, lens, c["V"])).to(dev)
 red = dp.FlatGradAllReducer(las, direct=True)

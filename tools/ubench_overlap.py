@@ -5,7 +5,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
 from las_pytorch_amd import _cabi
 L = _cabi.lib()
-B, T, H = 32, int(os.environ.get("T", 400)), 256
+B, T, H = int(os.environ.get("B", 32)), int(os.environ.get("T", 400)), 256
 g = torch.Generator().manual_seed(0)
 w = [((torch.rand(4 * H, H, generator=g) * 2 - 1) / np.sqrt(H)).cuda() for _ in range(2)]
 pre = torch.randn(2 * B * T * 4 * H, generator=g).cuda() * 0.1
