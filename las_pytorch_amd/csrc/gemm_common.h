@@ -62,7 +62,8 @@ constexpr int GROUP_MAX = 8;
 struct GemmGroupParams {
     GemmParams prob[GROUP_MAX]; long first[GROUP_MAX + 1]; int n; int xcd_swz;
     unsigned* xcd_probe;
-    unsigned* run_counter;      // xcd_lo > 0: zeroed before the launch; the surviving workgroups draw their runs from it
+    unsigned* run_counter;      // drawn-runs form (xcd_lo > 0 or nruns > 0): zeroed before the launch; the workgroups draw their runs from it
+    int nruns;                  // ... number of equal runs the whole problem is cut into (any number of workgroups may take part)
     int xcd_lo;      // > 0: the workgroups that find themselves on XCDs [0, xcd_lo) (actual XCC id) leave at once; the others draw the W' =
                      // gridDim.x / 8 * (8 - xcd_lo) equal runs of the whole problem from run_counter — correct for ANY placement of the blocks
                      // (XCD partition beside a latency-bound chain kernel confined to those XCDs)

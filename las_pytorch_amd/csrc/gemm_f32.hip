@@ -957,12 +957,14 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_group_kernel(GemmGroupPa
     // (mailbox of the run draw: the first word of the operand buffers, free between two runs — no second __shared__ object in front of the
     // dynamic LDS, whose 16-byte alignment the fragment reads rely on)
     volatile unsigned* mbox = MODE == 0 ? reinterpret_cast<volatile unsigned*>(&As[0][0][0]) : reinterpret_cast<volatile unsigned*>(sp);
-    if (PART) {      // XCD partition (host guarantees W % 8 == 0 and the atomic combination): runs are drawn, not assigned
-        unsigned xcc;
-        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID, 0, 4)" : "=s"(xcc));
-        if (g.xcd_probe && threadIdx.x == 0 && blockIdx.x < 1024) g.xcd_probe[1024 + blockIdx.x] = xcc + 1;
-        if ((int)xcc < g.xcd_lo) return;
-        W = (W >> 3) * (8 - g.xcd_lo);
+    if (PART) {      // drawn runs (the atomic combination only): correct for any number and placement of the workgroups that take part
+        if (g.xcd_lo > 0) {      // XCD partition: leave XCDs [0, xcd_lo) to the chain kernel confined there
+            unsigned xcc;
+            asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID, 0, 4)" : "=s"(xcc));
+            if (g.xcd_probe && threadIdx.x == 0 && blockIdx.x < 1024) g.xcd_probe[1024 + blockIdx.x] = xcc + 1;
+            if ((int)xcc < g.xcd_lo) return;
+        }
+        W = g.nruns;
     }
     const long total = g.first[g.n];
     const long per = (total + W - 1) / W;
@@ -1095,7 +1097,7 @@ static int launch_group_part(const GemmGroupParams& g, int mode, dim3 grid, hipS
 }
 static int launch_group(const GemmGroupParams& g, bool a_kc, bool b_kc, bool planes, dim3 grid, hipStream_t stream) {
     const int mode = planes ? 2 : (gemm_get_arith() == 1 ? 1 : 0);
-    if (g.xcd_lo > 0) return launch_group_part(g, mode, grid, stream);
+    if (g.nruns > 0) return launch_group_part(g, mode, grid, stream);
     if (a_kc && b_kc) return launch_group_ab<true, true>(g, mode, grid, stream);
     if (a_kc && !b_kc) return launch_group_ab<true, false>(g, mode, grid, stream);
     if (!a_kc && b_kc) return launch_group_ab<false, true>(g, mode, grid, stream);
@@ -1227,12 +1229,12 @@ static unsigned* group_run_counter(hipStream_t stream) {
     return p;
 }
 
-int gemm_f32_group(const GemmDesc* ds, int n, hipStream_t stream, int xcd_lo) {
+int gemm_f32_group(const GemmDesc* ds, int n, hipStream_t stream, int xcd_lo, int drawn_runs) {
     const int group_on = (int)opt_get(OPT_GEMM_GROUP);
     const int W = gemm_resident_slots();
     if (xcd_lo < 0 || xcd_lo > 6 || W % 8 != 0) xcd_lo = 0;
     unsigned* run_counter = nullptr;
-    if (group_on && xcd_lo == 0) {      // 256-tile form where the group's tiles are big enough
+    if (group_on && xcd_lo == 0 && drawn_runs <= 0) {      // 256-tile form where the group's tiles are big enough
         const int rc = gemm_big_group(ds, n, stream);
         if (rc != LAS_ERR_UNSUPPORTED) return rc;
     }
@@ -1241,7 +1243,7 @@ int gemm_f32_group(const GemmDesc* ds, int n, hipStream_t stream, int xcd_lo) {
     // workgroup runs, so an owner would fetch up to 512 KB of parked tiles serially at the end of its run, where atomics are fire-and-
     // forget and overlap the next segment (measured: L0 dW group 185 against 164 us, the others +3 .. +7 us).  GEMM_SK_FIXUP=2 selects
     // the fix-up form here too (outputs then need not start from zero; results are run-to-run deterministic).
-    const SkScratch* sc = (ok && xcd_lo == 0 && opt_get(OPT_GEMM_SK_FIXUP) >= 2) ? sk_scratch(stream, W) : nullptr;
+    const SkScratch* sc = (ok && xcd_lo == 0 && drawn_runs <= 0 && opt_get(OPT_GEMM_SK_FIXUP) >= 2) ? sk_scratch(stream, W) : nullptr;
     for (int i = 0; ok && i < n; ++i) {
         const GemmDesc& d = ds[i];
         ok = d.batch <= 1 && !d.relu && !d.bias0 && !d.bias1 && (d.c_zeroed || d.accumulate || sc != nullptr) && d.a_kc == ds[0].a_kc && d.b_kc == ds[0].b_kc &&
@@ -1252,13 +1254,15 @@ int gemm_f32_group(const GemmDesc* ds, int n, hipStream_t stream, int xcd_lo) {
         return LAS_OK;
     }
     LAS_TRY(gemm_sk_check());
-    if (xcd_lo > 0 && (ds[0].a_kc || ds[0].b_kc || ds[0].planes || (run_counter = group_run_counter(stream)) == nullptr)) xcd_lo = 0;
+    const bool want_drawn = xcd_lo > 0 || drawn_runs > 0;
+    if (want_drawn && (ds[0].a_kc || ds[0].b_kc || ds[0].planes || (run_counter = group_run_counter(stream)) == nullptr)) { xcd_lo = 0; drawn_runs = 0; }
     GemmGroupParams g;
     g.n = n;
     g.first[0] = 0;
     const int xcd_swz = (int)opt_get(OPT_GEMM_XCD_SWZ);
     g.xcd_swz = xcd_swz;
     g.xcd_lo = xcd_lo; g.xcd_probe = xcd_lo > 0 ? xcd_probe_ptr() : nullptr; g.run_counter = run_counter;
+    g.nruns = run_counter == nullptr ? 0 : (drawn_runs > 0 ? drawn_runs : (W >> 3) * (8 - xcd_lo));
     for (int i = 0; i < n; ++i) {
         const GemmDesc& d = ds[i];
         GemmParams& p = g.prob[i];

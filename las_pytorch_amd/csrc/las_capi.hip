@@ -361,8 +361,13 @@ int las_pblstm_bwd(const float* x, const float* dout, int B, int T_in, int D_in,
     if (confine > 0) {
         if (hipStream_t s = defer_side().begin(stream)) { ws = s; deferred = true; }
     }
-    path_note(PATH_DW, deferred ? "deferred" : "inline");
-    if (!deferred) {
+    if (dx) path_note(PATH_DW, deferred ? "deferred" : "inline");      // (the input layer has no recurrence after it to hide under: not noted)
+    // Neither deferred nor the input layer: dX (the critical path: 200 - 400 tiles, which leave 20 - 60 % of the resident slots idle) and the
+    // weight-gradient group run at the SAME time on two streams and are joined before the call returns — the group draws its runs from a counter,
+    // so its workgroups take whatever CUs dX leaves (option DW_CONCURRENT; nothing runs beside the next layer's recurrence)
+    hipStream_t cs = nullptr;
+    if (!deferred && dx && opt_get(OPT_DW_CONCURRENT) != 0 && !(flags & LAS_FLAG_FORCE_GENERIC)) cs = defer_side().begin_joined(stream);
+    if (!deferred && cs == nullptr) {
         LAS_TRY(gemm_f32_group(dw, 4, stream));
         for (int dir = 0; dir < 2 && !db_done; ++dir)
             LAS_TRY(colsum(dgates + (size_t)dir * BT * 4 * H, 4 * H, BT, 4 * H, dir ? db_ih_r : db_ih_f, zg, stream, dir ? db_hh_r : db_hh_f));
@@ -374,6 +379,13 @@ int las_pblstm_bwd(const float* x, const float* dout, int B, int T_in, int D_in,
         g.A2 = dgates + (size_t)BT * 4 * H; g.B2 = w_ih_r; g.K1 = 4 * H;
         g.C = dx; g.ldc = D; g.M = BT; g.N = D; g.K = 8 * H; g.splitk = 1;
         LAS_TRY(gemm_f32(g, stream));
+    }
+    if (cs != nullptr) {
+        const int rc = gemm_f32_group(dw, 4, cs, 0, (int)opt_get(OPT_DW_CONCURRENT));
+        for (int dir = 0; rc == LAS_OK && dir < 2 && !db_done; ++dir)
+            (void)colsum(dgates + (size_t)dir * BT * 4 * H, 4 * H, BT, 4 * H, dir ? db_ih_r : db_ih_f, zg, cs, dir ? db_hh_r : db_hh_f);
+        LAS_TRY(defer_side().end_joined(stream));      // (joined on every path: the side stream must not outlive the call)
+        LAS_TRY(rc);
     }
     if (deferred) {      // (issued after dX so that the critical-path GEMM is first in the hardware queues; both start once the recurrence is done)
         LAS_TRY(gemm_f32_group(dw, 4, ws, confine));

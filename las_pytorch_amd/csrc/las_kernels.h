@@ -40,7 +40,9 @@ inline size_t planes_floats(size_t rows, size_t ld) { return (rows * ld * 6 + 15
 // k-iterations of all problems spread evenly over the resident workgroups.  Falls back to n launches when not groupable.
 // xcd_lo > 0: the launch leaves XCDs [0, xcd_lo) alone (their workgroups exit at once; the 128-tile group kernel only): for a group that runs on a
 // side stream beside a chain kernel confined to those XCDs (pblstm_rec_bwd's confine_nx).  Falls back to one launch per problem as before.
-int gemm_f32_group(const GemmDesc* ds, int n, hipStream_t stream, int xcd_lo = 0);
+// drawn_runs > 0: the group's k-iterations are cut into that many equal runs which the workgroups DRAW from a counter (instead of one assigned run
+// each): for a group that shares the chip with another GEMM on a second stream — whichever workgroups get CUs first do the work.
+int gemm_f32_group(const GemmDesc* ds, int n, hipStream_t stream, int xcd_lo = 0, int drawn_runs = 0);
 // LAS_ERR_DEVICE once after a stream-K fix-up wait ran into its spin limit (GEMM workgroups not all resident); clears the report
 int gemm_sk_check();
 // true when gemm_f32 on this stream takes the stream-K fix-up schedule for an M x N output (option on, enough output tiles, scratch there or
@@ -172,6 +174,9 @@ struct DeferSide {
     hipStream_t begin(hipStream_t main);
     int end();
     int join(hipStream_t main);
+    // the same side stream for work that is joined inside the call that issued it (fork ... join around two concurrent launches)
+    hipStream_t begin_joined(hipStream_t main) { return begin(main); }
+    int end_joined(hipStream_t main);
 };
 DeferSide& defer_side();
 // placement probe (las_debug_xcd_probe): 2 x 1024 words; the XCD-confined recurrence writes XCC id + 1 of block b at [b], the XCD-partitioned

@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Turn gpurun_out/evidence/ (written by tools/gpu_evidence.sh on the GPU box) into the committed profiles/r05_* files."""
+"""Turn gpurun_out/evidence/ (written by tools/gpu_evidence.sh on the GPU box) into the committed profiles/<round>_* files (LAS_ROUND, default r06)."""
 import collections
 import json
 import os
@@ -9,6 +9,8 @@ import sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 E = os.path.join(ROOT, "gpurun_out", "evidence")
 P = os.path.join(ROOT, "profiles")
+R = os.environ.get("LAS_ROUND", "r06")
+RN = R.lstrip("r0") or "0"
 
 
 def find_db(d):
@@ -22,7 +24,7 @@ def find_db(d):
 def main():
     line = open(os.path.join(E, "bench.json")).read().strip().splitlines()[-1]
     j = json.loads(line)
-    json.dump(j, open(os.path.join(P, "r05_bench_line.json"), "w"), indent=1)
+    json.dump(j, open(os.path.join(P, f"{R}_bench_line.json"), "w"), indent=1)
     if os.environ.get("LAS_COLLECT_LOGS_ONLY") != "1":
         databases()
     logs(j)
@@ -31,8 +33,8 @@ def main():
 def databases():
     """Everything that reads a rocprofv3 database: runs on the GPU box (tools/gpu_evidence.sh), the databases do not travel."""
     stats = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "rocpd_stats.py"), find_db("stats"), "40"], capture_output=True, text=True).stdout
-    with open(os.path.join(P, "r05_kernel_stats.txt"), "w") as f:
-        f.write("# rocprofv3 --kernel-trace --stats over `python3 bench.py --steps 20 --warmup 5` (25 training steps incl. warm-up), round 5;\n"
+    with open(os.path.join(P, f"{R}_kernel_stats.txt"), "w") as f:
+        f.write("# rocprofv3 --kernel-trace --stats over `python3 bench.py --steps 20 --warmup 5` (25 training steps incl. warm-up), round " + RN + ";\n"
                 "# divide total_ms by 25 for the per-step share of a kernel.\n" + stats)
     subprocess.run([sys.executable, os.path.join(ROOT, "tools", "make_pmc_profiles.py"), "rec", find_db("pmc_fetch"), find_db("pmc_write"), "32", "400", "256"], check=True)
     subprocess.run([sys.executable, os.path.join(ROOT, "tools", "make_pmc_profiles.py"), "speller", find_db("pmc_step/fetch"), find_db("pmc_step/write"),
@@ -45,9 +47,9 @@ def databases():
     subprocess.run([sys.executable, os.path.join(ROOT, "tools", "make_pmc_profiles.py"), "speller", find_db("pmc_long_step/fetch"), find_db("pmc_long_step/write"),
                     "8", "375", "128", "512"], check=True, env=env_long)
     stats_long = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "rocpd_stats.py"), find_db("stats_long"), "30"], capture_output=True, text=True).stdout
-    with open(os.path.join(P, "r05_kernel_stats_long.txt"), "w") as f:
+    with open(os.path.join(P, f"{R}_kernel_stats_long.txt"), "w") as f:
         f.write("# rocprofv3 --kernel-trace --stats over `python3 bench.py --workload P_long --batch 8 --steps 10 --warmup 3` (BASELINE configs[4]: B = 8, T = 3000;\n"
-                "# 14 training steps incl. warm-up and the first-loss step), round 5\n" + stats_long)
+                "# 14 training steps incl. warm-up and the first-loss step), round " + RN + "\n" + stats_long)
     subprocess.run([sys.executable, os.path.join(ROOT, "tools", "make_pmc_profiles.py"), "recmfma", find_db("pmc_recm_a"), find_db("pmc_recm_b"),
                     find_db("pmc_recm_f"), find_db("pmc_recm_w"), "512", "400", "256"], check=True)
 
@@ -59,8 +61,8 @@ def logs(j):
     for name in ("rec_mfma_trace", "gemm_skf_b32", "gemm_skf_b128", "spin_timeout", "big_decode", "gemm_big", "gemm_planes", "gemm_planes_ablation", "lds_long", "multihead", "solver_step", "soak_mixed", "ler"):
         src = os.path.join(E, name + ".log")
         if os.path.exists(src):
-            open(os.path.join(P, f"r05_{name}.txt"), "w").write("".join(l for l in open(src) if "amdgpu.ids" not in l and "trace wg0:" not in l))
-    open(os.path.join(P, "r05_gemm_split_vs_fp32.txt"), "w").write(
+            open(os.path.join(P, f"{R}_{name}.txt"), "w").write("".join(l for l in open(src) if "amdgpu.ids" not in l and "trace wg0:" not in l))
+    open(os.path.join(P, f"{R}_gemm_split_vs_fp32.txt"), "w").write(
         "# tools/ubench_gemm_split.py on one MI355X: fp32-MFMA GEMM against the split-operand bf16-MFMA GEMM, same operands; err = max |C - ref| /\n"
         "# (|A||B|) in units of 2^-24 against a float64 reference\n" + open(os.path.join(E, "gemm_split.log")).read())
     rows = [json.loads(l) for l in open(os.path.join(ROOT, "gpurun_out", "parity_observed.jsonl"))]
@@ -75,15 +77,15 @@ def logs(j):
         d["tensors"] += 1
         d["worst_ratio_of_tolerance"] = max(d["worst_ratio_of_tolerance"], r.get("worst_ratio", 0.0))
         d["max_abs_err"] = max(d["max_abs_err"], r["max_abs_err"])
-    json.dump({"source": "tests/hip_util.py::record during `pytest tests -m gpu` on MI355X (round 5)",
+    json.dump({"source": "tests/hip_util.py::record during `pytest tests -m gpu` on MI355X (round " + RN + ")",
                "tolerance": "|a-b| <= 1e-3*|b| + 1e-5*max|b| + 5e-7*max grad norm; ratio 1.0 = at tolerance", "cases": by,
                "kernel_paths_asserted": paths,
                "gemm_arithmetic_vs_float64": {"unit": "max |C - AB| / (|A||B|) in units of 2^-24; name = layout_MxNxK_s<exponent spread>",
                                               "rows": gemm_rows}},
-              open(os.path.join(P, "r05_parity_observed.json"), "w"), indent=1)
-    open(os.path.join(P, "r05_rec_sweep.txt"), "w").write(open(os.path.join(E, "rec_sweep.log")).read())
+              open(os.path.join(P, f"{R}_parity_observed.json"), "w"), indent=1)
+    open(os.path.join(P, f"{R}_rec_sweep.txt"), "w").write(open(os.path.join(E, "rec_sweep.log")).read())
     lines = open(os.path.join(E, "pytest_gpu.log")).readlines()
-    open(os.path.join(P, "r05_pytest_gpu.txt"), "w").write("".join([l for l in lines if " passed" in l or " failed" in l or l.startswith("FAILED")] + lines[-6:]))
+    open(os.path.join(P, f"{R}_pytest_gpu.txt"), "w").write("".join([l for l in lines if " passed" in l or " failed" in l or l.startswith("FAILED")] + lines[-6:]))
     runs = []
     for l in open(os.path.join(E, "variants.jsonl")):
         if l.startswith("{"):
@@ -91,10 +93,10 @@ def logs(j):
             runs.append({"workload": v["config"]["workload"], "per_gpu_batch": v["config"]["per_gpu_batch"], "utt_per_s": v["value"],
                          "ms_per_step": v["ms_per_step"], "steps": v["steps"]})
     soak = json.loads(open(os.path.join(E, "soak.json")).read().strip().splitlines()[-1])
-    json.dump({"source": "python bench.py --workload W --batch B --steps 10 --warmup 3 on one MI355X (round 5)", "runs": runs,
+    json.dump({"source": "python bench.py --workload W --batch B --steps 10 --warmup 3 on one MI355X (round " + RN + ")", "runs": runs,
                "soak": {"steps": soak["steps"], "ms_per_step": soak["ms_per_step"], "utt_per_s": soak["value"],
                         "note": "1500 consecutive training steps, device error word clean at the end (bench.py asserts it)"}},
-              open(os.path.join(P, "r05_bench_variants.json"), "w"), indent=1)
+              open(os.path.join(P, f"{R}_bench_variants.json"), "w"), indent=1)
     print("value", j["value"], "ms", j["ms_per_step"], "roofline", j["roofline"]["frac"], j["roofline"]["traffic"], "mfma", j["roofline_mfma"]["achieved"],
           "speller fwd/bwd us per step", j.get("roofline_speller_fwd", {}).get("us_per_decode_step"), j.get("roofline_speller_bwd", {}).get("us_per_decode_step"))
 

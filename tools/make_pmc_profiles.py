@@ -14,7 +14,7 @@ import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
-ROUND = os.environ.get("LAS_ROUND", "r05")
+ROUND = os.environ.get("LAS_ROUND", "r06")
 SUFFIX = os.environ.get("LAS_PROFILE_SUFFIX", "")      # e.g. "_long": the T = 3000 shapes beside the headline ones
 
 

@@ -1,4 +1,4 @@
-"""profiles/r05_pmc_step_traffic.json from two rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE) over bench.py:
+"""profiles/<round>_pmc_step_traffic.json from two rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE) over bench.py:
    gpurun -- 'cd /tmp && export TMPDIR=/tmp && R=$GRAFT_REPO_ROOT && F="--steps 4 --warmup 2 --no-cpu-baseline --no-sweep --no-mfma --no-roofline --no-secondary" &&
               rocprofv3 --pmc FETCH_SIZE -d $R/gpurun_out/evidence/pmc_step/fetch -o x -- python3 $R/bench.py $F; rocprofv3 --pmc WRITE_SIZE -d $R/gpurun_out/evidence/pmc_step/write -o x -- python3 $R/bench.py $F'
    python tools/pmc_step_traffic.py"""
@@ -27,7 +27,7 @@ out = {"source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes
                  "training step per kernel; FETCH_SIZE raw (the guide's x2 correction applies to wide 16-B/lane streams only)",
        "total_fetch_MB_raw_per_step": round(sum(r[2] for r in rows), 1), "total_write_MB_per_step": round(sum(r[3] for r in rows), 1),
        "kernels": [{"kernel": r[0], "dispatches": r[1], "fetch_MB_raw_per_step": round(r[2], 1), "write_MB_per_step": round(r[3], 1)} for r in rows[:25]]}
-json.dump(out, open(os.path.join(ROOT, "profiles/r05_pmc_step_traffic.json"), "w"), indent=1)
+json.dump(out, open(os.path.join(ROOT, "profiles/" + os.environ.get("LAS_ROUND", "r06") + "_pmc_step_traffic.json"), "w"), indent=1)
 print(out["total_fetch_MB_raw_per_step"], out["total_write_MB_per_step"])
 for r in rows[:10]:
     print(r)
