@@ -59,6 +59,7 @@ PROTOTYPES = {
     "las_debug_big_trace": (None, [_f]),
     "las_debug_big_bwd_trace": (None, [_f]),
     "las_debug_kernel_ms": (C.c_int, [C.c_int, C.POINTER(C.c_float)]),
+    "las_debug_xcd_probe": (None, [C.c_void_p]),
     "las_debug_last_path": (C.c_int, [C.c_int, C.c_char_p, C.c_int]),
     "las_pblstm_reserve_floats": (C.c_size_t, [C.c_int] * 4),
     "las_pblstm_fwd": (C.c_int, [_f, C.c_int, C.c_int, C.c_int, C.c_int] + [_f] * 8 + [_f, _f, _f, C.c_int, _f]),

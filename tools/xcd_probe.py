@@ -19,7 +19,7 @@ step = bench.make_train_step(las, x, lab, red, opt)
 for _ in range(3): step()
 buf = torch.zeros(2048, dtype=torch.int32, device=dev)
 L = _cabi.lib()
-L.las_debug_xcd_probe.argtypes = [ctypes.c_void_p]; L.las_debug_xcd_probe.restype = None
+
 L.las_debug_xcd_probe(buf.data_ptr())
 step(); torch.cuda.synchronize()
 L.las_debug_xcd_probe(None)
