@@ -425,9 +425,9 @@ size_t las_speller_reserve_floats(const las_speller_desc* d, int U) { return Spe
 
 int las_speller_decode_batch(const las_speller_desc* d, int teacher_forced, int decode_mode) {
     if (!d || check_desc(d) != LAS_OK) return 0;
-    if (d->relu > LAS_ACT_RELU) return 0;
-    // the YAML sizes (speller_big.hip): 16 utterances per launch, teacher forcing only
-    if ((teacher_forced || decode_mode == 1) &&
+    // the YAML sizes (speller_big.hip): 16 utterances per launch, teacher forcing only (relu / no activation; the Hs <= 512 kernels take
+    // every activation code)
+    if ((teacher_forced || decode_mode == 1) && d->relu <= LAS_ACT_RELU &&
         speller_big_eligible(16, d->Tp, d->Hs, d->D, d->M, d->V, d->L, d->multi_head, d->use_mlp, !teacher_forced))
         return 16;
     if (opt_get(OPT_SPELLER_PERSIST) == 0 || (!teacher_forced && decode_mode == 2)) return 0;
@@ -490,13 +490,12 @@ int las_speller_fwd(const las_speller_desc* d, const float* feat, const float* k
     // every call: in training the parameters change every step, so there is nothing to cache across calls)
     const bool persist_on = opt_get(OPT_SPELLER_PERSIST) != 0;
     const bool persist = persist_on && err_word && !(flags & LAS_FLAG_FORCE_GENERIC) && (teacher_forced || decode_mode != 2) &&
-                         d->relu <= LAS_ACT_RELU &&        // the persistent kernels implement relu / no activation
                          speller_persist_eligible(B, Tp, Hs, D, d->M, V, L, d->multi_head, d->use_mlp, !teacher_forced);
     // the pre-multiplied context variant of the persistent kernel (teacher forcing): P = feat . W_ctx^T in the cell
     // workgroups' column order; the kernel then publishes sum_t a_t P_t instead of the context, which one batched GEMM
     // recovers afterwards (the backward pass and the character distribution need it)
     // (independent of the classic kernel's eligibility: at Hs = 256 and T' > 448 only the PRE variant, with the keys split by frames, applies)
-    const bool pre = persist_on && err_word && !(flags & LAS_FLAG_FORCE_GENERIC) && d->relu <= LAS_ACT_RELU && teacher_forced && lay.pre &&
+    const bool pre = persist_on && err_word && !(flags & LAS_FLAG_FORCE_GENERIC) && teacher_forced && lay.pre &&
                      speller_persist_pre_eligible(B, Tp, Hs, D, d->M, V, L, d->multi_head, d->use_mlp);
     // What a teacher-forced forward leaves in `reserve` depends on the SHAPE only (lay.pre), never on switches, the error word
     // or the occupancy calculator: P = feat . W_ctx^T and the per-step sums gx_s = sum_t a_t P_t are always there, so that
@@ -508,18 +507,18 @@ int las_speller_fwd(const las_speller_desc* d, const float* feat, const float* k
     // symbols: a stashing forward leaves the same P / gx in the reserve (tf_like) and las_speller_bwd takes its PRE path for it too.
     const bool tf_like = teacher_forced || decode_mode == 1;
     const bool preg = !teacher_forced && decode_mode == 1 && lay.pre && persist_on && err_word &&
-                      !(flags & LAS_FLAG_FORCE_GENERIC) && d->relu <= LAS_ACT_RELU && logp &&
+                      !(flags & LAS_FLAG_FORCE_GENERIC) && logp &&
                       speller_persist_pre_greedy_eligible(B, Tp, Hs, D, d->M, V, L, d->multi_head, d->use_mlp);
     const bool pre_stash = tf_like && lay.pre && ((flags & LAS_FLAG_STASH) || pre || preg);
     // ... and its multi-head form (heads 2..4, teacher forcing): one set of attention workgroups per (utterance, head), dim_reduce folded into P
-    const bool pre_mh = persist_on && err_word && !(flags & LAS_FLAG_FORCE_GENERIC) && teacher_forced && d->relu <= LAS_ACT_RELU && lay.pre_mh &&
+    const bool pre_mh = persist_on && err_word && !(flags & LAS_FLAG_FORCE_GENERIC) && teacher_forced && lay.pre_mh &&
                         speller_persist_pre_mh_eligible(B, Tp, Hs, D, d->M, V, L, d->multi_head, d->use_mlp);
     // (as for the single head: what a teacher-forced stashing forward leaves — P and gx per head — depends on the shape only, so that
     // las_speller_bwd can take its multi-head PRE path whichever forward kernels ran)
     // Free-running decode_mode 1 with several heads runs the per-step kernels forward, but its backward is the teacher-forced one over the emitted
     // symbols (tf_like, as for the single head): a stashing forward leaves P and gx for it too.
     const bool preg_mh = !teacher_forced && decode_mode == 1 && lay.pre_mh && persist_on && err_word && !(flags & LAS_FLAG_FORCE_GENERIC) &&
-                         d->relu <= LAS_ACT_RELU && logp && speller_persist_pre_mh_greedy_eligible(B, Tp, Hs, D, d->M, V, L, d->multi_head, d->use_mlp);
+                         logp && speller_persist_pre_mh_greedy_eligible(B, Tp, Hs, D, d->M, V, L, d->multi_head, d->use_mlp);
     const bool pre_mh_stash = tf_like && lay.pre_mh && ((flags & LAS_FLAG_STASH) || pre_mh || preg_mh);
     bool mh_gx_written = false;
     LAS_TRY(speller_prologue(d->w_ih[0], w0p, Hs, V, Vp, (pre_stash || preg || pre_mh_stash) ? reserve + lay.wperm : nullptr, (pre || preg || pre_mh || preg_mh) ? reserve + lay.wyperm : nullptr,
@@ -957,13 +956,13 @@ int las_speller_bwd(const las_speller_desc* d, const float* feat, const float* k
     float* dctxcat_all = NH > 1 ? workspace + wl.dctxcat_all : nullptr;
     const float* ctxcat_all = NH > 1 ? reserve + lay.ctxcat_all : nullptr;
     const bool persist_on = opt_get(OPT_SPELLER_PERSIST_BWD) != 0;
-    const bool persist = persist_on && hoist && err_word && !(flags & LAS_FLAG_FORCE_GENERIC) && d->relu <= LAS_ACT_RELU &&
+    const bool persist = persist_on && hoist && err_word && !(flags & LAS_FLAG_FORCE_GENERIC) &&
                          speller_persist_bwd_eligible(B, Tp, Hs, D, M, V, L, NH, d->use_mlp);
     bool persist_ran = persist;
     float* dx0_ctx = dx0 + V;              // gradient of the initial context (step 0's context input) and its row stride
     long ld_dx0 = V + D;
     // multi-head (heads 2..4) on the PRE backward: the forward left P and gx per head for this shape (pre_mh_stash)
-    const bool pre_mh = NH > 1 && hoist && err_word && !(flags & LAS_FLAG_FORCE_GENERIC) && d->relu <= LAS_ACT_RELU && lay.pre_mh &&
+    const bool pre_mh = NH > 1 && hoist && err_word && !(flags & LAS_FLAG_FORCE_GENERIC) && lay.pre_mh &&
                         (flags & LAS_FLAG_TEACHER_FORCED) && speller_persist_bwd_pre_mh_eligible(B, Tp, Hs, D, M, V, L, NH, d->use_mlp);
     if (pre_mh) {
         PersistBwd p;

@@ -842,7 +842,7 @@ struct AttnRole {
                 acc = gsum<16>(acc);
                 if (pk == 0) {
                     acc += bphi;
-                    if (a.relu) acc = fmaxf(acc, 0.f);
+                    acc = act_apply(acc, a.relu);      // (a.relu: the activation code of las_speller_desc — none / relu / tanh / sigmoid, wave-uniform)
                     qs[prow] = acc;
                     if (part_id == 0) a.q_all[((size_t)s * B + b) * PS_M + prow] = acc;
                 }
@@ -1213,7 +1213,7 @@ struct AttnPreRole {
                 acc = gsum<16>(acc);
                 if (pk == 0) {
                     acc += bphi;
-                    if (a.relu) acc = fmaxf(acc, 0.f);
+                    acc = act_apply(acc, a.relu);      // (a.relu: the activation code of las_speller_desc — none / relu / tanh / sigmoid, wave-uniform)
                     qs[prow] = acc;
                     if (part_id == 0) *at_bytes(a.q_all + (((size_t)s * B + b) * NH + hd) * PS_M, opaque(4u * (unsigned)prow)) = acc;
                 }

@@ -750,7 +750,7 @@ struct AttnBwdRole {
                 for (int t = tg; t < nt; t += 16) acc = fmaf(de[t], ks[t * PS_KLD + m], acc);
                 acc = gsum<16>(acc);
                 if (tg == 0) {
-                    if (a.relu && !(qs[m] > 0.f)) acc = 0.f;
+                    acc *= act_grad(qs[m], a.relu);      // (qs: the POST-activation query; relu -> 0 / 1, tanh -> 1 - q^2, sigmoid -> q (1 - q))
                     dqpre[m] = acc;
                     a.dqpre_part[(((size_t)half * U + s) * B + b) * PS_M + m] = acc;
                 }
@@ -921,7 +921,7 @@ struct AttnBwdPreRole {
                 for (int t = tg; t < nt; t += 16) acc = fmaf(de[t], ks[t * PS_KLD + m], acc);
                 acc = gsum<16>(acc);
                 if (tg == 0) {
-                    if (a.relu && !(qs[m] > 0.f)) acc = 0.f;
+                    acc *= act_grad(qs[m], a.relu);      // (qs: the POST-activation query; relu -> 0 / 1, tanh -> 1 - q^2, sigmoid -> q (1 - q))
                     dqpre[m] = acc;
                     *at_bytes(a.dqpre_part + (((size_t)part * U + s) * B + b) * PS_M, opaque(4u * (unsigned)m)) = acc;
                 }
@@ -1165,7 +1165,7 @@ struct AttnBwdPre2Role {
                 for (int t = tg; t < nt; t += 16) acc = fmaf(de[t], ks[t * PS_KLD + m], acc);
                 acc = gsum<16>(acc);
                 if (tg == 0) {
-                    if (a.relu && !(qs[m] > 0.f)) acc = 0.f;
+                    acc *= act_grad(qs[m], a.relu);      // (qs: the POST-activation query; relu -> 0 / 1, tanh -> 1 - q^2, sigmoid -> q (1 - q))
                     dqpre[m] = acc;
                 }
             }

@@ -39,12 +39,12 @@ def expected_paths(info):
         per_dir = 256 // (2 * max(1, H * H // 16384))        # utterances one launch steps one-per-group
         rec_f = rec_b = "fast" if B <= per_dir else "multi"
     one_launch = info["multi_head"] == 1 and info["use_mlp"] and info["activate"] in ("relu", "None")
-    if one_launch and Hs in (256, 512):
+    if info["multi_head"] == 1 and info["use_mlp"] and Hs in (256, 512):      # (every activation code since round 6)
         # (greedy: the golden tests decode without a backward pass, which takes the free-running form of the PRE kernel)
         tf, bwd, greedy = "persist_pre", "persist_pre", "persist_pre_greedy"
     elif one_launch and Hs == 1024:
         tf = bwd = greedy = "big"
-    elif (2 <= info["multi_head"] <= 4 and info["use_mlp"] and info["activate"] in ("relu", "None") and Hs in (256, 512)):
+    elif (2 <= info["multi_head"] <= 4 and info["use_mlp"] and Hs in (256, 512)):
         # multi-head (round 5): the PRE kernels both ways, one set of attention workgroups per (utterance, head), 32 // heads utterances per
         # launch; the free-running form exchanges the heads' shares of the character distribution as well (distinct names: the multi-head
         # instantiations are different kernels)

@@ -528,6 +528,16 @@ def test_persistent_decode_kernel_without_attention_activation():
     _persistent_vs_stepwise("S", 9, 40, 6, None, "None")
 
 
+@pytest.mark.parametrize("cfg_name,B,Tp,U,scale,activate,heads", [("P", 32, 100, 8, None, "tanh", 1), ("P", 11, 57, 5, 0.1, "sigmoid", 1),
+                                                                   ("S", 16, 200, 6, None, "tanh", 1), ("P", 16, 100, 6, None, "sigmoid", 2),
+                                                                   ("P", 8, 60, 5, 0.1, "tanh", 4), ("P", 8, 375, 4, None, "tanh", 1)])
+def test_persistent_decode_kernels_with_tanh_and_sigmoid_attention(cfg_name, B, Tp, U, scale, activate, heads):
+    """mlp_activate_in_attention = tanh / sigmoid (the reference resolves any torch.nn.functional name, las_model.py:270-273) on the one-launch
+    decode kernels, single- and multi-head, forward and backward, against the per-step launch chains (which the reference-generated
+    tiny_tanh / tiny_sigmoid goldens pin): the query activation and its derivative are a run-time switch (act_apply / act_grad) there."""
+    _persistent_vs_stepwise(cfg_name, B, Tp, U, scale, activate, heads=heads)
+
+
 @pytest.mark.parametrize("cfg_name,B,Tp,U", [("P", 32, 100, 16), ("P", 7, 57, 5), ("S", 20, 111, 6), ("S", 32, 200, 5), ("P", 16, 200, 4),
                                              ("P", 8, 375, 4), ("S", 16, 300, 4)])
 def test_pre_multiplied_context_backward_matches_classic_persistent_backward(cfg_name, B, Tp, U):
