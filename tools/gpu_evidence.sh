@@ -6,6 +6,7 @@ R=${GRAFT_REPO_ROOT:-/root/repo}
 O=$R/gpurun_out/evidence
 rm -rf $O; mkdir -p $O
 cd $R
+export LAS_ROUND=r06
 rm -f gpurun_out/parity_observed.jsonl
 python -m pytest tests -m gpu -q > $O/pytest_gpu.log 2>&1
 python -c "import __graft_entry__ as g; g.smoke()" > $O/smoke.log 2>&1
@@ -33,6 +34,9 @@ FS4="--workload S_long --batch 8 --steps 4 --warmup 2 --no-cpu-baseline --no-swe
 rocprofv3 --pmc SQ_INSTS_LDS SQ_LDS_IDX_ACTIVE SQ_LDS_BANK_CONFLICT SQ_ACTIVE_INST_LDS SQ_WAVE_CYCLES SQ_WAIT_ANY -d $O/pmc_slong_lds -o x -- python3 $R/bench.py $FS4 > $O/pmc_slong_lds.log 2>&1
 rocprofv3 --kernel-trace --stats -d $O/stats_slong -o x -- python3 $R/bench.py $FS4 > $O/stats_slong.log 2>&1
 python3 $R/tools/lds_long_table.py $O > $O/lds_long.log 2>&1
+# ordered timelines of one step (headline and configs[4]; the latter shows the two queues of the deferred weight-gradient groups)
+python3 $R/tools/step_timeline.py $(find $O/stats -name "*.db" | head -1) > $O/step_timeline.log 2>&1
+python3 $R/tools/step_timeline.py $(find $O/stats_long -name "*.db" | head -1) > $O/step_timeline_long.log 2>&1
 # MFMA-busy / stall / LDS counters of the GEMM in both arithmetic modes (1 = split-operand bf16 MFMA, the default; 0 = fp32 MFMA)
 for a in 1 0; do
   export LAS_GEMM_ARITH=$a
@@ -47,6 +51,7 @@ rocprofv3 --pmc SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_ACTIVE_INST_LDS SQ_ACT
 rocprofv3 --pmc FETCH_SIZE -d $O/pmc_recm_f -o x -- python3 $R/tools/ubench_rec_mfma_pmc.py > $O/pmc_recm_f.log 2>&1
 rocprofv3 --pmc WRITE_SIZE -d $O/pmc_recm_w -o x -- python3 $R/tools/ubench_rec_mfma_pmc.py > $O/pmc_recm_w.log 2>&1
 cd $R
+export LAS_ROUND=r06
 TRACE=1 BS=128,512,768 python tools/ubench_rec_mfma.py > $O/rec_mfma_trace.log 2>&1
 python tools/ubench_gemm_skf.py 32 > $O/gemm_skf_b32.log 2>&1
 python tools/ubench_gemm_skf.py 128 > $O/gemm_skf_b128.log 2>&1
@@ -63,13 +68,26 @@ B=16 python tools/ubench_multihead.py 2>&1 | grep -v amdgpu.ids >> $O/multihead.
 python tools/solver_step_profile.py 300 2>&1 | grep -v amdgpu.ids > $O/solver_step.log
 python tools/soak_mixed.py 1500 2>&1 | grep -v amdgpu.ids > $O/soak_mixed.log
 (python tools/ubench_ler.py; B=7 U=600 python tools/ubench_ler.py; B=3 U=4095 python tools/ubench_ler.py) 2>&1 | grep "las_letter_error_rate" > $O/ler.log
+# round 6: in-process A/B of this round's switches (tools/ab_step_option.py alternates the two values on one box) and the block -> XCD probe
+(echo "# REC_EPOCH_SCRATCH (hand-off granules in the library's epoch-tagged scratch vs a fill per launch), headline step";
+ python tools/ab_step_option.py REC_EPOCH_SCRATCH 1 0 60 4;
+ echo "# KEYS_SPLITK (psi keys GEMM split over K + activation pass vs one pass), headline step";
+ python tools/ab_step_option.py KEYS_SPLITK 1 0 60 4;
+ echo "# DW_CONCURRENT (weight-gradient group beside dX on a second stream, joined in the call; runs drawn), headline step";
+ python tools/ab_step_option.py DW_CONCURRENT 1024 0 60 4) 2>&1 | grep -v amdgpu.ids > $O/ab_switches.log
+(echo "# DEFER_DW at BASELINE configs[4] (B = 8, T = 3000): weight-gradient groups on the side stream, XCD partition";
+ B=8 T=3000 python tools/ab_step_option.py DEFER_DW 1 0 20 4;
+ echo "# block -> XCD placement of the two partitioned launches (tools/xcd_probe.py)";
+ B=8 T=3000 python tools/xcd_probe.py;
+ echo "# recurrence + GEMM group on two streams, B = 8, T_l = 1500 (tools/ubench_overlap.py; unpartitioned launches)";
+ B=8 T=1500 python tools/ubench_overlap.py) 2>&1 | grep -v amdgpu.ids > $O/defer_dw.log
 # soak: 1500 consecutive training steps (~1e7 inter-workgroup hand-offs) must end without a device error word
 python bench.py --steps 1500 --warmup 5 --no-cpu-baseline --no-sweep --no-mfma --no-roofline --no-secondary > $O/soak.json 2> $O/soak.err
 for w in "P_long 8" "S_long 8" "S_train 32" "Y_train 16" "P_fwd 32" "S_fwd 32" "P_train 128"; do set -- $w; python bench.py --workload $1 --batch $2 --steps 10 --warmup 3 --no-cpu-baseline --no-sweep --no-mfma --no-secondary --no-roofline 2>/dev/null | tail -1; done > $O/variants.jsonl
 tail -3 $O/pytest_gpu.log; tail -1 $O/smoke.log; tail -c 300 $O/bench.json
 # summaries are made HERE (the rocprofv3 databases are too large to travel: gpurun merges at most 64 MiB back) and copied next to the logs
-LAS_ROUND=r05 python tools/collect_evidence.py > $O/collect.log 2>&1
-mkdir -p $R/gpurun_out/r05_profiles && cp $R/profiles/r05_* $R/gpurun_out/r05_profiles/ 2>/dev/null
+LAS_ROUND=r06 python tools/collect_evidence.py > $O/collect.log 2>&1
+mkdir -p $R/gpurun_out/r06_profiles && cp $R/profiles/r06_* $R/gpurun_out/r06_profiles/ 2>/dev/null
 find $O -name "*.db" -delete
 find $O -name "*.csv" -size +1M -delete
 du -sh $R/gpurun_out
