@@ -44,6 +44,7 @@ enum Opt : int {
     OPT_KEYS_SPLITK,            // psi keys GEMM (64 output columns: few tiles) split over K with a separate activation pass (1) or one pass with the activation in its epilogue (0)
     OPT_DEFER_DW,               // honour LAS_FLAG_DEFER_DW (weight-gradient groups on a side stream beside XCD-confined backward recurrences); 0: inline (A/B)
     OPT_DW_CONCURRENT,          // a Listener layer's weight-gradient group beside its dX GEMM on a second stream, joined inside the call: number of runs the group is cut into (0 = off, the default: measured 5.904 - 5.948 ms per step at 512 - 2048 runs against 5.918 on one stream)
+    OPT_REC_EPOCH_SEED,         // test hook of the epoch-tagged hand-off scratch: the next launch's epoch base is at least this (exercises the wrap-around re-zero)
     OPT_COUNT
 };
 

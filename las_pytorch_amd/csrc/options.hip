@@ -21,7 +21,7 @@ const OptDef kDefs[OPT_COUNT] = {
     {"GEMM_SK_FIXUP", 0}, {"GEMM_SKF_MIN_KT", -1}, {"GEMM_SKF_MIN_RUN", -1},
     {"SIDE_FILLS", 0}, {"TRUST_ZEROED_GRADS", 1}, {"SPELLER_BIG", 1}, {"SPELLER_BIG_BWD", 1}, {"SPELLER_BIG_TUNE", 0},
     {"TIME_KERNELS", 0}, {"GEMM_BIG", 1}, {"SPELLER_PRE_GREEDY", 1}, {"SPELLER_PRE_MH", 1},
-    {"REC_EPOCH_SCRATCH", 1}, {"KEYS_SPLITK", 1}, {"DEFER_DW", 1}, {"DW_CONCURRENT", 0},
+    {"REC_EPOCH_SCRATCH", 1}, {"KEYS_SPLITK", 1}, {"DEFER_DW", 1}, {"DW_CONCURRENT", 0}, {"REC_EPOCH_SEED", 0},
 };
 std::atomic<long> g_val[OPT_COUNT];
 std::atomic<int> g_init{0};

@@ -973,6 +973,8 @@ static u64* rec_scratch(size_t bytes, unsigned epochs, hipStream_t stream, unsig
         if (r->buf) (void)hipFree(r->buf);
         r->buf = nb; r->bytes = want; r->next = 1u;
     }
+    const unsigned seed = (unsigned)opt_get(OPT_REC_EPOCH_SEED);      // test hook: while set, every launch starts at least there (towards the wrap-around)
+    if (seed > r->next) r->next = seed;
     if (r->next > 0xFFFF0000u - epochs - 2u) {
         if (hipMemsetAsync(r->buf, 0, r->bytes, stream) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
         r->next = 1u;

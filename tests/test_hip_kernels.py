@@ -442,6 +442,50 @@ def test_recurrence_fwd_vs_oracle(H, B, T, generic):
     assert np.array_equal(hp[1][:, :-1], o[:, 1:, H:]) and (hp[1][:, -1] == 0).all()
 
 
+def test_epoch_tagged_handoff_scratch_across_shapes_and_wrap_around():
+    """The register-resident recurrences exchange {epoch, value} granules through the library's persistent scratch (no fill per launch): every
+    launch draws a fresh epoch range, so what an earlier launch of ANY layout left behind can never match.  Back-to-back launches of different
+    (B, T) on the same stream — so that granule and placement-id regions of one layout overlay the other's — must reproduce the fill-per-launch
+    results (option REC_EPOCH_SCRATCH = 0) bit for bit; then the epoch base is pushed to the wrap-around (test hook REC_EPOCH_SEED), which
+    re-zeroes the scratch and restarts the range, and the launches must still agree."""
+    from las_pytorch_amd import _cabi
+    L = _cabi.lib()
+    H = 256
+    g = torch.Generator().manual_seed(3)
+    w = [((torch.rand(4 * H, H, generator=g) * 2 - 1) / np.sqrt(H) * 2).cuda() for _ in range(2)]
+    err = _cabi.err_word("cuda")
+
+    def run(B, T):
+        gg = torch.Generator().manual_seed(B * 1000 + T)
+        gates = torch.randn(2, B, T, 4 * H, generator=gg).cuda()
+        out = torch.full((B, T, 2 * H), float("nan"), device="cuda")
+        cbuf = torch.empty(2, B, T, H, device="cuda"); hprev = torch.empty(2, B, T, H, device="cuda")
+        xbuf = torch.empty(L.las_rec_xbuf_bytes(B, H) // 4 + 4, device="cuda")
+        _cabi.check(L.las_pblstm_rec_fwd(_cabi.ptr(gates), _cabi.ptr(w[0]), _cabi.ptr(w[1]), _cabi.ptr(out), _cabi.ptr(cbuf), _cabi.ptr(hprev),
+                                         B, T, H, _cabi.ptr(xbuf), _cabi.ptr(err), _cabi.FLAG_STASH, _cabi.stream_ptr()))
+        return out
+
+    shapes = [(32, 24), (5, 40), (17, 9), (32, 24), (8, 31), (40, 6)]      # (40: the multi-utterance kernel, two utterances per group)
+    try:
+        _cabi.set_option("REC_EPOCH_SCRATCH", 0)
+        want = [run(B, T).cpu().numpy() for B, T in shapes]
+        _cabi.set_option("REC_EPOCH_SCRATCH", 1)
+        got = [run(B, T) for B, T in shapes]                       # no synchronisation in between: the launches queue back to back
+        torch.cuda.synchronize()
+        _cabi.check_device_errors()
+        for (B, T), a, b in zip(shapes, got, want):
+            assert np.array_equal(a.cpu().numpy(), b), f"epoch scratch changed the result at B={B}, T={T}"
+        _cabi.set_option("REC_EPOCH_SEED", 0xFFFEFFF0)                 # the next launch would cross 0xFFFF0000: re-zero, restart at 1
+        got = [run(B, T) for B, T in shapes]
+        torch.cuda.synchronize()
+        _cabi.check_device_errors()
+        for (B, T), a, b in zip(shapes, got, want):
+            assert np.array_equal(a.cpu().numpy(), b), f"wrap-around changed the result at B={B}, T={T}"
+    finally:
+        _cabi.set_option("REC_EPOCH_SEED", 0)
+        _cabi.set_option("REC_EPOCH_SCRATCH", 1)
+
+
 def test_recurrence_agent_scope_handoff_path():
     """The placement-independent agent-scope hand-off (used when a group spans XCDs) must give the same result as the
     same-XCD L2 path: run the H=256 recurrence test in a child process with LAS_REC_AGENT_HANDOFF=1."""
