@@ -68,7 +68,8 @@ extern "C" {
                                        BASELINE configs[4]; measured slower at 4).  Ignored otherwise (and during stream capture). */
 
 int las_abi_version(void);
-/* Make `stream` wait for the deferred work of this thread's earlier LAS_FLAG_DEFER_DW calls on the current device (no-op if none). */
+/* Make `stream` wait for the deferred work of earlier LAS_FLAG_DEFER_DW calls on the current device — issued by ANY host thread (PyTorch runs
+ * backward on its autograd worker thread, the caller joins from its own) — no-op if none. */
 int las_join_deferred(void* stream);
 const char* las_last_error(void);
 
@@ -389,7 +390,7 @@ void las_debug_xcd_probe(unsigned* dev_buf);
  * "rec_bwd_mfma" | "rec_bwd_generic"), 2 decode loop forward ("persist_pre" | "persist_pre_greedy" (free-running form) | "persist_pre_mh" |
  * "persist_pre_mh_greedy" (multi-head instantiations) | "persist" | "big" | "stepwise"), 3 decode loop backward ("persist_pre" | "persist_pre_mh" |
  * "persist" | "big" | "stepwise"), 5 the weight-gradient group of the most recent backward entry point ("deferred": left on the side stream under
- * LAS_FLAG_DEFER_DW | "inline"), 4 the most recent GEMM's operand path ("split" | "split256" (256 x 256 tiles, gemm_big.hip) | "f32" | "planes").  The parity tests assert it per fixture, so a silent
+ * LAS_FLAG_DEFER_DW | "inline"; las_join_deferred overwrites it with "joined" when it found pending work), 4 the most recent GEMM's operand path ("split" | "split256" (256 x 256 tiles, gemm_big.hip) | "f32" | "planes").  The parity tests assert it per fixture, so a silent
  * fall-back (e.g. LAS_ERR_UNSUPPORTED from a residency check) cannot leave a golden green on the wrong kernel.  Returns 0 / LAS_ERR_ARG. */
 int las_debug_last_path(int which, char* out, int cap);
 

@@ -166,7 +166,8 @@ struct SideStream {
     int join(hipStream_t main);
 };
 SideStream& side_stream();
-// Deferred weight-gradient work (LAS_FLAG_DEFER_DW): a second library-owned stream per (host thread, device) whose launches are NOT joined
+// Deferred weight-gradient work (LAS_FLAG_DEFER_DW): a second library-owned stream per DEVICE (shared by the host threads: the autograd worker
+// thread defers, the caller's thread joins) whose launches are NOT joined
 // before the entry point returns; las_join_deferred makes a stream wait for everything issued there.  begin() records the fork on `main`
 // and returns the side stream (nullptr: unavailable — stream capture, creation failure — do the work on `main`); end() marks the work pending.
 struct DeferSide {

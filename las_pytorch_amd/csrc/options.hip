@@ -130,13 +130,18 @@ int SideStream::join(hipStream_t main) {
 
 static std::atomic<unsigned*> g_xcd_probe{nullptr};
 unsigned* xcd_probe_ptr() { return g_xcd_probe.load(std::memory_order_relaxed); }
+// One instance per DEVICE, not per host thread: PyTorch runs the backward Functions on its autograd worker thread while the caller joins from
+// the thread that drives the step — work deferred by one thread must be visible to the other.  (One host thread per device at a time, as
+// for every entry point; the mutex orders the hand-over between the autograd thread and the caller's.)
+static std::mutex g_defer_mu;
 DeferSide& defer_side() {
-    thread_local DeferSide tl[16];
+    static DeferSide inst[16];
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) dev = 0;
-    return tl[dev];
+    return inst[dev];
 }
 hipStream_t DeferSide::begin(hipStream_t main) {
+    std::lock_guard<std::mutex> lk(g_defer_mu);
     hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
     if (hipStreamIsCapturing(main, &cap) != hipSuccess || cap != hipStreamCaptureStatusNone) return nullptr;      // a capture keeps everything on one stream
     if (s == nullptr) {
@@ -153,20 +158,24 @@ hipStream_t DeferSide::begin(hipStream_t main) {
     return s;
 }
 int DeferSide::end() {
+    std::lock_guard<std::mutex> lk(g_defer_mu);
     LAS_HIP_CHECK(hipEventRecord(e_done, s));
     pending = true;
     return LAS_OK;
 }
 int DeferSide::end_joined(hipStream_t main) {
+    std::lock_guard<std::mutex> lk(g_defer_mu);
     hipEvent_t e = pending ? e_fork : e_done;      // (e_done may be what an earlier deferred launch is still known by: keep it)
     LAS_HIP_CHECK(hipEventRecord(e, s));
     LAS_HIP_CHECK(hipStreamWaitEvent(main, e, 0));
     return LAS_OK;
 }
 int DeferSide::join(hipStream_t main) {
+    std::lock_guard<std::mutex> lk(g_defer_mu);
     if (!pending) return LAS_OK;
     pending = false;
     LAS_HIP_CHECK(hipStreamWaitEvent(main, e_done, 0));
+    path_note(PATH_DW, "joined");      // (what a test asserts: the deferred work of the step was really waited for)
     return LAS_OK;
 }
 

@@ -173,7 +173,8 @@ def test_solver_step_with_deferred_weight_gradients(name):
             np.random.seed(0)
             loss, ler = S.batch_iterator(xg, lab, las, opt, tf_rate=1.0, is_training=True, max_label_len=info["U"], label_smoothing=0.1)
             torch.cuda.synchronize()
-            assert _cabi.last_path(_cabi.PATH_DW) == ("deferred" if defer else "inline"), _cabi.last_path(_cabi.PATH_DW)
+            # "joined": las_join_deferred found pending work of this step — issued by the autograd worker thread, joined from this one
+            assert _cabi.last_path(_cabi.PATH_DW) == ("joined" if defer else "inline"), _cabi.last_path(_cabi.PATH_DW)
             assert not red._deferred_keep, "the deferred work was not joined"
             assert abs(float(loss) - gold["step_loss"][0]) < 2e-5 * max(1.0, abs(gold["step_loss"][0]))
             np.testing.assert_allclose(np.array(ler), gold["step_ler"], rtol=1e-6)
