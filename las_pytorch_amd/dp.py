@@ -52,7 +52,7 @@ class FlatGradAllReducer:
         module._las_flat_reducer = self      # solver.batch_iterator picks it up (zero / all-reduce / clip on the flat buffer)
         # Deferred weight gradients (LAS_FLAG_DEFER_DW, direct writes only): inside ``with reducer.deferring():`` the backward entry points may
         # leave their weight-gradient GEMM groups running on the library's side stream — hidden under the next layer's recurrence where the
-        # batch leaves XCDs free (B <= 16 at paper size) — and ``join_deferred()`` (called by every consumer of the flat buffer here, and at
+        # batch leaves XCDs free (B <= 8 at paper size) — and ``join_deferred()`` (called by every consumer of the flat buffer here, and at
         # the end of the block) makes the current stream wait for them.  The tensors those GEMMs read are kept alive until then.
         self._defer_active = False
         self._deferred_keep = []

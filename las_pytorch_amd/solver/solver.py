@@ -324,7 +324,7 @@ def batch_iterator(batch_data, batch_label, las_model, optimizer, tf_rate, is_tr
             from ..model.las_model import set_force_generic
             warnings.warn(f"liblas_hip: persistent-kernel hand-off timeout ({failed or 'reported by a peer rank'}); re-running this "
                           "step once on the generic kernels (another kernel was resident on the GPU?)")
-            if is_training and reducer is not None and reducer.direct:
+            if is_training and reducer is not None and reducer.direct and _cabi.last_path(_cabi.PATH_DW) in ("deferred", "joined"):
                 # (the XCD-confined recurrences number their workgroups by the XCC id they find themselves on: should a dispatcher ever place
                 # blocks differently, a role is missing and the spin timeout lands here — leave that mode for the rest of the process)
                 _cabi.set_option("DEFER_DW", 0)
