@@ -558,7 +558,7 @@ def make_train_step(las, x, lab, reducer, opt, graph=False, tf_rate=1.0):
         reducer.zero()
         preds, _ = las(batch_data=x, batch_label=lab, teacher_force_rate=tf_rate, is_training=True)
         # fused loss + gradient kernel, no copies; the gradient seeds the backward directly (what solver.batch_iterator does)
-        with reducer.deferring():      # as in solver.batch_iterator: weight-gradient groups beside the next layer's recurrence where the batch leaves XCDs free
+        with reducer.deferring():      # as in solver.batch_iterator; a no-op unless the reducer was built with defer_dw / LAS_DEFER_DW=1 (measured not to pay)
             if seeded:
                 return label_smoothing_loss_backward_device(stack_steps(preds), lab, 0.1)
             loss = label_smoothing_loss_device(stack_steps(preds), lab, 0.1)

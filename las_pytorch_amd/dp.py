@@ -19,7 +19,7 @@ class FlatGradAllReducer:
     """Makes every ``p.grad`` a view into one contiguous fp32 buffer so the whole gradient crosses the fabric as a
     single collective (message: S 7.96 MB, P 39.9 MB)."""
 
-    def __init__(self, module: torch.nn.Module, force: bool = False, direct: bool = False, comm=None):
+    def __init__(self, module: torch.nn.Module, force: bool = False, direct: bool = False, comm=None, defer_dw: bool = False):
         self.force = force          # all-reduce even in a 1-rank group (exercises the collective path)
         self.comm = comm            # optional CabiComm: the collective goes through liblas_hip's las_allreduce_f32
         self.direct = direct
@@ -54,6 +54,11 @@ class FlatGradAllReducer:
         # leave their weight-gradient GEMM groups running on the library's side stream — hidden under the next layer's recurrence where the
         # batch leaves XCDs free (B <= 8 at paper size) — and ``join_deferred()`` (called by every consumer of the flat buffer here, and at
         # the end of the block) makes the current stream wait for them.  The tensors those GEMMs read are kept alive until then.
+        # OFF by default (``defer_dw`` / env LAS_DEFER_DW=1): measured at BASELINE configs[4] (B = 8, T = 3000) the step gains 0.0 - 0.09 ms of
+        # the 0.41 ms the hidden GEMMs take alone — a GEMM group beside a resident recurrence runs ~9x slower than alone even on disjoint
+        # XCDs and slows the critical-path launches around it (profiles/r06_defer_dw.txt).
+        import os
+        self.defer_dw = bool(defer_dw) or os.environ.get("LAS_DEFER_DW") == "1"
         self._defer_active = False
         self._deferred_keep = []
 
@@ -64,7 +69,7 @@ class FlatGradAllReducer:
 
         class _Ctx:
             def __enter__(self_inner):
-                red._defer_active = bool(red.direct and red.flat.is_cuda)
+                red._defer_active = bool(red.defer_dw and red.direct and red.flat.is_cuda)
                 return red
 
             def __exit__(self_inner, *exc):

@@ -327,14 +327,20 @@ def make_free_training_golden(refmods, which="tsp"):
     if "p" in which: cases.append(("P_B32_T800_U16_free_train", "P", 32, 800, 16, 0.2, 43))      # weights / inputs of P_B32_T800_U32_s
     # round 6: the multi-head free-running training step at paper size (heads = 2: one slice of 16 utterances per launch)
     if "m" in which: cases.append(("P_B16_T800_U12_mh2_free_train", "P", 16, 800, 12, 0.1, 23, 2))
+    # round 6: decode_mode 0 TRAINING steps (las_model.py:219-221: the raw log-probabilities are fed back, so — unlike mode 1 — the gradient
+    # also flows through the fed-back input, :198-203 via the concatenation): what las_speller_bwd's feedback_mode0 path must reproduce
+    if "0" in which:
+        cases += [("tiny_mode0_train", "tiny", 3, 32, 6, 0.3, 17, 1, 0), ("S_mode0_train", "S", 4, 64, 8, 0.2, 43, 1, 0),
+                  ("P_mode0_train", "P", 8, 128, 6, 0.15, 43, 1, 0)]
     for name, cfg_name, B, T, U, scale, seed, *rest in cases:
         heads = rest[0] if rest else 1
+        dmode = rest[1] if len(rest) > 1 else 1
         c = synth.CONFIGS[cfg_name]
         sd_np = synth.make_state_dict(synth.config_shapes(cfg_name, multi_head=heads), seed=seed, scale=scale)
         x = torch.from_numpy(synth.make_inputs(B, T, c["F"], seed=seed))
         idx, lens = synth.make_labels(B, U, c["V"], seed=seed, ragged=(cfg_name != "P"))
         labels = torch.from_numpy(synth.onehot_labels(idx, lens, c["V"]))
-        las = build_ref(LAS, Listener, Speller, c, sd_np, max_label_len=U, decode_mode=1, multi_head=heads)
+        las = build_ref(LAS, Listener, Speller, c, sd_np, max_label_len=U, decode_mode=dmode, multi_head=heads)
         las.zero_grad()
         preds, _ = las(batch_data=x, batch_label=labels, teacher_force_rate=0.0, is_training=True)
         assert len(preds) == U
@@ -345,6 +351,7 @@ def make_free_training_golden(refmods, which="tsp"):
         top2 = np.sort(logp, axis=-1)[..., -2:]
         gn = {k: p.grad.detach().numpy() for k, p in las.named_parameters()}
         out = dict(meta=np.array([B, T, U, seed], dtype=np.int64), scale=np.array([scale]), cfg=np.array(cfg_name), heads=np.array([heads]),
+                   decode_mode=np.array([dmode]),
                    ragged=np.array([int(cfg_name != "P")]), free_logp=logp, free_argmax=logp.argmax(-1),
                    free_margin=np.array([float((top2[..., 1] - top2[..., 0]).min())]), loss_ls=np.array([loss.item()]),
                    gradnorm_ls=np.array([np.linalg.norm(g.astype(np.float64)) for g in gn.values()]),

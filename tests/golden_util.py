@@ -143,6 +143,13 @@ def tf_argmax_mask(tf_logp, min_gap=5e-5):
 FREE_TRAIN_CASES = ["tiny_free_train", "S_free_train", "P_B32_T800_U16_free_train",
                     # round 6: the multi-head (heads = 2) free-running training step at paper size
                     "P_B16_T800_U12_mh2_free_train"]
+# decode_mode 0 training steps (the fed-back log-probabilities carry gradient): same file format, loaded by load_free_train_case
+MODE0_TRAIN_CASES = ["tiny_mode0_train", "S_mode0_train", "P_mode0_train"]
+
+
+def free_train_decode_mode(g):
+    """decode_mode of a free-running training fixture (1 unless the file says otherwise: the mode-0 fixtures of round 6)."""
+    return int(g["decode_mode"][0]) if "decode_mode" in g else 1
 
 
 def load_free_train_case(name):

@@ -168,7 +168,7 @@ def test_solver_step_with_deferred_weight_gradients(name):
         _cabi.set_option("DEFER_DW", defer)
         try:
             las = build_las(info["cfg"], sd_np, max_label_len=info["free_len"])
-            red = dp.FlatGradAllReducer(las, direct=True)
+            red = dp.FlatGradAllReducer(las, direct=True, defer_dw=True)      # (off by default: measured not to pay)
             opt = FusedClipAdam(red, lr=2e-4)
             np.random.seed(0)
             loss, ler = S.batch_iterator(xg, lab, las, opt, tf_rate=1.0, is_training=True, max_label_len=info["U"], label_smoothing=0.1)

@@ -5,7 +5,8 @@ import numpy as np
 import pytest
 import torch
 
-from golden_util import ALL_CASES, BIG_CASES, FREE_TRAIN_CASES, load_case, load_free_train_case, oracle_cfg, tf_argmax_mask
+from golden_util import (ALL_CASES, BIG_CASES, FREE_TRAIN_CASES, MODE0_TRAIN_CASES, free_train_decode_mode, load_case, load_free_train_case, oracle_cfg,
+                         tf_argmax_mask)
 from hip_util import assert_close, build_las, grad_close, record
 from las_pytorch_amd import _cabi
 
@@ -228,27 +229,31 @@ def test_free_running_training_step_vs_oracle():
     _check_err()
 
 
-@pytest.mark.parametrize("name", FREE_TRAIN_CASES)
+@pytest.mark.parametrize("name", FREE_TRAIN_CASES + MODE0_TRAIN_CASES)
 def test_free_running_training_step_golden(name):
     """A free-running training step against the UNMODIFIED reference's (fixtures of make_golden.py::make_free_training_golden): log-probs,
     arg-max sequences, the label-smoothing loss, all per-parameter gradient norms and 64-element slices.  The paper-size fixture (B = 32,
     T = 800, weights of the "_s" cases: 19 distinct symbols, margin 1.3e-3) must run the free-running PRE forward and the PRE backward."""
     g, c, cfg_name, (B, T, U), sd_np, x, onehot, heads = load_free_train_case(name)
-    las = build_las(c, sd_np, max_label_len=U, multi_head=heads)
+    dmode = free_train_decode_mode(g)      # 1, or 0 for the round-6 fixtures whose fed-back log-probabilities carry gradient (las_model.py:219-221)
+    las = build_las(c, sd_np, max_label_len=U, multi_head=heads, decode_mode=dmode)
     xg, labg = torch.from_numpy(x).cuda(), torch.from_numpy(onehot).cuda()
     preds, _ = las(batch_data=xg, batch_label=labg, teacher_force_rate=0.0, is_training=True)
     assert len(preds) == U
     mh = "_mh" if heads > 1 else ""
-    if cfg_name == "P":
+    if cfg_name == "P" and dmode == 1:
         assert _cabi.last_path(_cabi.PATH_DECODE_FWD) == f"persist_pre{mh}_greedy", _cabi.last_path(_cabi.PATH_DECODE_FWD)
+    if cfg_name in ("S", "P") and dmode == 0:      # mode 0: the classic (feat-resident) one-launch kernel forward, its backward with the feedback term
+        assert _cabi.last_path(_cabi.PATH_DECODE_FWD) == "persist", _cabi.last_path(_cabi.PATH_DECODE_FWD)
     logp = torch.stack(preds).detach().cpu().numpy()
     assert (logp.argmax(-1) == g["free_argmax"]).all(), "free-running arg-max sequence differs from the reference's"
     assert_close(logp, g["free_logp"], f"{name}/free_logp")
     loss = _loss_ls(preds, labg, U)
     loss.backward()
     torch.cuda.synchronize()
-    if cfg_name == "P":
+    if cfg_name == "P" and dmode == 1:
         assert _cabi.last_path(_cabi.PATH_DECODE_BWD) == f"persist_pre{mh}", _cabi.last_path(_cabi.PATH_DECODE_BWD)
+    record(f"{name}/path/bwd", path=_cabi.last_path(_cabi.PATH_DECODE_BWD), expected="")
     assert abs(loss.item() - g["loss_ls"][0]) <= 1e-4 * abs(g["loss_ls"][0]) + 1e-6
     assert [k for k, _ in las.named_parameters()] == [str(k) for k in g["grad_keys"]]
     norms = np.array([p.grad.double().norm().item() for _, p in las.named_parameters()])

@@ -16,7 +16,7 @@ las, c, _ = bench.build_model("P", 128, dev)
 x = torch.from_numpy(synth.make_inputs(B, T, c["F"], seed=17)).to(dev)
 idx, lens = synth.make_labels(B, 128, c["V"], seed=17)
 lab = torch.from_numpy(synth.onehot_labels(idx, lens, c["V"])).to(dev)
-red = dp.FlatGradAllReducer(las, direct=True)
+red = dp.FlatGradAllReducer(las, direct=True, defer_dw=(key.upper().replace("LAS_", "") == "DEFER_DW"))
 opt = FusedClipAdam(red, lr=2e-4)
 step = bench.make_train_step(las, x, lab, red, opt)
 for _ in range(10): step()

@@ -59,7 +59,7 @@ def databases():
 
 def logs(j):
     for name in ("rec_mfma_trace", "gemm_skf_b32", "gemm_skf_b128", "spin_timeout", "big_decode", "gemm_big", "gemm_planes", "gemm_planes_ablation", "lds_long", "multihead", "solver_step", "soak_mixed", "ler",
-                 "step_timeline", "step_timeline_long", "ab_switches", "defer_dw"):
+                 "step_timeline", "step_timeline_long", "step_timeline_long_deferred", "ab_switches", "defer_dw"):
         src = os.path.join(E, name + ".log")
         if os.path.exists(src):
             open(os.path.join(P, f"{R}_{name}.txt"), "w").write("".join(l for l in open(src) if "amdgpu.ids" not in l and "trace wg0:" not in l))

@@ -37,6 +37,11 @@ python3 $R/tools/lds_long_table.py $O > $O/lds_long.log 2>&1
 # ordered timelines of one step (headline and configs[4]; the latter shows the two queues of the deferred weight-gradient groups)
 python3 $R/tools/step_timeline.py $(find $O/stats -name "*.db" | head -1) > $O/step_timeline.log 2>&1
 python3 $R/tools/step_timeline.py $(find $O/stats_long -name "*.db" | head -1) > $O/step_timeline_long.log 2>&1
+# ... and the same step with the deferred weight-gradient groups switched ON (LAS_DEFER_DW=1; off by default): the two-queue trace
+export LAS_DEFER_DW=1
+rocprofv3 --kernel-trace -d $O/kt_long_defer -o x -- python3 $R/bench.py --workload P_long --batch 8 --steps 6 --warmup 3 --no-cpu-baseline --no-sweep --no-mfma --no-roofline --no-secondary > $O/kt_long_defer.log 2>&1
+unset LAS_DEFER_DW
+python3 $R/tools/step_timeline.py $(find $O/kt_long_defer -name "*.db" | head -1) > $O/step_timeline_long_deferred.log 2>&1
 # MFMA-busy / stall / LDS counters of the GEMM in both arithmetic modes (1 = split-operand bf16 MFMA, the default; 0 = fp32 MFMA)
 for a in 1 0; do
   export LAS_GEMM_ARITH=$a

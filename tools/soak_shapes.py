@@ -20,7 +20,7 @@ for i, (B, T) in enumerate(shapes):
     x = torch.from_numpy(synth.make_inputs(B, T, c["F"], seed=17 + i)).to(dev)
     idx, lens = synth.make_labels(B, U, c["V"], seed=17 + i, ragged=True)
     data.append((x, torch.from_numpy(synth.onehot_labels(idx, lens, c["V"])).to(dev)))
-red = dp.FlatGradAllReducer(las, direct=True)
+red = dp.FlatGradAllReducer(las, direct=True, defer_dw=True)
 opt = FusedClipAdam(red, lr=2e-4)
 np.random.seed(0)
 dw, losses = {}, []
