@@ -244,7 +244,7 @@ def multi_head_block(device, T, U, heads=2, B=16, iters=5):
 def roofline_rec_fwd(c, B, T, iters=20, with_traffic=True):
     """Times the dominant kernel (layer-0 forward recurrence, rec_fwd_fast<H>) alone with HIP events on the stream it
     is launched on, on real pre-activations, and prices it against the HBM roofline with the ALGORITHMIC bytes of the
-    pBLSTM layer it belongs to (DESIGN.md section 4): B*4*T_l*(D_l+2H) + weights."""
+    pBLSTM layer it belongs to (DESIGN.md section 3.2): B*4*T_l*(D_l+2H) + weights."""
     from las_pytorch_amd import _cabi, synth
     L = _cabi.lib()
     H, F = c["H"], c["F"]

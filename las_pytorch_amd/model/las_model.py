@@ -607,7 +607,7 @@ class Speller(nn.Module):
         if nb <= 0 or B <= nb:
             return _SpellerFn.apply(cfg + (True, grad_on), listener_feature, labels, noise, *params)
         # Batches beyond what one launch of the decode kernels takes: slices of nb utterances, each decoded in ONE launch (the per-step
-        # kernels would need U launch chains for the whole batch: P at B=128 26 ms -> see DESIGN.md 4.3).  The utterances of a batch
+        # kernels would need U launch chains for the whole batch: P at B=128 26 ms -> see DESIGN.md 3.3).  The utterances of a batch
         # are independent in the Speller (reference las_model.py:205-236), so this is the same arithmetic per utterance; parameter
         # gradients of the slices are summed by autograd (no direct writes: every parameter is used once per slice).
         feats = listener_feature.split(nb, 0)

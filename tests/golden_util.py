@@ -55,7 +55,7 @@ def expected_paths(info):
 
 
 # fixtures whose path differs from the rule above: BASELINE configs[4] (T = 3000), where an utterance's attention operands no longer fit one
-# workgroup's registers + LDS ("LDS residency vs spill"):
+# workgroup's registers + LDS (DESIGN_HISTORY.md section 4.3, "LDS residency vs spill"):
 #   P (T' = 375, Hs 512): teacher forcing keeps P[b] = feat[b] W_ctx^T in 16 workgroups per utterance (persist_pre, both ways); the
 #       free-running form of that kernel needs Q^T (57 KB) beside the keys (102 KB): the keys are split by frames over the 16 workgroups
 #   S (T' = 750, Hs 256): keys 192 KB > 160 KB of LDS: the teacher-forced forward splits them by frames over the 16 workgroups of an utterance,

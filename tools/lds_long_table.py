@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """LDS residency vs spill at T = 3000 (BASELINE configs[4]): per kernel of the P_long and S_long training steps, the LDS counters
 (rocprofv3 --pmc SQ_INSTS_LDS SQ_LDS_IDX_ACTIVE SQ_LDS_BANK_CONFLICT SQ_ACTIVE_INST_LDS SQ_WAVE_CYCLES SQ_WAIT_ANY) next to the kernel's
-time per launch — the table DESIGN.md section 4.3 quotes.   python tools/lds_long_table.py <evidence dir>"""
+time per launch — the table DESIGN_HISTORY.md section 4.3 quotes.   python tools/lds_long_table.py <evidence dir>"""
 import os
 import sqlite3
 import sys

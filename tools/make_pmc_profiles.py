@@ -166,7 +166,7 @@ def recmfma(db_a, db_b, db_f, db_w, B, T_l, H):
             })
     out["reading"] = ("MfmaUtil = SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE per XCD x 1024 SIMDs); mfma_floor_us = the kernel's recurrent product (2 B T_l "
                       "sequence-steps x 4H x H MACs x 6 partial products) at 512 MACs per cycle and SIMD at the profiled clock.  Both kernels are far from "
-                      "that floor: the step of a batch is a chain (publish -> tile in at ~41 GB/s per CU -> product -> cell), see DESIGN.md 4.2.")
+                      "that floor: the step of a batch is a chain (publish -> tile in at ~41 GB/s per CU -> product -> cell), see DESIGN_HISTORY.md 4.2 (DESIGN.md 3.2).")
     path = os.path.join(ROOT, "profiles", f"{ROUND}_pmc_rec_mfma.json")
     json.dump(out, open(path, "w"), indent=1)
     print(path)
